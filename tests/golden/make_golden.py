@@ -1,0 +1,137 @@
+"""
+Generates the golden fixtures under tests/golden/ by running the UNMODIFIED reference.
+
+Run in the build container only (needs /root/reference, which does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+What it does
+  1. converts the only preprocessed fixtures the reference ships,
+     data/pre-training/gdb13_1K-debug/{train,valid,test}.h5 (int8 `nodes`,`edges`,`APDs`), to
+     compressed .npz (h5py is not installed; libhdf5 is read through ctypes);
+  2. imports the reference model classes (`gnn.mpnn.GGNN`, gnn/mpnn.py:229-303) from
+     /root/reference/graphinvent, loads deterministic weights (oracle.init_params — numpy PCG64,
+     machine independent), runs forward + KL loss (restated from Workflow.py:850-858, the
+     Workflow module itself needs rdkit) + backward on fixed inputs, and stores inputs, logits,
+     loss and parameter gradients:
+       golden_tiny.npz     small dims, full weights + every gradient tensor, edge cases included
+       golden_gdb13.npz    reference default dims (5.9 M params): logits, loss and per-parameter
+                           gradient digests (sum, |sum|, leading + strided samples) — weights are
+                           regenerated from the seed, not stored
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/graphinvent"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from oracle import ggnn_oracle as O                      # noqa: E402
+from graphinvent_amd import synthetic                    # noqa: E402
+from tests.golden.spec import TINY, digest, tiny_inputs   # noqa: E402
+import gnn.mpnn as ref_mpnn                              # noqa: E402  (the reference)
+
+assert ref_mpnn.__file__.startswith(REF), ref_mpnn.__file__
+
+
+# ---------------------------------------------------------------------------------------------
+def read_h5_int8(path: str) -> dict:
+    lib = ctypes.CDLL("/opt/conda/lib/libhdf5.so")
+    lib.H5open()
+    lib.H5Fopen.restype = ctypes.c_int64
+    lib.H5Dopen2.restype = ctypes.c_int64
+    lib.H5Dget_space.restype = ctypes.c_int64
+    lib.H5Fopen.argtypes = [ctypes.c_char_p, ctypes.c_uint, ctypes.c_int64]
+    lib.H5Dopen2.argtypes = [ctypes.c_int64, ctypes.c_char_p, ctypes.c_int64]
+    lib.H5Dget_space.argtypes = [ctypes.c_int64]
+    lib.H5Sget_simple_extent_ndims.argtypes = [ctypes.c_int64]
+    lib.H5Sget_simple_extent_dims.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    lib.H5Dread.argtypes = [ctypes.c_int64] * 5 + [ctypes.c_void_p]
+    int8_t = ctypes.c_int64.in_dll(lib, "H5T_NATIVE_INT8_g").value
+    f = lib.H5Fopen(path.encode(), 0, 0)
+    assert f >= 0, path
+    out = {}
+    for name in ("nodes", "edges", "APDs"):
+        d = lib.H5Dopen2(f, name.encode(), 0)
+        assert d >= 0, name
+        s = lib.H5Dget_space(d)
+        nd = lib.H5Sget_simple_extent_ndims(s)
+        dims = (ctypes.c_uint64 * nd)()
+        lib.H5Sget_simple_extent_dims(s, dims, None)
+        arr = np.empty(tuple(int(x) for x in dims), dtype=np.int8)
+        rc = lib.H5Dread(d, int8_t, 0, 0, 0, arr.ctypes.data)
+        assert rc >= 0
+        out[name] = arr
+    return out
+
+
+def convert_fixtures():
+    src = "/root/reference/data/pre-training/gdb13_1K-debug"
+    for split in ("train", "valid", "test"):
+        d = read_h5_int8(f"{src}/{split}.h5")
+        np.savez_compressed(f"{HERE}/gdb13_1K-debug_{split}.npz", **d)
+        print(split, {k: v.shape for k, v in d.items()})
+
+
+# ---------------------------------------------------------------------------------------------
+def reference_run(cfg, P, nodes, edges, target):
+    """Unmodified reference forward/backward with the given weights."""
+    model = ref_mpnn.GGNN(O.as_constants(cfg))
+    missing = model.load_state_dict(P, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert list(model.state_dict().keys()) == list(P.keys())          # registration order too
+    model.train()
+    out = model(nodes, edges)
+    model.zero_grad()
+    # Workflow.py:850-858, restated (Workflow imports rdkit/h5py/tensorboard)
+    logp = torch.nn.LogSoftmax(dim=1)(out)
+    tgt = target / torch.sum(target, dim=1, keepdim=True)
+    loss = torch.nn.KLDivLoss(reduction="batchmean")(target=tgt, input=logp)
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    return out.detach(), loss.detach(), grads
+
+
+def make_tiny():
+    cfg = O.make_config(**TINY)
+    P = O.init_params(cfg, seed=11)
+    n8, e8, a8 = tiny_inputs()
+    nodes, edges, target = (torch.from_numpy(x).float() for x in (n8, e8, a8))
+    out, loss, grads = reference_run(cfg, P, nodes, edges, target)
+    blob = dict(nodes=n8, edges=e8, apds=a8, logits=out.numpy(), loss=loss.numpy())
+    blob.update({"cfg." + k: np.asarray(v) for k, v in TINY.items()})
+    blob.update({"param." + k: v.numpy() for k, v in P.items()})
+    blob.update({"grad." + k: v.numpy() for k, v in grads.items()})
+    np.savez_compressed(f"{HERE}/golden_tiny.npz", **blob)
+    print("tiny: loss", float(loss), "logits", tuple(out.shape))
+
+
+def make_gdb13():
+    cfg = O.make_config()
+    P = O.init_params(cfg, seed=1)
+    fx = np.load(f"{HERE}/gdb13_1K-debug_valid.npz")
+    sn, se, sa = synthetic.make_batch(16, **synthetic.SHAPES["gdb13"], seed=3)
+    n8 = np.concatenate([fx["nodes"][:32], sn]); e8 = np.concatenate([fx["edges"][:32], se])
+    a8 = np.concatenate([fx["APDs"][:32], sa])
+    nodes, edges, target = (torch.from_numpy(x).float() for x in (n8, e8, a8))
+    out, loss, grads = reference_run(cfg, P, nodes, edges, target)
+    blob = dict(nodes=n8, edges=e8, apds=a8, logits=out.numpy(), loss=loss.numpy(),
+                seed=np.asarray(1))
+    blob.update({"gdigest." + k: digest(v) for k, v in grads.items()})
+    np.savez_compressed(f"{HERE}/golden_gdb13.npz", **blob)
+    print("gdb13: loss", float(loss), "logits", tuple(out.shape),
+          "n_params", sum(v.numel() for v in P.values()))
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    convert_fixtures()
+    make_tiny()
+    make_gdb13()

@@ -1,0 +1,42 @@
+"""Shared between make_golden.py (build container, imports the reference) and the tests (any
+box): the tiny-config hyper-parameters, its hand-made edge-case inputs and the gradient digest."""
+import numpy as np
+import torch
+
+from graphinvent_amd import synthetic
+
+
+def digest(g: torch.Tensor) -> np.ndarray:
+    """sum, abs-sum, 16 leading and 16 strided samples of a gradient tensor (float64)."""
+    f = g.double().flatten()
+    stride = max(1, f.numel() // 16)
+    samp = f[::stride][:16]
+    lead = f[:16]
+    pad = lambda t: torch.cat([t, torch.zeros(16 - t.numel(), dtype=torch.float64)])
+    return torch.cat([f.sum().view(1), f.abs().sum().view(1), pad(lead), pad(samp)]).numpy()
+
+
+TINY = dict(n_node_features=5, n_edge_features=3, max_n_nodes=6, len_f_add_per_node=18,
+            len_f_conn_per_node=3, hidden_node_features=16, message_size=12, message_passes=2,
+            enn_depth=2, enn_hidden_dim=24, gather_width=10, gather_att_depth=2,
+            gather_att_hidden_dim=20, gather_emb_depth=2, gather_emb_hidden_dim=28,
+            mlp1_depth=2, mlp1_hidden_dim=32, mlp2_depth=2, mlp2_hidden_dim=36)
+
+
+def tiny_inputs():
+    """12 graphs, N=6: synthetic + hand-made edge cases (empty graph, single atom, a self-loop as
+    GraphGenerator.py:418-423 pins in slot 0, a fully connected graph)."""
+    n, e, a = synthetic.make_batch(12, 6, 3, 2, 3, seed=7, frac_empty=0.0, frac_single=0.0)
+    n[0] = 0; e[0] = 0; n[0, 0, 0] = 1; n[0, 0, 3] = 1; e[0, 0, 0, 0] = 1      # dummy self-loop graph
+    n[1] = 0; e[1] = 0                                                          # empty graph
+    n[2] = 0; e[2] = 0; n[2, 0, 1] = 1; n[2, 0, 4] = 1                          # single atom, no edge
+    e[3] = 0
+    n[3] = 0
+    for i in range(6):
+        n[3, i, i % 3] = 1; n[3, i, 3 + i % 2] = 1
+        for j in range(6):
+            if i != j:
+                e[3, i, j, (i + j) % 3] = 1                                      # complete graph
+    return n, e, a
+
+

@@ -1,0 +1,93 @@
+"""Pins the oracle (oracle/ggnn_oracle.py) against outputs of the unmodified reference that
+tests/golden/make_golden.py recorded in the build container.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ggnn_oracle as O
+from tests.golden.spec import TINY, digest
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+
+def test_state_dict_contract():
+    """Keys, order and shapes of the checkpoint wire format."""
+    shapes = O.param_shapes(O.make_config())
+    keys = list(shapes)
+    assert keys[0] == "msg_nns.0.seq.0.weight" and shapes[keys[0]] == (250, 100)
+    assert shapes["msg_nns.2.seq.12.weight"] == (100, 250)
+    assert shapes["gru.weight_ih"] == (300, 100) and shapes["gru.bias_hh"] == (300,)
+    assert shapes["gather.att_nn.seq.0.weight"] == (250, 108)
+    assert shapes["APDReadout.fAddNet2.seq.0.weight"] == (500, 685)
+    assert shapes["APDReadout.fAddNet2.seq.12.weight"] == (585, 500)
+    assert shapes["APDReadout.fTermNet2.seq.12.weight"] == (1, 500)
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 5914773
+    assert O.apd_width(O.make_config()) == 625
+
+
+def test_tiny_forward_backward_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "golden_tiny.npz"))
+    cfg = O.make_config(**TINY)
+    P = O.init_params(cfg, seed=11)
+    for k, v in P.items():                         # weights are machine independent
+        assert np.array_equal(v.numpy(), g["param." + k]), k
+    nodes, edges, tgt = (torch.from_numpy(g[k]).float() for k in ("nodes", "edges", "apds"))
+    out, loss, grads = O.forward_backward(P, cfg, nodes, edges, tgt)
+    assert rel(out.numpy(), g["logits"]) < 2e-6
+    assert abs(float(loss) - float(g["loss"])) < 1e-6 * abs(float(g["loss"]))
+    for k, v in grads.items():
+        assert rel(v.numpy(), g["grad." + k]) < 2e-5, k
+
+
+def test_tiny_fp64_agrees_with_reference_fp32(golden_dir):
+    """fp64 run of the oracle = tie-breaker; fully-masked graphs (rows 1,2: empty / single atom)
+    carry the fl32(e - 1e6) quantisation and are checked with a looser bound."""
+    g = np.load(os.path.join(golden_dir, "golden_tiny.npz"))
+    cfg = O.make_config(**TINY)
+    P = O.init_params(cfg, seed=11, dtype=torch.float64)
+    nodes, edges = (torch.from_numpy(g[k]).double() for k in ("nodes", "edges"))
+    out = O.ggnn_forward(P, cfg, nodes, edges).numpy()
+    masked = np.array([1, 2])
+    rest = np.setdiff1d(np.arange(out.shape[0]), masked)
+    assert rel(out[rest], g["logits"][rest]) < 1e-5
+    assert rel(out[masked], g["logits"][masked]) < 2e-2
+
+
+def test_gdb13_default_dims_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "golden_gdb13.npz"))
+    cfg = O.make_config()
+    P = O.init_params(cfg, seed=int(g["seed"]))
+    nodes, edges, tgt = (torch.from_numpy(g[k]).float() for k in ("nodes", "edges", "apds"))
+    out, loss, grads = O.forward_backward(P, cfg, nodes, edges, tgt)
+    assert rel(out.numpy(), g["logits"]) < 5e-6
+    assert abs(float(loss) - float(g["loss"])) < 1e-6 * abs(float(g["loss"]))
+    for k, v in grads.items():
+        d, ref = digest(v), g["gdigest." + k]
+        scale = max(np.max(np.abs(ref[2:])), 1e-12)
+        assert np.max(np.abs(d[2:] - ref[2:])) / scale < 1e-4, k
+        assert abs(d[1] - ref[1]) <= 1e-4 * ref[1] + 1e-12, k
+
+
+def test_fixture_quirks(golden_dir):
+    """train rows 129-149 are all-zero padding -> NaN reference loss; valid/test
+    have none; empty and single-atom graphs are present."""
+    tr = np.load(os.path.join(golden_dir, "gdb13_1K-debug_train.npz"))
+    assert tr["nodes"].shape == (150, 13, 8) and tr["edges"].shape == (150, 13, 13, 3)
+    assert tr["APDs"].shape == (150, 625)
+    assert not tr["APDs"][129:].any() and tr["APDs"][:129].sum(1).min() > 0
+    n_nodes = tr["nodes"][:129].any(2).sum(1)
+    assert (n_nodes == 0).sum() == 3
+    no_edges = ~tr["edges"][:129].reshape(129, -1).any(1)
+    assert ((n_nodes == 1) & no_edges).sum() == 4
+    for split in ("valid", "test"):
+        d = np.load(os.path.join(golden_dir, f"gdb13_1K-debug_{split}.npz"))
+        assert d["APDs"].sum(1).min() > 0
+    cfg = O.make_config()
+    P = O.init_params(cfg, seed=1)
+    nodes, edges, tgt = (torch.from_numpy(tr[k][120:150]).float() for k in ("nodes", "edges", "APDs"))
+    assert torch.isnan(O.kl_loss(O.ggnn_forward(P, cfg, nodes, edges), tgt))
