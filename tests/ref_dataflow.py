@@ -1,0 +1,295 @@
+"""
+Test infrastructure: a CPU (numpy / torch-CPU) model of the *new* MI355X dataflow, op for op as the
+C-ABI kernels in graphinvent_amd/csrc implement it — compact CSR graph layout with a shared "zero
+row", per-bond-type routed message MLPs, segmented sums, explicit hand-derived backward.
+
+Two uses:
+  * tests/test_dataflow_cpu.py proves (CPU, fp64) that this dataflow and its hand-written backward
+    are mathematically identical to the reference algorithm (the oracle + autograd);
+  * the -m gpu kernel tests use the individual functions here as per-kernel references.
+
+Not imported by the product.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+SELU_ALPHA = 1.6732632423543772848170429916717
+SELU_SCALE = 1.0507009873554804934193349852946
+
+
+# ---------------------------------------------------------------------------------------------
+# graph_compact  (integer work: bit-exact reference for gi_compact_*)
+# ---------------------------------------------------------------------------------------------
+def compact(nodes: np.ndarray, edges: np.ndarray) -> Dict[str, np.ndarray]:
+    """nodes [B,N,Fn], edges [B,N,N,Fe] (any numeric dtype, one-hot bond types).
+
+    Compact rows 0..S-1 are the *active* slots in ascending slot order (a slot is active when its
+    feature row is non-zero, or it has an incoming edge, or it is some edge's neighbour); row S is
+    the shared zero row standing for every inactive slot (hidden state identically 0 forever).
+    Edges are enumerated in the reference's order (row-major nonzero of the adjacency,
+    gnn/summation_mpnn.py:103-105 — i.e. sorted by destination slot) and stored bucketed by bond
+    type ("type-major"), which is the row order of every per-edge activation buffer."""
+    B, N, Fn = nodes.shape
+    Fe = edges.shape[3]
+    adj = edges.sum(3) != 0
+    ones = (edges == 1).sum(3)
+    zeros = (edges == 0).sum(3)
+    err = int(np.any(adj & ~((ones == 1) & (zeros == Fe - 1))))
+    etype = np.where(adj, edges.argmax(3), -1).astype(np.int8)          # [B,N,N]
+    rowcnt = adj.sum(2).reshape(-1)                                      # incoming per dst slot
+    colcnt = adj.sum(1).reshape(-1)                                      # outgoing per src slot
+    active = (nodes != 0).any(2).reshape(-1) | (rowcnt > 0) | (colcnt > 0)
+    S = int(active.sum())
+    cidx = np.full(B * N, S, dtype=np.int32)
+    cidx[active] = np.arange(S, dtype=np.int32)
+    slot_of = np.nonzero(active)[0].astype(np.int32)
+    eb, ei, ej = np.nonzero(adj)                                         # dst-major order
+    E = eb.size
+    et = etype[eb, ei, ej].astype(np.int64)
+    dst_c = cidx[eb * N + ei]
+    src_c = cidx[eb * N + ej]
+    type_cnt = np.bincount(et, minlength=Fe).astype(np.int32)
+    type_off = np.concatenate([[0], np.cumsum(type_cnt)]).astype(np.int32)
+    # position of every dst-major edge in the type-major arrays
+    pos = np.empty(E, dtype=np.int32)
+    for t in range(Fe):
+        sel = np.nonzero(et == t)[0]
+        pos[sel] = type_off[t] + np.arange(sel.size, dtype=np.int32)
+    e_src = np.empty(E, dtype=np.int32)
+    e_dst = np.empty(E, dtype=np.int32)
+    e_src[pos] = src_c
+    e_dst[pos] = dst_c
+    in_perm = pos.copy()                                                 # dst-major k -> row
+    seg_off = np.zeros(S + 2, dtype=np.int32)
+    np.add.at(seg_off, dst_c + 1, 1)
+    seg_off = np.cumsum(seg_off).astype(np.int32)                        # [S+2], row S empty
+    # out-CSR: edges grouped by source node, inside a group ordered by dst-major order
+    order = np.argsort(src_c, kind="stable")
+    out_perm = pos[order].astype(np.int32)
+    src_off = np.zeros(S + 2, dtype=np.int32)
+    np.add.at(src_off, src_c + 1, 1)
+    src_off = np.cumsum(src_off).astype(np.int32)
+    node_mask = (rowcnt > 0).astype(np.uint8)
+    return dict(S=S, E=E, err=err, cidx=cidx, slot_of=slot_of, e_src=e_src, e_dst=e_dst,
+                in_perm=in_perm, seg_off=seg_off, out_perm=out_perm, src_off=src_off,
+                type_off=type_off, node_mask=node_mask)
+
+
+# ---------------------------------------------------------------------------------------------
+# elementary ops (each mirrors one C-ABI kernel)
+# ---------------------------------------------------------------------------------------------
+def selu(x):
+    return SELU_SCALE * torch.where(x > 0, x, SELU_ALPHA * torch.expm1(x))
+
+
+def selu_grad_from_out(y):
+    """d selu(x)/dx expressed through y = selu(x): scale for y>0 else y + scale*alpha."""
+    return torch.where(y > 0, torch.full_like(y, SELU_SCALE), y + SELU_SCALE * SELU_ALPHA)
+
+
+def linear(x, w, b, act=True, idx=None):
+    if idx is not None:
+        x = x[idx]
+    y = x @ w.t() + b
+    return selu(y) if act else y
+
+
+def seg_sum(vals, perm, off, rows):
+    """out[c] = sum_{k in [off[c], off[c+1])} vals[perm[k]]  for c < rows."""
+    out = torch.zeros(rows, vals.shape[1], dtype=vals.dtype)
+    if perm.numel():
+        seg = torch.repeat_interleave(torch.arange(rows), (off[1:rows + 1] - off[:rows]).long())
+        out.index_add_(0, seg, vals[perm.long()])
+    return out
+
+
+def gru_gates(gi, gh, h_prev, has_edge):
+    H = h_prev.shape[1]
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+    z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+    hn = gh[:, 2 * H:]
+    n = torch.tanh(gi[:, 2 * H:] + r * hn)
+    h_new = torch.where(has_edge[:, None], (1 - z) * n + z * h_prev, h_prev)
+    return h_new, (r, z, n, hn)
+
+
+def gru_gates_bwd(dh_new, saved, h_prev, has_edge):
+    r, z, n, hn = saved
+    m = has_edge[:, None].to(dh_new.dtype)
+    dn = dh_new * (1 - z)
+    dz = dh_new * (h_prev - n)
+    dpre_n = dn * (1 - n * n)
+    dpre_r = dpre_n * hn * r * (1 - r)
+    dpre_z = dz * z * (1 - z)
+    dgi = torch.cat([dpre_r, dpre_z, dpre_n], 1) * m
+    dgh = torch.cat([dpre_r, dpre_z, dpre_n * r], 1) * m
+    dh_direct = torch.where(has_edge[:, None], dh_new * z, dh_new)
+    return dgi, dgh, dh_direct
+
+
+def gather_readout(en, emb, cidx, mask, B, N, big):
+    """en/emb [S+1,G] compact rows; returns g [B,G] and attention [B,N,G]."""
+    c = cidx.view(B, N).long()
+    e = en[c] - ((mask.view(B, N) == 0).to(en.dtype) * big)[:, :, None]
+    att = torch.softmax(e, dim=1)
+    return (att * emb[c]).sum(1), att
+
+
+def gather_readout_bwd(dg, att, emb, cidx, B, N, rows):
+    """d energies / d embeddings on compact rows (zero row accumulates every inactive slot)."""
+    c = cidx.view(B, N).long()
+    demb_s = att * dg[:, None, :]
+    datt = emb[c] * dg[:, None, :]
+    de_s = att * (datt - (att * datt).sum(1, keepdim=True))
+    G = emb.shape[1]
+    demb = torch.zeros(rows, G, dtype=emb.dtype).index_add_(0, c.reshape(-1), demb_s.reshape(-1, G))
+    den = torch.zeros(rows, G, dtype=emb.dtype).index_add_(0, c.reshape(-1), de_s.reshape(-1, G))
+    return den, demb
+
+
+# ---------------------------------------------------------------------------------------------
+# whole model, forward + hand-written backward
+# ---------------------------------------------------------------------------------------------
+def _mlp_keys(P, prefix):
+    out, layer = [], 0
+    while f"{prefix}.seq.{3 * layer}.weight" in P:
+        out.append((f"{prefix}.seq.{3 * layer}.weight", f"{prefix}.seq.{3 * layer}.bias"))
+        layer += 1
+    return out
+
+
+def mlp_fwd(P, prefix, x, idx=None):
+    """Returns the list of post-activation outputs of every layer (saved for backward)."""
+    acts = []
+    for li, (wk, bk) in enumerate(_mlp_keys(P, prefix)):
+        x = linear(x, P[wk], P[bk], True, idx if li == 0 else None)
+        acts.append(x)
+    return acts
+
+
+def mlp_bwd(P, prefix, x_in, acts, d_last_z, grads, idx=None, need_dx=True):
+    """d_last_z = gradient w.r.t. the *pre-activation* of the last layer.  Accumulates dW, db
+    into `grads`; returns dX of the first layer's (gathered) input or None."""
+    keys = _mlp_keys(P, prefix)
+    dz = d_last_z
+    for li in range(len(keys) - 1, -1, -1):
+        wk, bk = keys[li]
+        x = acts[li - 1] if li > 0 else (x_in[idx] if idx is not None else x_in)
+        grads[wk] = grads.get(wk, 0) + dz.t() @ x
+        grads[bk] = grads.get(bk, 0) + dz.sum(0)
+        if li > 0:
+            dz = (dz @ P[wk]) * selu_grad_from_out(acts[li - 1])
+        elif need_dx:
+            return dz @ P[wk]
+    return None
+
+
+def forward(P, cfg, nodes, edges, keep=False):
+    dtype = nodes.dtype
+    B, N, Fn = nodes.shape
+    H, M, G = cfg["hidden_node_features"], cfg["message_size"], cfg["gather_width"]
+    Fe, A, C = cfg["n_edge_features"], cfg["len_f_add_per_node"], cfg["len_f_conn_per_node"]
+    g = compact(nodes.numpy(), edges.numpy())
+    assert g["err"] == 0
+    S, E = g["S"], g["E"]
+    T = {k: torch.from_numpy(v) for k, v in g.items() if isinstance(v, np.ndarray)}
+    R = S + 1
+    x = torch.zeros(R, Fn, dtype=dtype)
+    x[:S] = nodes.reshape(B * N, Fn)[T["slot_of"].long()]
+    h = torch.zeros(R, H, dtype=dtype)
+    h[:, :Fn] = x
+    has_edge = (T["seg_off"][1:R + 1] - T["seg_off"][:R]) > 0
+    tape = dict(g=g, T=T, x=x, has_edge=has_edge, passes=[])
+    for _ in range(cfg["message_passes"]):
+        acts_t = []
+        m = torch.zeros(E, M, dtype=dtype)
+        for t in range(Fe):
+            lo, hi = int(g["type_off"][t]), int(g["type_off"][t + 1])
+            a = mlp_fwd(P, f"msg_nns.{t}", h, idx=T["e_src"][lo:hi].long())
+            acts_t.append(a)
+            m[lo:hi] = a[-1]
+        agg = seg_sum(m, T["in_perm"], T["seg_off"], R)
+        gi = linear(agg, P["gru.weight_ih"], P["gru.bias_ih"], False)
+        gh = linear(h, P["gru.weight_hh"], P["gru.bias_hh"], False)
+        h_new, saved = gru_gates(gi, gh, h, has_edge)
+        tape["passes"].append(dict(h_prev=h, acts_t=acts_t, m=m, agg=agg, saved=saved))
+        h = h_new
+    hx = torch.cat([h, x], 1)
+    att_acts = mlp_fwd(P, "gather.att_nn", hx)
+    emb_acts = mlp_fwd(P, "gather.emb_nn", h)
+    mask = T["node_mask"]
+    gemb, att = gather_readout(att_acts[-1], emb_acts[-1], T["cidx"], mask, B, N, cfg["big_positive"])
+    add1 = mlp_fwd(P, "APDReadout.fAddNet1", h)
+    conn1 = mlp_fwd(P, "APDReadout.fConnNet1", h)
+    c = T["cidx"].view(B, N).long()
+    cat_add = torch.cat([add1[-1][c].reshape(B, N * A), gemb], 1)
+    cat_conn = torch.cat([conn1[-1][c].reshape(B, N * C), gemb], 1)
+    add2 = mlp_fwd(P, "APDReadout.fAddNet2", cat_add)
+    conn2 = mlp_fwd(P, "APDReadout.fConnNet2", cat_conn)
+    term2 = mlp_fwd(P, "APDReadout.fTermNet2", gemb)
+    out = torch.cat([add2[-1], conn2[-1], term2[-1]], 1)
+    tape.update(h=h, hx=hx, att_acts=att_acts, emb_acts=emb_acts, att=att, gemb=gemb, add1=add1,
+                conn1=conn1, cat_add=cat_add, cat_conn=cat_conn, add2=add2, conn2=conn2,
+                term2=term2, c=c, out=out)
+    return (out, tape) if keep else out
+
+
+def backward(P, cfg, tape, d_out) -> Dict[str, torch.Tensor]:
+    T, g = tape["T"], tape["g"]
+    B, N = tape["c"].shape
+    H, M, G = cfg["hidden_node_features"], cfg["message_size"], cfg["gather_width"]
+    Fe, A, C = cfg["n_edge_features"], cfg["len_f_add_per_node"], cfg["len_f_conn_per_node"]
+    S = g["S"]
+    R = S + 1
+    grads: Dict[str, torch.Tensor] = {}
+    NA, NC = N * A, N * C
+    # tier 2
+    dz = d_out[:, :NA] * selu_grad_from_out(tape["add2"][-1])
+    dcat_add = mlp_bwd(P, "APDReadout.fAddNet2", tape["cat_add"], tape["add2"], dz, grads)
+    dz = d_out[:, NA:NA + NC] * selu_grad_from_out(tape["conn2"][-1])
+    dcat_conn = mlp_bwd(P, "APDReadout.fConnNet2", tape["cat_conn"], tape["conn2"], dz, grads)
+    dz = d_out[:, NA + NC:] * selu_grad_from_out(tape["term2"][-1])
+    dg = mlp_bwd(P, "APDReadout.fTermNet2", tape["gemb"], tape["term2"], dz, grads)
+    dg = dg + dcat_add[:, NA:] + dcat_conn[:, NC:]
+    # compress tier-1 grads onto compact rows (zero row sums all inactive slots)
+    cflat = tape["c"].reshape(-1)
+    dadd1 = torch.zeros(R, A, dtype=d_out.dtype).index_add_(0, cflat, dcat_add[:, :NA].reshape(-1, A))
+    dconn1 = torch.zeros(R, C, dtype=d_out.dtype).index_add_(0, cflat, dcat_conn[:, :NC].reshape(-1, C))
+    h = tape["h"]
+    dh = mlp_bwd(P, "APDReadout.fAddNet1", h, tape["add1"],
+                 dadd1 * selu_grad_from_out(tape["add1"][-1]), grads)
+    dh = dh + mlp_bwd(P, "APDReadout.fConnNet1", h, tape["conn1"],
+                      dconn1 * selu_grad_from_out(tape["conn1"][-1]), grads)
+    # gather
+    den, demb = gather_readout_bwd(dg, tape["att"], tape["emb_acts"][-1], T["cidx"], B, N, R)
+    dh = dh + mlp_bwd(P, "gather.emb_nn", h, tape["emb_acts"],
+                      demb * selu_grad_from_out(tape["emb_acts"][-1]), grads)
+    dhx = mlp_bwd(P, "gather.att_nn", tape["hx"], tape["att_acts"],
+                  den * selu_grad_from_out(tape["att_acts"][-1]), grads)
+    dh = dh + dhx[:, :H]
+    # message passes, reversed
+    for pi in range(cfg["message_passes"] - 1, -1, -1):
+        ps = tape["passes"][pi]
+        dgi, dgh, dh_prev = gru_gates_bwd(dh, ps["saved"], ps["h_prev"], tape["has_edge"])
+        grads["gru.weight_ih"] = grads.get("gru.weight_ih", 0) + dgi.t() @ ps["agg"]
+        grads["gru.bias_ih"] = grads.get("gru.bias_ih", 0) + dgi.sum(0)
+        grads["gru.weight_hh"] = grads.get("gru.weight_hh", 0) + dgh.t() @ ps["h_prev"]
+        grads["gru.bias_hh"] = grads.get("gru.bias_hh", 0) + dgh.sum(0)
+        dagg = dgi @ P["gru.weight_ih"]
+        dh_prev = dh_prev + dgh @ P["gru.weight_hh"]
+        dm = dagg[T["e_dst"].long()] * selu_grad_from_out(ps["m"])
+        dxe = torch.zeros(g["E"], H, dtype=d_out.dtype)
+        for t in range(Fe):
+            lo, hi = int(g["type_off"][t]), int(g["type_off"][t + 1])
+            d = mlp_bwd(P, f"msg_nns.{t}", ps["h_prev"], ps["acts_t"][t], dm[lo:hi], grads,
+                        idx=T["e_src"][lo:hi].long(), need_dx=pi > 0)
+            if d is not None:
+                dxe[lo:hi] = d
+        if pi > 0:
+            dh_prev = dh_prev + seg_sum(dxe, T["out_perm"], T["src_off"], R)
+        dh = dh_prev
+    return grads
