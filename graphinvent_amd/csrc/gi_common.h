@@ -1,0 +1,26 @@
+// Shared device/host helpers for libgraphinvent_amd (gfx950 only; wavefront = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "graphinvent_amd.h"
+
+#define GI_SELU_ALPHA 1.6732632423543772848170429916717f
+#define GI_SELU_SCALE 1.0507009873554804934193349852946f
+
+// SELU exactly as torch.nn.SELU (gnn/modules.py:126,164): scale * (x > 0 ? x : alpha * expm1(x))
+__device__ __forceinline__ float gi_selu(float x) {
+    return GI_SELU_SCALE * (x > 0.f ? x : GI_SELU_ALPHA * expm1f(x));
+}
+// d selu(x)/dx through y = selu(x):  y > 0 -> scale,  else y + scale*alpha  (x <= 0 <=> y <= 0)
+__device__ __forceinline__ float gi_selu_grad(float y) {
+    return y > 0.f ? GI_SELU_SCALE : y + GI_SELU_SCALE * GI_SELU_ALPHA;
+}
+__device__ __forceinline__ float gi_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+static inline int gi_launch_status() {
+    hipError_t e = hipGetLastError();
+    return (int)e;
+}
+static inline int gi_r4(int x) { return (x + 3) & ~3; }
+static inline long long gi_r4l(long long x) { return (x + 3) & ~3LL; }
+static inline int gi_cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,266 @@
+// K1 graph_compact: dense one-hot adjacency [B,N,N,Fe] -> compact CSR graph (gfx950).
+//
+// Replaces gnn/summation_mpnn.py:100-124 (`edges.sum(3)`, `nonzero` x2, the dense [V,E] equality
+// matrix, `edges[eb,ei,ej,:]`, the zero-padded hidden state) and :146 (`node_mask`).
+// Integer / byte work, HBM-bound (reads B*N*N*Fe*4 + B*N*Fn*4 bytes once); three launches:
+//   count : one workgroup per graph; adjacency staged in LDS as int8 bond types; per-slot
+//           in/out degrees, per-type in-degrees, activity flags
+//   scan  : one 1024-thread workgroup; exclusive scans over the B*N slots -> compact row ids,
+//           CSR offsets, bond-type bucket offsets, totals (S, E, E_t)
+//   fill  : one workgroup per graph; edge arrays in bond-type-major order, dst- and src-CSR
+//           permutations (deterministic order), initial node rows
+// Edge enumeration order = row-major nonzero of the adjacency = the reference's edge order, so
+// every destination's edges are one contiguous CSR segment and no atomics are needed anywhere.
+#include "gi_common.h"
+
+namespace {
+
+struct Lay {
+    int counts, type_off, cidx, node_mask, slot_of, seg_off, src_off, scratch, total;
+    // scratch sub-arrays (ints)
+    int rowcnt, colcnt, active, seg_start, src_start, rowcnt_t, tstart, etype;
+};
+
+inline Lay make_layout(int B, int N, int Fe) {
+    Lay L;
+    const int ns = B * N;
+    int o = 0;
+    auto take = [&](int n) { int r = o; o += gi_r4(n); return r; };
+    L.counts = take(16);
+    L.type_off = take(GI_MAX_GROUPS + 1);
+    L.cidx = take(ns);
+    L.node_mask = take(ns);
+    L.slot_of = take(ns);
+    L.seg_off = take(ns + 2);
+    L.src_off = take(ns + 2);
+    L.scratch = o;
+    L.rowcnt = take(ns);
+    L.colcnt = take(ns);
+    L.active = take(ns);
+    L.seg_start = take(ns);
+    L.src_start = take(ns);
+    L.rowcnt_t = take(Fe * ns);
+    L.tstart = take(Fe * ns);
+    L.etype = take((int)(((long long)B * N * N + 3) / 4));
+    L.total = o;
+    return L;
+}
+
+// ---- count ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void compact_count_kernel(
+    const float* __restrict__ nodes, const float* __restrict__ edges, int N, int Fn, int Fe,
+    int* __restrict__ gfix, Lay L) {
+    __shared__ signed char typ[GI_MAX_NODES * GI_MAX_NODES];
+    __shared__ int err_s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int NN = N * N;
+    if (tid == 0) err_s = 0;
+    __syncthreads();
+    const float* eg = edges + (long long)b * NN * Fe;
+    signed char* etype_g = reinterpret_cast<signed char*>(gfix + L.etype) + (long long)b * NN;
+    for (int idx = tid; idx < NN; idx += 256) {
+        float sum = 0.f;
+        int t = -1, ones = 0, zeros = 0;
+        for (int f = 0; f < Fe; ++f) {
+            const float v = eg[(long long)idx * Fe + f];
+            sum += v;
+            if (v == 1.f) { ++ones; if (t < 0) t = f; }
+            else if (v == 0.f) ++zeros;
+        }
+        signed char code = -1;
+        if (sum != 0.f) {                        // adjacency != 0  (gnn/summation_mpnn.py:100-105)
+            if (!(ones == 1 && zeros == Fe - 1)) err_s = 1;   // not one-hot: outside the data contract
+            code = (signed char)(t < 0 ? 0 : t);
+        }
+        typ[idx] = code;
+        etype_g[idx] = code;
+    }
+    __syncthreads();
+    const int ns = gridDim.x * N;
+    for (int i = tid; i < N; i += 256) {
+        const int slot = b * N + i;
+        int rc = 0, cc = 0;
+        int rct[GI_MAX_GROUPS];
+#pragma unroll
+        for (int f = 0; f < GI_MAX_GROUPS; ++f) rct[f] = 0;
+        for (int j = 0; j < N; ++j) {
+            const int t = typ[i * N + j];
+            if (t >= 0) {
+                ++rc;
+#pragma unroll
+                for (int f = 0; f < GI_MAX_GROUPS; ++f) rct[f] += (t == f);
+            }
+            cc += (typ[j * N + i] >= 0);
+        }
+        bool nz = false;
+        for (int f = 0; f < Fn; ++f) nz |= (nodes[(long long)slot * Fn + f] != 0.f);
+        gfix[L.rowcnt + slot] = rc;
+        gfix[L.colcnt + slot] = cc;
+        gfix[L.active + slot] = (nz || rc > 0 || cc > 0) ? 1 : 0;
+        gfix[L.node_mask + slot] = rc > 0 ? 1 : 0;                       // :146
+        for (int f = 0; f < Fe; ++f) gfix[L.rowcnt_t + f * ns + slot] = rct[f];
+    }
+    __syncthreads();
+    if (tid == 0 && err_s) atomicOr(&gfix[L.counts + 2], 1);
+}
+
+// ---- scan -----------------------------------------------------------------------------------
+// exclusive scan of src[0..n) -> dst, returns total (valid in every thread). 1024 threads.
+__device__ int block_exscan(const int* __restrict__ src, int* __restrict__ dst, int n,
+                            int* sh /*[1024]*/) {
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = min(tid * per, n), hi = min(lo + per, n);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += src[i];
+    sh[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {           // Hillis-Steele inclusive scan
+        int v = (tid >= off) ? sh[tid - off] : 0;
+        __syncthreads();
+        sh[tid] += v;
+        __syncthreads();
+    }
+    const int total = sh[1023];
+    int run = sh[tid] - sum;
+    for (int i = lo; i < hi; ++i) { const int v = src[i]; dst[i] = run; run += v; }
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(1024) void compact_scan_kernel(int ns, int Fe, int* __restrict__ gfix,
+                                                            Lay L) {
+    __shared__ int sh[1024];
+    __shared__ int tot[GI_MAX_GROUPS];
+    const int tid = threadIdx.x;
+    const int S = block_exscan(gfix + L.active, gfix + L.cidx, ns, sh);
+    const int E = block_exscan(gfix + L.rowcnt, gfix + L.seg_start, ns, sh);
+    block_exscan(gfix + L.colcnt, gfix + L.src_start, ns, sh);
+    for (int f = 0; f < Fe; ++f) {
+        const int t = block_exscan(gfix + L.rowcnt_t + f * ns, gfix + L.tstart + f * ns, ns, sh);
+        if (tid == 0) tot[f] = t;
+    }
+    __syncthreads();
+    // compact-row views: slot_of, seg_off, src_off; inactive slots map to the zero row S
+    for (int slot = tid; slot < ns; slot += 1024) {
+        if (gfix[L.active + slot]) {
+            const int c = gfix[L.cidx + slot];
+            gfix[L.slot_of + c] = slot;
+            gfix[L.seg_off + c] = gfix[L.seg_start + slot];
+            gfix[L.src_off + c] = gfix[L.src_start + slot];
+        } else {
+            gfix[L.cidx + slot] = S;
+        }
+    }
+    if (tid == 0) {
+        gfix[L.seg_off + S] = E; gfix[L.seg_off + S + 1] = E;
+        gfix[L.src_off + S] = E; gfix[L.src_off + S + 1] = E;
+        gfix[L.counts + 0] = S; gfix[L.counts + 1] = E;
+        int run = 0;
+        for (int f = 0; f < Fe; ++f) {
+            gfix[L.type_off + f] = run;
+            gfix[L.counts + 4 + f] = tot[f];
+            run += tot[f];
+        }
+        for (int f = Fe; f <= GI_MAX_GROUPS; ++f) gfix[L.type_off + f] = run;
+    }
+}
+
+// ---- fill -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void compact_fill_kernel(
+    const float* __restrict__ nodes, int N, int Fn, int Fe, const int* __restrict__ gfix, Lay L,
+    int S, int* __restrict__ e_src, int* __restrict__ e_dst, int* __restrict__ in_perm,
+    int* __restrict__ out_perm, float* __restrict__ hx0, int ldhx, int H) {
+    __shared__ signed char typ[GI_MAX_NODES * GI_MAX_NODES];
+    __shared__ int ppos[GI_MAX_NODES * GI_MAX_NODES];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int NN = N * N, ns = gridDim.x * N;
+    const signed char* etype_g =
+        reinterpret_cast<const signed char*>(gfix + L.etype) + (long long)b * NN;
+    for (int idx = tid; idx < NN; idx += 256) typ[idx] = etype_g[idx];
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) {                 // incoming edges of slot i, j ascending
+        const int slot = b * N + i;
+        const int cd = gfix[L.cidx + slot];
+        int ed = gfix[L.seg_start + slot];
+        int cur[GI_MAX_GROUPS];
+#pragma unroll
+        for (int f = 0; f < GI_MAX_GROUPS; ++f)
+            cur[f] = (f < Fe) ? gfix[L.type_off + f] + gfix[L.tstart + f * ns + slot] : 0;
+        for (int j = 0; j < N; ++j) {
+            const int t = typ[i * N + j];
+            if (t < 0) continue;
+            int pos = 0;
+#pragma unroll
+            for (int f = 0; f < GI_MAX_GROUPS; ++f)
+                if (t == f) { pos = cur[f]; cur[f] = pos + 1; }
+            e_src[pos] = gfix[L.cidx + b * N + j];
+            e_dst[pos] = cd;
+            in_perm[ed++] = pos;
+            ppos[i * N + j] = pos;
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < N; j += 256) {                 // outgoing edges of slot j, i ascending
+        int k = gfix[L.src_start + b * N + j];
+        for (int i = 0; i < N; ++i)
+            if (typ[i * N + j] >= 0) out_perm[k++] = ppos[i * N + j];
+    }
+    // initial node rows: hx0[c] = [x, 0 .. 0 | x]  (:121-126 zero-padded hidden state; the copy of
+    // the raw features at columns [H, H+Fn) feeds the gather attention MLP, gnn/modules.py:45)
+    for (int idx = tid; idx < N * ldhx; idx += 256) {
+        const int i = idx / ldhx, col = idx - i * ldhx;
+        const int slot = b * N + i;
+        if (!gfix[L.active + slot]) continue;
+        const int c = gfix[L.cidx + slot];
+        float v = 0.f;
+        if (col < Fn) v = nodes[(long long)slot * Fn + col];
+        else if (col >= H && col < H + Fn) v = nodes[(long long)slot * Fn + col - H];
+        hx0[(long long)c * ldhx + col] = v;
+    }
+    if (b == 0)
+        for (int col = tid; col < ldhx; col += 256) hx0[(long long)S * ldhx + col] = 0.f;
+}
+
+}  // namespace
+
+extern "C" int gi_abi_version(void) { return GI_ABI_VERSION; }
+
+extern "C" int gi_compact_layout(int B, int N, int Fe, gi_compact_layout_t* out) {
+    if (!out || B <= 0 || N <= 0 || Fe <= 0) return GI_EINVAL;
+    if (N > GI_MAX_NODES || Fe > GI_MAX_GROUPS) return GI_ELIMIT;
+    if ((long long)B * N * N > 0x7fffffffLL) return GI_ELIMIT;
+    const Lay L = make_layout(B, N, Fe);
+    out->total_ints = L.total;
+    out->counts = L.counts; out->type_off = L.type_off; out->cidx = L.cidx;
+    out->node_mask = L.node_mask; out->slot_of = L.slot_of; out->seg_off = L.seg_off;
+    out->src_off = L.src_off; out->scratch = L.scratch;
+    return 0;
+}
+
+extern "C" int gi_compact_count(const float* nodes, const float* edges, int B, int N, int Fn,
+                                int Fe, int* gfix, void* stream) {
+    if (!nodes || !edges || !gfix || B <= 0 || N <= 0 || Fn <= 0 || Fe <= 0) return GI_EINVAL;
+    if (N > GI_MAX_NODES || Fe > GI_MAX_GROUPS) return GI_ELIMIT;
+    const Lay L = make_layout(B, N, Fe);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(gfix + L.counts, 0, 16 * sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(compact_count_kernel, dim3(B), dim3(256), 0, st, nodes, edges, N, Fn, Fe,
+                       gfix, L);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, st, B * N, Fe, gfix, L);
+    return gi_launch_status();
+}
+
+extern "C" int gi_compact_fill(const float* nodes, int B, int N, int Fn, int Fe, const int* gfix,
+                               int S, int E, int* e_src, int* e_dst, int* in_perm, int* out_perm,
+                               float* hx0, int ldhx, int H, void* stream) {
+    if (!nodes || !gfix || !hx0 || B <= 0 || N <= 0 || S < 0 || E < 0) return GI_EINVAL;
+    if (E > 0 && (!e_src || !e_dst || !in_perm || !out_perm)) return GI_EINVAL;
+    if (N > GI_MAX_NODES || Fe > GI_MAX_GROUPS) return GI_ELIMIT;
+    if (ldhx < H + Fn || Fn > H) return GI_EINVAL;
+    const Lay L = make_layout(B, N, Fe);
+    hipLaunchKernelGGL(compact_fill_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, nodes, N,
+                       Fn, Fe, gfix, L, S, e_src, e_dst, in_perm, out_perm, hx0, ldhx, H);
+    return gi_launch_status();
+}

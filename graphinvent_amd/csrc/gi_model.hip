@@ -1,0 +1,573 @@
+// Host-side orchestration of the whole GGNN forward / backward on one HIP stream (gfx950).
+//
+// One call from Python enqueues every kernel of `SummationMPNN.forward`'s message passes and
+// `GGNN.readout` (gnn/summation_mpnn.py:128-149, gnn/mpnn.py:284-303) — no Python between
+// launches, no host synchronisation, no allocation: all buffers are carved out of one caller
+// provided fp32 workspace by `make_ws`, which forward and backward evaluate identically.
+//
+// Data layout in HBM (all fp32 row-major, leading dimensions rounded up to 4 floats = 16 B):
+//   node level  : R = S+1 compact rows (row S = shared zero row);  hx[p] = [h (H) | x (Fn)] per pass
+//   edge level  : E rows in bond-type-major order (rows of type t = [type_off[t], type_off[t+1]))
+//   graph level : B rows
+// Backward runs IN PLACE over the saved activations: the buffer of layer l's SELU output is
+// overwritten by dZ_l (gradient w.r.t. its pre-activation) once nobody needs the activation.
+#include <string.h>
+
+#include <algorithm>
+
+#include "gi_common.h"
+
+namespace {
+
+constexpr int MAXL = 12;   // max Linear layers per MLP (depth + 1)
+constexpr int MAXP = 16;   // max message passes
+
+struct Mlp {
+    int base, in, hidden, depth, out;
+    int layers() const { return depth + 1; }
+    int fan_in(int l) const { return l == 0 ? in : hidden; }
+    int fan_out(int l) const { return l == depth ? out : hidden; }
+    int w(int l) const { return base + 2 * l; }
+    int b(int l) const { return base + 2 * l + 1; }
+};
+
+struct Model {
+    gi_ggnn_dims d;
+    Mlp msg[GI_MAX_GROUPS], att, emb, add1, conn1, add2, conn2, term2;
+    int gru_wih, gru_whh, gru_bih, gru_bhh, nparams, NA, NC;
+};
+
+int build_model(const gi_ggnn_dims* dp, Model& m) {
+    if (!dp) return GI_EINVAL;
+    const gi_ggnn_dims& d = *dp;
+    if (d.B <= 0 || d.N <= 0 || d.Fn <= 0 || d.Fe <= 0 || d.H <= 0 || d.M <= 0 || d.G <= 0 ||
+        d.A <= 0 || d.C <= 0 || d.passes < 0 || d.Fn > d.H)
+        return GI_EINVAL;
+    if (d.N > GI_MAX_NODES || d.Fe > GI_MAX_GROUPS || d.passes > MAXP) return GI_ELIMIT;
+    const int depths[] = {d.enn_depth, d.att_depth, d.emb_depth, d.mlp1_depth, d.mlp2_depth};
+    for (int x : depths)
+        if (x < 0 || x + 1 > MAXL) return GI_ELIMIT;
+    m.d = d;
+    m.NA = d.N * d.A;
+    m.NC = d.N * d.C;
+    int idx = 0;
+    auto mk = [&](int in, int hidden, int depth, int out) {
+        Mlp r{idx, in, hidden, depth, out};
+        idx += 2 * (depth + 1);
+        return r;
+    };
+    for (int t = 0; t < d.Fe; ++t) m.msg[t] = mk(d.H, d.enn_hidden, d.enn_depth, d.M);
+    m.gru_wih = idx++; m.gru_whh = idx++; m.gru_bih = idx++; m.gru_bhh = idx++;
+    m.att = mk(d.H + d.Fn, d.att_hidden, d.att_depth, d.G);
+    m.emb = mk(d.H, d.emb_hidden, d.emb_depth, d.G);
+    m.add1 = mk(d.H, d.mlp1_hidden, d.mlp1_depth, d.A);
+    m.conn1 = mk(d.H, d.mlp1_hidden, d.mlp1_depth, d.C);
+    m.add2 = mk(m.NA + d.G, d.mlp2_hidden, d.mlp2_depth, m.NA);
+    m.conn2 = mk(m.NC + d.G, d.mlp2_hidden, d.mlp2_depth, m.NC);
+    m.term2 = mk(d.G, d.mlp2_hidden, d.mlp2_depth, 1);
+    m.nparams = idx;
+    return 0;
+}
+
+// ---- workspace --------------------------------------------------------------------------------
+struct Ws {
+    int R, E, B;
+    int ldhx, ldH, ldM, ld3H, ldG, ldA, ldC, ldEh, ldAtt, ldEmb, ldM1, ldM2, ldNA, ldNC, ldCA,
+        ldCC, ldZG;
+    long long hx[MAXP + 1];
+    long long eact[MAXP][MAXL], m[MAXP], agg[MAXP], gi[MAXP], gh[MAXP];
+    long long att_act[MAXL], en, emb_act[MAXL], embo, add1_act[MAXL], add1o, conn1_act[MAXL],
+        conn1o;
+    long long cat_add, cat_conn, gemb, add2_act[MAXL], conn2_act[MAXL], term2_act[MAXL];
+    long long dzA, dzC, dzT, dcat_add, dcat_conn, dgemb, zpart_g, zpart_a, zpart_c, dh, dh2, dxe;
+    long long total;
+};
+
+void make_ws(const Model& m, int S, int E, Ws& w) {
+    const gi_ggnn_dims& d = m.d;
+    memset(&w, 0, sizeof(w));
+    w.R = S + 1; w.E = E; w.B = d.B;
+    w.ldhx = gi_r4(d.H + d.Fn); w.ldH = gi_r4(d.H); w.ldM = gi_r4(d.M); w.ld3H = gi_r4(3 * d.H);
+    w.ldG = gi_r4(d.G); w.ldA = gi_r4(d.A); w.ldC = gi_r4(d.C); w.ldEh = gi_r4(d.enn_hidden);
+    w.ldAtt = gi_r4(d.att_hidden); w.ldEmb = gi_r4(d.emb_hidden); w.ldM1 = gi_r4(d.mlp1_hidden);
+    w.ldM2 = gi_r4(d.mlp2_hidden); w.ldNA = gi_r4(m.NA); w.ldNC = gi_r4(m.NC);
+    w.ldCA = gi_r4(m.NA + d.G); w.ldCC = gi_r4(m.NC + d.G); w.ldZG = gi_r4(2 * d.G);
+    long long o = 0;
+    auto take = [&](long long rows, int ld) { long long r = o; o += gi_r4l(rows * ld); return r; };
+    const long long R = w.R, B = d.B, Er = std::max(E, 1);
+    for (int p = 0; p <= d.passes; ++p) w.hx[p] = take(R, w.ldhx);
+    for (int p = 0; p < d.passes; ++p) {
+        for (int l = 0; l < d.enn_depth; ++l) w.eact[p][l] = take(Er, w.ldEh);
+        w.m[p] = take(Er, w.ldM);
+        w.agg[p] = take(R, w.ldM);
+        w.gi[p] = take(R, w.ld3H);
+        w.gh[p] = take(R, w.ld3H);
+    }
+    for (int l = 0; l < d.att_depth; ++l) w.att_act[l] = take(R, w.ldAtt);
+    w.en = take(R, w.ldG);
+    for (int l = 0; l < d.emb_depth; ++l) w.emb_act[l] = take(R, w.ldEmb);
+    w.embo = take(R, w.ldG);
+    for (int l = 0; l < d.mlp1_depth; ++l) w.add1_act[l] = take(R, w.ldM1);
+    w.add1o = take(R, w.ldA);
+    for (int l = 0; l < d.mlp1_depth; ++l) w.conn1_act[l] = take(R, w.ldM1);
+    w.conn1o = take(R, w.ldC);
+    w.cat_add = take(B, w.ldCA);
+    w.cat_conn = take(B, w.ldCC);
+    w.gemb = take(B, w.ldG);
+    for (int l = 0; l < d.mlp2_depth; ++l) w.add2_act[l] = take(B, w.ldM2);
+    for (int l = 0; l < d.mlp2_depth; ++l) w.conn2_act[l] = take(B, w.ldM2);
+    for (int l = 0; l < d.mlp2_depth; ++l) w.term2_act[l] = take(B, w.ldM2);
+    // backward scratch
+    w.dzA = take(B, w.ldNA); w.dzC = take(B, w.ldNC); w.dzT = take(B, 4);
+    w.dcat_add = take(B, w.ldCA); w.dcat_conn = take(B, w.ldCC); w.dgemb = take(B, w.ldG);
+    w.zpart_g = take(B, w.ldZG); w.zpart_a = take(B, w.ldA); w.zpart_c = take(B, w.ldC);
+    w.dh = take(R, w.ldH); w.dh2 = take(R, w.ldH); w.dxe = take(Er, w.ldH);
+    w.total = o;
+}
+
+// ---- wgrad slab plan ----------------------------------------------------------------------------
+struct SlabEntry { long long off, stride; int nsplit, calls, done, n_out, n_in, ld, tn; };
+struct SlabPlan { SlabEntry e[160]; long long total; };
+
+void wgrad_shape(int n_out, int n_in, int red_rows, int groups, int& tn, int& nsplit) {
+    tn = (n_in + 1 > 64) ? 2 : 1;
+    const int tiles = gi_cdiv(n_out, 64) * gi_cdiv(n_in + 1, 64 * tn) * groups;
+    const int kt = gi_cdiv(std::max(red_rows, 1), 32);
+    nsplit = std::min(std::max(gi_cdiv(256, tiles), 1), std::max(1, kt / 2));
+}
+
+void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {
+    const gi_ggnn_dims& d = m.d;
+    memset(&sp, 0, sizeof(sp));
+    long long o = 0;
+    int maxEt = 0;
+    for (int t = 0; t < d.Fe; ++t) maxEt = std::max(maxEt, Et ? Et[t] : E);
+    auto add = [&](int widx, int n_out, int n_in, int red, int calls, int groups) {
+        SlabEntry& e = sp.e[widx];
+        e.n_out = n_out; e.n_in = n_in; e.ld = gi_r4(n_in + 1); e.calls = calls; e.done = 0;
+        wgrad_shape(n_out, n_in, red, groups, e.tn, e.nsplit);
+        e.stride = gi_r4l((long long)n_out * e.ld);
+        e.off = o;
+        o += e.stride * e.nsplit * calls;
+    };
+    auto add_mlp = [&](const Mlp& q, int red, int calls, int groups = 1) {
+        for (int l = 0; l < q.layers(); ++l)
+            add(q.w(l), q.fan_out(l), q.fan_in(l), red, calls, groups);
+    };
+    const int R = S + 1;
+    for (int t = 0; t < d.Fe; ++t) add_mlp(m.msg[t], maxEt, d.passes, d.Fe);
+    add(m.gru_wih, 3 * d.H, d.M, R, d.passes, 1);
+    add(m.gru_whh, 3 * d.H, d.H, R, d.passes, 1);
+    add_mlp(m.att, R, 1); add_mlp(m.emb, R, 1); add_mlp(m.add1, R, 1); add_mlp(m.conn1, R, 1);
+    add_mlp(m.add2, d.B, 1); add_mlp(m.conn2, d.B, 1); add_mlp(m.term2, d.B, 1);
+    sp.total = o;
+}
+
+// ---- launch helpers -----------------------------------------------------------------------------
+struct Grp { int n; const int* off; int max_rows; };    // n == 0: ungrouped
+
+struct Run {
+    hipStream_t st;
+    const float* const* P;
+    int rc;
+    bool ok() const { return rc == 0; }
+    void chk(int r) { if (rc == 0 && r != 0) rc = r; }
+};
+
+void pick_tile(int rows, int ncols, int& tm, int& tn) {
+    if (ncols <= 64) { tm = 1; tn = 1; return; }
+    tn = 2;
+    const long long b22 = (long long)gi_cdiv(rows, 128) * gi_cdiv(ncols, 128);
+    tm = (b22 >= 512) ? 2 : 1;
+}
+
+void gemm_defaults(gi_gemm_params& p) {
+    memset(&p, 0, sizeof(p));
+    p.nsplit = 1;
+    p.ones_col = -1;
+}
+
+// Y[rows, out] = (selu)(X[a_idx][rows, in] W^T + b); group t uses mlps[t]'s layer l
+void linear_fwd(Run& r, const Mlp* mlps, int l, const Grp& g, const float* X, int ldx,
+                const int* a_idx, int rows, float* Y, int ldy) {
+    if (!r.ok() || rows <= 0) return;
+    gi_gemm_params p;
+    gemm_defaults(p);
+    const Mlp& q = mlps[0];
+    p.A = X; p.lda = ldx; p.a_idx = a_idx;
+    p.C = Y; p.ldc = ldy;
+    p.M = rows; p.N = q.fan_out(l); p.K = q.fan_in(l); p.ldb = q.fan_in(l);
+    p.flags = GI_EPI_BIAS | GI_EPI_SELU;
+    if (g.n) {
+        p.ngroups = g.n; p.grp_off = g.off; p.max_group_rows = g.max_rows;
+        for (int t = 0; t < g.n; ++t) { p.Bg[t] = r.P[mlps[t].w(l)]; p.biasg[t] = r.P[mlps[t].b(l)]; }
+    } else {
+        p.B = r.P[q.w(l)]; p.bias = r.P[q.b(l)];
+    }
+    pick_tile(g.n ? g.max_rows : rows, p.N, p.tm, p.tn);
+    r.chk(gi_gemm(&p, r.st));
+}
+
+// plain linear without activation (GRU pre-activations)
+void linear_plain(Run& r, const float* W, const float* b, int in, int out, const float* X, int ldx,
+                  int rows, float* Y, int ldy) {
+    if (!r.ok() || rows <= 0) return;
+    gi_gemm_params p;
+    gemm_defaults(p);
+    p.A = X; p.lda = ldx; p.B = W; p.ldb = in; p.bias = b; p.C = Y; p.ldc = ldy;
+    p.M = rows; p.N = out; p.K = in;
+    p.flags = GI_EPI_BIAS;
+    pick_tile(rows, out, p.tm, p.tn);
+    r.chk(gi_gemm(&p, r.st));
+}
+
+// dX[rows, ncols] (+)= (dZ[rows, n_out] W[n_out, n_in][:, :ncols]) (* selu'(act))
+void linear_dgrad(Run& r, const float* const* Wg, const float* W, const Grp& g, int n_out,
+                  int n_in, int ncols, const float* dZ, int lddz, int rows, float* dX, int lddx,
+                  const float* act, int ldact, bool accumulate) {
+    if (!r.ok() || rows <= 0) return;
+    gi_gemm_params p;
+    gemm_defaults(p);
+    p.A = dZ; p.lda = lddz; p.C = dX; p.ldc = lddx;
+    p.M = rows; p.N = ncols; p.K = n_out; p.ldb = n_in; p.b_major = 1;
+    p.act = act; p.ldact = ldact;
+    p.flags = (act ? GI_EPI_DSELU : 0) | (accumulate ? GI_EPI_ACCUM : 0);
+    if (g.n) {
+        p.ngroups = g.n; p.grp_off = g.off; p.max_group_rows = g.max_rows;
+        for (int t = 0; t < g.n; ++t) p.Bg[t] = Wg[t];
+    } else {
+        p.B = W;
+    }
+    pick_tile(g.n ? g.max_rows : rows, ncols, p.tm, p.tn);
+    r.chk(gi_gemm(&p, r.st));
+}
+
+// slabs of [dW | db] = dZ^T [X[b_idx] | 1], reduction over `rows`
+void linear_wgrad(Run& r, SlabPlan& sp, float* slabs, const int* widx, const Grp& g,
+                  const float* dZ, int lddz, const float* X, int ldx, const int* b_idx, int rows) {
+    if (!r.ok()) return;
+    gi_gemm_params p;
+    gemm_defaults(p);
+    SlabEntry& e0 = sp.e[widx[0]];
+    p.A = dZ; p.lda = lddz; p.a_major = 1;
+    p.B = X; p.ldb = ldx; p.b_major = 1; p.b_idx = b_idx;
+    p.M = e0.n_out; p.N = e0.n_in + 1; p.K = rows; p.ldc = e0.ld;
+    p.ones_col = e0.n_in;
+    p.flags = GI_GEMM_SPLITK;
+    p.nsplit = e0.nsplit; p.c_split_stride = e0.stride;
+    p.tm = 1; p.tn = e0.tn;
+    if (g.n) {
+        p.ngroups = g.n; p.grp_off = g.off;
+        for (int t = 0; t < g.n; ++t) {
+            SlabEntry& e = sp.e[widx[t]];
+            p.Cg[t] = slabs + e.off + (long long)e.done * e.nsplit * e.stride;
+            e.done++;
+        }
+    } else {
+        p.C = slabs + e0.off + (long long)e0.done * e0.nsplit * e0.stride;
+        e0.done++;
+    }
+    r.chk(gi_gemm(&p, r.st));
+}
+
+void mlp_forward(Run& r, float* ws, const Mlp* mlps, const Grp& g, const float* X, int ldx,
+                 const int* a_idx, int rows, const long long* acts, int ldh, float* final_dst,
+                 int ld_final) {
+    const int L = mlps[0].layers();
+    for (int l = 0; l < L; ++l) {
+        const float* src = (l == 0) ? X : ws + acts[l - 1];
+        float* dst = (l == L - 1) ? final_dst : ws + acts[l];
+        linear_fwd(r, mlps, l, g, src, l == 0 ? ldx : ldh, l == 0 ? a_idx : nullptr, rows, dst,
+                   l == L - 1 ? ld_final : ldh);
+    }
+}
+
+// Zlast holds dZ of the last layer on entry.  Hidden activation buffers are overwritten with
+// their dZ.  dX (first-layer input gradient, first dx_cols columns) only if dX != nullptr.
+void mlp_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, const Mlp* mlps, const Grp& g,
+                  const float* X, int ldx, const int* a_idx, int rows, const long long* acts,
+                  int ldh, const float* Zlast, int ldz, float* dX, int lddx, int dx_cols,
+                  bool accumulate) {
+    const int L = mlps[0].layers();
+    const int ngr = g.n ? g.n : 1;
+    for (int l = L - 1; l >= 0; --l) {
+        const float* dZ = (l == L - 1) ? Zlast : ws + acts[l];
+        const int lddz = (l == L - 1) ? ldz : ldh;
+        const float* Xl = (l == 0) ? X : ws + acts[l - 1];
+        const int ldxl = (l == 0) ? ldx : ldh;
+        int widx[GI_MAX_GROUPS];
+        const float* Wg[GI_MAX_GROUPS];
+        for (int t = 0; t < ngr; ++t) { widx[t] = mlps[t].w(l); Wg[t] = r.P[widx[t]]; }
+        linear_wgrad(r, sp, slabs, widx, g, dZ, lddz, Xl, ldxl, l == 0 ? a_idx : nullptr, rows);
+        const Mlp& q = mlps[0];
+        if (l > 0) {
+            float* prev = ws + acts[l - 1];
+            linear_dgrad(r, Wg, Wg[0], g, q.fan_out(l), q.fan_in(l), q.fan_in(l), dZ, lddz, rows,
+                         prev, ldh, prev, ldh, false);
+        } else if (dX) {
+            linear_dgrad(r, Wg, Wg[0], g, q.fan_out(0), q.fan_in(0), dx_cols, dZ, lddz, rows, dX,
+                         lddx, nullptr, 0, accumulate);
+        }
+    }
+}
+
+}  // namespace
+
+// ================================ C ABI ==========================================================
+extern "C" int gi_ggnn_num_params(const gi_ggnn_dims* d) {
+    Model m;
+    const int rc = build_model(d, m);
+    return rc ? rc : m.nparams;
+}
+
+extern "C" long long gi_ggnn_workspace_floats(const gi_ggnn_dims* d, int S, int E) {
+    Model m;
+    if (build_model(d, m) || S < 0 || E < 0) return GI_EINVAL;
+    Ws w;
+    make_ws(m, S, E, w);
+    return w.total;
+}
+
+extern "C" long long gi_ggnn_hx0_offset(const gi_ggnn_dims* d, int S, int E) {
+    Model m;
+    if (build_model(d, m) || S < 0 || E < 0) return GI_EINVAL;
+    Ws w;
+    make_ws(m, S, E, w);
+    return w.hx[0];
+}
+
+extern "C" int gi_ggnn_ldhx(const gi_ggnn_dims* d) {
+    Model m;
+    if (build_model(d, m)) return GI_EINVAL;
+    return gi_r4(d->H + d->Fn);
+}
+
+extern "C" long long gi_ggnn_slab_floats(const gi_ggnn_dims* d, int S, int E, const int* Et) {
+    Model m;
+    if (build_model(d, m) || S < 0 || E < 0) return GI_EINVAL;
+    static_assert(sizeof(SlabPlan) < (1 << 16), "plan size");
+    SlabPlan sp;
+    if (m.nparams > 160) return GI_ELIMIT;
+    plan_slabs(m, S, E, Et, sp);
+    return sp.total;
+}
+
+// Debug/test hook: offset (floats) and leading dimension of a named workspace buffer.
+extern "C" int gi_ggnn_ws_query(const gi_ggnn_dims* d, int S, int E, const char* name, int i, int j,
+                                long long* off, int* ld) {
+    Model m;
+    if (build_model(d, m) || S < 0 || E < 0 || !name || !off || !ld) return GI_EINVAL;
+    if (i < 0 || i > MAXP || j < 0 || j >= MAXL) return GI_EINVAL;
+    Ws w;
+    make_ws(m, S, E, w);
+    struct Item { const char* n; long long o; int l; };
+    const Item items[] = {
+        {"hx", w.hx[i], w.ldhx}, {"eact", w.eact[i < MAXP ? i : 0][j], w.ldEh},
+        {"m", w.m[i < MAXP ? i : 0], w.ldM}, {"agg", w.agg[i < MAXP ? i : 0], w.ldM},
+        {"gi", w.gi[i < MAXP ? i : 0], w.ld3H}, {"gh", w.gh[i < MAXP ? i : 0], w.ld3H},
+        {"att_act", w.att_act[j], w.ldAtt}, {"en", w.en, w.ldG},
+        {"emb_act", w.emb_act[j], w.ldEmb}, {"emb", w.embo, w.ldG},
+        {"add1_act", w.add1_act[j], w.ldM1}, {"add1", w.add1o, w.ldA},
+        {"conn1_act", w.conn1_act[j], w.ldM1}, {"conn1", w.conn1o, w.ldC},
+        {"cat_add", w.cat_add, w.ldCA}, {"cat_conn", w.cat_conn, w.ldCC}, {"gemb", w.gemb, w.ldG},
+        {"add2_act", w.add2_act[j], w.ldM2}, {"conn2_act", w.conn2_act[j], w.ldM2},
+        {"term2_act", w.term2_act[j], w.ldM2}, {"dcat_add", w.dcat_add, w.ldCA},
+        {"dcat_conn", w.dcat_conn, w.ldCC}, {"dgemb", w.dgemb, w.ldG}, {"dh", w.dh, w.ldH},
+        {"dh2", w.dh2, w.ldH}, {"dxe", w.dxe, w.ldH},
+    };
+    for (const Item& it : items)
+        if (!strcmp(it.n, name)) { *off = it.o; *ld = it.l; return 0; }
+    return GI_EINVAL;
+}
+
+extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* params, const int* gfix,
+                               const int* e_src, const int* in_perm, int S, int E, const int* Et,
+                               float* ws, float* out, int ldout, void* stream) {
+    Model m;
+    int rc = build_model(dp, m);
+    if (rc) return rc;
+    if (!params || !gfix || !ws || !out || S < 0 || E < 0 || !Et) return GI_EINVAL;
+    if (E > 0 && (!e_src || !in_perm)) return GI_EINVAL;
+    const gi_ggnn_dims& d = m.d;
+    if (ldout < m.NA + m.NC + 1) return GI_EINVAL;
+    gi_compact_layout_t L;
+    rc = gi_compact_layout(d.B, d.N, d.Fe, &L);
+    if (rc) return rc;
+    Ws w;
+    make_ws(m, S, E, w);
+    Run r{(hipStream_t)stream, params, 0};
+    const int R = w.R;
+    int maxEt = 0;
+    for (int t = 0; t < d.Fe; ++t) maxEt = std::max(maxEt, Et[t]);
+    const Grp none{0, nullptr, 0};
+    const Grp bytype{d.Fe, gfix + L.type_off, maxEt};
+    const int* seg_off = gfix + L.seg_off;
+    const int* cidx = gfix + L.cidx;
+    const int* mask = gfix + L.node_mask;
+
+    // ---- message passes (gnn/summation_mpnn.py:128-144) ----------------------------------------
+    for (int p = 0; p < d.passes; ++p) {
+        const float* hx = ws + w.hx[p];
+        if (E > 0)   // m_e = MLP_type(e)(h_src(e)), gnn/mpnn.py:284-294 routed per bond type
+            mlp_forward(r, ws, m.msg, bytype, hx, w.ldhx, e_src, E, w.eact[p], w.ldEh,
+                        ws + w.m[p], w.ldM);
+        // a_v = sum of incoming messages (:141)
+        r.chk(gi_seg_sum(ws + w.m[p], w.ldM, in_perm, seg_off, R, d.M, ws + w.agg[p], w.ldM, 0,
+                         r.st));
+        // GRU update (gnn/mpnn.py:296-297)
+        linear_plain(r, params[m.gru_wih], params[m.gru_bih], d.M, 3 * d.H, ws + w.agg[p], w.ldM,
+                     R, ws + w.gi[p], w.ld3H);
+        linear_plain(r, params[m.gru_whh], params[m.gru_bhh], d.H, 3 * d.H, hx, w.ldhx, R,
+                     ws + w.gh[p], w.ld3H);
+        r.chk(gi_gru_gates_fwd(ws + w.gi[p], ws + w.gh[p], w.ld3H, hx, ws + w.hx[p + 1], w.ldhx,
+                               seg_off, R, d.H, d.Fn, r.st));
+    }
+    // ---- readout (gnn/mpnn.py:299-303) -----------------------------------------------------------
+    const float* hx = ws + w.hx[d.passes];
+    mlp_forward(r, ws, &m.att, none, hx, w.ldhx, nullptr, R, w.att_act, w.ldAtt, ws + w.en, w.ldG);
+    mlp_forward(r, ws, &m.emb, none, hx, w.ldhx, nullptr, R, w.emb_act, w.ldEmb, ws + w.embo, w.ldG);
+    mlp_forward(r, ws, &m.add1, none, hx, w.ldhx, nullptr, R, w.add1_act, w.ldM1, ws + w.add1o, w.ldA);
+    mlp_forward(r, ws, &m.conn1, none, hx, w.ldhx, nullptr, R, w.conn1_act, w.ldM1, ws + w.conn1o, w.ldC);
+    r.chk(gi_gather_readout_fwd(ws + w.en, ws + w.embo, w.ldG, cidx, mask, d.B, d.N, d.G,
+                                d.big_positive, ws + w.cat_add + m.NA, w.ldCA,
+                                ws + w.cat_conn + m.NC, w.ldCC, ws + w.gemb, w.ldG, r.st));
+    r.chk(gi_expand_slots(ws + w.add1o, w.ldA, cidx, d.B, d.N, d.A, ws + w.cat_add, w.ldCA, r.st));
+    r.chk(gi_expand_slots(ws + w.conn1o, w.ldC, cidx, d.B, d.N, d.C, ws + w.cat_conn, w.ldCC, r.st));
+    mlp_forward(r, ws, &m.add2, none, ws + w.cat_add, w.ldCA, nullptr, d.B, w.add2_act, w.ldM2,
+                out, ldout);
+    mlp_forward(r, ws, &m.conn2, none, ws + w.cat_conn, w.ldCC, nullptr, d.B, w.conn2_act, w.ldM2,
+                out + m.NA, ldout);
+    mlp_forward(r, ws, &m.term2, none, ws + w.gemb, w.ldG, nullptr, d.B, w.term2_act, w.ldM2,
+                out + m.NA + m.NC, ldout);
+    return r.rc;
+}
+
+extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* params, const int* gfix,
+                                const int* e_src, const int* e_dst, const int* out_perm, int S,
+                                int E, const int* Et, float* ws, float* slabs, const float* y_out,
+                                int ldout, const float* d_out, int lddout, float* const* grads,
+                                void* stream) {
+    Model m;
+    int rc = build_model(dp, m);
+    if (rc) return rc;
+    if (!params || !gfix || !ws || !slabs || !y_out || !d_out || !grads || S < 0 || E < 0 || !Et)
+        return GI_EINVAL;
+    if (E > 0 && (!e_src || !e_dst || !out_perm)) return GI_EINVAL;
+    if (m.nparams > 160) return GI_ELIMIT;
+    const gi_ggnn_dims& d = m.d;
+    gi_compact_layout_t L;
+    rc = gi_compact_layout(d.B, d.N, d.Fe, &L);
+    if (rc) return rc;
+    Ws w;
+    make_ws(m, S, E, w);
+    SlabPlan sp;
+    plan_slabs(m, S, E, Et, sp);
+    Run r{(hipStream_t)stream, params, 0};
+    const int R = w.R;
+    int maxEt = 0;
+    for (int t = 0; t < d.Fe; ++t) maxEt = std::max(maxEt, Et[t]);
+    const Grp none{0, nullptr, 0};
+    const Grp bytype{d.Fe, gfix + L.type_off, maxEt};
+    const int* seg_off = gfix + L.seg_off;
+    const int* src_off = gfix + L.src_off;
+    const int* cidx = gfix + L.cidx;
+    const int* mask = gfix + L.node_mask;
+    const int NA = m.NA, NC = m.NC;
+
+    // ---- tier 2 (gnn/modules.py:265-279) ---------------------------------------------------------
+    r.chk(gi_selu_bwd_rows(d_out, lddout, nullptr, y_out, ldout, ws + w.dzA, w.ldNA, d.B, NA, r.st));
+    r.chk(gi_selu_bwd_rows(d_out + NA, lddout, nullptr, y_out + NA, ldout, ws + w.dzC, w.ldNC, d.B,
+                           NC, r.st));
+    r.chk(gi_selu_bwd_rows(d_out + NA + NC, lddout, nullptr, y_out + NA + NC, ldout, ws + w.dzT, 4,
+                           d.B, 1, r.st));
+    mlp_backward(r, ws, sp, slabs, &m.add2, none, ws + w.cat_add, w.ldCA, nullptr, d.B, w.add2_act,
+                 w.ldM2, ws + w.dzA, w.ldNA, ws + w.dcat_add, w.ldCA, NA + d.G, false);
+    mlp_backward(r, ws, sp, slabs, &m.conn2, none, ws + w.cat_conn, w.ldCC, nullptr, d.B,
+                 w.conn2_act, w.ldM2, ws + w.dzC, w.ldNC, ws + w.dcat_conn, w.ldCC, NC + d.G, false);
+    mlp_backward(r, ws, sp, slabs, &m.term2, none, ws + w.gemb, w.ldG, nullptr, d.B, w.term2_act,
+                 w.ldM2, ws + w.dzT, 4, ws + w.dgemb, w.ldG, d.G, false);
+    // ---- gather + tier-1 glue: dZ of the last att/emb/add1/conn1 layers, in place ----------------
+    r.chk(gi_gather_readout_bwd(ws + w.en, ws + w.embo, w.ldG, cidx, mask, d.B, d.N, d.G, S,
+                                d.big_positive, ws + w.dgemb, w.ldG, ws + w.dcat_add + NA, w.ldCA,
+                                ws + w.dcat_conn + NC, w.ldCC, ws + w.zpart_g, r.st));
+    float* en_z = ws + w.en + (long long)S * w.ldG;
+    float* emb_z = ws + w.embo + (long long)S * w.ldG;
+    r.chk(gi_colsum(ws + w.zpart_g, w.ldZG, d.B, d.G, en_z, en_z, r.st));
+    r.chk(gi_colsum(ws + w.zpart_g + d.G, w.ldZG, d.B, d.G, emb_z, emb_z, r.st));
+    r.chk(gi_compress_slots(ws + w.add1o, w.ldA, cidx, d.B, d.N, d.A, S, ws + w.dcat_add, w.ldCA,
+                            ws + w.zpart_a, w.ldA, r.st));
+    float* add_z = ws + w.add1o + (long long)S * w.ldA;
+    r.chk(gi_colsum(ws + w.zpart_a, w.ldA, d.B, d.A, add_z, add_z, r.st));
+    r.chk(gi_compress_slots(ws + w.conn1o, w.ldC, cidx, d.B, d.N, d.C, S, ws + w.dcat_conn, w.ldCC,
+                            ws + w.zpart_c, w.ldC, r.st));
+    float* conn_z = ws + w.conn1o + (long long)S * w.ldC;
+    r.chk(gi_colsum(ws + w.zpart_c, w.ldC, d.B, d.C, conn_z, conn_z, r.st));
+    // ---- node-level readout MLPs -> dh -------------------------------------------------------------
+    const float* hxP = ws + w.hx[d.passes];
+    float* dh = ws + w.dh;
+    float* dh2 = ws + w.dh2;
+    mlp_backward(r, ws, sp, slabs, &m.add1, none, hxP, w.ldhx, nullptr, R, w.add1_act, w.ldM1,
+                 ws + w.add1o, w.ldA, dh, w.ldH, d.H, false);
+    mlp_backward(r, ws, sp, slabs, &m.conn1, none, hxP, w.ldhx, nullptr, R, w.conn1_act, w.ldM1,
+                 ws + w.conn1o, w.ldC, dh, w.ldH, d.H, true);
+    mlp_backward(r, ws, sp, slabs, &m.emb, none, hxP, w.ldhx, nullptr, R, w.emb_act, w.ldEmb,
+                 ws + w.embo, w.ldG, dh, w.ldH, d.H, true);
+    mlp_backward(r, ws, sp, slabs, &m.att, none, hxP, w.ldhx, nullptr, R, w.att_act, w.ldAtt,
+                 ws + w.en, w.ldG, dh, w.ldH, d.H, true);
+    // ---- message passes, reversed -------------------------------------------------------------------
+    for (int p = d.passes - 1; p >= 0; --p) {
+        const float* hx = ws + w.hx[p];
+        float* gi = ws + w.gi[p];
+        float* gh = ws + w.gh[p];
+        float* agg = ws + w.agg[p];
+        r.chk(gi_gru_gates_bwd(gi, gh, w.ld3H, hx, w.ldhx, dh, dh2, w.ldH, seg_off, R, d.H, r.st));
+        const int wih = m.gru_wih, whh = m.gru_whh;
+        linear_wgrad(r, sp, slabs, &wih, none, gi, w.ld3H, agg, w.ldM, nullptr, R);
+        linear_wgrad(r, sp, slabs, &whh, none, gh, w.ld3H, hx, w.ldhx, nullptr, R);
+        // d agg = d gi W_ih  (in place over agg: its wgrad above is already enqueued)
+        linear_dgrad(r, nullptr, params[m.gru_wih], none, 3 * d.H, d.M, d.M, gi, w.ld3H, R, agg,
+                     w.ldM, nullptr, 0, false);
+        if (p > 0)
+            linear_dgrad(r, nullptr, params[m.gru_whh], none, 3 * d.H, d.H, d.H, gh, w.ld3H, R,
+                         dh2, w.ldH, nullptr, 0, true);
+        if (E > 0) {
+            // d m_e = d agg[dst(e)] * selu'(m_e)   (backward of the segmented sum + last SELU)
+            r.chk(gi_selu_bwd_rows(agg, w.ldM, e_dst, ws + w.m[p], w.ldM, ws + w.m[p], w.ldM, E,
+                                   d.M, r.st));
+            mlp_backward(r, ws, sp, slabs, m.msg, bytype, hx, w.ldhx, e_src, E, w.eact[p], w.ldEh,
+                         ws + w.m[p], w.ldM, p > 0 ? ws + w.dxe : nullptr, w.ldH, d.H, false);
+            if (p > 0)   // scatter d h_src back to nodes: segmented sum over the source CSR
+                r.chk(gi_seg_sum(ws + w.dxe, w.ldH, out_perm, src_off, R, d.H, dh2, w.ldH, 1, r.st));
+        } else {
+            // no edges: the message MLP weights still need zeroed slabs
+            for (int t = 0; t < d.Fe; ++t)
+                for (int l = 0; l < m.msg[t].layers(); ++l) {
+                    SlabEntry& e = sp.e[m.msg[t].w(l)];
+                    r.chk((int)hipMemsetAsync(slabs + e.off + (long long)e.done * e.nsplit * e.stride,
+                                              0, sizeof(float) * e.nsplit * e.stride, r.st));
+                    e.done++;
+                }
+        }
+        std::swap(dh, dh2);
+    }
+    // ---- slabs -> parameter gradients -----------------------------------------------------------------
+    gi_reduce_desc descs[160];
+    int nd = 0;
+    auto add_desc = [&](int widx, int bidx) {
+        const SlabEntry& e = sp.e[widx];
+        gi_reduce_desc& q = descs[nd++];
+        q.slabs = slabs + e.off; q.dW = grads[widx]; q.db = grads[bidx];
+        q.slab_stride = e.stride; q.n_slabs = e.nsplit * e.calls; q.N = e.n_out; q.K = e.n_in;
+        q.ld = e.ld;
+    };
+    auto add_mlp_desc = [&](const Mlp& q) {
+        for (int l = 0; l < q.layers(); ++l) add_desc(q.w(l), q.b(l));
+    };
+    for (int t = 0; t < d.Fe; ++t) add_mlp_desc(m.msg[t]);
+    add_desc(m.gru_wih, m.gru_bih);
+    add_desc(m.gru_whh, m.gru_bhh);
+    add_mlp_desc(m.att); add_mlp_desc(m.emb); add_mlp_desc(m.add1); add_mlp_desc(m.conn1);
+    add_mlp_desc(m.add2); add_mlp_desc(m.conn2); add_mlp_desc(m.term2);
+    if (r.ok()) r.chk(gi_reduce_slabs(descs, nd, r.st));
+    return r.rc;
+}

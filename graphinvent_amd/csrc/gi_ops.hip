@@ -1,0 +1,360 @@
+// Graph-structured and pointwise kernels of the GGNN hot path (gfx950).  All HBM/L2-bound
+// streaming kernels: coalesced row reads, 16-byte vectors where the layout allows, no atomics,
+// deterministic summation order.
+#include "gi_common.h"
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// ---- K4 seg_sum -----------------------------------------------------------------------------
+// one thread per (compact row, 16-byte column group); lanes of a row group share perm[k] (broadcast
+// load) and read one contiguous row of `vals` -> fully coalesced row gathers.
+__global__ __launch_bounds__(256) void seg_sum_kernel(
+    const float* __restrict__ vals, int ldv, const int* __restrict__ perm,
+    const int* __restrict__ off, int rows, int c4n, float* out, int ldo, int accumulate) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(t / c4n), q = (int)(t - (long long)c * c4n);
+    if (c >= rows) return;
+    const int lo = off[c], hi = off[c + 1];
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    int k = lo;
+    for (; k + 1 < hi; k += 2) {                      // two independent row loads in flight
+        const int p0 = perm[k], p1 = perm[k + 1];
+        const v4f a = *(const v4f*)(vals + (long long)p0 * ldv + 4 * q);
+        const v4f b = *(const v4f*)(vals + (long long)p1 * ldv + 4 * q);
+        acc += a;
+        acc += b;
+    }
+    if (k < hi) acc += *(const v4f*)(vals + (long long)perm[k] * ldv + 4 * q);
+    v4f* dst = (v4f*)(out + (long long)c * ldo + 4 * q);
+    if (accumulate) acc += *dst;
+    *dst = acc;
+}
+
+__global__ __launch_bounds__(256) void selu_bwd_rows_kernel(
+    const float* __restrict__ dY, int lddy, const int* __restrict__ idx, const float* Y, int ldy,
+    float* out, int ldo, int rows, int cols) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int r = (int)(t / cols), c = (int)(t - (long long)r * cols);
+    if (r >= rows) return;
+    const long long sr = idx ? idx[r] : r;
+    out[(long long)r * ldo + c] = dY[sr * lddy + c] * gi_selu_grad(Y[(long long)r * ldy + c]);
+}
+
+// ---- GRU gates --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gru_gates_fwd_kernel(
+    float* gi, const float* __restrict__ gh, int ldg, const float* __restrict__ hx_prev,
+    float* __restrict__ hx_new, int ldh, const int* __restrict__ seg_off, int rows, int H) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int row = (int)(t / ldh), j = (int)(t - (long long)row * ldh);
+    if (row >= rows) return;
+    const float hp = hx_prev[(long long)row * ldh + j];
+    float hn_out = hp;                                  // feature tail / padding: plain copy
+    if (j < H && seg_off[row + 1] > seg_off[row]) {
+        float* g = gi + (long long)row * ldg;
+        const float* h = gh + (long long)row * ldg;
+        const float r = gi_sigmoid(g[j] + h[j]);
+        const float z = gi_sigmoid(g[H + j] + h[H + j]);
+        const float n = tanhf(g[2 * H + j] + r * h[2 * H + j]);
+        hn_out = (1.f - z) * n + z * hp;
+        g[j] = r; g[H + j] = z; g[2 * H + j] = n;       // saved for backward
+    }
+    hx_new[(long long)row * ldh + j] = hn_out;
+}
+
+__global__ __launch_bounds__(256) void gru_gates_bwd_kernel(
+    float* gi, float* gh, int ldg, const float* __restrict__ hx_prev, int ldh,
+    const float* __restrict__ dh_new, float* __restrict__ dh_prev, int lddh,
+    const int* __restrict__ seg_off, int rows, int H) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int row = (int)(t / H), j = (int)(t - (long long)row * H);
+    if (row >= rows) return;
+    float* g = gi + (long long)row * ldg;
+    float* h = gh + (long long)row * ldg;
+    const float d = dh_new[(long long)row * lddh + j];
+    if (seg_off[row + 1] > seg_off[row]) {
+        const float r = g[j], z = g[H + j], n = g[2 * H + j], hn = h[2 * H + j];
+        const float hp = hx_prev[(long long)row * ldh + j];
+        const float dn = d * (1.f - z);
+        const float dz = d * (hp - n);
+        const float dpn = dn * (1.f - n * n);
+        const float dpr = dpn * hn * r * (1.f - r);
+        const float dpz = dz * z * (1.f - z);
+        g[j] = dpr; g[H + j] = dpz; g[2 * H + j] = dpn;
+        h[j] = dpr; h[H + j] = dpz; h[2 * H + j] = dpn * r;
+        dh_prev[(long long)row * lddh + j] = d * z;
+    } else {
+        g[j] = 0.f; g[H + j] = 0.f; g[2 * H + j] = 0.f;
+        h[j] = 0.f; h[H + j] = 0.f; h[2 * H + j] = 0.f;
+        dh_prev[(long long)row * lddh + j] = d;
+    }
+}
+
+// ---- K7 gather readout ------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void gather_fwd_kernel(
+    const float* __restrict__ en, const float* __restrict__ emb, int ld,
+    const int* __restrict__ cidx, const int* __restrict__ mask, int N, int G, float big,
+    float* out0, int ld0, float* out1, int ld1, float* out2, int ld2) {
+    __shared__ int c_s[GI_MAX_NODES];
+    __shared__ float pen_s[GI_MAX_NODES];
+    const int b = blockIdx.x;
+    for (int n = threadIdx.x; n < N; n += 128) {
+        c_s[n] = cidx[b * N + n];
+        pen_s[n] = mask[b * N + n] ? 0.f : big;       // (node_mask == 0) * big_positive, modules.py:46
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += 128) {
+        float m = -INFINITY;
+        for (int n = 0; n < N; ++n) m = fmaxf(m, en[(long long)c_s[n] * ld + g] - pen_s[n]);
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += expf((en[(long long)c_s[n] * ld + g] - pen_s[n]) - m);
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const long long o = (long long)c_s[n] * ld + g;
+            acc += (expf((en[o] - pen_s[n]) - m) / s) * emb[o];
+        }
+        if (out0) out0[(long long)b * ld0 + g] = acc;
+        if (out1) out1[(long long)b * ld1 + g] = acc;
+        if (out2) out2[(long long)b * ld2 + g] = acc;
+    }
+}
+
+__global__ __launch_bounds__(128) void gather_bwd_kernel(
+    float* en, float* emb, int ld, const int* __restrict__ cidx, const int* __restrict__ mask,
+    int N, int G, int S, float big, const float* __restrict__ dg0, int ld0,
+    const float* __restrict__ dg1, int ld1, const float* __restrict__ dg2, int ld2,
+    float* __restrict__ zpart) {
+    __shared__ int c_s[GI_MAX_NODES];
+    __shared__ float pen_s[GI_MAX_NODES];
+    const int b = blockIdx.x;
+    for (int n = threadIdx.x; n < N; n += 128) {
+        c_s[n] = cidx[b * N + n];
+        pen_s[n] = mask[b * N + n] ? 0.f : big;
+    }
+    __syncthreads();
+    const int ldz = 2 * G;
+    for (int g = threadIdx.x; g < G; g += 128) {
+        float dg = 0.f;
+        if (dg0) dg += dg0[(long long)b * ld0 + g];
+        if (dg1) dg += dg1[(long long)b * ld1 + g];
+        if (dg2) dg += dg2[(long long)b * ld2 + g];
+        float m = -INFINITY;
+        for (int n = 0; n < N; ++n) m = fmaxf(m, en[(long long)c_s[n] * ld + g] - pen_s[n]);
+        float s = 0.f, sd = 0.f;                                 // sum p, sum p * (emb*dg)
+        for (int n = 0; n < N; ++n) {
+            const long long o = (long long)c_s[n] * ld + g;
+            const float p = expf((en[o] - pen_s[n]) - m);
+            s += p;
+            sd += p * (emb[o] * dg);
+        }
+        const float dot = sd / s;                                // sum_n att_n * datt_n
+        float zen = 0.f, zemb = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const long long o = (long long)c_s[n] * ld + g;
+            const float ev = en[o], mv = emb[o];
+            const float att = expf((ev - pen_s[n]) - m) / s;
+            const float de = att * (mv * dg - dot);
+            const float dm = att * dg;
+            if (c_s[n] < S) {                                    // this slot owns its compact row
+                en[o] = de * gi_selu_grad(ev);
+                emb[o] = dm * gi_selu_grad(mv);
+            } else {                                             // shared zero row: per-graph partial
+                zen += de;
+                zemb += dm;
+            }
+        }
+        zpart[(long long)b * ldz + g] = zen;
+        zpart[(long long)b * ldz + G + g] = zemb;
+    }
+}
+
+// ---- tier-1 <-> tier-2 glue ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void expand_slots_kernel(
+    const float* __restrict__ t1, int ldt, const int* __restrict__ cidx, int NW, int W,
+    float* __restrict__ cat, int ldc, long long total) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int b = (int)(t / NW), r = (int)(t - (long long)b * NW);
+    const int n = r / W, w = r - n * W;
+    const int N = NW / W;
+    cat[(long long)b * ldc + r] = t1[(long long)cidx[b * N + n] * ldt + w];
+}
+
+__global__ __launch_bounds__(64) void compress_slots_kernel(
+    float* t1, int ldt, const int* __restrict__ cidx, int N, int W, int S,
+    const float* __restrict__ dcat, int ldc, float* __restrict__ zpart, int ldz) {
+    const int b = blockIdx.x;
+    for (int w = threadIdx.x; w < W; w += 64) {
+        float z = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const int c = cidx[b * N + n];
+            const float d = dcat[(long long)b * ldc + n * W + w];
+            if (c < S) {
+                float* p = t1 + (long long)c * ldt + w;
+                *p = d * gi_selu_grad(*p);
+            } else {
+                z += d;
+            }
+        }
+        zpart[(long long)b * ldz + w] = z;
+    }
+}
+
+// out[c] = (sum_r part[r, c]) * selu'(y[c]); 64 columns per block, 16 row groups, fixed tree
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ part, int ldp,
+                                                      int rows, int cols, const float* y,
+                                                      float* out) {
+    __shared__ float red[16][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float acc = 0.f;
+    if (c < cols)
+        for (int r = rg; r < rows; r += 16) acc += part[(long long)r * ldp + c];
+    red[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0 && c < cols) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += red[i][cl];
+        if (y) s *= gi_selu_grad(y[c]);
+        out[c] = s;
+    }
+}
+
+// ---- wgrad slab reduction ----------------------------------------------------------------------
+#define GI_REDUCE_MAX 40
+struct ReduceTable { gi_reduce_desc d[GI_REDUCE_MAX]; };
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceTable tab) {
+    const gi_reduce_desc& d = tab.d[blockIdx.y];
+    const int K1 = d.K + 1;
+    const long long total = (long long)d.N * K1;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * 256) {
+        const int n = (int)(idx / K1), k = (int)(idx - (long long)n * K1);
+        const float* src = d.slabs + (long long)n * d.ld + k;
+        float s = 0.f;
+        for (int i = 0; i < d.n_slabs; ++i) s += src[(long long)i * d.slab_stride];
+        if (k < d.K) d.dW[(long long)n * d.K + k] = s;
+        else if (d.db) d.db[n] = s;
+    }
+}
+
+}  // namespace
+
+// ================================ C ABI ==========================================================
+extern "C" int gi_seg_sum(const float* vals, int ldv, const int* perm, const int* off, int rows,
+                          int cols, float* out, int ldo, int accumulate, void* stream) {
+    if (rows <= 0) return 0;
+    if (!vals || !off || !out || cols <= 0 || (ldv & 3) || (ldo & 3) || ldv < cols || ldo < cols)
+        return GI_EINVAL;
+    if (((uintptr_t)vals & 15) || ((uintptr_t)out & 15)) return GI_EINVAL;
+    const int c4n = (cols + 3) / 4;
+    const long long threads = (long long)rows * c4n;
+    hipLaunchKernelGGL(seg_sum_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, vals, ldv, perm, off, rows, c4n, out, ldo, accumulate);
+    return gi_launch_status();
+}
+
+extern "C" int gi_selu_bwd_rows(const float* dY, int lddy, const int* idx, const float* Y, int ldy,
+                                float* out, int ldo, int rows, int cols, void* stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    if (!dY || !Y || !out) return GI_EINVAL;
+    const long long threads = (long long)rows * cols;
+    hipLaunchKernelGGL(selu_bwd_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, dY, lddy, idx, Y, ldy, out, ldo, rows, cols);
+    return gi_launch_status();
+}
+
+extern "C" int gi_gru_gates_fwd(float* gi, float* gh, int ldg, const float* hx_prev, float* hx_new,
+                                int ldh, const int* seg_off, int rows, int H, int Fn,
+                                void* stream) {
+    if (rows <= 0) return 0;
+    if (!gi || !gh || !hx_prev || !hx_new || !seg_off || ldg < 3 * H || ldh < H + Fn)
+        return GI_EINVAL;
+    const long long threads = (long long)rows * ldh;
+    hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, gi, gh, ldg, hx_prev, hx_new, ldh, seg_off, rows, H);
+    return gi_launch_status();
+}
+
+extern "C" int gi_gru_gates_bwd(float* gi, float* gh, int ldg, const float* hx_prev, int ldh,
+                                const float* dh_new, float* dh_prev, int lddh, const int* seg_off,
+                                int rows, int H, void* stream) {
+    if (rows <= 0) return 0;
+    if (!gi || !gh || !hx_prev || !dh_new || !dh_prev || !seg_off || ldg < 3 * H || lddh < H)
+        return GI_EINVAL;
+    const long long threads = (long long)rows * H;
+    hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, gi, gh, ldg, hx_prev, ldh, dh_new, dh_prev, lddh,
+                       seg_off, rows, H);
+    return gi_launch_status();
+}
+
+extern "C" int gi_gather_readout_fwd(const float* en, const float* emb, int ld, const int* cidx,
+                                     const int* node_mask, int B, int N, int G, float big,
+                                     float* out0, int ld0, float* out1, int ld1, float* out2,
+                                     int ld2, void* stream) {
+    if (B <= 0) return 0;
+    if (!en || !emb || !cidx || !node_mask || N <= 0 || N > GI_MAX_NODES || G <= 0 || ld < G)
+        return GI_EINVAL;
+    hipLaunchKernelGGL(gather_fwd_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, en, emb, ld,
+                       cidx, node_mask, N, G, big, out0, ld0, out1, ld1, out2, ld2);
+    return gi_launch_status();
+}
+
+extern "C" int gi_gather_readout_bwd(float* en, float* emb, int ld, const int* cidx,
+                                     const int* node_mask, int B, int N, int G, int S, float big,
+                                     const float* dg0, int ld0, const float* dg1, int ld1,
+                                     const float* dg2, int ld2, float* zpart, void* stream) {
+    if (B <= 0) return 0;
+    if (!en || !emb || !cidx || !node_mask || !zpart || N <= 0 || N > GI_MAX_NODES || G <= 0)
+        return GI_EINVAL;
+    hipLaunchKernelGGL(gather_bwd_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, en, emb, ld,
+                       cidx, node_mask, N, G, S, big, dg0, ld0, dg1, ld1, dg2, ld2, zpart);
+    return gi_launch_status();
+}
+
+extern "C" int gi_expand_slots(const float* t1, int ldt, const int* cidx, int B, int N, int W,
+                               float* cat, int ldc, void* stream) {
+    if (B <= 0) return 0;
+    if (!t1 || !cidx || !cat || N <= 0 || W <= 0 || ldt < W || ldc < N * W) return GI_EINVAL;
+    const long long total = (long long)B * N * W;
+    hipLaunchKernelGGL(expand_slots_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, t1, ldt, cidx, N * W, W, cat, ldc, total);
+    return gi_launch_status();
+}
+
+extern "C" int gi_compress_slots(float* t1, int ldt, const int* cidx, int B, int N, int W, int S,
+                                 const float* dcat, int ldc, float* zpart, int ldz, void* stream) {
+    if (B <= 0) return 0;
+    if (!t1 || !cidx || !dcat || !zpart || N <= 0 || W <= 0 || ldz < W) return GI_EINVAL;
+    hipLaunchKernelGGL(compress_slots_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, t1, ldt,
+                       cidx, N, W, S, dcat, ldc, zpart, ldz);
+    return gi_launch_status();
+}
+
+extern "C" int gi_colsum(const float* part, int ldp, int rows, int cols, const float* y,
+                         float* out, void* stream) {
+    if (cols <= 0) return 0;
+    if (!part || !out || rows < 0) return GI_EINVAL;
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream,
+                       part, ldp, rows, cols, y, out);
+    return gi_launch_status();
+}
+
+extern "C" int gi_reduce_slabs(const gi_reduce_desc* descs, int n_desc, void* stream) {
+    if (n_desc <= 0) return 0;
+    if (!descs) return GI_EINVAL;
+    for (int base = 0; base < n_desc; base += GI_REDUCE_MAX) {
+        const int n = (n_desc - base < GI_REDUCE_MAX) ? n_desc - base : GI_REDUCE_MAX;
+        ReduceTable tab;
+        for (int i = 0; i < n; ++i) tab.d[i] = descs[base + i];
+        for (int i = n; i < GI_REDUCE_MAX; ++i) tab.d[i] = descs[base];
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, tab);
+        const int rc = gi_launch_status();
+        if (rc) return rc;
+    }
+    return 0;
+}

@@ -1,0 +1,182 @@
+"""
+``gnn.mpnn.GGNN`` — MI355X-native gated-graph neural network with the reference's model-class API.
+
+Boundary kept from the reference: ``GGNN(constants)`` (gnn/mpnn.py:229-282) builds
+the same sub-modules in the same registration order with the same ``state_dict`` keys and the same
+RNG consumption; ``forward(nodes[B,N,Fn], edges[B,N,N,Fe]) -> logits[B, N*A + N*Fe + 1]``
+(gnn/summation_mpnn.py:80-149, gnn/mpnn.py:284-303), differentiable w.r.t. the parameters, usable
+under ``train()/eval()/no_grad()``, ``.to("cuda")``, ``deepcopy`` and ``load_state_dict``.
+
+What differs is everything underneath: the whole forward is ONE call into hand-written HIP
+(``gi_ggnn_forward``) and the whole backward another (``gi_ggnn_backward``), on torch's current
+stream, through the C ABI of ``include/graphinvent_amd.h``.  There is no eager / CPU fallback: a
+missing library or a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import namedtuple
+from typing import List
+
+import torch
+
+try:                                        # imported as graphinvent_amd.gnn.mpnn
+    from .. import lib as _L
+    from .. import ops as _ops
+    from . import modules as _modules
+except ImportError:                         # imported as top-level `gnn.mpnn` (drop-in layout)
+    import os as _os
+    import sys as _sys
+    _root = _os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+    if _root not in _sys.path:
+        _sys.path.append(_root)
+    from graphinvent_amd import lib as _L
+    from graphinvent_amd import ops as _ops
+    from graphinvent_amd.gnn import modules as _modules
+
+
+def _dims_from_constants(c, B: int) -> "_L.GgnnDims":
+    d = _L.GgnnDims()
+    d.B, d.N, d.Fn, d.Fe = B, c.max_n_nodes, c.n_node_features, c.n_edge_features
+    d.H, d.M, d.G = c.hidden_node_features, c.message_size, c.gather_width
+    d.A, d.C, d.passes = c.len_f_add_per_node, c.len_f_conn_per_node, c.message_passes
+    d.enn_depth, d.enn_hidden = c.enn_depth, c.enn_hidden_dim
+    d.att_depth, d.att_hidden = c.gather_att_depth, c.gather_att_hidden_dim
+    d.emb_depth, d.emb_hidden = c.gather_emb_depth, c.gather_emb_hidden_dim
+    d.mlp1_depth, d.mlp1_hidden = c.mlp1_depth, c.mlp1_hidden_dim
+    d.mlp2_depth, d.mlp2_hidden = c.mlp2_depth, c.mlp2_hidden_dim
+    d.big_positive = float(c.big_positive)
+    return d
+
+
+def _ptr_table(tensors) -> "C.Array":
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def ggnn_forward_raw(consts, nodes, edges, params):
+    """graph_compact + the fused forward.  Returns (logits, tape); the tape
+    (dims, CompactGraph, workspace, per-type edge counts) is what backward consumes."""
+    lib = _L.load()
+    nodes, lay, gfix, S, E, Et = _ops.compact_count(nodes, edges)
+    B = nodes.shape[0]
+    dims = _dims_from_constants(consts, B)
+    if lib.gi_ggnn_num_params(C.byref(dims)) != len(params):
+        raise RuntimeError("parameter table does not match the model dimensions")
+    for p in params:
+        if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+            raise RuntimeError("GGNN parameters must be contiguous fp32 CUDA tensors "
+                               "(call model.to('cuda'))")
+    dev = nodes.device
+    n_ws = lib.gi_ggnn_workspace_floats(C.byref(dims), S, E)
+    if n_ws < 0:
+        _L.check(int(n_ws), "gi_ggnn_workspace_floats")
+    ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+    ldhx = lib.gi_ggnn_ldhx(C.byref(dims))
+    hx0 = ws[lib.gi_ggnn_hx0_offset(C.byref(dims), S, E):]
+    graph = _ops.compact_fill(nodes, lay, gfix, S, E, Et, hx0, ldhx, dims.H)
+    apd = dims.N * dims.A + dims.N * dims.C + 1
+    out = torch.empty((B, apd), dtype=torch.float32, device=dev)
+    Et_c = (C.c_int * len(Et))(*Et)
+    _L.check(lib.gi_ggnn_forward(C.byref(dims), _ptr_table(params), gfix.data_ptr(),
+                                 graph.gvar[0].data_ptr(), graph.gvar[2].data_ptr(), S, E, Et_c,
+                                 ws.data_ptr(), out.data_ptr(), apd,
+                                 torch.cuda.current_stream().cuda_stream), "gi_ggnn_forward")
+    return out, (dims, graph, ws, Et)
+
+
+def ggnn_backward_raw(tape, out, d_out, params):
+    """The fused backward; consumes the tape's activations in place.  Returns (grads, gflat):
+    per-parameter gradient views into ONE flat fp32 buffer (state_dict order, 16-byte aligned
+    segments) — the bucket a data-parallel all-reduce operates on."""
+    lib = _L.load()
+    dims, graph, ws, Et = tape
+    d_out = d_out.contiguous().float()
+    dev = out.device
+    Et_c = (C.c_int * len(Et))(*Et)
+    n_slab = lib.gi_ggnn_slab_floats(C.byref(dims), graph.S, graph.E, Et_c)
+    if n_slab < 0:
+        _L.check(int(n_slab), "gi_ggnn_slab_floats")
+    slabs = torch.empty(max(int(n_slab), 4), dtype=torch.float32, device=dev)
+    sizes = [p.numel() for p in params]
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (n + 3) & ~3                       # every gradient 16-byte aligned
+    gflat = torch.empty(total, dtype=torch.float32, device=dev)
+    grads = [gflat[o:o + n].view(p.shape) for o, n, p in zip(offs, sizes, params)]
+    _L.check(lib.gi_ggnn_backward(
+        C.byref(dims), _ptr_table(params), graph.gfix.data_ptr(), graph.gvar[0].data_ptr(),
+        graph.gvar[1].data_ptr(), graph.gvar[3].data_ptr(), graph.S, graph.E, Et_c,
+        ws.data_ptr(), slabs.data_ptr(), out.data_ptr(), out.stride(0), d_out.data_ptr(),
+        d_out.stride(0), _ptr_table(grads), torch.cuda.current_stream().cuda_stream),
+        "gi_ggnn_backward")
+    return grads, gflat
+
+
+class _GGNNFunction(torch.autograd.Function):
+    """forward = gi_compact_* + gi_ggnn_forward; backward = gi_ggnn_backward."""
+
+    @staticmethod
+    def forward(ctx, consts, nodes, edges, *params):
+        out, tape = ggnn_forward_raw(consts, nodes, edges, params)
+        ctx.tape = tape
+        ctx.save_for_backward(out, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        if ctx.tape is None:
+            raise RuntimeError("GGNN backward called twice: the HIP backward consumes the saved "
+                               "activations in place (retain_graph is not supported)")
+        tape, ctx.tape = ctx.tape, None
+        out, *params = ctx.saved_tensors
+        grads, _ = ggnn_backward_raw(tape, out, d_out, params)
+        return (None, None, None, *grads)
+
+
+class GGNN(torch.nn.Module):
+    """The "gated-graph neural network" model (gnn/mpnn.py:229-303) on MI355X HIP kernels."""
+
+    def __init__(self, constants: namedtuple) -> None:
+        super().__init__()
+        c = constants
+        # attributes SummationMPNN.__init__ caches (gnn/summation_mpnn.py:14-22)
+        self.hidden_node_features = c.hidden_node_features
+        self.edge_features = c.n_edge_features
+        self.message_size = c.message_size
+        self.message_passes = c.message_passes
+        self.constants = c
+
+        # registration order of gnn/mpnn.py:238-282 (fixes state_dict order and RNG consumption)
+        self.msg_nns = torch.nn.ModuleList()
+        for _ in range(c.n_edge_features):
+            self.msg_nns.append(_modules.MLP(c.hidden_node_features,
+                                             [c.enn_hidden_dim] * c.enn_depth, c.message_size,
+                                             c.enn_dropout_p))
+        self.gru = torch.nn.GRUCell(input_size=c.message_size, hidden_size=c.hidden_node_features,
+                                    bias=True)
+        self.gather = _modules.GraphGather(
+            node_features=c.n_node_features, hidden_node_features=c.hidden_node_features,
+            out_features=c.gather_width, att_depth=c.gather_att_depth,
+            att_hidden_dim=c.gather_att_hidden_dim, att_dropout_p=c.gather_att_dropout_p,
+            emb_depth=c.gather_emb_depth, emb_hidden_dim=c.gather_emb_hidden_dim,
+            emb_dropout_p=c.gather_emb_dropout_p, big_positive=c.big_positive)
+        self.APDReadout = _modules.GlobalReadout(
+            node_emb_size=c.hidden_node_features, graph_emb_size=c.gather_width,
+            mlp1_hidden_dim=c.mlp1_hidden_dim, mlp1_depth=c.mlp1_depth,
+            mlp1_dropout_p=c.mlp1_dropout_p, mlp2_hidden_dim=c.mlp2_hidden_dim,
+            mlp2_depth=c.mlp2_depth, mlp2_dropout_p=c.mlp2_dropout_p,
+            f_add_elems=c.len_f_add_per_node, f_conn_elems=c.len_f_conn_per_node, f_term_elems=1,
+            max_n_nodes=c.max_n_nodes, device=c.device)
+
+    def _dropout_active(self) -> bool:
+        return self.training and any(m.dropout_p > 0 for m in self.modules()
+                                     if isinstance(m, _modules.MLP))
+
+    def forward(self, nodes: torch.Tensor, edges: torch.Tensor) -> torch.Tensor:
+        if self._dropout_active():
+            raise NotImplementedError(
+                "AlphaDropout with p > 0 in training mode is not implemented in the MI355X HIP "
+                "path (every reference default is p = 0.0, parameters/defaults.py:280-300)")
+        params: List[torch.Tensor] = list(self.parameters())
+        return _GGNNFunction.apply(self.constants, nodes, edges, *params)

@@ -1,0 +1,130 @@
+"""
+ctypes binding of ``libgraphinvent_amd.so`` (the C ABI declared in ``include/graphinvent_amd.h``).
+
+The shared object is built in-tree by ``graphinvent_amd/csrc/Makefile`` (``hipcc
+--offload-arch=gfx950``) — see ``__graft_entry__.build()``.  There is deliberately NO fallback: if
+the library is missing, fails to load, or lacks a symbol, importing the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgraphinvent_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+GI_MAX_GROUPS = 8
+GI_MAX_NODES = 128
+EPI_BIAS, EPI_SELU, EPI_DSELU, EPI_ACCUM, GEMM_SPLITK = 1, 2, 4, 8, 16
+
+vp = C.c_void_p
+ci = C.c_int
+cll = C.c_longlong
+
+
+class CompactLayout(C.Structure):
+    _fields_ = [(n, ci) for n in ("total_ints", "counts", "type_off", "cidx", "node_mask",
+                                  "slot_of", "seg_off", "src_off", "scratch")]
+
+
+class GemmParams(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("bias", vp), ("act", vp),
+                ("a_idx", vp), ("b_idx", vp), ("grp_off", vp),
+                ("M", ci), ("N", ci), ("K", ci),
+                ("lda", ci), ("ldb", ci), ("ldc", ci), ("ldact", ci),
+                ("flags", ci), ("a_major", ci), ("b_major", ci), ("tm", ci), ("tn", ci),
+                ("ngroups", ci), ("nsplit", ci), ("max_group_rows", ci), ("ones_col", ci),
+                ("c_split_stride", cll),
+                ("Bg", vp * GI_MAX_GROUPS), ("biasg", vp * GI_MAX_GROUPS),
+                ("Cg", vp * GI_MAX_GROUPS)]
+
+
+class ReduceDesc(C.Structure):
+    _fields_ = [("slabs", vp), ("dW", vp), ("db", vp), ("slab_stride", cll),
+                ("n_slabs", ci), ("N", ci), ("K", ci), ("ld", ci)]
+
+
+class GgnnDims(C.Structure):
+    _fields_ = [(n, ci) for n in ("B", "N", "Fn", "Fe", "H", "M", "G", "A", "C", "passes",
+                                  "enn_depth", "enn_hidden", "att_depth", "att_hidden",
+                                  "emb_depth", "emb_hidden", "mlp1_depth", "mlp1_hidden",
+                                  "mlp2_depth", "mlp2_hidden")] + [("big_positive", C.c_float)]
+
+
+# name -> (restype, argtypes); every symbol include/graphinvent_amd.h declares
+SIGNATURES = {
+    "gi_abi_version": (ci, []),
+    "gi_compact_layout": (ci, [ci, ci, ci, C.POINTER(CompactLayout)]),
+    "gi_compact_count": (ci, [vp, vp, ci, ci, ci, ci, vp, vp]),
+    "gi_compact_fill": (ci, [vp, ci, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp]),
+    "gi_gemm": (ci, [C.POINTER(GemmParams), vp]),
+    "gi_seg_sum": (ci, [vp, ci, vp, vp, ci, ci, vp, ci, ci, vp]),
+    "gi_selu_bwd_rows": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, vp]),
+    "gi_gru_gates_fwd": (ci, [vp, vp, ci, vp, vp, ci, vp, ci, ci, ci, vp]),
+    "gi_gru_gates_bwd": (ci, [vp, vp, ci, vp, ci, vp, vp, ci, vp, ci, ci, vp]),
+    "gi_gather_readout_fwd": (ci, [vp, vp, ci, vp, vp, ci, ci, ci, C.c_float,
+                                   vp, ci, vp, ci, vp, ci, vp]),
+    "gi_gather_readout_bwd": (ci, [vp, vp, ci, vp, vp, ci, ci, ci, ci, C.c_float,
+                                   vp, ci, vp, ci, vp, ci, vp, vp]),
+    "gi_expand_slots": (ci, [vp, ci, vp, ci, ci, ci, vp, ci, vp]),
+    "gi_compress_slots": (ci, [vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, ci, vp]),
+    "gi_colsum": (ci, [vp, ci, ci, ci, vp, vp, vp]),
+    "gi_reduce_slabs": (ci, [C.POINTER(ReduceDesc), ci, vp]),
+    "gi_ggnn_num_params": (ci, [C.POINTER(GgnnDims)]),
+    "gi_ggnn_workspace_floats": (cll, [C.POINTER(GgnnDims), ci, ci]),
+    "gi_ggnn_slab_floats": (cll, [C.POINTER(GgnnDims), ci, ci, C.POINTER(ci)]),
+    "gi_ggnn_hx0_offset": (cll, [C.POINTER(GgnnDims), ci, ci]),
+    "gi_ggnn_ldhx": (ci, [C.POINTER(GgnnDims)]),
+    "gi_ggnn_ws_query": (ci, [C.POINTER(GgnnDims), ci, ci, C.c_char_p, ci, ci,
+                              C.POINTER(cll), C.POINTER(ci)]),
+    "gi_ggnn_forward": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), vp, vp, vp, ci, ci,
+                             C.POINTER(ci), vp, vp, ci, vp]),
+    "gi_ggnn_backward": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), vp, vp, vp, vp, ci, ci,
+                              C.POINTER(ci), vp, vp, vp, ci, vp, ci, C.POINTER(vp), vp]),
+}
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into the in-tree shared object."""
+    res = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+        print(res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError("building libgraphinvent_amd.so failed (hipcc --offload-arch=gfx950)")
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raises (never falls back) when it is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the MI355X HIP extension is required (there is no CPU or "
+            "eager fallback). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C {CSRC}`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)             # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gi_abi_version() != 1:
+        raise RuntimeError("libgraphinvent_amd.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc == 0:
+        return
+    if rc < 0:
+        kind = {-1: "GI_EINVAL (bad argument)", -2: "GI_ELIMIT (compiled-in limit exceeded)"}.get(
+            rc, f"error {rc}")
+        raise RuntimeError(f"graphinvent_amd {what}: {kind}")
+    raise RuntimeError(f"graphinvent_amd {what}: HIP error {rc}")

@@ -1,0 +1,177 @@
+"""
+Thin torch-tensor wrappers over the C ABI (``graphinvent_amd/lib.py``).  Every function enqueues
+on torch's current HIP stream and takes/returns CUDA tensors; nothing here computes on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+
+from . import lib as L
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA (ROCm) tensor: the MI355X HIP path has no CPU "
+                           "fallback")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def r4(x: int) -> int:
+    return (x + 3) & ~3
+
+
+# ------------------------------------------------------------------------------------------------
+# K1 graph_compact
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class CompactGraph:
+    B: int
+    N: int
+    Fn: int
+    Fe: int
+    S: int                      # active node slots (compact rows 0..S-1; row S = zero row)
+    E: int                      # directed edges
+    Et: Sequence[int]           # edges per bond type
+    layout: L.CompactLayout
+    gfix: torch.Tensor          # int32, fixed-size part (see include/graphinvent_amd.h)
+    gvar: torch.Tensor          # int32 [4, E4]: e_src, e_dst, in_perm, out_perm
+
+    def view(self, name: str, n: int) -> torch.Tensor:
+        o = getattr(self.layout, name)
+        return self.gfix[o:o + n]
+
+    @property
+    def e_src(self): return self.gvar[0, :self.E]
+    @property
+    def e_dst(self): return self.gvar[1, :self.E]
+    @property
+    def in_perm(self): return self.gvar[2, :self.E]
+    @property
+    def out_perm(self): return self.gvar[3, :self.E]
+    @property
+    def cidx(self): return self.view("cidx", self.B * self.N)
+    @property
+    def node_mask(self): return self.view("node_mask", self.B * self.N)
+    @property
+    def slot_of(self): return self.view("slot_of", self.S)
+    @property
+    def seg_off(self): return self.view("seg_off", self.S + 2)
+    @property
+    def src_off(self): return self.view("src_off", self.S + 2)
+    @property
+    def type_off(self): return self.view("type_off", self.Fe + 1)
+
+
+def compact_count(nodes: torch.Tensor, edges: torch.Tensor):
+    """Phase 1; returns (layout, gfix, S, E, Et).  One host read-back of 16 ints (the only
+    synchronisation point of a forward pass)."""
+    lib = L.load()
+    nodes = _need_cuda_f32(nodes, "nodes")
+    edges = _need_cuda_f32(edges, "edges")
+    B, N, Fn = nodes.shape
+    Fe = edges.shape[3]
+    if edges.shape[:3] != (B, N, N):
+        raise ValueError(f"edges shape {tuple(edges.shape)} does not match nodes {tuple(nodes.shape)}")
+    lay = L.CompactLayout()
+    L.check(lib.gi_compact_layout(B, N, Fe, C.byref(lay)), "gi_compact_layout")
+    gfix = torch.empty(lay.total_ints, dtype=torch.int32, device=nodes.device)
+    L.check(lib.gi_compact_count(nodes.data_ptr(), edges.data_ptr(), B, N, Fn, Fe,
+                                 gfix.data_ptr(), _stream()), "gi_compact_count")
+    counts = gfix[lay.counts:lay.counts + 16].cpu().tolist()
+    S, E, err = counts[0], counts[1], counts[2]
+    if err:
+        raise ValueError("edges tensor violates the preprocessed-HDF contract: every bonded pair "
+                         "must carry exactly one one-hot bond type (DataProcesser.py / "
+                         "MolecularGraph.py edge features)")
+    return nodes, lay, gfix, S, E, counts[4:4 + Fe]
+
+
+def compact_fill(nodes, lay, gfix, S, E, Et, hx0: torch.Tensor, ldhx: int, H: int) -> CompactGraph:
+    lib = L.load()
+    B, N, Fn = nodes.shape
+    Fe = len(Et)
+    E4 = max(r4(E), 4)
+    gvar = torch.empty((4, E4), dtype=torch.int32, device=nodes.device)
+    L.check(lib.gi_compact_fill(nodes.data_ptr(), B, N, Fn, Fe, gfix.data_ptr(), S, E,
+                                gvar[0].data_ptr(), gvar[1].data_ptr(), gvar[2].data_ptr(),
+                                gvar[3].data_ptr(), hx0.data_ptr(), ldhx, H, _stream()),
+            "gi_compact_fill")
+    return CompactGraph(B, N, Fn, Fe, S, E, list(Et), lay, gfix, gvar)
+
+
+def compact(nodes: torch.Tensor, edges: torch.Tensor, H: int):
+    """Both phases; returns (CompactGraph, hx0[S+1, ldhx])."""
+    nodes, lay, gfix, S, E, Et = compact_count(nodes, edges)
+    ldhx = r4(H + nodes.shape[2])
+    hx0 = torch.empty((S + 1, ldhx), dtype=torch.float32, device=nodes.device)
+    g = compact_fill(nodes, lay, gfix, S, E, Et, hx0, ldhx, H)
+    return g, hx0
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM family
+# ------------------------------------------------------------------------------------------------
+def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, flags=0, bias=None, act=None, ldact=0,
+         a_idx=None, b_idx=None, a_major=False, b_major=False, tm=1, tn=1, grp_off=None,
+         ngroups=0, max_group_rows=0, Bg=(), biasg=(), Cg=(), nsplit=1, c_split_stride=0,
+         ones_col=-1):
+    lib = L.load()
+    p = L.GemmParams()
+    p.A, p.B, p.C = _ptr(A), _ptr(B), _ptr(C_out)
+    p.bias, p.act, p.a_idx, p.b_idx, p.grp_off = (_ptr(bias), _ptr(act), _ptr(a_idx), _ptr(b_idx),
+                                                  _ptr(grp_off))
+    p.M, p.N, p.K, p.lda, p.ldb, p.ldc, p.ldact = M, N, K, lda, ldb, ldc, ldact
+    p.flags, p.a_major, p.b_major, p.tm, p.tn = flags, int(a_major), int(b_major), tm, tn
+    p.ngroups, p.nsplit, p.max_group_rows, p.ones_col = ngroups, nsplit, max_group_rows, ones_col
+    p.c_split_stride = c_split_stride
+    for i, t in enumerate(Bg):
+        p.Bg[i] = _ptr(t)
+    for i, t in enumerate(biasg):
+        p.biasg[i] = _ptr(t)
+    for i, t in enumerate(Cg):
+        p.Cg[i] = _ptr(t)
+    L.check(lib.gi_gemm(C.byref(p), _stream()), "gi_gemm")
+
+
+def seg_sum(vals, perm, off, rows, cols, out, accumulate=False):
+    L.check(L.load().gi_seg_sum(vals.data_ptr(), vals.stride(0), _ptr(perm), off.data_ptr(), rows,
+                                cols, out.data_ptr(), out.stride(0), int(accumulate), _stream()),
+            "gi_seg_sum")
+
+
+def selu_bwd_rows(dY, idx, Y, out, rows, cols):
+    L.check(L.load().gi_selu_bwd_rows(dY.data_ptr(), dY.stride(0), _ptr(idx), Y.data_ptr(),
+                                      Y.stride(0), out.data_ptr(), out.stride(0), rows, cols,
+                                      _stream()), "gi_selu_bwd_rows")
+
+
+def reduce_slabs(items):
+    """items: iterable of (slabs, dW, db, slab_stride, n_slabs, N, K, ld)."""
+    items = list(items)
+    arr = (L.ReduceDesc * len(items))()
+    for d, (slabs, dW, db, stride, n, N, K, ld) in zip(arr, items):
+        d.slabs, d.dW, d.db = slabs.data_ptr(), dW.data_ptr(), _ptr(db)
+        d.slab_stride, d.n_slabs, d.N, d.K, d.ld = stride, n, N, K, ld
+    L.check(L.load().gi_reduce_slabs(arr, len(items), _stream()), "gi_reduce_slabs")
+
+
+def ws_view(ws: torch.Tensor, dims, S: int, E: int, name: str, rows: int, i: int = 0, j: int = 0):
+    """Test/debug: a [rows, ld] view of a named workspace buffer (gi_ggnn_ws_query)."""
+    off, ld = C.c_longlong(), C.c_int()
+    L.check(L.load().gi_ggnn_ws_query(C.byref(dims), S, E, name.encode(), i, j, C.byref(off),
+                                      C.byref(ld)), f"gi_ggnn_ws_query({name})")
+    return ws[off.value:off.value + rows * ld.value].view(rows, ld.value)

@@ -1,0 +1,195 @@
+/*
+ * graphinvent_amd.h — C ABI of libgraphinvent_amd.so (gfx950 / MI355X only).
+ *
+ * Drop-in boundary.  The reference has NO native layer: its GGNN hot path
+ * (graphinvent/gnn/summation_mpnn.py:80-149, gnn/mpnn.py:229-303, gnn/modules.py:12-52,111-281) is
+ * stock PyTorch called as `model(nodes, edges)` from Workflow.py:785,826, GraphGenerator.py:121,
+ * GraphGeneratorRL.py:131-132 and Analyzer.py:759.  The Python boundary therefore stays the
+ * reference's own — `gnn.mpnn.GGNN(constants).forward(nodes, edges)` — and this header is what
+ * that class binds underneath (ctypes, graphinvent_amd/lib.py).  Each entry point names the
+ * reference statement(s) it replaces.
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory owned by the caller (torch tensors passed by data_ptr());
+ *     nothing here allocates or frees; workspaces are caller provided;
+ *   - matrices are fp32 row-major with an explicit leading dimension in floats; index arrays
+ *     are int32;
+ *   - `stream` is a hipStream_t; all work is enqueued asynchronously on it;
+ *   - return value: 0 = success, >0 = hipError_t from a launch, <0 = argument error (GI_E*);
+ *   - no exceptions cross the ABI, no global mutable state, one process per GPU.
+ */
+#ifndef GRAPHINVENT_AMD_H
+#define GRAPHINVENT_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GI_ABI_VERSION 1
+#define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
+#define GI_MAX_NODES 128      /* max max_n_nodes */
+
+#define GI_EINVAL   (-1)      /* bad dims / null pointer */
+#define GI_ELIMIT   (-2)      /* exceeds a compiled-in limit */
+
+int gi_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1 graph_compact — replaces the dense->sparse bookkeeping of gnn/summation_mpnn.py:100-124
+ * (`edges.sum(3)`, two `nonzero`s, the [V,E] 0/1 summation matrix, `edges[eb,ei,ej,:]`, the
+ * zero-padded `hidden_nodes`) and `node_mask` (:146).
+ *
+ * Layout of the fixed-size int32 index buffer `gfix` (offsets in ints, from gi_compact_layout):
+ *   counts[16]   [0]=S active node slots, [1]=E directed edges, [2]=error flag (an edge whose
+ *                feature vector is not one-hot), [4+t]=edges of bond type t
+ *   type_off[GI_MAX_GROUPS+1], cidx[B*N] (slot -> compact row, S for inactive slots),
+ *   node_mask[B*N] (1 if the slot has >=1 incoming edge), slot_of[B*N], seg_off[B*N+2] (CSR by
+ *   destination over compact rows, row S empty), src_off[B*N+2] (CSR by source), then scratch.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gi_compact_layout_t {
+    int total_ints;
+    int counts, type_off, cidx, node_mask, slot_of, seg_off, src_off, scratch;
+} gi_compact_layout_t;
+
+int gi_compact_layout(int B, int N, int Fe, gi_compact_layout_t* out);
+
+/* phase 1: per-graph counting + global scans; fills everything in gfix. */
+int gi_compact_count(const float* nodes, const float* edges, int B, int N, int Fn, int Fe,
+                     int* gfix, void* stream);
+/* phase 2 (after the host has read S and E from counts): edge arrays in bond-type-major order,
+ * the two CSR permutations, and the initial node rows hx0[S+1, ldhx] = [x | 0.. | x] with the
+ * input features in columns [0,Fn) and again in [H, H+Fn) (row S = 0). */
+int gi_compact_fill(const float* nodes, int B, int N, int Fn, int Fe, const int* gfix,
+                    int S, int E, int* e_src, int* e_dst, int* in_perm, int* out_perm,
+                    float* hx0, int ldhx, int H, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32) with fused prologue/epilogue.  One kernel
+ * family serves
+ *   forward  Y = selu(X[a_idx] W^T + b)      torch.nn.Linear + SELU, gnn/modules.py:130-142,166-170
+ *   dgrad    dX = (dZ W) * selu'(Xact)        autograd of the same
+ *   wgrad    [dW | db] = dZ^T [X[b_idx] | 1]  autograd of the same (split over rows, slabs)
+ * grouped per bond type (gnn/mpnn.py:284-294 evaluates all Fe MLPs on all edges and masks; here
+ * every edge row only meets its own type's weights).
+ * ------------------------------------------------------------------------------------------ */
+#define GI_EPI_BIAS    1   /* v += bias[col]                                 */
+#define GI_EPI_SELU    2   /* v = selu(v)                                    */
+#define GI_EPI_DSELU   4   /* v *= selu'(act[row,col]) (act = selu output)   */
+#define GI_EPI_ACCUM   8   /* v += C[row,col]                                */
+#define GI_GEMM_SPLITK 16  /* reduction range partitioned by groups/splits; C is a slab set */
+
+typedef struct gi_gemm_params {
+    const float* A; const float* B; float* C;
+    const float* bias; const float* act;
+    const int* a_idx; const int* b_idx;   /* gather on the STORED rows of A / B, or NULL */
+    const int* grp_off;                   /* device [ngroups+1] or NULL */
+    int M, N, K;                          /* output M x N, reduction length K */
+    int lda, ldb, ldc, ldact;
+    int flags;                            /* GI_EPI_* | GI_GEMM_SPLITK */
+    int a_major, b_major;                 /* operand stored [reduction][rows] instead of [rows][reduction] */
+    int tm, tn;                           /* block tile = 64*tm x 64*tn, (tm,tn) in {(1,1),(1,2),(2,2)} */
+    int ngroups, nsplit;                  /* ngroups 0 = ungrouped; nsplit >= 1 */
+    int max_group_rows;                   /* host upper bound of rows per group (grid sizing) */
+    int ones_col;                         /* B stored column that reads as 1.0 (bias-grad column), -1 = none */
+    long long c_split_stride;             /* floats between split slabs */
+    const float* Bg[GI_MAX_GROUPS]; const float* biasg[GI_MAX_GROUPS]; float* Cg[GI_MAX_GROUPS];
+} gi_gemm_params;
+
+int gi_gemm(const gi_gemm_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Graph / pointwise kernels
+ * ------------------------------------------------------------------------------------------ */
+/* K4 seg_sum — replaces `torch.matmul(message_summation_matrix, message_terms)`
+ * (gnn/summation_mpnn.py:141) and, in backward, the scatter of d(gathered rows):
+ *   out[c, 0:cols] (+)= sum_{k in [off[c], off[c+1])} vals[perm[k], 0:cols],  c < rows */
+int gi_seg_sum(const float* vals, int ldv, const int* perm, const int* off, int rows, int cols,
+               float* out, int ldo, int accumulate, void* stream);
+
+/* out[r, c] = dY[idx ? idx[r] : r, c] * selu'(Y[r, c])  (may run in place on Y) */
+int gi_selu_bwd_rows(const float* dY, int lddy, const int* idx, const float* Y, int ldy,
+                     float* out, int ldo, int rows, int cols, void* stream);
+
+/* GRU gates — torch.nn.GRUCell as used at gnn/mpnn.py:249-253,296-297, applied only to rows
+ * with >=1 incoming edge (gnn/summation_mpnn.py:107,124,143-144 update only those nodes).
+ * In: gi,gh [rows,3H] (+bias already added), hx_prev [rows, ldh]; out: hx_new (cols [0,H) and
+ * the feature tail [H,H+Fn) copied); gi is overwritten with (r|z|n), gh keeps W_hn h + b_hn. */
+int gi_gru_gates_fwd(float* gi, float* gh, int ldg, const float* hx_prev, float* hx_new, int ldh,
+                     const int* seg_off, int rows, int H, int Fn, void* stream);
+/* In: dh_new [rows, lddh]; gi=(r|z|n), gh=(..|..|hn) from forward are overwritten with d gi, d gh;
+ * dh_prev = direct part of the gradient to h_prev. */
+int gi_gru_gates_bwd(float* gi, float* gh, int ldg, const float* hx_prev, int ldh,
+                     const float* dh_new, float* dh_prev, int lddh, const int* seg_off,
+                     int rows, int H, void* stream);
+
+/* K7 gather readout — gnn/modules.py:44-52: g[b,:] = sum_n softmax_n(en[cidx[b,n]] - big*[mask==0]) * emb[cidx[b,n]],
+ * written to up to three destinations (tier-2 concat inputs). */
+int gi_gather_readout_fwd(const float* en, const float* emb, int ld, const int* cidx,
+                          const int* node_mask, int B, int N, int G, float big,
+                          float* out0, int ld0, float* out1, int ld1, float* out2, int ld2,
+                          void* stream);
+/* backward: dg = dg0+dg1+dg2 per graph; writes dZ of the last att/emb layers IN PLACE over
+ * en/emb rows < S, and per-graph partial sums for the zero row into zpart[B, 2*G]. */
+int gi_gather_readout_bwd(float* en, float* emb, int ld, const int* cidx, const int* node_mask,
+                          int B, int N, int G, int S, float big,
+                          const float* dg0, int ld0, const float* dg1, int ld1,
+                          const float* dg2, int ld2, float* zpart, void* stream);
+
+/* tier-1 -> tier-2 glue (gnn/modules.py:256-262 `view` + `cat`):
+ *   cat[b, n*W + w] = t1[cidx[b,n], w] */
+int gi_expand_slots(const float* t1, int ldt, const int* cidx, int B, int N, int W,
+                    float* cat, int ldc, void* stream);
+/* backward: t1 rows < S are overwritten in place with dcat * selu'(t1); inactive slots are
+ * summed per graph into zpart[B, W] (raw, no selu'). */
+int gi_compress_slots(float* t1, int ldt, const int* cidx, int B, int N, int W, int S,
+                      const float* dcat, int ldc, float* zpart, int ldz, void* stream);
+/* out[c] = (sum_b part[b, c]) * (y ? selu'(y[c]) : 1), deterministic */
+int gi_colsum(const float* part, int ldp, int rows, int cols, const float* y, float* out,
+              void* stream);
+
+/* sums wgrad slabs into the parameter gradients: for each descriptor,
+ *   dW[n,k] = sum_s slab[s][n*ld + k] (k < K),  db[n] = sum_s slab[s][n*ld + K] */
+typedef struct gi_reduce_desc {
+    const float* slabs; float* dW; float* db;
+    long long slab_stride; int n_slabs, N, K, ld;
+} gi_reduce_desc;
+int gi_reduce_slabs(const gi_reduce_desc* descs, int n_desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-model entry points: one call enqueues the complete GGNN forward (or backward) —
+ * `SummationMPNN.forward` message passes + `GGNN.readout` (gnn/summation_mpnn.py:128-149,
+ * gnn/mpnn.py:284-303).  Parameters are passed as a pointer table in state_dict order.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gi_ggnn_dims {
+    int B, N, Fn, Fe, H, M, G, A, C, passes;
+    int enn_depth, enn_hidden, att_depth, att_hidden, emb_depth, emb_hidden;
+    int mlp1_depth, mlp1_hidden, mlp2_depth, mlp2_hidden;
+    float big_positive;
+} gi_ggnn_dims;
+
+int gi_ggnn_num_params(const gi_ggnn_dims* d);
+long long gi_ggnn_workspace_floats(const gi_ggnn_dims* d, int S, int E);
+long long gi_ggnn_slab_floats(const gi_ggnn_dims* d, int S, int E, const int* Et);
+/* ws must hold hx0 (from gi_compact_fill) at offset gi_ggnn_hx0_offset(); forward keeps every
+ * activation in ws for backward. */
+long long gi_ggnn_hx0_offset(const gi_ggnn_dims* d, int S, int E);
+int gi_ggnn_ldhx(const gi_ggnn_dims* d);
+/* test/debug hook: offset (floats) and leading dimension of a named workspace buffer
+ * ("hx" i=pass, "eact" i=pass j=layer, "m","agg","gi","gh" i=pass, "att_act" j=layer, "en", ...) */
+int gi_ggnn_ws_query(const gi_ggnn_dims* d, int S, int E, const char* name, int i, int j,
+                     long long* off, int* ld);
+int gi_ggnn_forward(const gi_ggnn_dims* d, const float* const* params, const int* gfix,
+                    const int* e_src, const int* in_perm, int S, int E, const int* Et,
+                    float* ws, float* out, int ldout, void* stream);
+/* consumes (overwrites) the activations in ws; y_out = the logits forward returned; grads[i]
+ * receives the gradient of params[i]; slabs = gi_ggnn_slab_floats() floats of scratch.
+ * Et = HOST array of per-bond-type edge counts (counts[4..4+Fe) read back by the caller). */
+int gi_ggnn_backward(const gi_ggnn_dims* d, const float* const* params, const int* gfix,
+                     const int* e_src, const int* e_dst, const int* out_perm, int S, int E,
+                     const int* Et, float* ws, float* slabs, const float* y_out, int ldout,
+                     const float* d_out, int lddout, float* const* grads, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,206 @@
+"""-m gpu: every building-block kernel, called through the C ABI, against its CPU reference
+(tests/ref_dataflow.py).  Integer work is compared bit-exactly; fp32 GEMMs within 2e-5 relative of
+an fp64 CPU product (exact-fp32 MFMA = fmaf chain, so only the summation order differs)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from graphinvent_amd import lib as L
+from graphinvent_amd import ops, synthetic
+from tests import ref_dataflow as D
+from tests.golden.spec import tiny_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+# ------------------------------------------------------------------------------------------------
+def _compact_case(n8, e8, H=16):
+    ref = D.compact(n8, e8)
+    g, hx0 = ops.compact(torch.from_numpy(n8).float().to(DEV), torch.from_numpy(e8).float().to(DEV), H)
+    assert (g.S, g.E) == (ref["S"], ref["E"])
+    assert list(g.Et) == np.diff(ref["type_off"]).tolist()
+    for name in ("cidx", "slot_of", "e_src", "e_dst", "in_perm", "seg_off", "out_perm", "src_off",
+                 "type_off"):
+        got = getattr(g, name).cpu().numpy()
+        assert np.array_equal(got, ref[name]), name
+    assert np.array_equal(g.node_mask.cpu().numpy(), ref["node_mask"].astype(np.int32))
+    B, N, Fn = n8.shape
+    x = np.zeros((g.S + 1, hx0.shape[1]), dtype=np.float32)
+    rows = n8.reshape(B * N, Fn)[ref["slot_of"]].astype(np.float32)
+    x[:g.S, :Fn] = rows
+    x[:g.S, H:H + Fn] = rows
+    assert np.array_equal(hx0.cpu().numpy(), x)
+
+
+def test_compact_tiny_edge_cases():
+    n8, e8, _ = tiny_inputs()
+    _compact_case(n8, e8)
+    n8[4] = 0; e8[4] = 0; n8[4, 0, 0] = 1; e8[4, 0, 5, 1] = 1          # asymmetric, inactive neighbour
+    _compact_case(n8, e8)
+
+
+def test_compact_no_edges_at_all():
+    n8, e8, _ = tiny_inputs()
+    e8[:] = 0
+    _compact_case(n8, e8)
+
+
+def test_compact_fixture_and_shapes(golden_dir):
+    d = np.load(os.path.join(golden_dir, "gdb13_1K-debug_train.npz"))
+    _compact_case(d["nodes"], d["edges"], H=100)
+    for shape, B in (("zinc", 300), ("chembl", 64)):
+        n8, e8, _ = synthetic.make_batch(B, **synthetic.SHAPES[shape], seed=5)
+        _compact_case(n8, e8, H=100)
+
+
+def test_compact_rejects_non_onehot_edges():
+    n8, e8, _ = tiny_inputs()
+    e8[5, 0, 1, :] = [1, 1, 0]
+    with pytest.raises(ValueError):
+        ops.compact(torch.from_numpy(n8).float().to(DEV), torch.from_numpy(e8).float().to(DEV), 16)
+
+
+# ------------------------------------------------------------------------------------------------
+TILES = [(1, 1), (1, 2), (2, 2)]
+
+
+@pytest.mark.parametrize("tm,tn", TILES)
+@pytest.mark.parametrize("M,N,K", [(1000, 250, 100), (333, 500, 685), (130, 45, 500), (64, 1, 500),
+                                   (300, 128, 136), (5, 3, 7)])
+def test_gemm_forward_bias_selu(M, N, K, tm, tn):
+    g = torch.Generator().manual_seed(M + N + K)
+    lda = ops.r4(K) + 4
+    X = torch.randn(M, lda, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ldc = ops.r4(N) + 8
+    Y = torch.full((M, ldc), 7.0, device=DEV)
+    ops.gemm(X.to(DEV), W.to(DEV), Y, M, N, K, lda, K, ldc, flags=L.EPI_BIAS | L.EPI_SELU,
+             bias=b.to(DEV), tm=tm, tn=tn)
+    ref = D.selu(X[:, :K].double() @ W.double().t() + b.double())
+    assert rel(Y[:, :N], ref) < 2e-5
+    assert bool((Y[:, N:] == 7.0).all())                # nothing written outside [M, N]
+
+
+def test_gemm_forward_gather_and_groups():
+    g = torch.Generator().manual_seed(1)
+    R, K, N, E = 200, 100, 250, 777
+    h = torch.randn(R, 104, generator=g)
+    idx = torch.randint(0, R, (E,), generator=g, dtype=torch.int32)
+    off = torch.tensor([0, 600, 600, 777], dtype=torch.int32)          # middle group empty
+    Ws = [torch.randn(N, K, generator=g) / 10 for _ in range(3)]
+    bs = [torch.randn(N, generator=g) for _ in range(3)]
+    Y = torch.zeros(E, 252, device=DEV)
+    ops.gemm(h.to(DEV), None, Y, E, N, K, 104, K, 252, flags=L.EPI_BIAS | L.EPI_SELU,
+             a_idx=idx.to(DEV), tm=1, tn=2, grp_off=off.to(DEV), ngroups=3, max_group_rows=600,
+             Bg=[w.to(DEV) for w in Ws], biasg=[b.to(DEV) for b in bs])
+    ref = torch.zeros(E, N, dtype=torch.float64)
+    for t in range(3):
+        lo, hi = int(off[t]), int(off[t + 1])
+        ref[lo:hi] = D.selu(h[idx[lo:hi].long(), :K].double() @ Ws[t].double().t() + bs[t].double())
+    assert rel(Y[:, :N], ref) < 2e-5
+
+
+@pytest.mark.parametrize("tm,tn", TILES)
+def test_gemm_dgrad_dselu_inplace_and_accumulate(tm, tn):
+    g = torch.Generator().manual_seed(2)
+    R, n_out, n_in = 517, 250, 500
+    dZ = torch.randn(R, 252, generator=g)
+    W = torch.randn(n_out, n_in, generator=g) / 16
+    act = D.selu(torch.randn(R, n_in, generator=g))
+    buf = act.clone().to(DEV)                                           # in place: C == act
+    ops.gemm(dZ.to(DEV), W.to(DEV), buf, R, n_in, n_out, 252, n_in, n_in, flags=L.EPI_DSELU,
+             act=buf, ldact=n_in, b_major=True, tm=tm, tn=tn)
+    ref = (dZ[:, :n_out].double() @ W.double()) * D.selu_grad_from_out(act.double())
+    assert rel(buf, ref) < 2e-5
+    acc = torch.ones(R, 104, device=DEV)                                 # first 100 columns only, +=
+    ops.gemm(dZ.to(DEV), W.to(DEV), acc, R, 100, n_out, 252, n_in, 104, flags=L.EPI_ACCUM,
+             b_major=True, tm=tm, tn=tn)
+    ref2 = 1.0 + dZ[:, :n_out].double() @ W.double()[:, :100]
+    assert rel(acc[:, :100], ref2) < 2e-5
+    assert bool((acc[:, 100:] == 1.0).all())
+
+
+@pytest.mark.parametrize("tn", [1, 2])
+@pytest.mark.parametrize("R,n_out,n_in,nsplit", [(1000, 250, 100, 4), (999, 45, 500, 7),
+                                                 (70, 500, 128, 1), (33, 1, 500, 3)])
+def test_gemm_wgrad_slabs_and_reduce(R, n_out, n_in, nsplit, tn):
+    g = torch.Generator().manual_seed(R)
+    dZ = torch.randn(R, ops.r4(n_out), generator=g)
+    X = torch.randn(R, ops.r4(n_in) + 4, generator=g)
+    ld = ops.r4(n_in + 1)
+    stride = ops.r4(n_out * ld)
+    slabs = torch.full((nsplit * stride,), float("nan"), device=DEV)
+    ops.gemm(dZ.to(DEV), X.to(DEV), slabs, n_out, n_in + 1, R, dZ.shape[1], X.shape[1], ld,
+             flags=L.GEMM_SPLITK, a_major=True, b_major=True, tm=1, tn=tn, nsplit=nsplit,
+             c_split_stride=stride, ones_col=n_in)
+    dW = torch.empty(n_out, n_in, device=DEV)
+    db = torch.empty(n_out, device=DEV)
+    ops.reduce_slabs([(slabs, dW, db, stride, nsplit, n_out, n_in, ld)])
+    assert rel(dW, dZ[:, :n_out].double().t() @ X[:, :n_in].double()) < 2e-5
+    assert rel(db, dZ[:, :n_out].double().sum(0)) < 2e-5
+
+
+def test_gemm_wgrad_grouped_gather():
+    g = torch.Generator().manual_seed(3)
+    Rn, E, n_out, n_in, nsplit = 150, 901, 250, 100, 3
+    h = torch.randn(Rn, 104, generator=g)
+    idx = torch.randint(0, Rn, (E,), generator=g, dtype=torch.int32)
+    dZ = torch.randn(E, 252, generator=g)
+    off = torch.tensor([0, 700, 890, 890, 901], dtype=torch.int32)       # 4 groups, one empty
+    ld = ops.r4(n_in + 1)
+    stride = ops.r4(n_out * ld)
+    slabs = [torch.full((nsplit * stride,), float("nan"), device=DEV) for _ in range(4)]
+    ops.gemm(dZ.to(DEV), h.to(DEV), None, n_out, n_in + 1, E, 252, 104, ld, flags=L.GEMM_SPLITK,
+             a_major=True, b_major=True, b_idx=idx.to(DEV), tm=1, tn=2, nsplit=nsplit,
+             c_split_stride=stride, ones_col=n_in, grp_off=off.to(DEV), ngroups=4, Cg=slabs)
+    for t in range(4):
+        lo, hi = int(off[t]), int(off[t + 1])
+        dW = torch.empty(n_out, n_in, device=DEV)
+        db = torch.empty(n_out, device=DEV)
+        ops.reduce_slabs([(slabs[t], dW, db, stride, nsplit, n_out, n_in, ld)])
+        refW = dZ[lo:hi, :n_out].double().t() @ h[idx[lo:hi].long(), :n_in].double()
+        if hi > lo:
+            assert rel(dW, refW) < 2e-5 and rel(db, dZ[lo:hi, :n_out].double().sum(0)) < 2e-5
+        else:
+            assert float(dW.abs().max()) == 0.0 and float(db.abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------
+def test_seg_sum_and_accumulate():
+    n8, e8, _ = synthetic.make_batch(200, **synthetic.SHAPES["gdb13"], seed=9)
+    ref = D.compact(n8, e8)
+    S, E = ref["S"], ref["E"]
+    g = torch.Generator().manual_seed(4)
+    for cols in (128, 100, 12):
+        ld = ops.r4(cols)
+        vals = torch.randn(E, ld, generator=g)
+        for perm_k, off_k in (("in_perm", "seg_off"), ("out_perm", "src_off")):
+            perm = torch.from_numpy(ref[perm_k])
+            off = torch.from_numpy(ref[off_k])
+            out = torch.full((S + 1, ld), 3.0, device=DEV)
+            ops.seg_sum(vals.to(DEV), perm.to(DEV), off.to(DEV), S + 1, cols, out)
+            want = D.seg_sum(vals.double(), perm, off, S + 1)
+            assert rel(out[:, :cols], want[:, :cols]) < 1e-6
+            assert float(out[S].abs().max()) == 0.0
+            ops.seg_sum(vals.to(DEV), perm.to(DEV), off.to(DEV), S + 1, cols, out, accumulate=True)
+            assert rel(out[:, :cols], 2 * want[:, :cols]) < 1e-6
+
+
+def test_selu_bwd_rows_gather():
+    g = torch.Generator().manual_seed(5)
+    dA = torch.randn(50, 128, generator=g)
+    idx = torch.randint(0, 50, (300,), generator=g, dtype=torch.int32)
+    Y = D.selu(torch.randn(300, 128, generator=g))
+    buf = Y.clone().to(DEV)
+    ops.selu_bwd_rows(dA.to(DEV), idx.to(DEV), buf, buf, 300, 128)
+    assert rel(buf, dA[idx.long()].double() * D.selu_grad_from_out(Y.double())) < 1e-6
