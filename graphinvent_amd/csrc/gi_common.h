@@ -24,3 +24,17 @@ static inline int gi_launch_status() {
 static inline int gi_r4(int x) { return (x + 3) & ~3; }
 static inline long long gi_r4l(long long x) { return (x + 3) & ~3LL; }
 static inline int gi_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- optional per-launch timing (bench.py roofline leg) -----------------------------------------
+// When enabled, gi_gemm / gi_seg_sum bracket each kernel launch with hipEvents on the launch
+// stream; gi_prof_collect synchronises and sums the elapsed times.  Off by default (zero cost).
+enum { GI_PROF_GEMM = 0, GI_PROF_SEGSUM = 1, GI_PROF_KINDS = 2 };
+bool gi_prof_on();
+void gi_prof_push(int kind, double work, hipEvent_t start, hipEvent_t stop);
+struct GiProfScope {
+    hipStream_t st; int kind; double work; hipEvent_t a, b; bool on;
+    GiProfScope(hipStream_t s, int k, double w) : st(s), kind(k), work(w), a(nullptr), b(nullptr), on(gi_prof_on()) {
+        if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
+    }
+    ~GiProfScope() { if (on) { (void)hipEventRecord(b, st); gi_prof_push(kind, work, a, b); } }
+};

@@ -305,6 +305,8 @@ extern "C" int gi_gemm(const gi_gemm_params* pp, void* stream) {
     dim3 grid(gi_cdiv(p.N, BN), gi_cdiv(rows, BM), splitk ? groups * p.nsplit : groups);
     if (grid.y > 65535u || grid.z > 65535u) return GI_ELIMIT;
     hipStream_t st = (hipStream_t)stream;
+    // useful flops of this launch (real dims; for grouped / split launches M resp. K is the total)
+    GiProfScope prof(st, GI_PROF_GEMM, 2.0 * (double)p.M * (double)p.N * (double)p.K);
     if (p.tm == 1 && p.tn == 1) return launch_tile<1, 1>(p, grid, st);
     if (p.tm == 1 && p.tn == 2) return launch_tile<1, 2>(p, grid, st);
     if (p.tm == 2 && p.tn == 2) return launch_tile<2, 2>(p, grid, st);

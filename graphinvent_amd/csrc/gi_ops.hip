@@ -243,6 +243,36 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceTable tab
 
 }  // namespace
 
+// ---- profiling registry ---------------------------------------------------------------------------
+#include <vector>
+namespace {
+struct ProfRec { int kind; double work; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+}  // namespace
+bool gi_prof_on() { return g_prof_on; }
+void gi_prof_push(int kind, double work, hipEvent_t a, hipEvent_t b) { g_prof.push_back({kind, work, a, b}); }
+
+extern "C" int gi_prof_enable(int on) {
+    g_prof_on = on != 0;
+    return 0;
+}
+// ms[k], work[k], launches[k] for k in {GEMM (work = flops), SEGSUM (work = bytes)}; clears the log
+extern "C" int gi_prof_collect(double* ms, double* work, int* launches) {
+    if (!ms || !work || !launches) return GI_EINVAL;
+    for (int k = 0; k < GI_PROF_KINDS; ++k) { ms[k] = 0; work[k] = 0; launches[k] = 0; }
+    int rc = 0;
+    for (ProfRec& r : g_prof) {
+        (void)hipEventSynchronize(r.b);
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) rc = GI_EINVAL;
+        ms[r.kind] += t; work[r.kind] += r.work; launches[r.kind] += 1;
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    return rc;
+}
+
 // ================================ C ABI ==========================================================
 extern "C" int gi_seg_sum(const float* vals, int ldv, const int* perm, const int* off, int rows,
                           int cols, float* out, int ldo, int accumulate, void* stream) {
@@ -252,6 +282,8 @@ extern "C" int gi_seg_sum(const float* vals, int ldv, const int* perm, const int
     if (((uintptr_t)vals & 15) || ((uintptr_t)out & 15)) return GI_EINVAL;
     const int c4n = (cols + 3) / 4;
     const long long threads = (long long)rows * c4n;
+    // (algorithmic bytes depend on the device-side segment lengths; the caller knows them)
+    GiProfScope prof((hipStream_t)stream, GI_PROF_SEGSUM, 0.0);
     hipLaunchKernelGGL(seg_sum_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, vals, ldv, perm, off, rows, c4n, out, ldo, accumulate);
     return gi_launch_status();

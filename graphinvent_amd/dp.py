@@ -1,0 +1,120 @@
+"""
+Data-parallel training of the GGNN hot path: one process per GPU, ``torch.distributed`` (backend
+``nccl`` = RCCL over xGMI on the MI355X node; ``gloo`` in the CPU tests).
+
+The reference trains single-process, single-GPU (Workflow.py:766-798; no DDP / NCCL call site
+anywhere).  Graphs are independent units, so the path shards by batch with exactly
+ONE exchange step per optimizer step:
+
+* every rank draws its own disjoint slice of each global minibatch from the same shuffled block
+  (``ShardedBatchSampler``: identical permutation on all ranks from a shared seed, rank r takes
+  global batches r, r+W, ...; ragged tails dropped so ranks stay in lock-step);
+* forward / loss / backward are rank-local;
+* gradients are averaged with one all-reduce over a single flat fp32 bucket.  The fused HIP
+  backward already writes every parameter gradient into one contiguous buffer
+  (``GGNN._grad_bucket``), so on the GPU path the collective runs in place on that buffer — no
+  flatten / unflatten copies.  xGMI is point-to-point, a ring all-reduce is per-link bound: one
+  24 MB bucket instead of 104 small tensors keeps it at a single latency term;
+* identical Adam steps follow on every rank (``batchmean`` loss per rank + gradient mean =
+  global-batch mean when the per-rank batch sizes are equal).
+"""
+from __future__ import annotations
+
+from typing import Callable, Iterator, List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .loss import apd_kl_loss
+
+
+class ShardedBatchSampler:
+    """Index batches of one rank for one epoch over ``n_rows`` examples of a block
+    (mirrors BlockDatasetLoader.py:32-63's shuffled minibatches; per-rank sharding is new)."""
+
+    def __init__(self, n_rows: int, batch_size: int, rank: int = 0, world_size: int = 1,
+                 seed: int = 0, shuffle: bool = True):
+        if not (0 <= rank < world_size):
+            raise ValueError("rank out of range")
+        self.n_rows, self.batch_size = n_rows, batch_size
+        self.rank, self.world_size, self.seed, self.shuffle = rank, world_size, seed, shuffle
+        self.epoch = 0
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = epoch
+
+    def __len__(self) -> int:
+        return (self.n_rows // self.batch_size) // self.world_size
+
+    def __iter__(self) -> Iterator[np.ndarray]:
+        order = np.arange(self.n_rows)
+        if self.shuffle:
+            order = np.random.default_rng([self.seed, self.epoch]).permutation(self.n_rows)
+        for k in range(len(self)):
+            g = k * self.world_size + self.rank                 # global batch index
+            yield order[g * self.batch_size:(g + 1) * self.batch_size]
+
+
+class DataParallel:
+    """Wraps (model, optimizer[, scheduler]) into a data-parallel train step."""
+
+    def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer,
+                 scheduler=None, loss_fn: Callable = apd_kl_loss,
+                 process_group: Optional[dist.ProcessGroup] = None):
+        self.model, self.optimizer, self.scheduler, self.loss_fn = model, optimizer, scheduler, loss_fn
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.params: List[torch.nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
+        self.last_bucket_zero_copy = False
+
+    def broadcast_parameters(self, src: int = 0) -> None:
+        """Make every rank start from rank `src`'s weights."""
+        if self.world_size == 1:
+            return
+        with torch.no_grad():
+            for p in self.params:
+                dist.broadcast(p.data, src=src, group=self.group)
+
+    # -- the one exchange step ---------------------------------------------------------------
+    def _model_bucket(self) -> Optional[torch.Tensor]:
+        bucket = getattr(self.model, "_grad_bucket", None)
+        if bucket is None:
+            return None
+        base = bucket.untyped_storage().data_ptr()
+        for p in self.params:
+            if p.grad is None or p.grad.untyped_storage().data_ptr() != base:
+                return None
+        return bucket
+
+    def allreduce_gradients(self) -> None:
+        if self.world_size == 1:
+            return
+        bucket = self._model_bucket()
+        self.last_bucket_zero_copy = bucket is not None
+        if bucket is not None:                      # gradients already live in one flat buffer
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+            bucket.mul_(1.0 / self.world_size)
+            return
+        grads = [p.grad for p in self.params]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.mul_(1.0 / self.world_size)
+        off = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n
+
+    def step(self, nodes: torch.Tensor, edges: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        """forward -> zero_grad -> loss -> backward -> all-reduce -> optimizer (-> scheduler):
+        the order of Workflow.py:785-796 with the exchange step inserted before the update."""
+        output = self.model(nodes, edges)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.loss_fn(output, target)
+        loss.backward()
+        self.allreduce_gradients()
+        self.optimizer.step()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        return loss.detach()

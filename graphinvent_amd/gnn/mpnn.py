@@ -117,8 +117,9 @@ class _GGNNFunction(torch.autograd.Function):
     """forward = gi_compact_* + gi_ggnn_forward; backward = gi_ggnn_backward."""
 
     @staticmethod
-    def forward(ctx, consts, nodes, edges, *params):
-        out, tape = ggnn_forward_raw(consts, nodes, edges, params)
+    def forward(ctx, owner, nodes, edges, *params):
+        out, tape = ggnn_forward_raw(owner.constants, nodes, edges, params)
+        ctx.owner = owner
         ctx.tape = tape
         ctx.save_for_backward(out, *params)
         return out
@@ -130,7 +131,8 @@ class _GGNNFunction(torch.autograd.Function):
                                "activations in place (retain_graph is not supported)")
         tape, ctx.tape = ctx.tape, None
         out, *params = ctx.saved_tensors
-        grads, _ = ggnn_backward_raw(tape, out, d_out, params)
+        grads, gflat = ggnn_backward_raw(tape, out, d_out, params)
+        ctx.owner._grad_bucket = gflat          # the flat bucket graphinvent_amd.dp all-reduces
         return (None, None, None, *grads)
 
 
@@ -161,6 +163,7 @@ class GGNN(torch.nn.Module):
             att_hidden_dim=c.gather_att_hidden_dim, att_dropout_p=c.gather_att_dropout_p,
             emb_depth=c.gather_emb_depth, emb_hidden_dim=c.gather_emb_hidden_dim,
             emb_dropout_p=c.gather_emb_dropout_p, big_positive=c.big_positive)
+        self._grad_bucket = None    # flat gradient buffer of the latest backward (transient)
         self.APDReadout = _modules.GlobalReadout(
             node_emb_size=c.hidden_node_features, graph_emb_size=c.gather_width,
             mlp1_hidden_dim=c.mlp1_hidden_dim, mlp1_depth=c.mlp1_depth,
@@ -179,4 +182,5 @@ class GGNN(torch.nn.Module):
                 "AlphaDropout with p > 0 in training mode is not implemented in the MI355X HIP "
                 "path (every reference default is p = 0.0, parameters/defaults.py:280-300)")
         params: List[torch.Tensor] = list(self.parameters())
-        return _GGNNFunction.apply(self.constants, nodes, edges, *params)
+        self._grad_bucket = None
+        return _GGNNFunction.apply(self, nodes, edges, *params)

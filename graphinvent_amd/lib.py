@@ -72,6 +72,8 @@ SIGNATURES = {
     "gi_compress_slots": (ci, [vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, ci, vp]),
     "gi_colsum": (ci, [vp, ci, ci, ci, vp, vp, vp]),
     "gi_reduce_slabs": (ci, [C.POINTER(ReduceDesc), ci, vp]),
+    "gi_prof_enable": (ci, [ci]),
+    "gi_prof_collect": (ci, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci)]),
     "gi_ggnn_num_params": (ci, [C.POINTER(GgnnDims)]),
     "gi_ggnn_workspace_floats": (cll, [C.POINTER(GgnnDims), ci, ci]),
     "gi_ggnn_slab_floats": (cll, [C.POINTER(GgnnDims), ci, ci, C.POINTER(ci)]),

@@ -86,9 +86,20 @@ def selu(x):
     return SELU_SCALE * torch.where(x > 0, x, SELU_ALPHA * torch.expm1(x))
 
 
+#: optional branch pins for the SELU derivative: id(activation tensor) -> bool mask "y > 0".
+#: SELU'(x) jumps from scale*alpha (1.758) to scale (1.051) at x = 0, so an activation that two
+#: implementations round to opposite sides of 0 (|x| ~ 1e-7) changes the gradient by O(1) for that
+#: element.  Pinning the branch to the one the implementation under test took makes a gradient
+#: comparison insensitive to that (measure-zero in exact arithmetic) discontinuity.
+BRANCH_PINS = {}
+
+
 def selu_grad_from_out(y):
     """d selu(x)/dx expressed through y = selu(x): scale for y>0 else y + scale*alpha."""
-    return torch.where(y > 0, torch.full_like(y, SELU_SCALE), y + SELU_SCALE * SELU_ALPHA)
+    pos = BRANCH_PINS.get(id(y))
+    if pos is None:
+        pos = y > 0
+    return torch.where(pos, torch.full_like(y, SELU_SCALE), y + SELU_SCALE * SELU_ALPHA)
 
 
 def linear(x, w, b, act=True, idx=None):

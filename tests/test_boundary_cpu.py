@@ -1,0 +1,99 @@
+"""CPU: the drop-in boundary — C ABI exports, module API, checkpoint wire format, loud failure
+without a GPU.  No device compute is issued."""
+import copy
+import ctypes as C
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from graphinvent_amd import lib as L
+from graphinvent_amd.gnn import mpnn
+from oracle import ggnn_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/graphinvent"
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "graphinvent_amd.h")).read()
+    declared = set(re.findall(r"^(?:int|long long)\s+(gi_\w+)\s*\(", hdr, flags=re.M))
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    lib = L.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.gi_abi_version() == 1
+
+
+def test_host_side_planning_functions():
+    lib = L.load()
+    d = mpnn._dims_from_constants(O.as_constants(O.make_config()), 1000)
+    assert lib.gi_ggnn_num_params(C.byref(d)) == 104
+    lay = L.CompactLayout()
+    assert lib.gi_compact_layout(1000, 13, 3, C.byref(lay)) == 0 and lay.total_ints > 13000 * 8
+    assert lib.gi_compact_layout(4, 200, 3, C.byref(lay)) == -2          # N > GI_MAX_NODES
+    ws = lib.gi_ggnn_workspace_floats(C.byref(d), 6900, 12600)
+    ws0 = lib.gi_ggnn_workspace_floats(C.byref(d), 0, 0)
+    assert ws > ws0 > 0 and ws % 4 == 0
+    Et = (C.c_int * 3)(10000, 2500, 100)
+    assert lib.gi_ggnn_slab_floats(C.byref(d), 6900, 12600, Et) > 0
+    d.Fn = d.H + 1
+    assert lib.gi_ggnn_workspace_floats(C.byref(d), 1, 1) == -1          # GI_EINVAL
+
+
+def test_state_dict_is_the_reference_wire_format():
+    cfg = O.make_config()
+    model = mpnn.GGNN(O.as_constants(cfg))
+    sd = model.state_dict()
+    shapes = O.param_shapes(cfg)
+    assert list(sd) == list(shapes)
+    assert all(tuple(sd[k].shape) == shapes[k] for k in shapes)
+    assert [n for n, _ in model.named_parameters()] == list(shapes)
+    model.load_state_dict(O.init_params(cfg, seed=3))
+    clone = copy.deepcopy(model)
+    assert all(torch.equal(a, b) for a, b in zip(model.parameters(), clone.parameters()))
+    model.eval(); model.train(); model.zero_grad()
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present on this box")
+def test_constructor_is_seed_for_seed_identical_to_the_reference():
+    sys.path.insert(0, REF)
+    try:
+        import gnn.mpnn as ref_mpnn
+    finally:
+        sys.path.remove(REF)
+    assert ref_mpnn.__file__.startswith(REF)
+    c = O.as_constants(O.make_config())
+    torch.manual_seed(123)
+    ref = ref_mpnn.GGNN(c)
+    torch.manual_seed(123)
+    ours = mpnn.GGNN(c)
+    a, b = ref.state_dict(), ours.state_dict()
+    assert list(a) == list(b)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    for m in [k for k in sys.modules if k == "gnn" or k.startswith("gnn.")]:
+        del sys.modules[m]
+
+
+def test_forward_fails_loudly_off_gpu():
+    cfg = O.make_config()
+    model = mpnn.GGNN(O.as_constants(cfg))
+    with pytest.raises(RuntimeError, match="no CPU"):
+        model(torch.zeros(2, 13, 8), torch.zeros(2, 13, 13, 3))
+
+
+def test_dropout_in_training_mode_is_rejected_not_ignored():
+    cfg = O.make_config(mlp1_dropout_p=0.1)
+    model = mpnn.GGNN(O.as_constants(cfg)).train()
+    with pytest.raises(NotImplementedError):
+        model(torch.zeros(2, 13, 8), torch.zeros(2, 13, 13, 3))
+
+
+def test_missing_library_raises(monkeypatch, tmp_path):
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU or"):
+        L.load()

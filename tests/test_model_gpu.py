@@ -182,23 +182,104 @@ def _live_only(n8, e8, a8):
     return n8[keep], e8[keep], a8[keep]
 
 
+def _oracle_both(cfg, P, n8, e8, a8):
+    t = lambda x, dt: torch.from_numpy(x).to(dt)
+    r32 = O.forward_backward(P, cfg, t(n8, torch.float32), t(e8, torch.float32), t(a8, torch.float32))
+    P64 = {k: v.double() for k, v in P.items()}
+    r64 = O.forward_backward(P64, cfg, t(n8, torch.float64), t(e8, torch.float64), t(a8, torch.float64))
+    return r32, r64
+
+
 @pytest.mark.parametrize("shape,B,over", [
     ("gdb13", 1000, dict(hidden_node_features=128, message_size=128)),      # BASELINE config 2
     ("zinc", 96, {}),                                                        # config 3 shape
 ])
-def test_strict_parity_on_unmasked_graphs(shape, B, over):
+def test_full_size_parity_vs_fp32_and_fp64_oracle(shape, B, over):
+    """Logits and loss: strict 1e-4 against the fp32 oracle.  Gradients: the reference's own fp32
+    gradients are NOT reproducible to 1e-4 at this size — SELU' is discontinuous at 0 and a few of
+    the ~1e7 activations per step round to opposite sides of 0 in fp32 vs fp64 (measured: 4 sign
+    flips at B=300 move the fp32 oracle's gradients by up to 5.6e-3 of max|g| from its fp64 run).
+    So the raw gradient check is: HIP is as close to the exact (fp64) gradient as the reference's
+    fp32 arithmetic is, within 3x; the branch-pinned test below is the strict one."""
     sh = synthetic.SHAPES[shape]
     cfg = O.shaped_config(sh["n_atom_types"], sh["n_formal_charge"], sh["max_n_nodes"], **over)
     P = O.init_params(cfg, seed=4)
     n8, e8, a8 = _live_only(*synthetic.make_batch(B, **sh, seed=6))
     model = make_model(cfg, P)
     out, loss, grads = hip_forward_backward(model, n8, e8, a8)
-    t = lambda x: torch.from_numpy(x).float()
-    o32, l32, g32 = O.forward_backward(P, cfg, t(n8), t(e8), t(a8))
-    assert rel(out, o32) < TOL
+    (o32, l32, g32), (o64, l64, g64) = _oracle_both(cfg, P, n8, e8, a8)
+    assert rel(out, o32) < TOL and rel(out, o64) < TOL
     assert abs(loss - float(l32)) < TOL * abs(float(l32))
-    for k in grads:
-        assert rel(grads[k], g32[k]) < TOL, k
+    ref_noise = max(rel(g32[k], g64[k]) for k in g64)
+    hip_err = max((rel(grads[k], g64[k]), k) for k in g64)
+    assert hip_err[0] < max(TOL, 3 * ref_noise), (hip_err, ref_noise)
+    assert hip_err[0] < 2e-2, hip_err
+
+
+def test_gradients_strict_with_selu_branch_pinned():
+    """Strict 1e-4 gradient parity at BASELINE config-2 dimensions: the fp64 dataflow model
+    differentiates the same piecewise-smooth branch the HIP forward took (SELU sign pattern read
+    back from the HIP activations), which removes the only discontinuity of the loss."""
+    sh = synthetic.SHAPES["gdb13"]
+    cfg = O.shaped_config(sh["n_atom_types"], sh["n_formal_charge"], sh["max_n_nodes"],
+                          hidden_node_features=128, message_size=128)
+    P = O.init_params(cfg, seed=4)
+    n8, e8, a8 = _live_only(*synthetic.make_batch(256, **sh, seed=12))
+    model = make_model(cfg, P)
+    params = list(model.parameters())
+    nodes, edges, tgt = to_dev(n8, e8, a8)
+    out, tape_hip = mpnn.ggnn_forward_raw(model.constants, nodes, edges, params)
+    dims, graph, ws, Et = tape_hip
+    S, E, B = graph.S, graph.E, n8.shape[0]
+    R = S + 1
+    view = lambda name, rows, i=0, j=0: ops.ws_view(ws, dims, S, E, name, rows, i, j).cpu()
+    # fp64 reference forward on the CPU dataflow model
+    P64 = {k: v.double() for k, v in P.items()}
+    t64 = lambda x: torch.from_numpy(x).double()
+    out64, tape = D.forward(P64, cfg, t64(n8), t64(e8), keep=True)
+    assert rel(out, out64) < TOL
+    pins = {}
+    toff = graph.type_off.cpu().tolist()
+    for p, ps in enumerate(tape["passes"]):
+        for l in range(dims.enn_depth):
+            hv = view("eact", E, p, l)
+            for t in range(dims.Fe):
+                a = ps["acts_t"][t][l]
+                pins[id(a)] = hv[toff[t]:toff[t + 1], :a.shape[1]] > 0
+        pins[id(ps["m"])] = view("m", E, p)[:, :dims.M] > 0
+    for key, act_name, out_name, depth in (("att_acts", "att_act", "en", dims.att_depth),
+                                           ("emb_acts", "emb_act", "emb", dims.emb_depth),
+                                           ("add1", "add1_act", "add1", dims.mlp1_depth),
+                                           ("conn1", "conn1_act", "conn1", dims.mlp1_depth)):
+        for l in range(depth):
+            a = tape[key][l]
+            pins[id(a)] = view(act_name, R, 0, l)[:, :a.shape[1]] > 0
+        a = tape[key][-1]
+        pins[id(a)] = view(out_name, R)[:, :a.shape[1]] > 0
+    NA, NC = dims.N * dims.A, dims.N * dims.C
+    o_cpu = out.cpu()
+    for key, act_name, cols in (("add2", "add2_act", slice(0, NA)),
+                                ("conn2", "conn2_act", slice(NA, NA + NC)),
+                                ("term2", "term2_act", slice(NA + NC, NA + NC + 1))):
+        for l in range(dims.mlp2_depth):
+            a = tape[key][l]
+            pins[id(a)] = view(act_name, B, 0, l)[:, :a.shape[1]] > 0
+        pins[id(tape[key][-1])] = o_cpu[:, cols] > 0
+    # backward on both sides
+    o_leaf = out.detach().clone().requires_grad_(True)
+    O.kl_loss(o_leaf, tgt).backward()
+    grads, _ = mpnn.ggnn_backward_raw(tape_hip, out, o_leaf.grad, params)
+    o64_leaf = out64.detach().clone().requires_grad_(True)
+    O.kl_loss(o64_leaf, t64(a8)).backward()
+    D.BRANCH_PINS.clear()
+    D.BRANCH_PINS.update(pins)
+    try:
+        g64 = D.backward(P64, cfg, tape, o64_leaf.grad)
+    finally:
+        D.BRANCH_PINS.clear()
+    names = [k for k, _ in model.named_parameters()]
+    for k, g in zip(names, grads):
+        assert rel(g, g64[k]) < TOL, k
 
 
 def test_full_batch_properties():
