@@ -240,6 +240,7 @@ extern "C" int gi_compact_layout(int B, int N, int Fe, gi_compact_layout_t* out)
 
 extern "C" int gi_compact_count(const float* nodes, const float* edges, int B, int N, int Fn,
                                 int Fe, int* gfix, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (!nodes || !edges || !gfix || B <= 0 || N <= 0 || Fn <= 0 || Fe <= 0) return GI_EINVAL;
     if (N > GI_MAX_NODES || Fe > GI_MAX_GROUPS) return GI_ELIMIT;
     const Lay L = make_layout(B, N, Fe);
@@ -255,6 +256,7 @@ extern "C" int gi_compact_count(const float* nodes, const float* edges, int B, i
 extern "C" int gi_compact_fill(const float* nodes, int B, int N, int Fn, int Fe, const int* gfix,
                                int S, int E, int* e_src, int* e_dst, int* in_perm, int* out_perm,
                                float* hx0, int ldhx, int H, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (!nodes || !gfix || !hx0 || B <= 0 || N <= 0 || S < 0 || E < 0) return GI_EINVAL;
     if (E > 0 && (!e_src || !e_dst || !in_perm || !out_perm)) return GI_EINVAL;
     if (N > GI_MAX_NODES || Fe > GI_MAX_GROUPS) return GI_ELIMIT;

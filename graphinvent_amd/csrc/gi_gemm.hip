@@ -27,6 +27,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef v4f v4f_u __attribute__((aligned(4)));     // global rows are only guaranteed 4-byte aligned
 
+// Branch-free guarded 16-byte staging load, split in two so the data is not touched until it is
+// written to LDS (the loads of a tile issue back to back and stay in flight under the MFMAs):
+//   gi_load4_raw : address clamped so the load always ends inside the row ([ncols-4, ncols), or
+//                  [0,4) for rows narrower than 4 floats, whose storage is padded to 4)
+//   gi_fix4      : v[j] = (valid && col + j < ncols) ? rowp[col + j] : 0 by shifting lanes back
+// cmax = largest column a 16-byte load may start at: ncols-4 for exactly-sized rows, r4(ncols)-4
+// when the row storage is padded to 4 floats (then no lane shift is ever needed).
+__device__ __forceinline__ v4f gi_load4_raw(const float* rowp, int col, int cmax) {
+    return *(const v4f_u*)(rowp + max(min(col, cmax), 0));
+}
+__device__ __forceinline__ v4f gi_fix4(v4f w, int col, int cmax, int ncols, bool valid) {
+    const int s = col - max(min(col, cmax), 0);          // 0..3 = lanes to shift back, >= 4 = nothing valid
+    const bool s1 = (s & 1) != 0, s2 = (s & 2) != 0;
+    float x = w.x, y = w.y, z = w.z, t = w.w;            // two select stages (v_cndmask), no branches
+    x = s1 ? y : x; y = s1 ? z : y; z = s1 ? t : z; t = s1 ? 0.f : t;
+    x = s2 ? z : x; y = s2 ? t : y; z = s2 ? 0.f : z; t = s2 ? 0.f : t;
+    const bool v = valid & (s < 4);
+    v4f r;
+    r.x = (v & (col < ncols)) ? x : 0.f;
+    r.y = (v & (col + 1 < ncols)) ? y : 0.f;
+    r.z = (v & (col + 2 < ncols)) ? z : 0.f;
+    r.w = (v & (col + 3 < ncols)) ? t : 0.f;
+    return r;
+}
+
 template <int TM, int TN, bool A_MAJOR, bool B_MAJOR>
 __global__ __launch_bounds__(256) void gi_gemm_kernel(const gi_gemm_params p) {
     constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32;
@@ -46,8 +71,14 @@ __global__ __launch_bounds__(256) void gi_gemm_kernel(const gi_gemm_params p) {
 
     // ---- group / split resolution (block-uniform) -------------------------------------------
     const bool splitk = (p.flags & GI_GEMM_SPLITK) != 0;
-    int g = blockIdx.z, s = 0;
-    if (splitk) { g = blockIdx.z / p.nsplit; s = blockIdx.z - g * p.nsplit; }
+    int g = blockIdx.z, s = 0, nsp = p.nsplit;
+    if (splitk) {
+        g = 0; s = blockIdx.z;
+        if (p.ngroups) {                                  // per-group slab counts (work-proportional)
+            while (g < p.ngroups - 1 && s >= p.gsplit[g]) { s -= p.gsplit[g]; ++g; }
+            nsp = p.gsplit[g];
+        }
+    }
     const float* __restrict__ Ap = p.A;
     const float* __restrict__ Bp = (p.ngroups && !splitk) ? p.Bg[g] : p.B;
     const float* __restrict__ biasp = (p.ngroups && !splitk) ? p.biasg[g] : p.bias;
@@ -60,7 +91,7 @@ __global__ __launch_bounds__(256) void gi_gemm_kernel(const gi_gemm_params p) {
     }
     if (splitk) {
         const int len = k_end - k_begin;
-        const int chunk = (((len + p.nsplit - 1) / p.nsplit) + 31) & ~31;
+        const int chunk = (((len + nsp - 1) / nsp) + 31) & ~31;
         const int kb = k_begin + s * chunk;
         k_end = min(kb + chunk, k_end);
         k_begin = kb;
@@ -80,111 +111,117 @@ __global__ __launch_bounds__(256) void gi_gemm_kernel(const gi_gemm_params p) {
     const int a_mc4 = tid % A_C4, a_mr = tid / A_C4;
     const int b_mc4 = tid % B_C4, b_mr = tid / B_C4;
 
-    long long a_off[NA], b_off[NB];                    // element offsets of fixed (contig) rows, -1 = out of range
+    long long a_off[NA], b_off[NB];        // element offsets of the fixed (contig) rows; invalid rows -> row 0
+    bool a_ok[NA], b_ok[NB];
     if (!A_MAJOR) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int row = m0 + crow + 32 * i;
-            a_off[i] = -1;
-            if (row < m_end) a_off[i] = (long long)(p.a_idx ? p.a_idx[row] : row) * p.lda;
+            a_ok[i] = row < m_end;
+            const int rr = a_ok[i] ? row : m0;
+            a_off[i] = (long long)(p.a_idx ? p.a_idx[rr] : rr) * p.lda;
         }
     }
     if (!B_MAJOR) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int row = n0 + crow + 32 * i;
-            b_off[i] = (row < p.N) ? (long long)row * p.ldb : -1;
+            b_ok[i] = row < p.N;
+            b_off[i] = (long long)(b_ok[i] ? row : 0) * p.ldb;
         }
     }
 
     v4f ra[NA], rb[NB];
 
-    auto gload = [&](int k0) {
+    // Only the REDUCTION dimension needs zero fill (garbage there would reach valid outputs).  Along
+    // the output dimensions out-of-range rows/columns are merely clamped to readable addresses:
+    // whatever they hold only feeds output elements the epilogue discards.  So every tile that is
+    // full in k stores the raw vectors ("fast"); the last, partial k tile takes the fix-up path.
+    const int a_cmax = A_MAJOR ? ((p.lda >= ((p.M + 3) & ~3)) ? ((p.M + 3) & ~3) - 4 : p.M - 4) : k_end - 4;
+    const int b_cmax = B_MAJOR ? ((p.ldb >= ((bcols + 3) & ~3)) ? ((bcols + 3) & ~3) - 4 : bcols - 4)
+                               : k_end - 4;
+    const bool a_fast = A_MAJOR ? (p.lda >= ((p.M + 3) & ~3)) : true;
+    const bool b_fast = B_MAJOR ? (p.ldb >= ((bcols + 3) & ~3)) : true;
+
+    auto gload = [&](int k0) {                       // raw loads only: nothing consumes the data here
         if (!A_MAJOR) {
-            const int kk = k0 + 4 * cc4;
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                v4f v = {0.f, 0.f, 0.f, 0.f};
-                if (a_off[i] >= 0) {
-                    const float* src = Ap + a_off[i] + kk;
-                    if (kk + 4 <= k_end) v = *(const v4f_u*)src;
-                    else {
-                        if (kk < k_end) v.x = src[0];
-                        if (kk + 1 < k_end) v.y = src[1];
-                        if (kk + 2 < k_end) v.z = src[2];
-                    }
-                }
-                ra[i] = v;
-            }
+            for (int i = 0; i < NA; ++i) ra[i] = gi_load4_raw(Ap + a_off[i], k0 + 4 * cc4, a_cmax);
         } else {
-            const int col = m0 + 4 * a_mc4;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int red = k0 + a_mr + i * A_RP;
-                v4f v = {0.f, 0.f, 0.f, 0.f};
-                if (red < k_end) {
-                    const float* src = Ap + (long long)red * p.lda + col;
-                    if (col + 4 <= p.M) v = *(const v4f_u*)src;
-                    else {
-                        if (col < p.M) v.x = src[0];
-                        if (col + 1 < p.M) v.y = src[1];
-                        if (col + 2 < p.M) v.z = src[2];
-                    }
-                }
-                ra[i] = v;
+                const int red = min(k0 + a_mr + i * A_RP, k_end - 1);
+                ra[i] = gi_load4_raw(Ap + (long long)red * p.lda, m0 + 4 * a_mc4, a_cmax);
             }
         }
         if (!B_MAJOR) {
-            const int kk = k0 + 4 * cc4;
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                v4f v = {0.f, 0.f, 0.f, 0.f};
-                if (b_off[i] >= 0) {
-                    const float* src = Bp + b_off[i] + kk;
-                    if (kk + 4 <= k_end) v = *(const v4f_u*)src;
-                    else {
-                        if (kk < k_end) v.x = src[0];
-                        if (kk + 1 < k_end) v.y = src[1];
-                        if (kk + 2 < k_end) v.z = src[2];
-                    }
-                }
-                rb[i] = v;
-            }
+            for (int i = 0; i < NB; ++i) rb[i] = gi_load4_raw(Bp + b_off[i], k0 + 4 * cc4, b_cmax);
         } else {
-            const int col = n0 + 4 * b_mc4;
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int red = k0 + b_mr + i * B_RP;
-                v4f v = {0.f, 0.f, 0.f, 0.f};
-                if (red < k_end) {
-                    const long long srow = p.b_idx ? p.b_idx[red] : red;
-                    const float* src = Bp + srow * p.ldb + col;
-                    if (col + 4 <= bcols) v = *(const v4f_u*)src;
-                    else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int c = col + j;
-                            v[j] = (c < bcols) ? src[j] : ((c == p.ones_col) ? 1.f : 0.f);
-                        }
-                    }
-                }
-                rb[i] = v;
+                const int red = min(k0 + b_mr + i * B_RP, k_end - 1);
+                const long long srow = p.b_idx ? p.b_idx[red] : red;
+                rb[i] = gi_load4_raw(Bp + srow * p.ldb, n0 + 4 * b_mc4, b_cmax);
             }
         }
     };
 
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, int k0) {             // (fix-up of the last k tile) + LDS write
         float* a = As + buf * A_SZ;
         float* b = Bs + buf * B_SZ;
+        const bool full_k = k0 + BK <= k_end;        // block-uniform
+        if (full_k && a_fast) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            if (!A_MAJOR) *(v4f*)&a[(crow + 32 * i) * A_LD + 4 * cc4] = ra[i];
-            else *(v4f*)&a[(a_mr + i * A_RP) * A_LD + 4 * a_mc4] = ra[i];
+            for (int i = 0; i < NA; ++i) {
+                if (!A_MAJOR) *(v4f*)&a[(crow + 32 * i) * A_LD + 4 * cc4] = ra[i];
+                else *(v4f*)&a[(a_mr + i * A_RP) * A_LD + 4 * a_mc4] = ra[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                if (!A_MAJOR) {
+                    *(v4f*)&a[(crow + 32 * i) * A_LD + 4 * cc4] =
+                        gi_fix4(ra[i], k0 + 4 * cc4, a_cmax, k_end, a_ok[i]);
+                } else {
+                    const bool ok = k0 + a_mr + i * A_RP < k_end;
+                    *(v4f*)&a[(a_mr + i * A_RP) * A_LD + 4 * a_mc4] =
+                        gi_fix4(ra[i], m0 + 4 * a_mc4, a_cmax, p.M, ok);
+                }
+            }
         }
+        if (full_k && b_fast) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            if (!B_MAJOR) *(v4f*)&b[(crow + 32 * i) * B_LD + 4 * cc4] = rb[i];
-            else *(v4f*)&b[(b_mr + i * B_RP) * B_LD + 4 * b_mc4] = rb[i];
+            for (int i = 0; i < NB; ++i) {
+                if (!B_MAJOR) {
+                    *(v4f*)&b[(crow + 32 * i) * B_LD + 4 * cc4] = rb[i];
+                } else {
+                    const int col = n0 + 4 * b_mc4;
+                    v4f v = rb[i];                   // bias-gradient column of wgrad (-1 never matches)
+                    v.x = (col == p.ones_col) ? 1.f : v.x;
+                    v.y = (col + 1 == p.ones_col) ? 1.f : v.y;
+                    v.z = (col + 2 == p.ones_col) ? 1.f : v.z;
+                    v.w = (col + 3 == p.ones_col) ? 1.f : v.w;
+                    *(v4f*)&b[(b_mr + i * B_RP) * B_LD + 4 * b_mc4] = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                if (!B_MAJOR) {
+                    *(v4f*)&b[(crow + 32 * i) * B_LD + 4 * cc4] =
+                        gi_fix4(rb[i], k0 + 4 * cc4, b_cmax, k_end, b_ok[i]);
+                } else {
+                    const bool ok = k0 + b_mr + i * B_RP < k_end;
+                    const int col = n0 + 4 * b_mc4;
+                    v4f v = gi_fix4(rb[i], col, b_cmax, bcols, ok);
+                    v.x = (ok & (col == p.ones_col)) ? 1.f : v.x;
+                    v.y = (ok & (col + 1 == p.ones_col)) ? 1.f : v.y;
+                    v.z = (ok & (col + 2 == p.ones_col)) ? 1.f : v.z;
+                    v.w = (ok & (col + 3 == p.ones_col)) ? 1.f : v.w;
+                    *(v4f*)&b[(b_mr + i * B_RP) * B_LD + 4 * b_mc4] = v;
+                }
+            }
         }
     };
 
@@ -239,14 +276,14 @@ __global__ __launch_bounds__(256) void gi_gemm_kernel(const gi_gemm_params p) {
     const int nk = (k_end > k_begin) ? (k_end - k_begin + BK - 1) / BK : 0;
     if (nk > 0) {
         gload(k_begin);
-        sstore(0);
+        sstore(0, k_begin);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = (kt + 1 < nk);
         if (more) gload(k_begin + (kt + 1) * BK);
         compute(kt & 1);
-        if (more) sstore((kt + 1) & 1);
+        if (more) sstore((kt + 1) & 1, k_begin + (kt + 1) * BK);
         __syncthreads();
     }
 
@@ -288,6 +325,7 @@ static int launch_tile(const gi_gemm_params& p, dim3 grid, hipStream_t st) {
 }
 
 extern "C" int gi_gemm(const gi_gemm_params* pp, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (!pp) return GI_EINVAL;
     const gi_gemm_params& p = *pp;
     if (p.M < 0 || p.N <= 0 || p.K < 0 || p.nsplit < 1 || p.ngroups < 0 ||
@@ -302,7 +340,15 @@ extern "C" int gi_gemm(const gi_gemm_params* pp, void* stream) {
     const int rows = splitk ? p.M : (p.ngroups ? p.max_group_rows : p.M);
     if (rows <= 0) return 0;
     const int groups = p.ngroups ? p.ngroups : 1;
-    dim3 grid(gi_cdiv(p.N, BN), gi_cdiv(rows, BM), splitk ? groups * p.nsplit : groups);
+    int zsplit = p.nsplit;
+    if (splitk && p.ngroups) {
+        zsplit = 0;
+        for (int g = 0; g < p.ngroups; ++g) {
+            if (p.gsplit[g] < 1) return GI_EINVAL;
+            zsplit += p.gsplit[g];
+        }
+    }
+    dim3 grid(gi_cdiv(p.N, BN), gi_cdiv(rows, BM), splitk ? zsplit : groups);
     if (grid.y > 65535u || grid.z > 65535u) return GI_ELIMIT;
     hipStream_t st = (hipStream_t)stream;
     // useful flops of this launch (real dims; for grouped / split launches M resp. K is the total)

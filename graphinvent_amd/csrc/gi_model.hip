@@ -129,11 +129,15 @@ void make_ws(const Model& m, int S, int E, Ws& w) {
 struct SlabEntry { long long off, stride; int nsplit, calls, done, n_out, n_in, ld, tn; };
 struct SlabPlan { SlabEntry e[160]; long long total; };
 
-void wgrad_shape(int n_out, int n_in, int red_rows, int groups, int& tn, int& nsplit) {
-    tn = (n_in + 1 > 64) ? 2 : 1;
-    const int tiles = gi_cdiv(n_out, 64) * gi_cdiv(n_in + 1, 64 * tn) * groups;
+// wgrad launch shape: 64x64 output tiles (slab traffic depends only on the split count, so the
+// small tile buys blocks for free); `share` = this problem's fraction of the launch's rows, so a
+// grouped launch hands every bond type slabs in proportion to its edges.
+void wgrad_shape(int n_out, int n_in, int red_rows, double share, int& tn, int& nsplit) {
+    tn = 1;
+    const int tiles = gi_cdiv(n_out, 64) * gi_cdiv(n_in + 1, 64);
     const int kt = gi_cdiv(std::max(red_rows, 1), 32);
-    nsplit = std::min(std::max(gi_cdiv(256, tiles), 1), std::max(1, kt / 2));
+    const int want = (int)(640.0 * share / tiles + 0.5);
+    nsplit = std::min(std::max(want, 1), std::max(1, kt / 2));
 }
 
 void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {
@@ -142,22 +146,25 @@ void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {
     long long o = 0;
     int maxEt = 0;
     for (int t = 0; t < d.Fe; ++t) maxEt = std::max(maxEt, Et ? Et[t] : E);
-    auto add = [&](int widx, int n_out, int n_in, int red, int calls, int groups) {
+    auto add = [&](int widx, int n_out, int n_in, int red, int calls, double share) {
         SlabEntry& e = sp.e[widx];
         e.n_out = n_out; e.n_in = n_in; e.ld = gi_r4(n_in + 1); e.calls = calls; e.done = 0;
-        wgrad_shape(n_out, n_in, red, groups, e.tn, e.nsplit);
+        wgrad_shape(n_out, n_in, red, share, e.tn, e.nsplit);
         e.stride = gi_r4l((long long)n_out * e.ld);
         e.off = o;
         o += e.stride * e.nsplit * calls;
     };
-    auto add_mlp = [&](const Mlp& q, int red, int calls, int groups = 1) {
+    auto add_mlp = [&](const Mlp& q, int red, int calls, double share = 1.0) {
         for (int l = 0; l < q.layers(); ++l)
-            add(q.w(l), q.fan_out(l), q.fan_in(l), red, calls, groups);
+            add(q.w(l), q.fan_out(l), q.fan_in(l), red, calls, share);
     };
     const int R = S + 1;
-    for (int t = 0; t < d.Fe; ++t) add_mlp(m.msg[t], maxEt, d.passes, d.Fe);
-    add(m.gru_wih, 3 * d.H, d.M, R, d.passes, 1);
-    add(m.gru_whh, 3 * d.H, d.H, R, d.passes, 1);
+    for (int t = 0; t < d.Fe; ++t) {
+        const int et = Et ? Et[t] : E / d.Fe;
+        add_mlp(m.msg[t], et, d.passes, E > 0 ? (double)et / E : 1.0);
+    }
+    add(m.gru_wih, 3 * d.H, d.M, R, d.passes, 1.0);
+    add(m.gru_whh, 3 * d.H, d.H, R, d.passes, 1.0);
     add_mlp(m.att, R, 1); add_mlp(m.emb, R, 1); add_mlp(m.add1, R, 1); add_mlp(m.conn1, R, 1);
     add_mlp(m.add2, d.B, 1); add_mlp(m.conn2, d.B, 1); add_mlp(m.term2, d.B, 1);
     sp.total = o;
@@ -174,11 +181,13 @@ struct Run {
     void chk(int r) { if (rc == 0 && r != 0) rc = r; }
 };
 
+// forward / dgrad tile: at this path's sizes (10^3..10^4 rows, 100..700 columns, K <= 700) the
+// 64x64 tile wins everywhere measured (tools/bench_gemm.py): it keeps 4 blocks per CU resident
+// and more than one block per CU in flight; 64x128 only pays beyond a few thousand tiles.
 void pick_tile(int rows, int ncols, int& tm, int& tn) {
-    if (ncols <= 64) { tm = 1; tn = 1; return; }
-    tn = 2;
-    const long long b22 = (long long)gi_cdiv(rows, 128) * gi_cdiv(ncols, 128);
-    tm = (b22 >= 512) ? 2 : 1;
+    tm = 1;
+    const long long b11 = (long long)gi_cdiv(rows, 64) * gi_cdiv(ncols, 64);
+    tn = (ncols > 64 && b11 > 4096) ? 2 : 1;
 }
 
 void gemm_defaults(gi_gemm_params& p) {
@@ -261,6 +270,7 @@ void linear_wgrad(Run& r, SlabPlan& sp, float* slabs, const int* widx, const Grp
         for (int t = 0; t < g.n; ++t) {
             SlabEntry& e = sp.e[widx[t]];
             p.Cg[t] = slabs + e.off + (long long)e.done * e.nsplit * e.stride;
+            p.gsplit[t] = e.nsplit;
             e.done++;
         }
     } else {
@@ -383,6 +393,7 @@ extern "C" int gi_ggnn_ws_query(const gi_ggnn_dims* d, int S, int E, const char*
 extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* params, const int* gfix,
                                const int* e_src, const int* in_perm, int S, int E, const int* Et,
                                float* ws, float* out, int ldout, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     Model m;
     int rc = build_model(dp, m);
     if (rc) return rc;
@@ -447,6 +458,7 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
                                 int E, const int* Et, float* ws, float* slabs, const float* y_out,
                                 int ldout, const float* d_out, int lddout, float* const* grads,
                                 void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     Model m;
     int rc = build_model(dp, m);
     if (rc) return rc;

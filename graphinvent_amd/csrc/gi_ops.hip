@@ -276,6 +276,7 @@ extern "C" int gi_prof_collect(double* ms, double* work, int* launches) {
 // ================================ C ABI ==========================================================
 extern "C" int gi_seg_sum(const float* vals, int ldv, const int* perm, const int* off, int rows,
                           int cols, float* out, int ldo, int accumulate, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (rows <= 0) return 0;
     if (!vals || !off || !out || cols <= 0 || (ldv & 3) || (ldo & 3) || ldv < cols || ldo < cols)
         return GI_EINVAL;
@@ -291,6 +292,7 @@ extern "C" int gi_seg_sum(const float* vals, int ldv, const int* perm, const int
 
 extern "C" int gi_selu_bwd_rows(const float* dY, int lddy, const int* idx, const float* Y, int ldy,
                                 float* out, int ldo, int rows, int cols, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (rows <= 0 || cols <= 0) return 0;
     if (!dY || !Y || !out) return GI_EINVAL;
     const long long threads = (long long)rows * cols;
@@ -302,6 +304,7 @@ extern "C" int gi_selu_bwd_rows(const float* dY, int lddy, const int* idx, const
 extern "C" int gi_gru_gates_fwd(float* gi, float* gh, int ldg, const float* hx_prev, float* hx_new,
                                 int ldh, const int* seg_off, int rows, int H, int Fn,
                                 void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (rows <= 0) return 0;
     if (!gi || !gh || !hx_prev || !hx_new || !seg_off || ldg < 3 * H || ldh < H + Fn)
         return GI_EINVAL;
@@ -314,6 +317,7 @@ extern "C" int gi_gru_gates_fwd(float* gi, float* gh, int ldg, const float* hx_p
 extern "C" int gi_gru_gates_bwd(float* gi, float* gh, int ldg, const float* hx_prev, int ldh,
                                 const float* dh_new, float* dh_prev, int lddh, const int* seg_off,
                                 int rows, int H, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (rows <= 0) return 0;
     if (!gi || !gh || !hx_prev || !dh_new || !dh_prev || !seg_off || ldg < 3 * H || lddh < H)
         return GI_EINVAL;
@@ -328,6 +332,7 @@ extern "C" int gi_gather_readout_fwd(const float* en, const float* emb, int ld, 
                                      const int* node_mask, int B, int N, int G, float big,
                                      float* out0, int ld0, float* out1, int ld1, float* out2,
                                      int ld2, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (B <= 0) return 0;
     if (!en || !emb || !cidx || !node_mask || N <= 0 || N > GI_MAX_NODES || G <= 0 || ld < G)
         return GI_EINVAL;
@@ -340,6 +345,7 @@ extern "C" int gi_gather_readout_bwd(float* en, float* emb, int ld, const int* c
                                      const int* node_mask, int B, int N, int G, int S, float big,
                                      const float* dg0, int ld0, const float* dg1, int ld1,
                                      const float* dg2, int ld2, float* zpart, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (B <= 0) return 0;
     if (!en || !emb || !cidx || !node_mask || !zpart || N <= 0 || N > GI_MAX_NODES || G <= 0)
         return GI_EINVAL;
@@ -350,6 +356,7 @@ extern "C" int gi_gather_readout_bwd(float* en, float* emb, int ld, const int* c
 
 extern "C" int gi_expand_slots(const float* t1, int ldt, const int* cidx, int B, int N, int W,
                                float* cat, int ldc, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (B <= 0) return 0;
     if (!t1 || !cidx || !cat || N <= 0 || W <= 0 || ldt < W || ldc < N * W) return GI_EINVAL;
     const long long total = (long long)B * N * W;
@@ -360,6 +367,7 @@ extern "C" int gi_expand_slots(const float* t1, int ldt, const int* cidx, int B,
 
 extern "C" int gi_compress_slots(float* t1, int ldt, const int* cidx, int B, int N, int W, int S,
                                  const float* dcat, int ldc, float* zpart, int ldz, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (B <= 0) return 0;
     if (!t1 || !cidx || !dcat || !zpart || N <= 0 || W <= 0 || ldz < W) return GI_EINVAL;
     hipLaunchKernelGGL(compress_slots_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, t1, ldt,
@@ -369,6 +377,7 @@ extern "C" int gi_compress_slots(float* t1, int ldt, const int* cidx, int B, int
 
 extern "C" int gi_colsum(const float* part, int ldp, int rows, int cols, const float* y,
                          float* out, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (cols <= 0) return 0;
     if (!part || !out || rows < 0) return GI_EINVAL;
     hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream,
@@ -377,6 +386,7 @@ extern "C" int gi_colsum(const float* part, int ldp, int rows, int cols, const f
 }
 
 extern "C" int gi_reduce_slabs(const gi_reduce_desc* descs, int n_desc, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (n_desc <= 0) return 0;
     if (!descs) return GI_EINVAL;
     for (int base = 0; base < n_desc; base += GI_REDUCE_MAX) {

@@ -11,6 +11,12 @@ import ctypes as C
 import os
 import subprocess
 
+# torch must be imported BEFORE the shared object is dlopen'ed: torch ships its own
+# libamdhip64.so, and the kernels here are enqueued on torch's streams, so both must resolve to the
+# same HIP runtime instance (loading ours first binds /opt/rocm's copy and every launch then
+# fails with hipErrorNoDevice).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgraphinvent_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
@@ -38,7 +44,7 @@ class GemmParams(C.Structure):
                 ("ngroups", ci), ("nsplit", ci), ("max_group_rows", ci), ("ones_col", ci),
                 ("c_split_stride", cll),
                 ("Bg", vp * GI_MAX_GROUPS), ("biasg", vp * GI_MAX_GROUPS),
-                ("Cg", vp * GI_MAX_GROUPS)]
+                ("Cg", vp * GI_MAX_GROUPS), ("gsplit", ci * GI_MAX_GROUPS)]
 
 
 class ReduceDesc(C.Structure):

@@ -128,7 +128,7 @@ def compact(nodes: torch.Tensor, edges: torch.Tensor, H: int):
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, flags=0, bias=None, act=None, ldact=0,
          a_idx=None, b_idx=None, a_major=False, b_major=False, tm=1, tn=1, grp_off=None,
          ngroups=0, max_group_rows=0, Bg=(), biasg=(), Cg=(), nsplit=1, c_split_stride=0,
-         ones_col=-1):
+         ones_col=-1, gsplit=()):
     lib = L.load()
     p = L.GemmParams()
     p.A, p.B, p.C = _ptr(A), _ptr(B), _ptr(C_out)
@@ -144,6 +144,8 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, flags=0, bias=None, act=None, l
         p.biasg[i] = _ptr(t)
     for i, t in enumerate(Cg):
         p.Cg[i] = _ptr(t)
+    for i in range(ngroups):
+        p.gsplit[i] = gsplit[i] if gsplit else nsplit
     L.check(lib.gi_gemm(C.byref(p), _stream()), "gi_gemm")
 
 

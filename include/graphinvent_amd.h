@@ -93,6 +93,7 @@ typedef struct gi_gemm_params {
     int ones_col;                         /* B stored column that reads as 1.0 (bias-grad column), -1 = none */
     long long c_split_stride;             /* floats between split slabs */
     const float* Bg[GI_MAX_GROUPS]; const float* biasg[GI_MAX_GROUPS]; float* Cg[GI_MAX_GROUPS];
+    int gsplit[GI_MAX_GROUPS];            /* grouped split-K: slabs of group g (>= 1 each); nsplit ignored */
 } gi_gemm_params;
 
 int gi_gemm(const gi_gemm_params* p, void* stream);

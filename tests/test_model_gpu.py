@@ -173,8 +173,13 @@ def test_fixture_batches_vs_oracle(golden_dir, split, rows):
     assert rel(out[live], o32[live]) < TOL
     assert rel(out[masked], o32[masked]) < 5e-3
     assert abs(loss - float(l32)) < 1e-3 * abs(float(l32))
+    # batches with fully-masked graphs: a 1/16 energy-quantisation flip or a SELU sign flip moves
+    # single tensors by ~1e-2 of their max in either implementation -> global L2 + gross-error cap
+    num = sum(float((grads[k].double() - g32[k].double()).pow(2).sum()) for k in grads)
+    den = sum(float(g32[k].double().pow(2).sum()) for k in grads)
+    assert (num / den) ** 0.5 < 5e-3, (num / den) ** 0.5
     worst = max((rel(grads[k], g32[k]), k) for k in grads)
-    assert worst[0] < 5e-3, worst
+    assert worst[0] < 5e-2, worst
 
 
 def _live_only(n8, e8, a8):
@@ -210,21 +215,31 @@ def test_full_size_parity_vs_fp32_and_fp64_oracle(shape, B, over):
     (o32, l32, g32), (o64, l64, g64) = _oracle_both(cfg, P, n8, e8, a8)
     assert rel(out, o32) < TOL and rel(out, o64) < TOL
     assert abs(loss - float(l32)) < TOL * abs(float(l32))
-    ref_noise = max(rel(g32[k], g64[k]) for k in g64)
-    hip_err = max((rel(grads[k], g64[k]), k) for k in g64)
-    assert hip_err[0] < max(TOL, 3 * ref_noise), (hip_err, ref_noise)
-    assert hip_err[0] < 2e-2, hip_err
+    # raw gradients: global relative L2 error against the exact (fp64) gradient, next to the
+    # reference-fp32 oracle's own; per-tensor max-norm only as a gross-error cap (a single SELU
+    # sign flip moves small tensors like fConnNet1 by ~1e-2 of their max in either implementation)
+    def l2(ga):
+        num = sum(float((ga[k].double().cpu() - g64[k]).pow(2).sum()) for k in g64)
+        den = sum(float(g64[k].pow(2).sum()) for k in g64)
+        return (num / den) ** 0.5
+    hip_l2, ref_l2 = l2(grads), l2(g32)
+    assert hip_l2 < max(5 * ref_l2, 1e-4) and hip_l2 < 5e-3, (hip_l2, ref_l2)
+    worst = max((rel(grads[k], g64[k]), k) for k in g64)
+    assert worst[0] < 5e-2, worst
 
 
-def test_gradients_strict_with_selu_branch_pinned():
-    """Strict 1e-4 gradient parity at BASELINE config-2 dimensions: the fp64 dataflow model
-    differentiates the same piecewise-smooth branch the HIP forward took (SELU sign pattern read
-    back from the HIP activations), which removes the only discontinuity of the loss."""
-    sh = synthetic.SHAPES["gdb13"]
-    cfg = O.shaped_config(sh["n_atom_types"], sh["n_formal_charge"], sh["max_n_nodes"],
-                          hidden_node_features=128, message_size=128)
+@pytest.mark.parametrize("shape,B,over", [
+    ("gdb13", 256, dict(hidden_node_features=128, message_size=128)),       # BASELINE config 2 dims
+    ("zinc", 64, {}),                                                        # config 3 dims
+])
+def test_gradients_strict_with_selu_branch_pinned(shape, B, over):
+    """Strict 1e-4 gradient parity at BASELINE dimensions: the fp64 dataflow model differentiates
+    the same piecewise-smooth branch the HIP forward took (SELU sign pattern read back from the
+    HIP activations), which removes the only discontinuity of the loss."""
+    sh = synthetic.SHAPES[shape]
+    cfg = O.shaped_config(sh["n_atom_types"], sh["n_formal_charge"], sh["max_n_nodes"], **over)
     P = O.init_params(cfg, seed=4)
-    n8, e8, a8 = _live_only(*synthetic.make_batch(256, **sh, seed=12))
+    n8, e8, a8 = _live_only(*synthetic.make_batch(B, **sh, seed=12))
     model = make_model(cfg, P)
     params = list(model.parameters())
     nodes, edges, tgt = to_dev(n8, e8, a8)
