@@ -21,6 +21,8 @@
 //
 // Pipeline: global -> registers for tile t+1 is issued before the MFMAs of tile t, written to the
 // other LDS buffer after them; one __syncthreads per 32-deep tile.
+#include <string.h>
+
 #include "gi_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -55,7 +57,8 @@ __device__ __forceinline__ v4f gi_fix4(v4f w, int col, int cmax, int ncols, bool
 }
 
 template <int TM, int TN, bool A_MAJOR, bool B_MAJOR>
-__global__ __launch_bounds__(256) void gi_gemm_kernel(const gi_gemm_params p) {
+__device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int bx, const int by,
+                                             const int bz) {
     constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32;
     constexpr int A_LD = A_MAJOR ? BM + 4 : BK + 4;
     constexpr int A_ROWS = A_MAJOR ? BK : BM;
@@ -73,9 +76,9 @@ __global__ __launch_bounds__(256) void gi_gemm_kernel(const gi_gemm_params p) {
 
     // ---- group / split resolution (block-uniform) -------------------------------------------
     const bool splitk = (p.flags & GI_GEMM_SPLITK) != 0;
-    int g = blockIdx.z, s = 0, nsp = p.nsplit;
+    int g = bz, s = 0, nsp = p.nsplit;
     if (splitk) {
-        g = 0; s = blockIdx.z;
+        g = 0; s = bz;
         if (p.ngroups) {                                  // per-group slab counts (work-proportional)
             while (g < p.ngroups - 1 && s >= p.gsplit[g]) { s -= p.gsplit[g]; ++g; }
             nsp = p.gsplit[g];
@@ -99,8 +102,8 @@ __global__ __launch_bounds__(256) void gi_gemm_kernel(const gi_gemm_params p) {
         k_begin = kb;
         Cp += (long long)s * p.c_split_stride;
     }
-    const int m0 = m_begin + blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    const int m0 = m_begin + by * BM;
+    const int n0 = bx * BN;
     if (m0 >= m_end) return;
     const int bcols = (p.ones_col >= 0) ? p.ones_col : p.N;     // real stored columns of a major B
 
@@ -340,23 +343,37 @@ __global__ __launch_bounds__(256) void gi_gemm_kernel(const gi_gemm_params p) {
     }
 }
 
-template <int TM, int TN>
-static int launch_tile(const gi_gemm_params& p, dim3 grid, hipStream_t st) {
-    if (!p.a_major && !p.b_major)
-        hipLaunchKernelGGL((gi_gemm_kernel<TM, TN, false, false>), grid, dim3(256), 0, st, p);
-    else if (!p.a_major && p.b_major)
-        hipLaunchKernelGGL((gi_gemm_kernel<TM, TN, false, true>), grid, dim3(256), 0, st, p);
-    else if (p.a_major && p.b_major)
-        hipLaunchKernelGGL((gi_gemm_kernel<TM, TN, true, true>), grid, dim3(256), 0, st, p);
-    else
-        return GI_EINVAL;
-    return gi_launch_status();
+template <int TM, int TN, bool A_MAJOR, bool B_MAJOR>
+__global__ __launch_bounds__(256) void gi_gemm_kernel(const gi_gemm_params p) {
+    gi_gemm_body<TM, TN, A_MAJOR, B_MAJOR>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-extern "C" int gi_gemm(const gi_gemm_params* pp, void* stream) {
-    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
-    if (!pp) return GI_EINVAL;
-    const gi_gemm_params& p = *pp;
+// Several independent GEMMs of the same tile/layout class in ONE launch ("horizontal fusion"):
+// the sibling MLPs of the readout (4 node-level stacks, 3 graph-level stacks) and the two GRU
+// projections have 16..450 workgroups each — together they fill the 256 CUs and halve the number of
+// launch ramps on the critical path.  Workgroup id -> (problem, x, y, z) through a prefix table.
+#define GI_GEMM_BATCH_MAX 8
+struct GemmBatch {
+    gi_gemm_params p[GI_GEMM_BATCH_MAX];
+    int start[GI_GEMM_BATCH_MAX + 1];          // first workgroup id of every problem
+    int gx[GI_GEMM_BATCH_MAX], gy[GI_GEMM_BATCH_MAX];
+    int n;
+};
+
+template <int TM, int TN, bool A_MAJOR, bool B_MAJOR>
+__global__ __launch_bounds__(256) void gi_gemm_batch_kernel(const GemmBatch b) {
+    int i = 0;
+    const int id = blockIdx.x;
+    while (i < b.n - 1 && id >= b.start[i + 1]) ++i;
+    const int local = id - b.start[i];
+    const int gx = b.gx[i], gxy = gx * b.gy[i];
+    const int bz = local / gxy;
+    const int rem = local - bz * gxy;
+    const int by = rem / gx;
+    gi_gemm_body<TM, TN, A_MAJOR, B_MAJOR>(b.p[i], rem - by * gx, by, bz);
+}
+
+static int validate(const gi_gemm_params& p) {
     if (p.M < 0 || p.N <= 0 || p.K < 0 || p.nsplit < 1 || p.ngroups < 0 ||
         p.ngroups > GI_MAX_GROUPS)
         return GI_EINVAL;
@@ -365,25 +382,92 @@ extern "C" int gi_gemm(const gi_gemm_params* pp, void* stream) {
     const bool splitk = (p.flags & GI_GEMM_SPLITK) != 0;
     if (p.ngroups && !p.grp_off) return GI_EINVAL;
     if (!splitk && p.nsplit != 1) return GI_EINVAL;
+    if (p.a_major && !p.b_major) return GI_EINVAL;
+    if (!((p.tm == 1 && p.tn == 1) || (p.tm == 1 && p.tn == 2) || (p.tm == 2 && p.tn == 2)))
+        return GI_EINVAL;
+    // rows narrower than one 16-byte vector must be stored padded to 4 floats
+    if (!p.a_major && p.K < 4 && p.lda < 4) return GI_EINVAL;
+    if (!p.b_major && p.K < 4 && p.ldb < 4) return GI_EINVAL;
+    if (p.a_major && p.M < 4 && p.lda < 4) return GI_EINVAL;
+    if (p.b_major && p.N < 4 && p.ldb < 4) return GI_EINVAL;
+    if (splitk && p.ngroups)
+        for (int g = 0; g < p.ngroups; ++g)
+            if (p.gsplit[g] < 1) return GI_EINVAL;
+    return 0;
+}
+
+// grid of one problem; x*y*z == 0 means "nothing to launch"
+static dim3 problem_grid(const gi_gemm_params& p) {
+    const bool splitk = (p.flags & GI_GEMM_SPLITK) != 0;
     const int BM = 64 * p.tm, BN = 64 * p.tn;
     const int rows = splitk ? p.M : (p.ngroups ? p.max_group_rows : p.M);
-    if (rows <= 0) return 0;
+    if (rows <= 0) return dim3(0, 0, 0);
     const int groups = p.ngroups ? p.ngroups : 1;
     int zsplit = p.nsplit;
     if (splitk && p.ngroups) {
         zsplit = 0;
-        for (int g = 0; g < p.ngroups; ++g) {
-            if (p.gsplit[g] < 1) return GI_EINVAL;
-            zsplit += p.gsplit[g];
-        }
+        for (int g = 0; g < p.ngroups; ++g) zsplit += p.gsplit[g];
     }
-    dim3 grid(gi_cdiv(p.N, BN), gi_cdiv(rows, BM), splitk ? zsplit : groups);
+    return dim3(gi_cdiv(p.N, BN), gi_cdiv(rows, BM), splitk ? zsplit : groups);
+}
+
+#define GI_DISPATCH(KERNEL, TMV, TNV, GRID, ARG)                                                   \
+    do {                                                                                           \
+        if (!am && !bm) hipLaunchKernelGGL((KERNEL<TMV, TNV, false, false>), GRID, dim3(256), 0, st, ARG); \
+        else if (!am && bm) hipLaunchKernelGGL((KERNEL<TMV, TNV, false, true>), GRID, dim3(256), 0, st, ARG); \
+        else hipLaunchKernelGGL((KERNEL<TMV, TNV, true, true>), GRID, dim3(256), 0, st, ARG);      \
+    } while (0)
+
+extern "C" int gi_gemm(const gi_gemm_params* pp, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
+    if (!pp) return GI_EINVAL;
+    const gi_gemm_params& p = *pp;
+    const int rc = validate(p);
+    if (rc) return rc;
+    const dim3 grid = problem_grid(p);
+    if (grid.x == 0) return 0;
     if (grid.y > 65535u || grid.z > 65535u) return GI_ELIMIT;
     hipStream_t st = (hipStream_t)stream;
     // useful flops of this launch (real dims; for grouped / split launches M resp. K is the total)
     GiProfScope prof(st, GI_PROF_GEMM, 2.0 * (double)p.M * (double)p.N * (double)p.K);
-    if (p.tm == 1 && p.tn == 1) return launch_tile<1, 1>(p, grid, st);
-    if (p.tm == 1 && p.tn == 2) return launch_tile<1, 2>(p, grid, st);
-    if (p.tm == 2 && p.tn == 2) return launch_tile<2, 2>(p, grid, st);
-    return GI_EINVAL;
+    const bool am = p.a_major, bm = p.b_major;
+    if (p.tm == 1 && p.tn == 1) GI_DISPATCH(gi_gemm_kernel, 1, 1, grid, p);
+    else if (p.tm == 1 && p.tn == 2) GI_DISPATCH(gi_gemm_kernel, 1, 2, grid, p);
+    else GI_DISPATCH(gi_gemm_kernel, 2, 2, grid, p);
+    return gi_launch_status();
+}
+
+extern "C" int gi_gemm_batch(const gi_gemm_params* probs, int n, void* stream) {
+    (void)hipGetLastError();
+    if (!probs || n < 1 || n > GI_GEMM_BATCH_MAX) return GI_EINVAL;
+    if (n == 1) return gi_gemm(probs, stream);
+    GemmBatch b;
+    memset(&b, 0, sizeof(b));
+    double flops = 0;
+    int total = 0, k = 0;
+    for (int i = 0; i < n; ++i) {
+        const gi_gemm_params& p = probs[i];
+        const int rc = validate(p);
+        if (rc) return rc;
+        if (p.tm != probs[0].tm || p.tn != probs[0].tn || p.a_major != probs[0].a_major ||
+            p.b_major != probs[0].b_major)
+            return GI_EINVAL;
+        const dim3 g = problem_grid(p);
+        if (g.x == 0) continue;
+        b.p[k] = p; b.gx[k] = g.x; b.gy[k] = g.y; b.start[k] = total;
+        total += g.x * g.y * g.z;
+        flops += 2.0 * (double)p.M * (double)p.N * (double)p.K;
+        ++k;
+    }
+    if (k == 0) return 0;
+    b.start[k] = total;
+    b.n = k;
+    hipStream_t st = (hipStream_t)stream;
+    GiProfScope prof(st, GI_PROF_GEMM, flops);
+    const bool am = probs[0].a_major, bm = probs[0].b_major;
+    const dim3 grid(total);
+    if (probs[0].tm == 1 && probs[0].tn == 1) GI_DISPATCH(gi_gemm_batch_kernel, 1, 1, grid, b);
+    else if (probs[0].tm == 1 && probs[0].tn == 2) GI_DISPATCH(gi_gemm_batch_kernel, 1, 2, grid, b);
+    else GI_DISPATCH(gi_gemm_batch_kernel, 2, 2, grid, b);
+    return gi_launch_status();
 }

@@ -80,6 +80,7 @@ struct Ws {
         conn1o;
     long long cat_add, cat_conn, gemb, add2_act[MAXL], conn2_act[MAXL], term2_act[MAXL];
     long long dzA, dzC, dzT, dcat_add, dcat_conn, dgemb, zpart_g, zpart_a, zpart_c, dh, dh2, dxe;
+    long long dhb, dhc, dhd;           // per-sibling input gradients of the node-level readout stacks
     long long total;
 };
 
@@ -122,6 +123,7 @@ void make_ws(const Model& m, int S, int E, Ws& w) {
     w.dcat_add = take(B, w.ldCA); w.dcat_conn = take(B, w.ldCC); w.dgemb = take(B, w.ldG);
     w.zpart_g = take(B, w.ldZG); w.zpart_a = take(B, w.ldA); w.zpart_c = take(B, w.ldC);
     w.dh = take(R, w.ldH); w.dh2 = take(R, w.ldH); w.dxe = take(Er, w.ldH);
+    w.dhb = take(R, w.ldH); w.dhc = take(R, w.ldH); w.dhd = take(R, w.ldH);
     w.total = o;
 }
 
@@ -163,10 +165,12 @@ void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {
         const int et = Et ? Et[t] : E / d.Fe;
         add_mlp(m.msg[t], et, d.passes, E > 0 ? (double)et / E : 1.0);
     }
-    add(m.gru_wih, 3 * d.H, d.M, R, d.passes, 1.0);
-    add(m.gru_whh, 3 * d.H, d.H, R, d.passes, 1.0);
-    add_mlp(m.att, R, 1); add_mlp(m.emb, R, 1); add_mlp(m.add1, R, 1); add_mlp(m.conn1, R, 1);
-    add_mlp(m.add2, d.B, 1); add_mlp(m.conn2, d.B, 1); add_mlp(m.term2, d.B, 1);
+    add(m.gru_wih, 3 * d.H, d.M, R, d.passes, 0.5);      // the two GRU projections share a launch
+    add(m.gru_whh, 3 * d.H, d.H, R, d.passes, 0.5);
+    // sibling stacks share launches: slabs in proportion to their output tiles
+    add_mlp(m.att, R, 1, 0.15); add_mlp(m.emb, R, 1, 0.15); add_mlp(m.add1, R, 1, 0.35);
+    add_mlp(m.conn1, R, 1, 0.35);
+    add_mlp(m.add2, d.B, 1, 0.4); add_mlp(m.conn2, d.B, 1, 0.3); add_mlp(m.term2, d.B, 1, 0.3);
     sp.total = o;
 }
 
@@ -321,6 +325,120 @@ void mlp_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, const Mlp* mlps
     }
 }
 
+// ---- batched ("horizontally fused") execution of sibling MLPs -----------------------------------
+// The readout's four node-level stacks (att, emb, fAddNet1, fConnNet1), its three graph-level
+// stacks (fAddNet2, fConnNet2, fTermNet2) and the two GRU projections are mutually independent;
+// layer l of every sibling goes into ONE gi_gemm_batch launch (and in backward one wgrad launch +
+// one dgrad launch per layer level).
+struct MlpJob {
+    const Mlp* mlp;
+    const float* X; int ldx; int rows;           // input (first `fan_in(0)` columns are used)
+    const long long* acts; int ldh;              // hidden activation buffers (ws offsets)
+    float* out; int ldout;                       // forward: last layer's destination
+    const float* Zlast; int ldz;                 // backward: dZ of the last layer
+    float* dX; int lddx; int dx_cols; bool accumulate;   // backward: first-layer input gradient (or null)
+};
+
+struct Batch {
+    gi_gemm_params p[8];
+    int n = 0;
+    gi_gemm_params& next() { gemm_defaults(p[n]); return p[n++]; }
+};
+
+void flush_batch(Run& r, Batch& b, bool wgrad) {
+    if (!r.ok() || b.n == 0) { b.n = 0; return; }
+    if (!wgrad) {                               // common tile for the whole launch
+        long long b11 = 0;
+        for (int i = 0; i < b.n; ++i) b11 += (long long)gi_cdiv(b.p[i].M, 64) * gi_cdiv(b.p[i].N, 64);
+        const int tn = b11 > 8192 ? 2 : 1;
+        for (int i = 0; i < b.n; ++i) { b.p[i].tm = 1; b.p[i].tn = tn; }
+    }
+    r.chk(gi_gemm_batch(b.p, b.n, r.st));
+    b.n = 0;
+}
+
+void add_fwd(Batch& b, Run& r, const float* W, const float* bias, int in, int out, const float* X,
+             int ldx, int rows, float* Y, int ldy, bool selu) {
+    if (rows <= 0) return;
+    gi_gemm_params& p = b.next();
+    p.A = X; p.lda = ldx; p.B = W; p.ldb = in; p.bias = bias; p.C = Y; p.ldc = ldy;
+    p.M = rows; p.N = out; p.K = in;
+    p.flags = GI_EPI_BIAS | (selu ? GI_EPI_SELU : 0);
+}
+
+void add_dgrad(Batch& b, const float* W, int n_out, int n_in, int ncols, const float* dZ, int lddz,
+               int rows, float* dX, int lddx, const float* act, int ldact, bool accumulate) {
+    if (rows <= 0) return;
+    gi_gemm_params& p = b.next();
+    p.A = dZ; p.lda = lddz; p.B = W; p.ldb = n_in; p.b_major = 1; p.C = dX; p.ldc = lddx;
+    p.M = rows; p.N = ncols; p.K = n_out;
+    p.act = act; p.ldact = ldact;
+    p.flags = (act ? GI_EPI_DSELU : 0) | (accumulate ? GI_EPI_ACCUM : 0);
+}
+
+void add_wgrad(Batch& b, SlabPlan& sp, float* slabs, int widx, const float* dZ, int lddz,
+               const float* X, int ldx, int rows) {
+    SlabEntry& e = sp.e[widx];
+    gi_gemm_params& p = b.next();
+    p.A = dZ; p.lda = lddz; p.a_major = 1;
+    p.B = X; p.ldb = ldx; p.b_major = 1;
+    p.M = e.n_out; p.N = e.n_in + 1; p.K = rows; p.ldc = e.ld;
+    p.ones_col = e.n_in;
+    p.flags = GI_GEMM_SPLITK;
+    p.nsplit = e.nsplit; p.c_split_stride = e.stride;
+    p.tm = 1; p.tn = 1;
+    p.C = slabs + e.off + (long long)e.done * e.nsplit * e.stride;
+    e.done++;
+}
+
+void mlp_jobs_forward(Run& r, float* ws, const MlpJob* jobs, int n) {
+    int maxL = 0;
+    for (int j = 0; j < n; ++j) maxL = std::max(maxL, jobs[j].mlp->layers());
+    for (int l = 0; l < maxL; ++l) {
+        Batch b;
+        for (int j = 0; j < n; ++j) {
+            const MlpJob& q = jobs[j];
+            const int L = q.mlp->layers();
+            if (l >= L) continue;
+            const float* src = (l == 0) ? q.X : ws + q.acts[l - 1];
+            float* dst = (l == L - 1) ? q.out : ws + q.acts[l];
+            add_fwd(b, r, r.P[q.mlp->w(l)], r.P[q.mlp->b(l)], q.mlp->fan_in(l), q.mlp->fan_out(l), src,
+                    l == 0 ? q.ldx : q.ldh, q.rows, dst, l == L - 1 ? q.ldout : q.ldh, true);
+        }
+        flush_batch(r, b, false);
+    }
+}
+
+// Layers are aligned from the END (step s handles layer L_j-1-s of job j).  Hidden activation
+// buffers are overwritten with their dZ; first-layer input gradients go to the jobs' (distinct) dX.
+void mlp_jobs_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, const MlpJob* jobs, int n) {
+    int maxL = 0;
+    for (int j = 0; j < n; ++j) maxL = std::max(maxL, jobs[j].mlp->layers());
+    for (int s = 0; s < maxL; ++s) {
+        Batch bw, bd;
+        for (int j = 0; j < n; ++j) {
+            const MlpJob& q = jobs[j];
+            const int L = q.mlp->layers(), l = L - 1 - s;
+            if (l < 0) continue;
+            const float* dZ = (l == L - 1) ? q.Zlast : ws + q.acts[l];
+            const int lddz = (l == L - 1) ? q.ldz : q.ldh;
+            const float* Xl = (l == 0) ? q.X : ws + q.acts[l - 1];
+            add_wgrad(bw, sp, slabs, q.mlp->w(l), dZ, lddz, Xl, l == 0 ? q.ldx : q.ldh, q.rows);
+            const float* W = r.P[q.mlp->w(l)];
+            if (l > 0) {
+                float* prev = ws + q.acts[l - 1];
+                add_dgrad(bd, W, q.mlp->fan_out(l), q.mlp->fan_in(l), q.mlp->fan_in(l), dZ, lddz,
+                          q.rows, prev, q.ldh, prev, q.ldh, false);
+            } else if (q.dX) {
+                add_dgrad(bd, W, q.mlp->fan_out(0), q.mlp->fan_in(0), q.dx_cols, dZ, lddz, q.rows,
+                          q.dX, q.lddx, nullptr, 0, q.accumulate);
+            }
+        }
+        flush_batch(r, bw, true);
+        flush_batch(r, bd, false);
+    }
+}
+
 }  // namespace
 
 // ================================ C ABI ==========================================================
@@ -410,7 +528,6 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
     const int R = w.R;
     int maxEt = 0;
     for (int t = 0; t < d.Fe; ++t) maxEt = std::max(maxEt, Et[t]);
-    const Grp none{0, nullptr, 0};
     const Grp bytype{d.Fe, gfix + L.type_off, maxEt};
     const int* seg_off = gfix + L.seg_off;
     const int* cidx = gfix + L.cidx;
@@ -425,31 +542,40 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
         // a_v = sum of incoming messages (:141)
         r.chk(gi_seg_sum(ws + w.m[p], w.ldM, in_perm, seg_off, R, d.M, ws + w.agg[p], w.ldM, 0,
                          r.st));
-        // GRU update (gnn/mpnn.py:296-297)
-        linear_plain(r, params[m.gru_wih], params[m.gru_bih], d.M, 3 * d.H, ws + w.agg[p], w.ldM,
-                     R, ws + w.gi[p], w.ld3H);
-        linear_plain(r, params[m.gru_whh], params[m.gru_bhh], d.H, 3 * d.H, hx, w.ldhx, R,
-                     ws + w.gh[p], w.ld3H);
+        // GRU update (gnn/mpnn.py:296-297): both input projections in one launch
+        {
+            Batch b;
+            add_fwd(b, r, params[m.gru_wih], params[m.gru_bih], d.M, 3 * d.H, ws + w.agg[p], w.ldM, R,
+                    ws + w.gi[p], w.ld3H, false);
+            add_fwd(b, r, params[m.gru_whh], params[m.gru_bhh], d.H, 3 * d.H, hx, w.ldhx, R,
+                    ws + w.gh[p], w.ld3H, false);
+            flush_batch(r, b, false);
+        }
         r.chk(gi_gru_gates_fwd(ws + w.gi[p], ws + w.gh[p], w.ld3H, hx, ws + w.hx[p + 1], w.ldhx,
                                seg_off, R, d.H, d.Fn, r.st));
     }
     // ---- readout (gnn/mpnn.py:299-303) -----------------------------------------------------------
     const float* hx = ws + w.hx[d.passes];
-    mlp_forward(r, ws, &m.att, none, hx, w.ldhx, nullptr, R, w.att_act, w.ldAtt, ws + w.en, w.ldG);
-    mlp_forward(r, ws, &m.emb, none, hx, w.ldhx, nullptr, R, w.emb_act, w.ldEmb, ws + w.embo, w.ldG);
-    mlp_forward(r, ws, &m.add1, none, hx, w.ldhx, nullptr, R, w.add1_act, w.ldM1, ws + w.add1o, w.ldA);
-    mlp_forward(r, ws, &m.conn1, none, hx, w.ldhx, nullptr, R, w.conn1_act, w.ldM1, ws + w.conn1o, w.ldC);
+    {   // the four node-level stacks, layer by layer in shared launches
+        MlpJob jobs[4] = {};
+        jobs[0] = {&m.att, hx, w.ldhx, R, w.att_act, w.ldAtt, ws + w.en, w.ldG};
+        jobs[1] = {&m.emb, hx, w.ldhx, R, w.emb_act, w.ldEmb, ws + w.embo, w.ldG};
+        jobs[2] = {&m.add1, hx, w.ldhx, R, w.add1_act, w.ldM1, ws + w.add1o, w.ldA};
+        jobs[3] = {&m.conn1, hx, w.ldhx, R, w.conn1_act, w.ldM1, ws + w.conn1o, w.ldC};
+        mlp_jobs_forward(r, ws, jobs, 4);
+    }
     r.chk(gi_gather_readout_fwd(ws + w.en, ws + w.embo, w.ldG, cidx, mask, d.B, d.N, d.G,
                                 d.big_positive, ws + w.cat_add + m.NA, w.ldCA,
                                 ws + w.cat_conn + m.NC, w.ldCC, ws + w.gemb, w.ldG, r.st));
     r.chk(gi_expand_slots(ws + w.add1o, w.ldA, cidx, d.B, d.N, d.A, ws + w.cat_add, w.ldCA, r.st));
     r.chk(gi_expand_slots(ws + w.conn1o, w.ldC, cidx, d.B, d.N, d.C, ws + w.cat_conn, w.ldCC, r.st));
-    mlp_forward(r, ws, &m.add2, none, ws + w.cat_add, w.ldCA, nullptr, d.B, w.add2_act, w.ldM2,
-                out, ldout);
-    mlp_forward(r, ws, &m.conn2, none, ws + w.cat_conn, w.ldCC, nullptr, d.B, w.conn2_act, w.ldM2,
-                out + m.NA, ldout);
-    mlp_forward(r, ws, &m.term2, none, ws + w.gemb, w.ldG, nullptr, d.B, w.term2_act, w.ldM2,
-                out + m.NA + m.NC, ldout);
+    {   // the three graph-level stacks write straight into the logits
+        MlpJob jobs[3] = {};
+        jobs[0] = {&m.add2, ws + w.cat_add, w.ldCA, d.B, w.add2_act, w.ldM2, out, ldout};
+        jobs[1] = {&m.conn2, ws + w.cat_conn, w.ldCC, d.B, w.conn2_act, w.ldM2, out + m.NA, ldout};
+        jobs[2] = {&m.term2, ws + w.gemb, w.ldG, d.B, w.term2_act, w.ldM2, out + m.NA + m.NC, ldout};
+        mlp_jobs_forward(r, ws, jobs, 3);
+    }
     return r.rc;
 }
 
@@ -478,7 +604,6 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
     const int R = w.R;
     int maxEt = 0;
     for (int t = 0; t < d.Fe; ++t) maxEt = std::max(maxEt, Et[t]);
-    const Grp none{0, nullptr, 0};
     const Grp bytype{d.Fe, gfix + L.type_off, maxEt};
     const int* seg_off = gfix + L.seg_off;
     const int* src_off = gfix + L.src_off;
@@ -492,12 +617,16 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
                            NC, r.st));
     r.chk(gi_selu_bwd_rows(d_out + NA + NC, lddout, nullptr, y_out + NA + NC, ldout, ws + w.dzT, 4,
                            d.B, 1, r.st));
-    mlp_backward(r, ws, sp, slabs, &m.add2, none, ws + w.cat_add, w.ldCA, nullptr, d.B, w.add2_act,
-                 w.ldM2, ws + w.dzA, w.ldNA, ws + w.dcat_add, w.ldCA, NA + d.G, false);
-    mlp_backward(r, ws, sp, slabs, &m.conn2, none, ws + w.cat_conn, w.ldCC, nullptr, d.B,
-                 w.conn2_act, w.ldM2, ws + w.dzC, w.ldNC, ws + w.dcat_conn, w.ldCC, NC + d.G, false);
-    mlp_backward(r, ws, sp, slabs, &m.term2, none, ws + w.gemb, w.ldG, nullptr, d.B, w.term2_act,
-                 w.ldM2, ws + w.dzT, 4, ws + w.dgemb, w.ldG, d.G, false);
+    {
+        MlpJob jobs[3] = {};
+        jobs[0] = {&m.add2, ws + w.cat_add, w.ldCA, d.B, w.add2_act, w.ldM2, nullptr, 0,
+                   ws + w.dzA, w.ldNA, ws + w.dcat_add, w.ldCA, NA + d.G, false};
+        jobs[1] = {&m.conn2, ws + w.cat_conn, w.ldCC, d.B, w.conn2_act, w.ldM2, nullptr, 0,
+                   ws + w.dzC, w.ldNC, ws + w.dcat_conn, w.ldCC, NC + d.G, false};
+        jobs[2] = {&m.term2, ws + w.gemb, w.ldG, d.B, w.term2_act, w.ldM2, nullptr, 0,
+                   ws + w.dzT, 4, ws + w.dgemb, w.ldG, d.G, false};
+        mlp_jobs_backward(r, ws, sp, slabs, jobs, 3);
+    }
     // ---- gather + tier-1 glue: dZ of the last att/emb/add1/conn1 layers, in place ----------------
     r.chk(gi_gather_readout_bwd(ws + w.en, ws + w.embo, w.ldG, cidx, mask, d.B, d.N, d.G, S,
                                 d.big_positive, ws + w.dgemb, w.ldG, ws + w.dcat_add + NA, w.ldCA,
@@ -518,30 +647,46 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
     const float* hxP = ws + w.hx[d.passes];
     float* dh = ws + w.dh;
     float* dh2 = ws + w.dh2;
-    mlp_backward(r, ws, sp, slabs, &m.add1, none, hxP, w.ldhx, nullptr, R, w.add1_act, w.ldM1,
-                 ws + w.add1o, w.ldA, dh, w.ldH, d.H, false);
-    mlp_backward(r, ws, sp, slabs, &m.conn1, none, hxP, w.ldhx, nullptr, R, w.conn1_act, w.ldM1,
-                 ws + w.conn1o, w.ldC, dh, w.ldH, d.H, true);
-    mlp_backward(r, ws, sp, slabs, &m.emb, none, hxP, w.ldhx, nullptr, R, w.emb_act, w.ldEmb,
-                 ws + w.embo, w.ldG, dh, w.ldH, d.H, true);
-    mlp_backward(r, ws, sp, slabs, &m.att, none, hxP, w.ldhx, nullptr, R, w.att_act, w.ldAtt,
-                 ws + w.en, w.ldG, dh, w.ldH, d.H, true);
+    float* dhb = ws + w.dhb;
+    float* dhc = ws + w.dhc;
+    float* dhd = ws + w.dhd;
+    {   // every sibling writes its own d h; the GRU-gate backward of the last pass sums the four
+        MlpJob jobs[4] = {};
+        jobs[0] = {&m.add1, hxP, w.ldhx, R, w.add1_act, w.ldM1, nullptr, 0, ws + w.add1o, w.ldA, dh,
+                   w.ldH, d.H, false};
+        jobs[1] = {&m.conn1, hxP, w.ldhx, R, w.conn1_act, w.ldM1, nullptr, 0, ws + w.conn1o, w.ldC,
+                   dhb, w.ldH, d.H, false};
+        jobs[2] = {&m.emb, hxP, w.ldhx, R, w.emb_act, w.ldEmb, nullptr, 0, ws + w.embo, w.ldG, dhc,
+                   w.ldH, d.H, false};
+        jobs[3] = {&m.att, hxP, w.ldhx, R, w.att_act, w.ldAtt, nullptr, 0, ws + w.en, w.ldG, dhd,
+                   w.ldH, d.H, false};
+        mlp_jobs_backward(r, ws, sp, slabs, jobs, 4);
+    }
     // ---- message passes, reversed -------------------------------------------------------------------
     for (int p = d.passes - 1; p >= 0; --p) {
         const float* hx = ws + w.hx[p];
         float* gi = ws + w.gi[p];
         float* gh = ws + w.gh[p];
         float* agg = ws + w.agg[p];
-        r.chk(gi_gru_gates_bwd(gi, gh, w.ld3H, hx, w.ldhx, dh, dh2, w.ldH, seg_off, R, d.H, r.st));
-        const int wih = m.gru_wih, whh = m.gru_whh;
-        linear_wgrad(r, sp, slabs, &wih, none, gi, w.ld3H, agg, w.ldM, nullptr, R);
-        linear_wgrad(r, sp, slabs, &whh, none, gh, w.ld3H, hx, w.ldhx, nullptr, R);
-        // d agg = d gi W_ih  (in place over agg: its wgrad above is already enqueued)
-        linear_dgrad(r, nullptr, params[m.gru_wih], none, 3 * d.H, d.M, d.M, gi, w.ld3H, R, agg,
-                     w.ldM, nullptr, 0, false);
-        if (p > 0)
-            linear_dgrad(r, nullptr, params[m.gru_whh], none, 3 * d.H, d.H, d.H, gh, w.ld3H, R,
-                         dh2, w.ldH, nullptr, 0, true);
+        const bool last = (p == d.passes - 1);
+        r.chk(gi_gru_gates_bwd(gi, gh, w.ld3H, hx, w.ldhx, dh, last ? dhb : nullptr,
+                               last ? dhc : nullptr, last ? dhd : nullptr, dh2, w.ldH, seg_off, R,
+                               d.H, r.st));
+        {
+            Batch bw;
+            add_wgrad(bw, sp, slabs, m.gru_wih, gi, w.ld3H, agg, w.ldM, R);
+            add_wgrad(bw, sp, slabs, m.gru_whh, gh, w.ld3H, hx, w.ldhx, R);
+            flush_batch(r, bw, true);
+            // d agg = d gi W_ih (in place over agg: its wgrad above is already enqueued);
+            // d h_prev += d gh W_hh
+            Batch bd;
+            add_dgrad(bd, params[m.gru_wih], 3 * d.H, d.M, d.M, gi, w.ld3H, R, agg, w.ldM, nullptr, 0,
+                      false);
+            if (p > 0)
+                add_dgrad(bd, params[m.gru_whh], 3 * d.H, d.H, d.H, gh, w.ld3H, R, dh2, w.ldH, nullptr,
+                          0, true);
+            flush_batch(r, bd, false);
+        }
         if (E > 0) {
             // d m_e = d agg[dst(e)] * selu'(m_e)   (backward of the segmented sum + last SELU)
             r.chk(gi_selu_bwd_rows(agg, w.ldM, e_dst, ws + w.m[p], w.ldM, ws + w.m[p], w.ldM, E,

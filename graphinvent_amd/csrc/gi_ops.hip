@@ -65,14 +65,18 @@ __global__ __launch_bounds__(256) void gru_gates_fwd_kernel(
 
 __global__ __launch_bounds__(256) void gru_gates_bwd_kernel(
     float* gi, float* gh, int ldg, const float* __restrict__ hx_prev, int ldh,
-    const float* __restrict__ dh_new, float* __restrict__ dh_prev, int lddh,
+    const float* __restrict__ dh_new, const float* __restrict__ dh_b, const float* __restrict__ dh_c,
+    const float* __restrict__ dh_d, float* __restrict__ dh_prev, int lddh,
     const int* __restrict__ seg_off, int rows, int H) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int row = (int)(t / H), j = (int)(t - (long long)row * H);
     if (row >= rows) return;
     float* g = gi + (long long)row * ldg;
     float* h = gh + (long long)row * ldg;
-    const float d = dh_new[(long long)row * lddh + j];
+    float d = dh_new[(long long)row * lddh + j];             // + the sibling stacks' contributions
+    if (dh_b) d += dh_b[(long long)row * lddh + j];
+    if (dh_c) d += dh_c[(long long)row * lddh + j];
+    if (dh_d) d += dh_d[(long long)row * lddh + j];
     if (seg_off[row + 1] > seg_off[row]) {
         const float r = g[j], z = g[H + j], n = g[2 * H + j], hn = h[2 * H + j];
         const float hp = hx_prev[(long long)row * ldh + j];
@@ -315,7 +319,8 @@ extern "C" int gi_gru_gates_fwd(float* gi, float* gh, int ldg, const float* hx_p
 }
 
 extern "C" int gi_gru_gates_bwd(float* gi, float* gh, int ldg, const float* hx_prev, int ldh,
-                                const float* dh_new, float* dh_prev, int lddh, const int* seg_off,
+                                const float* dh_new, const float* dh_b, const float* dh_c,
+                                const float* dh_d, float* dh_prev, int lddh, const int* seg_off,
                                 int rows, int H, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (rows <= 0) return 0;
@@ -323,8 +328,8 @@ extern "C" int gi_gru_gates_bwd(float* gi, float* gh, int ldg, const float* hx_p
         return GI_EINVAL;
     const long long threads = (long long)rows * H;
     hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, gi, gh, ldg, hx_prev, ldh, dh_new, dh_prev, lddh,
-                       seg_off, rows, H);
+                       (hipStream_t)stream, gi, gh, ldg, hx_prev, ldh, dh_new, dh_b, dh_c, dh_d,
+                       dh_prev, lddh, seg_off, rows, H);
     return gi_launch_status();
 }
 

@@ -66,10 +66,11 @@ SIGNATURES = {
     "gi_compact_count": (ci, [vp, vp, ci, ci, ci, ci, vp, vp]),
     "gi_compact_fill": (ci, [vp, ci, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp]),
     "gi_gemm": (ci, [C.POINTER(GemmParams), vp]),
+    "gi_gemm_batch": (ci, [C.POINTER(GemmParams), ci, vp]),
     "gi_seg_sum": (ci, [vp, ci, vp, vp, ci, ci, vp, ci, ci, vp]),
     "gi_selu_bwd_rows": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, vp]),
     "gi_gru_gates_fwd": (ci, [vp, vp, ci, vp, vp, ci, vp, ci, ci, ci, vp]),
-    "gi_gru_gates_bwd": (ci, [vp, vp, ci, vp, ci, vp, vp, ci, vp, ci, ci, vp]),
+    "gi_gru_gates_bwd": (ci, [vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, vp]),
     "gi_gather_readout_fwd": (ci, [vp, vp, ci, vp, vp, ci, ci, ci, C.c_float,
                                    vp, ci, vp, ci, vp, ci, vp]),
     "gi_gather_readout_bwd": (ci, [vp, vp, ci, vp, vp, ci, ci, ci, ci, C.c_float,

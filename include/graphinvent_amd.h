@@ -97,6 +97,8 @@ typedef struct gi_gemm_params {
 } gi_gemm_params;
 
 int gi_gemm(const gi_gemm_params* p, void* stream);
+/* n (<= 8) independent problems of the same tile shape and operand layouts in ONE launch. */
+int gi_gemm_batch(const gi_gemm_params* problems, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Graph / pointwise kernels
@@ -117,11 +119,12 @@ int gi_selu_bwd_rows(const float* dY, int lddy, const int* idx, const float* Y, 
  * the feature tail [H,H+Fn) copied); gi is overwritten with (r|z|n), gh keeps W_hn h + b_hn. */
 int gi_gru_gates_fwd(float* gi, float* gh, int ldg, const float* hx_prev, float* hx_new, int ldh,
                      const int* seg_off, int rows, int H, int Fn, void* stream);
-/* In: dh_new [rows, lddh]; gi=(r|z|n), gh=(..|..|hn) from forward are overwritten with d gi, d gh;
+/* In: dh_new (+ up to three more partial gradients dh_b/c/d or NULL, all [rows, lddh]);
+ * gi=(r|z|n), gh=(..|..|hn) from forward are overwritten with d gi, d gh;
  * dh_prev = direct part of the gradient to h_prev. */
 int gi_gru_gates_bwd(float* gi, float* gh, int ldg, const float* hx_prev, int ldh,
-                     const float* dh_new, float* dh_prev, int lddh, const int* seg_off,
-                     int rows, int H, void* stream);
+                     const float* dh_new, const float* dh_b, const float* dh_c, const float* dh_d,
+                     float* dh_prev, int lddh, const int* seg_off, int rows, int H, void* stream);
 
 /* K7 gather readout — gnn/modules.py:44-52: g[b,:] = sum_n softmax_n(en[cidx[b,n]] - big*[mask==0]) * emb[cidx[b,n]],
  * written to up to three destinations (tier-2 concat inputs). */
