@@ -7,7 +7,7 @@ bench.py — training graphs/sec of the MI355X-native GGNN hot path (BASELINE.js
 
 A "step" is one full training step of the hot path over one minibatch of synthetic molecular
 graphs already resident in HBM: forward (graph_compact + message passes + readout) -> KL loss ->
-backward -> gradient all-reduce (N > 1) -> Adam -> OneCycleLR, in the order of
+backward -> gradient all-reduce (N > 1) -> Adam (FusedAdam, same math) -> OneCycleLR, in the order of
 Workflow.py:785-796.  Workload = BASELINE.json configs[1]: GGNN, hidden = message = 128, 3 message
 passes, GDB-13-shaped graphs (max_n_nodes 13, 5 atom types x 3 charges, 3 bond types), batch 1000
 PER GPU (weak scaling).  fp32 throughout (the reference's dtype and the parity bar).
@@ -38,6 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from graphinvent_amd import dp, lib, ops, synthetic          # noqa: E402
+from graphinvent_amd.optim import FusedAdam                  # noqa: E402
 from graphinvent_amd.gnn import mpnn                         # noqa: E402
 from graphinvent_amd.loss import apd_kl_loss                 # noqa: E402
 
@@ -162,7 +163,7 @@ def main():
     model = mpnn.GGNN(constants).to(device).train()
     batches = make_batches(rank, device)
     total_steps = args.steps + args.warmup + 16
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4)    # defaults.py:120 init_lr
+    opt = FusedAdam(model.parameters(), lr=1e-4)           # Adam, defaults.py:120 init_lr; one HIP launch/step
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-4, total_steps=total_steps + 1)
     trainer = dp.DataParallel(model, opt, sched, loss_fn=apd_kl_loss)
     trainer.broadcast_parameters()

@@ -5,8 +5,8 @@
 // Integer / byte work, HBM-bound (reads B*N*N*Fe*4 + B*N*Fn*4 bytes once); three launches:
 //   count : one workgroup per graph; adjacency staged in LDS as int8 bond types; per-slot
 //           in/out degrees, per-type in-degrees, activity flags
-//   scan  : one 1024-thread workgroup; exclusive scans over the B*N slots -> compact row ids,
-//           CSR offsets, bond-type bucket offsets, totals (S, E, E_t)
+//   scan  : one 1024-thread workgroup per scanned array; exclusive scans over the B*N slots ->
+//           compact row ids, CSR offsets, bond-type bucket offsets, totals (S, E, E_t); + finish
 //   fill  : one workgroup per graph; edge arrays in bond-type-major order, dst- and src-CSR
 //           permutations (deterministic order), initial node rows
 // Edge enumeration order = row-major nonzero of the adjacency = the reference's edge order, so
@@ -105,44 +105,51 @@ __global__ __launch_bounds__(256) void compact_count_kernel(
 }
 
 // ---- scan -----------------------------------------------------------------------------------
-// exclusive scan of src[0..n) -> dst, returns total (valid in every thread). 1024 threads.
-__device__ int block_exscan(const int* __restrict__ src, int* __restrict__ dst, int n,
-                            int* sh /*[1024]*/) {
-    const int tid = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int lo = min(tid * per, n), hi = min(lo + per, n);
-    int sum = 0;
-    for (int i = lo; i < hi; ++i) sum += src[i];
-    sh[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {           // Hillis-Steele inclusive scan
-        int v = (tid >= off) ? sh[tid - off] : 0;
-        __syncthreads();
-        sh[tid] += v;
-        __syncthreads();
-    }
-    const int total = sh[1023];
-    int run = sh[tid] - sum;
-    for (int i = lo; i < hi; ++i) { const int v = src[i]; dst[i] = run; run += v; }
-    __syncthreads();
-    return total;
-}
-
+// One 1024-thread workgroup per scanned array (3 + Fe arrays, independent), chunks of 1024
+// elements: coalesced load, wave-shuffle inclusive scan + 16 wave totals through LDS, running carry,
+// coalesced store.  Totals go straight to counts[]; a second small kernel builds the compact-row
+// views that depend on several of the scans.
 __global__ __launch_bounds__(1024) void compact_scan_kernel(int ns, int Fe, int* __restrict__ gfix,
                                                             Lay L) {
-    __shared__ int sh[1024];
-    __shared__ int tot[GI_MAX_GROUPS];
-    const int tid = threadIdx.x;
-    const int S = block_exscan(gfix + L.active, gfix + L.cidx, ns, sh);
-    const int E = block_exscan(gfix + L.rowcnt, gfix + L.seg_start, ns, sh);
-    block_exscan(gfix + L.colcnt, gfix + L.src_start, ns, sh);
-    for (int f = 0; f < Fe; ++f) {
-        const int t = block_exscan(gfix + L.rowcnt_t + f * ns, gfix + L.tstart + f * ns, ns, sh);
-        if (tid == 0) tot[f] = t;
-    }
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int* src; int* dst; int* total;
+    if (a == 0) { src = gfix + L.active; dst = gfix + L.cidx; total = gfix + L.counts + 0; }
+    else if (a == 1) { src = gfix + L.rowcnt; dst = gfix + L.seg_start; total = gfix + L.counts + 1; }
+    else if (a == 2) { src = gfix + L.colcnt; dst = gfix + L.src_start; total = nullptr; }
+    else { const int f = a - 3; src = gfix + L.rowcnt_t + f * ns; dst = gfix + L.tstart + f * ns;
+           total = gfix + L.counts + 4 + f; }
+    if (tid == 0) carry_s = 0;
     __syncthreads();
-    // compact-row views: slot_of, seg_off, src_off; inactive slots map to the zero row S
-    for (int slot = tid; slot < ns; slot += 1024) {
+    for (int base = 0; base < ns; base += 1024) {
+        const int i = base + tid;
+        const int v = (i < ns) ? src[i] : 0;
+        int x = v;                                            // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[wid] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wsum[w];
+        const int carry = carry_s;
+        if (i < ns) dst[i] = carry + woff + x - v;            // exclusive
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    if (tid == 0 && total) *total = carry_s;
+}
+
+// compact-row views: slot_of, seg_off, src_off; inactive slots map to the zero row S; type offsets
+__global__ __launch_bounds__(256) void compact_finish_kernel(int ns, int Fe, int* __restrict__ gfix,
+                                                             Lay L) {
+    const int S = gfix[L.counts + 0], E = gfix[L.counts + 1];
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot < ns) {
         if (gfix[L.active + slot]) {
             const int c = gfix[L.cidx + slot];
             gfix[L.slot_of + c] = slot;
@@ -152,16 +159,11 @@ __global__ __launch_bounds__(1024) void compact_scan_kernel(int ns, int Fe, int*
             gfix[L.cidx + slot] = S;
         }
     }
-    if (tid == 0) {
+    if (slot == 0) {
         gfix[L.seg_off + S] = E; gfix[L.seg_off + S + 1] = E;
         gfix[L.src_off + S] = E; gfix[L.src_off + S + 1] = E;
-        gfix[L.counts + 0] = S; gfix[L.counts + 1] = E;
         int run = 0;
-        for (int f = 0; f < Fe; ++f) {
-            gfix[L.type_off + f] = run;
-            gfix[L.counts + 4 + f] = tot[f];
-            run += tot[f];
-        }
+        for (int f = 0; f < Fe; ++f) { gfix[L.type_off + f] = run; run += gfix[L.counts + 4 + f]; }
         for (int f = Fe; f <= GI_MAX_GROUPS; ++f) gfix[L.type_off + f] = run;
     }
 }
@@ -249,7 +251,9 @@ extern "C" int gi_compact_count(const float* nodes, const float* edges, int B, i
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(compact_count_kernel, dim3(B), dim3(256), 0, st, nodes, edges, N, Fn, Fe,
                        gfix, L);
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, st, B * N, Fe, gfix, L);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(3 + Fe), dim3(1024), 0, st, B * N, Fe, gfix, L);
+    hipLaunchKernelGGL(compact_finish_kernel, dim3(gi_cdiv(B * N, 256)), dim3(256), 0, st, B * N, Fe,
+                       gfix, L);
     return gi_launch_status();
 }
 

@@ -1,6 +1,10 @@
 // Graph-structured and pointwise kernels of the GGNN hot path (gfx950).  All HBM/L2-bound
 // streaming kernels: coalesced row reads, 16-byte vectors where the layout allows, no atomics,
 // deterministic summation order.
+#include <math.h>
+
+#include <algorithm>
+
 #include "gi_common.h"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -228,21 +232,94 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
 
 // ---- wgrad slab reduction ----------------------------------------------------------------------
 #define GI_REDUCE_MAX 40
-struct ReduceTable { gi_reduce_desc d[GI_REDUCE_MAX]; };
+struct ReduceTable { gi_reduce_desc d[GI_REDUCE_MAX]; int start[GI_REDUCE_MAX + 1]; int n; };
 
+// one thread per output element (dW[n,k] or db[n]); blocks are dealt to descriptors through a
+// prefix table so big weight matrices get proportionally many workgroups
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceTable tab) {
-    const gi_reduce_desc& d = tab.d[blockIdx.y];
+    int i = 0;
+    const int id = blockIdx.x;
+    while (i < tab.n - 1 && id >= tab.start[i + 1]) ++i;
+    const gi_reduce_desc& d = tab.d[i];
     const int K1 = d.K + 1;
     const long long total = (long long)d.N * K1;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * 256) {
-        const int n = (int)(idx / K1), k = (int)(idx - (long long)n * K1);
-        const float* src = d.slabs + (long long)n * d.ld + k;
-        float s = 0.f;
-        for (int i = 0; i < d.n_slabs; ++i) s += src[(long long)i * d.slab_stride];
-        if (k < d.K) d.dW[(long long)n * d.K + k] = s;
-        else if (d.db) d.db[n] = s;
+    const long long idx = (long long)(id - tab.start[i]) * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int n = (int)(idx / K1), k = (int)(idx - (long long)n * K1);
+    const float* src = d.slabs + (long long)n * d.ld + k;
+    float s0 = 0.f, s1 = 0.f;
+    int j = 0;
+    for (; j + 1 < d.n_slabs; j += 2) {                 // two independent loads in flight
+        s0 += src[(long long)j * d.slab_stride];
+        s1 += src[(long long)(j + 1) * d.slab_stride];
     }
+    if (j < d.n_slabs) s0 += src[(long long)j * d.slab_stride];
+    const float sum = s0 + s1;
+    if (k < d.K) d.dW[(long long)n * d.K + k] = sum;
+    else if (d.db) d.db[n] = sum;
+}
+
+// ---- Adam (torch.optim.Adam semantics, one flat fp32 bucket) ------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   long long n4, float lr, float b1, float b2,
+                                                   float eps, float wd, float bc1, float bc2_sqrt) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * 256) {
+        v4f pp = ((v4f*)p)[i], gg = ((const v4f*)g)[i], mm = ((v4f*)m)[i], vv = ((v4f*)v)[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float gr = gg[c] + wd * pp[c];
+            mm[c] = b1 * mm[c] + (1.f - b1) * gr;
+            vv[c] = b2 * vv[c] + (1.f - b2) * gr * gr;
+            const float denom = sqrtf(vv[c]) / bc2_sqrt + eps;
+            pp[c] -= (lr / bc1) * (mm[c] / denom);
+        }
+        ((v4f*)p)[i] = pp; ((v4f*)m)[i] = mm; ((v4f*)v)[i] = vv;
+    }
+}
+
+// ---- KL-divergence training loss (Workflow.py:850-858), forward + gradient in one pass ----------
+// one workgroup per graph: t = target / sum(target); logp = log_softmax(out);
+// row_loss = sum_j xlogy(t_j, t_j) - t_j * logp_j;  d_out_j = (softmax_j * sum(t) - t_j) / B
+__global__ __launch_bounds__(256) void kl_loss_kernel(const float* __restrict__ out, int ldo,
+                                                      const float* __restrict__ tgt, int ldt,
+                                                      int width, float inv_b,
+                                                      float* __restrict__ row_loss,
+                                                      float* __restrict__ d_out, int ldd) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float* o = out + (long long)b * ldo;
+    const float* t = tgt + (long long)b * ldt;
+    auto block_reduce = [&](float x, bool is_max) {
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) {
+            const float y = __shfl_xor(x, s);
+            x = is_max ? fmaxf(x, y) : x + y;
+        }
+        __syncthreads();
+        if (lane == 0) red[wid] = x;
+        __syncthreads();
+        return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))
+                      : (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    float mx = -INFINITY, ts = 0.f;
+    for (int j = tid; j < width; j += 256) { mx = fmaxf(mx, o[j]); ts += t[j]; }
+    mx = block_reduce(mx, true);
+    ts = block_reduce(ts, false);
+    float se = 0.f;
+    for (int j = tid; j < width; j += 256) se += expf(o[j] - mx);
+    se = block_reduce(se, false);
+    const float lse = logf(se);
+    float loss = 0.f;
+    for (int j = tid; j < width; j += 256) {
+        const float logp = (o[j] - mx) - lse;
+        const float tn = t[j] / ts;                       // 0/0 = NaN on all-zero rows, as the reference
+        loss += ((tn > 0.f) ? tn * logf(tn) : (tn == 0.f ? 0.f : tn)) - tn * logp;
+        if (d_out) d_out[(long long)b * ldd + j] = (expf(logp) * (ts / ts) - tn) * inv_b;
+    }
+    loss = block_reduce(loss, false);
+    if (tid == 0) row_loss[b] = loss;
 }
 
 }  // namespace
@@ -397,11 +474,45 @@ extern "C" int gi_reduce_slabs(const gi_reduce_desc* descs, int n_desc, void* st
     for (int base = 0; base < n_desc; base += GI_REDUCE_MAX) {
         const int n = (n_desc - base < GI_REDUCE_MAX) ? n_desc - base : GI_REDUCE_MAX;
         ReduceTable tab;
-        for (int i = 0; i < n; ++i) tab.d[i] = descs[base + i];
+        int total = 0;
+        for (int i = 0; i < n; ++i) {
+            tab.d[i] = descs[base + i];
+            tab.start[i] = total;
+            total += (int)(((long long)tab.d[i].N * (tab.d[i].K + 1) + 255) / 256);
+        }
         for (int i = n; i < GI_REDUCE_MAX; ++i) tab.d[i] = descs[base];
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, tab);
+        tab.start[n] = total;
+        tab.n = n;
+        if (total == 0) continue;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, tab);
         const int rc = gi_launch_status();
         if (rc) return rc;
     }
     return 0;
+}
+
+extern "C" int gi_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, int step,
+                            void* stream) {
+    (void)hipGetLastError();
+    if (n <= 0) return 0;
+    if (!p || !g || !m || !v || step < 1 || (n & 3)) return GI_EINVAL;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return GI_EINVAL;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    const long long n4 = n / 4;
+    const int blocks = (int)std::min<long long>((n4 + 255) / 256, 4096);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4,
+                       lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
+    return gi_launch_status();
+}
+
+extern "C" int gi_kl_loss(const float* out, int ldo, const float* target, int ldt, int B, int width,
+                          float* row_loss, float* d_out, int ldd, void* stream) {
+    (void)hipGetLastError();
+    if (B <= 0) return 0;
+    if (!out || !target || !row_loss || width <= 0 || ldo < width || ldt < width) return GI_EINVAL;
+    hipLaunchKernelGGL(kl_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, out, ldo, target,
+                       ldt, width, 1.f / (float)B, row_loss, d_out, ldd);
+    return gi_launch_status();
 }

@@ -79,6 +79,9 @@ SIGNATURES = {
     "gi_compress_slots": (ci, [vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, ci, vp]),
     "gi_colsum": (ci, [vp, ci, ci, ci, vp, vp, vp]),
     "gi_reduce_slabs": (ci, [C.POINTER(ReduceDesc), ci, vp]),
+    "gi_adam_step": (ci, [vp, vp, vp, vp, cll, C.c_float, C.c_float, C.c_float, C.c_float,
+                          C.c_float, ci, vp]),
+    "gi_kl_loss": (ci, [vp, ci, vp, ci, ci, ci, vp, vp, ci, vp]),
     "gi_prof_enable": (ci, [ci]),
     "gi_prof_collect": (ci, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci)]),
     "gi_ggnn_num_params": (ci, [C.POINTER(GgnnDims)]),

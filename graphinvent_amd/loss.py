@@ -2,14 +2,46 @@
 The training loss of the reference, ``Workflow.loss`` (Workflow.py:833-860):
 ``KLDivLoss(reduction="batchmean")(log_softmax(output, dim=1), target / target.sum(1, keepdim=True))``.
 
-Runs on the device the logits live on (a handful of small torch kernels over [B, APD]; the fused
-HIP version is SURVEY.md §8f row 2).  Rows whose target is all zero give 0/0 = NaN exactly as in
-the reference (DataProcesser.py:268-269 padding rows); callers slice them off.
+``apd_kl_loss`` dispatches on the device: CUDA logits go through ONE fused HIP kernel
+(``gi_kl_loss``: log-softmax, target normalisation, KL and the gradient w.r.t. the logits in a
+single pass over [B, APD] — SURVEY.md §8f row 2) instead of ~10 small torch kernels; anything else
+uses the plain torch expression (``apd_kl_loss_torch``), which is also the reference the fused
+kernel is tested against.  Rows whose target is all zero give NaN exactly as in the reference
+(DataProcesser.py:268-269 padding rows); callers slice them off.
 """
 import torch
 
 
-def apd_kl_loss(output: torch.Tensor, target_output: torch.Tensor) -> torch.Tensor:
+def apd_kl_loss_torch(output: torch.Tensor, target_output: torch.Tensor) -> torch.Tensor:
     log_p = torch.log_softmax(output, dim=1)
     target = target_output / torch.sum(target_output, dim=1, keepdim=True)
     return torch.nn.functional.kl_div(log_p, target, reduction="batchmean")
+
+
+class _FusedKL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, output, target):
+        from . import lib as L
+        lib = L.load()
+        out = output.contiguous()
+        tgt = target.contiguous().float()
+        B, W = out.shape
+        row = torch.empty(B, dtype=torch.float32, device=out.device)
+        need_grad = ctx.needs_input_grad[0]
+        d_out = torch.empty_like(out) if need_grad else None
+        L.check(lib.gi_kl_loss(out.data_ptr(), out.stride(0), tgt.data_ptr(), tgt.stride(0), B, W,
+                               row.data_ptr(), d_out.data_ptr() if need_grad else None,
+                               d_out.stride(0) if need_grad else 0,
+                               torch.cuda.current_stream().cuda_stream), "gi_kl_loss")
+        ctx.d_out = d_out
+        return row.sum() / B
+
+    @staticmethod
+    def backward(ctx, grad):
+        return ctx.d_out * grad, None
+
+
+def apd_kl_loss(output: torch.Tensor, target_output: torch.Tensor) -> torch.Tensor:
+    if output.is_cuda and output.dtype == torch.float32 and output.dim() == 2:
+        return _FusedKL.apply(output, target_output)
+    return apd_kl_loss_torch(output, target_output)

@@ -1,0 +1,92 @@
+"""
+``FusedAdam`` — ``torch.optim.Adam`` (the optimizer the reference builds at Workflow.py:219-263) as ONE
+HIP launch per step over a flat fp32 parameter bucket.
+
+On construction the parameters of each group are re-pointed into one flat, 16-byte-segmented buffer
+(``p.data`` becomes a view; ``Parameter`` identity, ``state_dict`` keys and ``load_state_dict`` are
+unaffected).  The segment layout is the one the fused GGNN backward uses for its gradient bucket
+(``gnn.mpnn.ggnn_backward_raw``), so when the gradients already live in that bucket the step reads
+them in place; otherwise they are packed first.  Learning-rate schedulers work as usual
+(``group["lr"]`` is read every step).  Semantics: Adam without amsgrad, ``weight_decay`` as L2 term,
+bias correction as in torch.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+
+from . import lib as L
+
+
+def _pack_offsets(params) -> (List[int], int):
+    offs, total = [], 0
+    for p in params:
+        offs.append(total)
+        total += (p.numel() + 3) & ~3
+    return offs, total
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        L.load()
+        self._flat = []
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.requires_grad]
+            if not ps:
+                self._flat.append(None)
+                continue
+            dev = ps[0].device
+            if not all(p.is_cuda and p.dtype == torch.float32 and p.device == dev for p in ps):
+                raise RuntimeError("FusedAdam needs fp32 CUDA parameters on one device "
+                                   "(call model.to('cuda') first)")
+            offs, total = _pack_offsets(ps)
+            flat = torch.zeros(total, dtype=torch.float32, device=dev)
+            with torch.no_grad():
+                for p, o in zip(ps, offs):
+                    flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+                    p.data = flat[o:o + p.numel()].view_as(p)
+            self._flat.append(dict(params=ps, offs=offs, total=total, p=flat,
+                                   m=torch.zeros_like(flat), v=torch.zeros_like(flat),
+                                   g=None, step=0))
+
+    def _grad_bucket(self, st) -> torch.Tensor:
+        ps, offs = st["params"], st["offs"]
+        g0 = ps[0].grad
+        if g0 is not None:
+            base = g0.data_ptr()
+            store = g0.untyped_storage()
+            if all(p.grad is not None and p.grad.is_contiguous() and
+                   p.grad.data_ptr() == base + 4 * o for p, o in zip(ps, offs)) and \
+                    base % 16 == 0 and store.nbytes() - (base - store.data_ptr()) >= 4 * st["total"]:
+                # gradients already form the flat bucket (fused GGNN backward): zero-copy view
+                return torch.as_strided(g0, (st["total"],), (1,))
+        if st["g"] is None:
+            st["g"] = torch.zeros(st["total"], dtype=torch.float32, device=st["p"].device)
+        for p, o in zip(ps, offs):
+            seg = st["g"][o:o + p.numel()]
+            if p.grad is None:
+                seg.zero_()
+            else:
+                seg.copy_(p.grad.reshape(-1))
+        return st["g"]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = L.load()
+        for group, st in zip(self.param_groups, self._flat):
+            if st is None:
+                continue
+            g = self._grad_bucket(st)
+            st["step"] += 1
+            b1, b2 = group["betas"]
+            L.check(lib.gi_adam_step(st["p"].data_ptr(), g.data_ptr(), st["m"].data_ptr(),
+                                     st["v"].data_ptr(), st["total"], float(group["lr"]), b1, b2,
+                                     group["eps"], group["weight_decay"], st["step"],
+                                     torch.cuda.current_stream().cuda_stream), "gi_adam_step")
+        return loss

@@ -159,6 +159,17 @@ typedef struct gi_reduce_desc {
 } gi_reduce_desc;
 int gi_reduce_slabs(const gi_reduce_desc* descs, int n_desc, void* stream);
 
+/* torch.optim.Adam step (no amsgrad) over ONE flat fp32 bucket of n floats (n % 4 == 0, 16-byte
+ * aligned): the optimizer the reference builds at Workflow.py:219-263, as a single launch. */
+int gi_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, int step, void* stream);
+
+/* Workflow.loss (Workflow.py:833-860) forward + gradient in one pass over the logits:
+ * row_loss[b] = KL(target_b / sum(target_b) || softmax(out_b)); loss = mean_b row_loss[b];
+ * d_out (may be NULL) = d loss / d out.  All-zero target rows give NaN like the reference. */
+int gi_kl_loss(const float* out, int ldo, const float* target, int ldt, int B, int width,
+               float* row_loss, float* d_out, int ldd, void* stream);
+
 /* Optional per-launch timing for the benchmark's roofline leg: when enabled, every gi_gemm and
  * gi_seg_sum launch is bracketed by hipEvents on its stream.  gi_prof_collect blocks until the
  * recorded work finished and returns, per kernel family k (0 = GEMM, 1 = seg_sum): summed elapsed

@@ -204,3 +204,45 @@ def test_selu_bwd_rows_gather():
     buf = Y.clone().to(DEV)
     ops.selu_bwd_rows(dA.to(DEV), idx.to(DEV), buf, buf, 300, 128)
     assert rel(buf, dA[idx.long()].double() * D.selu_grad_from_out(Y.double())) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+def test_fused_kl_loss_matches_torch_expression():
+    from graphinvent_amd.loss import apd_kl_loss, apd_kl_loss_torch
+    g = torch.Generator().manual_seed(6)
+    out = (torch.randn(257, 625, generator=g) * 3).to(DEV)
+    tgt = torch.randint(0, 4, (257, 625), generator=g).float()
+    tgt[:, 0] += 1                                           # every row has mass
+    tgt = tgt.to(DEV)
+    a = out.clone().requires_grad_(True)
+    b = out.clone().requires_grad_(True)
+    la, lb = apd_kl_loss(a, tgt), apd_kl_loss_torch(b, tgt)
+    (2.5 * la).backward()
+    (2.5 * lb).backward()
+    assert abs(float(la) - float(lb)) < 1e-5 * abs(float(lb))
+    assert rel(a.grad, b.grad) < 1e-5
+    tgt[3] = 0                                               # all-zero row: NaN like the reference
+    assert torch.isnan(apd_kl_loss(out, tgt)) and torch.isnan(apd_kl_loss_torch(out, tgt))
+    with torch.no_grad():
+        assert abs(float(apd_kl_loss(out[:3], tgt[:3])) - float(apd_kl_loss_torch(out[:3], tgt[:3]))) < 1e-5
+
+
+def test_fused_adam_matches_torch_adam():
+    from graphinvent_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(7)
+    shapes = [(250, 100), (250,), (3, 7), (1,), (500, 685)]
+    ref = [torch.nn.Parameter(torch.randn(*s, generator=g).to(DEV)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    o_ref = torch.optim.Adam(ref, lr=3e-3, weight_decay=1e-2)
+    o_mine = FusedAdam(mine, lr=3e-3, weight_decay=1e-2)
+    sched = torch.optim.lr_scheduler.OneCycleLR(o_mine, max_lr=3e-3, total_steps=20)
+    sched_ref = torch.optim.lr_scheduler.OneCycleLR(o_ref, max_lr=3e-3, total_steps=20)
+    for step in range(6):
+        for p, q in zip(ref, mine):
+            gr = torch.randn(p.shape, generator=g).to(DEV)
+            p.grad = gr.clone()
+            q.grad = gr.clone() if step % 2 else gr.clone()
+        o_ref.step(); o_mine.step(); sched.step(); sched_ref.step()
+    for p, q in zip(ref, mine):
+        assert rel(q, p) < 2e-6
+    assert mine[0].data_ptr() + 4 * 25000 == mine[1].data_ptr()        # flat, 16-byte segments
