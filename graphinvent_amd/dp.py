@@ -61,9 +61,10 @@ class DataParallel:
 
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer,
                  scheduler=None, loss_fn: Callable = apd_kl_loss,
-                 process_group: Optional[dist.ProcessGroup] = None):
+                 process_group: Optional[dist.ProcessGroup] = None, always_reduce: bool = False):
         self.model, self.optimizer, self.scheduler, self.loss_fn = model, optimizer, scheduler, loss_fn
         self.group = process_group
+        self.always_reduce = always_reduce     # run the collective even at world size 1 (tests)
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params: List[torch.nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
         self.last_bucket_zero_copy = False
@@ -88,7 +89,7 @@ class DataParallel:
         return bucket
 
     def allreduce_gradients(self) -> None:
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.always_reduce:
             return
         bucket = self._model_bucket()
         self.last_bucket_zero_copy = bucket is not None

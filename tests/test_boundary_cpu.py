@@ -97,3 +97,15 @@ def test_missing_library_raises(monkeypatch, tmp_path):
     monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU or"):
         L.load()
+
+
+def test_drop_in_import_as_top_level_gnn_package():
+    """Workflow.py:23 does `import gnn.mpnn`: with graphinvent_amd/ first on sys.path that must
+    resolve to this implementation (fresh interpreter so the reference's `gnn` cannot interfere)."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import gnn.mpnn as m; "
+            "assert m.__file__.startswith(%r), m.__file__; "
+            "assert hasattr(m, 'GGNN'); print('ok')") % (os.path.join(ROOT, "graphinvent_amd"),
+                                                         os.path.join(ROOT, "graphinvent_amd"))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
+    assert res.returncode == 0 and "ok" in res.stdout, res.stderr[-800:]
