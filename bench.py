@@ -221,10 +221,16 @@ def main():
         lib.check(handle.gi_prof_collect(ms, work, n), "gi_prof_collect")
         handle.gi_prof_enable(0)
         tf = work[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
+        traffic = None                      # HBM-side bytes per launch from the committed PMC passes
+        tpath = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_side_bytes_per_launch")
         result["roofline"] = {
             "bound": "mfma", "kernel": "gi_gemm_kernel<TM,TN,A_MAJOR,B_MAJOR> (fp32 MFMA GEMM family)",
             "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "traffic_source": "profiles/r01/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                              "bytes per launch; not re-measured live)",
             "launches_per_step": n[0] // prof_steps,
             "avg_launch_us": round(ms[0] * 1e3 / max(n[0], 1), 2),
             "flop_per_launch": round(work[0] / max(n[0], 1)),
