@@ -47,8 +47,11 @@ inline Lay make_layout(int B, int N, int Fe) {
 }
 
 // ---- count ----------------------------------------------------------------------------------
+// T = float (what BlockDatasetLoader.HDFDataset hands the reference model) or signed char (the int8
+// the preprocessed HDF actually stores, DataProcesser.py:157-161 — 4x less input traffic, no host cast)
+template <typename T>
 __global__ __launch_bounds__(256) void compact_count_kernel(
-    const float* __restrict__ nodes, const float* __restrict__ edges, int N, int Fn, int Fe,
+    const T* __restrict__ nodes, const T* __restrict__ edges, int N, int Fn, int Fe,
     int* __restrict__ gfix, Lay L) {
     __shared__ signed char typ[GI_MAX_NODES * GI_MAX_NODES];
     __shared__ int err_s;
@@ -56,13 +59,13 @@ __global__ __launch_bounds__(256) void compact_count_kernel(
     const int NN = N * N;
     if (tid == 0) err_s = 0;
     __syncthreads();
-    const float* eg = edges + (long long)b * NN * Fe;
+    const T* eg = edges + (long long)b * NN * Fe;
     signed char* etype_g = reinterpret_cast<signed char*>(gfix + L.etype) + (long long)b * NN;
     for (int idx = tid; idx < NN; idx += 256) {
         float sum = 0.f;
         int t = -1, ones = 0, zeros = 0;
         for (int f = 0; f < Fe; ++f) {
-            const float v = eg[(long long)idx * Fe + f];
+            const float v = (float)eg[(long long)idx * Fe + f];
             sum += v;
             if (v == 1.f) { ++ones; if (t < 0) t = f; }
             else if (v == 0.f) ++zeros;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void compact_count_kernel(
             cc += (typ[j * N + i] >= 0);
         }
         bool nz = false;
-        for (int f = 0; f < Fn; ++f) nz |= (nodes[(long long)slot * Fn + f] != 0.f);
+        for (int f = 0; f < Fn; ++f) nz |= ((float)nodes[(long long)slot * Fn + f] != 0.f);
         gfix[L.rowcnt + slot] = rc;
         gfix[L.colcnt + slot] = cc;
         gfix[L.active + slot] = (nz || rc > 0 || cc > 0) ? 1 : 0;
@@ -169,8 +172,9 @@ __global__ __launch_bounds__(256) void compact_finish_kernel(int ns, int Fe, int
 }
 
 // ---- fill -----------------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(256) void compact_fill_kernel(
-    const float* __restrict__ nodes, int N, int Fn, int Fe, const int* __restrict__ gfix, Lay L,
+    const T* __restrict__ nodes, int N, int Fn, int Fe, const int* __restrict__ gfix, Lay L,
     int S, int* __restrict__ e_src, int* __restrict__ e_dst, int* __restrict__ in_perm,
     int* __restrict__ out_perm, float* __restrict__ hx0, int ldhx, int H) {
     __shared__ signed char typ[GI_MAX_NODES * GI_MAX_NODES];
@@ -216,8 +220,8 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
         if (!gfix[L.active + slot]) continue;
         const int c = gfix[L.cidx + slot];
         float v = 0.f;
-        if (col < Fn) v = nodes[(long long)slot * Fn + col];
-        else if (col >= H && col < H + Fn) v = nodes[(long long)slot * Fn + col - H];
+        if (col < Fn) v = (float)nodes[(long long)slot * Fn + col];
+        else if (col >= H && col < H + Fn) v = (float)nodes[(long long)slot * Fn + col - H];
         hx0[(long long)c * ldhx + col] = v;
     }
     if (b == 0)
@@ -240,24 +244,29 @@ extern "C" int gi_compact_layout(int B, int N, int Fe, gi_compact_layout_t* out)
     return 0;
 }
 
-extern "C" int gi_compact_count(const float* nodes, const float* edges, int B, int N, int Fn,
-                                int Fe, int* gfix, void* stream) {
+extern "C" int gi_compact_count(const void* nodes, const void* edges, int in_dtype, int B, int N,
+                                int Fn, int Fe, int* gfix, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (!nodes || !edges || !gfix || B <= 0 || N <= 0 || Fn <= 0 || Fe <= 0) return GI_EINVAL;
+    if (in_dtype != GI_DTYPE_F32 && in_dtype != GI_DTYPE_I8) return GI_EINVAL;
     if (N > GI_MAX_NODES || Fe > GI_MAX_GROUPS) return GI_ELIMIT;
     const Lay L = make_layout(B, N, Fe);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(gfix + L.counts, 0, 16 * sizeof(int), st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(compact_count_kernel, dim3(B), dim3(256), 0, st, nodes, edges, N, Fn, Fe,
-                       gfix, L);
+    if (in_dtype == GI_DTYPE_F32)
+        hipLaunchKernelGGL(compact_count_kernel<float>, dim3(B), dim3(256), 0, st,
+                           (const float*)nodes, (const float*)edges, N, Fn, Fe, gfix, L);
+    else
+        hipLaunchKernelGGL(compact_count_kernel<signed char>, dim3(B), dim3(256), 0, st,
+                           (const signed char*)nodes, (const signed char*)edges, N, Fn, Fe, gfix, L);
     hipLaunchKernelGGL(compact_scan_kernel, dim3(3 + Fe), dim3(1024), 0, st, B * N, Fe, gfix, L);
     hipLaunchKernelGGL(compact_finish_kernel, dim3(gi_cdiv(B * N, 256)), dim3(256), 0, st, B * N, Fe,
                        gfix, L);
     return gi_launch_status();
 }
 
-extern "C" int gi_compact_fill(const float* nodes, int B, int N, int Fn, int Fe, const int* gfix,
+extern "C" int gi_compact_fill(const void* nodes, int in_dtype, int B, int N, int Fn, int Fe, const int* gfix,
                                int S, int E, int* e_src, int* e_dst, int* in_perm, int* out_perm,
                                float* hx0, int ldhx, int H, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
@@ -266,7 +275,15 @@ extern "C" int gi_compact_fill(const float* nodes, int B, int N, int Fn, int Fe,
     if (N > GI_MAX_NODES || Fe > GI_MAX_GROUPS) return GI_ELIMIT;
     if (ldhx < H + Fn || Fn > H) return GI_EINVAL;
     const Lay L = make_layout(B, N, Fe);
-    hipLaunchKernelGGL(compact_fill_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, nodes, N,
-                       Fn, Fe, gfix, L, S, e_src, e_dst, in_perm, out_perm, hx0, ldhx, H);
+    if (in_dtype == GI_DTYPE_F32)
+        hipLaunchKernelGGL(compact_fill_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)nodes, N, Fn, Fe, gfix, L, S, e_src, e_dst, in_perm,
+                           out_perm, hx0, ldhx, H);
+    else if (in_dtype == GI_DTYPE_I8)
+        hipLaunchKernelGGL(compact_fill_kernel<signed char>, dim3(B), dim3(256), 0,
+                           (hipStream_t)stream, (const signed char*)nodes, N, Fn, Fe, gfix, L, S,
+                           e_src, e_dst, in_perm, out_perm, hx0, ldhx, H);
+    else
+        return GI_EINVAL;
     return gi_launch_status();
 }

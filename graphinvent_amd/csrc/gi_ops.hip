@@ -282,15 +282,16 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // ---- KL-divergence training loss (Workflow.py:850-858), forward + gradient in one pass ----------
 // one workgroup per graph: t = target / sum(target); logp = log_softmax(out);
 // row_loss = sum_j xlogy(t_j, t_j) - t_j * logp_j;  d_out_j = (softmax_j * sum(t) - t_j) / B
+template <typename T>
 __global__ __launch_bounds__(256) void kl_loss_kernel(const float* __restrict__ out, int ldo,
-                                                      const float* __restrict__ tgt, int ldt,
+                                                      const T* __restrict__ tgt, int ldt,
                                                       int width, float inv_b,
                                                       float* __restrict__ row_loss,
                                                       float* __restrict__ d_out, int ldd) {
     __shared__ float red[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float* o = out + (long long)b * ldo;
-    const float* t = tgt + (long long)b * ldt;
+    const T* t = tgt + (long long)b * ldt;
     auto block_reduce = [&](float x, bool is_max) {
 #pragma unroll
         for (int s = 32; s > 0; s >>= 1) {
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256) void kl_loss_kernel(const float* __restrict__ 
                       : (red[0] + red[1]) + (red[2] + red[3]);
     };
     float mx = -INFINITY, ts = 0.f;
-    for (int j = tid; j < width; j += 256) { mx = fmaxf(mx, o[j]); ts += t[j]; }
+    for (int j = tid; j < width; j += 256) { mx = fmaxf(mx, o[j]); ts += (float)t[j]; }
     mx = block_reduce(mx, true);
     ts = block_reduce(ts, false);
     float se = 0.f;
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256) void kl_loss_kernel(const float* __restrict__ 
     float loss = 0.f;
     for (int j = tid; j < width; j += 256) {
         const float logp = (o[j] - mx) - lse;
-        const float tn = t[j] / ts;                       // 0/0 = NaN on all-zero rows, as the reference
+        const float tn = (float)t[j] / ts;                // 0/0 = NaN on all-zero rows, as the reference
         loss += ((tn > 0.f) ? tn * logf(tn) : (tn == 0.f ? 0.f : tn)) - tn * logp;
         if (d_out) d_out[(long long)b * ldd + j] = (expf(logp) * (ts / ts) - tn) * inv_b;
     }
@@ -507,12 +508,19 @@ extern "C" int gi_adam_step(float* p, const float* g, float* m, float* v, long l
     return gi_launch_status();
 }
 
-extern "C" int gi_kl_loss(const float* out, int ldo, const float* target, int ldt, int B, int width,
-                          float* row_loss, float* d_out, int ldd, void* stream) {
+extern "C" int gi_kl_loss(const float* out, int ldo, const void* target, int tgt_dtype, int ldt, int B,
+                          int width, float* row_loss, float* d_out, int ldd, void* stream) {
     (void)hipGetLastError();
     if (B <= 0) return 0;
     if (!out || !target || !row_loss || width <= 0 || ldo < width || ldt < width) return GI_EINVAL;
-    hipLaunchKernelGGL(kl_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, out, ldo, target,
-                       ldt, width, 1.f / (float)B, row_loss, d_out, ldd);
+    if (tgt_dtype == GI_DTYPE_F32)
+        hipLaunchKernelGGL(kl_loss_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream, out, ldo,
+                           (const float*)target, ldt, width, 1.f / (float)B, row_loss, d_out, ldd);
+    else if (tgt_dtype == GI_DTYPE_I8)
+        hipLaunchKernelGGL(kl_loss_kernel<signed char>, dim3(B), dim3(256), 0, (hipStream_t)stream, out,
+                           ldo, (const signed char*)target, ldt, width, 1.f / (float)B, row_loss,
+                           d_out, ldd);
+    else
+        return GI_EINVAL;
     return gi_launch_status();
 }

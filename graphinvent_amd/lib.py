@@ -24,6 +24,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GI_MAX_GROUPS = 8
 GI_MAX_NODES = 128
 EPI_BIAS, EPI_SELU, EPI_DSELU, EPI_ACCUM, GEMM_SPLITK = 1, 2, 4, 8, 16
+DTYPE_F32, DTYPE_I8 = 0, 1
 
 vp = C.c_void_p
 ci = C.c_int
@@ -63,8 +64,8 @@ class GgnnDims(C.Structure):
 SIGNATURES = {
     "gi_abi_version": (ci, []),
     "gi_compact_layout": (ci, [ci, ci, ci, C.POINTER(CompactLayout)]),
-    "gi_compact_count": (ci, [vp, vp, ci, ci, ci, ci, vp, vp]),
-    "gi_compact_fill": (ci, [vp, ci, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp]),
+    "gi_compact_count": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp]),
+    "gi_compact_fill": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp]),
     "gi_gemm": (ci, [C.POINTER(GemmParams), vp]),
     "gi_gemm_batch": (ci, [C.POINTER(GemmParams), ci, vp]),
     "gi_seg_sum": (ci, [vp, ci, vp, vp, ci, ci, vp, ci, ci, vp]),
@@ -81,7 +82,7 @@ SIGNATURES = {
     "gi_reduce_slabs": (ci, [C.POINTER(ReduceDesc), ci, vp]),
     "gi_adam_step": (ci, [vp, vp, vp, vp, cll, C.c_float, C.c_float, C.c_float, C.c_float,
                           C.c_float, ci, vp]),
-    "gi_kl_loss": (ci, [vp, ci, vp, ci, ci, ci, vp, vp, ci, vp]),
+    "gi_kl_loss": (ci, [vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, vp]),
     "gi_prof_enable": (ci, [ci]),
     "gi_prof_collect": (ci, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci)]),
     "gi_ggnn_num_params": (ci, [C.POINTER(GgnnDims)]),

@@ -24,12 +24,15 @@ class _FusedKL(torch.autograd.Function):
         from . import lib as L
         lib = L.load()
         out = output.contiguous()
-        tgt = target.contiguous().float()
+        if target.dtype == torch.int8:                       # HDF dtype, read directly
+            tgt, tdt = target.contiguous(), L.DTYPE_I8
+        else:
+            tgt, tdt = target.contiguous().float(), L.DTYPE_F32
         B, W = out.shape
         row = torch.empty(B, dtype=torch.float32, device=out.device)
         need_grad = ctx.needs_input_grad[0]
         d_out = torch.empty_like(out) if need_grad else None
-        L.check(lib.gi_kl_loss(out.data_ptr(), out.stride(0), tgt.data_ptr(), tgt.stride(0), B, W,
+        L.check(lib.gi_kl_loss(out.data_ptr(), out.stride(0), tgt.data_ptr(), tdt, tgt.stride(0), B, W,
                                row.data_ptr(), d_out.data_ptr() if need_grad else None,
                                d_out.stride(0) if need_grad else 0,
                                torch.cuda.current_stream().cuda_stream), "gi_kl_loss")

@@ -30,6 +30,19 @@ def _need_cuda_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+def _model_input(t: torch.Tensor, name: str):
+    """Model inputs may stay int8 (the dtype of the preprocessed HDF) or be fp32 (what the
+    reference's HDFDataset converts to, BlockDatasetLoader.py:139-141); returns (tensor, GI_DTYPE)."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA (ROCm) tensor: the MI355X HIP path has no CPU "
+                           "fallback")
+    if t.dtype == torch.int8:
+        return t.contiguous(), L.DTYPE_I8
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous(), L.DTYPE_F32
+
+
 def r4(x: int) -> int:
     return (x + 3) & ~3
 
@@ -80,8 +93,10 @@ def compact_count(nodes: torch.Tensor, edges: torch.Tensor):
     """Phase 1; returns (layout, gfix, S, E, Et).  One host read-back of 16 ints (the only
     synchronisation point of a forward pass)."""
     lib = L.load()
-    nodes = _need_cuda_f32(nodes, "nodes")
-    edges = _need_cuda_f32(edges, "edges")
+    nodes, dt_n = _model_input(nodes, "nodes")
+    edges, dt_e = _model_input(edges, "edges")
+    if dt_n != dt_e:                          # mixed dtypes: promote both to fp32
+        nodes, edges, dt_n = nodes.float(), edges.float(), L.DTYPE_F32
     B, N, Fn = nodes.shape
     Fe = edges.shape[3]
     if edges.shape[:3] != (B, N, N):
@@ -89,7 +104,7 @@ def compact_count(nodes: torch.Tensor, edges: torch.Tensor):
     lay = L.CompactLayout()
     L.check(lib.gi_compact_layout(B, N, Fe, C.byref(lay)), "gi_compact_layout")
     gfix = torch.empty(lay.total_ints, dtype=torch.int32, device=nodes.device)
-    L.check(lib.gi_compact_count(nodes.data_ptr(), edges.data_ptr(), B, N, Fn, Fe,
+    L.check(lib.gi_compact_count(nodes.data_ptr(), edges.data_ptr(), dt_n, B, N, Fn, Fe,
                                  gfix.data_ptr(), _stream()), "gi_compact_count")
     counts = gfix[lay.counts:lay.counts + 16].cpu().tolist()
     S, E, err = counts[0], counts[1], counts[2]
@@ -106,7 +121,8 @@ def compact_fill(nodes, lay, gfix, S, E, Et, hx0: torch.Tensor, ldhx: int, H: in
     Fe = len(Et)
     E4 = max(r4(E), 4)
     gvar = torch.empty((4, E4), dtype=torch.int32, device=nodes.device)
-    L.check(lib.gi_compact_fill(nodes.data_ptr(), B, N, Fn, Fe, gfix.data_ptr(), S, E,
+    dt = L.DTYPE_I8 if nodes.dtype == torch.int8 else L.DTYPE_F32
+    L.check(lib.gi_compact_fill(nodes.data_ptr(), dt, B, N, Fn, Fe, gfix.data_ptr(), S, E,
                                 gvar[0].data_ptr(), gvar[1].data_ptr(), gvar[2].data_ptr(),
                                 gvar[3].data_ptr(), hx0.data_ptr(), ldhx, H, _stream()),
             "gi_compact_fill")

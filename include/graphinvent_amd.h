@@ -29,6 +29,9 @@ extern "C" {
 #define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
 #define GI_MAX_NODES 128      /* max max_n_nodes */
 
+#define GI_DTYPE_F32 0        /* element type of model INPUTS (nodes, edges, APD targets): fp32 ... */
+#define GI_DTYPE_I8  1        /* ... or the int8 the preprocessed HDF stores (DataProcesser.py:157-161) */
+
 #define GI_EINVAL   (-1)      /* bad dims / null pointer */
 #define GI_ELIMIT   (-2)      /* exceeds a compiled-in limit */
 
@@ -54,12 +57,12 @@ typedef struct gi_compact_layout_t {
 int gi_compact_layout(int B, int N, int Fe, gi_compact_layout_t* out);
 
 /* phase 1: per-graph counting + global scans; fills everything in gfix. */
-int gi_compact_count(const float* nodes, const float* edges, int B, int N, int Fn, int Fe,
-                     int* gfix, void* stream);
+int gi_compact_count(const void* nodes, const void* edges, int in_dtype, int B, int N, int Fn,
+                     int Fe, int* gfix, void* stream);
 /* phase 2 (after the host has read S and E from counts): edge arrays in bond-type-major order,
  * the two CSR permutations, and the initial node rows hx0[S+1, ldhx] = [x | 0.. | x] with the
  * input features in columns [0,Fn) and again in [H, H+Fn) (row S = 0). */
-int gi_compact_fill(const float* nodes, int B, int N, int Fn, int Fe, const int* gfix,
+int gi_compact_fill(const void* nodes, int in_dtype, int B, int N, int Fn, int Fe, const int* gfix,
                     int S, int E, int* e_src, int* e_dst, int* in_perm, int* out_perm,
                     float* hx0, int ldhx, int H, void* stream);
 
@@ -167,8 +170,8 @@ int gi_adam_step(float* p, const float* g, float* m, float* v, long long n, floa
 /* Workflow.loss (Workflow.py:833-860) forward + gradient in one pass over the logits:
  * row_loss[b] = KL(target_b / sum(target_b) || softmax(out_b)); loss = mean_b row_loss[b];
  * d_out (may be NULL) = d loss / d out.  All-zero target rows give NaN like the reference. */
-int gi_kl_loss(const float* out, int ldo, const float* target, int ldt, int B, int width,
-               float* row_loss, float* d_out, int ldd, void* stream);
+int gi_kl_loss(const float* out, int ldo, const void* target, int tgt_dtype, int ldt, int B,
+               int width, float* row_loss, float* d_out, int ldd, void* stream);
 
 /* Optional per-launch timing for the benchmark's roofline leg: when enabled, every gi_gemm and
  * gi_seg_sum launch is bracketed by hipEvents on its stream.  gi_prof_collect blocks until the

@@ -1,0 +1,57 @@
+"""CPU: the int8 sharded block loader (host-side logic; device copies are covered by -m gpu)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from graphinvent_amd.loader import ShardedBlockLoader, read_hdf_int8
+
+REF_H5 = "/root/reference/data/pre-training/gdb13_1K-debug/train.h5"
+
+
+def _fixture(golden_dir, split="train"):
+    d = np.load(os.path.join(golden_dir, f"gdb13_1K-debug_{split}.npz"))
+    return d["nodes"], d["edges"], d["APDs"]
+
+
+def test_drops_padding_rows_and_shards_disjointly(golden_dir):
+    n, e, a = _fixture(golden_dir)
+    loaders = [ShardedBlockLoader(n, e, a, 16, rank=r, world_size=2, seed=3, device=None)
+               for r in range(2)]
+    assert loaders[0].block[0].shape[0] == 129                 # 21 all-zero padding rows dropped
+    assert len(loaders[0]) == len(loaders[1]) == (129 // 16) // 2
+    seen = []
+    for ld in loaders:
+        for nodes, edges, apds in ld:
+            assert nodes.dtype == edges.dtype == apds.dtype == torch.int8
+            assert nodes.shape == (16, 13, 8) and edges.shape == (16, 13, 13, 3) and apds.shape == (16, 625)
+            assert int(apds.ne(0).any(1).sum()) == 16
+            seen.append(apds.numpy().tobytes())
+    assert len(seen) == 8
+    keep = ShardedBlockLoader(n, e, a, 16, device=None, drop_zero_targets=False)
+    assert keep.block[0].shape[0] == 150
+
+
+def test_epochs_reshuffle_but_ranks_agree_on_the_permutation(golden_dir):
+    n, e, a = _fixture(golden_dir, "valid")
+    a0 = ShardedBlockLoader(n, e, a, 10, rank=0, world_size=2, seed=1, device=None)
+    b0 = ShardedBlockLoader(n, e, a, 10, rank=0, world_size=2, seed=1, device=None)
+    first = [x[2].clone() for x in a0]
+    assert all(torch.equal(p, q[2]) for p, q in zip(first, b0))       # deterministic
+    a0.set_epoch(1)
+    assert not all(torch.equal(p, q[2]) for p, q in zip(first, a0))    # reshuffled
+
+
+def test_rejects_non_int8():
+    with pytest.raises(TypeError):
+        ShardedBlockLoader(np.zeros((4, 2, 2), np.float32), np.zeros((4, 2, 2, 1), np.int8),
+                           np.zeros((4, 3), np.int8), 2, device=None)
+
+
+@pytest.mark.skipif(not (os.path.exists(REF_H5) and os.path.exists("/opt/conda/lib/libhdf5.so")),
+                    reason="reference HDF fixture / libhdf5 not on this box")
+def test_hdf_reader_matches_committed_fixture(golden_dir):
+    n, e, a = read_hdf_int8(REF_H5)
+    fn, fe, fa = _fixture(golden_dir)
+    assert np.array_equal(n, fn) and np.array_equal(e, fe) and np.array_equal(a, fa)
