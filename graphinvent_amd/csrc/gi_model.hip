@@ -81,6 +81,10 @@ struct Ws {
     long long cat_add, cat_conn, gemb, add2_act[MAXL], conn2_act[MAXL], term2_act[MAXL];
     long long dzA, dzC, dzT, dcat_add, dcat_conn, dgemb, zpart_g, zpart_a, zpart_c, dh, dh2, dxe;
     long long dhb, dhc, dhd;           // per-sibling input gradients of the node-level readout stacks
+    // dZ of the hidden layers (same shapes as the activations): kept separate from the activations
+    // so that every weight-gradient GEMM can be deferred and batched off the critical path
+    long long edz[MAXP][MAXL], att_dz[MAXL], emb_dz[MAXL], add1_dz[MAXL], conn1_dz[MAXL],
+        add2_dz[MAXL], conn2_dz[MAXL], term2_dz[MAXL], dagg[MAXP];
     long long total;
 };
 
@@ -124,6 +128,16 @@ void make_ws(const Model& m, int S, int E, Ws& w) {
     w.zpart_g = take(B, w.ldZG); w.zpart_a = take(B, w.ldA); w.zpart_c = take(B, w.ldC);
     w.dh = take(R, w.ldH); w.dh2 = take(R, w.ldH); w.dxe = take(Er, w.ldH);
     w.dhb = take(R, w.ldH); w.dhc = take(R, w.ldH); w.dhd = take(R, w.ldH);
+    for (int p = 0; p < d.passes; ++p) {
+        for (int l = 0; l < d.enn_depth; ++l) w.edz[p][l] = take(Er, w.ldEh);
+        w.dagg[p] = take(R, w.ldM);
+    }
+    for (int l = 0; l < d.att_depth; ++l) w.att_dz[l] = take(R, w.ldAtt);
+    for (int l = 0; l < d.emb_depth; ++l) w.emb_dz[l] = take(R, w.ldEmb);
+    for (int l = 0; l < d.mlp1_depth; ++l) { w.add1_dz[l] = take(R, w.ldM1); w.conn1_dz[l] = take(R, w.ldM1); }
+    for (int l = 0; l < d.mlp2_depth; ++l) {
+        w.add2_dz[l] = take(B, w.ldM2); w.conn2_dz[l] = take(B, w.ldM2); w.term2_dz[l] = take(B, w.ldM2);
+    }
     w.total = o;
 }
 
@@ -131,14 +145,14 @@ void make_ws(const Model& m, int S, int E, Ws& w) {
 struct SlabEntry { long long off, stride; int nsplit, calls, done, n_out, n_in, ld, tn; };
 struct SlabPlan { SlabEntry e[160]; long long total; };
 
-// wgrad launch shape: 64x64 output tiles (slab traffic depends only on the split count, so the
-// small tile buys blocks for free); `share` = this problem's fraction of the launch's rows, so a
-// grouped launch hands every bond type slabs in proportion to its edges.
+// wgrad launch shape: 64x64 output tiles.  Weight-gradient GEMMs are deferred and launched in
+// batches of up to 8 problems, so ONE problem only needs ~256 workgroups (x its share of a
+// type-grouped launch); fewer splits = fewer slabs to write and reduce.
 void wgrad_shape(int n_out, int n_in, int red_rows, double share, int& tn, int& nsplit) {
     tn = 1;
     const int tiles = gi_cdiv(n_out, 64) * gi_cdiv(n_in + 1, 64);
     const int kt = gi_cdiv(std::max(red_rows, 1), 32);
-    const int want = (int)(640.0 * share / tiles + 0.5);
+    const int want = (int)(256.0 * share / tiles + 0.5);
     nsplit = std::min(std::max(want, 1), std::max(1, kt / 2));
 }
 
@@ -163,14 +177,12 @@ void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {
     const int R = S + 1;
     for (int t = 0; t < d.Fe; ++t) {
         const int et = Et ? Et[t] : E / d.Fe;
-        add_mlp(m.msg[t], et, d.passes, E > 0 ? (double)et / E : 1.0);
+        add_mlp(m.msg[t], et, d.passes, E > 0 ? 1.5 * (double)et / E : 1.0);
     }
-    add(m.gru_wih, 3 * d.H, d.M, R, d.passes, 0.5);      // the two GRU projections share a launch
-    add(m.gru_whh, 3 * d.H, d.H, R, d.passes, 0.5);
-    // sibling stacks share launches: slabs in proportion to their output tiles
-    add_mlp(m.att, R, 1, 0.15); add_mlp(m.emb, R, 1, 0.15); add_mlp(m.add1, R, 1, 0.35);
-    add_mlp(m.conn1, R, 1, 0.35);
-    add_mlp(m.add2, d.B, 1, 0.4); add_mlp(m.conn2, d.B, 1, 0.3); add_mlp(m.term2, d.B, 1, 0.3);
+    add(m.gru_wih, 3 * d.H, d.M, R, d.passes, 1.0);
+    add(m.gru_whh, 3 * d.H, d.H, R, d.passes, 1.0);
+    add_mlp(m.att, R, 1); add_mlp(m.emb, R, 1); add_mlp(m.add1, R, 1); add_mlp(m.conn1, R, 1);
+    add_mlp(m.add2, d.B, 1); add_mlp(m.conn2, d.B, 1); add_mlp(m.term2, d.B, 1);
     sp.total = o;
 }
 
@@ -255,35 +267,6 @@ void linear_dgrad(Run& r, const float* const* Wg, const float* W, const Grp& g, 
     r.chk(gi_gemm(&p, r.st));
 }
 
-// slabs of [dW | db] = dZ^T [X[b_idx] | 1], reduction over `rows`
-void linear_wgrad(Run& r, SlabPlan& sp, float* slabs, const int* widx, const Grp& g,
-                  const float* dZ, int lddz, const float* X, int ldx, const int* b_idx, int rows) {
-    if (!r.ok()) return;
-    gi_gemm_params p;
-    gemm_defaults(p);
-    SlabEntry& e0 = sp.e[widx[0]];
-    p.A = dZ; p.lda = lddz; p.a_major = 1;
-    p.B = X; p.ldb = ldx; p.b_major = 1; p.b_idx = b_idx;
-    p.M = e0.n_out; p.N = e0.n_in + 1; p.K = rows; p.ldc = e0.ld;
-    p.ones_col = e0.n_in;
-    p.flags = GI_GEMM_SPLITK;
-    p.nsplit = e0.nsplit; p.c_split_stride = e0.stride;
-    p.tm = 1; p.tn = e0.tn;
-    if (g.n) {
-        p.ngroups = g.n; p.grp_off = g.off;
-        for (int t = 0; t < g.n; ++t) {
-            SlabEntry& e = sp.e[widx[t]];
-            p.Cg[t] = slabs + e.off + (long long)e.done * e.nsplit * e.stride;
-            p.gsplit[t] = e.nsplit;
-            e.done++;
-        }
-    } else {
-        p.C = slabs + e0.off + (long long)e0.done * e0.nsplit * e0.stride;
-        e0.done++;
-    }
-    r.chk(gi_gemm(&p, r.st));
-}
-
 void mlp_forward(Run& r, float* ws, const Mlp* mlps, const Grp& g, const float* X, int ldx,
                  const int* a_idx, int rows, const long long* acts, int ldh, float* final_dst,
                  int ld_final) {
@@ -293,35 +276,6 @@ void mlp_forward(Run& r, float* ws, const Mlp* mlps, const Grp& g, const float* 
         float* dst = (l == L - 1) ? final_dst : ws + acts[l];
         linear_fwd(r, mlps, l, g, src, l == 0 ? ldx : ldh, l == 0 ? a_idx : nullptr, rows, dst,
                    l == L - 1 ? ld_final : ldh);
-    }
-}
-
-// Zlast holds dZ of the last layer on entry.  Hidden activation buffers are overwritten with
-// their dZ.  dX (first-layer input gradient, first dx_cols columns) only if dX != nullptr.
-void mlp_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, const Mlp* mlps, const Grp& g,
-                  const float* X, int ldx, const int* a_idx, int rows, const long long* acts,
-                  int ldh, const float* Zlast, int ldz, float* dX, int lddx, int dx_cols,
-                  bool accumulate) {
-    const int L = mlps[0].layers();
-    const int ngr = g.n ? g.n : 1;
-    for (int l = L - 1; l >= 0; --l) {
-        const float* dZ = (l == L - 1) ? Zlast : ws + acts[l];
-        const int lddz = (l == L - 1) ? ldz : ldh;
-        const float* Xl = (l == 0) ? X : ws + acts[l - 1];
-        const int ldxl = (l == 0) ? ldx : ldh;
-        int widx[GI_MAX_GROUPS];
-        const float* Wg[GI_MAX_GROUPS];
-        for (int t = 0; t < ngr; ++t) { widx[t] = mlps[t].w(l); Wg[t] = r.P[widx[t]]; }
-        linear_wgrad(r, sp, slabs, widx, g, dZ, lddz, Xl, ldxl, l == 0 ? a_idx : nullptr, rows);
-        const Mlp& q = mlps[0];
-        if (l > 0) {
-            float* prev = ws + acts[l - 1];
-            linear_dgrad(r, Wg, Wg[0], g, q.fan_out(l), q.fan_in(l), q.fan_in(l), dZ, lddz, rows,
-                         prev, ldh, prev, ldh, false);
-        } else if (dX) {
-            linear_dgrad(r, Wg, Wg[0], g, q.fan_out(0), q.fan_in(0), dx_cols, dZ, lddz, rows, dX,
-                         lddx, nullptr, 0, accumulate);
-        }
     }
 }
 
@@ -335,12 +289,21 @@ struct MlpJob {
     const float* X; int ldx; int rows;           // input (first `fan_in(0)` columns are used)
     const long long* acts; int ldh;              // hidden activation buffers (ws offsets)
     float* out; int ldout;                       // forward: last layer's destination
+    const long long* dzs;                        // backward: dZ buffers of the hidden layers
     const float* Zlast; int ldz;                 // backward: dZ of the last layer
     float* dX; int lddx; int dx_cols; bool accumulate;   // backward: first-layer input gradient (or null)
 };
 
 struct Batch {
     gi_gemm_params p[8];
+    int n = 0;
+    gi_gemm_params& next() { gemm_defaults(p[n]); return p[n++]; }
+};
+
+// Weight-gradient GEMMs only feed the final slab reduction, so they are collected here while the
+// dZ chain (the critical path) runs and launched afterwards in batches of 8 problems.
+struct Deferred {
+    gi_gemm_params p[96];
     int n = 0;
     gi_gemm_params& next() { gemm_defaults(p[n]); return p[n++]; }
 };
@@ -376,19 +339,38 @@ void add_dgrad(Batch& b, const float* W, int n_out, int n_in, int ncols, const f
     p.flags = (act ? GI_EPI_DSELU : 0) | (accumulate ? GI_EPI_ACCUM : 0);
 }
 
-void add_wgrad(Batch& b, SlabPlan& sp, float* slabs, int widx, const float* dZ, int lddz,
-               const float* X, int ldx, int rows) {
-    SlabEntry& e = sp.e[widx];
-    gi_gemm_params& p = b.next();
+void flush_deferred(Run& r, Deferred& q);
+
+void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* widx, const Grp& g,
+                 const float* dZ, int lddz, const float* X, int ldx, const int* b_idx, int rows) {
+    if (q.n == 96) flush_deferred(r, q);          // list full (very deep configurations only)
+    gi_gemm_params& p = q.next();
+    SlabEntry& e0 = sp.e[widx[0]];
     p.A = dZ; p.lda = lddz; p.a_major = 1;
-    p.B = X; p.ldb = ldx; p.b_major = 1;
-    p.M = e.n_out; p.N = e.n_in + 1; p.K = rows; p.ldc = e.ld;
-    p.ones_col = e.n_in;
+    p.B = X; p.ldb = ldx; p.b_major = 1; p.b_idx = b_idx;
+    p.M = e0.n_out; p.N = e0.n_in + 1; p.K = rows; p.ldc = e0.ld;
+    p.ones_col = e0.n_in;
     p.flags = GI_GEMM_SPLITK;
-    p.nsplit = e.nsplit; p.c_split_stride = e.stride;
+    p.nsplit = e0.nsplit; p.c_split_stride = e0.stride;
     p.tm = 1; p.tn = 1;
-    p.C = slabs + e.off + (long long)e.done * e.nsplit * e.stride;
-    e.done++;
+    if (g.n) {
+        p.ngroups = g.n; p.grp_off = g.off;
+        for (int t = 0; t < g.n; ++t) {
+            SlabEntry& e = sp.e[widx[t]];
+            p.Cg[t] = slabs + e.off + (long long)e.done * e.nsplit * e.stride;
+            p.gsplit[t] = e.nsplit;
+            e.done++;
+        }
+    } else {
+        p.C = slabs + e0.off + (long long)e0.done * e0.nsplit * e0.stride;
+        e0.done++;
+    }
+}
+
+void flush_deferred(Run& r, Deferred& q) {
+    for (int base = 0; base < q.n && r.ok(); base += 8)
+        r.chk(gi_gemm_batch(q.p + base, std::min(8, q.n - base), r.st));
+    q.n = 0;
 }
 
 void mlp_jobs_forward(Run& r, float* ws, const MlpJob* jobs, int n) {
@@ -409,33 +391,61 @@ void mlp_jobs_forward(Run& r, float* ws, const MlpJob* jobs, int n) {
     }
 }
 
-// Layers are aligned from the END (step s handles layer L_j-1-s of job j).  Hidden activation
-// buffers are overwritten with their dZ; first-layer input gradients go to the jobs' (distinct) dX.
-void mlp_jobs_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, const MlpJob* jobs, int n) {
+// Layers are aligned from the END (step s handles layer L_j-1-s of job j).  dZ of hidden layer l
+// goes to the job's dz buffer l; first-layer input gradients go to the jobs' (distinct) dX;
+// weight gradients are deferred.
+void mlp_jobs_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred& dq,
+                       const MlpJob* jobs, int n) {
     int maxL = 0;
+    const Grp none{0, nullptr, 0};
     for (int j = 0; j < n; ++j) maxL = std::max(maxL, jobs[j].mlp->layers());
     for (int s = 0; s < maxL; ++s) {
-        Batch bw, bd;
+        Batch bd;
         for (int j = 0; j < n; ++j) {
             const MlpJob& q = jobs[j];
             const int L = q.mlp->layers(), l = L - 1 - s;
             if (l < 0) continue;
-            const float* dZ = (l == L - 1) ? q.Zlast : ws + q.acts[l];
+            const float* dZ = (l == L - 1) ? q.Zlast : ws + q.dzs[l];
             const int lddz = (l == L - 1) ? q.ldz : q.ldh;
             const float* Xl = (l == 0) ? q.X : ws + q.acts[l - 1];
-            add_wgrad(bw, sp, slabs, q.mlp->w(l), dZ, lddz, Xl, l == 0 ? q.ldx : q.ldh, q.rows);
-            const float* W = r.P[q.mlp->w(l)];
+            const int widx = q.mlp->w(l);
+            defer_wgrad(r, dq, sp, slabs, &widx, none, dZ, lddz, Xl, l == 0 ? q.ldx : q.ldh, nullptr,
+                        q.rows);
+            const float* W = r.P[widx];
             if (l > 0) {
-                float* prev = ws + q.acts[l - 1];
                 add_dgrad(bd, W, q.mlp->fan_out(l), q.mlp->fan_in(l), q.mlp->fan_in(l), dZ, lddz,
-                          q.rows, prev, q.ldh, prev, q.ldh, false);
+                          q.rows, ws + q.dzs[l - 1], q.ldh, ws + q.acts[l - 1], q.ldh, false);
             } else if (q.dX) {
                 add_dgrad(bd, W, q.mlp->fan_out(0), q.mlp->fan_in(0), q.dx_cols, dZ, lddz, q.rows,
                           q.dX, q.lddx, nullptr, 0, q.accumulate);
             }
         }
-        flush_batch(r, bw, true);
         flush_batch(r, bd, false);
+    }
+}
+
+// The bond-type-grouped message MLP: dZ chain now, weight gradients deferred.
+void msg_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred& dq, const Mlp* mlps,
+                  const Grp& g, const float* X, int ldx, const int* a_idx, int rows,
+                  const long long* acts, const long long* dzs, int ldh, const float* Zlast, int ldz,
+                  float* dX, int lddx, int dx_cols) {
+    const int L = mlps[0].layers();
+    for (int l = L - 1; l >= 0; --l) {
+        const float* dZ = (l == L - 1) ? Zlast : ws + dzs[l];
+        const int lddz = (l == L - 1) ? ldz : ldh;
+        const float* Xl = (l == 0) ? X : ws + acts[l - 1];
+        int widx[GI_MAX_GROUPS];
+        const float* Wg[GI_MAX_GROUPS];
+        for (int t = 0; t < g.n; ++t) { widx[t] = mlps[t].w(l); Wg[t] = r.P[widx[t]]; }
+        defer_wgrad(r, dq, sp, slabs, widx, g, dZ, lddz, Xl, l == 0 ? ldx : ldh,
+                    l == 0 ? a_idx : nullptr, rows);
+        const Mlp& q = mlps[0];
+        if (l > 0)
+            linear_dgrad(r, Wg, Wg[0], g, q.fan_out(l), q.fan_in(l), q.fan_in(l), dZ, lddz, rows,
+                         ws + dzs[l - 1], ldh, ws + acts[l - 1], ldh, false);
+        else if (dX)
+            linear_dgrad(r, Wg, Wg[0], g, q.fan_out(0), q.fan_in(0), dx_cols, dZ, lddz, rows, dX,
+                         lddx, nullptr, 0, false);
     }
 }
 
@@ -611,6 +621,8 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
     const int* mask = gfix + L.node_mask;
     const int NA = m.NA, NC = m.NC;
 
+    Deferred dq;
+    const Grp none{0, nullptr, 0};
     // ---- tier 2 (gnn/modules.py:265-279) ---------------------------------------------------------
     r.chk(gi_selu_bwd_rows(d_out, lddout, nullptr, y_out, ldout, ws + w.dzA, w.ldNA, d.B, NA, r.st));
     r.chk(gi_selu_bwd_rows(d_out + NA, lddout, nullptr, y_out + NA, ldout, ws + w.dzC, w.ldNC, d.B,
@@ -619,13 +631,13 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
                            d.B, 1, r.st));
     {
         MlpJob jobs[3] = {};
-        jobs[0] = {&m.add2, ws + w.cat_add, w.ldCA, d.B, w.add2_act, w.ldM2, nullptr, 0,
+        jobs[0] = {&m.add2, ws + w.cat_add, w.ldCA, d.B, w.add2_act, w.ldM2, nullptr, 0, w.add2_dz,
                    ws + w.dzA, w.ldNA, ws + w.dcat_add, w.ldCA, NA + d.G, false};
         jobs[1] = {&m.conn2, ws + w.cat_conn, w.ldCC, d.B, w.conn2_act, w.ldM2, nullptr, 0,
-                   ws + w.dzC, w.ldNC, ws + w.dcat_conn, w.ldCC, NC + d.G, false};
-        jobs[2] = {&m.term2, ws + w.gemb, w.ldG, d.B, w.term2_act, w.ldM2, nullptr, 0,
+                   w.conn2_dz, ws + w.dzC, w.ldNC, ws + w.dcat_conn, w.ldCC, NC + d.G, false};
+        jobs[2] = {&m.term2, ws + w.gemb, w.ldG, d.B, w.term2_act, w.ldM2, nullptr, 0, w.term2_dz,
                    ws + w.dzT, 4, ws + w.dgemb, w.ldG, d.G, false};
-        mlp_jobs_backward(r, ws, sp, slabs, jobs, 3);
+        mlp_jobs_backward(r, ws, sp, slabs, dq, jobs, 3);
     }
     // ---- gather + tier-1 glue: dZ of the last att/emb/add1/conn1 layers, in place ----------------
     r.chk(gi_gather_readout_bwd(ws + w.en, ws + w.embo, w.ldG, cidx, mask, d.B, d.N, d.G, S,
@@ -652,15 +664,15 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
     float* dhd = ws + w.dhd;
     {   // every sibling writes its own d h; the GRU-gate backward of the last pass sums the four
         MlpJob jobs[4] = {};
-        jobs[0] = {&m.add1, hxP, w.ldhx, R, w.add1_act, w.ldM1, nullptr, 0, ws + w.add1o, w.ldA, dh,
-                   w.ldH, d.H, false};
-        jobs[1] = {&m.conn1, hxP, w.ldhx, R, w.conn1_act, w.ldM1, nullptr, 0, ws + w.conn1o, w.ldC,
-                   dhb, w.ldH, d.H, false};
-        jobs[2] = {&m.emb, hxP, w.ldhx, R, w.emb_act, w.ldEmb, nullptr, 0, ws + w.embo, w.ldG, dhc,
-                   w.ldH, d.H, false};
-        jobs[3] = {&m.att, hxP, w.ldhx, R, w.att_act, w.ldAtt, nullptr, 0, ws + w.en, w.ldG, dhd,
-                   w.ldH, d.H, false};
-        mlp_jobs_backward(r, ws, sp, slabs, jobs, 4);
+        jobs[0] = {&m.add1, hxP, w.ldhx, R, w.add1_act, w.ldM1, nullptr, 0, w.add1_dz, ws + w.add1o,
+                   w.ldA, dh, w.ldH, d.H, false};
+        jobs[1] = {&m.conn1, hxP, w.ldhx, R, w.conn1_act, w.ldM1, nullptr, 0, w.conn1_dz,
+                   ws + w.conn1o, w.ldC, dhb, w.ldH, d.H, false};
+        jobs[2] = {&m.emb, hxP, w.ldhx, R, w.emb_act, w.ldEmb, nullptr, 0, w.emb_dz, ws + w.embo,
+                   w.ldG, dhc, w.ldH, d.H, false};
+        jobs[3] = {&m.att, hxP, w.ldhx, R, w.att_act, w.ldAtt, nullptr, 0, w.att_dz, ws + w.en, w.ldG,
+                   dhd, w.ldH, d.H, false};
+        mlp_jobs_backward(r, ws, sp, slabs, dq, jobs, 4);
     }
     // ---- message passes, reversed -------------------------------------------------------------------
     for (int p = d.passes - 1; p >= 0; --p) {
@@ -672,15 +684,14 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
         r.chk(gi_gru_gates_bwd(gi, gh, w.ld3H, hx, w.ldhx, dh, last ? dhb : nullptr,
                                last ? dhc : nullptr, last ? dhd : nullptr, dh2, w.ldH, seg_off, R,
                                d.H, r.st));
+        float* dagg = ws + w.dagg[p];
         {
-            Batch bw;
-            add_wgrad(bw, sp, slabs, m.gru_wih, gi, w.ld3H, agg, w.ldM, R);
-            add_wgrad(bw, sp, slabs, m.gru_whh, gh, w.ld3H, hx, w.ldhx, R);
-            flush_batch(r, bw, true);
-            // d agg = d gi W_ih (in place over agg: its wgrad above is already enqueued);
-            // d h_prev += d gh W_hh
+            const int wih = m.gru_wih, whh = m.gru_whh;
+            defer_wgrad(r, dq, sp, slabs, &wih, none, gi, w.ld3H, agg, w.ldM, nullptr, R);
+            defer_wgrad(r, dq, sp, slabs, &whh, none, gh, w.ld3H, hx, w.ldhx, nullptr, R);
+            // d agg = d gi W_ih;  d h_prev += d gh W_hh   (one launch)
             Batch bd;
-            add_dgrad(bd, params[m.gru_wih], 3 * d.H, d.M, d.M, gi, w.ld3H, R, agg, w.ldM, nullptr, 0,
+            add_dgrad(bd, params[m.gru_wih], 3 * d.H, d.M, d.M, gi, w.ld3H, R, dagg, w.ldM, nullptr, 0,
                       false);
             if (p > 0)
                 add_dgrad(bd, params[m.gru_whh], 3 * d.H, d.H, d.H, gh, w.ld3H, R, dh2, w.ldH, nullptr,
@@ -689,10 +700,11 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
         }
         if (E > 0) {
             // d m_e = d agg[dst(e)] * selu'(m_e)   (backward of the segmented sum + last SELU)
-            r.chk(gi_selu_bwd_rows(agg, w.ldM, e_dst, ws + w.m[p], w.ldM, ws + w.m[p], w.ldM, E,
+            r.chk(gi_selu_bwd_rows(dagg, w.ldM, e_dst, ws + w.m[p], w.ldM, ws + w.m[p], w.ldM, E,
                                    d.M, r.st));
-            mlp_backward(r, ws, sp, slabs, m.msg, bytype, hx, w.ldhx, e_src, E, w.eact[p], w.ldEh,
-                         ws + w.m[p], w.ldM, p > 0 ? ws + w.dxe : nullptr, w.ldH, d.H, false);
+            msg_backward(r, ws, sp, slabs, dq, m.msg, bytype, hx, w.ldhx, e_src, E, w.eact[p],
+                         w.edz[p], w.ldEh, ws + w.m[p], w.ldM, p > 0 ? ws + w.dxe : nullptr, w.ldH,
+                         d.H);
             if (p > 0)   // scatter d h_src back to nodes: segmented sum over the source CSR
                 r.chk(gi_seg_sum(ws + w.dxe, w.ldH, out_perm, src_off, R, d.H, dh2, w.ldH, 1, r.st));
         } else {
@@ -707,7 +719,8 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
         }
         std::swap(dh, dh2);
     }
-    // ---- slabs -> parameter gradients -----------------------------------------------------------------
+    // ---- all weight-gradient GEMMs, 8 problems per launch, then slabs -> parameter gradients -------
+    flush_deferred(r, dq);
     gi_reduce_desc descs[160];
     int nd = 0;
     auto add_desc = [&](int widx, int bidx) {
