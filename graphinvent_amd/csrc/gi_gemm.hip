@@ -153,7 +153,7 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
         }
     }
 
-    v4f ra[NA], rb[NB];
+    v4f ra0[NA], rb0[NB], ra1[NA], rb1[NB];    // two register stages: k tiles t+1 and t+2 in flight
 
     // Only the REDUCTION dimension needs zero fill (garbage there would reach valid outputs).  Along
     // the output dimensions out-of-range rows/columns are merely clamped to readable addresses:
@@ -165,7 +165,9 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
     const bool a_fast = A_MAJOR ? (p.lda >= ((p.M + 3) & ~3)) : true;
     const bool b_fast = B_MAJOR ? (p.ldb >= ((bcols + 3) & ~3)) : true;
 
-    auto gload = [&](int k0) {                       // raw loads only: nothing consumes the data here
+    // raw loads only (nothing consumes the data here); A half and B half are issued separately so
+    // they can be spread between MFMA groups
+    auto gload_a = [&](v4f (&ra)[NA], int k0) {
         if (!A_MAJOR) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) ra[i] = gi_load4_raw(Ap + a_off[i], k0 + 4 * cc4, a_cmax);
@@ -176,6 +178,8 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
                 ra[i] = gi_load4_raw(Ap + (long long)red * p.lda, m0 + 4 * a_mc4, a_cmax);
             }
         }
+    };
+    auto gload_b = [&](v4f (&rb)[NB], int k0) {
         if (!B_MAJOR) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) rb[i] = gi_load4_raw(Bp + b_off[i], k0 + 4 * cc4, b_cmax);
@@ -189,9 +193,9 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
         }
     };
 
-    auto sstore = [&](int buf, int k0) {             // (fix-up of the last k tile) + LDS write
+    // (fix-up of the last / padding k tile) + LDS write, A half and B half
+    auto sstore_a = [&](v4f (&ra)[NA], int buf, int k0) {
         float* a = As + buf * A_SZ;
-        float* b = Bs + buf * B_SZ;
         const bool full_k = k0 + BK <= k_end;        // block-uniform
         if (full_k && a_fast) {
 #pragma unroll
@@ -212,6 +216,10 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
                 }
             }
         }
+    };
+    auto sstore_b = [&](v4f (&rb)[NB], int buf, int k0) {
+        float* b = Bs + buf * B_SZ;
+        const bool full_k = k0 + BK <= k_end;
         if (full_k && b_fast) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
@@ -255,59 +263,84 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto compute = [&](int buf) {
+    // fragments of one 8-deep reduction group
+    auto read_frags = [&](int buf, int k8, float (&af)[TM][4], float (&bf)[TN][4]) {
         const float* a = As + buf * A_SZ;
         const float* b = Bs + buf * B_SZ;
 #pragma unroll
-        for (int k8 = 0; k8 < 4; ++k8) {
-            float af[TM][4], bf[TN][4];
+        for (int t = 0; t < TM; ++t) {
+            const int row = wm * 32 * TM + t * 32 + l31;
+            if (!A_MAJOR) {
+                const v4f v = *(const v4f*)&a[row * A_LD + k8 * 8 + 4 * lhi];
+                af[t][0] = v.x; af[t][1] = v.y; af[t][2] = v.z; af[t][3] = v.w;
+            } else {
 #pragma unroll
-            for (int t = 0; t < TM; ++t) {
-                const int row = wm * 32 * TM + t * 32 + l31;
-                if (!A_MAJOR) {
-                    const v4f v = *(const v4f*)&a[row * A_LD + k8 * 8 + 4 * lhi];
-                    af[t][0] = v.x; af[t][1] = v.y; af[t][2] = v.z; af[t][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) af[t][j] = a[(k8 * 8 + j + 4 * lhi) * A_LD + row];
-                }
+                for (int j = 0; j < 4; ++j) af[t][j] = a[(k8 * 8 + j + 4 * lhi) * A_LD + row];
             }
-#pragma unroll
-            for (int t = 0; t < TN; ++t) {
-                const int row = wn * 32 * TN + t * 32 + l31;
-                if (!B_MAJOR) {
-                    const v4f v = *(const v4f*)&b[row * B_LD + k8 * 8 + 4 * lhi];
-                    bf[t][0] = v.x; bf[t][1] = v.y; bf[t][2] = v.z; bf[t][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) bf[t][j] = b[(k8 * 8 + j + 4 * lhi) * B_LD + row];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][j], bf[tn][j],
-                                                                           acc[tm][tn], 0, 0, 0);
         }
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const int row = wn * 32 * TN + t * 32 + l31;
+            if (!B_MAJOR) {
+                const v4f v = *(const v4f*)&b[row * B_LD + k8 * 8 + 4 * lhi];
+                bf[t][0] = v.x; bf[t][1] = v.y; bf[t][2] = v.z; bf[t][3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[t][j] = b[(k8 * 8 + j + 4 * lhi) * B_LD + row];
+            }
+        }
+    };
+    auto mma = [&](const float (&af)[TM][4], const float (&bf)[TN][4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][j], bf[tn][j],
+                                                                       acc[tm][tn], 0, 0, 0);
     };
 
     // ---- main loop ----------------------------------------------------------------------------
-    const int nk = (k_end > k_begin) ? (k_end - k_begin + BK - 1) / BK : 0;
+    // Software pipeline, pinned with sched_barrier(0) (hipcc otherwise parks every non-MFMA
+    // instruction after the tile's MFMA block, where nothing hides it — a lone wave then reaches only
+    // 54 % MFMA duty, measured).  While the MFMAs of tile t run, the wave also issues
+    //   - the LDS fragment reads of the NEXT 8-deep group,
+    //   - the global loads of tile t+2 into the register stage that has just been drained,
+    //   - the LDS writes of tile t+1 (loaded during tile t-1) into the other LDS buffer,
+    // i.e. every memory instruction sits in the shadow of a 64-cycle MFMA.  The tile count is
+    // rounded up to even (a tile past k_end stages zeros) so the two-stage body has no mid exit.
+    const int nk = (k_end > k_begin) ? (((k_end - k_begin + BK - 1) / BK + 1) & ~1) : 0;
+    float af0[TM][4], bf0[TN][4], af1[TM][4], bf1[TN][4];
+#define GI_TILE(BUF, SA, SB_, RA, RB, KSTORE, KLOAD, DO_STORE, DO_LOAD)                         \
+    {                                                                                             \
+        read_frags(BUF, 0, af0, bf0);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        mma(af0, bf0); read_frags(BUF, 1, af1, bf1); if (DO_LOAD) gload_a(RA, KLOAD);             \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        mma(af1, bf1); read_frags(BUF, 2, af0, bf0); if (DO_LOAD) gload_b(RB, KLOAD);             \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        mma(af0, bf0); read_frags(BUF, 3, af1, bf1); if (DO_STORE) sstore_a(SA, (BUF) ^ 1, KSTORE); \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        mma(af1, bf1); if (DO_STORE) sstore_b(SB_, (BUF) ^ 1, KSTORE);                            \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        __syncthreads();                                                                          \
+    }
     if (nk > 0) {
-        gload(k_begin);
-        sstore(0, k_begin);
+        gload_a(ra0, k_begin); gload_b(rb0, k_begin);
+        gload_a(ra1, k_begin + BK); gload_b(rb1, k_begin + BK);
+        sstore_a(ra0, 0, k_begin); sstore_b(rb0, 0, k_begin);
     }
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1 < nk);
-        if (more) gload(k_begin + (kt + 1) * BK);
-        compute(kt & 1);
-        if (more) sstore((kt + 1) & 1, k_begin + (kt + 1) * BK);
-        __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        const bool more = kt + 2 < nk;
+        const int k1 = k_begin + (kt + 1) * BK, k2 = k1 + BK, k3 = k2 + BK;
+        // tile kt from LDS buffer 0: store tile kt+1 (stage 1) -> buffer 1, fetch tile kt+2 -> stage 0
+        GI_TILE(0, ra1, rb1, ra0, rb0, k1, k2, true, more)
+        // tile kt+1 from LDS buffer 1: store tile kt+2 (stage 0) -> buffer 0, fetch tile kt+3 -> stage 1
+        GI_TILE(1, ra0, rb0, ra1, rb1, k2, k3, more, more)
     }
+#undef GI_TILE
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     // Per 32x32 tile: ALL loads (activation for selu', old C for accumulate) are issued first from
