@@ -66,6 +66,13 @@ GDB13_DEFAULTS = dict(
     mlp2_depth=4,
     mlp2_hidden_dim=500,
     mlp2_dropout_p=0.0,
+    # AttGGNN only (parameters/defaults.py:340-363): per-bond-type message and attention MLPs
+    msg_depth=4,
+    msg_hidden_dim=250,
+    msg_dropout_p=0.0,
+    att_depth=4,
+    att_hidden_dim=250,
+    att_dropout_p=0.0,
 )
 
 
@@ -118,15 +125,23 @@ def _mlp_shapes(prefix: str, fan_in: int, hidden: int, depth: int, fan_out: int)
     return out
 
 
-def param_shapes(cfg: dict) -> "OrderedDict[str, Tuple[int, ...]]":
-    """state_dict keys and shapes of the reference ``GGNN`` in registration order
-    (gnn/mpnn.py:238-282; gnn/modules.py:24-37, 193-235)."""
+def param_shapes(cfg: dict, model: str = "GGNN") -> "OrderedDict[str, Tuple[int, ...]]":
+    """state_dict keys and shapes of the reference ``GGNN`` (gnn/mpnn.py:238-282) or
+    ``AttentionGGNN`` (gnn/mpnn.py:313-368) in registration order (gnn/modules.py:24-37, 193-235).
+    AttentionGGNN registers ``msg_nns`` before ``att_nns`` (both ModuleLists are created first,
+    :316-317) although the MLPs are constructed interleaved (:319-335)."""
     H, M, G = cfg["hidden_node_features"], cfg["message_size"], cfg["gather_width"]
     Fn, Fe, N = cfg["n_node_features"], cfg["n_edge_features"], cfg["max_n_nodes"]
     A, C = cfg["len_f_add_per_node"], cfg["len_f_conn_per_node"]
     items: List[Tuple[str, Tuple[int, ...]]] = []
-    for t in range(Fe):
-        items += _mlp_shapes(f"msg_nns.{t}", H, cfg["enn_hidden_dim"], cfg["enn_depth"], M)
+    if model == "AttGGNN":
+        for t in range(Fe):
+            items += _mlp_shapes(f"msg_nns.{t}", H, cfg["msg_hidden_dim"], cfg["msg_depth"], M)
+        for t in range(Fe):
+            items += _mlp_shapes(f"att_nns.{t}", H, cfg["att_hidden_dim"], cfg["att_depth"], M)
+    else:
+        for t in range(Fe):
+            items += _mlp_shapes(f"msg_nns.{t}", H, cfg["enn_hidden_dim"], cfg["enn_depth"], M)
     items += [("gru.weight_ih", (3 * H, M)), ("gru.weight_hh", (3 * H, H)),
               ("gru.bias_ih", (3 * H,)), ("gru.bias_hh", (3 * H,))]
     items += _mlp_shapes("gather.att_nn", Fn + H, cfg["gather_att_hidden_dim"],
@@ -143,7 +158,8 @@ def param_shapes(cfg: dict) -> "OrderedDict[str, Tuple[int, ...]]":
     return OrderedDict(items)
 
 
-def init_params(cfg: dict, seed: int = 0, dtype=torch.float32) -> "OrderedDict[str, torch.Tensor]":
+def init_params(cfg: dict, seed: int = 0, dtype=torch.float32,
+                model: str = "GGNN") -> "OrderedDict[str, torch.Tensor]":
     """Deterministic parameters with the reference's init *distributions* (Xavier-uniform Linear
     weights gnn/modules.py:163, torch-default Linear bias and GRUCell U(-1/sqrt(fan),+)), drawn
     from numpy's PCG64 so the same seed gives the same weights on every machine and torch
@@ -151,13 +167,14 @@ def init_params(cfg: dict, seed: int = 0, dtype=torch.float32) -> "OrderedDict[s
     rng = np.random.default_rng(seed)
     H = cfg["hidden_node_features"]
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
-    for key, shape in param_shapes(cfg).items():
+    shapes = param_shapes(cfg, model)
+    for key, shape in shapes.items():
         if key.startswith("gru."):
             bound = 1.0 / math.sqrt(H)
         elif key.endswith(".weight"):
             bound = math.sqrt(6.0 / (shape[0] + shape[1]))
         else:
-            fan_in = param_shapes(cfg)[key[:-4] + "weight"][1]
+            fan_in = shapes[key[:-4] + "weight"][1]
             bound = 1.0 / math.sqrt(fan_in)
         arr = rng.uniform(-bound, bound, size=shape).astype(np.float32)
         out[key] = torch.from_numpy(arr).to(dtype)
@@ -259,6 +276,56 @@ def ggnn_forward(P: Dict[str, torch.Tensor], cfg: dict, nodes: torch.Tensor,
     return global_readout(P, hidden, graph_emb)                          # mpnn.py:302
 
 
+def attggnn_forward(P: Dict[str, torch.Tensor], cfg: dict, nodes: torch.Tensor,
+                    edges: torch.Tensor) -> torch.Tensor:
+    """``AttentionGGNN.forward`` = ``AggregationMPNN.forward`` (gnn/aggregation_mpnn.py:83-168)
+    with ``aggregate_message`` (gnn/mpnn.py:370-389): neighbour-padded [V, maxdeg, .] layout, every
+    bond-type MLP (message and attention) on every padded neighbour slot, gated by the slot's
+    bond-type indicator, energies of padding slots pushed down by big_positive, softmax over the
+    neighbour axis per feature, weighted sum, GRU update of the nodes that have neighbours."""
+    dtype = nodes.dtype
+    H = cfg["hidden_node_features"]
+    adjacency = edges.sum(dim=3)                                                  # :113
+    eb, ei, ej = adjacency.nonzero(as_tuple=True)                                 # :116-117
+    nb, ni = adjacency.sum(-1).nonzero(as_tuple=True)                             # :119
+    degrees = adjacency[nb, ni, :].sum(-1).long()                                 # :120-122
+    V = nb.shape[0]
+    maxdeg = int(degrees.max()) if V else 0                                       # :123
+    slot_in_node = torch.cat([torch.arange(int(k)) for k in degrees]) if V else eb   # :134-136
+    node_of_edge = torch.repeat_interleave(torch.arange(V), degrees)              # :138-140
+    nghb_mask = torch.zeros(V, maxdeg, dtype=dtype)                               # :142-146
+    nghb_mask[node_of_edge, slot_in_node] = 1
+    nghb_edges = torch.zeros(V, maxdeg, cfg["n_edge_features"], dtype=dtype)      # :128-131,148-149
+    nghb_edges[node_of_edge, slot_in_node, :] = edges[eb, ei, ej, :]
+    hidden = torch.zeros(nodes.shape[0], nodes.shape[1], H, dtype=dtype)          # :152-156
+    hidden[:, :, :nodes.shape[2]] = nodes
+    for _ in range(cfg["message_passes"]):                                        # :158
+        node_rows = hidden[nb, ni, :]                                             # :160
+        nghb_hidden = torch.zeros(V, maxdeg, H, dtype=dtype)                      # :124-127,161-162
+        nghb_hidden[node_of_edge, slot_in_node, :] = hidden[eb, ej, :]
+        # aggregate_message, gnn/mpnn.py:370-389
+        energy_mask = (nghb_mask == 0).to(dtype) * cfg["big_positive"]
+        emb = None
+        en = None
+        for t in range(cfg["n_edge_features"]):
+            gate = nghb_edges[:, :, t].unsqueeze(-1)
+            e_t = gate * mlp(P, f"msg_nns.{t}", nghb_hidden)
+            a_t = gate * mlp(P, f"att_nns.{t}", nghb_hidden)
+            emb = e_t if emb is None else emb + e_t
+            en = a_t if en is None else en + a_t
+        attention = torch.softmax(en - energy_mask.unsqueeze(-1), dim=1)
+        messages = torch.sum(attention * emb, dim=1)
+        new_rows = gru_cell(P, messages, node_rows)                               # :169-170
+        hidden = hidden.clone()
+        hidden[nb, ni, :] = new_rows
+    node_mask = adjacency.sum(-1) != 0                                            # :164
+    graph_emb = graph_gather(P, cfg, hidden, nodes, node_mask)
+    return global_readout(P, hidden, graph_emb)
+
+
+FORWARDS = {"GGNN": ggnn_forward, "AttGGNN": None}   # filled below
+
+
 def kl_loss(output: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     """Workflow.py:850-858 — KLDivLoss(batchmean)(log_softmax(out), target / sum(target))."""
     logp = torch.log_softmax(output, dim=1)
@@ -266,11 +333,14 @@ def kl_loss(output: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     return torch.nn.functional.kl_div(logp, tgt, reduction="batchmean")
 
 
-def forward_backward(P, cfg, nodes, edges, target):
+FORWARDS["AttGGNN"] = attggnn_forward
+
+
+def forward_backward(P, cfg, nodes, edges, target, model: str = "GGNN"):
     """One forward + loss + backward; returns (logits, loss, grads-by-key).  Train-step order of
     Workflow.py:785-796 up to (not including) the optimizer."""
     leaves = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in P.items())
-    out = ggnn_forward(leaves, cfg, nodes, edges)
+    out = FORWARDS[model](leaves, cfg, nodes, edges)
     loss = kl_loss(out, target)
     grads = torch.autograd.grad(loss, list(leaves.values()))
     return out.detach(), loss.detach(), OrderedDict(zip(leaves.keys(), grads))
@@ -280,15 +350,16 @@ class OracleGGNN(torch.nn.Module):
     """nn.Module wrapper over the functional oracle (same state_dict keys as the reference) so
     tests and the CPU-baseline timer can drive it with a torch optimizer."""
 
-    def __init__(self, cfg: dict, seed: int = 0):
+    def __init__(self, cfg: dict, seed: int = 0, model: str = "GGNN"):
         super().__init__()
         self.cfg = dict(cfg)
-        self._keys = list(param_shapes(cfg).keys())
+        self.model = model
+        self._keys = list(param_shapes(cfg, model).keys())
         self._flat = torch.nn.ParameterList(
-            [torch.nn.Parameter(v) for v in init_params(cfg, seed).values()])
+            [torch.nn.Parameter(v) for v in init_params(cfg, seed, model=model).values()])
 
     def named_oracle_params(self):
         return OrderedDict(zip(self._keys, self._flat))
 
     def forward(self, nodes, edges):
-        return ggnn_forward(self.named_oracle_params(), self.cfg, nodes, edges)
+        return FORWARDS[self.model](self.named_oracle_params(), self.cfg, nodes, edges)

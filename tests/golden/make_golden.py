@@ -34,7 +34,7 @@ sys.path.insert(0, REF)
 
 from oracle import ggnn_oracle as O                      # noqa: E402
 from graphinvent_amd import synthetic                    # noqa: E402
-from tests.golden.spec import TINY, digest, tiny_inputs   # noqa: E402
+from tests.golden.spec import TINY, TINY_ATT, digest, tiny_inputs   # noqa: E402
 import gnn.mpnn as ref_mpnn                              # noqa: E402  (the reference)
 
 assert ref_mpnn.__file__.startswith(REF), ref_mpnn.__file__
@@ -80,9 +80,9 @@ def convert_fixtures():
 
 
 # ---------------------------------------------------------------------------------------------
-def reference_run(cfg, P, nodes, edges, target):
+def reference_run(cfg, P, nodes, edges, target, cls=None):
     """Unmodified reference forward/backward with the given weights."""
-    model = ref_mpnn.GGNN(O.as_constants(cfg))
+    model = (cls or ref_mpnn.GGNN)(O.as_constants(cfg))
     missing = model.load_state_dict(P, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     assert list(model.state_dict().keys()) == list(P.keys())          # registration order too
@@ -129,9 +129,24 @@ def make_gdb13():
           "n_params", sum(v.numel() for v in P.values()))
 
 
+def make_att_tiny():
+    """AttentionGGNN (gnn/mpnn.py:306-398), BASELINE config 5's model class."""
+    cfg = O.make_config(**{k: v for k, v in TINY_ATT.items()})
+    P = O.init_params(cfg, seed=13, model="AttGGNN")
+    n8, e8, a8 = tiny_inputs()
+    nodes, edges, target = (torch.from_numpy(x).float() for x in (n8, e8, a8))
+    out, loss, grads = reference_run(cfg, P, nodes, edges, target, cls=ref_mpnn.AttentionGGNN)
+    blob = dict(nodes=n8, edges=e8, apds=a8, logits=out.numpy(), loss=loss.numpy())
+    blob.update({"param." + k: v.numpy() for k, v in P.items()})
+    blob.update({"grad." + k: v.numpy() for k, v in grads.items()})
+    np.savez_compressed(f"{HERE}/golden_att_tiny.npz", **blob)
+    print("att tiny: loss", float(loss), "logits", tuple(out.shape), "params", len(P))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     convert_fixtures()
     make_tiny()
     make_gdb13()
+    make_att_tiny()

@@ -40,3 +40,7 @@ def tiny_inputs():
     return n, e, a
 
 
+
+
+# AttentionGGNN tiny config = TINY plus the per-bond-type message / attention MLP sizes
+TINY_ATT = dict(TINY, msg_depth=2, msg_hidden_dim=24, att_depth=2, att_hidden_dim=20)

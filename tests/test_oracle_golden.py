@@ -91,3 +91,20 @@ def test_fixture_quirks(golden_dir):
     P = O.init_params(cfg, seed=1)
     nodes, edges, tgt = (torch.from_numpy(tr[k][120:150]).float() for k in ("nodes", "edges", "APDs"))
     assert torch.isnan(O.kl_loss(O.ggnn_forward(P, cfg, nodes, edges), tgt))
+
+
+def test_attggnn_oracle_matches_reference(golden_dir):
+    """AttentionGGNN (BASELINE config 5's model): oracle restatement vs the reference's outputs."""
+    from tests.golden.spec import TINY_ATT
+    g = np.load(os.path.join(golden_dir, "golden_att_tiny.npz"))
+    cfg = O.make_config(**TINY_ATT)
+    P = O.init_params(cfg, seed=13, model="AttGGNN")
+    assert [k[6:] for k in g.files if k.startswith("param.")] == list(P)      # registration order
+    for k, v in P.items():
+        assert np.array_equal(v.numpy(), g["param." + k]), k
+    nodes, edges, tgt = (torch.from_numpy(g[k]).float() for k in ("nodes", "edges", "apds"))
+    out, loss, grads = O.forward_backward(P, cfg, nodes, edges, tgt, model="AttGGNN")
+    assert rel(out.numpy(), g["logits"]) < 2e-6
+    assert abs(float(loss) - float(g["loss"])) < 1e-6 * abs(float(g["loss"]))
+    for k, v in grads.items():
+        assert rel(v.numpy(), g["grad." + k]) < 2e-5, k
