@@ -33,7 +33,7 @@ struct Mlp {
 
 struct Model {
     gi_ggnn_dims d;
-    Mlp msg[GI_MAX_GROUPS], att, emb, add1, conn1, add2, conn2, term2;
+    Mlp msg[GI_MAX_GROUPS], eatt[GI_MAX_GROUPS], att, emb, add1, conn1, add2, conn2, term2;
     int gru_wih, gru_whh, gru_bih, gru_bhh, nparams, NA, NC;
 };
 
@@ -44,7 +44,11 @@ int build_model(const gi_ggnn_dims* dp, Model& m) {
         d.A <= 0 || d.C <= 0 || d.passes < 0 || d.Fn > d.H)
         return GI_EINVAL;
     if (d.N > GI_MAX_NODES || d.Fe > GI_MAX_GROUPS || d.passes > MAXP) return GI_ELIMIT;
-    const int depths[] = {d.enn_depth, d.att_depth, d.emb_depth, d.mlp1_depth, d.mlp2_depth};
+    if (d.kind != GI_KIND_GGNN && d.kind != GI_KIND_ATTGGNN) return GI_EINVAL;
+    const bool attn = d.kind == GI_KIND_ATTGGNN;
+    if (attn && d.eatt_hidden <= 0 && d.eatt_depth > 0) return GI_EINVAL;
+    const int depths[] = {d.enn_depth, d.att_depth, d.emb_depth, d.mlp1_depth, d.mlp2_depth,
+                          attn ? d.eatt_depth : 0};
     for (int x : depths)
         if (x < 0 || x + 1 > MAXL) return GI_ELIMIT;
     m.d = d;
@@ -57,6 +61,8 @@ int build_model(const gi_ggnn_dims* dp, Model& m) {
         return r;
     };
     for (int t = 0; t < d.Fe; ++t) m.msg[t] = mk(d.H, d.enn_hidden, d.enn_depth, d.M);
+    if (attn)   // AttentionGGNN registers msg_nns before att_nns (gnn/mpnn.py:316-317)
+        for (int t = 0; t < d.Fe; ++t) m.eatt[t] = mk(d.H, d.eatt_hidden, d.eatt_depth, d.M);
     m.gru_wih = idx++; m.gru_whh = idx++; m.gru_bih = idx++; m.gru_bhh = idx++;
     m.att = mk(d.H + d.Fn, d.att_hidden, d.att_depth, d.G);
     m.emb = mk(d.H, d.emb_hidden, d.emb_depth, d.G);
@@ -73,8 +79,11 @@ int build_model(const gi_ggnn_dims* dp, Model& m) {
 struct Ws {
     int R, E, B;
     int ldhx, ldH, ldM, ld3H, ldG, ldA, ldC, ldEh, ldAtt, ldEmb, ldM1, ldM2, ldNA, ldNC, ldCA,
-        ldCC, ldZG;
+        ldCC, ldZG, ldEa;
     long long hx[MAXP + 1];
+    // AttGGNN only: hidden activations / dZ of the per-bond-type energy MLP, its output (edge
+    // energies), and its first-layer input gradient
+    long long aact[MAXP][MAXL], een[MAXP], adz[MAXP][MAXL], dxa;
     long long eact[MAXP][MAXL], m[MAXP], agg[MAXP], gi[MAXP], gh[MAXP];
     long long att_act[MAXL], en, emb_act[MAXL], embo, add1_act[MAXL], add1o, conn1_act[MAXL],
         conn1o;
@@ -97,6 +106,8 @@ void make_ws(const Model& m, int S, int E, Ws& w) {
     w.ldAtt = gi_r4(d.att_hidden); w.ldEmb = gi_r4(d.emb_hidden); w.ldM1 = gi_r4(d.mlp1_hidden);
     w.ldM2 = gi_r4(d.mlp2_hidden); w.ldNA = gi_r4(m.NA); w.ldNC = gi_r4(m.NC);
     w.ldCA = gi_r4(m.NA + d.G); w.ldCC = gi_r4(m.NC + d.G); w.ldZG = gi_r4(2 * d.G);
+    const bool attn = d.kind == GI_KIND_ATTGGNN;
+    w.ldEa = attn ? gi_r4(d.eatt_hidden) : 4;
     long long o = 0;
     auto take = [&](long long rows, int ld) { long long r = o; o += gi_r4l(rows * ld); return r; };
     const long long R = w.R, B = d.B, Er = std::max(E, 1);
@@ -104,6 +115,10 @@ void make_ws(const Model& m, int S, int E, Ws& w) {
     for (int p = 0; p < d.passes; ++p) {
         for (int l = 0; l < d.enn_depth; ++l) w.eact[p][l] = take(Er, w.ldEh);
         w.m[p] = take(Er, w.ldM);
+        if (attn) {
+            for (int l = 0; l < d.eatt_depth; ++l) w.aact[p][l] = take(Er, w.ldEa);
+            w.een[p] = take(Er, w.ldM);
+        }
         w.agg[p] = take(R, w.ldM);
         w.gi[p] = take(R, w.ld3H);
         w.gh[p] = take(R, w.ld3H);
@@ -130,8 +145,11 @@ void make_ws(const Model& m, int S, int E, Ws& w) {
     w.dhb = take(R, w.ldH); w.dhc = take(R, w.ldH); w.dhd = take(R, w.ldH);
     for (int p = 0; p < d.passes; ++p) {
         for (int l = 0; l < d.enn_depth; ++l) w.edz[p][l] = take(Er, w.ldEh);
+        if (attn)
+            for (int l = 0; l < d.eatt_depth; ++l) w.adz[p][l] = take(Er, w.ldEa);
         w.dagg[p] = take(R, w.ldM);
     }
+    if (attn) w.dxa = take(Er, w.ldH);
     for (int l = 0; l < d.att_depth; ++l) w.att_dz[l] = take(R, w.ldAtt);
     for (int l = 0; l < d.emb_depth; ++l) w.emb_dz[l] = take(R, w.ldEmb);
     for (int l = 0; l < d.mlp1_depth; ++l) { w.add1_dz[l] = take(R, w.ldM1); w.conn1_dz[l] = take(R, w.ldM1); }
@@ -178,6 +196,8 @@ void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {
     for (int t = 0; t < d.Fe; ++t) {
         const int et = Et ? Et[t] : E / d.Fe;
         add_mlp(m.msg[t], et, d.passes, E > 0 ? 1.5 * (double)et / E : 1.0);
+        if (d.kind == GI_KIND_ATTGGNN)
+            add_mlp(m.eatt[t], et, d.passes, E > 0 ? 1.5 * (double)et / E : 1.0);
     }
     add(m.gru_wih, 3 * d.H, d.M, R, d.passes, 1.0);
     add(m.gru_whh, 3 * d.H, d.H, R, d.passes, 1.0);
@@ -449,6 +469,87 @@ void msg_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred& dq, c
     }
 }
 
+// ---- AttGGNN: the message MLP and the energy MLP of a pass are siblings (same input rows, same
+// bond-type grouping): layer l of both goes into one launch, like the readout's sibling stacks.
+struct EdgeChain {
+    const Mlp* mlps;               // [Fe] per-bond-type stacks
+    const long long* acts;         // hidden activations (ws offsets)
+    const long long* dzs;          // hidden dZ buffers (ws offsets)
+    int ldh;
+    float* out; int ldout;         // forward: last layer's output; backward: its dZ (in place)
+    float* dX;                     // backward: first-layer input gradient [E, ldH] or null
+};
+
+void grouped_problem(gi_gemm_params& p, const Grp& g) {
+    p.ngroups = g.n; p.grp_off = g.off; p.max_group_rows = g.max_rows;
+}
+
+void edge_chains_forward(Run& r, float* ws, const EdgeChain* ch, int n, const Grp& g,
+                         const float* X, int ldx, const int* a_idx, int rows) {
+    int maxL = 0;
+    for (int j = 0; j < n; ++j) maxL = std::max(maxL, ch[j].mlps[0].layers());
+    for (int l = 0; l < maxL; ++l) {
+        Batch b;
+        for (int j = 0; j < n; ++j) {
+            const EdgeChain& c = ch[j];
+            const Mlp& q = c.mlps[0];
+            const int L = q.layers();
+            if (l >= L) continue;
+            gi_gemm_params& p = b.next();
+            p.A = (l == 0) ? X : ws + c.acts[l - 1];
+            p.lda = (l == 0) ? ldx : c.ldh;
+            p.a_idx = (l == 0) ? a_idx : nullptr;
+            p.C = (l == L - 1) ? c.out : ws + c.acts[l];
+            p.ldc = (l == L - 1) ? c.ldout : c.ldh;
+            p.M = rows; p.N = q.fan_out(l); p.K = q.fan_in(l); p.ldb = q.fan_in(l);
+            p.flags = GI_EPI_BIAS | GI_EPI_SELU;
+            grouped_problem(p, g);
+            for (int t = 0; t < g.n; ++t) {
+                p.Bg[t] = r.P[c.mlps[t].w(l)]; p.biasg[t] = r.P[c.mlps[t].b(l)];
+            }
+        }
+        flush_batch(r, b, false);
+    }
+}
+
+// layers aligned from the end; weight gradients deferred
+void edge_chains_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred& dq,
+                          const EdgeChain* ch, int n, const Grp& g, const float* X, int ldx,
+                          const int* a_idx, int rows, int lddx, int dx_cols) {
+    int maxL = 0;
+    for (int j = 0; j < n; ++j) maxL = std::max(maxL, ch[j].mlps[0].layers());
+    for (int s = 0; s < maxL; ++s) {
+        Batch bd;
+        for (int j = 0; j < n; ++j) {
+            const EdgeChain& c = ch[j];
+            const Mlp& q = c.mlps[0];
+            const int L = q.layers(), l = L - 1 - s;
+            if (l < 0) continue;
+            const float* dZ = (l == L - 1) ? c.out : ws + c.dzs[l];
+            const int lddz = (l == L - 1) ? c.ldout : c.ldh;
+            const float* Xl = (l == 0) ? X : ws + c.acts[l - 1];
+            int widx[GI_MAX_GROUPS];
+            for (int t = 0; t < g.n; ++t) widx[t] = c.mlps[t].w(l);
+            defer_wgrad(r, dq, sp, slabs, widx, g, dZ, lddz, Xl, l == 0 ? ldx : c.ldh,
+                        l == 0 ? a_idx : nullptr, rows);
+            if (l == 0 && !c.dX) continue;
+            gi_gemm_params& p = bd.next();
+            p.A = dZ; p.lda = lddz; p.M = rows; p.K = q.fan_out(l); p.ldb = q.fan_in(l);
+            p.b_major = 1;
+            grouped_problem(p, g);
+            for (int t = 0; t < g.n; ++t) p.Bg[t] = r.P[widx[t]];
+            if (l > 0) {
+                p.C = ws + c.dzs[l - 1]; p.ldc = c.ldh; p.N = q.fan_in(l);
+                p.act = ws + c.acts[l - 1]; p.ldact = c.ldh;
+                p.flags = GI_EPI_DSELU;
+            } else {
+                p.C = c.dX; p.ldc = lddx; p.N = dx_cols;
+            }
+        }
+        flush_batch(r, bd, false);
+    }
+}
+
 }  // namespace
 
 // ================================ C ABI ==========================================================
@@ -512,6 +613,7 @@ extern "C" int gi_ggnn_ws_query(const gi_ggnn_dims* d, int S, int E, const char*
         {"term2_act", w.term2_act[j], w.ldM2}, {"dcat_add", w.dcat_add, w.ldCA},
         {"dcat_conn", w.dcat_conn, w.ldCC}, {"dgemb", w.dgemb, w.ldG}, {"dh", w.dh, w.ldH},
         {"dh2", w.dh2, w.ldH}, {"dxe", w.dxe, w.ldH},
+        {"aact", w.aact[i < MAXP ? i : 0][j], w.ldEa}, {"een", w.een[i < MAXP ? i : 0], w.ldM},
     };
     for (const Item& it : items)
         if (!strcmp(it.n, name)) { *off = it.o; *ld = it.l; return 0; }
@@ -529,6 +631,7 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
     if (E > 0 && (!e_src || !in_perm)) return GI_EINVAL;
     const gi_ggnn_dims& d = m.d;
     if (ldout < m.NA + m.NC + 1) return GI_EINVAL;
+    if (d.kind == GI_KIND_ATTGGNN && E == 0) in_perm = in_perm ? in_perm : gfix;   // never read
     gi_compact_layout_t L;
     rc = gi_compact_layout(d.B, d.N, d.Fe, &L);
     if (rc) return rc;
@@ -542,16 +645,30 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
     const int* seg_off = gfix + L.seg_off;
     const int* cidx = gfix + L.cidx;
     const int* mask = gfix + L.node_mask;
+    const bool attn = d.kind == GI_KIND_ATTGGNN;
 
     // ---- message passes (gnn/summation_mpnn.py:128-144) ----------------------------------------
     for (int p = 0; p < d.passes; ++p) {
         const float* hx = ws + w.hx[p];
-        if (E > 0)   // m_e = MLP_type(e)(h_src(e)), gnn/mpnn.py:284-294 routed per bond type
-            mlp_forward(r, ws, m.msg, bytype, hx, w.ldhx, e_src, E, w.eact[p], w.ldEh,
-                        ws + w.m[p], w.ldM);
-        // a_v = sum of incoming messages (:141)
-        r.chk(gi_seg_sum(ws + w.m[p], w.ldM, in_perm, seg_off, R, d.M, ws + w.agg[p], w.ldM, 0,
-                         r.st));
+        if (attn) {
+            // AttentionGGNN.aggregate_message (gnn/mpnn.py:370-389): message and energy MLPs of the
+            // edge's bond type on h_src(e), softmax over each node's incoming edges, weighted sum
+            if (E > 0) {
+                EdgeChain ch[2] = {
+                    {m.msg, w.eact[p], w.edz[p], w.ldEh, ws + w.m[p], w.ldM, nullptr},
+                    {m.eatt, w.aact[p], w.adz[p], w.ldEa, ws + w.een[p], w.ldM, nullptr}};
+                edge_chains_forward(r, ws, ch, 2, bytype, hx, w.ldhx, e_src, E);
+            }
+            r.chk(gi_seg_softmax_fwd(ws + w.een[p], ws + w.m[p], w.ldM, in_perm, seg_off, R, d.M,
+                                     ws + w.agg[p], w.ldM, r.st));
+        } else {
+            if (E > 0)   // m_e = MLP_type(e)(h_src(e)), gnn/mpnn.py:284-294 routed per bond type
+                mlp_forward(r, ws, m.msg, bytype, hx, w.ldhx, e_src, E, w.eact[p], w.ldEh,
+                            ws + w.m[p], w.ldM);
+            // a_v = sum of incoming messages (:141)
+            r.chk(gi_seg_sum(ws + w.m[p], w.ldM, in_perm, seg_off, R, d.M, ws + w.agg[p], w.ldM, 0,
+                             r.st));
+        }
         // GRU update (gnn/mpnn.py:296-297): both input projections in one launch
         {
             Batch b;
@@ -590,8 +707,8 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
 }
 
 extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* params, const int* gfix,
-                                const int* e_src, const int* e_dst, const int* out_perm, int S,
-                                int E, const int* Et, float* ws, float* slabs, const float* y_out,
+                                const int* e_src, const int* e_dst, const int* in_perm,
+                                const int* out_perm, int S, int E, const int* Et, float* ws, float* slabs, const float* y_out,
                                 int ldout, const float* d_out, int lddout, float* const* grads,
                                 void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
@@ -600,7 +717,7 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
     if (rc) return rc;
     if (!params || !gfix || !ws || !slabs || !y_out || !d_out || !grads || S < 0 || E < 0 || !Et)
         return GI_EINVAL;
-    if (E > 0 && (!e_src || !e_dst || !out_perm)) return GI_EINVAL;
+    if (E > 0 && (!e_src || !e_dst || !in_perm || !out_perm)) return GI_EINVAL;
     if (m.nparams > 160) return GI_ELIMIT;
     const gi_ggnn_dims& d = m.d;
     gi_compact_layout_t L;
@@ -620,6 +737,7 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
     const int* cidx = gfix + L.cidx;
     const int* mask = gfix + L.node_mask;
     const int NA = m.NA, NC = m.NC;
+    const bool attn = d.kind == GI_KIND_ATTGGNN;
 
     Deferred dq;
     const Grp none{0, nullptr, 0};
@@ -698,7 +816,21 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
                           0, true);
             flush_batch(r, bd, false);
         }
-        if (E > 0) {
+        if (E > 0 && attn) {
+            // backward of softmax-weighted aggregation + last SELU of both stacks, in place
+            r.chk(gi_seg_softmax_bwd(ws + w.een[p], ws + w.m[p], w.ldM, in_perm, seg_off, R, d.M,
+                                     dagg, w.ldM, r.st));
+            EdgeChain ch[2] = {
+                {m.msg, w.eact[p], w.edz[p], w.ldEh, ws + w.m[p], w.ldM, p > 0 ? ws + w.dxe : nullptr},
+                {m.eatt, w.aact[p], w.adz[p], w.ldEa, ws + w.een[p], w.ldM,
+                 p > 0 ? ws + w.dxa : nullptr}};
+            edge_chains_backward(r, ws, sp, slabs, dq, ch, 2, bytype, hx, w.ldhx, e_src, E, w.ldH,
+                                 d.H);
+            if (p > 0) {
+                r.chk(gi_seg_sum(ws + w.dxe, w.ldH, out_perm, src_off, R, d.H, dh2, w.ldH, 1, r.st));
+                r.chk(gi_seg_sum(ws + w.dxa, w.ldH, out_perm, src_off, R, d.H, dh2, w.ldH, 1, r.st));
+            }
+        } else if (E > 0) {
             // d m_e = d agg[dst(e)] * selu'(m_e)   (backward of the segmented sum + last SELU)
             r.chk(gi_selu_bwd_rows(dagg, w.ldM, e_dst, ws + w.m[p], w.ldM, ws + w.m[p], w.ldM, E,
                                    d.M, r.st));
@@ -709,12 +841,16 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
                 r.chk(gi_seg_sum(ws + w.dxe, w.ldH, out_perm, src_off, R, d.H, dh2, w.ldH, 1, r.st));
         } else {
             // no edges: the message MLP weights still need zeroed slabs
-            for (int t = 0; t < d.Fe; ++t)
-                for (int l = 0; l < m.msg[t].layers(); ++l) {
-                    SlabEntry& e = sp.e[m.msg[t].w(l)];
-                    r.chk((int)hipMemsetAsync(slabs + e.off + (long long)e.done * e.nsplit * e.stride,
-                                              0, sizeof(float) * e.nsplit * e.stride, r.st));
-                    e.done++;
+            for (int k = 0; k < (attn ? 2 : 1); ++k)
+                for (int t = 0; t < d.Fe; ++t) {
+                    const Mlp& q = k ? m.eatt[t] : m.msg[t];
+                    for (int l = 0; l < q.layers(); ++l) {
+                        SlabEntry& e = sp.e[q.w(l)];
+                        r.chk((int)hipMemsetAsync(
+                            slabs + e.off + (long long)e.done * e.nsplit * e.stride, 0,
+                            sizeof(float) * e.nsplit * e.stride, r.st));
+                        e.done++;
+                    }
                 }
         }
         std::swap(dh, dh2);
@@ -734,6 +870,8 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
         for (int l = 0; l < q.layers(); ++l) add_desc(q.w(l), q.b(l));
     };
     for (int t = 0; t < d.Fe; ++t) add_mlp_desc(m.msg[t]);
+    if (attn)
+        for (int t = 0; t < d.Fe; ++t) add_mlp_desc(m.eatt[t]);
     add_desc(m.gru_wih, m.gru_bih);
     add_desc(m.gru_whh, m.gru_bhh);
     add_mlp_desc(m.att); add_mlp_desc(m.emb); add_mlp_desc(m.add1); add_mlp_desc(m.conn1);

@@ -36,6 +36,81 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(
     *dst = acc;
 }
 
+// ---- AttGGNN attention aggregation (gnn/mpnn.py:370-389) ------------------------------------------
+// One thread per (destination row, 16-byte feature group).  The reference pads every node's
+// neighbour list to the batch's maximum degree and masks with -1e6; here the softmax runs over the
+// node's own CSR segment (padding slots contribute exp(-1e6 - max) == 0 in fp32 there too).
+// Three short passes over the segment (<= max degree rows): max, sum of exp, weighted sum.
+__device__ __forceinline__ v4f v4_max(v4f a, v4f b) {
+    return v4f{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)};
+}
+__device__ __forceinline__ v4f v4_exp(v4f a) {
+    return v4f{__expf(a.x), __expf(a.y), __expf(a.z), __expf(a.w)};
+}
+__device__ __forceinline__ v4f v4_rcp(v4f a) {
+    return v4f{1.f / a.x, 1.f / a.y, 1.f / a.z, 1.f / a.w};
+}
+__device__ __forceinline__ v4f v4_selu_grad(v4f y) {
+    return v4f{gi_selu_grad(y.x), gi_selu_grad(y.y), gi_selu_grad(y.z), gi_selu_grad(y.w)};
+}
+
+__global__ __launch_bounds__(256) void seg_softmax_fwd_kernel(
+    const float* __restrict__ en, const float* __restrict__ emb, int ld,
+    const int* __restrict__ perm, const int* __restrict__ off, int rows, int c4n,
+    float* __restrict__ out, int ldo) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(t / c4n), q = (int)(t - (long long)c * c4n);
+    if (c >= rows) return;
+    const int lo = off[c], hi = off[c + 1];
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    if (hi > lo) {
+        v4f mx = *(const v4f*)(en + (long long)perm[lo] * ld + 4 * q);
+        for (int k = lo + 1; k < hi; ++k)
+            mx = v4_max(mx, *(const v4f*)(en + (long long)perm[k] * ld + 4 * q));
+        v4f den = {0.f, 0.f, 0.f, 0.f};
+        for (int k = lo; k < hi; ++k) {
+            const long long r = (long long)perm[k] * ld + 4 * q;
+            const v4f e = v4_exp(*(const v4f*)(en + r) - mx);
+            den += e;
+            acc += e * *(const v4f*)(emb + r);
+        }
+        acc = acc * v4_rcp(den);
+    }
+    *(v4f*)(out + (long long)c * ldo + 4 * q) = acc;
+}
+
+// Backward of the attention aggregation fused with the SELU backward of both last layers, in
+// place: en <- d(pre-activation of the energy MLP's last layer), emb <- same for the message MLP.
+__global__ __launch_bounds__(256) void seg_softmax_bwd_kernel(
+    float* en, float* emb, int ld, const int* __restrict__ perm, const int* __restrict__ off,
+    int rows, int c4n, const float* __restrict__ dagg, int ldd) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(t / c4n), q = (int)(t - (long long)c * c4n);
+    if (c >= rows) return;
+    const int lo = off[c], hi = off[c + 1];
+    if (hi <= lo) return;
+    const v4f d = *(const v4f*)(dagg + (long long)c * ldd + 4 * q);
+    v4f mx = *(const v4f*)(en + (long long)perm[lo] * ld + 4 * q);
+    for (int k = lo + 1; k < hi; ++k)
+        mx = v4_max(mx, *(const v4f*)(en + (long long)perm[k] * ld + 4 * q));
+    v4f den = {0.f, 0.f, 0.f, 0.f}, inner = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lo; k < hi; ++k) {
+        const long long r = (long long)perm[k] * ld + 4 * q;
+        const v4f e = v4_exp(*(const v4f*)(en + r) - mx);
+        den += e;
+        inner += e * *(const v4f*)(emb + r) * d;          // sum_k exp_k * d att_k
+    }
+    const v4f inv = v4_rcp(den);
+    inner = inner * inv;                                  // sum_k att_k * d att_k
+    for (int k = lo; k < hi; ++k) {
+        const long long r = (long long)perm[k] * ld + 4 * q;
+        const v4f y_en = *(const v4f*)(en + r), y_emb = *(const v4f*)(emb + r);
+        const v4f att = v4_exp(y_en - mx) * inv;
+        *(v4f*)(en + r) = att * (y_emb * d - inner) * v4_selu_grad(y_en);
+        *(v4f*)(emb + r) = att * d * v4_selu_grad(y_emb);
+    }
+}
+
 __global__ __launch_bounds__(256) void selu_bwd_rows_kernel(
     const float* __restrict__ dY, int lddy, const int* __restrict__ idx, const float* Y, int ldy,
     float* out, int ldo, int rows, int cols) {
@@ -369,6 +444,43 @@ extern "C" int gi_seg_sum(const float* vals, int ldv, const int* perm, const int
     GiProfScope prof((hipStream_t)stream, GI_PROF_SEGSUM, 0.0);
     hipLaunchKernelGGL(seg_sum_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, vals, ldv, perm, off, rows, c4n, out, ldo, accumulate);
+    return gi_launch_status();
+}
+
+static int seg_softmax_args_ok(const void* en, const void* emb, int ld, const int* perm,
+                               const int* off, int cols) {
+    if (!en || !emb || !perm || !off || cols <= 0 || (ld & 3) || ld < cols) return 0;
+    return !(((uintptr_t)en & 15) || ((uintptr_t)emb & 15));
+}
+
+extern "C" int gi_seg_softmax_fwd(const float* en, const float* emb, int ld, const int* perm,
+                                  const int* off, int rows, int cols, float* out, int ldo,
+                                  void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
+    if (rows <= 0) return 0;
+    if (!seg_softmax_args_ok(en, emb, ld, perm, off, cols) || !out || (ldo & 3) || ldo < cols ||
+        ((uintptr_t)out & 15))
+        return GI_EINVAL;
+    const int c4n = (cols + 3) / 4;
+    const long long threads = (long long)rows * c4n;
+    GiProfScope prof((hipStream_t)stream, GI_PROF_SEGSUM, 0.0);
+    hipLaunchKernelGGL(seg_softmax_fwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256),
+                       0, (hipStream_t)stream, en, emb, ld, perm, off, rows, c4n, out, ldo);
+    return gi_launch_status();
+}
+
+extern "C" int gi_seg_softmax_bwd(float* en, float* emb, int ld, const int* perm, const int* off,
+                                  int rows, int cols, const float* dagg, int ldd, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
+    if (rows <= 0) return 0;
+    if (!seg_softmax_args_ok(en, emb, ld, perm, off, cols) || !dagg || (ldd & 3) || ldd < cols ||
+        ((uintptr_t)dagg & 15))
+        return GI_EINVAL;
+    const int c4n = (cols + 3) / 4;
+    const long long threads = (long long)rows * c4n;
+    GiProfScope prof((hipStream_t)stream, GI_PROF_SEGSUM, 0.0);
+    hipLaunchKernelGGL(seg_softmax_bwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256),
+                       0, (hipStream_t)stream, en, emb, ld, perm, off, rows, c4n, dagg, ldd);
     return gi_launch_status();
 }
 

@@ -35,12 +35,17 @@ except ImportError:                         # imported as top-level `gnn.mpnn` (
     from graphinvent_amd.gnn import modules as _modules
 
 
-def _dims_from_constants(c, B: int) -> "_L.GgnnDims":
+def _dims_from_constants(c, B: int, kind: int = _L.KIND_GGNN) -> "_L.GgnnDims":
     d = _L.GgnnDims()
+    d.kind = kind
     d.B, d.N, d.Fn, d.Fe = B, c.max_n_nodes, c.n_node_features, c.n_edge_features
     d.H, d.M, d.G = c.hidden_node_features, c.message_size, c.gather_width
     d.A, d.C, d.passes = c.len_f_add_per_node, c.len_f_conn_per_node, c.message_passes
-    d.enn_depth, d.enn_hidden = c.enn_depth, c.enn_hidden_dim
+    if kind == _L.KIND_ATTGGNN:         # per-bond-type message + energy MLPs (gnn/mpnn.py:319-335)
+        d.enn_depth, d.enn_hidden = c.msg_depth, c.msg_hidden_dim
+        d.eatt_depth, d.eatt_hidden = c.att_depth, c.att_hidden_dim
+    else:
+        d.enn_depth, d.enn_hidden = c.enn_depth, c.enn_hidden_dim
     d.att_depth, d.att_hidden = c.gather_att_depth, c.gather_att_hidden_dim
     d.emb_depth, d.emb_hidden = c.gather_emb_depth, c.gather_emb_hidden_dim
     d.mlp1_depth, d.mlp1_hidden = c.mlp1_depth, c.mlp1_hidden_dim
@@ -53,13 +58,13 @@ def _ptr_table(tensors) -> "C.Array":
     return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
-def ggnn_forward_raw(consts, nodes, edges, params):
+def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN):
     """graph_compact + the fused forward.  Returns (logits, tape); the tape
     (dims, CompactGraph, workspace, per-type edge counts) is what backward consumes."""
     lib = _L.load()
     nodes, lay, gfix, S, E, Et = _ops.compact_count(nodes, edges)
     B = nodes.shape[0]
-    dims = _dims_from_constants(consts, B)
+    dims = _dims_from_constants(consts, B, kind)
     if lib.gi_ggnn_num_params(C.byref(dims)) != len(params):
         raise RuntimeError("parameter table does not match the model dimensions")
     for p in params:
@@ -106,7 +111,8 @@ def ggnn_backward_raw(tape, out, d_out, params):
     grads = [gflat[o:o + n].view(p.shape) for o, n, p in zip(offs, sizes, params)]
     _L.check(lib.gi_ggnn_backward(
         C.byref(dims), _ptr_table(params), graph.gfix.data_ptr(), graph.gvar[0].data_ptr(),
-        graph.gvar[1].data_ptr(), graph.gvar[3].data_ptr(), graph.S, graph.E, Et_c,
+        graph.gvar[1].data_ptr(), graph.gvar[2].data_ptr(), graph.gvar[3].data_ptr(), graph.S,
+        graph.E, Et_c,
         ws.data_ptr(), slabs.data_ptr(), out.data_ptr(), out.stride(0), d_out.data_ptr(),
         d_out.stride(0), _ptr_table(grads), torch.cuda.current_stream().cuda_stream),
         "gi_ggnn_backward")
@@ -118,7 +124,7 @@ class _GGNNFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, owner, nodes, edges, *params):
-        out, tape = ggnn_forward_raw(owner.constants, nodes, edges, params)
+        out, tape = ggnn_forward_raw(owner.constants, nodes, edges, params, owner._KIND)
         ctx.owner = owner
         ctx.tape = tape
         ctx.save_for_backward(out, *params)
@@ -136,7 +142,46 @@ class _GGNNFunction(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
-class GGNN(torch.nn.Module):
+class _FusedMPNN(torch.nn.Module):
+    """Shared front end of the fused models: one HIP call per forward, one per backward."""
+
+    _KIND = _L.KIND_GGNN
+
+    def _dropout_active(self) -> bool:
+        return self.training and any(m.dropout_p > 0 for m in self.modules()
+                                     if isinstance(m, _modules.MLP))
+
+    def forward(self, nodes: torch.Tensor, edges: torch.Tensor) -> torch.Tensor:
+        if self._dropout_active():
+            raise NotImplementedError(
+                "AlphaDropout with p > 0 in training mode is not implemented in the MI355X HIP "
+                "path (every reference default is p = 0.0, parameters/defaults.py:280-363)")
+        params: List[torch.Tensor] = list(self.parameters())
+        self._grad_bucket = None
+        return _GGNNFunction.apply(self, nodes, edges, *params)
+
+    def _build_update_and_readout(self, c) -> None:
+        """GRU cell, graph gather and APD readout — identical in GGNN and AttentionGGNN
+        (gnn/mpnn.py:249-282 and :337-368)."""
+        self.gru = torch.nn.GRUCell(input_size=c.message_size, hidden_size=c.hidden_node_features,
+                                    bias=True)
+        self.gather = _modules.GraphGather(
+            node_features=c.n_node_features, hidden_node_features=c.hidden_node_features,
+            out_features=c.gather_width, att_depth=c.gather_att_depth,
+            att_hidden_dim=c.gather_att_hidden_dim, att_dropout_p=c.gather_att_dropout_p,
+            emb_depth=c.gather_emb_depth, emb_hidden_dim=c.gather_emb_hidden_dim,
+            emb_dropout_p=c.gather_emb_dropout_p, big_positive=c.big_positive)
+        self._grad_bucket = None    # flat gradient buffer of the latest backward (transient)
+        self.APDReadout = _modules.GlobalReadout(
+            node_emb_size=c.hidden_node_features, graph_emb_size=c.gather_width,
+            mlp1_hidden_dim=c.mlp1_hidden_dim, mlp1_depth=c.mlp1_depth,
+            mlp1_dropout_p=c.mlp1_dropout_p, mlp2_hidden_dim=c.mlp2_hidden_dim,
+            mlp2_depth=c.mlp2_depth, mlp2_dropout_p=c.mlp2_dropout_p,
+            f_add_elems=c.len_f_add_per_node, f_conn_elems=c.len_f_conn_per_node, f_term_elems=1,
+            max_n_nodes=c.max_n_nodes, device=c.device)
+
+
+class GGNN(_FusedMPNN):
     """The "gated-graph neural network" model (gnn/mpnn.py:229-303) on MI355X HIP kernels."""
 
     def __init__(self, constants: namedtuple) -> None:
@@ -155,32 +200,36 @@ class GGNN(torch.nn.Module):
             self.msg_nns.append(_modules.MLP(c.hidden_node_features,
                                              [c.enn_hidden_dim] * c.enn_depth, c.message_size,
                                              c.enn_dropout_p))
-        self.gru = torch.nn.GRUCell(input_size=c.message_size, hidden_size=c.hidden_node_features,
-                                    bias=True)
-        self.gather = _modules.GraphGather(
-            node_features=c.n_node_features, hidden_node_features=c.hidden_node_features,
-            out_features=c.gather_width, att_depth=c.gather_att_depth,
-            att_hidden_dim=c.gather_att_hidden_dim, att_dropout_p=c.gather_att_dropout_p,
-            emb_depth=c.gather_emb_depth, emb_hidden_dim=c.gather_emb_hidden_dim,
-            emb_dropout_p=c.gather_emb_dropout_p, big_positive=c.big_positive)
-        self._grad_bucket = None    # flat gradient buffer of the latest backward (transient)
-        self.APDReadout = _modules.GlobalReadout(
-            node_emb_size=c.hidden_node_features, graph_emb_size=c.gather_width,
-            mlp1_hidden_dim=c.mlp1_hidden_dim, mlp1_depth=c.mlp1_depth,
-            mlp1_dropout_p=c.mlp1_dropout_p, mlp2_hidden_dim=c.mlp2_hidden_dim,
-            mlp2_depth=c.mlp2_depth, mlp2_dropout_p=c.mlp2_dropout_p,
-            f_add_elems=c.len_f_add_per_node, f_conn_elems=c.len_f_conn_per_node, f_term_elems=1,
-            max_n_nodes=c.max_n_nodes, device=c.device)
+        self._build_update_and_readout(c)
 
-    def _dropout_active(self) -> bool:
-        return self.training and any(m.dropout_p > 0 for m in self.modules()
-                                     if isinstance(m, _modules.MLP))
 
-    def forward(self, nodes: torch.Tensor, edges: torch.Tensor) -> torch.Tensor:
-        if self._dropout_active():
-            raise NotImplementedError(
-                "AlphaDropout with p > 0 in training mode is not implemented in the MI355X HIP "
-                "path (every reference default is p = 0.0, parameters/defaults.py:280-300)")
-        params: List[torch.Tensor] = list(self.parameters())
-        self._grad_bucket = None
-        return _GGNNFunction.apply(self, nodes, edges, *params)
+class AttentionGGNN(_FusedMPNN):
+    """The "GGNN with attention" model (gnn/mpnn.py:306-398; ``AggregationMPNN.forward``,
+    gnn/aggregation_mpnn.py:83-168) on MI355X HIP kernels: per bond type one message MLP and one
+    energy MLP on the neighbour's hidden state, softmax over each node's incoming edges
+    (``gi_seg_softmax_fwd``) instead of the reference's max-degree-padded masked softmax."""
+
+    _KIND = _L.KIND_ATTGGNN
+
+    def __init__(self, constants: namedtuple) -> None:
+        super().__init__()
+        c = constants
+        # attributes AggregationMPNN.__init__ caches (gnn/aggregation_mpnn.py:17-21)
+        self.hidden_node_features = c.hidden_node_features
+        self.edge_features = c.n_edge_features
+        self.message_size = c.message_size
+        self.message_passes = c.message_passes
+        self.constants = c
+
+        # both ModuleLists are registered first (state_dict: every msg_nns.* before att_nns.*), the
+        # MLPs are constructed interleaved (RNG order msg_0, att_0, msg_1, ...): gnn/mpnn.py:316-335
+        self.msg_nns = torch.nn.ModuleList()
+        self.att_nns = torch.nn.ModuleList()
+        for _ in range(c.n_edge_features):
+            self.msg_nns.append(_modules.MLP(c.hidden_node_features,
+                                             [c.msg_hidden_dim] * c.msg_depth, c.message_size,
+                                             c.msg_dropout_p))
+            self.att_nns.append(_modules.MLP(c.hidden_node_features,
+                                             [c.att_hidden_dim] * c.att_depth, c.message_size,
+                                             c.att_dropout_p))
+        self._build_update_and_readout(c)

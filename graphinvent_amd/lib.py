@@ -24,6 +24,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GI_MAX_GROUPS = 8
 GI_MAX_NODES = 128
 EPI_BIAS, EPI_SELU, EPI_DSELU, EPI_ACCUM, GEMM_SPLITK = 1, 2, 4, 8, 16
+KIND_GGNN, KIND_ATTGGNN = 0, 1
 DTYPE_F32, DTYPE_I8 = 0, 1
 
 vp = C.c_void_p
@@ -57,7 +58,8 @@ class GgnnDims(C.Structure):
     _fields_ = [(n, ci) for n in ("B", "N", "Fn", "Fe", "H", "M", "G", "A", "C", "passes",
                                   "enn_depth", "enn_hidden", "att_depth", "att_hidden",
                                   "emb_depth", "emb_hidden", "mlp1_depth", "mlp1_hidden",
-                                  "mlp2_depth", "mlp2_hidden")] + [("big_positive", C.c_float)]
+                                  "mlp2_depth", "mlp2_hidden")] + [("big_positive", C.c_float)] + \
+               [(n, ci) for n in ("kind", "eatt_depth", "eatt_hidden")]
 
 
 # name -> (restype, argtypes); every symbol include/graphinvent_amd.h declares
@@ -69,6 +71,8 @@ SIGNATURES = {
     "gi_gemm": (ci, [C.POINTER(GemmParams), vp]),
     "gi_gemm_batch": (ci, [C.POINTER(GemmParams), ci, vp]),
     "gi_seg_sum": (ci, [vp, ci, vp, vp, ci, ci, vp, ci, ci, vp]),
+    "gi_seg_softmax_fwd": (ci, [vp, vp, ci, vp, vp, ci, ci, vp, ci, vp]),
+    "gi_seg_softmax_bwd": (ci, [vp, vp, ci, vp, vp, ci, ci, vp, ci, vp]),
     "gi_selu_bwd_rows": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, vp]),
     "gi_gru_gates_fwd": (ci, [vp, vp, ci, vp, vp, ci, vp, ci, ci, ci, vp]),
     "gi_gru_gates_bwd": (ci, [vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, vp]),
@@ -94,7 +98,7 @@ SIGNATURES = {
                               C.POINTER(cll), C.POINTER(ci)]),
     "gi_ggnn_forward": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), vp, vp, vp, ci, ci,
                              C.POINTER(ci), vp, vp, ci, vp]),
-    "gi_ggnn_backward": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), vp, vp, vp, vp, ci, ci,
+    "gi_ggnn_backward": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), vp, vp, vp, vp, vp, ci, ci,
                               C.POINTER(ci), vp, vp, vp, ci, vp, ci, C.POINTER(vp), vp]),
 }
 

@@ -112,6 +112,19 @@ int gi_gemm_batch(const gi_gemm_params* problems, int n, void* stream);
 int gi_seg_sum(const float* vals, int ldv, const int* perm, const int* off, int rows, int cols,
                float* out, int ldo, int accumulate, void* stream);
 
+/* Attention aggregation of AttentionGGNN — replaces `aggregate_message` (gnn/mpnn.py:370-389:
+ * mask, Softmax(dim=1) over the padded neighbour axis, weighted sum) on the destination CSR:
+ *   att[k, f] = softmax over k in [off[c], off[c+1]) of en[perm[k], f];
+ *   out[c, f] = sum_k att[k, f] * emb[perm[k], f]        (0 for an empty segment),  c < rows.
+ * en / emb: [E, ld] post-SELU outputs of the per-bond-type energy / message MLPs. */
+int gi_seg_softmax_fwd(const float* en, const float* emb, int ld, const int* perm, const int* off,
+                       int rows, int cols, float* out, int ldo, void* stream);
+/* Its backward fused with the SELU backward of both producers, IN PLACE: on return
+ *   en  = d loss / d (pre-activation of the energy MLP's last layer),
+ *   emb = d loss / d (pre-activation of the message MLP's last layer),  given dagg = d loss / d out. */
+int gi_seg_softmax_bwd(float* en, float* emb, int ld, const int* perm, const int* off, int rows,
+                       int cols, const float* dagg, int ldd, void* stream);
+
 /* out[r, c] = dY[idx ? idx[r] : r, c] * selu'(Y[r, c])  (may run in place on Y) */
 int gi_selu_bwd_rows(const float* dY, int lddy, const int* idx, const float* Y, int ldy,
                      float* out, int ldo, int rows, int cols, void* stream);
@@ -191,7 +204,15 @@ typedef struct gi_ggnn_dims {
     int enn_depth, enn_hidden, att_depth, att_hidden, emb_depth, emb_hidden;
     int mlp1_depth, mlp1_hidden, mlp2_depth, mlp2_hidden;
     float big_positive;
+    /* model kind: GI_KIND_GGNN — sum aggregation (gnn/mpnn.py:229-303);  GI_KIND_ATTGGNN —
+     * `AttentionGGNN` (gnn/mpnn.py:306-398): a second per-bond-type MLP (eatt_depth/eatt_hidden =
+     * constants.att_depth / att_hidden_dim; enn_* then carry msg_depth / msg_hidden_dim) gives
+     * attention energies, aggregated with gi_seg_softmax_*.  Parameter table order: msg_nns of all
+     * bond types, [att_nns of all bond types,] gru, gather, APDReadout (state_dict order). */
+    int kind, eatt_depth, eatt_hidden;
 } gi_ggnn_dims;
+#define GI_KIND_GGNN 0
+#define GI_KIND_ATTGGNN 1
 
 int gi_ggnn_num_params(const gi_ggnn_dims* d);
 long long gi_ggnn_workspace_floats(const gi_ggnn_dims* d, int S, int E);
@@ -211,8 +232,8 @@ int gi_ggnn_forward(const gi_ggnn_dims* d, const float* const* params, const int
  * receives the gradient of params[i]; slabs = gi_ggnn_slab_floats() floats of scratch.
  * Et = HOST array of per-bond-type edge counts (counts[4..4+Fe) read back by the caller). */
 int gi_ggnn_backward(const gi_ggnn_dims* d, const float* const* params, const int* gfix,
-                     const int* e_src, const int* e_dst, const int* out_perm, int S, int E,
-                     const int* Et, float* ws, float* slabs, const float* y_out, int ldout,
+                     const int* e_src, const int* e_dst, const int* in_perm, const int* out_perm,
+                     int S, int E, const int* Et, float* ws, float* slabs, const float* y_out, int ldout,
                      const float* d_out, int lddout, float* const* grads, void* stream);
 
 #ifdef __cplusplus

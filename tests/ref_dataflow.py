@@ -118,6 +118,33 @@ def seg_sum(vals, perm, off, rows):
     return out
 
 
+def seg_softmax_sum(en, emb, perm, off, rows):
+    """Attention aggregation of AttGGNN (gnn/mpnn.py:370-389) on the dst-CSR: per destination row c
+    and per feature, softmax of en over the segment's edges, weighted sum of emb.  Empty segments
+    give 0.  Returns (agg [rows, M], att [E, M] in edge-row order)."""
+    E, M = en.shape
+    agg = torch.zeros(rows, M, dtype=en.dtype)
+    att = torch.zeros_like(en)
+    for c in range(rows):
+        lo, hi = int(off[c]), int(off[c + 1])
+        if hi > lo:
+            r = perm[lo:hi].long()
+            a = torch.softmax(en[r], dim=0)
+            att[r] = a
+            agg[c] = (a * emb[r]).sum(0)
+    return agg, att
+
+
+def seg_softmax_sum_bwd(dagg, att, emb, e_dst):
+    """(d en, d emb) per edge row for agg = sum_k att_k emb_k, att = softmax_k(en)."""
+    d = dagg[e_dst.long()]
+    demb = att * d
+    datt = emb * d
+    inner = torch.zeros_like(dagg).index_add_(0, e_dst.long(), att * datt)
+    den = att * (datt - inner[e_dst.long()])
+    return den, demb
+
+
 def gru_gates(gi, gh, h_prev, has_edge):
     H = h_prev.shape[1]
     r = torch.sigmoid(gi[:, :H] + gh[:, :H])
@@ -199,8 +226,9 @@ def mlp_bwd(P, prefix, x_in, acts, d_last_z, grads, idx=None, need_dx=True):
     return None
 
 
-def forward(P, cfg, nodes, edges, keep=False):
+def forward(P, cfg, nodes, edges, keep=False, model="GGNN"):
     dtype = nodes.dtype
+    attn = model == "AttGGNN"
     B, N, Fn = nodes.shape
     H, M, G = cfg["hidden_node_features"], cfg["message_size"], cfg["gather_width"]
     Fe, A, C = cfg["n_edge_features"], cfg["len_f_add_per_node"], cfg["len_f_conn_per_node"]
@@ -223,11 +251,23 @@ def forward(P, cfg, nodes, edges, keep=False):
             a = mlp_fwd(P, f"msg_nns.{t}", h, idx=T["e_src"][lo:hi].long())
             acts_t.append(a)
             m[lo:hi] = a[-1]
-        agg = seg_sum(m, T["in_perm"], T["seg_off"], R)
+        ps_extra = {}
+        if attn:      # second per-bond-type MLP gives the attention energies
+            aacts_t = []
+            en_e = torch.zeros(E, M, dtype=dtype)
+            for t in range(Fe):
+                lo, hi = int(g["type_off"][t]), int(g["type_off"][t + 1])
+                a = mlp_fwd(P, f"att_nns.{t}", h, idx=T["e_src"][lo:hi].long())
+                aacts_t.append(a)
+                en_e[lo:hi] = a[-1]
+            agg, att_e = seg_softmax_sum(en_e, m, T["in_perm"], T["seg_off"], R)
+            ps_extra = dict(aacts_t=aacts_t, en_e=en_e, att_e=att_e)
+        else:
+            agg = seg_sum(m, T["in_perm"], T["seg_off"], R)
         gi = linear(agg, P["gru.weight_ih"], P["gru.bias_ih"], False)
         gh = linear(h, P["gru.weight_hh"], P["gru.bias_hh"], False)
         h_new, saved = gru_gates(gi, gh, h, has_edge)
-        tape["passes"].append(dict(h_prev=h, acts_t=acts_t, m=m, agg=agg, saved=saved))
+        tape["passes"].append(dict(h_prev=h, acts_t=acts_t, m=m, agg=agg, saved=saved, **ps_extra))
         h = h_new
     hx = torch.cat([h, x], 1)
     att_acts = mlp_fwd(P, "gather.att_nn", hx)
@@ -245,7 +285,7 @@ def forward(P, cfg, nodes, edges, keep=False):
     out = torch.cat([add2[-1], conn2[-1], term2[-1]], 1)
     tape.update(h=h, hx=hx, att_acts=att_acts, emb_acts=emb_acts, att=att, gemb=gemb, add1=add1,
                 conn1=conn1, cat_add=cat_add, cat_conn=cat_conn, add2=add2, conn2=conn2,
-                term2=term2, c=c, out=out)
+                term2=term2, c=c, out=out, attn=attn)
     return (out, tape) if keep else out
 
 
@@ -292,14 +332,25 @@ def backward(P, cfg, tape, d_out) -> Dict[str, torch.Tensor]:
         grads["gru.bias_hh"] = grads.get("gru.bias_hh", 0) + dgh.sum(0)
         dagg = dgi @ P["gru.weight_ih"]
         dh_prev = dh_prev + dgh @ P["gru.weight_hh"]
-        dm = dagg[T["e_dst"].long()] * selu_grad_from_out(ps["m"])
         dxe = torch.zeros(g["E"], H, dtype=d_out.dtype)
+        if tape["attn"]:
+            den, demb = seg_softmax_sum_bwd(dagg, ps["att_e"], ps["m"], T["e_dst"])
+            dm = demb * selu_grad_from_out(ps["m"])
+            da = den * selu_grad_from_out(ps["en_e"])
+            for t in range(Fe):
+                lo, hi = int(g["type_off"][t]), int(g["type_off"][t + 1])
+                d = mlp_bwd(P, f"att_nns.{t}", ps["h_prev"], ps["aacts_t"][t], da[lo:hi], grads,
+                            idx=T["e_src"][lo:hi].long(), need_dx=pi > 0)
+                if d is not None:
+                    dxe[lo:hi] = d
+        else:
+            dm = dagg[T["e_dst"].long()] * selu_grad_from_out(ps["m"])
         for t in range(Fe):
             lo, hi = int(g["type_off"][t]), int(g["type_off"][t + 1])
             d = mlp_bwd(P, f"msg_nns.{t}", ps["h_prev"], ps["acts_t"][t], dm[lo:hi], grads,
                         idx=T["e_src"][lo:hi].long(), need_dx=pi > 0)
             if d is not None:
-                dxe[lo:hi] = d
+                dxe[lo:hi] = dxe[lo:hi] + d
         if pi > 0:
             dh_prev = dh_prev + seg_sum(dxe, T["out_perm"], T["src_off"], R)
         dh = dh_prev

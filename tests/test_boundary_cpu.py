@@ -40,6 +40,11 @@ def test_host_side_planning_functions():
     assert ws > ws0 > 0 and ws % 4 == 0
     Et = (C.c_int * 3)(10000, 2500, 100)
     assert lib.gi_ggnn_slab_floats(C.byref(d), 6900, 12600, Et) > 0
+    da = mpnn._dims_from_constants(O.as_constants(O.make_config()), 1000, L.KIND_ATTGGNN)
+    assert lib.gi_ggnn_num_params(C.byref(da)) == 134                     # + 3 energy MLPs x 10
+    assert lib.gi_ggnn_workspace_floats(C.byref(da), 6900, 12600) > ws
+    da.kind = 7
+    assert lib.gi_ggnn_num_params(C.byref(da)) == -1                      # unknown model kind
     d.Fn = d.H + 1
     assert lib.gi_ggnn_workspace_floats(C.byref(d), 1, 1) == -1          # GI_EINVAL
 
@@ -56,6 +61,10 @@ def test_state_dict_is_the_reference_wire_format():
     clone = copy.deepcopy(model)
     assert all(torch.equal(a, b) for a, b in zip(model.parameters(), clone.parameters()))
     model.eval(); model.train(); model.zero_grad()
+    att = mpnn.AttentionGGNN(O.as_constants(cfg))
+    shapes = O.param_shapes(cfg, "AttGGNN")
+    assert [n for n, _ in att.named_parameters()] == list(shapes) == list(att.state_dict())
+    assert all(tuple(p.shape) == shapes[n] for n, p in att.named_parameters())
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present on this box")
@@ -67,13 +76,14 @@ def test_constructor_is_seed_for_seed_identical_to_the_reference():
         sys.path.remove(REF)
     assert ref_mpnn.__file__.startswith(REF)
     c = O.as_constants(O.make_config())
-    torch.manual_seed(123)
-    ref = ref_mpnn.GGNN(c)
-    torch.manual_seed(123)
-    ours = mpnn.GGNN(c)
-    a, b = ref.state_dict(), ours.state_dict()
-    assert list(a) == list(b)
-    assert all(torch.equal(a[k], b[k]) for k in a)
+    for name in ("GGNN", "AttentionGGNN"):
+        torch.manual_seed(123)
+        ref = getattr(ref_mpnn, name)(c)
+        torch.manual_seed(123)
+        ours = getattr(mpnn, name)(c)
+        a, b = ref.state_dict(), ours.state_dict()
+        assert list(a) == list(b), name
+        assert all(torch.equal(a[k], b[k]) for k in a), name
     for m in [k for k in sys.modules if k == "gnn" or k.startswith("gnn.")]:
         del sys.modules[m]
 
