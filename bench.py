@@ -49,6 +49,7 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achie
 
 
 SHAPE = "gdb13"                # --shape zinc runs BASELINE configs[2] (not the headline metric)
+MODEL = "ggnn"                 # --model attggnn --shape chembl --batch 250 = configs[4]'s per-GPU work
 
 
 def workload_constants(device: str):
@@ -63,7 +64,10 @@ def workload_constants(device: str):
         enn_hidden_dim=250, enn_dropout_p=0.0, gather_width=100, gather_att_depth=4,
         gather_att_hidden_dim=250, gather_att_dropout_p=0.0, gather_emb_depth=4,
         gather_emb_hidden_dim=250, gather_emb_dropout_p=0.0, mlp1_depth=4, mlp1_hidden_dim=500,
-        mlp1_dropout_p=0.0, mlp2_depth=4, mlp2_hidden_dim=500, mlp2_dropout_p=0.0)
+        mlp1_dropout_p=0.0, mlp2_depth=4, mlp2_hidden_dim=500, mlp2_dropout_p=0.0,
+        # AttGGNN only, parameters/defaults.py:340-363
+        msg_depth=4, msg_hidden_dim=250, msg_dropout_p=0.0, att_depth=4, att_hidden_dim=250,
+        att_dropout_p=0.0)
     return cfg, namedtuple("CONSTANTS", sorted(cfg))(**cfg)
 
 
@@ -79,7 +83,7 @@ def make_batches(rank: int, device):
 def seg_sum_hbm_probe(device, M=128, replicas=64):
     """seg_sum on a graph batch replicated until E*M*4 exceeds the 256 MB Infinity Cache."""
     sh = synthetic.SHAPES["gdb13"]
-    n8, e8, _ = synthetic.make_batch(BATCH, **sh, seed=77)
+    n8, e8, _ = synthetic.make_batch(1000, **sh, seed=77)
     g, _ = ops.compact(torch.from_numpy(n8).float().to(device),
                        torch.from_numpy(e8).float().to(device), M)
     S, E = g.S, g.E
@@ -142,11 +146,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=64)
-    ap.add_argument("--shape", default="gdb13", choices=["gdb13", "zinc"],
-                    help="gdb13 = BASELINE configs[1] (the metric); zinc = configs[2], for reference")
+    ap.add_argument("--shape", default="gdb13", choices=["gdb13", "zinc", "chembl"],
+                    help="gdb13 = BASELINE configs[1] (the metric); zinc = configs[2]; chembl = the "
+                         "graph shape of configs[4] — both for reference, not the headline")
+    ap.add_argument("--model", default="ggnn", choices=["ggnn", "attggnn"],
+                    help="attggnn = gnn.mpnn.AttentionGGNN (configs[4]'s model class), for reference")
+    ap.add_argument("--batch", type=int, default=BATCH, help="graphs per GPU per step")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the product path).  gloo + ranks sharing one GPU is "
+                         "a control-flow smoke test of the multi-rank path on a 1-GPU box; its "
+                         "numbers are not a measurement")
     args = ap.parse_args()
-    global SHAPE
-    SHAPE = args.shape
+    global SHAPE, MODEL, BATCH
+    SHAPE, MODEL, BATCH = args.shape, args.model, args.batch
+    headline = SHAPE == "gdb13" and MODEL == "ggnn" and BATCH == 1000
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -159,16 +172,20 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     lib.load()
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     cfg, constants = workload_constants("cuda")
     torch.manual_seed(0)                                   # identical initial weights on every rank
-    model = mpnn.GGNN(constants).to(device).train()
+    model = (mpnn.GGNN if MODEL == "ggnn" else mpnn.AttentionGGNN)(constants).to(device).train()
     batches = make_batches(rank, device)
     total_steps = args.steps + args.warmup + 16
     opt = FusedAdam(model.parameters(), lr=1e-4)           # Adam, defaults.py:120 init_lr; one HIP launch/step
@@ -198,35 +215,44 @@ def main():
         raise SystemExit("non-finite loss in the timed region")
 
     result = {
-        "metric": "training graphs/sec (GGNN, GDB-13 max_n_nodes=13)",
+        "metric": "training graphs/sec (GGNN, GDB-13 max_n_nodes=13)" if headline else
+                  f"training graphs/sec ({MODEL}, {SHAPE} shape)",
         "value": round(BATCH * world * args.steps / dt, 1), "unit": "graphs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("BASELINE configs[1]: GGNN hidden=128 message=128 3 MP steps, "
                                 "GDB-13-shaped synthetic graphs max_n_nodes=13, train step "
-                                "fwd+KL+bwd+allreduce+Adam") if SHAPE == "gdb13" else
-                               ("BASELINE configs[2]: GGNN hidden=100 3 MP steps, ZINC-250k-shaped "
-                                "synthetic graphs max_n_nodes=38, train step fwd+KL+bwd+allreduce+Adam"),
+                                "fwd+KL+bwd+allreduce+Adam") if headline else
+                               (f"NOT the headline config: {MODEL} on {SHAPE}-shaped synthetic graphs "
+                                f"max_n_nodes={synthetic.SHAPES[SHAPE]['max_n_nodes']}, hidden="
+                                f"{cfg['hidden_node_features']}, 3 MP steps, train step "
+                                "fwd+KL+bwd+allreduce+Adam"),
                    "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                    "parallelism": f"dp{world}", "loss": round(loss_val, 5)},
     }
+    if args.backend != "nccl":
+        result["config"]["backend"] = args.backend + " (control-flow smoke test, not a measurement)"
 
+    # ---- roofline leg: per-launch HIP-event timing of the GEMM family + seg_sum -----------------
+    # Every rank runs the extra steps (they contain the gradient all-reduce, a collective); only
+    # rank 0 records and reports.
+    handle = lib.load()
+    prof_steps = 3
+    torch.cuda.synchronize()
     if rank == 0:
-        # ---- roofline leg: per-launch HIP-event timing of the GEMM family + seg_sum -------------
-        handle = lib.load()
-        prof_steps = 3
-        torch.cuda.synchronize()
         handle.gi_prof_enable(1)
-        seg_bytes = 0.0
-        for i in range(prof_steps):
-            b = batches[i % N_BATCHES]
+    seg_bytes = 0.0
+    for i in range(prof_steps):
+        b = batches[i % N_BATCHES]
+        if rank == 0:
             _, _, _, S, E, _ = ops.compact_count(b[0], b[1])
             R, Mm, H, P = S + 1, cfg["message_size"], cfg["hidden_node_features"], cfg["message_passes"]
             seg_bytes += P * (E * Mm * 4 + E * 4 + (R + 1) * 4 + R * Mm * 4)              # forward
             seg_bytes += (P - 1) * (E * H * 4 + E * 4 + (R + 1) * 4 + 2 * R * H * 4)      # backward scatter
-            trainer.step(*b)
-        torch.cuda.synchronize()
+        trainer.step(*b)
+    torch.cuda.synchronize()
+    if rank == 0:
         ms = (C.c_double * 2)(); work = (C.c_double * 2)(); n = (C.c_int * 2)()
         lib.check(handle.gi_prof_collect(ms, work, n), "gi_prof_collect")
         handle.gi_prof_enable(0)
@@ -258,7 +284,7 @@ def main():
             "beyond_infinity_cache": {"achieved": probe["GBps"],
                                       "frac": round(probe["GBps"] / PEAK_HBM_GBS, 4), **probe},
         }
-        if world == 1 and not args.no_cpu_baseline and SHAPE == "gdb13":
+        if world == 1 and not args.no_cpu_baseline and headline:
             result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_threads)
             result["speedup_vs_cpu_baseline"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
         print(json.dumps(result), flush=True)
