@@ -140,6 +140,7 @@ def cpu_baseline(cfg, threads: int, timed_steps: int = 2):
 
 
 def main():
+    global SHAPE, MODEL, BATCH
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -157,7 +158,6 @@ def main():
                          "a control-flow smoke test of the multi-rank path on a 1-GPU box; its "
                          "numbers are not a measurement")
     args = ap.parse_args()
-    global SHAPE, MODEL, BATCH
     SHAPE, MODEL, BATCH = args.shape, args.model, args.batch
     headline = SHAPE == "gdb13" and MODEL == "ggnn" and BATCH == 1000
 
