@@ -152,6 +152,8 @@ def main():
                          "graph shape of configs[4] — both for reference, not the headline")
     ap.add_argument("--model", default="ggnn", choices=["ggnn", "attggnn"],
                     help="attggnn = gnn.mpnn.AttentionGGNN (configs[4]'s model class), for reference")
+    ap.add_argument("--no-probe", action="store_true",
+                    help="skip the beyond-Infinity-Cache seg_sum probe (keeps kernel traces clean)")
     ap.add_argument("--batch", type=int, default=BATCH, help="graphs per GPU per step")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path).  gloo + ranks sharing one GPU is "
@@ -275,7 +277,7 @@ def main():
             "method": f"hipEvent pair around every launch on its stream, {prof_steps} extra steps",
         }
         agg_gbs = seg_bytes / (ms[1] * 1e-3) / 1e9 if ms[1] > 0 else 0.0
-        probe = seg_sum_hbm_probe(device)
+        probe = dict(GBps=0.0, skipped=True) if args.no_probe else seg_sum_hbm_probe(device)
         result["aggregation"] = {
             "bound": "hbm", "kernel": "seg_sum_kernel", "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "in_step": {"achieved": round(agg_gbs, 1), "frac": round(agg_gbs / PEAK_HBM_GBS, 4),

@@ -24,6 +24,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "gi_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -429,6 +432,28 @@ static bool env_remap() {
     return v;
 }
 
+// Measurement aid (tools/gemm_launch_report.py): GI_GEMM_LOG=<file> appends one line per launch
+// — layout class, workgroups, useful flops, then M,N,K,groups per problem — to correlate with a
+// rocprofv3 kernel trace.
+static FILE* launch_log() {
+    static FILE* f = [] {
+        const char* path = getenv("GI_GEMM_LOG");
+        return path ? fopen(path, "a") : nullptr;
+    }();
+    return f;
+}
+
+static void log_launch(const gi_gemm_params* probs, int n, int blocks, double flops) {
+    FILE* f = launch_log();
+    if (!f) return;
+    fprintf(f, "%d%d %d %d %.0f", probs[0].a_major, probs[0].b_major, n, blocks, flops);
+    for (int i = 0; i < n; ++i)
+        fprintf(f, " %dx%dx%d:g%d:s%d", probs[i].M, probs[i].N, probs[i].K, probs[i].ngroups,
+                probs[i].nsplit);
+    fputc('\n', f);
+    fflush(f);
+}
+
 static int validate(const gi_gemm_params& p) {
     if (p.M < 0 || p.N <= 0 || p.K < 0 || p.nsplit < 1 || p.ngroups < 0 ||
         p.ngroups > GI_MAX_GROUPS)
@@ -487,6 +512,7 @@ extern "C" int gi_gemm(const gi_gemm_params* pp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     // useful flops of this launch (real dims; for grouped / split launches M resp. K is the total)
     GiProfScope prof(st, GI_PROF_GEMM, 2.0 * (double)p.M * (double)p.N * (double)p.K);
+    log_launch(&p, 1, grid.x * grid.y * grid.z, 2.0 * (double)p.M * (double)p.N * (double)p.K);
     const bool am = p.a_major, bm = p.b_major;
     if (p.tm == 1 && p.tn == 1) GI_DISPATCH(gi_gemm_kernel, 1, 1, grid, p);
     else if (p.tm == 1 && p.tn == 2) GI_DISPATCH(gi_gemm_kernel, 1, 2, grid, p);
@@ -522,6 +548,7 @@ extern "C" int gi_gemm_batch(const gi_gemm_params* probs, int n, void* stream) {
     b.n = k;
     hipStream_t st = (hipStream_t)stream;
     GiProfScope prof(st, GI_PROF_GEMM, flops);
+    log_launch(b.p, k, total, flops);
     const bool am = probs[0].a_major, bm = probs[0].b_major;
     const dim3 grid(total);
     if (probs[0].tm == 1 && probs[0].tn == 1) GI_DISPATCH(gi_gemm_batch_kernel, 1, 1, grid, b);

@@ -209,10 +209,13 @@ void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {
 // ---- launch helpers -----------------------------------------------------------------------------
 struct Grp { int n; const int* off; int max_rows; };    // n == 0: ungrouped
 
+struct SideStream;
+
 struct Run {
     hipStream_t st;
     const float* const* P;
     int rc;
+    SideStream* side = nullptr;    // optional second stream for the weight-gradient GEMMs
     bool ok() const { return rc == 0; }
     void chk(int r) { if (rc == 0 && r != 0) rc = r; }
 };
@@ -360,6 +363,7 @@ void add_dgrad(Batch& b, const float* W, int n_out, int n_in, int ncols, const f
 }
 
 void flush_deferred(Run& r, Deferred& q);
+void kick_deferred(Run& r, Deferred& q, SideStream* side, bool all);
 
 void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* widx, const Grp& g,
                  const float* dZ, int lddz, const float* X, int ldx, const int* b_idx, int rows) {
@@ -385,12 +389,56 @@ void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* wid
         p.C = slabs + e0.off + (long long)e0.done * e0.nsplit * e0.stride;
         e0.done++;
     }
+    if (r.side && q.n >= 8) kick_deferred(r, q, r.side, false);
 }
 
 void flush_deferred(Run& r, Deferred& q) {
     for (int base = 0; base < q.n && r.ok(); base += 8)
         r.chk(gi_gemm_batch(q.p + base, std::min(8, q.n - base), r.st));
     q.n = 0;
+}
+
+// ---- weight gradients on a second stream --------------------------------------------------------
+// The dZ chain is a sequence of short dependent launches that leave MFMA slots idle (few blocks per
+// CU, all in prologue / epilogue at the same time); the weight-gradient GEMMs only feed the final
+// slab reduction.  With a caller-provided side stream they are launched there, 8 problems at a
+// time, as soon as their operands exist (event from the main stream), and run in the gaps of the
+// chain; the main stream joins before gi_reduce_slabs.
+struct SideStream {
+    hipStream_t st;
+    int used;
+    static constexpr int NEV = 48;
+    static hipEvent_t* pool() {
+        static hipEvent_t ev[NEV];
+        static bool made = false;
+        if (!made) {
+            for (hipEvent_t& e : ev) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            made = true;
+        }
+        return ev;
+    }
+    hipEvent_t next() { return pool()[used++ % NEV]; }
+};
+
+// launch every complete batch of 8 queued problems (all of them when `all`) on the side stream
+void kick_deferred(Run& r, Deferred& q, SideStream* side, bool all) {
+    if (!side || !r.ok()) return;
+    const int n = all ? q.n : (q.n / 8) * 8;
+    if (n == 0) return;
+    hipEvent_t ready = side->next();
+    r.chk((int)hipEventRecord(ready, r.st));
+    r.chk((int)hipStreamWaitEvent(side->st, ready, 0));
+    for (int base = 0; base < n && r.ok(); base += 8)
+        r.chk(gi_gemm_batch(q.p + base, std::min(8, n - base), side->st));
+    for (int i = n; i < q.n; ++i) q.p[i - n] = q.p[i];
+    q.n -= n;
+}
+
+void join_side(Run& r, SideStream* side) {
+    if (!side || !r.ok()) return;
+    hipEvent_t done = side->next();
+    r.chk((int)hipEventRecord(done, side->st));
+    r.chk((int)hipStreamWaitEvent(r.st, done, 0));
 }
 
 void mlp_jobs_forward(Run& r, float* ws, const MlpJob* jobs, int n) {
@@ -553,6 +601,25 @@ void edge_chains_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferre
 }  // namespace
 
 // ================================ C ABI ==========================================================
+// A stream of the lowest priority the device offers, for gi_ggnn_backward's side_stream: the
+// weight-gradient GEMMs should only fill what the dZ chain (on the caller's stream) leaves idle.
+extern "C" int gi_side_stream_create(void** out) {
+    if (!out) return GI_EINVAL;
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return (int)e;
+    hipStream_t st = nullptr;
+    e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least);
+    if (e != hipSuccess) return (int)e;
+    *out = (void*)st;
+    return 0;
+}
+
+extern "C" int gi_side_stream_destroy(void* stream) {
+    if (!stream) return 0;
+    return (int)hipStreamDestroy((hipStream_t)stream);
+}
+
 extern "C" int gi_ggnn_num_params(const gi_ggnn_dims* d) {
     Model m;
     const int rc = build_model(d, m);
@@ -708,9 +775,10 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
 
 extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* params, const int* gfix,
                                 const int* e_src, const int* e_dst, const int* in_perm,
-                                const int* out_perm, int S, int E, const int* Et, float* ws, float* slabs, const float* y_out,
-                                int ldout, const float* d_out, int lddout, float* const* grads,
-                                void* stream) {
+                                const int* out_perm, int S, int E, const int* Et, float* ws,
+                                float* slabs, const float* y_out, int ldout, const float* d_out,
+                                int lddout, float* const* grads, void* stream,
+                                void* side_stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     Model m;
     int rc = build_model(dp, m);
@@ -740,6 +808,8 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
     const bool attn = d.kind == GI_KIND_ATTGGNN;
 
     Deferred dq;
+    SideStream side_obj{(hipStream_t)side_stream, 0};
+    r.side = side_stream ? &side_obj : nullptr;
     const Grp none{0, nullptr, 0};
     // ---- tier 2 (gnn/modules.py:265-279) ---------------------------------------------------------
     r.chk(gi_selu_bwd_rows(d_out, lddout, nullptr, y_out, ldout, ws + w.dzA, w.ldNA, d.B, NA, r.st));
@@ -856,7 +926,12 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
         std::swap(dh, dh2);
     }
     // ---- all weight-gradient GEMMs, 8 problems per launch, then slabs -> parameter gradients -------
-    flush_deferred(r, dq);
+    if (r.side) {
+        kick_deferred(r, dq, r.side, true);
+        join_side(r, r.side);
+    } else {
+        flush_deferred(r, dq);
+    }
     gi_reduce_desc descs[160];
     int nd = 0;
     auto add_desc = [&](int widx, int bidx) {

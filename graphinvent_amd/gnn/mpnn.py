@@ -89,6 +89,29 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN):
     return out, (dims, graph, ws, Et)
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device: torch.device) -> int:
+    """Second HIP stream (one per device) on which gi_ggnn_backward runs the weight-gradient GEMMs
+    concurrently with the dZ chain; GI_WGRAD_SIDE_STREAM=0 keeps everything on one stream."""
+    if _os_environ_flag("GI_WGRAD_SIDE_STREAM", "1") == "0":
+        return 0
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        handle = C.c_void_p()
+        with torch.cuda.device(key):
+            _L.check(_L.load().gi_side_stream_create(C.byref(handle)), "gi_side_stream_create")
+        st = _SIDE_STREAMS[key] = handle.value      # lives as long as the process
+    return st
+
+
+def _os_environ_flag(name: str, default: str) -> str:
+    import os
+    return os.environ.get(name, default)
+
+
 def ggnn_backward_raw(tape, out, d_out, params):
     """The fused backward; consumes the tape's activations in place.  Returns (grads, gflat):
     per-parameter gradient views into ONE flat fp32 buffer (state_dict order, 16-byte aligned
@@ -114,8 +137,8 @@ def ggnn_backward_raw(tape, out, d_out, params):
         graph.gvar[1].data_ptr(), graph.gvar[2].data_ptr(), graph.gvar[3].data_ptr(), graph.S,
         graph.E, Et_c,
         ws.data_ptr(), slabs.data_ptr(), out.data_ptr(), out.stride(0), d_out.data_ptr(),
-        d_out.stride(0), _ptr_table(grads), torch.cuda.current_stream().cuda_stream),
-        "gi_ggnn_backward")
+        d_out.stride(0), _ptr_table(grads), torch.cuda.current_stream().cuda_stream,
+        _side_stream(dev)), "gi_ggnn_backward")
     return grads, gflat
 
 

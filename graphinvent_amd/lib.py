@@ -89,6 +89,8 @@ SIGNATURES = {
     "gi_kl_loss": (ci, [vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, vp]),
     "gi_prof_enable": (ci, [ci]),
     "gi_prof_collect": (ci, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci)]),
+    "gi_side_stream_create": (ci, [C.POINTER(vp)]),
+    "gi_side_stream_destroy": (ci, [vp]),
     "gi_ggnn_num_params": (ci, [C.POINTER(GgnnDims)]),
     "gi_ggnn_workspace_floats": (cll, [C.POINTER(GgnnDims), ci, ci]),
     "gi_ggnn_slab_floats": (cll, [C.POINTER(GgnnDims), ci, ci, C.POINTER(ci)]),
@@ -99,7 +101,7 @@ SIGNATURES = {
     "gi_ggnn_forward": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), vp, vp, vp, ci, ci,
                              C.POINTER(ci), vp, vp, ci, vp]),
     "gi_ggnn_backward": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), vp, vp, vp, vp, vp, ci, ci,
-                              C.POINTER(ci), vp, vp, vp, ci, vp, ci, C.POINTER(vp), vp]),
+                              C.POINTER(ci), vp, vp, vp, ci, vp, ci, C.POINTER(vp), vp, vp]),
 }
 
 _lib = None

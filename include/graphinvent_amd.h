@@ -214,6 +214,12 @@ typedef struct gi_ggnn_dims {
 #define GI_KIND_GGNN 0
 #define GI_KIND_ATTGGNN 1
 
+/* Creates / destroys a lowest-priority, non-blocking stream on the current device for
+ * gi_ggnn_backward's `side_stream` argument (caller-owned handle; any other stream of the same
+ * device works too). */
+int gi_side_stream_create(void** stream);
+int gi_side_stream_destroy(void* stream);
+
 int gi_ggnn_num_params(const gi_ggnn_dims* d);
 long long gi_ggnn_workspace_floats(const gi_ggnn_dims* d, int S, int E);
 long long gi_ggnn_slab_floats(const gi_ggnn_dims* d, int S, int E, const int* Et);
@@ -230,11 +236,16 @@ int gi_ggnn_forward(const gi_ggnn_dims* d, const float* const* params, const int
                     float* ws, float* out, int ldout, void* stream);
 /* consumes (overwrites) the activations in ws; y_out = the logits forward returned; grads[i]
  * receives the gradient of params[i]; slabs = gi_ggnn_slab_floats() floats of scratch.
- * Et = HOST array of per-bond-type edge counts (counts[4..4+Fe) read back by the caller). */
+ * Et = HOST array of per-bond-type edge counts (counts[4..4+Fe) read back by the caller).
+ * side_stream (may be NULL): a second hipStream_t of the same device.  When given, the weight-
+ * gradient GEMMs run there, ordered after their operands by events, concurrently with the dZ chain
+ * on `stream`; `stream` waits for them before the final slab reduction, so on return every piece of
+ * work is ordered before whatever the caller enqueues next on `stream`. */
 int gi_ggnn_backward(const gi_ggnn_dims* d, const float* const* params, const int* gfix,
                      const int* e_src, const int* e_dst, const int* in_perm, const int* out_perm,
                      int S, int E, const int* Et, float* ws, float* slabs, const float* y_out, int ldout,
-                     const float* d_out, int lddout, float* const* grads, void* stream);
+                     const float* d_out, int lddout, float* const* grads, void* stream,
+                     void* side_stream);
 
 #ifdef __cplusplus
 }

@@ -4,7 +4,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1
 g = collections.defaultdict(list); o = collections.defaultdict(list)
 for r in rows:
-    n = r['Kernel_Name']; d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    n = r['Kernel_Name'].replace('(anonymous namespace)::', ''); d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     wg = int(r['Workgroup_Size_X'])
     if 'gi_gemm' in n:
         key = (n.replace('void gi_gemm_kernel', '').replace('(gi_gemm_params)', ''), int(r['Grid_Size_X']) // wg, int(r['Grid_Size_Y']), int(r['Grid_Size_Z']))
