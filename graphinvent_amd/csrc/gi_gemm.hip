@@ -125,7 +125,6 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
     const int m0 = m_begin + by * BM;
     const int n0 = bx * BN;
     if (m0 >= m_end) return;
-    if (p.flags & 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // EXPERIMENT: fence cost
     const int bcols = (p.ones_col >= 0) ? p.ones_col : p.N;     // real stored columns of a major B
 
     // ---- per-thread staging coordinates -----------------------------------------------------
@@ -395,7 +394,6 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
             }
         }
     }
-    if (p.flags & 64) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // EXPERIMENT: fence cost
 }
 
 template <int TM, int TN, bool A_MAJOR, bool B_MAJOR>
