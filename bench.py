@@ -80,19 +80,22 @@ def make_batches(rank: int, device):
     return out
 
 
-def seg_sum_hbm_probe(device, M=128, replicas=64):
-    """seg_sum on a graph batch replicated until E*M*4 exceeds the 256 MB Infinity Cache."""
+def seg_sum_hbm_probe(device, M=128, replicas=128):
+    """seg_sum (the aggregation a_v = sum of incoming messages) on a graph batch replicated until its
+    message rows exceed the 256 MB Infinity Cache.  Bytes counted = what must cross HBM once: every
+    message row once (rows read by several edges are re-read from cache), the index, the offsets and
+    the output — i.e. the SURVEY.md §8d form with the de-duplicated row count."""
     sh = synthetic.SHAPES["gdb13"]
     n8, e8, _ = synthetic.make_batch(1000, **sh, seed=77)
     g, _ = ops.compact(torch.from_numpy(n8).float().to(device),
                        torch.from_numpy(e8).float().to(device), M)
-    S, E = g.S, g.E
-    perm = torch.cat([g.in_perm + r * E for r in range(replicas)])
+    S, E, U = g.S, g.E, g.U
+    perm = torch.cat([g.in_perm + r * U for r in range(replicas)])
     seg = g.seg_off[:S + 1]
     off = torch.cat([seg[:-1] + r * E for r in range(replicas)] +
                     [torch.tensor([replicas * E, replicas * E], dtype=torch.int32, device=device)])
-    rows, nnz = replicas * S, replicas * E
-    vals = torch.randn(nnz, M, device=device)
+    rows, nnz, mrows = replicas * S, replicas * E, replicas * U
+    vals = torch.randn(mrows, M, device=device)
     out = torch.empty(rows + 1, M, device=device)
     for _ in range(3):
         ops.seg_sum(vals, perm, off, rows, M, out)
@@ -104,8 +107,8 @@ def seg_sum_hbm_probe(device, M=128, replicas=64):
     ev1.record()
     torch.cuda.synchronize()
     ms = ev0.elapsed_time(ev1) / reps
-    nbytes = nnz * M * 4 + nnz * 4 + (rows + 1) * 4 + rows * M * 4
-    return dict(rows=rows, nnz=nnz, working_set_MB=round(nnz * M * 4 / 1e6, 1),
+    nbytes = mrows * M * 4 + nnz * 4 + (rows + 1) * 4 + rows * M * 4
+    return dict(rows=rows, nnz=nnz, message_rows=mrows, working_set_MB=round(mrows * M * 4 / 1e6, 1),
                 us=round(ms * 1e3, 2), GBps=round(nbytes / ms / 1e6, 1))
 
 
@@ -248,10 +251,13 @@ def main():
     for i in range(prof_steps):
         b = batches[i % N_BATCHES]
         if rank == 0:
-            _, _, _, S, E, _ = ops.compact_count(b[0], b[1])
+            _, _, _, S, E, U, _ = ops.compact_count(b[0], b[1])
             R, Mm, H, P = S + 1, cfg["message_size"], cfg["hidden_node_features"], cfg["message_passes"]
-            seg_bytes += P * (E * Mm * 4 + E * 4 + (R + 1) * 4 + R * Mm * 4)              # forward
-            seg_bytes += (P - 1) * (E * H * 4 + E * 4 + (R + 1) * 4 + 2 * R * H * 4)      # backward scatter
+            # algorithmic bytes of the three segmented sums (SURVEY.md §8d form): values read through
+            # the index + index + offsets + output
+            seg_bytes += P * (E * Mm * 4 + E * 4 + (R + 1) * 4 + R * Mm * 4)              # aggregation
+            seg_bytes += P * (E * Mm * 4 + E * 4 + (U + 1) * 4 + 2 * U * Mm * 4)          # its backward
+            seg_bytes += (P - 1) * (U * H * 4 + U * 4 + (R + 1) * 4 + 2 * R * H * 4)      # d h scatter
         trainer.step(*b)
     torch.cuda.synchronize()
     if rank == 0:

@@ -4,13 +4,22 @@
 // matrix, `edges[eb,ei,ej,:]`, the zero-padded hidden state) and :146 (`node_mask`).
 // Integer / byte work, HBM-bound (reads B*N*N*Fe*4 + B*N*Fn*4 bytes once); three launches:
 //   count : one workgroup per graph; adjacency staged in LDS as int8 bond types; per-slot
-//           in/out degrees, per-type in-degrees, activity flags
+//           in-degree, per-type out-degrees, activity flags
 //   scan  : one 1024-thread workgroup per scanned array; exclusive scans over the B*N slots ->
-//           compact row ids, CSR offsets, bond-type bucket offsets, totals (S, E, E_t); + finish
-//   fill  : one workgroup per graph; edge arrays in bond-type-major order, dst- and src-CSR
-//           permutations (deterministic order), initial node rows
+//           compact row ids, CSR offsets, message-row ids, totals (S, E, U, U_t, E_t); + finish
+//   fill  : one workgroup per graph; dst-CSR, message CSR and source CSR index arrays
+//           (deterministic order), initial node rows
 // Edge enumeration order = row-major nonzero of the adjacency = the reference's edge order, so
 // every destination's edges are one contiguous CSR segment and no atomics are needed anywhere.
+//
+// MESSAGE ROWS.  The message an edge carries, MLP_type(e)(h_src(e)) (gnn/mpnn.py:284-294), depends
+// only on (source node, bond type); a carbon with three single bonds sends the same vector three
+// times.  The message MLP therefore runs on one row per distinct (source slot, bond type) pair — U
+// rows, 0.55-0.63 E on molecular graphs — ordered bond-type-major (the grouped GEMM's buckets),
+// inside a type by source slot.  Aggregation reads message rows through the dst-CSR (`in_perm`);
+// its backward sums, per message row, the gradients of the edges that read it (message CSR
+// `mu_off / mu_dst / mu_slot`); the input gradient of the message MLP goes back to the nodes
+// through the source CSR over message rows (`out_perm`, `src_off`).
 #include "gi_common.h"
 
 namespace {
@@ -18,15 +27,17 @@ namespace {
 struct Lay {
     int counts, type_off, cidx, node_mask, slot_of, seg_off, src_off, scratch, total;
     // scratch sub-arrays (ints)
-    int rowcnt, colcnt, active, seg_start, src_start, rowcnt_t, tstart, etype;
+    int rowcnt, nmsg, active, seg_start, srcm_start, colcnt_t, cstart_t, mflag_t, mstart_t,
+        etype_off, etype;
 };
+constexpr int CNT_S = 0, CNT_E = 1, CNT_ERR = 2, CNT_U = 3, CNT_UT = 4, CNT_ET = 12, CNT_N = 24;
 
 inline Lay make_layout(int B, int N, int Fe) {
     Lay L;
     const int ns = B * N;
     int o = 0;
     auto take = [&](int n) { int r = o; o += gi_r4(n); return r; };
-    L.counts = take(16);
+    L.counts = take(CNT_N);
     L.type_off = take(GI_MAX_GROUPS + 1);
     L.cidx = take(ns);
     L.node_mask = take(ns);
@@ -35,12 +46,15 @@ inline Lay make_layout(int B, int N, int Fe) {
     L.src_off = take(ns + 2);
     L.scratch = o;
     L.rowcnt = take(ns);
-    L.colcnt = take(ns);
+    L.nmsg = take(ns);
     L.active = take(ns);
     L.seg_start = take(ns);
-    L.src_start = take(ns);
-    L.rowcnt_t = take(Fe * ns);
-    L.tstart = take(Fe * ns);
+    L.srcm_start = take(ns);
+    L.colcnt_t = take(Fe * ns);
+    L.cstart_t = take(Fe * ns);
+    L.mflag_t = take(Fe * ns);
+    L.mstart_t = take(Fe * ns);
+    L.etype_off = take(GI_MAX_GROUPS + 1);
     L.etype = take((int)(((long long)B * N * N + 3) / 4));
     L.total = o;
     return L;
@@ -82,33 +96,39 @@ __global__ __launch_bounds__(256) void compact_count_kernel(
     const int ns = gridDim.x * N;
     for (int i = tid; i < N; i += 256) {
         const int slot = b * N + i;
-        int rc = 0, cc = 0;
-        int rct[GI_MAX_GROUPS];
+        int rc = 0, cc = 0, nm = 0;
+        int cct[GI_MAX_GROUPS];                          // out-degree of slot i per bond type
 #pragma unroll
-        for (int f = 0; f < GI_MAX_GROUPS; ++f) rct[f] = 0;
+        for (int f = 0; f < GI_MAX_GROUPS; ++f) cct[f] = 0;
         for (int j = 0; j < N; ++j) {
-            const int t = typ[i * N + j];
+            rc += (typ[i * N + j] >= 0);
+            const int t = typ[j * N + i];
             if (t >= 0) {
-                ++rc;
+                ++cc;
 #pragma unroll
-                for (int f = 0; f < GI_MAX_GROUPS; ++f) rct[f] += (t == f);
+                for (int f = 0; f < GI_MAX_GROUPS; ++f) cct[f] += (t == f);
             }
-            cc += (typ[j * N + i] >= 0);
         }
         bool nz = false;
         for (int f = 0; f < Fn; ++f) nz |= ((float)nodes[(long long)slot * Fn + f] != 0.f);
         gfix[L.rowcnt + slot] = rc;
-        gfix[L.colcnt + slot] = cc;
         gfix[L.active + slot] = (nz || rc > 0 || cc > 0) ? 1 : 0;
         gfix[L.node_mask + slot] = rc > 0 ? 1 : 0;                       // :146
-        for (int f = 0; f < Fe; ++f) gfix[L.rowcnt_t + f * ns + slot] = rct[f];
+#pragma unroll
+        for (int f = 0; f < GI_MAX_GROUPS; ++f)
+            if (f < Fe) {
+                gfix[L.colcnt_t + f * ns + slot] = cct[f];
+                gfix[L.mflag_t + f * ns + slot] = cct[f] > 0 ? 1 : 0;   // slot sends a type-f message
+                nm += cct[f] > 0;
+            }
+        gfix[L.nmsg + slot] = nm;
     }
     __syncthreads();
-    if (tid == 0 && err_s) atomicOr(&gfix[L.counts + 2], 1);
+    if (tid == 0 && err_s) atomicOr(&gfix[L.counts + CNT_ERR], 1);
 }
 
 // ---- scan -----------------------------------------------------------------------------------
-// One 1024-thread workgroup per scanned array (3 + Fe arrays, independent), chunks of 1024
+// One 1024-thread workgroup per scanned array (3 + 2 Fe arrays, independent), chunks of 1024
 // elements: coalesced load, wave-shuffle inclusive scan + 16 wave totals through LDS, running carry,
 // coalesced store.  Totals go straight to counts[]; a second small kernel builds the compact-row
 // views that depend on several of the scans.
@@ -118,11 +138,13 @@ __global__ __launch_bounds__(1024) void compact_scan_kernel(int ns, int Fe, int*
     __shared__ int carry_s;
     const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int* src; int* dst; int* total;
-    if (a == 0) { src = gfix + L.active; dst = gfix + L.cidx; total = gfix + L.counts + 0; }
-    else if (a == 1) { src = gfix + L.rowcnt; dst = gfix + L.seg_start; total = gfix + L.counts + 1; }
-    else if (a == 2) { src = gfix + L.colcnt; dst = gfix + L.src_start; total = nullptr; }
-    else { const int f = a - 3; src = gfix + L.rowcnt_t + f * ns; dst = gfix + L.tstart + f * ns;
-           total = gfix + L.counts + 4 + f; }
+    if (a == 0) { src = gfix + L.active; dst = gfix + L.cidx; total = gfix + L.counts + CNT_S; }
+    else if (a == 1) { src = gfix + L.rowcnt; dst = gfix + L.seg_start; total = gfix + L.counts + CNT_E; }
+    else if (a == 2) { src = gfix + L.nmsg; dst = gfix + L.srcm_start; total = gfix + L.counts + CNT_U; }
+    else if (a < 3 + Fe) { const int f = a - 3; src = gfix + L.mflag_t + f * ns;
+                           dst = gfix + L.mstart_t + f * ns; total = gfix + L.counts + CNT_UT + f; }
+    else { const int f = a - 3 - Fe; src = gfix + L.colcnt_t + f * ns;
+           dst = gfix + L.cstart_t + f * ns; total = gfix + L.counts + CNT_ET + f; }
     if (tid == 0) carry_s = 0;
     __syncthreads();
     for (int base = 0; base < ns; base += 1024) {
@@ -150,24 +172,27 @@ __global__ __launch_bounds__(1024) void compact_scan_kernel(int ns, int Fe, int*
 // compact-row views: slot_of, seg_off, src_off; inactive slots map to the zero row S; type offsets
 __global__ __launch_bounds__(256) void compact_finish_kernel(int ns, int Fe, int* __restrict__ gfix,
                                                              Lay L) {
-    const int S = gfix[L.counts + 0], E = gfix[L.counts + 1];
+    const int S = gfix[L.counts + CNT_S], E = gfix[L.counts + CNT_E], U = gfix[L.counts + CNT_U];
     const int slot = blockIdx.x * 256 + threadIdx.x;
     if (slot < ns) {
         if (gfix[L.active + slot]) {
             const int c = gfix[L.cidx + slot];
             gfix[L.slot_of + c] = slot;
             gfix[L.seg_off + c] = gfix[L.seg_start + slot];
-            gfix[L.src_off + c] = gfix[L.src_start + slot];
+            gfix[L.src_off + c] = gfix[L.srcm_start + slot];
         } else {
             gfix[L.cidx + slot] = S;
         }
     }
     if (slot == 0) {
         gfix[L.seg_off + S] = E; gfix[L.seg_off + S + 1] = E;
-        gfix[L.src_off + S] = E; gfix[L.src_off + S + 1] = E;
-        int run = 0;
-        for (int f = 0; f < Fe; ++f) { gfix[L.type_off + f] = run; run += gfix[L.counts + 4 + f]; }
-        for (int f = Fe; f <= GI_MAX_GROUPS; ++f) gfix[L.type_off + f] = run;
+        gfix[L.src_off + S] = U; gfix[L.src_off + S + 1] = U;
+        int run = 0, erun = 0;                          // message-row and edge prefixes per bond type
+        for (int f = 0; f < Fe; ++f) {
+            gfix[L.type_off + f] = run; run += gfix[L.counts + CNT_UT + f];
+            gfix[L.etype_off + f] = erun; erun += gfix[L.counts + CNT_ET + f];
+        }
+        for (int f = Fe; f <= GI_MAX_GROUPS; ++f) { gfix[L.type_off + f] = run; gfix[L.etype_off + f] = erun; }
     }
 }
 
@@ -175,10 +200,11 @@ __global__ __launch_bounds__(256) void compact_finish_kernel(int ns, int Fe, int
 template <typename T>
 __global__ __launch_bounds__(256) void compact_fill_kernel(
     const T* __restrict__ nodes, int N, int Fn, int Fe, const int* __restrict__ gfix, Lay L,
-    int S, int* __restrict__ e_src, int* __restrict__ e_dst, int* __restrict__ in_perm,
+    int S, int E, int U, int* __restrict__ u_src, int* __restrict__ in_perm,
+    int* __restrict__ mu_off, int* __restrict__ mu_dst, int* __restrict__ mu_slot,
     int* __restrict__ out_perm, float* __restrict__ hx0, int ldhx, int H) {
     __shared__ signed char typ[GI_MAX_NODES * GI_MAX_NODES];
-    __shared__ int ppos[GI_MAX_NODES * GI_MAX_NODES];
+    __shared__ int kpos[GI_MAX_NODES * GI_MAX_NODES];   // dst-CSR slot of edge (i <- j)
     const int b = blockIdx.x, tid = threadIdx.x;
     const int NN = N * N, ns = gridDim.x * N;
     const signed char* etype_g =
@@ -186,32 +212,35 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
     for (int idx = tid; idx < NN; idx += 256) typ[idx] = etype_g[idx];
     __syncthreads();
     for (int i = tid; i < N; i += 256) {                 // incoming edges of slot i, j ascending
-        const int slot = b * N + i;
-        const int cd = gfix[L.cidx + slot];
-        int ed = gfix[L.seg_start + slot];
-        int cur[GI_MAX_GROUPS];
-#pragma unroll
-        for (int f = 0; f < GI_MAX_GROUPS; ++f)
-            cur[f] = (f < Fe) ? gfix[L.type_off + f] + gfix[L.tstart + f * ns + slot] : 0;
+        int ed = gfix[L.seg_start + b * N + i];
         for (int j = 0; j < N; ++j) {
             const int t = typ[i * N + j];
             if (t < 0) continue;
-            int pos = 0;
-#pragma unroll
-            for (int f = 0; f < GI_MAX_GROUPS; ++f)
-                if (t == f) { pos = cur[f]; cur[f] = pos + 1; }
-            e_src[pos] = gfix[L.cidx + b * N + j];
-            e_dst[pos] = cd;
-            in_perm[ed++] = pos;
-            ppos[i * N + j] = pos;
+            in_perm[ed] = gfix[L.type_off + t] + gfix[L.mstart_t + t * ns + b * N + j];
+            kpos[i * N + j] = ed++;
         }
     }
     __syncthreads();
-    for (int j = tid; j < N; j += 256) {                 // outgoing edges of slot j, i ascending
-        int k = gfix[L.src_start + b * N + j];
-        for (int i = 0; i < N; ++i)
-            if (typ[i * N + j] >= 0) out_perm[k++] = ppos[i * N + j];
+    for (int j = tid; j < N; j += 256) {                 // message rows of source slot j, by type
+        const int slot = b * N + j;
+        const int cs = gfix[L.cidx + slot];
+        int ko = gfix[L.srcm_start + slot];
+        for (int t = 0; t < Fe; ++t) {
+            if (gfix[L.colcnt_t + t * ns + slot] == 0) continue;
+            const int u = gfix[L.type_off + t] + gfix[L.mstart_t + t * ns + slot];
+            int mo = gfix[L.etype_off + t] + gfix[L.cstart_t + t * ns + slot];
+            u_src[u] = cs;
+            out_perm[ko++] = u;
+            mu_off[u] = mo;
+            for (int i = 0; i < N; ++i)                  // its edges, destination ascending
+                if (typ[i * N + j] == t) {
+                    mu_dst[mo] = gfix[L.cidx + b * N + i];
+                    mu_slot[mo] = kpos[i * N + j];
+                    ++mo;
+                }
+        }
     }
+    if (b == 0 && tid == 0) mu_off[U] = E;
     // initial node rows: hx0[c] = [x, 0 .. 0 | x]  (:121-126 zero-padded hidden state; the copy of
     // the raw features at columns [H, H+Fn) feeds the gather attention MLP, gnn/modules.py:45)
     for (int idx = tid; idx < N * ldhx; idx += 256) {
@@ -252,7 +281,7 @@ extern "C" int gi_compact_count(const void* nodes, const void* edges, int in_dty
     if (N > GI_MAX_NODES || Fe > GI_MAX_GROUPS) return GI_ELIMIT;
     const Lay L = make_layout(B, N, Fe);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(gfix + L.counts, 0, 16 * sizeof(int), st);
+    hipError_t e = hipMemsetAsync(gfix + L.counts, 0, CNT_N * sizeof(int), st);
     if (e != hipSuccess) return (int)e;
     if (in_dtype == GI_DTYPE_F32)
         hipLaunchKernelGGL(compact_count_kernel<float>, dim3(B), dim3(256), 0, st,
@@ -260,29 +289,31 @@ extern "C" int gi_compact_count(const void* nodes, const void* edges, int in_dty
     else
         hipLaunchKernelGGL(compact_count_kernel<signed char>, dim3(B), dim3(256), 0, st,
                            (const signed char*)nodes, (const signed char*)edges, N, Fn, Fe, gfix, L);
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(3 + Fe), dim3(1024), 0, st, B * N, Fe, gfix, L);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(3 + 2 * Fe), dim3(1024), 0, st, B * N, Fe, gfix, L);
     hipLaunchKernelGGL(compact_finish_kernel, dim3(gi_cdiv(B * N, 256)), dim3(256), 0, st, B * N, Fe,
                        gfix, L);
     return gi_launch_status();
 }
 
-extern "C" int gi_compact_fill(const void* nodes, int in_dtype, int B, int N, int Fn, int Fe, const int* gfix,
-                               int S, int E, int* e_src, int* e_dst, int* in_perm, int* out_perm,
-                               float* hx0, int ldhx, int H, void* stream) {
+extern "C" int gi_compact_fill(const void* nodes, int in_dtype, int B, int N, int Fn, int Fe,
+                               const int* gfix, int S, int E, int U, int* u_src, int* in_perm,
+                               int* mu_off, int* mu_dst, int* mu_slot, int* out_perm, float* hx0,
+                               int ldhx, int H, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
-    if (!nodes || !gfix || !hx0 || B <= 0 || N <= 0 || S < 0 || E < 0) return GI_EINVAL;
-    if (E > 0 && (!e_src || !e_dst || !in_perm || !out_perm)) return GI_EINVAL;
+    if (!nodes || !gfix || !hx0 || !mu_off || B <= 0 || N <= 0 || S < 0 || E < 0 || U < 0 || U > E)
+        return GI_EINVAL;
+    if (E > 0 && (!u_src || !in_perm || !mu_dst || !mu_slot || !out_perm)) return GI_EINVAL;
     if (N > GI_MAX_NODES || Fe > GI_MAX_GROUPS) return GI_ELIMIT;
     if (ldhx < H + Fn || Fn > H) return GI_EINVAL;
     const Lay L = make_layout(B, N, Fe);
     if (in_dtype == GI_DTYPE_F32)
         hipLaunchKernelGGL(compact_fill_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)nodes, N, Fn, Fe, gfix, L, S, e_src, e_dst, in_perm,
-                           out_perm, hx0, ldhx, H);
+                           (const float*)nodes, N, Fn, Fe, gfix, L, S, E, U, u_src, in_perm, mu_off,
+                           mu_dst, mu_slot, out_perm, hx0, ldhx, H);
     else if (in_dtype == GI_DTYPE_I8)
         hipLaunchKernelGGL(compact_fill_kernel<signed char>, dim3(B), dim3(256), 0,
-                           (hipStream_t)stream, (const signed char*)nodes, N, Fn, Fe, gfix, L, S,
-                           e_src, e_dst, in_perm, out_perm, hx0, ldhx, H);
+                           (hipStream_t)stream, (const signed char*)nodes, N, Fn, Fe, gfix, L, S, E,
+                           U, u_src, in_perm, mu_off, mu_dst, mu_slot, out_perm, hx0, ldhx, H);
     else
         return GI_EINVAL;
     return gi_launch_status();

@@ -7,7 +7,8 @@
 //
 // Data layout in HBM (all fp32 row-major, leading dimensions rounded up to 4 floats = 16 B):
 //   node level  : R = S+1 compact rows (row S = shared zero row);  hx[p] = [h (H) | x (Fn)] per pass
-//   edge level  : E rows in bond-type-major order (rows of type t = [type_off[t], type_off[t+1]))
+//   message lvl : U rows, one per distinct (source node, bond type) pair, bond-type-major (rows of
+//                 type t = [type_off[t], type_off[t+1])); see gi_compact.hip
 //   graph level : B rows
 // Backward runs IN PLACE over the saved activations: the buffer of layer l's SELU output is
 // overwritten by dZ_l (gradient w.r.t. its pre-activation) once nobody needs the activation.
@@ -77,13 +78,13 @@ int build_model(const gi_ggnn_dims* dp, Model& m) {
 
 // ---- workspace --------------------------------------------------------------------------------
 struct Ws {
-    int R, E, B;
+    int R, E, U, B;
     int ldhx, ldH, ldM, ld3H, ldG, ldA, ldC, ldEh, ldAtt, ldEmb, ldM1, ldM2, ldNA, ldNC, ldCA,
         ldCC, ldZG, ldEa;
     long long hx[MAXP + 1];
     // AttGGNN only: hidden activations / dZ of the per-bond-type energy MLP, its output (edge
     // energies), and its first-layer input gradient
-    long long aact[MAXP][MAXL], een[MAXP], adz[MAXP][MAXL], dxa;
+    long long aact[MAXP][MAXL], een[MAXP], adz[MAXP][MAXL], dxa, tmp_en, tmp_emb;
     long long eact[MAXP][MAXL], m[MAXP], agg[MAXP], gi[MAXP], gh[MAXP];
     long long att_act[MAXL], en, emb_act[MAXL], embo, add1_act[MAXL], add1o, conn1_act[MAXL],
         conn1o;
@@ -97,10 +98,10 @@ struct Ws {
     long long total;
 };
 
-void make_ws(const Model& m, int S, int E, Ws& w) {
+void make_ws(const Model& m, int S, int E, int U, Ws& w) {
     const gi_ggnn_dims& d = m.d;
     memset(&w, 0, sizeof(w));
-    w.R = S + 1; w.E = E; w.B = d.B;
+    w.R = S + 1; w.E = E; w.U = U; w.B = d.B;
     w.ldhx = gi_r4(d.H + d.Fn); w.ldH = gi_r4(d.H); w.ldM = gi_r4(d.M); w.ld3H = gi_r4(3 * d.H);
     w.ldG = gi_r4(d.G); w.ldA = gi_r4(d.A); w.ldC = gi_r4(d.C); w.ldEh = gi_r4(d.enn_hidden);
     w.ldAtt = gi_r4(d.att_hidden); w.ldEmb = gi_r4(d.emb_hidden); w.ldM1 = gi_r4(d.mlp1_hidden);
@@ -110,7 +111,7 @@ void make_ws(const Model& m, int S, int E, Ws& w) {
     w.ldEa = attn ? gi_r4(d.eatt_hidden) : 4;
     long long o = 0;
     auto take = [&](long long rows, int ld) { long long r = o; o += gi_r4l(rows * ld); return r; };
-    const long long R = w.R, B = d.B, Er = std::max(E, 1);
+    const long long R = w.R, B = d.B, Er = std::max(U, 1);   // message-row buffers
     for (int p = 0; p <= d.passes; ++p) w.hx[p] = take(R, w.ldhx);
     for (int p = 0; p < d.passes; ++p) {
         for (int l = 0; l < d.enn_depth; ++l) w.eact[p][l] = take(Er, w.ldEh);
@@ -149,7 +150,11 @@ void make_ws(const Model& m, int S, int E, Ws& w) {
             for (int l = 0; l < d.eatt_depth; ++l) w.adz[p][l] = take(Er, w.ldEa);
         w.dagg[p] = take(R, w.ldM);
     }
-    if (attn) w.dxa = take(Er, w.ldH);
+    if (attn) {
+        w.dxa = take(Er, w.ldH);
+        w.tmp_en = take(std::max(E, 1), w.ldM);      // per-edge softmax-backward contributions
+        w.tmp_emb = take(std::max(E, 1), w.ldM);
+    }
     for (int l = 0; l < d.att_depth; ++l) w.att_dz[l] = take(R, w.ldAtt);
     for (int l = 0; l < d.emb_depth; ++l) w.emb_dz[l] = take(R, w.ldEmb);
     for (int l = 0; l < d.mlp1_depth; ++l) { w.add1_dz[l] = take(R, w.ldM1); w.conn1_dz[l] = take(R, w.ldM1); }
@@ -174,7 +179,7 @@ void wgrad_shape(int n_out, int n_in, int red_rows, double share, int& tn, int& 
     nsplit = std::min(std::max(want, 1), std::max(1, kt / 2));
 }
 
-void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {
+void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {   // E, Et: message rows
     const gi_ggnn_dims& d = m.d;
     memset(&sp, 0, sizeof(sp));
     long long o = 0;
@@ -626,19 +631,19 @@ extern "C" int gi_ggnn_num_params(const gi_ggnn_dims* d) {
     return rc ? rc : m.nparams;
 }
 
-extern "C" long long gi_ggnn_workspace_floats(const gi_ggnn_dims* d, int S, int E) {
+extern "C" long long gi_ggnn_workspace_floats(const gi_ggnn_dims* d, int S, int E, int U) {
     Model m;
-    if (build_model(d, m) || S < 0 || E < 0) return GI_EINVAL;
+    if (build_model(d, m) || S < 0 || E < 0 || U < 0 || U > E) return GI_EINVAL;
     Ws w;
-    make_ws(m, S, E, w);
+    make_ws(m, S, E, U, w);
     return w.total;
 }
 
-extern "C" long long gi_ggnn_hx0_offset(const gi_ggnn_dims* d, int S, int E) {
+extern "C" long long gi_ggnn_hx0_offset(const gi_ggnn_dims* d, int S, int E, int U) {
     Model m;
-    if (build_model(d, m) || S < 0 || E < 0) return GI_EINVAL;
+    if (build_model(d, m) || S < 0 || E < 0 || U < 0 || U > E) return GI_EINVAL;
     Ws w;
-    make_ws(m, S, E, w);
+    make_ws(m, S, E, U, w);
     return w.hx[0];
 }
 
@@ -648,8 +653,10 @@ extern "C" int gi_ggnn_ldhx(const gi_ggnn_dims* d) {
     return gi_r4(d->H + d->Fn);
 }
 
-extern "C" long long gi_ggnn_slab_floats(const gi_ggnn_dims* d, int S, int E, const int* Et) {
+extern "C" long long gi_ggnn_slab_floats(const gi_ggnn_dims* d, int S, int U, const int* Ut) {
     Model m;
+    const int E = U;
+    const int* Et = Ut;
     if (build_model(d, m) || S < 0 || E < 0) return GI_EINVAL;
     static_assert(sizeof(SlabPlan) < (1 << 16), "plan size");
     SlabPlan sp;
@@ -659,13 +666,14 @@ extern "C" long long gi_ggnn_slab_floats(const gi_ggnn_dims* d, int S, int E, co
 }
 
 // Debug/test hook: offset (floats) and leading dimension of a named workspace buffer.
-extern "C" int gi_ggnn_ws_query(const gi_ggnn_dims* d, int S, int E, const char* name, int i, int j,
-                                long long* off, int* ld) {
+extern "C" int gi_ggnn_ws_query(const gi_ggnn_dims* d, int S, int E, int U, const char* name, int i,
+                                int j, long long* off, int* ld) {
     Model m;
-    if (build_model(d, m) || S < 0 || E < 0 || !name || !off || !ld) return GI_EINVAL;
+    if (build_model(d, m) || S < 0 || E < 0 || U < 0 || U > E || !name || !off || !ld)
+        return GI_EINVAL;
     if (i < 0 || i > MAXP || j < 0 || j >= MAXL) return GI_EINVAL;
     Ws w;
-    make_ws(m, S, E, w);
+    make_ws(m, S, E, U, w);
     struct Item { const char* n; long long o; int l; };
     const Item items[] = {
         {"hx", w.hx[i], w.ldhx}, {"eact", w.eact[i < MAXP ? i : 0][j], w.ldEh},
@@ -687,15 +695,20 @@ extern "C" int gi_ggnn_ws_query(const gi_ggnn_dims* d, int S, int E, const char*
     return GI_EINVAL;
 }
 
-extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* params, const int* gfix,
-                               const int* e_src, const int* in_perm, int S, int E, const int* Et,
-                               float* ws, float* out, int ldout, void* stream) {
+extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* params,
+                               const gi_graph* gp, float* ws, float* out, int ldout, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     Model m;
     int rc = build_model(dp, m);
     if (rc) return rc;
-    if (!params || !gfix || !ws || !out || S < 0 || E < 0 || !Et) return GI_EINVAL;
-    if (E > 0 && (!e_src || !in_perm)) return GI_EINVAL;
+    if (!gp) return GI_EINVAL;
+    const int S = gp->S, E = gp->E, U = gp->U;
+    const int* gfix = gp->gfix;
+    const int* u_src = gp->u_src;
+    const int* in_perm = gp->in_perm;
+    const int* Ut = gp->Ut;
+    if (!params || !gfix || !ws || !out || S < 0 || E < 0 || U < 0 || U > E || !Ut) return GI_EINVAL;
+    if (E > 0 && (!u_src || !in_perm || U == 0)) return GI_EINVAL;
     const gi_ggnn_dims& d = m.d;
     if (ldout < m.NA + m.NC + 1) return GI_EINVAL;
     if (d.kind == GI_KIND_ATTGGNN && E == 0) in_perm = in_perm ? in_perm : gfix;   // never read
@@ -703,12 +716,12 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
     rc = gi_compact_layout(d.B, d.N, d.Fe, &L);
     if (rc) return rc;
     Ws w;
-    make_ws(m, S, E, w);
+    make_ws(m, S, E, U, w);
     Run r{(hipStream_t)stream, params, 0};
     const int R = w.R;
-    int maxEt = 0;
-    for (int t = 0; t < d.Fe; ++t) maxEt = std::max(maxEt, Et[t]);
-    const Grp bytype{d.Fe, gfix + L.type_off, maxEt};
+    int maxUt = 0;
+    for (int t = 0; t < d.Fe; ++t) maxUt = std::max(maxUt, Ut[t]);
+    const Grp bytype{d.Fe, gfix + L.type_off, maxUt};
     const int* seg_off = gfix + L.seg_off;
     const int* cidx = gfix + L.cidx;
     const int* mask = gfix + L.node_mask;
@@ -724,13 +737,13 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
                 EdgeChain ch[2] = {
                     {m.msg, w.eact[p], w.edz[p], w.ldEh, ws + w.m[p], w.ldM, nullptr},
                     {m.eatt, w.aact[p], w.adz[p], w.ldEa, ws + w.een[p], w.ldM, nullptr}};
-                edge_chains_forward(r, ws, ch, 2, bytype, hx, w.ldhx, e_src, E);
+                edge_chains_forward(r, ws, ch, 2, bytype, hx, w.ldhx, u_src, U);
             }
             r.chk(gi_seg_softmax_fwd(ws + w.een[p], ws + w.m[p], w.ldM, in_perm, seg_off, R, d.M,
                                      ws + w.agg[p], w.ldM, r.st));
         } else {
-            if (E > 0)   // m_e = MLP_type(e)(h_src(e)), gnn/mpnn.py:284-294 routed per bond type
-                mlp_forward(r, ws, m.msg, bytype, hx, w.ldhx, e_src, E, w.eact[p], w.ldEh,
+            if (E > 0)   // m_u = MLP_type(u)(h_src(u)), gnn/mpnn.py:284-294, once per message row
+                mlp_forward(r, ws, m.msg, bytype, hx, w.ldhx, u_src, U, w.eact[p], w.ldEh,
                             ws + w.m[p], w.ldM);
             // a_v = sum of incoming messages (:141)
             r.chk(gi_seg_sum(ws + w.m[p], w.ldM, in_perm, seg_off, R, d.M, ws + w.agg[p], w.ldM, 0,
@@ -773,33 +786,43 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
     return r.rc;
 }
 
-extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* params, const int* gfix,
-                                const int* e_src, const int* e_dst, const int* in_perm,
-                                const int* out_perm, int S, int E, const int* Et, float* ws,
-                                float* slabs, const float* y_out, int ldout, const float* d_out,
-                                int lddout, float* const* grads, void* stream,
-                                void* side_stream) {
+extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* params,
+                                const gi_graph* gp, float* ws, float* slabs, const float* y_out,
+                                int ldout, const float* d_out, int lddout, float* const* grads,
+                                void* stream, void* side_stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     Model m;
     int rc = build_model(dp, m);
     if (rc) return rc;
-    if (!params || !gfix || !ws || !slabs || !y_out || !d_out || !grads || S < 0 || E < 0 || !Et)
+    if (!gp) return GI_EINVAL;
+    const int S = gp->S, E = gp->E, U = gp->U;
+    const int* gfix = gp->gfix;
+    const int* u_src = gp->u_src;
+    const int* in_perm = gp->in_perm;
+    const int* mu_off = gp->mu_off;
+    const int* mu_dst = gp->mu_dst;
+    const int* mu_slot = gp->mu_slot;
+    const int* out_perm = gp->out_perm;
+    const int* Ut = gp->Ut;
+    if (!params || !gfix || !ws || !slabs || !y_out || !d_out || !grads || S < 0 || E < 0 || U < 0 ||
+        U > E || !Ut)
         return GI_EINVAL;
-    if (E > 0 && (!e_src || !e_dst || !in_perm || !out_perm)) return GI_EINVAL;
+    if (E > 0 && (!u_src || !in_perm || !mu_off || !mu_dst || !mu_slot || !out_perm || U == 0))
+        return GI_EINVAL;
     if (m.nparams > 160) return GI_ELIMIT;
     const gi_ggnn_dims& d = m.d;
     gi_compact_layout_t L;
     rc = gi_compact_layout(d.B, d.N, d.Fe, &L);
     if (rc) return rc;
     Ws w;
-    make_ws(m, S, E, w);
+    make_ws(m, S, E, U, w);
     SlabPlan sp;
-    plan_slabs(m, S, E, Et, sp);
+    plan_slabs(m, S, U, Ut, sp);
     Run r{(hipStream_t)stream, params, 0};
     const int R = w.R;
-    int maxEt = 0;
-    for (int t = 0; t < d.Fe; ++t) maxEt = std::max(maxEt, Et[t]);
-    const Grp bytype{d.Fe, gfix + L.type_off, maxEt};
+    int maxUt = 0;
+    for (int t = 0; t < d.Fe; ++t) maxUt = std::max(maxUt, Ut[t]);
+    const Grp bytype{d.Fe, gfix + L.type_off, maxUt};
     const int* seg_off = gfix + L.seg_off;
     const int* src_off = gfix + L.src_off;
     const int* cidx = gfix + L.cidx;
@@ -887,24 +910,29 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
             flush_batch(r, bd, false);
         }
         if (E > 0 && attn) {
-            // backward of softmax-weighted aggregation + last SELU of both stacks, in place
+            // backward of the softmax-weighted aggregation: per-edge contributions, then per message
+            // row their sum times the SELU derivative of both stacks' last layer (in place)
             r.chk(gi_seg_softmax_bwd(ws + w.een[p], ws + w.m[p], w.ldM, in_perm, seg_off, R, d.M,
-                                     dagg, w.ldM, r.st));
+                                     dagg, w.ldM, ws + w.tmp_en, ws + w.tmp_emb, w.ldM, r.st));
+            r.chk(gi_seg_sum_dselu(ws + w.tmp_emb, w.ldM, mu_slot, mu_off, U, d.M, ws + w.m[p],
+                                   w.ldM, r.st));
+            r.chk(gi_seg_sum_dselu(ws + w.tmp_en, w.ldM, mu_slot, mu_off, U, d.M, ws + w.een[p],
+                                   w.ldM, r.st));
             EdgeChain ch[2] = {
                 {m.msg, w.eact[p], w.edz[p], w.ldEh, ws + w.m[p], w.ldM, p > 0 ? ws + w.dxe : nullptr},
                 {m.eatt, w.aact[p], w.adz[p], w.ldEa, ws + w.een[p], w.ldM,
                  p > 0 ? ws + w.dxa : nullptr}};
-            edge_chains_backward(r, ws, sp, slabs, dq, ch, 2, bytype, hx, w.ldhx, e_src, E, w.ldH,
+            edge_chains_backward(r, ws, sp, slabs, dq, ch, 2, bytype, hx, w.ldhx, u_src, U, w.ldH,
                                  d.H);
             if (p > 0) {
                 r.chk(gi_seg_sum(ws + w.dxe, w.ldH, out_perm, src_off, R, d.H, dh2, w.ldH, 1, r.st));
                 r.chk(gi_seg_sum(ws + w.dxa, w.ldH, out_perm, src_off, R, d.H, dh2, w.ldH, 1, r.st));
             }
         } else if (E > 0) {
-            // d m_e = d agg[dst(e)] * selu'(m_e)   (backward of the segmented sum + last SELU)
-            r.chk(gi_selu_bwd_rows(dagg, w.ldM, e_dst, ws + w.m[p], w.ldM, ws + w.m[p], w.ldM, E,
-                                   d.M, r.st));
-            msg_backward(r, ws, sp, slabs, dq, m.msg, bytype, hx, w.ldhx, e_src, E, w.eact[p],
+            // d m_u = selu'(m_u) * sum over the edges reading row u of d agg[dst(e)]
+            // (backward of the segmented sum + last SELU, over the message CSR)
+            r.chk(gi_seg_sum_dselu(dagg, w.ldM, mu_dst, mu_off, U, d.M, ws + w.m[p], w.ldM, r.st));
+            msg_backward(r, ws, sp, slabs, dq, m.msg, bytype, hx, w.ldhx, u_src, U, w.eact[p],
                          w.edz[p], w.ldEh, ws + w.m[p], w.ldM, p > 0 ? ws + w.dxe : nullptr, w.ldH,
                          d.H);
             if (p > 0)   // scatter d h_src back to nodes: segmented sum over the source CSR

@@ -36,6 +36,29 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(
     *dst = acc;
 }
 
+// seg_sum over the message CSR with the SELU backward of the destination buffer fused in
+__global__ __launch_bounds__(256) void seg_sum_dselu_kernel(
+    const float* __restrict__ vals, int ldv, const int* __restrict__ perm,
+    const int* __restrict__ off, int rows, int c4n, float* y, int ldy) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(t / c4n), q = (int)(t - (long long)c * c4n);
+    if (c >= rows) return;
+    const int lo = off[c], hi = off[c + 1];
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    int k = lo;
+    for (; k + 1 < hi; k += 2) {
+        const int p0 = perm[k], p1 = perm[k + 1];
+        const v4f a = *(const v4f*)(vals + (long long)p0 * ldv + 4 * q);
+        const v4f b = *(const v4f*)(vals + (long long)p1 * ldv + 4 * q);
+        acc += a;
+        acc += b;
+    }
+    if (k < hi) acc += *(const v4f*)(vals + (long long)perm[k] * ldv + 4 * q);
+    v4f* dst = (v4f*)(y + (long long)c * ldy + 4 * q);
+    const v4f yv = *dst;
+    *dst = acc * v4f{gi_selu_grad(yv.x), gi_selu_grad(yv.y), gi_selu_grad(yv.z), gi_selu_grad(yv.w)};
+}
+
 // ---- AttGGNN attention aggregation (gnn/mpnn.py:370-389) ------------------------------------------
 // One thread per (destination row, 16-byte feature group).  The reference pads every node's
 // neighbour list to the batch's maximum degree and masks with -1e6; here the softmax runs over the
@@ -79,11 +102,13 @@ __global__ __launch_bounds__(256) void seg_softmax_fwd_kernel(
     *(v4f*)(out + (long long)c * ldo + 4 * q) = acc;
 }
 
-// Backward of the attention aggregation fused with the SELU backward of both last layers, in
-// place: en <- d(pre-activation of the energy MLP's last layer), emb <- same for the message MLP.
+// Backward of the attention aggregation: per-edge contributions in dst-CSR slot order (a message
+// row may feed several destinations; its gradient is the seg_sum_dselu of these over the message CSR).
 __global__ __launch_bounds__(256) void seg_softmax_bwd_kernel(
-    float* en, float* emb, int ld, const int* __restrict__ perm, const int* __restrict__ off,
-    int rows, int c4n, const float* __restrict__ dagg, int ldd) {
+    const float* __restrict__ en, const float* __restrict__ emb, int ld,
+    const int* __restrict__ perm, const int* __restrict__ off, int rows, int c4n,
+    const float* __restrict__ dagg, int ldd, float* __restrict__ d_en_e,
+    float* __restrict__ d_emb_e, int lde) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int c = (int)(t / c4n), q = (int)(t - (long long)c * c4n);
     if (c >= rows) return;
@@ -104,10 +129,9 @@ __global__ __launch_bounds__(256) void seg_softmax_bwd_kernel(
     inner = inner * inv;                                  // sum_k att_k * d att_k
     for (int k = lo; k < hi; ++k) {
         const long long r = (long long)perm[k] * ld + 4 * q;
-        const v4f y_en = *(const v4f*)(en + r), y_emb = *(const v4f*)(emb + r);
-        const v4f att = v4_exp(y_en - mx) * inv;
-        *(v4f*)(en + r) = att * (y_emb * d - inner) * v4_selu_grad(y_en);
-        *(v4f*)(emb + r) = att * d * v4_selu_grad(y_emb);
+        const v4f att = v4_exp(*(const v4f*)(en + r) - mx) * inv;
+        *(v4f*)(d_en_e + (long long)k * lde + 4 * q) = att * (*(const v4f*)(emb + r) * d - inner);
+        *(v4f*)(d_emb_e + (long long)k * lde + 4 * q) = att * d;
     }
 }
 
@@ -469,18 +493,37 @@ extern "C" int gi_seg_softmax_fwd(const float* en, const float* emb, int ld, con
     return gi_launch_status();
 }
 
-extern "C" int gi_seg_softmax_bwd(float* en, float* emb, int ld, const int* perm, const int* off,
-                                  int rows, int cols, const float* dagg, int ldd, void* stream) {
+extern "C" int gi_seg_softmax_bwd(const float* en, const float* emb, int ld, const int* perm,
+                                  const int* off, int rows, int cols, const float* dagg, int ldd,
+                                  float* d_en_e, float* d_emb_e, int lde, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (rows <= 0) return 0;
     if (!seg_softmax_args_ok(en, emb, ld, perm, off, cols) || !dagg || (ldd & 3) || ldd < cols ||
-        ((uintptr_t)dagg & 15))
+        ((uintptr_t)dagg & 15) || !d_en_e || !d_emb_e || (lde & 3) || lde < cols ||
+        ((uintptr_t)d_en_e & 15) || ((uintptr_t)d_emb_e & 15))
         return GI_EINVAL;
     const int c4n = (cols + 3) / 4;
     const long long threads = (long long)rows * c4n;
     GiProfScope prof((hipStream_t)stream, GI_PROF_SEGSUM, 0.0);
     hipLaunchKernelGGL(seg_softmax_bwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256),
-                       0, (hipStream_t)stream, en, emb, ld, perm, off, rows, c4n, dagg, ldd);
+                       0, (hipStream_t)stream, en, emb, ld, perm, off, rows, c4n, dagg, ldd, d_en_e,
+                       d_emb_e, lde);
+    return gi_launch_status();
+}
+
+extern "C" int gi_seg_sum_dselu(const float* vals, int ldv, const int* perm, const int* off,
+                                int rows, int cols, float* y, int ldy, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
+    if (rows <= 0) return 0;
+    if (!vals || !perm || !off || !y || cols <= 0 || (ldv & 3) || (ldy & 3) || ldv < cols ||
+        ldy < cols)
+        return GI_EINVAL;
+    if (((uintptr_t)vals & 15) || ((uintptr_t)y & 15)) return GI_EINVAL;
+    const int c4n = (cols + 3) / 4;
+    const long long threads = (long long)rows * c4n;
+    GiProfScope prof((hipStream_t)stream, GI_PROF_SEGSUM, 0.0);
+    hipLaunchKernelGGL(seg_sum_dselu_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, vals, ldv, perm, off, rows, c4n, y, ldy);
     return gi_launch_status();
 }
 

@@ -62,7 +62,7 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN):
     """graph_compact + the fused forward.  Returns (logits, tape); the tape
     (dims, CompactGraph, workspace, per-type edge counts) is what backward consumes."""
     lib = _L.load()
-    nodes, lay, gfix, S, E, Et = _ops.compact_count(nodes, edges)
+    nodes, lay, gfix, S, E, U, Ut = _ops.compact_count(nodes, edges)
     B = nodes.shape[0]
     dims = _dims_from_constants(consts, B, kind)
     if lib.gi_ggnn_num_params(C.byref(dims)) != len(params):
@@ -72,21 +72,20 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN):
             raise RuntimeError("GGNN parameters must be contiguous fp32 CUDA tensors "
                                "(call model.to('cuda'))")
     dev = nodes.device
-    n_ws = lib.gi_ggnn_workspace_floats(C.byref(dims), S, E)
+    n_ws = lib.gi_ggnn_workspace_floats(C.byref(dims), S, E, U)
     if n_ws < 0:
         _L.check(int(n_ws), "gi_ggnn_workspace_floats")
     ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
     ldhx = lib.gi_ggnn_ldhx(C.byref(dims))
-    hx0 = ws[lib.gi_ggnn_hx0_offset(C.byref(dims), S, E):]
-    graph = _ops.compact_fill(nodes, lay, gfix, S, E, Et, hx0, ldhx, dims.H)
+    hx0 = ws[lib.gi_ggnn_hx0_offset(C.byref(dims), S, E, U):]
+    graph = _ops.compact_fill(nodes, lay, gfix, S, E, U, Ut, hx0, ldhx, dims.H)
     apd = dims.N * dims.A + dims.N * dims.C + 1
     out = torch.empty((B, apd), dtype=torch.float32, device=dev)
-    Et_c = (C.c_int * len(Et))(*Et)
-    _L.check(lib.gi_ggnn_forward(C.byref(dims), _ptr_table(params), gfix.data_ptr(),
-                                 graph.gvar[0].data_ptr(), graph.gvar[2].data_ptr(), S, E, Et_c,
-                                 ws.data_ptr(), out.data_ptr(), apd,
-                                 torch.cuda.current_stream().cuda_stream), "gi_ggnn_forward")
-    return out, (dims, graph, ws, Et)
+    gs = graph.c_struct()
+    _L.check(lib.gi_ggnn_forward(C.byref(dims), _ptr_table(params), C.byref(gs), ws.data_ptr(),
+                                 out.data_ptr(), apd, torch.cuda.current_stream().cuda_stream),
+             "gi_ggnn_forward")
+    return out, (dims, graph, ws)
 
 
 _SIDE_STREAMS = {}
@@ -117,11 +116,11 @@ def ggnn_backward_raw(tape, out, d_out, params):
     per-parameter gradient views into ONE flat fp32 buffer (state_dict order, 16-byte aligned
     segments) — the bucket a data-parallel all-reduce operates on."""
     lib = _L.load()
-    dims, graph, ws, Et = tape
+    dims, graph, ws = tape
     d_out = d_out.contiguous().float()
     dev = out.device
-    Et_c = (C.c_int * len(Et))(*Et)
-    n_slab = lib.gi_ggnn_slab_floats(C.byref(dims), graph.S, graph.E, Et_c)
+    gs = graph.c_struct()
+    n_slab = lib.gi_ggnn_slab_floats(C.byref(dims), graph.S, graph.U, gs.Ut)
     if n_slab < 0:
         _L.check(int(n_slab), "gi_ggnn_slab_floats")
     slabs = torch.empty(max(int(n_slab), 4), dtype=torch.float32, device=dev)
@@ -133,12 +132,9 @@ def ggnn_backward_raw(tape, out, d_out, params):
     gflat = torch.empty(total, dtype=torch.float32, device=dev)
     grads = [gflat[o:o + n].view(p.shape) for o, n, p in zip(offs, sizes, params)]
     _L.check(lib.gi_ggnn_backward(
-        C.byref(dims), _ptr_table(params), graph.gfix.data_ptr(), graph.gvar[0].data_ptr(),
-        graph.gvar[1].data_ptr(), graph.gvar[2].data_ptr(), graph.gvar[3].data_ptr(), graph.S,
-        graph.E, Et_c,
-        ws.data_ptr(), slabs.data_ptr(), out.data_ptr(), out.stride(0), d_out.data_ptr(),
-        d_out.stride(0), _ptr_table(grads), torch.cuda.current_stream().cuda_stream,
-        _side_stream(dev)), "gi_ggnn_backward")
+        C.byref(dims), _ptr_table(params), C.byref(gs), ws.data_ptr(), slabs.data_ptr(),
+        out.data_ptr(), out.stride(0), d_out.data_ptr(), d_out.stride(0), _ptr_table(grads),
+        torch.cuda.current_stream().cuda_stream, _side_stream(dev)), "gi_ggnn_backward")
     return grads, gflat
 
 

@@ -25,6 +25,8 @@ GI_MAX_GROUPS = 8
 GI_MAX_NODES = 128
 EPI_BIAS, EPI_SELU, EPI_DSELU, EPI_ACCUM, GEMM_SPLITK = 1, 2, 4, 8, 16
 KIND_GGNN, KIND_ATTGGNN = 0, 1
+COUNTS = 24          # GI_COUNTS
+ABI_VERSION = 2      # GI_ABI_VERSION
 DTYPE_F32, DTYPE_I8 = 0, 1
 
 vp = C.c_void_p
@@ -54,6 +56,13 @@ class ReduceDesc(C.Structure):
                 ("n_slabs", ci), ("N", ci), ("K", ci), ("ld", ci)]
 
 
+class Graph(C.Structure):
+    """gi_graph: the compacted graph as the fused model calls take it."""
+    _fields_ = [("S", ci), ("E", ci), ("U", ci), ("gfix", vp), ("u_src", vp), ("in_perm", vp),
+                ("mu_off", vp), ("mu_dst", vp), ("mu_slot", vp), ("out_perm", vp),
+                ("Ut", C.POINTER(ci))]
+
+
 class GgnnDims(C.Structure):
     _fields_ = [(n, ci) for n in ("B", "N", "Fn", "Fe", "H", "M", "G", "A", "C", "passes",
                                   "enn_depth", "enn_hidden", "att_depth", "att_hidden",
@@ -67,12 +76,14 @@ SIGNATURES = {
     "gi_abi_version": (ci, []),
     "gi_compact_layout": (ci, [ci, ci, ci, C.POINTER(CompactLayout)]),
     "gi_compact_count": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp]),
-    "gi_compact_fill": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp]),
+    "gi_compact_fill": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci,
+                             ci, vp]),
     "gi_gemm": (ci, [C.POINTER(GemmParams), vp]),
     "gi_gemm_batch": (ci, [C.POINTER(GemmParams), ci, vp]),
     "gi_seg_sum": (ci, [vp, ci, vp, vp, ci, ci, vp, ci, ci, vp]),
     "gi_seg_softmax_fwd": (ci, [vp, vp, ci, vp, vp, ci, ci, vp, ci, vp]),
-    "gi_seg_softmax_bwd": (ci, [vp, vp, ci, vp, vp, ci, ci, vp, ci, vp]),
+    "gi_seg_softmax_bwd": (ci, [vp, vp, ci, vp, vp, ci, ci, vp, ci, vp, vp, ci, vp]),
+    "gi_seg_sum_dselu": (ci, [vp, ci, vp, vp, ci, ci, vp, ci, vp]),
     "gi_selu_bwd_rows": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, vp]),
     "gi_gru_gates_fwd": (ci, [vp, vp, ci, vp, vp, ci, vp, ci, ci, ci, vp]),
     "gi_gru_gates_bwd": (ci, [vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, vp]),
@@ -92,16 +103,15 @@ SIGNATURES = {
     "gi_side_stream_create": (ci, [C.POINTER(vp)]),
     "gi_side_stream_destroy": (ci, [vp]),
     "gi_ggnn_num_params": (ci, [C.POINTER(GgnnDims)]),
-    "gi_ggnn_workspace_floats": (cll, [C.POINTER(GgnnDims), ci, ci]),
+    "gi_ggnn_workspace_floats": (cll, [C.POINTER(GgnnDims), ci, ci, ci]),
     "gi_ggnn_slab_floats": (cll, [C.POINTER(GgnnDims), ci, ci, C.POINTER(ci)]),
-    "gi_ggnn_hx0_offset": (cll, [C.POINTER(GgnnDims), ci, ci]),
+    "gi_ggnn_hx0_offset": (cll, [C.POINTER(GgnnDims), ci, ci, ci]),
     "gi_ggnn_ldhx": (ci, [C.POINTER(GgnnDims)]),
-    "gi_ggnn_ws_query": (ci, [C.POINTER(GgnnDims), ci, ci, C.c_char_p, ci, ci,
+    "gi_ggnn_ws_query": (ci, [C.POINTER(GgnnDims), ci, ci, ci, C.c_char_p, ci, ci,
                               C.POINTER(cll), C.POINTER(ci)]),
-    "gi_ggnn_forward": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), vp, vp, vp, ci, ci,
-                             C.POINTER(ci), vp, vp, ci, vp]),
-    "gi_ggnn_backward": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), vp, vp, vp, vp, vp, ci, ci,
-                              C.POINTER(ci), vp, vp, vp, ci, vp, ci, C.POINTER(vp), vp, vp]),
+    "gi_ggnn_forward": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), C.POINTER(Graph), vp, vp, ci, vp]),
+    "gi_ggnn_backward": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), C.POINTER(Graph), vp, vp, vp, ci,
+                              vp, ci, C.POINTER(vp), vp, vp]),
 }
 
 _lib = None
@@ -133,7 +143,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)             # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.gi_abi_version() != 1:
+    if lib.gi_abi_version() != ABI_VERSION:
         raise RuntimeError("libgraphinvent_amd.so ABI version mismatch")
     _lib = lib
     return lib

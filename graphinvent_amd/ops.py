@@ -58,23 +58,35 @@ class CompactGraph:
     Fe: int
     S: int                      # active node slots (compact rows 0..S-1; row S = zero row)
     E: int                      # directed edges
-    Et: Sequence[int]           # edges per bond type
+    U: int                      # message rows = distinct (source slot, bond type) pairs
+    Ut: Sequence[int]           # message rows per bond type
     layout: L.CompactLayout
     gfix: torch.Tensor          # int32, fixed-size part (see include/graphinvent_amd.h)
-    gvar: torch.Tensor          # int32 [4, E4]: e_src, e_dst, in_perm, out_perm
+    gvar: torch.Tensor          # int32, variable-size part: u_src | in_perm | mu_off | mu_dst | mu_slot | out_perm
 
     def view(self, name: str, n: int) -> torch.Tensor:
         o = getattr(self.layout, name)
         return self.gfix[o:o + n]
 
+    def _var(self, k: int, n: int) -> torch.Tensor:
+        return self.gvar[self._offs[k]:self._offs[k] + n]
+
     @property
-    def e_src(self): return self.gvar[0, :self.E]
+    def _offs(self):
+        return _gvar_offsets(self.E, self.U)[0]
+
     @property
-    def e_dst(self): return self.gvar[1, :self.E]
+    def u_src(self): return self._var(0, self.U)
     @property
-    def in_perm(self): return self.gvar[2, :self.E]
+    def in_perm(self): return self._var(1, self.E)
     @property
-    def out_perm(self): return self.gvar[3, :self.E]
+    def mu_off(self): return self._var(2, self.U + 1)
+    @property
+    def mu_dst(self): return self._var(3, self.E)
+    @property
+    def mu_slot(self): return self._var(4, self.E)
+    @property
+    def out_perm(self): return self._var(5, self.U)
     @property
     def cidx(self): return self.view("cidx", self.B * self.N)
     @property
@@ -88,9 +100,31 @@ class CompactGraph:
     @property
     def type_off(self): return self.view("type_off", self.Fe + 1)
 
+    def c_struct(self) -> "L.Graph":
+        """gi_graph for the fused model calls (keeps the host Ut array alive on the struct)."""
+        g = L.Graph()
+        g.S, g.E, g.U = self.S, self.E, self.U
+        g.gfix = self.gfix.data_ptr()
+        base, offs = self.gvar.data_ptr(), self._offs
+        g.u_src, g.in_perm, g.mu_off, g.mu_dst, g.mu_slot, g.out_perm = (base + 4 * o for o in offs)
+        g._ut = (C.c_int * self.Fe)(*self.Ut)
+        g.Ut = g._ut
+        return g
+
+
+def _gvar_offsets(E: int, U: int):
+    """Offsets (ints, 16-byte aligned) of u_src[U], in_perm[E], mu_off[U+1], mu_dst[E], mu_slot[E],
+    out_perm[U] inside the variable-size index buffer, and its total length."""
+    sizes = (U, E, U + 1, E, E, U)
+    offs, o = [], 0
+    for n in sizes:
+        offs.append(o)
+        o += max(r4(n), 4)
+    return offs, o
+
 
 def compact_count(nodes: torch.Tensor, edges: torch.Tensor):
-    """Phase 1; returns (layout, gfix, S, E, Et).  One host read-back of 16 ints (the only
+    """Phase 1; returns (nodes, layout, gfix, S, E, U, Ut).  One host read-back of 24 ints (the only
     synchronisation point of a forward pass)."""
     lib = L.load()
     nodes, dt_n = _model_input(nodes, "nodes")
@@ -106,35 +140,35 @@ def compact_count(nodes: torch.Tensor, edges: torch.Tensor):
     gfix = torch.empty(lay.total_ints, dtype=torch.int32, device=nodes.device)
     L.check(lib.gi_compact_count(nodes.data_ptr(), edges.data_ptr(), dt_n, B, N, Fn, Fe,
                                  gfix.data_ptr(), _stream()), "gi_compact_count")
-    counts = gfix[lay.counts:lay.counts + 16].cpu().tolist()
-    S, E, err = counts[0], counts[1], counts[2]
+    counts = gfix[lay.counts:lay.counts + L.COUNTS].cpu().tolist()
+    S, E, err, U = counts[0], counts[1], counts[2], counts[3]
     if err:
         raise ValueError("edges tensor violates the preprocessed-HDF contract: every bonded pair "
                          "must carry exactly one one-hot bond type (DataProcesser.py / "
                          "MolecularGraph.py edge features)")
-    return nodes, lay, gfix, S, E, counts[4:4 + Fe]
+    return nodes, lay, gfix, S, E, U, counts[4:4 + Fe]
 
 
-def compact_fill(nodes, lay, gfix, S, E, Et, hx0: torch.Tensor, ldhx: int, H: int) -> CompactGraph:
+def compact_fill(nodes, lay, gfix, S, E, U, Ut, hx0: torch.Tensor, ldhx: int, H: int) -> CompactGraph:
     lib = L.load()
     B, N, Fn = nodes.shape
-    Fe = len(Et)
-    E4 = max(r4(E), 4)
-    gvar = torch.empty((4, E4), dtype=torch.int32, device=nodes.device)
+    Fe = len(Ut)
+    offs, total = _gvar_offsets(E, U)
+    gvar = torch.empty(total, dtype=torch.int32, device=nodes.device)
     dt = L.DTYPE_I8 if nodes.dtype == torch.int8 else L.DTYPE_F32
-    L.check(lib.gi_compact_fill(nodes.data_ptr(), dt, B, N, Fn, Fe, gfix.data_ptr(), S, E,
-                                gvar[0].data_ptr(), gvar[1].data_ptr(), gvar[2].data_ptr(),
-                                gvar[3].data_ptr(), hx0.data_ptr(), ldhx, H, _stream()),
+    base = gvar.data_ptr()
+    L.check(lib.gi_compact_fill(nodes.data_ptr(), dt, B, N, Fn, Fe, gfix.data_ptr(), S, E, U,
+                                *(base + 4 * o for o in offs), hx0.data_ptr(), ldhx, H, _stream()),
             "gi_compact_fill")
-    return CompactGraph(B, N, Fn, Fe, S, E, list(Et), lay, gfix, gvar)
+    return CompactGraph(B, N, Fn, Fe, S, E, U, list(Ut), lay, gfix, gvar)
 
 
 def compact(nodes: torch.Tensor, edges: torch.Tensor, H: int):
     """Both phases; returns (CompactGraph, hx0[S+1, ldhx])."""
-    nodes, lay, gfix, S, E, Et = compact_count(nodes, edges)
+    nodes, lay, gfix, S, E, U, Ut = compact_count(nodes, edges)
     ldhx = r4(H + nodes.shape[2])
     hx0 = torch.empty((S + 1, ldhx), dtype=torch.float32, device=nodes.device)
-    g = compact_fill(nodes, lay, gfix, S, E, Et, hx0, ldhx, H)
+    g = compact_fill(nodes, lay, gfix, S, E, U, Ut, hx0, ldhx, H)
     return g, hx0
 
 
@@ -187,9 +221,10 @@ def reduce_slabs(items):
     L.check(L.load().gi_reduce_slabs(arr, len(items), _stream()), "gi_reduce_slabs")
 
 
-def ws_view(ws: torch.Tensor, dims, S: int, E: int, name: str, rows: int, i: int = 0, j: int = 0):
+def ws_view(ws: torch.Tensor, dims, S: int, E: int, U: int, name: str, rows: int, i: int = 0,
+            j: int = 0):
     """Test/debug: a [rows, ld] view of a named workspace buffer (gi_ggnn_ws_query)."""
     off, ld = C.c_longlong(), C.c_int()
-    L.check(L.load().gi_ggnn_ws_query(C.byref(dims), S, E, name.encode(), i, j, C.byref(off),
+    L.check(L.load().gi_ggnn_ws_query(C.byref(dims), S, E, U, name.encode(), i, j, C.byref(off),
                                       C.byref(ld)), f"gi_ggnn_ws_query({name})")
     return ws[off.value:off.value + rows * ld.value].view(rows, ld.value)

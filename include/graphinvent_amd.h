@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GI_ABI_VERSION 1
+#define GI_ABI_VERSION 2
 #define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
 #define GI_MAX_NODES 128      /* max max_n_nodes */
 
@@ -42,13 +42,27 @@ int gi_abi_version(void);
  * (`edges.sum(3)`, two `nonzero`s, the [V,E] 0/1 summation matrix, `edges[eb,ei,ej,:]`, the
  * zero-padded `hidden_nodes`) and `node_mask` (:146).
  *
+ * MESSAGE ROWS.  The message an edge carries, MLP_type(e)(h_src(e)) (gnn/mpnn.py:284-294), depends
+ * only on (source node, bond type); it is computed once per distinct pair: U <= E rows (0.55-0.63 E
+ * on molecular graphs), bond-type-major, inside a type by source slot.
+ *
  * Layout of the fixed-size int32 index buffer `gfix` (offsets in ints, from gi_compact_layout):
- *   counts[16]   [0]=S active node slots, [1]=E directed edges, [2]=error flag (an edge whose
- *                feature vector is not one-hot), [4+t]=edges of bond type t
- *   type_off[GI_MAX_GROUPS+1], cidx[B*N] (slot -> compact row, S for inactive slots),
- *   node_mask[B*N] (1 if the slot has >=1 incoming edge), slot_of[B*N], seg_off[B*N+2] (CSR by
- *   destination over compact rows, row S empty), src_off[B*N+2] (CSR by source), then scratch.
+ *   counts[GI_COUNTS]  [0]=S active node slots, [1]=E directed edges, [2]=error flag (an edge whose
+ *                feature vector is not one-hot), [3]=U message rows, [4+t]=message rows of bond
+ *                type t, [12+t]=edges of bond type t
+ *   type_off[GI_MAX_GROUPS+1] (message rows per bond type, prefix), cidx[B*N] (slot -> compact row,
+ *   S for inactive slots), node_mask[B*N] (1 if the slot has >=1 incoming edge), slot_of[B*N],
+ *   seg_off[B*N+2] (dst-CSR over compact rows: row c's incoming edges are slots
+ *   [seg_off[c], seg_off[c+1]); row S empty), src_off[B*N+2] (source CSR over MESSAGE rows: row c
+ *   sends out_perm[src_off[c] .. src_off[c+1])), then scratch.
+ * Variable-size arrays (caller-allocated once S, E, U are known, written by gi_compact_fill):
+ *   u_src[U]    message row -> source compact row (the message MLP's gather index)
+ *   in_perm[E]  dst-CSR slot -> message row (edges in the reference's order: row-major nonzero)
+ *   mu_off[U+1], mu_dst[E], mu_slot[E]   message row -> its edges: destination compact row and
+ *               dst-CSR slot of each, ascending destination (backward of the aggregation)
+ *   out_perm[U] message rows grouped by source compact row, inside a row by bond type
  * ------------------------------------------------------------------------------------------ */
+#define GI_COUNTS 24
 typedef struct gi_compact_layout_t {
     int total_ints;
     int counts, type_off, cidx, node_mask, slot_of, seg_off, src_off, scratch;
@@ -59,12 +73,21 @@ int gi_compact_layout(int B, int N, int Fe, gi_compact_layout_t* out);
 /* phase 1: per-graph counting + global scans; fills everything in gfix. */
 int gi_compact_count(const void* nodes, const void* edges, int in_dtype, int B, int N, int Fn,
                      int Fe, int* gfix, void* stream);
-/* phase 2 (after the host has read S and E from counts): edge arrays in bond-type-major order,
- * the two CSR permutations, and the initial node rows hx0[S+1, ldhx] = [x | 0.. | x] with the
- * input features in columns [0,Fn) and again in [H, H+Fn) (row S = 0). */
+/* phase 2 (after the host has read S, E, U from counts): the variable-size index arrays and the
+ * initial node rows hx0[S+1, ldhx] = [x | 0.. | x] with the input features in columns [0,Fn) and
+ * again in [H, H+Fn) (row S = 0). */
 int gi_compact_fill(const void* nodes, int in_dtype, int B, int N, int Fn, int Fe, const int* gfix,
-                    int S, int E, int* e_src, int* e_dst, int* in_perm, int* out_perm,
-                    float* hx0, int ldhx, int H, void* stream);
+                    int S, int E, int U, int* u_src, int* in_perm, int* mu_off, int* mu_dst,
+                    int* mu_slot, int* out_perm, float* hx0, int ldhx, int H, void* stream);
+
+/* The compacted graph as the fused model calls take it. */
+typedef struct gi_graph {
+    int S, E, U;
+    const int* gfix;
+    const int* u_src; const int* in_perm; const int* mu_off; const int* mu_dst; const int* mu_slot;
+    const int* out_perm;
+    const int* Ut;            /* HOST array [Fe]: message rows per bond type (counts[4..4+Fe)) */
+} gi_graph;
 
 /* ------------------------------------------------------------------------------------------
  * Dense GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32) with fused prologue/epilogue.  One kernel
@@ -112,18 +135,26 @@ int gi_gemm_batch(const gi_gemm_params* problems, int n, void* stream);
 int gi_seg_sum(const float* vals, int ldv, const int* perm, const int* off, int rows, int cols,
                float* out, int ldo, int accumulate, void* stream);
 
+/* Backward of the aggregation onto MESSAGE rows, fused with the SELU backward of the message MLP's
+ * last layer, in place:  y[u, c] = selu'(y[u, c]) * sum_{k in [off[u], off[u+1])} vals[perm[k], c] */
+int gi_seg_sum_dselu(const float* vals, int ldv, const int* perm, const int* off, int rows, int cols,
+                     float* y, int ldy, void* stream);
+
 /* Attention aggregation of AttentionGGNN — replaces `aggregate_message` (gnn/mpnn.py:370-389:
  * mask, Softmax(dim=1) over the padded neighbour axis, weighted sum) on the destination CSR:
  *   att[k, f] = softmax over k in [off[c], off[c+1]) of en[perm[k], f];
  *   out[c, f] = sum_k att[k, f] * emb[perm[k], f]        (0 for an empty segment),  c < rows.
- * en / emb: [E, ld] post-SELU outputs of the per-bond-type energy / message MLPs. */
+ * en / emb: [U, ld] post-SELU outputs of the per-bond-type energy / message MLPs on message rows;
+ * perm = in_perm (dst-CSR slot -> message row). */
 int gi_seg_softmax_fwd(const float* en, const float* emb, int ld, const int* perm, const int* off,
                        int rows, int cols, float* out, int ldo, void* stream);
-/* Its backward fused with the SELU backward of both producers, IN PLACE: on return
- *   en  = d loss / d (pre-activation of the energy MLP's last layer),
- *   emb = d loss / d (pre-activation of the message MLP's last layer),  given dagg = d loss / d out. */
-int gi_seg_softmax_bwd(float* en, float* emb, int ld, const int* perm, const int* off, int rows,
-                       int cols, const float* dagg, int ldd, void* stream);
+/* Its backward, per edge: with dagg = d loss / d out,
+ *   d_emb_e[k, f] = att[k, f] * dagg[c, f],   d_en_e[k, f] = att[k, f] * (emb[perm[k], f] * dagg[c, f] - <att, emb*dagg>_c)
+ * written in dst-CSR slot order [E, lde] (the softmax is recomputed from en).  The message-row
+ * gradients are gi_seg_sum_dselu of these over the message CSR (perm = mu_slot, off = mu_off). */
+int gi_seg_softmax_bwd(const float* en, const float* emb, int ld, const int* perm, const int* off,
+                       int rows, int cols, const float* dagg, int ldd, float* d_en_e,
+                       float* d_emb_e, int lde, void* stream);
 
 /* out[r, c] = dY[idx ? idx[r] : r, c] * selu'(Y[r, c])  (may run in place on Y) */
 int gi_selu_bwd_rows(const float* dY, int lddy, const int* idx, const float* Y, int ldy,
@@ -221,31 +252,28 @@ int gi_side_stream_create(void** stream);
 int gi_side_stream_destroy(void* stream);
 
 int gi_ggnn_num_params(const gi_ggnn_dims* d);
-long long gi_ggnn_workspace_floats(const gi_ggnn_dims* d, int S, int E);
-long long gi_ggnn_slab_floats(const gi_ggnn_dims* d, int S, int E, const int* Et);
+/* S active slots, E directed edges, U message rows (counts[0], [1], [3]) */
+long long gi_ggnn_workspace_floats(const gi_ggnn_dims* d, int S, int E, int U);
+long long gi_ggnn_slab_floats(const gi_ggnn_dims* d, int S, int U, const int* Ut);
 /* ws must hold hx0 (from gi_compact_fill) at offset gi_ggnn_hx0_offset(); forward keeps every
  * activation in ws for backward. */
-long long gi_ggnn_hx0_offset(const gi_ggnn_dims* d, int S, int E);
+long long gi_ggnn_hx0_offset(const gi_ggnn_dims* d, int S, int E, int U);
 int gi_ggnn_ldhx(const gi_ggnn_dims* d);
 /* test/debug hook: offset (floats) and leading dimension of a named workspace buffer
  * ("hx" i=pass, "eact" i=pass j=layer, "m","agg","gi","gh" i=pass, "att_act" j=layer, "en", ...) */
-int gi_ggnn_ws_query(const gi_ggnn_dims* d, int S, int E, const char* name, int i, int j,
+int gi_ggnn_ws_query(const gi_ggnn_dims* d, int S, int E, int U, const char* name, int i, int j,
                      long long* off, int* ld);
-int gi_ggnn_forward(const gi_ggnn_dims* d, const float* const* params, const int* gfix,
-                    const int* e_src, const int* in_perm, int S, int E, const int* Et,
+int gi_ggnn_forward(const gi_ggnn_dims* d, const float* const* params, const gi_graph* g,
                     float* ws, float* out, int ldout, void* stream);
 /* consumes (overwrites) the activations in ws; y_out = the logits forward returned; grads[i]
  * receives the gradient of params[i]; slabs = gi_ggnn_slab_floats() floats of scratch.
- * Et = HOST array of per-bond-type edge counts (counts[4..4+Fe) read back by the caller).
  * side_stream (may be NULL): a second hipStream_t of the same device.  When given, the weight-
  * gradient GEMMs run there, ordered after their operands by events, concurrently with the dZ chain
  * on `stream`; `stream` waits for them before the final slab reduction, so on return every piece of
  * work is ordered before whatever the caller enqueues next on `stream`. */
-int gi_ggnn_backward(const gi_ggnn_dims* d, const float* const* params, const int* gfix,
-                     const int* e_src, const int* e_dst, const int* in_perm, const int* out_perm,
-                     int S, int E, const int* Et, float* ws, float* slabs, const float* y_out, int ldout,
-                     const float* d_out, int lddout, float* const* grads, void* stream,
-                     void* side_stream);
+int gi_ggnn_backward(const gi_ggnn_dims* d, const float* const* params, const gi_graph* g,
+                     float* ws, float* slabs, const float* y_out, int ldout, const float* d_out,
+                     int lddout, float* const* grads, void* stream, void* side_stream);
 
 #ifdef __cplusplus
 }

@@ -30,9 +30,17 @@ def compact(nodes: np.ndarray, edges: np.ndarray) -> Dict[str, np.ndarray]:
     Compact rows 0..S-1 are the *active* slots in ascending slot order (a slot is active when its
     feature row is non-zero, or it has an incoming edge, or it is some edge's neighbour); row S is
     the shared zero row standing for every inactive slot (hidden state identically 0 forever).
-    Edges are enumerated in the reference's order (row-major nonzero of the adjacency,
-    gnn/summation_mpnn.py:103-105 — i.e. sorted by destination slot) and stored bucketed by bond
-    type ("type-major"), which is the row order of every per-edge activation buffer."""
+
+    Message rows: the message an edge carries, MLP_type(e)(h_src(e)) (gnn/mpnn.py:284-294), depends
+    only on (source node, bond type), so it is computed once per distinct pair — U <= E rows (0.55-0.63 E
+    on molecular graphs), ordered bond-type-major, inside a type by source slot.  Edges are
+    enumerated in the reference's order (row-major nonzero of the adjacency,
+    gnn/summation_mpnn.py:103-105 = sorted by destination slot, "dst-CSR").  Index arrays:
+      in_perm [E]  dst-CSR slot k -> message row          seg_off [R+1] dst-CSR offsets per compact row
+      u_src   [U]  message row -> source compact row      type_off [Fe+1] message rows per bond type
+      mu_off  [U+1], mu_dst [E], mu_slot [E]   message row -> its edges: destination compact row and
+                                               dst-CSR slot of each (ascending destination)
+      out_perm [U], src_off [R+1]              source compact row -> its message rows (by type)"""
     B, N, Fn = nodes.shape
     Fe = edges.shape[3]
     adj = edges.sum(3) != 0
@@ -44,6 +52,7 @@ def compact(nodes: np.ndarray, edges: np.ndarray) -> Dict[str, np.ndarray]:
     colcnt = adj.sum(1).reshape(-1)                                      # outgoing per src slot
     active = (nodes != 0).any(2).reshape(-1) | (rowcnt > 0) | (colcnt > 0)
     S = int(active.sum())
+    R = S + 1
     cidx = np.full(B * N, S, dtype=np.int32)
     cidx[active] = np.arange(S, dtype=np.int32)
     slot_of = np.nonzero(active)[0].astype(np.int32)
@@ -51,32 +60,30 @@ def compact(nodes: np.ndarray, edges: np.ndarray) -> Dict[str, np.ndarray]:
     E = eb.size
     et = etype[eb, ei, ej].astype(np.int64)
     dst_c = cidx[eb * N + ei]
-    src_c = cidx[eb * N + ej]
-    type_cnt = np.bincount(et, minlength=Fe).astype(np.int32)
+    src_slot = eb * N + ej
+    key = et * (B * N) + src_slot
+    ukeys, in_perm = np.unique(key, return_inverse=True)                 # type-major, then slot
+    U = ukeys.size
+    u_type = ukeys // (B * N)
+    u_src = cidx[ukeys % (B * N)].astype(np.int32)
+    type_cnt = np.bincount(u_type, minlength=Fe).astype(np.int32)
     type_off = np.concatenate([[0], np.cumsum(type_cnt)]).astype(np.int32)
-    # position of every dst-major edge in the type-major arrays
-    pos = np.empty(E, dtype=np.int32)
-    for t in range(Fe):
-        sel = np.nonzero(et == t)[0]
-        pos[sel] = type_off[t] + np.arange(sel.size, dtype=np.int32)
-    e_src = np.empty(E, dtype=np.int32)
-    e_dst = np.empty(E, dtype=np.int32)
-    e_src[pos] = src_c
-    e_dst[pos] = dst_c
-    in_perm = pos.copy()                                                 # dst-major k -> row
-    seg_off = np.zeros(S + 2, dtype=np.int32)
+    seg_off = np.zeros(R + 1, dtype=np.int64)
     np.add.at(seg_off, dst_c + 1, 1)
-    seg_off = np.cumsum(seg_off).astype(np.int32)                        # [S+2], row S empty
-    # out-CSR: edges grouped by source node, inside a group ordered by dst-major order
-    order = np.argsort(src_c, kind="stable")
-    out_perm = pos[order].astype(np.int32)
-    src_off = np.zeros(S + 2, dtype=np.int32)
-    np.add.at(src_off, src_c + 1, 1)
+    seg_off = np.cumsum(seg_off).astype(np.int32)                        # [R+1], row S empty
+    order = np.argsort(in_perm, kind="stable")                           # edges grouped by message row
+    mu_slot = order.astype(np.int32)
+    mu_dst = dst_c[order].astype(np.int32)
+    mu_off = np.concatenate([[0], np.cumsum(np.bincount(in_perm, minlength=U))]).astype(np.int32)
+    out_perm = np.argsort(u_src, kind="stable").astype(np.int32)         # by source row, then type
+    src_off = np.zeros(R + 1, dtype=np.int64)
+    np.add.at(src_off, u_src + 1, 1)
     src_off = np.cumsum(src_off).astype(np.int32)
     node_mask = (rowcnt > 0).astype(np.uint8)
-    return dict(S=S, E=E, err=err, cidx=cidx, slot_of=slot_of, e_src=e_src, e_dst=e_dst,
-                in_perm=in_perm, seg_off=seg_off, out_perm=out_perm, src_off=src_off,
-                type_off=type_off, node_mask=node_mask)
+    return dict(S=S, E=E, U=U, err=err, cidx=cidx, slot_of=slot_of, u_src=u_src,
+                in_perm=in_perm.astype(np.int32), seg_off=seg_off, mu_off=mu_off, mu_dst=mu_dst,
+                mu_slot=mu_slot, out_perm=out_perm, src_off=src_off, type_off=type_off,
+                node_mask=node_mask)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -121,27 +128,35 @@ def seg_sum(vals, perm, off, rows):
 def seg_softmax_sum(en, emb, perm, off, rows):
     """Attention aggregation of AttGGNN (gnn/mpnn.py:370-389) on the dst-CSR: per destination row c
     and per feature, softmax of en over the segment's edges, weighted sum of emb.  Empty segments
-    give 0.  Returns (agg [rows, M], att [E, M] in edge-row order)."""
-    E, M = en.shape
+    give 0.  en / emb are message rows [U, M]; perm maps dst-CSR slot -> message row.
+    Returns (agg [rows, M], att [E, M] in dst-CSR slot order)."""
+    M = en.shape[1]
+    E = perm.numel()
     agg = torch.zeros(rows, M, dtype=en.dtype)
-    att = torch.zeros_like(en)
+    att = torch.zeros(E, M, dtype=en.dtype)
     for c in range(rows):
         lo, hi = int(off[c]), int(off[c + 1])
         if hi > lo:
             r = perm[lo:hi].long()
             a = torch.softmax(en[r], dim=0)
-            att[r] = a
+            att[lo:hi] = a
             agg[c] = (a * emb[r]).sum(0)
     return agg, att
 
 
-def seg_softmax_sum_bwd(dagg, att, emb, e_dst):
-    """(d en, d emb) per edge row for agg = sum_k att_k emb_k, att = softmax_k(en)."""
-    d = dagg[e_dst.long()]
+def seg_softmax_sum_bwd(dagg, att, en, emb, perm, off, rows):
+    """Per-edge (d en, d emb) contributions in dst-CSR slot order [E, M] for
+    agg = sum_k att_k emb_k, att = softmax_k(en): the message-row gradients are their sums over
+    each row's edges (seg_sum over the message CSR)."""
+    E = perm.numel()
+    dst = torch.repeat_interleave(torch.arange(rows), (off[1:rows + 1] - off[:rows]).long())
+    d = dagg[dst]
+    e_rows = emb[perm.long()]
     demb = att * d
-    datt = emb * d
-    inner = torch.zeros_like(dagg).index_add_(0, e_dst.long(), att * datt)
-    den = att * (datt - inner[e_dst.long()])
+    datt = e_rows * d
+    inner = torch.zeros_like(dagg).index_add_(0, dst, att * datt)
+    den = att * (datt - inner[dst])
+    assert den.shape[0] == E
     return den, demb
 
 
@@ -234,7 +249,7 @@ def forward(P, cfg, nodes, edges, keep=False, model="GGNN"):
     Fe, A, C = cfg["n_edge_features"], cfg["len_f_add_per_node"], cfg["len_f_conn_per_node"]
     g = compact(nodes.numpy(), edges.numpy())
     assert g["err"] == 0
-    S, E = g["S"], g["E"]
+    S, E, U = g["S"], g["E"], g["U"]
     T = {k: torch.from_numpy(v) for k, v in g.items() if isinstance(v, np.ndarray)}
     R = S + 1
     x = torch.zeros(R, Fn, dtype=dtype)
@@ -245,19 +260,19 @@ def forward(P, cfg, nodes, edges, keep=False, model="GGNN"):
     tape = dict(g=g, T=T, x=x, has_edge=has_edge, passes=[])
     for _ in range(cfg["message_passes"]):
         acts_t = []
-        m = torch.zeros(E, M, dtype=dtype)
+        m = torch.zeros(U, M, dtype=dtype)           # one row per (source node, bond type)
         for t in range(Fe):
             lo, hi = int(g["type_off"][t]), int(g["type_off"][t + 1])
-            a = mlp_fwd(P, f"msg_nns.{t}", h, idx=T["e_src"][lo:hi].long())
+            a = mlp_fwd(P, f"msg_nns.{t}", h, idx=T["u_src"][lo:hi].long())
             acts_t.append(a)
             m[lo:hi] = a[-1]
         ps_extra = {}
         if attn:      # second per-bond-type MLP gives the attention energies
             aacts_t = []
-            en_e = torch.zeros(E, M, dtype=dtype)
+            en_e = torch.zeros(U, M, dtype=dtype)
             for t in range(Fe):
                 lo, hi = int(g["type_off"][t]), int(g["type_off"][t + 1])
-                a = mlp_fwd(P, f"att_nns.{t}", h, idx=T["e_src"][lo:hi].long())
+                a = mlp_fwd(P, f"att_nns.{t}", h, idx=T["u_src"][lo:hi].long())
                 aacts_t.append(a)
                 en_e[lo:hi] = a[-1]
             agg, att_e = seg_softmax_sum(en_e, m, T["in_perm"], T["seg_off"], R)
@@ -332,23 +347,26 @@ def backward(P, cfg, tape, d_out) -> Dict[str, torch.Tensor]:
         grads["gru.bias_hh"] = grads.get("gru.bias_hh", 0) + dgh.sum(0)
         dagg = dgi @ P["gru.weight_ih"]
         dh_prev = dh_prev + dgh @ P["gru.weight_hh"]
-        dxe = torch.zeros(g["E"], H, dtype=d_out.dtype)
+        dxe = torch.zeros(g["U"], H, dtype=d_out.dtype)
+        U = g["U"]
         if tape["attn"]:
-            den, demb = seg_softmax_sum_bwd(dagg, ps["att_e"], ps["m"], T["e_dst"])
-            dm = demb * selu_grad_from_out(ps["m"])
-            da = den * selu_grad_from_out(ps["en_e"])
+            den, demb = seg_softmax_sum_bwd(dagg, ps["att_e"], ps["en_e"], ps["m"], T["in_perm"],
+                                            T["seg_off"], R)
+            # message-row gradients: sum of the row's per-edge contributions, then SELU backward
+            dm = seg_sum(demb, T["mu_slot"], T["mu_off"], U) * selu_grad_from_out(ps["m"])
+            da = seg_sum(den, T["mu_slot"], T["mu_off"], U) * selu_grad_from_out(ps["en_e"])
             for t in range(Fe):
                 lo, hi = int(g["type_off"][t]), int(g["type_off"][t + 1])
                 d = mlp_bwd(P, f"att_nns.{t}", ps["h_prev"], ps["aacts_t"][t], da[lo:hi], grads,
-                            idx=T["e_src"][lo:hi].long(), need_dx=pi > 0)
+                            idx=T["u_src"][lo:hi].long(), need_dx=pi > 0)
                 if d is not None:
                     dxe[lo:hi] = d
         else:
-            dm = dagg[T["e_dst"].long()] * selu_grad_from_out(ps["m"])
+            dm = seg_sum(dagg, T["mu_dst"], T["mu_off"], U) * selu_grad_from_out(ps["m"])
         for t in range(Fe):
             lo, hi = int(g["type_off"][t]), int(g["type_off"][t + 1])
             d = mlp_bwd(P, f"msg_nns.{t}", ps["h_prev"], ps["acts_t"][t], dm[lo:hi], grads,
-                        idx=T["e_src"][lo:hi].long(), need_dx=pi > 0)
+                        idx=T["u_src"][lo:hi].long(), need_dx=pi > 0)
             if d is not None:
                 dxe[lo:hi] = dxe[lo:hi] + d
         if pi > 0:

@@ -62,36 +62,45 @@ def hip_forward_backward(model, n8, e8, a8):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M", [100, 20, 7])
 def test_seg_softmax_kernels(M):
-    """gi_seg_softmax_fwd / _bwd against the CPU dataflow model on a real dst-CSR (ragged segments,
-    empty segments, the zero row)."""
+    """gi_seg_softmax_fwd / _bwd (+ gi_seg_sum_dselu over the message CSR) against the CPU dataflow
+    model on a real graph batch (ragged segments, empty segments, the zero row, message rows read
+    by several destinations)."""
     lib = L.load()
     n8, e8, _ = synthetic.make_batch(37, **synthetic.SHAPES["gdb13"], seed=5)
     g = D.compact(n8, e8)
-    S, E = g["S"], g["E"]
+    S, E, U = g["S"], g["E"], g["U"]
     R = S + 1
     ld = (M + 3) & ~3
     gen = torch.Generator().manual_seed(M)
-    en = torch.randn(E, ld, generator=gen) * 2
-    emb = torch.randn(E, ld, generator=gen)
+    en = D.selu(torch.randn(U, ld, generator=gen) * 2)         # post-SELU message-row outputs
+    emb = D.selu(torch.randn(U, ld, generator=gen))
     dagg = torch.randn(R, ld, generator=gen)
-    T = {k: torch.from_numpy(g[k]) for k in ("in_perm", "seg_off", "e_dst")}
+    T = {k: torch.from_numpy(g[k]) for k in ("in_perm", "seg_off", "mu_slot", "mu_off")}
     agg_ref, att = D.seg_softmax_sum(en[:, :M].double(), emb[:, :M].double(), T["in_perm"],
                                      T["seg_off"], R)
-    den_ref, demb_ref = D.seg_softmax_sum_bwd(dagg[:, :M].double(), att, emb[:, :M].double(), T["e_dst"])
-    den_ref = den_ref * D.selu_grad_from_out(en[:, :M].double())
-    demb_ref = demb_ref * D.selu_grad_from_out(emb[:, :M].double())
+    den_e, demb_e = D.seg_softmax_sum_bwd(dagg[:, :M].double(), att, en[:, :M].double(),
+                                          emb[:, :M].double(), T["in_perm"], T["seg_off"], R)
+    den_ref = D.seg_sum(den_e, T["mu_slot"], T["mu_off"], U) * D.selu_grad_from_out(en[:, :M].double())
+    demb_ref = D.seg_sum(demb_e, T["mu_slot"], T["mu_off"], U) * D.selu_grad_from_out(emb[:, :M].double())
     en_d, emb_d, dagg_d = en.to(DEV), emb.to(DEV), dagg.to(DEV)
     perm_d, off_d = T["in_perm"].to(DEV), T["seg_off"].to(DEV)
+    slot_d, moff_d = T["mu_slot"].to(DEV), T["mu_off"].to(DEV)
     out = torch.full((R, ld), float("nan"), device=DEV)
     st = torch.cuda.current_stream().cuda_stream
     L.check(lib.gi_seg_softmax_fwd(en_d.data_ptr(), emb_d.data_ptr(), ld, perm_d.data_ptr(),
                                    off_d.data_ptr(), R, M, out.data_ptr(), ld, st), "fwd")
     assert rel(out[:, :M], agg_ref) < 1e-6
     assert float(out[S, :M].abs().max()) == 0.0                 # zero row: empty segment
+    t_en = torch.empty(E, ld, device=DEV)
+    t_emb = torch.empty(E, ld, device=DEV)
     L.check(lib.gi_seg_softmax_bwd(en_d.data_ptr(), emb_d.data_ptr(), ld, perm_d.data_ptr(),
-                                   off_d.data_ptr(), R, M, dagg_d.data_ptr(), ld, st), "bwd")
-    assert rel(en_d[:, :M], den_ref) < 2e-6
-    assert rel(emb_d[:, :M], demb_ref) < 2e-6
+                                   off_d.data_ptr(), R, M, dagg_d.data_ptr(), ld, t_en.data_ptr(),
+                                   t_emb.data_ptr(), ld, st), "bwd")
+    assert rel(t_en[:, :M], den_e) < 2e-6 and rel(t_emb[:, :M], demb_e) < 2e-6
+    for tmp, buf, want in ((t_en, en_d, den_ref), (t_emb, emb_d, demb_ref)):
+        L.check(lib.gi_seg_sum_dselu(tmp.data_ptr(), ld, slot_d.data_ptr(), moff_d.data_ptr(), U, M,
+                                     buf.data_ptr(), ld, st), "dselu")
+        assert rel(buf[:, :M], want) < 2e-6
     # bad arguments are rejected, not launched
     assert lib.gi_seg_softmax_fwd(en_d.data_ptr(), emb_d.data_ptr(), ld - 1, perm_d.data_ptr(),
                                   off_d.data_ptr(), R, M, out.data_ptr(), ld, st) == -1
@@ -148,8 +157,8 @@ def test_full_dims_logits_and_branch_pinned_gradients(shape, B, over):
     params = list(model.parameters())
     nodes, edges, tgt = to_dev(n8, e8, a8)
     out, tape_hip = mpnn.ggnn_forward_raw(model.constants, nodes, edges, params, L.KIND_ATTGGNN)
-    dims, graph, ws, Et = tape_hip
-    S, E, B = graph.S, graph.E, n8.shape[0]
+    dims, graph, ws = tape_hip
+    S, E, U, B = graph.S, graph.E, graph.U, n8.shape[0]
     R = S + 1
     t32 = lambda x: torch.from_numpy(x).float()
     o32 = O.attggnn_forward(P, cfg, t32(n8), t32(e8))
@@ -157,7 +166,7 @@ def test_full_dims_logits_and_branch_pinned_gradients(shape, B, over):
     l_hip, l32 = float(O.kl_loss(out, tgt)), float(O.kl_loss(o32, t32(a8)))
     assert abs(l_hip - l32) < TOL * abs(l32)
 
-    view = lambda name, rows, i=0, j=0: ops.ws_view(ws, dims, S, E, name, rows, i, j).cpu()
+    view = lambda name, rows, i=0, j=0: ops.ws_view(ws, dims, S, E, U, name, rows, i, j).cpu()
     P64 = {k: v.double() for k, v in P.items()}
     t64 = lambda x: torch.from_numpy(x).double()
     out64, tape = D.forward(P64, cfg, t64(n8), t64(e8), keep=True, model=MODEL)
@@ -168,12 +177,12 @@ def test_full_dims_logits_and_branch_pinned_gradients(shape, B, over):
         assert rel(view("agg", R, p)[:, :dims.M], ps["agg"]) < TOL, f"agg[{p}]"
         for key, name, depth in (("acts_t", "eact", dims.enn_depth), ("aacts_t", "aact", dims.eatt_depth)):
             for l in range(depth):
-                hv = view(name, E, p, l)
+                hv = view(name, U, p, l)
                 for t in range(dims.Fe):
                     a = ps[key][t][l]
                     pins[id(a)] = hv[toff[t]:toff[t + 1], :a.shape[1]] > 0
-        pins[id(ps["m"])] = view("m", E, p)[:, :dims.M] > 0
-        pins[id(ps["en_e"])] = view("een", E, p)[:, :dims.M] > 0
+        pins[id(ps["m"])] = view("m", U, p)[:, :dims.M] > 0
+        pins[id(ps["en_e"])] = view("een", U, p)[:, :dims.M] > 0
     for key, act_name, out_name, depth in (("att_acts", "att_act", "en", dims.att_depth),
                                            ("emb_acts", "emb_act", "emb", dims.emb_depth),
                                            ("add1", "add1_act", "add1", dims.mlp1_depth),

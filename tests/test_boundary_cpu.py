@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.gi_abi_version() == 1
+    assert lib.gi_abi_version() == L.ABI_VERSION == 2
 
 
 def test_host_side_planning_functions():
@@ -35,18 +35,19 @@ def test_host_side_planning_functions():
     lay = L.CompactLayout()
     assert lib.gi_compact_layout(1000, 13, 3, C.byref(lay)) == 0 and lay.total_ints > 13000 * 8
     assert lib.gi_compact_layout(4, 200, 3, C.byref(lay)) == -2          # N > GI_MAX_NODES
-    ws = lib.gi_ggnn_workspace_floats(C.byref(d), 6900, 12600)
-    ws0 = lib.gi_ggnn_workspace_floats(C.byref(d), 0, 0)
+    ws = lib.gi_ggnn_workspace_floats(C.byref(d), 6900, 12600, 8000)
+    ws0 = lib.gi_ggnn_workspace_floats(C.byref(d), 0, 0, 0)
     assert ws > ws0 > 0 and ws % 4 == 0
-    Et = (C.c_int * 3)(10000, 2500, 100)
-    assert lib.gi_ggnn_slab_floats(C.byref(d), 6900, 12600, Et) > 0
+    assert lib.gi_ggnn_workspace_floats(C.byref(d), 6900, 12600, 12601) == -1   # U > E
+    Ut = (C.c_int * 3)(6000, 1900, 100)
+    assert lib.gi_ggnn_slab_floats(C.byref(d), 6900, 8000, Ut) > 0
     da = mpnn._dims_from_constants(O.as_constants(O.make_config()), 1000, L.KIND_ATTGGNN)
     assert lib.gi_ggnn_num_params(C.byref(da)) == 134                     # + 3 energy MLPs x 10
-    assert lib.gi_ggnn_workspace_floats(C.byref(da), 6900, 12600) > ws
+    assert lib.gi_ggnn_workspace_floats(C.byref(da), 6900, 12600, 8000) > ws
     da.kind = 7
     assert lib.gi_ggnn_num_params(C.byref(da)) == -1                      # unknown model kind
     d.Fn = d.H + 1
-    assert lib.gi_ggnn_workspace_floats(C.byref(d), 1, 1) == -1          # GI_EINVAL
+    assert lib.gi_ggnn_workspace_floats(C.byref(d), 1, 1, 1) == -1       # GI_EINVAL
 
 
 def test_state_dict_is_the_reference_wire_format():

@@ -69,19 +69,37 @@ def test_attggnn_gdb13_shape_small_hidden_fp64():
 
 def test_compact_invariants(golden_dir):
     d = np.load(os.path.join(golden_dir, "gdb13_1K-debug_valid.npz"))
-    g = D.compact(d["nodes"], d["edges"])
-    S, E = g["S"], g["E"]
-    assert g["err"] == 0 and E == int((d["edges"].sum(3) != 0).sum())
-    assert S == int(((d["nodes"] != 0).any(2)).sum())            # well-formed data: active == occupied
-    assert sorted(g["in_perm"].tolist()) == list(range(E)) == sorted(g["out_perm"].tolist())
-    assert g["seg_off"][S] == E == g["seg_off"][S + 1] == g["src_off"][S + 1]
-    assert np.all(np.diff(g["seg_off"]) >= 0) and g["type_off"][-1] == E
-    # every edge sits in the bucket of its type, and each dst segment lists exactly its edges
+    nodes, edges = d["nodes"], d["edges"]
+    g = D.compact(nodes, edges)
+    S, E, U = g["S"], g["E"], g["U"]
+    B, N = nodes.shape[:2]
+    assert g["err"] == 0 and E == int((edges.sum(3) != 0).sum())
+    assert S == int(((nodes != 0).any(2)).sum())            # well-formed data: active == occupied
+    # message rows = distinct (source slot, bond type) pairs, bond-type-major
+    pairs = {(b, j, int(edges[b, i, j].argmax())) for b, i, j in zip(*np.nonzero(edges.sum(3)))}
+    assert U == len(pairs) <= E and g["type_off"][-1] == U
+    assert sorted(g["out_perm"].tolist()) == list(range(U))
+    assert sorted(g["mu_slot"].tolist()) == list(range(E))
+    assert g["seg_off"][S] == E == g["seg_off"][S + 1] and g["src_off"][S + 1] == U == g["src_off"][S]
+    assert g["mu_off"][0] == 0 and g["mu_off"][U] == E and np.all(np.diff(g["mu_off"]) >= 1)
+    assert np.all(np.diff(g["seg_off"]) >= 0)
+    # dst-CSR: slot k of destination c carries the message row of (its k-th neighbour, bond type)
+    eb, ei, ej = np.nonzero(edges.sum(3))
+    et = edges[eb, ei, ej].argmax(1)
+    for k in range(E):
+        u = g["in_perm"][k]
+        t = int(np.searchsorted(g["type_off"], u, side="right") - 1)
+        assert t == et[k] and g["u_src"][u] == g["cidx"][eb[k] * N + ej[k]]
+        assert g["seg_off"][g["cidx"][eb[k] * N + ei[k]]] <= k < g["seg_off"][g["cidx"][eb[k] * N + ei[k]] + 1]
+    # message CSR: row u lists exactly the dst-CSR slots that read it, with their destinations
+    for u in range(U):
+        slots = g["mu_slot"][g["mu_off"][u]:g["mu_off"][u + 1]]
+        assert np.all(g["in_perm"][slots] == u) and np.all(np.diff(slots) > 0)
+        assert np.all(g["mu_dst"][g["mu_off"][u]:g["mu_off"][u + 1]] == g["cidx"][eb[slots] * N + ei[slots]])
+    # source CSR over message rows
     for c in range(S):
-        rows = g["in_perm"][g["seg_off"][c]:g["seg_off"][c + 1]]
-        assert np.all(g["e_dst"][rows] == c)
         rows = g["out_perm"][g["src_off"][c]:g["src_off"][c + 1]]
-        assert np.all(g["e_src"][rows] == c)
-    bad = d["edges"][:4].copy()
+        assert np.all(g["u_src"][rows] == c) and np.all(np.diff(rows) > 0)
+    bad = edges[:4].copy()
     bad[0, 0, 1, :] = [1, 1, 0]
-    assert D.compact(d["nodes"][:4], bad)["err"] == 1
+    assert D.compact(nodes[:4], bad)["err"] == 1

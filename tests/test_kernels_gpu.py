@@ -26,12 +26,14 @@ def rel(a, b):
 def _compact_case(n8, e8, H=16):
     ref = D.compact(n8, e8)
     g, hx0 = ops.compact(torch.from_numpy(n8).float().to(DEV), torch.from_numpy(e8).float().to(DEV), H)
-    assert (g.S, g.E) == (ref["S"], ref["E"])
-    assert list(g.Et) == np.diff(ref["type_off"]).tolist()
-    for name in ("cidx", "slot_of", "e_src", "e_dst", "in_perm", "seg_off", "out_perm", "src_off",
+    assert (g.S, g.E, g.U) == (ref["S"], ref["E"], ref["U"])
+    assert list(g.Ut) == np.diff(ref["type_off"]).tolist()
+    for name in ("cidx", "slot_of", "u_src", "in_perm", "mu_off", "mu_dst", "mu_slot", "out_perm",
                  "type_off"):
         got = getattr(g, name).cpu().numpy()
-        assert np.array_equal(got, ref[name]), name
+        assert np.array_equal(got, ref[name]), name            # integer work: bit-exact
+    for name in ("seg_off", "src_off"):                        # [R + 1] = [S + 2] entries
+        assert np.array_equal(getattr(g, name).cpu().numpy(), ref[name]), name
     assert np.array_equal(g.node_mask.cpu().numpy(), ref["node_mask"].astype(np.int32))
     B, N, Fn = n8.shape
     x = np.zeros((g.S + 1, hx0.shape[1]), dtype=np.float32)
@@ -179,11 +181,11 @@ def test_gemm_wgrad_grouped_gather():
 def test_seg_sum_and_accumulate():
     n8, e8, _ = synthetic.make_batch(200, **synthetic.SHAPES["gdb13"], seed=9)
     ref = D.compact(n8, e8)
-    S, E = ref["S"], ref["E"]
+    S, E, U = ref["S"], ref["E"], ref["U"]
     g = torch.Generator().manual_seed(4)
     for cols in (128, 100, 12):
         ld = ops.r4(cols)
-        vals = torch.randn(E, ld, generator=g)
+        vals = torch.randn(U, ld, generator=g)                 # message rows
         for perm_k, off_k in (("in_perm", "seg_off"), ("out_perm", "src_off")):
             perm = torch.from_numpy(ref[perm_k])
             off = torch.from_numpy(ref[off_k])
@@ -194,6 +196,19 @@ def test_seg_sum_and_accumulate():
             assert float(out[S].abs().max()) == 0.0
             ops.seg_sum(vals.to(DEV), perm.to(DEV), off.to(DEV), S + 1, cols, out, accumulate=True)
             assert rel(out[:, :cols], 2 * want[:, :cols]) < 1e-6
+        # backward of the aggregation over the message CSR, fused with the SELU backward (in place)
+        dagg = torch.randn(S + 1, ld, generator=g)
+        y = D.selu(torch.randn(U, ld, generator=g))
+        buf = y.clone().to(DEV)
+        lib = L.load()
+        dagg_d = dagg.to(DEV)                                  # keep the device copies alive
+        mu_dst_d, mu_off_d = (torch.from_numpy(ref[k]).to(DEV) for k in ("mu_dst", "mu_off"))
+        L.check(lib.gi_seg_sum_dselu(dagg_d.data_ptr(), ld, mu_dst_d.data_ptr(), mu_off_d.data_ptr(),
+                                     U, cols, buf.data_ptr(), ld,
+                                     torch.cuda.current_stream().cuda_stream), "dselu")
+        want = D.seg_sum(dagg.double(), torch.from_numpy(ref["mu_dst"]), torch.from_numpy(ref["mu_off"]), U) \
+            * D.selu_grad_from_out(y.double())
+        assert rel(buf[:, :cols], want[:, :cols]) < 1e-6
 
 
 def test_selu_bwd_rows_gather():

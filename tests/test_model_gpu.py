@@ -69,18 +69,19 @@ def test_forward_stage_by_stage_tiny():
                               keep=True)
     model = make_model(cfg, P)
     nodes, edges = to_dev(n8, e8)
-    out, (dims, graph, ws, Et) = mpnn.ggnn_forward_raw(model.constants, nodes, edges,
-                                                       list(model.parameters()))
-    S, E = graph.S, graph.E
+    out, (dims, graph, ws) = mpnn.ggnn_forward_raw(model.constants, nodes, edges,
+                                                   list(model.parameters()))
+    S, E, U = graph.S, graph.E, graph.U
+    assert (S, E, U) == (tape["g"]["S"], tape["g"]["E"], tape["g"]["U"]) and U < E
     R, B = S + 1, n8.shape[0]
     H, M, G, Fn = dims.H, dims.M, dims.G, dims.Fn
-    view = lambda name, rows, i=0, j=0: ops.ws_view(ws, dims, S, E, name, rows, i, j)
+    view = lambda name, rows, i=0, j=0: ops.ws_view(ws, dims, S, E, U, name, rows, i, j)
     for p, ps in enumerate(tape["passes"]):
         assert rel(view("hx", R, p)[:, :H], ps["h_prev"]) < 1e-5, f"hx[{p}]"
         for l in range(dims.enn_depth):
             want = torch.cat([ps["acts_t"][t][l] for t in range(dims.Fe)], 0)
-            assert rel(view("eact", E, p, l)[:, :dims.enn_hidden], want) < 1e-5, f"eact[{p}][{l}]"
-        assert rel(view("m", E, p)[:, :M], ps["m"]) < 1e-5, f"m[{p}]"
+            assert rel(view("eact", U, p, l)[:, :dims.enn_hidden], want) < 1e-5, f"eact[{p}][{l}]"
+        assert rel(view("m", U, p)[:, :M], ps["m"]) < 1e-5, f"m[{p}]"
         assert rel(view("agg", R, p)[:, :M], ps["agg"]) < 1e-5, f"agg[{p}]"
     hxP = view("hx", R, dims.passes)
     assert rel(hxP[:, :H], tape["h"]) < 1e-5
@@ -244,10 +245,10 @@ def test_gradients_strict_with_selu_branch_pinned(shape, B, over):
     params = list(model.parameters())
     nodes, edges, tgt = to_dev(n8, e8, a8)
     out, tape_hip = mpnn.ggnn_forward_raw(model.constants, nodes, edges, params)
-    dims, graph, ws, Et = tape_hip
-    S, E, B = graph.S, graph.E, n8.shape[0]
+    dims, graph, ws = tape_hip
+    S, E, U, B = graph.S, graph.E, graph.U, n8.shape[0]
     R = S + 1
-    view = lambda name, rows, i=0, j=0: ops.ws_view(ws, dims, S, E, name, rows, i, j).cpu()
+    view = lambda name, rows, i=0, j=0: ops.ws_view(ws, dims, S, E, U, name, rows, i, j).cpu()
     # fp64 reference forward on the CPU dataflow model
     P64 = {k: v.double() for k, v in P.items()}
     t64 = lambda x: torch.from_numpy(x).double()
@@ -257,11 +258,11 @@ def test_gradients_strict_with_selu_branch_pinned(shape, B, over):
     toff = graph.type_off.cpu().tolist()
     for p, ps in enumerate(tape["passes"]):
         for l in range(dims.enn_depth):
-            hv = view("eact", E, p, l)
+            hv = view("eact", U, p, l)
             for t in range(dims.Fe):
                 a = ps["acts_t"][t][l]
                 pins[id(a)] = hv[toff[t]:toff[t + 1], :a.shape[1]] > 0
-        pins[id(ps["m"])] = view("m", E, p)[:, :dims.M] > 0
+        pins[id(ps["m"])] = view("m", U, p)[:, :dims.M] > 0
     for key, act_name, out_name, depth in (("att_acts", "att_act", "en", dims.att_depth),
                                            ("emb_acts", "emb_act", "emb", dims.emb_depth),
                                            ("add1", "add1_act", "add1", dims.mlp1_depth),
