@@ -854,18 +854,22 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
     r.chk(gi_gather_readout_bwd(ws + w.en, ws + w.embo, w.ldG, cidx, mask, d.B, d.N, d.G, S,
                                 d.big_positive, ws + w.dgemb, w.ldG, ws + w.dcat_add + NA, w.ldCA,
                                 ws + w.dcat_conn + NC, w.ldCC, ws + w.zpart_g, r.st));
-    float* en_z = ws + w.en + (long long)S * w.ldG;
-    float* emb_z = ws + w.embo + (long long)S * w.ldG;
-    r.chk(gi_colsum(ws + w.zpart_g, w.ldZG, d.B, d.G, en_z, en_z, r.st));
-    r.chk(gi_colsum(ws + w.zpart_g + d.G, w.ldZG, d.B, d.G, emb_z, emb_z, r.st));
     r.chk(gi_compress_slots(ws + w.add1o, w.ldA, cidx, d.B, d.N, d.A, S, ws + w.dcat_add, w.ldCA,
                             ws + w.zpart_a, w.ldA, r.st));
-    float* add_z = ws + w.add1o + (long long)S * w.ldA;
-    r.chk(gi_colsum(ws + w.zpart_a, w.ldA, d.B, d.A, add_z, add_z, r.st));
     r.chk(gi_compress_slots(ws + w.conn1o, w.ldC, cidx, d.B, d.N, d.C, S, ws + w.dcat_conn, w.ldCC,
                             ws + w.zpart_c, w.ldC, r.st));
-    float* conn_z = ws + w.conn1o + (long long)S * w.ldC;
-    r.chk(gi_colsum(ws + w.zpart_c, w.ldC, d.B, d.C, conn_z, conn_z, r.st));
+    {   // zero-row gradients of the four stacks: per-graph partial sums -> row S, one launch
+        float* en_z = ws + w.en + (long long)S * w.ldG;
+        float* emb_z = ws + w.embo + (long long)S * w.ldG;
+        float* add_z = ws + w.add1o + (long long)S * w.ldA;
+        float* conn_z = ws + w.conn1o + (long long)S * w.ldC;
+        const gi_colsum_desc cs[4] = {
+            {ws + w.zpart_g, w.ldZG, d.B, d.G, en_z, en_z},
+            {ws + w.zpart_g + d.G, w.ldZG, d.B, d.G, emb_z, emb_z},
+            {ws + w.zpart_a, w.ldA, d.B, d.A, add_z, add_z},
+            {ws + w.zpart_c, w.ldC, d.B, d.C, conn_z, conn_z}};
+        r.chk(gi_colsum_multi(cs, 4, r.st));
+    }
     // ---- node-level readout MLPs -> dh -------------------------------------------------------------
     const float* hxP = ws + w.hx[d.passes];
     float* dh = ws + w.dh;

@@ -5,6 +5,8 @@
 
 #include <algorithm>
 
+#include <string.h>
+
 #include "gi_common.h"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -308,16 +310,33 @@ __global__ __launch_bounds__(64) void compress_slots_kernel(
     }
 }
 
-// out[c] = (sum_r part[r, c]) * selu'(y[c]); 64 columns per block, 16 row groups, fixed tree
-__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ part, int ldp,
-                                                      int rows, int cols, const float* y,
-                                                      float* out) {
+// out[c] = (sum_r part[r, c]) * selu'(y[c]); 64 columns per block, 16 row groups, fixed tree.
+// blockIdx.y selects one of up to 8 independent problems.
+struct ColsumTable { gi_colsum_desc d[8]; };
+
+__global__ __launch_bounds__(1024) void colsum_kernel(const ColsumTable tab) {
     __shared__ float red[16][64];
+    const gi_colsum_desc& q = tab.d[blockIdx.y];
+    const float* __restrict__ part = q.part;
+    const int ldp = q.ldp, rows = q.rows, cols = q.cols;
+    const float* y = q.y;
+    float* out = q.out;
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
+    if (blockIdx.x * 64 >= cols) return;                  // block-uniform
     float acc = 0.f;
-    if (c < cols)
-        for (int r = rg; r < rows; r += 16) acc += part[(long long)r * ldp + c];
+    if (c < cols) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;      // four loads in flight; fixed order
+        int r = rg;
+        for (; r + 48 < rows; r += 64) {
+            a0 += part[(long long)r * ldp + c];
+            a1 += part[(long long)(r + 16) * ldp + c];
+            a2 += part[(long long)(r + 32) * ldp + c];
+            a3 += part[(long long)(r + 48) * ldp + c];
+        }
+        for (; r < rows; r += 16) a0 += part[(long long)r * ldp + c];
+        acc = (a0 + a1) + (a2 + a3);
+    }
     red[rg][cl] = acc;
     __syncthreads();
     if (rg == 0 && c < cols) {
@@ -618,8 +637,29 @@ extern "C" int gi_colsum(const float* part, int ldp, int rows, int cols, const f
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (cols <= 0) return 0;
     if (!part || !out || rows < 0) return GI_EINVAL;
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream,
-                       part, ldp, rows, cols, y, out);
+    ColsumTable tab;
+    memset(&tab, 0, sizeof(tab));
+    tab.d[0] = gi_colsum_desc{part, ldp, rows, cols, y, out};
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, 1), dim3(1024), 0, (hipStream_t)stream,
+                       tab);
+    return gi_launch_status();
+}
+
+extern "C" int gi_colsum_multi(const gi_colsum_desc* descs, int n, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
+    if (n <= 0) return 0;
+    if (!descs || n > 8) return GI_EINVAL;
+    ColsumTable tab;
+    memset(&tab, 0, sizeof(tab));
+    int maxcols = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!descs[i].part || !descs[i].out || descs[i].rows < 0 || descs[i].cols < 0) return GI_EINVAL;
+        tab.d[i] = descs[i];
+        maxcols = descs[i].cols > maxcols ? descs[i].cols : maxcols;
+    }
+    if (maxcols == 0) return 0;
+    hipLaunchKernelGGL(colsum_kernel, dim3((maxcols + 63) / 64, n), dim3(1024), 0,
+                       (hipStream_t)stream, tab);
     return gi_launch_status();
 }
 

@@ -94,6 +94,7 @@ SIGNATURES = {
     "gi_expand_slots": (ci, [vp, ci, vp, ci, ci, ci, vp, ci, vp]),
     "gi_compress_slots": (ci, [vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, ci, vp]),
     "gi_colsum": (ci, [vp, ci, ci, ci, vp, vp, vp]),
+    "gi_colsum_multi": (ci, [vp, ci, vp]),
     "gi_reduce_slabs": (ci, [C.POINTER(ReduceDesc), ci, vp]),
     "gi_adam_step": (ci, [vp, vp, vp, vp, cll, C.c_float, C.c_float, C.c_float, C.c_float,
                           C.c_float, ci, vp]),

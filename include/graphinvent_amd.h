@@ -197,6 +197,11 @@ int gi_compress_slots(float* t1, int ldt, const int* cidx, int B, int N, int W, 
 /* out[c] = (sum_b part[b, c]) * (y ? selu'(y[c]) : 1), deterministic */
 int gi_colsum(const float* part, int ldp, int rows, int cols, const float* y, float* out,
               void* stream);
+/* n (<= 8) independent column sums in one launch */
+typedef struct gi_colsum_desc {
+    const float* part; int ldp, rows, cols; const float* y; float* out;
+} gi_colsum_desc;
+int gi_colsum_multi(const gi_colsum_desc* descs, int n, void* stream);
 
 /* sums wgrad slabs into the parameter gradients: for each descriptor,
  *   dW[n,k] = sum_s slab[s][n*ld + k] (k < K),  db[n] = sum_s slab[s][n*ld + K] */
