@@ -101,6 +101,7 @@ SIGNATURES = {
     "gi_kl_loss": (ci, [vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, vp]),
     "gi_prof_enable": (ci, [ci]),
     "gi_prof_collect": (ci, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci)]),
+    "gi_sample_actions": (ci, [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]),
     "gi_side_stream_create": (ci, [C.POINTER(vp)]),
     "gi_side_stream_destroy": (ci, [vp]),
     "gi_ggnn_num_params": (ci, [C.POINTER(GgnnDims)]),

@@ -222,6 +222,20 @@ int gi_adam_step(float* p, const float* g, float* m, float* v, long long n, floa
 int gi_kl_loss(const float* out, int ldo, const void* target, int tgt_dtype, int ldt, int B,
                int width, float* row_loss, float* d_out, int ldd, void* stream);
 
+/* Sampling step of graph generation — replaces `softmax(model(nodes, edges))` +
+ * GraphGenerator.get_actions / get_invalid_actions (GraphGenerator.py:121, 467-657) with one launch:
+ * per graph b, softmax of logits[b, 0:W] (W = N*A + N*Fe + 1), ONE categorical draw = the first
+ * action whose cumulative probability exceeds uniform[b] (inverse CDF; uniform in [0,1)), decode and
+ * validity rules.  n_nodes[B] int32 = atoms currently in each graph; edges [B,N,N,Fe] (GI_DTYPE).
+ *   action[b] = {kind (0 add, 1 connect, 2 terminate), node_to, rem, from}: rem = index inside the
+ *               node's block (add: ravelled (atom type, charge, ..., bond type); connect: bond type);
+ *               from = n_nodes (add; 0 where the reference resets it, :567) or n_nodes-1 (connect)
+ *   likelihood[b] = probability of the drawn action (:541)
+ *   flags[b]  bit 0: invalid action (:573-646); bit 1: the add's "connect to" index was reset (:650-654) */
+int gi_sample_actions(const float* logits, int ldl, const float* uniform, const int* n_nodes,
+                      const void* edges, int edges_dtype, int B, int N, int A, int Fe, int* action,
+                      float* likelihood, int* flags, void* stream);
+
 /* Optional per-launch timing for the benchmark's roofline leg: when enabled, every gi_gemm and
  * gi_seg_sum launch is bracketed by hipEvents on its stream.  gi_prof_collect blocks until the
  * recorded work finished and returns, per kernel family k (0 = GEMM, 1 = seg_sum): summed elapsed
