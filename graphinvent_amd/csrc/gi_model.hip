@@ -165,7 +165,7 @@ void make_ws(const Model& m, int S, int E, int U, Ws& w) {
 }
 
 // ---- wgrad slab plan ----------------------------------------------------------------------------
-struct SlabEntry { long long off, stride; int nsplit, calls, done, n_out, n_in, ld, tn; };
+struct SlabEntry { long long off, stride; int nsplit, calls, done, n_out, n_in, ld, tn, bidx, launched, reduced; };
 struct SlabPlan { SlabEntry e[160]; long long total; };
 
 // wgrad launch shape: 64x64 output tiles.  Weight-gradient GEMMs are deferred and launched in
@@ -185,8 +185,9 @@ void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {   /
     long long o = 0;
     int maxEt = 0;
     for (int t = 0; t < d.Fe; ++t) maxEt = std::max(maxEt, Et ? Et[t] : E);
-    auto add = [&](int widx, int n_out, int n_in, int red, int calls, double share) {
+    auto add = [&](int widx, int bidx, int n_out, int n_in, int red, int calls, double share) {
         SlabEntry& e = sp.e[widx];
+        e.bidx = bidx; e.launched = 0; e.reduced = 0;
         e.n_out = n_out; e.n_in = n_in; e.ld = gi_r4(n_in + 1); e.calls = calls; e.done = 0;
         wgrad_shape(n_out, n_in, red, share, e.tn, e.nsplit);
         e.stride = gi_r4l((long long)n_out * e.ld);
@@ -195,7 +196,7 @@ void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {   /
     };
     auto add_mlp = [&](const Mlp& q, int red, int calls, double share = 1.0) {
         for (int l = 0; l < q.layers(); ++l)
-            add(q.w(l), q.fan_out(l), q.fan_in(l), red, calls, share);
+            add(q.w(l), q.b(l), q.fan_out(l), q.fan_in(l), red, calls, share);
     };
     const int R = S + 1;
     for (int t = 0; t < d.Fe; ++t) {
@@ -204,8 +205,8 @@ void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {   /
         if (d.kind == GI_KIND_ATTGGNN)
             add_mlp(m.eatt[t], et, d.passes, E > 0 ? 1.5 * (double)et / E : 1.0);
     }
-    add(m.gru_wih, 3 * d.H, d.M, R, d.passes, 1.0);
-    add(m.gru_whh, 3 * d.H, d.H, R, d.passes, 1.0);
+    add(m.gru_wih, m.gru_bih, 3 * d.H, d.M, R, d.passes, 1.0);
+    add(m.gru_whh, m.gru_bhh, 3 * d.H, d.H, R, d.passes, 1.0);
     add_mlp(m.att, R, 1); add_mlp(m.emb, R, 1); add_mlp(m.add1, R, 1); add_mlp(m.conn1, R, 1);
     add_mlp(m.add2, d.B, 1); add_mlp(m.conn2, d.B, 1); add_mlp(m.term2, d.B, 1);
     sp.total = o;
@@ -221,6 +222,9 @@ struct Run {
     const float* const* P;
     int rc;
     SideStream* side = nullptr;    // optional second stream for the weight-gradient GEMMs
+    struct SlabPlan* sp = nullptr; // backward only: where the wgrad slabs go and what they reduce to
+    float* slabs = nullptr;
+    float* const* grads = nullptr;
     bool ok() const { return rc == 0; }
     void chk(int r) { if (rc == 0 && r != 0) rc = r; }
 };
@@ -332,8 +336,10 @@ struct Batch {
 // dZ chain (the critical path) runs and launched afterwards in batches of 8 problems.
 struct Deferred {
     gi_gemm_params p[96];
+    int widx[96][GI_MAX_GROUPS];     // weight indices each problem's slabs belong to
+    int nw[96];
     int n = 0;
-    gi_gemm_params& next() { gemm_defaults(p[n]); return p[n++]; }
+    gi_gemm_params& next() { gemm_defaults(p[n]); nw[n] = 0; return p[n++]; }
 };
 
 void flush_batch(Run& r, Batch& b, bool wgrad) {
@@ -370,6 +376,14 @@ void add_dgrad(Batch& b, const float* W, int n_out, int n_in, int ncols, const f
 void flush_deferred(Run& r, Deferred& q);
 void kick_deferred(Run& r, Deferred& q, SideStream* side, bool all);
 
+gi_reduce_desc reduce_desc(const SlabEntry& e, float* slabs, float* const* grads, int widx) {
+    gi_reduce_desc q;
+    q.slabs = slabs + e.off; q.dW = grads[widx]; q.db = grads[e.bidx];
+    q.slab_stride = e.stride; q.n_slabs = e.nsplit * e.calls; q.N = e.n_out; q.K = e.n_in;
+    q.ld = e.ld;
+    return q;
+}
+
 void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* widx, const Grp& g,
                  const float* dZ, int lddz, const float* X, int ldx, const int* b_idx, int rows) {
     if (q.n == 96) flush_deferred(r, q);          // list full (very deep configurations only)
@@ -382,6 +396,7 @@ void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* wid
     p.flags = GI_GEMM_SPLITK;
     p.nsplit = e0.nsplit; p.c_split_stride = e0.stride;
     p.tm = 1; p.tn = 1;
+    const int slot = q.n - 1;
     if (g.n) {
         p.ngroups = g.n; p.grp_off = g.off;
         for (int t = 0; t < g.n; ++t) {
@@ -389,10 +404,14 @@ void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* wid
             p.Cg[t] = slabs + e.off + (long long)e.done * e.nsplit * e.stride;
             p.gsplit[t] = e.nsplit;
             e.done++;
+            q.widx[slot][t] = widx[t];
         }
+        q.nw[slot] = g.n;
     } else {
         p.C = slabs + e0.off + (long long)e0.done * e0.nsplit * e0.stride;
         e0.done++;
+        q.widx[slot][0] = widx[0];
+        q.nw[slot] = 1;
     }
     if (r.side && q.n >= 8) kick_deferred(r, q, r.side, false);
 }
@@ -435,7 +454,24 @@ void kick_deferred(Run& r, Deferred& q, SideStream* side, bool all) {
     r.chk((int)hipStreamWaitEvent(side->st, ready, 0));
     for (int base = 0; base < n && r.ok(); base += 8)
         r.chk(gi_gemm_batch(q.p + base, std::min(8, n - base), side->st));
-    for (int i = n; i < q.n; ++i) q.p[i - n] = q.p[i];
+    // parameters whose last slab has just been queued: reduce them right behind, on the side stream
+    // too, so that only the final pass's gradients are left for the end of the backward
+    gi_reduce_desc descs[96 * GI_MAX_GROUPS > 160 ? 160 : 96 * GI_MAX_GROUPS];
+    int nd = 0;
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < q.nw[i]; ++k) {
+            SlabEntry& e = r.sp->e[q.widx[i][k]];
+            if (++e.launched == e.calls && !e.reduced && nd < 160) {
+                e.reduced = 1;
+                descs[nd++] = reduce_desc(e, r.slabs, r.grads, q.widx[i][k]);
+            }
+        }
+    if (nd && r.ok()) r.chk(gi_reduce_slabs(descs, nd, side->st));
+    for (int i = n; i < q.n; ++i) {
+        q.p[i - n] = q.p[i];
+        q.nw[i - n] = q.nw[i];
+        for (int k = 0; k < q.nw[i]; ++k) q.widx[i - n][k] = q.widx[i][k];
+    }
     q.n -= n;
 }
 
@@ -833,6 +869,7 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
     Deferred dq;
     SideStream side_obj{(hipStream_t)side_stream, 0};
     r.side = side_stream ? &side_obj : nullptr;
+    r.sp = &sp; r.slabs = slabs; r.grads = grads;
     const Grp none{0, nullptr, 0};
     // ---- tier 2 (gnn/modules.py:265-279) ---------------------------------------------------------
     r.chk(gi_selu_bwd_rows(d_out, lddout, nullptr, y_out, ldout, ws + w.dzA, w.ldNA, d.B, NA, r.st));
@@ -964,14 +1001,13 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
     } else {
         flush_deferred(r, dq);
     }
-    gi_reduce_desc descs[160];
+    gi_reduce_desc descs[160];            // whatever has not been reduced on the side stream yet
     int nd = 0;
-    auto add_desc = [&](int widx, int bidx) {
-        const SlabEntry& e = sp.e[widx];
-        gi_reduce_desc& q = descs[nd++];
-        q.slabs = slabs + e.off; q.dW = grads[widx]; q.db = grads[bidx];
-        q.slab_stride = e.stride; q.n_slabs = e.nsplit * e.calls; q.N = e.n_out; q.K = e.n_in;
-        q.ld = e.ld;
+    auto add_desc = [&](int widx, int) {
+        SlabEntry& e = sp.e[widx];
+        if (e.reduced) return;
+        e.reduced = 1;
+        descs[nd++] = reduce_desc(e, slabs, grads, widx);
     };
     auto add_mlp_desc = [&](const Mlp& q) {
         for (int l = 0; l < q.layers(); ++l) add_desc(q.w(l), q.b(l));
