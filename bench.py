@@ -155,6 +155,8 @@ def main():
                          "graph shape of configs[4] — both for reference, not the headline")
     ap.add_argument("--model", default="ggnn", choices=["ggnn", "attggnn"],
                     help="attggnn = gnn.mpnn.AttentionGGNN (configs[4]'s model class), for reference")
+    ap.add_argument("--no-prefetch-compact", action="store_true",
+                    help="run graph_compact's counting phase inside the step instead of one batch ahead")
     ap.add_argument("--no-probe", action="store_true",
                     help="skip the beyond-Infinity-Cache seg_sum probe (keeps kernel traces clean)")
     ap.add_argument("--batch", type=int, default=BATCH, help="graphs per GPU per step")
@@ -202,13 +204,23 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # Like the block loader (graphinvent_amd/loader.py), the loop hands the NEXT batch to
+    # ops.prefetch_compact before stepping on the current one: the counting phase of graph_compact
+    # (and its host read-back) for batch k+1 runs on a side stream during step k.  Every step still
+    # compacts its own batch — the result is consumed once, nothing is cached across steps.
+    def run_step(i):
+        if not args.no_prefetch_compact:
+            nxt = batches[(i + 1) % N_BATCHES]
+            ops.prefetch_compact(nxt[0], nxt[1])
+        return trainer.step(*batches[i % N_BATCHES])
+
     step_i = 0
     for _ in range(args.warmup):
-        trainer.step(*batches[step_i % N_BATCHES]); step_i += 1
+        run_step(step_i); step_i += 1
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = trainer.step(*batches[step_i % N_BATCHES]); step_i += 1
+        loss = run_step(step_i); step_i += 1
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:

@@ -81,7 +81,8 @@ class ShardedBlockLoader:
 
     def __init__(self, nodes, edges, apds, batch_size: int, rank: int = 0, world_size: int = 1,
                  seed: int = 0, shuffle: bool = True, device: Optional[str] = "cuda",
-                 drop_zero_targets: bool = True, prefetch: bool = True):
+                 drop_zero_targets: bool = True, prefetch: bool = True,
+                 prefetch_compact: bool = True):
         as_t = lambda a: torch.as_tensor(np.ascontiguousarray(a)) if not torch.is_tensor(a) else a
         nodes, edges, apds = as_t(nodes), as_t(edges), as_t(apds)
         if not (nodes.dtype == edges.dtype == apds.dtype == torch.int8):
@@ -100,6 +101,8 @@ class ShardedBlockLoader:
         self.sampler = ShardedBatchSampler(self.block[0].shape[0], batch_size, rank, world_size,
                                            seed, shuffle)
         self.prefetch = prefetch and self.on_gpu
+        # also run graph_compact's counting phase for the batch on the copy stream (ops.prefetch_compact)
+        self.prefetch_compact = prefetch_compact and self.on_gpu
         self._stream = torch.cuda.Stream(self.device) if self.on_gpu else None
         # two pinned staging slots per tensor (gather destination, H2D source)
         self._stage = [tuple(pin(torch.empty((batch_size,) + t.shape[1:], dtype=torch.int8))
@@ -123,6 +126,9 @@ class ShardedBlockLoader:
             torch.index_select(src, 0, index, out=dst)    # vectorised row gather, pinned -> pinned
         with torch.cuda.stream(self._stream):
             dev = tuple(s.to(self.device, non_blocking=True) for s in stage)
+            if self.prefetch_compact:
+                from . import ops
+                ops.prefetch_compact(dev[0], dev[1], stream=self._stream)
             ev = torch.cuda.Event()
             ev.record(self._stream)
         self._stage_done[slot] = ev

@@ -123,9 +123,9 @@ def _gvar_offsets(E: int, U: int):
     return offs, o
 
 
-def compact_count(nodes: torch.Tensor, edges: torch.Tensor):
-    """Phase 1; returns (nodes, layout, gfix, S, E, U, Ut).  One host read-back of 24 ints (the only
-    synchronisation point of a forward pass)."""
+def _count_launch(nodes: torch.Tensor, edges: torch.Tensor):
+    """Enqueue gi_compact_count on the current stream; returns (nodes as the kernels read them,
+    layout, gfix)."""
     lib = L.load()
     nodes, dt_n = _model_input(nodes, "nodes")
     edges, dt_e = _model_input(edges, "edges")
@@ -140,13 +140,79 @@ def compact_count(nodes: torch.Tensor, edges: torch.Tensor):
     gfix = torch.empty(lay.total_ints, dtype=torch.int32, device=nodes.device)
     L.check(lib.gi_compact_count(nodes.data_ptr(), edges.data_ptr(), dt_n, B, N, Fn, Fe,
                                  gfix.data_ptr(), _stream()), "gi_compact_count")
-    counts = gfix[lay.counts:lay.counts + L.COUNTS].cpu().tolist()
+    return nodes, lay, gfix, Fe
+
+
+def _unpack_counts(counts, Fe: int):
     S, E, err, U = counts[0], counts[1], counts[2], counts[3]
     if err:
         raise ValueError("edges tensor violates the preprocessed-HDF contract: every bonded pair "
                          "must carry exactly one one-hot bond type (DataProcesser.py / "
                          "MolecularGraph.py edge features)")
-    return nodes, lay, gfix, S, E, U, counts[4:4 + Fe]
+    return S, E, U, counts[4:4 + Fe]
+
+
+# ---- compaction one batch ahead -------------------------------------------------------------------
+# gi_compact_count ends in the forward pass's only host read-back (S, E, U decide buffer sizes and
+# launch grids).  A caller that knows its next batch (the block loader; bench.py) can run the
+# counting phase for it on a side stream while the current training step occupies the main stream;
+# the forward then finds the result here, already on the host, and neither waits for the device nor
+# puts the three counting kernels on its critical path.  Entries are consumed once.
+_PREFETCHED: "dict" = {}
+_PINNED: "list" = []
+_PINNED_NEXT = 0
+_PREFETCH_STREAMS: "dict" = {}
+
+
+def _batch_key(nodes: torch.Tensor, edges: torch.Tensor):
+    return (nodes.data_ptr(), edges.data_ptr(), nodes._version, edges._version, tuple(nodes.shape),
+            tuple(edges.shape), nodes.dtype, edges.dtype)
+
+
+def prefetch_compact(nodes: torch.Tensor, edges: torch.Tensor,
+                     stream: Optional["torch.cuda.Stream"] = None) -> None:
+    """Run the counting phase of graph_compact for a FUTURE forward(nodes, edges) on `stream`
+    (default: a per-device side stream that first waits for the current stream)."""
+    if not nodes.is_cuda:
+        return
+    dev = nodes.device
+    if stream is None:
+        stream = _PREFETCH_STREAMS.get(dev.index)
+        if stream is None:
+            stream = _PREFETCH_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+        stream.wait_stream(torch.cuda.current_stream(dev))
+    global _PINNED_NEXT
+    if len(_PINNED) < 8:                                     # pool of host buffers, round robin; at
+        _PINNED.append(torch.empty(L.COUNTS, dtype=torch.int32).pin_memory())   # most 4 are pending
+        pinned = _PINNED[-1]
+    else:
+        pinned = _PINNED[_PINNED_NEXT % 8]
+        _PINNED_NEXT += 1
+    with torch.cuda.stream(stream):
+        nodes_c, lay, gfix, Fe = _count_launch(nodes, edges)
+        pinned.copy_(gfix[lay.counts:lay.counts + L.COUNTS], non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(stream)
+    while len(_PREFETCHED) >= 4:                             # never-consumed entries do not pile up
+        _PREFETCHED.pop(next(iter(_PREFETCHED)))
+    _PREFETCHED[_batch_key(nodes, edges)] = (nodes_c, lay, gfix, Fe, pinned, done)
+
+
+def compact_count(nodes: torch.Tensor, edges: torch.Tensor):
+    """Phase 1; returns (nodes, layout, gfix, S, E, U, Ut).  One host read-back of 24 ints — the only
+    synchronisation point of a forward pass, unless `prefetch_compact` already ran for this batch."""
+    hit = _PREFETCHED.pop(_batch_key(nodes, edges), None) if _PREFETCHED else None
+    if hit is not None:
+        nodes_c, lay, gfix, Fe, pinned, done = hit
+        done.synchronize()                                   # normally long finished
+        cur = torch.cuda.current_stream(nodes_c.device)
+        cur.wait_event(done)
+        gfix.record_stream(cur)
+        nodes_c.record_stream(cur)
+        return (nodes_c, lay, gfix) + _unpack_counts(pinned.tolist(), Fe)
+    nodes, lay, gfix, Fe = _count_launch(nodes, edges)
+    counts = gfix[lay.counts:lay.counts + L.COUNTS].cpu().tolist()
+    return (nodes, lay, gfix) + _unpack_counts(counts, Fe)
 
 
 def compact_fill(nodes, lay, gfix, S, E, U, Ut, hx0: torch.Tensor, ldhx: int, H: int) -> CompactGraph:

@@ -425,3 +425,27 @@ def test_int8_inputs_and_prefetching_loader(golden_dir):
             assert float(l8) == float(l32) and np.isfinite(float(l8))
             n_batches += 1
     assert n_batches == 4
+
+
+def test_compaction_prefetched_one_batch_ahead_is_bitwise_identical():
+    """ops.prefetch_compact (what the block loader and bench.py call for the NEXT batch) must not
+    change a single bit, must be consumed exactly once, and must not be used for a batch that was
+    modified after the prefetch."""
+    cfg = O.make_config()
+    P = O.init_params(cfg, seed=2)
+    model = make_model(cfg, P).eval()
+    n8, e8, _ = synthetic.make_batch(64, **synthetic.SHAPES["gdb13"], seed=21)
+    nodes, edges = to_dev(n8, e8)
+    with torch.no_grad():
+        ref = model(nodes, edges)
+        ops.prefetch_compact(nodes, edges)
+        assert len(ops._PREFETCHED) == 1
+        assert torch.equal(model(nodes, edges), ref)
+        assert len(ops._PREFETCHED) == 0                        # consumed
+        ops.prefetch_compact(nodes, edges)
+        edges[0, 0, 1, :] = 0; edges[0, 1, 0, :] = 0            # in-place edit -> new tensor version
+        out = model(nodes, edges)
+        assert len(ops._PREFETCHED) == 1                        # stale entry was NOT used
+        ops._PREFETCHED.clear()
+        assert torch.equal(out, model(nodes, edges))
+        assert not torch.equal(out[0], ref[0])
