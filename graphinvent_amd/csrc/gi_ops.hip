@@ -458,17 +458,32 @@ extern "C" int gi_prof_enable(int on) {
     return 0;
 }
 // ms[k], work[k], launches[k] for k in {GEMM (work = flops), SEGSUM (work = bytes)}; clears the log
-extern "C" int gi_prof_collect(double* ms, double* work, int* launches) {
-    if (!ms || !work || !launches) return GI_EINVAL;
-    for (int k = 0; k < GI_PROF_KINDS; ++k) { ms[k] = 0; work[k] = 0; launches[k] = 0; }
+extern "C" int gi_prof_collect(double* ms, double* busy_ms, double* work, int* launches) {
+    if (!ms || !busy_ms || !work || !launches) return GI_EINVAL;
+    for (int k = 0; k < GI_PROF_KINDS; ++k) { ms[k] = 0; busy_ms[k] = 0; work[k] = 0; launches[k] = 0; }
     int rc = 0;
+    if (g_prof.empty()) return 0;
+    for (ProfRec& r : g_prof) (void)hipEventSynchronize(r.b);
+    // absolute [start, stop] of every launch relative to the first recorded event; launches on the
+    // two streams of the backward overlap, so the per-family busy time is the UNION of intervals
+    std::vector<std::pair<double, double>> iv[GI_PROF_KINDS];
+    const hipEvent_t base = g_prof.front().a;
     for (ProfRec& r : g_prof) {
-        (void)hipEventSynchronize(r.b);
-        float t = 0.f;
+        float t = 0.f, t0 = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) rc = GI_EINVAL;
+        if (hipEventElapsedTime(&t0, base, r.a) != hipSuccess) rc = GI_EINVAL;
         ms[r.kind] += t; work[r.kind] += r.work; launches[r.kind] += 1;
-        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+        iv[r.kind].push_back({(double)t0, (double)t0 + t});
     }
+    for (int k = 0; k < GI_PROF_KINDS; ++k) {
+        std::sort(iv[k].begin(), iv[k].end());
+        double end = -1e300;
+        for (const auto& x : iv[k]) {
+            if (x.first > end) { busy_ms[k] += x.second - x.first; end = x.second; }
+            else if (x.second > end) { busy_ms[k] += x.second - end; end = x.second; }
+        }
+    }
+    for (ProfRec& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();
     return rc;
 }

@@ -100,7 +100,7 @@ SIGNATURES = {
                           C.c_float, ci, vp]),
     "gi_kl_loss": (ci, [vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, vp]),
     "gi_prof_enable": (ci, [ci]),
-    "gi_prof_collect": (ci, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci)]),
+    "gi_prof_collect": (ci, [vp, vp, vp, vp]),
     "gi_sample_actions": (ci, [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]),
     "gi_side_stream_create": (ci, [C.POINTER(vp)]),
     "gi_side_stream_destroy": (ci, [vp]),

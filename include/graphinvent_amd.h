@@ -239,10 +239,11 @@ int gi_sample_actions(const float* logits, int ldl, const float* uniform, const 
 /* Optional per-launch timing for the benchmark's roofline leg: when enabled, every gi_gemm and
  * gi_seg_sum launch is bracketed by hipEvents on its stream.  gi_prof_collect blocks until the
  * recorded work finished and returns, per kernel family k (0 = GEMM, 1 = seg_sum): summed elapsed
- * ms, summed work (GEMM: useful flops 2*M*N*K; seg_sum: 0, the caller knows the bytes) and the
- * number of launches; it clears the log. */
+ * ms, busy ms = length of the UNION of the launches' [start, stop] intervals (launches on the
+ * backward's two streams overlap; the sum double-counts that time), summed work (GEMM: useful flops
+ * 2*M*N*K; seg_sum: 0, the caller knows the bytes) and the number of launches; it clears the log. */
 int gi_prof_enable(int on);
-int gi_prof_collect(double* ms, double* work, int* launches);
+int gi_prof_collect(double* ms, double* busy_ms, double* work, int* launches);
 
 /* ------------------------------------------------------------------------------------------
  * Whole-model entry points: one call enqueues the complete GGNN forward (or backward) —
