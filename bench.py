@@ -264,7 +264,7 @@ def main():
     for i in range(prof_steps):
         b = batches[i % N_BATCHES]
         if rank == 0:
-            _, _, _, S, E, U, _ = ops.compact_count(b[0], b[1])
+            _, _, _, S, E, U, _, _ = ops.compact_count(b[0], b[1])
             R, Mm, H, P = S + 1, cfg["message_size"], cfg["hidden_node_features"], cfg["message_passes"]
             # algorithmic bytes of the three segmented sums (SURVEY.md §8d form): values read through
             # the index + index + offsets + output

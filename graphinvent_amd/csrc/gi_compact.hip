@@ -20,6 +20,14 @@
 // its backward sums, per message row, the gradients of the edges that read it (message CSR
 // `mu_off / mu_dst / mu_slot`); the input gradient of the message MLP goes back to the nodes
 // through the source CSR over message rows (`out_perm`, `src_off`).
+//
+// PASS-0 ROWS.  At the first message pass h = [x | 0 .. 0] (gnn/summation_mpnn.py:121-126), so a
+// message row depends only on (feature row of its source, bond type): D0 distinct rows — atom type x
+// formal charge x bond type, a few dozen.  Classes = distinct 0/1 feature rows of the source slots
+// (64-bit pattern, LDS hash set + rank sort: deterministic ids), rows = present (bond type, class)
+// pairs, bond-type-major.  The pass-0 aggregation becomes agg = cmat . m0 with the [R, D0] matrix of
+// edge counts `cmat` (rows owned by the destination's thread: no atomics).  D0 = 0 (feature off)
+// when a feature is not 0/1, Fn > 62, or there are more than GI_P0_MAX_CLASSES classes.
 #include "gi_common.h"
 
 namespace {
@@ -29,8 +37,12 @@ struct Lay {
     // scratch sub-arrays (ints)
     int rowcnt, nmsg, active, seg_start, srcm_start, colcnt_t, cstart_t, mflag_t, mstart_t,
         etype_off, etype;
+    // pass-0 rows
+    int type_off0, key_lo, key_hi, cls, qkeys, present, rep, dmap, d_slot;
 };
-constexpr int CNT_S = 0, CNT_E = 1, CNT_ERR = 2, CNT_U = 3, CNT_UT = 4, CNT_ET = 12, CNT_N = 24;
+constexpr int CNT_S = 0, CNT_E = 1, CNT_ERR = 2, CNT_U = 3, CNT_UT = 4, CNT_ET = 12, CNT_D0 = 20,
+              CNT_P0BAD = 21, CNT_Q = 22, CNT_N = 24;
+constexpr int P0Q = GI_P0_MAX_CLASSES;
 
 inline Lay make_layout(int B, int N, int Fe) {
     Lay L;
@@ -44,6 +56,7 @@ inline Lay make_layout(int B, int N, int Fe) {
     L.slot_of = take(ns);
     L.seg_off = take(ns + 2);
     L.src_off = take(ns + 2);
+    L.type_off0 = take(GI_MAX_GROUPS + 1);
     L.scratch = o;
     L.rowcnt = take(ns);
     L.nmsg = take(ns);
@@ -55,6 +68,10 @@ inline Lay make_layout(int B, int N, int Fe) {
     L.mflag_t = take(Fe * ns);
     L.mstart_t = take(Fe * ns);
     L.etype_off = take(GI_MAX_GROUPS + 1);
+    L.key_lo = take(ns); L.key_hi = take(ns); L.cls = take(ns);
+    L.qkeys = take(2 * P0Q);
+    L.present = take(Fe * P0Q); L.rep = take(Fe * P0Q); L.dmap = take(Fe * P0Q);
+    L.d_slot = take(Fe * P0Q);
     L.etype = take((int)(((long long)B * N * N + 3) / 4));
     L.total = o;
     return L;
@@ -109,8 +126,17 @@ __global__ __launch_bounds__(256) void compact_count_kernel(
                 for (int f = 0; f < GI_MAX_GROUPS; ++f) cct[f] += (t == f);
             }
         }
-        bool nz = false;
-        for (int f = 0; f < Fn; ++f) nz |= ((float)nodes[(long long)slot * Fn + f] != 0.f);
+        bool nz = false, binary = Fn <= 62;
+        unsigned long long key = 0;                      // pattern of the 0/1 feature row
+        for (int f = 0; f < Fn; ++f) {
+            const float v = (float)nodes[(long long)slot * Fn + f];
+            nz |= (v != 0.f);
+            if (v == 1.f) key |= 1ull << (f & 63);
+            else if (v != 0.f) binary = false;
+        }
+        if (!binary) gfix[L.counts + CNT_P0BAD] = 1;     // benign race: everybody writes 1
+        gfix[L.key_lo + slot] = (int)(unsigned)(key & 0xffffffffull);
+        gfix[L.key_hi + slot] = (int)(unsigned)(key >> 32);
         gfix[L.rowcnt + slot] = rc;
         gfix[L.active + slot] = (nz || rc > 0 || cc > 0) ? 1 : 0;
         gfix[L.node_mask + slot] = rc > 0 ? 1 : 0;                       // :146
@@ -127,6 +153,56 @@ __global__ __launch_bounds__(256) void compact_count_kernel(
     if (tid == 0 && err_s) atomicOr(&gfix[L.counts + CNT_ERR], 1);
 }
 
+// ---- pass-0 classes: distinct feature patterns of the source slots, sorted (one workgroup) ----
+__device__ void p0_classes(int ns, int Fe, int* __restrict__ gfix, const Lay& L) {
+    constexpr int CAP = 4 * P0Q;
+    constexpr unsigned long long EMPTY = ~0ull;
+    __shared__ unsigned long long tab[CAP];
+    __shared__ unsigned long long list[P0Q];
+    __shared__ int n_s, bad_s;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < CAP; i += 1024) tab[i] = EMPTY;
+    for (int i = tid; i < Fe * P0Q; i += 1024) {
+        gfix[L.present + i] = 0; gfix[L.rep + i] = 0x7fffffff; gfix[L.dmap + i] = -1;
+    }
+    if (tid == 0) { n_s = 0; bad_s = 0; }
+    __syncthreads();
+    for (int slot = tid; slot < ns; slot += 1024) {
+        if (gfix[L.nmsg + slot] == 0) continue;          // only slots that send messages
+        const unsigned long long key = ((unsigned long long)(unsigned)gfix[L.key_hi + slot] << 32) |
+                                       (unsigned)gfix[L.key_lo + slot];
+        unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 40) & (CAP - 1);
+        for (int probe = 0; probe < CAP; ++probe) {
+            if (*(volatile int*)&bad_s) break;
+            const unsigned long long old = atomicCAS(&tab[h], EMPTY, key);
+            if (old == key) break;
+            if (old == EMPTY) { if (atomicAdd(&n_s, 1) >= P0Q) bad_s = 1; break; }
+            h = (h + 1) & (CAP - 1);
+        }
+    }
+    __syncthreads();
+    const bool bad = bad_s != 0;
+    const int total = bad ? 0 : n_s;
+    __syncthreads();
+    if (tid == 0) n_s = 0;
+    __syncthreads();
+    if (!bad)
+        for (int i = tid; i < CAP; i += 1024)
+            if (tab[i] != EMPTY) list[atomicAdd(&n_s, 1)] = tab[i];     // unordered ...
+    __syncthreads();
+    if (!bad && tid < total) {                                          // ... rank sort -> ordered
+        const unsigned long long k = list[tid];
+        int rank = 0;
+        for (int j = 0; j < total; ++j) rank += list[j] < k;
+        gfix[L.qkeys + 2 * rank] = (int)(unsigned)(k & 0xffffffffull);
+        gfix[L.qkeys + 2 * rank + 1] = (int)(unsigned)(k >> 32);
+    }
+    if (tid == 0) {
+        gfix[L.counts + CNT_Q] = total;
+        if (bad) gfix[L.counts + CNT_P0BAD] = 1;
+    }
+}
+
 // ---- scan -----------------------------------------------------------------------------------
 // One 1024-thread workgroup per scanned array (3 + 2 Fe arrays, independent), chunks of 1024
 // elements: coalesced load, wave-shuffle inclusive scan + 16 wave totals through LDS, running carry,
@@ -137,6 +213,10 @@ __global__ __launch_bounds__(1024) void compact_scan_kernel(int ns, int Fe, int*
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (a == 3 + 2 * Fe) {                                // the extra block: pass-0 feature classes
+        p0_classes(ns, Fe, gfix, L);
+        return;
+    }
     const int* src; int* dst; int* total;
     if (a == 0) { src = gfix + L.active; dst = gfix + L.cidx; total = gfix + L.counts + CNT_S; }
     else if (a == 1) { src = gfix + L.rowcnt; dst = gfix + L.seg_start; total = gfix + L.counts + CNT_E; }
@@ -184,6 +264,26 @@ __global__ __launch_bounds__(256) void compact_finish_kernel(int ns, int Fe, int
             gfix[L.cidx + slot] = S;
         }
     }
+    // pass-0: class of every sending slot (binary search in the sorted patterns), present (bond
+    // type, class) pairs and their lowest slot (the row the class's MLP input is gathered from)
+    if (slot < ns && gfix[L.nmsg + slot] > 0 && gfix[L.counts + CNT_P0BAD] == 0) {
+        const int Q = gfix[L.counts + CNT_Q];
+        const unsigned long long key = ((unsigned long long)(unsigned)gfix[L.key_hi + slot] << 32) |
+                                       (unsigned)gfix[L.key_lo + slot];
+        int lo = 0, hi = Q;                               // first pattern >= key
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const unsigned long long k = ((unsigned long long)(unsigned)gfix[L.qkeys + 2 * mid + 1] << 32) |
+                                         (unsigned)gfix[L.qkeys + 2 * mid];
+            if (k < key) lo = mid + 1; else hi = mid;
+        }
+        gfix[L.cls + slot] = lo;
+        for (int f = 0; f < Fe; ++f)
+            if (gfix[L.mflag_t + f * ns + slot]) {
+                gfix[L.present + f * P0Q + lo] = 1;
+                atomicMin(&gfix[L.rep + f * P0Q + lo], slot);
+            }
+    }
     if (slot == 0) {
         gfix[L.seg_off + S] = E; gfix[L.seg_off + S + 1] = E;
         gfix[L.src_off + S] = U; gfix[L.src_off + S + 1] = U;
@@ -196,13 +296,45 @@ __global__ __launch_bounds__(256) void compact_finish_kernel(int ns, int Fe, int
     }
 }
 
+// pass-0 rows: exclusive scan of the present (bond type, class) table in row order -> row ids,
+// per-type offsets, D0.  One workgroup, table in LDS.
+__global__ __launch_bounds__(1024) void compact_p0_kernel(int Fe, int* __restrict__ gfix, Lay L) {
+    __shared__ int pres[GI_MAX_GROUPS * P0Q];
+    __shared__ int toff[GI_MAX_GROUPS + 1];
+    const int tid = threadIdx.x, n = Fe * P0Q;
+    const bool bad = gfix[L.counts + CNT_P0BAD] != 0 || gfix[L.counts + CNT_E] == 0;
+    for (int i = tid; i < n; i += 1024) pres[i] = bad ? 0 : gfix[L.present + i];
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int f = 0; f < Fe; ++f) {
+            toff[f] = run;
+            for (int q = 0; q < P0Q; ++q) {
+                const int v = pres[f * P0Q + q];
+                pres[f * P0Q + q] = v ? run : -1;
+                run += v;
+            }
+        }
+        for (int f = Fe; f <= GI_MAX_GROUPS; ++f) toff[f] = run;
+        gfix[L.counts + CNT_D0] = run;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const int d = pres[i];
+        gfix[L.dmap + i] = d;
+        if (d >= 0) gfix[L.d_slot + d] = gfix[L.rep + i];
+    }
+    if (tid <= GI_MAX_GROUPS) gfix[L.type_off0 + tid] = toff[tid];
+}
+
 // ---- fill -----------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void compact_fill_kernel(
     const T* __restrict__ nodes, int N, int Fn, int Fe, const int* __restrict__ gfix, Lay L,
     int S, int E, int U, int* __restrict__ u_src, int* __restrict__ in_perm,
     int* __restrict__ mu_off, int* __restrict__ mu_dst, int* __restrict__ mu_slot,
-    int* __restrict__ out_perm, float* __restrict__ hx0, int ldhx, int H) {
+    int* __restrict__ out_perm, float* __restrict__ hx0, int ldhx, int H, int D0,
+    int* __restrict__ d_src, float* __restrict__ cmat, int ldc0) {
     __shared__ signed char typ[GI_MAX_NODES * GI_MAX_NODES];
     __shared__ int kpos[GI_MAX_NODES * GI_MAX_NODES];   // dst-CSR slot of edge (i <- j)
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -241,6 +373,25 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
         }
     }
     if (b == 0 && tid == 0) mu_off[U] = E;
+    if (D0 > 0) {
+        // pass-0 edge-count matrix: cmat[c_i, row(bond type, class of j)] = number of such edges
+        // into i.  A destination's row is zeroed and filled by the thread that owns the destination.
+        if (b == 0) {
+            for (int d = tid; d < D0; d += 256) d_src[d] = gfix[L.cidx + gfix[L.d_slot + d]];
+            for (int d = tid; d < ldc0; d += 256) cmat[(long long)S * ldc0 + d] = 0.f;
+        }
+        for (int i = tid; i < N; i += 256) {
+            const int slot = b * N + i;
+            if (!gfix[L.active + slot]) continue;
+            float* crow = cmat + (long long)gfix[L.cidx + slot] * ldc0;
+            for (int d = 0; d < ldc0; ++d) crow[d] = 0.f;
+            for (int j = 0; j < N; ++j) {
+                const int t = typ[i * N + j];
+                if (t < 0) continue;
+                crow[gfix[L.dmap + t * P0Q + gfix[L.cls + b * N + j]]] += 1.f;
+            }
+        }
+    }
     // initial node rows: hx0[c] = [x, 0 .. 0 | x]  (:121-126 zero-padded hidden state; the copy of
     // the raw features at columns [H, H+Fn) feeds the gather attention MLP, gnn/modules.py:45)
     for (int idx = tid; idx < N * ldhx; idx += 256) {
@@ -269,7 +420,7 @@ extern "C" int gi_compact_layout(int B, int N, int Fe, gi_compact_layout_t* out)
     out->total_ints = L.total;
     out->counts = L.counts; out->type_off = L.type_off; out->cidx = L.cidx;
     out->node_mask = L.node_mask; out->slot_of = L.slot_of; out->seg_off = L.seg_off;
-    out->src_off = L.src_off; out->scratch = L.scratch;
+    out->src_off = L.src_off; out->type_off0 = L.type_off0; out->scratch = L.scratch;
     return 0;
 }
 
@@ -289,31 +440,37 @@ extern "C" int gi_compact_count(const void* nodes, const void* edges, int in_dty
     else
         hipLaunchKernelGGL(compact_count_kernel<signed char>, dim3(B), dim3(256), 0, st,
                            (const signed char*)nodes, (const signed char*)edges, N, Fn, Fe, gfix, L);
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(3 + 2 * Fe), dim3(1024), 0, st, B * N, Fe, gfix, L);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(3 + 2 * Fe + 1), dim3(1024), 0, st, B * N, Fe, gfix,
+                       L);
     hipLaunchKernelGGL(compact_finish_kernel, dim3(gi_cdiv(B * N, 256)), dim3(256), 0, st, B * N, Fe,
                        gfix, L);
+    hipLaunchKernelGGL(compact_p0_kernel, dim3(1), dim3(1024), 0, st, Fe, gfix, L);
     return gi_launch_status();
 }
 
 extern "C" int gi_compact_fill(const void* nodes, int in_dtype, int B, int N, int Fn, int Fe,
                                const int* gfix, int S, int E, int U, int* u_src, int* in_perm,
                                int* mu_off, int* mu_dst, int* mu_slot, int* out_perm, float* hx0,
-                               int ldhx, int H, void* stream) {
+                               int ldhx, int H, int D0, int* d_src, float* cmat, int ldc0,
+                               void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (!nodes || !gfix || !hx0 || !mu_off || B <= 0 || N <= 0 || S < 0 || E < 0 || U < 0 || U > E)
         return GI_EINVAL;
     if (E > 0 && (!u_src || !in_perm || !mu_dst || !mu_slot || !out_perm)) return GI_EINVAL;
+    if (D0 < 0 || D0 > GI_MAX_GROUPS * GI_P0_MAX_CLASSES) return GI_EINVAL;
+    if (D0 > 0 && (!d_src || !cmat || ldc0 < D0 || (ldc0 & 3))) return GI_EINVAL;
     if (N > GI_MAX_NODES || Fe > GI_MAX_GROUPS) return GI_ELIMIT;
     if (ldhx < H + Fn || Fn > H) return GI_EINVAL;
     const Lay L = make_layout(B, N, Fe);
     if (in_dtype == GI_DTYPE_F32)
         hipLaunchKernelGGL(compact_fill_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream,
                            (const float*)nodes, N, Fn, Fe, gfix, L, S, E, U, u_src, in_perm, mu_off,
-                           mu_dst, mu_slot, out_perm, hx0, ldhx, H);
+                           mu_dst, mu_slot, out_perm, hx0, ldhx, H, D0, d_src, cmat, ldc0);
     else if (in_dtype == GI_DTYPE_I8)
         hipLaunchKernelGGL(compact_fill_kernel<signed char>, dim3(B), dim3(256), 0,
                            (hipStream_t)stream, (const signed char*)nodes, N, Fn, Fe, gfix, L, S, E,
-                           U, u_src, in_perm, mu_off, mu_dst, mu_slot, out_perm, hx0, ldhx, H);
+                           U, u_src, in_perm, mu_off, mu_dst, mu_slot, out_perm, hx0, ldhx, H, D0,
+                           d_src, cmat, ldc0);
     else
         return GI_EINVAL;
     return gi_launch_status();

@@ -78,7 +78,8 @@ int build_model(const gi_ggnn_dims* dp, Model& m) {
 
 // ---- workspace --------------------------------------------------------------------------------
 struct Ws {
-    int R, E, U, B;
+    int R, E, U, D0, B;
+    long long p0slab; int p0split;   // pass-0 shortcut: slabs of cmat^T . d agg
     int ldhx, ldH, ldM, ld3H, ldG, ldA, ldC, ldEh, ldAtt, ldEmb, ldM1, ldM2, ldNA, ldNC, ldCA,
         ldCC, ldZG, ldEa;
     long long hx[MAXP + 1];
@@ -98,10 +99,11 @@ struct Ws {
     long long total;
 };
 
-void make_ws(const Model& m, int S, int E, int U, Ws& w) {
+void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
     const gi_ggnn_dims& d = m.d;
     memset(&w, 0, sizeof(w));
     w.R = S + 1; w.E = E; w.U = U; w.B = d.B;
+    w.D0 = (d.kind == GI_KIND_GGNN && d.passes > 0) ? D0 : 0;   // sum aggregation only
     w.ldhx = gi_r4(d.H + d.Fn); w.ldH = gi_r4(d.H); w.ldM = gi_r4(d.M); w.ld3H = gi_r4(3 * d.H);
     w.ldG = gi_r4(d.G); w.ldA = gi_r4(d.A); w.ldC = gi_r4(d.C); w.ldEh = gi_r4(d.enn_hidden);
     w.ldAtt = gi_r4(d.att_hidden); w.ldEmb = gi_r4(d.emb_hidden); w.ldM1 = gi_r4(d.mlp1_hidden);
@@ -113,9 +115,11 @@ void make_ws(const Model& m, int S, int E, int U, Ws& w) {
     auto take = [&](long long rows, int ld) { long long r = o; o += gi_r4l(rows * ld); return r; };
     const long long R = w.R, B = d.B, Er = std::max(U, 1);   // message-row buffers
     for (int p = 0; p <= d.passes; ++p) w.hx[p] = take(R, w.ldhx);
+    const long long D0r = std::max(w.D0, 1);
     for (int p = 0; p < d.passes; ++p) {
-        for (int l = 0; l < d.enn_depth; ++l) w.eact[p][l] = take(Er, w.ldEh);
-        w.m[p] = take(Er, w.ldM);
+        const long long Ep = (p == 0 && w.D0 > 0) ? D0r : Er;       // pass 0 runs on the D0 class rows
+        for (int l = 0; l < d.enn_depth; ++l) w.eact[p][l] = take(Ep, w.ldEh);
+        w.m[p] = take(Ep, w.ldM);
         if (attn) {
             for (int l = 0; l < d.eatt_depth; ++l) w.aact[p][l] = take(Er, w.ldEa);
             w.een[p] = take(Er, w.ldM);
@@ -145,10 +149,17 @@ void make_ws(const Model& m, int S, int E, int U, Ws& w) {
     w.dh = take(R, w.ldH); w.dh2 = take(R, w.ldH); w.dxe = take(Er, w.ldH);
     w.dhb = take(R, w.ldH); w.dhc = take(R, w.ldH); w.dhd = take(R, w.ldH);
     for (int p = 0; p < d.passes; ++p) {
-        for (int l = 0; l < d.enn_depth; ++l) w.edz[p][l] = take(Er, w.ldEh);
+        const long long Ep = (p == 0 && w.D0 > 0) ? D0r : Er;
+        for (int l = 0; l < d.enn_depth; ++l) w.edz[p][l] = take(Ep, w.ldEh);
         if (attn)
             for (int l = 0; l < d.eatt_depth; ++l) w.adz[p][l] = take(Er, w.ldEa);
         w.dagg[p] = take(R, w.ldM);
+    }
+    if (w.D0 > 0) {          // split-K slabs of dm0 = cmat^T . dagg0: ~256 workgroups over the R rows
+        const int tiles = gi_cdiv(w.D0, 64) * gi_cdiv(d.M, 64);
+        const int kt = gi_cdiv((int)R, 32);
+        w.p0split = std::min(std::max(256 / tiles, 1), std::max(1, kt / 2));
+        w.p0slab = take((long long)w.p0split * gi_r4l(D0r * w.ldM), 1);
     }
     if (attn) {
         w.dxa = take(Er, w.ldH);
@@ -667,19 +678,23 @@ extern "C" int gi_ggnn_num_params(const gi_ggnn_dims* d) {
     return rc ? rc : m.nparams;
 }
 
-extern "C" long long gi_ggnn_workspace_floats(const gi_ggnn_dims* d, int S, int E, int U) {
+static bool sizes_ok(int S, int E, int U, int D0) {
+    return S >= 0 && E >= 0 && U >= 0 && U <= E && D0 >= 0 && D0 <= U;
+}
+
+extern "C" long long gi_ggnn_workspace_floats(const gi_ggnn_dims* d, int S, int E, int U, int D0) {
     Model m;
-    if (build_model(d, m) || S < 0 || E < 0 || U < 0 || U > E) return GI_EINVAL;
+    if (build_model(d, m) || !sizes_ok(S, E, U, D0)) return GI_EINVAL;
     Ws w;
-    make_ws(m, S, E, U, w);
+    make_ws(m, S, E, U, D0, w);
     return w.total;
 }
 
-extern "C" long long gi_ggnn_hx0_offset(const gi_ggnn_dims* d, int S, int E, int U) {
+extern "C" long long gi_ggnn_hx0_offset(const gi_ggnn_dims* d, int S, int E, int U, int D0) {
     Model m;
-    if (build_model(d, m) || S < 0 || E < 0 || U < 0 || U > E) return GI_EINVAL;
+    if (build_model(d, m) || !sizes_ok(S, E, U, D0)) return GI_EINVAL;
     Ws w;
-    make_ws(m, S, E, U, w);
+    make_ws(m, S, E, U, D0, w);
     return w.hx[0];
 }
 
@@ -702,14 +717,13 @@ extern "C" long long gi_ggnn_slab_floats(const gi_ggnn_dims* d, int S, int U, co
 }
 
 // Debug/test hook: offset (floats) and leading dimension of a named workspace buffer.
-extern "C" int gi_ggnn_ws_query(const gi_ggnn_dims* d, int S, int E, int U, const char* name, int i,
-                                int j, long long* off, int* ld) {
+extern "C" int gi_ggnn_ws_query(const gi_ggnn_dims* d, int S, int E, int U, int D0, const char* name,
+                                int i, int j, long long* off, int* ld) {
     Model m;
-    if (build_model(d, m) || S < 0 || E < 0 || U < 0 || U > E || !name || !off || !ld)
-        return GI_EINVAL;
+    if (build_model(d, m) || !sizes_ok(S, E, U, D0) || !name || !off || !ld) return GI_EINVAL;
     if (i < 0 || i > MAXP || j < 0 || j >= MAXL) return GI_EINVAL;
     Ws w;
-    make_ws(m, S, E, U, w);
+    make_ws(m, S, E, U, D0, w);
     struct Item { const char* n; long long o; int l; };
     const Item items[] = {
         {"hx", w.hx[i], w.ldhx}, {"eact", w.eact[i < MAXP ? i : 0][j], w.ldEh},
@@ -752,12 +766,15 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
     rc = gi_compact_layout(d.B, d.N, d.Fe, &L);
     if (rc) return rc;
     Ws w;
-    make_ws(m, S, E, U, w);
+    if (gp->D0 < 0 || gp->D0 > U || (gp->D0 > 0 && (!gp->d_src || !gp->cmat || gp->ldc0 < gp->D0)))
+        return GI_EINVAL;
+    make_ws(m, S, E, U, gp->D0, w);
     Run r{(hipStream_t)stream, params, 0};
     const int R = w.R;
     int maxUt = 0;
     for (int t = 0; t < d.Fe; ++t) maxUt = std::max(maxUt, Ut[t]);
     const Grp bytype{d.Fe, gfix + L.type_off, maxUt};
+    const Grp bytype0{d.Fe, gfix + L.type_off0, w.D0};   // pass-0 rows (upper bound per type: all)
     const int* seg_off = gfix + L.seg_off;
     const int* cidx = gfix + L.cidx;
     const int* mask = gfix + L.node_mask;
@@ -777,6 +794,18 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
             }
             r.chk(gi_seg_softmax_fwd(ws + w.een[p], ws + w.m[p], w.ldM, in_perm, seg_off, R, d.M,
                                      ws + w.agg[p], w.ldM, r.st));
+        } else if (p == 0 && w.D0 > 0) {
+            // pass 0: h = [x | 0], one message row per (feature class, bond type); a_v = cmat . m0
+            mlp_forward(r, ws, m.msg, bytype0, hx, w.ldhx, gp->d_src, w.D0, w.eact[0], w.ldEh,
+                        ws + w.m[0], w.ldM);
+            if (r.ok()) {
+                gi_gemm_params q;
+                gemm_defaults(q);
+                q.A = gp->cmat; q.lda = gp->ldc0; q.B = ws + w.m[0]; q.ldb = w.ldM; q.b_major = 1;
+                q.C = ws + w.agg[0]; q.ldc = w.ldM; q.M = R; q.N = d.M; q.K = w.D0;
+                q.tm = 1; q.tn = 1;
+                r.chk(gi_gemm(&q, r.st));
+            }
         } else {
             if (E > 0)   // m_u = MLP_type(u)(h_src(u)), gnn/mpnn.py:284-294, once per message row
                 mlp_forward(r, ws, m.msg, bytype, hx, w.ldhx, u_src, U, w.eact[p], w.ldEh,
@@ -851,9 +880,12 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
     rc = gi_compact_layout(d.B, d.N, d.Fe, &L);
     if (rc) return rc;
     Ws w;
-    make_ws(m, S, E, U, w);
+    if (gp->D0 < 0 || gp->D0 > U || (gp->D0 > 0 && (!gp->d_src || !gp->cmat || gp->ldc0 < gp->D0)))
+        return GI_EINVAL;
+    make_ws(m, S, E, U, gp->D0, w);
     SlabPlan sp;
     plan_slabs(m, S, U, Ut, sp);
+    const Grp bytype0{d.Fe, gfix + L.type_off0, w.D0};
     Run r{(hipStream_t)stream, params, 0};
     const int R = w.R;
     int maxUt = 0;
@@ -969,6 +1001,22 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
                 r.chk(gi_seg_sum(ws + w.dxe, w.ldH, out_perm, src_off, R, d.H, dh2, w.ldH, 1, r.st));
                 r.chk(gi_seg_sum(ws + w.dxa, w.ldH, out_perm, src_off, R, d.H, dh2, w.ldH, 1, r.st));
             }
+        } else if (p == 0 && w.D0 > 0) {
+            // pass 0: d m0 = selu'(m0) * (cmat^T . d agg): split-K over the R rows, slabs summed with
+            // the SELU backward folded in; then the MLP backward on the D0 class rows (no d h needed)
+            gi_gemm_params q;
+            gemm_defaults(q);
+            q.A = gp->cmat; q.lda = gp->ldc0; q.a_major = 1;
+            q.B = dagg; q.ldb = w.ldM; q.b_major = 1;
+            q.C = ws + w.p0slab; q.ldc = w.ldM; q.M = w.D0; q.N = d.M; q.K = R;
+            q.flags = GI_GEMM_SPLITK; q.nsplit = w.p0split;
+            q.c_split_stride = gi_r4l((long long)std::max(w.D0, 1) * w.ldM);
+            q.tm = 1; q.tn = 1;
+            r.chk(gi_gemm(&q, r.st));
+            r.chk(gi_slab_sum_dselu(ws + w.p0slab, w.p0split, q.c_split_stride, w.D0, d.M, w.ldM,
+                                    ws + w.m[0], w.ldM, r.st));
+            msg_backward(r, ws, sp, slabs, dq, m.msg, bytype0, hx, w.ldhx, gp->d_src, w.D0, w.eact[0],
+                         w.edz[0], w.ldEh, ws + w.m[0], w.ldM, nullptr, w.ldH, d.H);
         } else if (E > 0) {
             // d m_u = selu'(m_u) * sum over the edges reading row u of d agg[dst(e)]
             // (backward of the segmented sum + last SELU, over the message CSR)

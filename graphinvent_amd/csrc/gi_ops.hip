@@ -61,6 +61,19 @@ __global__ __launch_bounds__(256) void seg_sum_dselu_kernel(
     *dst = acc * v4f{gi_selu_grad(yv.x), gi_selu_grad(yv.y), gi_selu_grad(yv.z), gi_selu_grad(yv.w)};
 }
 
+// y[r, c] = selu'(y[r, c]) * sum_s slabs[s * stride + r * ld + c]   (pass-0 shortcut, tiny)
+__global__ __launch_bounds__(256) void slab_sum_dselu_kernel(const float* __restrict__ slabs,
+                                                             int nsplit, long long stride, int rows,
+                                                             int cols, int ld, float* y, int ldy) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int r = t / cols, c = t - r * cols;
+    if (r >= rows) return;
+    float acc = 0.f;
+    for (int s = 0; s < nsplit; ++s) acc += slabs[s * stride + (long long)r * ld + c];
+    float* dst = y + (long long)r * ldy + c;
+    *dst = acc * gi_selu_grad(*dst);
+}
+
 // ---- AttGGNN attention aggregation (gnn/mpnn.py:370-389) ------------------------------------------
 // One thread per (destination row, 16-byte feature group).  The reference pads every node's
 // neighbour list to the batch's maximum degree and masks with -1e6; here the softmax runs over the
@@ -558,6 +571,17 @@ extern "C" int gi_seg_sum_dselu(const float* vals, int ldv, const int* perm, con
     GiProfScope prof((hipStream_t)stream, GI_PROF_SEGSUM, 0.0);
     hipLaunchKernelGGL(seg_sum_dselu_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, vals, ldv, perm, off, rows, c4n, y, ldy);
+    return gi_launch_status();
+}
+
+extern "C" int gi_slab_sum_dselu(const float* slabs, int nsplit, long long stride, int rows, int cols,
+                                 int ld, float* y, int ldy, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
+    if (rows <= 0 || cols <= 0) return 0;
+    if (!slabs || !y || nsplit < 1 || ld < cols || ldy < cols) return GI_EINVAL;
+    const long long threads = (long long)rows * cols;
+    hipLaunchKernelGGL(slab_sum_dselu_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, slabs, nsplit, stride, rows, cols, ld, y, ldy);
     return gi_launch_status();
 }
 

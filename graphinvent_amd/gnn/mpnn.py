@@ -62,7 +62,9 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN):
     """graph_compact + the fused forward.  Returns (logits, tape); the tape
     (dims, CompactGraph, workspace, per-type edge counts) is what backward consumes."""
     lib = _L.load()
-    nodes, lay, gfix, S, E, U, Ut = _ops.compact_count(nodes, edges)
+    nodes, lay, gfix, S, E, U, D0, Ut = _ops.compact_count(nodes, edges)
+    if kind != _L.KIND_GGNN:
+        D0 = 0                          # the pass-0 shortcut needs a linear (sum) aggregation
     B = nodes.shape[0]
     dims = _dims_from_constants(consts, B, kind)
     if lib.gi_ggnn_num_params(C.byref(dims)) != len(params):
@@ -72,13 +74,13 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN):
             raise RuntimeError("GGNN parameters must be contiguous fp32 CUDA tensors "
                                "(call model.to('cuda'))")
     dev = nodes.device
-    n_ws = lib.gi_ggnn_workspace_floats(C.byref(dims), S, E, U)
+    n_ws = lib.gi_ggnn_workspace_floats(C.byref(dims), S, E, U, D0)
     if n_ws < 0:
         _L.check(int(n_ws), "gi_ggnn_workspace_floats")
     ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
     ldhx = lib.gi_ggnn_ldhx(C.byref(dims))
-    hx0 = ws[lib.gi_ggnn_hx0_offset(C.byref(dims), S, E, U):]
-    graph = _ops.compact_fill(nodes, lay, gfix, S, E, U, Ut, hx0, ldhx, dims.H)
+    hx0 = ws[lib.gi_ggnn_hx0_offset(C.byref(dims), S, E, U, D0):]
+    graph = _ops.compact_fill(nodes, lay, gfix, S, E, U, D0, Ut, hx0, ldhx, dims.H)
     apd = dims.N * dims.A + dims.N * dims.C + 1
     out = torch.empty((B, apd), dtype=torch.float32, device=dev)
     gs = graph.c_struct()

@@ -36,7 +36,7 @@ cll = C.c_longlong
 
 class CompactLayout(C.Structure):
     _fields_ = [(n, ci) for n in ("total_ints", "counts", "type_off", "cidx", "node_mask",
-                                  "slot_of", "seg_off", "src_off", "scratch")]
+                                  "slot_of", "seg_off", "src_off", "type_off0", "scratch")]
 
 
 class GemmParams(C.Structure):
@@ -60,7 +60,7 @@ class Graph(C.Structure):
     """gi_graph: the compacted graph as the fused model calls take it."""
     _fields_ = [("S", ci), ("E", ci), ("U", ci), ("gfix", vp), ("u_src", vp), ("in_perm", vp),
                 ("mu_off", vp), ("mu_dst", vp), ("mu_slot", vp), ("out_perm", vp),
-                ("Ut", C.POINTER(ci))]
+                ("Ut", C.POINTER(ci)), ("D0", ci), ("ldc0", ci), ("d_src", vp), ("cmat", vp)]
 
 
 class GgnnDims(C.Structure):
@@ -77,13 +77,14 @@ SIGNATURES = {
     "gi_compact_layout": (ci, [ci, ci, ci, C.POINTER(CompactLayout)]),
     "gi_compact_count": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp]),
     "gi_compact_fill": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci,
-                             ci, vp]),
+                             ci, ci, vp, vp, ci, vp]),
     "gi_gemm": (ci, [C.POINTER(GemmParams), vp]),
     "gi_gemm_batch": (ci, [C.POINTER(GemmParams), ci, vp]),
     "gi_seg_sum": (ci, [vp, ci, vp, vp, ci, ci, vp, ci, ci, vp]),
     "gi_seg_softmax_fwd": (ci, [vp, vp, ci, vp, vp, ci, ci, vp, ci, vp]),
     "gi_seg_softmax_bwd": (ci, [vp, vp, ci, vp, vp, ci, ci, vp, ci, vp, vp, ci, vp]),
     "gi_seg_sum_dselu": (ci, [vp, ci, vp, vp, ci, ci, vp, ci, vp]),
+    "gi_slab_sum_dselu": (ci, [vp, ci, cll, ci, ci, ci, vp, ci, vp]),
     "gi_selu_bwd_rows": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, vp]),
     "gi_gru_gates_fwd": (ci, [vp, vp, ci, vp, vp, ci, vp, ci, ci, ci, vp]),
     "gi_gru_gates_bwd": (ci, [vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, vp]),
@@ -105,11 +106,11 @@ SIGNATURES = {
     "gi_side_stream_create": (ci, [C.POINTER(vp)]),
     "gi_side_stream_destroy": (ci, [vp]),
     "gi_ggnn_num_params": (ci, [C.POINTER(GgnnDims)]),
-    "gi_ggnn_workspace_floats": (cll, [C.POINTER(GgnnDims), ci, ci, ci]),
+    "gi_ggnn_workspace_floats": (cll, [C.POINTER(GgnnDims), ci, ci, ci, ci]),
     "gi_ggnn_slab_floats": (cll, [C.POINTER(GgnnDims), ci, ci, C.POINTER(ci)]),
-    "gi_ggnn_hx0_offset": (cll, [C.POINTER(GgnnDims), ci, ci, ci]),
+    "gi_ggnn_hx0_offset": (cll, [C.POINTER(GgnnDims), ci, ci, ci, ci]),
     "gi_ggnn_ldhx": (ci, [C.POINTER(GgnnDims)]),
-    "gi_ggnn_ws_query": (ci, [C.POINTER(GgnnDims), ci, ci, ci, C.c_char_p, ci, ci,
+    "gi_ggnn_ws_query": (ci, [C.POINTER(GgnnDims), ci, ci, ci, ci, C.c_char_p, ci, ci,
                               C.POINTER(cll), C.POINTER(ci)]),
     "gi_ggnn_forward": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), C.POINTER(Graph), vp, vp, ci, vp]),
     "gi_ggnn_backward": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), C.POINTER(Graph), vp, vp, vp, ci,

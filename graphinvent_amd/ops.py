@@ -59,10 +59,12 @@ class CompactGraph:
     S: int                      # active node slots (compact rows 0..S-1; row S = zero row)
     E: int                      # directed edges
     U: int                      # message rows = distinct (source slot, bond type) pairs
+    D0: int                     # pass-0 rows = present (feature class, bond type) pairs; 0 = off
     Ut: Sequence[int]           # message rows per bond type
     layout: L.CompactLayout
     gfix: torch.Tensor          # int32, fixed-size part (see include/graphinvent_amd.h)
-    gvar: torch.Tensor          # int32, variable-size part: u_src | in_perm | mu_off | mu_dst | mu_slot | out_perm
+    gvar: torch.Tensor          # int32, variable-size part: u_src | in_perm | mu_off | mu_dst | mu_slot | out_perm | d_src
+    cmat: Optional[torch.Tensor] = None   # fp32 [S+1, ldc0] pass-0 edge-count matrix
 
     def view(self, name: str, n: int) -> torch.Tensor:
         o = getattr(self.layout, name)
@@ -73,7 +75,7 @@ class CompactGraph:
 
     @property
     def _offs(self):
-        return _gvar_offsets(self.E, self.U)[0]
+        return _gvar_offsets(self.E, self.U, self.D0)[0]
 
     @property
     def u_src(self): return self._var(0, self.U)
@@ -87,6 +89,10 @@ class CompactGraph:
     def mu_slot(self): return self._var(4, self.E)
     @property
     def out_perm(self): return self._var(5, self.U)
+    @property
+    def d_src(self): return self._var(6, self.D0)
+    @property
+    def type_off0(self): return self.view("type_off0", self.Fe + 1)
     @property
     def cidx(self): return self.view("cidx", self.B * self.N)
     @property
@@ -106,16 +112,20 @@ class CompactGraph:
         g.S, g.E, g.U = self.S, self.E, self.U
         g.gfix = self.gfix.data_ptr()
         base, offs = self.gvar.data_ptr(), self._offs
-        g.u_src, g.in_perm, g.mu_off, g.mu_dst, g.mu_slot, g.out_perm = (base + 4 * o for o in offs)
+        (g.u_src, g.in_perm, g.mu_off, g.mu_dst, g.mu_slot, g.out_perm,
+         g.d_src) = (base + 4 * o for o in offs)
+        g.D0 = self.D0
+        g.ldc0 = r4(self.D0)
+        g.cmat = self.cmat.data_ptr() if self.D0 > 0 else None
         g._ut = (C.c_int * self.Fe)(*self.Ut)
         g.Ut = g._ut
         return g
 
 
-def _gvar_offsets(E: int, U: int):
+def _gvar_offsets(E: int, U: int, D0: int = 0):
     """Offsets (ints, 16-byte aligned) of u_src[U], in_perm[E], mu_off[U+1], mu_dst[E], mu_slot[E],
-    out_perm[U] inside the variable-size index buffer, and its total length."""
-    sizes = (U, E, U + 1, E, E, U)
+    out_perm[U], d_src[D0] inside the variable-size index buffer, and its total length."""
+    sizes = (U, E, U + 1, E, E, U, D0)
     offs, o = [], 0
     for n in sizes:
         offs.append(o)
@@ -144,12 +154,12 @@ def _count_launch(nodes: torch.Tensor, edges: torch.Tensor):
 
 
 def _unpack_counts(counts, Fe: int):
-    S, E, err, U = counts[0], counts[1], counts[2], counts[3]
+    S, E, err, U, D0 = counts[0], counts[1], counts[2], counts[3], counts[20]
     if err:
         raise ValueError("edges tensor violates the preprocessed-HDF contract: every bonded pair "
                          "must carry exactly one one-hot bond type (DataProcesser.py / "
                          "MolecularGraph.py edge features)")
-    return S, E, U, counts[4:4 + Fe]
+    return S, E, U, D0, counts[4:4 + Fe]
 
 
 # ---- compaction one batch ahead -------------------------------------------------------------------
@@ -199,7 +209,7 @@ def prefetch_compact(nodes: torch.Tensor, edges: torch.Tensor,
 
 
 def compact_count(nodes: torch.Tensor, edges: torch.Tensor):
-    """Phase 1; returns (nodes, layout, gfix, S, E, U, Ut).  One host read-back of 24 ints — the only
+    """Phase 1; returns (nodes, layout, gfix, S, E, U, D0, Ut).  One host read-back of 24 ints — the only
     synchronisation point of a forward pass, unless `prefetch_compact` already ran for this batch."""
     hit = _PREFETCHED.pop(_batch_key(nodes, edges), None) if _PREFETCHED else None
     if hit is not None:
@@ -215,26 +225,30 @@ def compact_count(nodes: torch.Tensor, edges: torch.Tensor):
     return (nodes, lay, gfix) + _unpack_counts(counts, Fe)
 
 
-def compact_fill(nodes, lay, gfix, S, E, U, Ut, hx0: torch.Tensor, ldhx: int, H: int) -> CompactGraph:
+def compact_fill(nodes, lay, gfix, S, E, U, D0, Ut, hx0: torch.Tensor, ldhx: int,
+                 H: int) -> CompactGraph:
     lib = L.load()
     B, N, Fn = nodes.shape
     Fe = len(Ut)
-    offs, total = _gvar_offsets(E, U)
+    offs, total = _gvar_offsets(E, U, D0)
     gvar = torch.empty(total, dtype=torch.int32, device=nodes.device)
+    ldc0 = r4(D0)
+    cmat = torch.empty((S + 1, ldc0), dtype=torch.float32, device=nodes.device) if D0 > 0 else None
     dt = L.DTYPE_I8 if nodes.dtype == torch.int8 else L.DTYPE_F32
     base = gvar.data_ptr()
+    ptrs = [base + 4 * o for o in offs]
     L.check(lib.gi_compact_fill(nodes.data_ptr(), dt, B, N, Fn, Fe, gfix.data_ptr(), S, E, U,
-                                *(base + 4 * o for o in offs), hx0.data_ptr(), ldhx, H, _stream()),
-            "gi_compact_fill")
-    return CompactGraph(B, N, Fn, Fe, S, E, U, list(Ut), lay, gfix, gvar)
+                                *ptrs[:6], hx0.data_ptr(), ldhx, H, D0, ptrs[6], _ptr(cmat), ldc0,
+                                _stream()), "gi_compact_fill")
+    return CompactGraph(B, N, Fn, Fe, S, E, U, D0, list(Ut), lay, gfix, gvar, cmat)
 
 
 def compact(nodes: torch.Tensor, edges: torch.Tensor, H: int):
     """Both phases; returns (CompactGraph, hx0[S+1, ldhx])."""
-    nodes, lay, gfix, S, E, U, Ut = compact_count(nodes, edges)
+    nodes, lay, gfix, S, E, U, D0, Ut = compact_count(nodes, edges)
     ldhx = r4(H + nodes.shape[2])
     hx0 = torch.empty((S + 1, ldhx), dtype=torch.float32, device=nodes.device)
-    g = compact_fill(nodes, lay, gfix, S, E, U, Ut, hx0, ldhx, H)
+    g = compact_fill(nodes, lay, gfix, S, E, U, D0, Ut, hx0, ldhx, H)
     return g, hx0
 
 
@@ -287,10 +301,12 @@ def reduce_slabs(items):
     L.check(L.load().gi_reduce_slabs(arr, len(items), _stream()), "gi_reduce_slabs")
 
 
-def ws_view(ws: torch.Tensor, dims, S: int, E: int, U: int, name: str, rows: int, i: int = 0,
+def ws_view(ws: torch.Tensor, dims, graph: "CompactGraph", name: str, rows: int, i: int = 0,
             j: int = 0):
     """Test/debug: a [rows, ld] view of a named workspace buffer (gi_ggnn_ws_query)."""
     off, ld = C.c_longlong(), C.c_int()
-    L.check(L.load().gi_ggnn_ws_query(C.byref(dims), S, E, U, name.encode(), i, j, C.byref(off),
+    D0 = graph.D0 if dims.kind == L.KIND_GGNN else 0
+    L.check(L.load().gi_ggnn_ws_query(C.byref(dims), graph.S, graph.E, graph.U, D0, name.encode(), i,
+                                      j, C.byref(off),
                                       C.byref(ld)), f"gi_ggnn_ws_query({name})")
     return ws[off.value:off.value + rows * ld.value].view(rows, ld.value)

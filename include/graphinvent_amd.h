@@ -28,6 +28,7 @@ extern "C" {
 #define GI_ABI_VERSION 2
 #define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
 #define GI_MAX_NODES 128      /* max max_n_nodes */
+#define GI_P0_MAX_CLASSES 256 /* max distinct node feature rows for the pass-0 shortcut */
 
 #define GI_DTYPE_F32 0        /* element type of model INPUTS (nodes, edges, APD targets): fp32 ... */
 #define GI_DTYPE_I8  1        /* ... or the int8 the preprocessed HDF stores (DataProcesser.py:157-161) */
@@ -49,7 +50,7 @@ int gi_abi_version(void);
  * Layout of the fixed-size int32 index buffer `gfix` (offsets in ints, from gi_compact_layout):
  *   counts[GI_COUNTS]  [0]=S active node slots, [1]=E directed edges, [2]=error flag (an edge whose
  *                feature vector is not one-hot), [3]=U message rows, [4+t]=message rows of bond
- *                type t, [12+t]=edges of bond type t
+ *                type t, [12+t]=edges of bond type t, [20]=D0 pass-0 rows (0 = shortcut off)
  *   type_off[GI_MAX_GROUPS+1] (message rows per bond type, prefix), cidx[B*N] (slot -> compact row,
  *   S for inactive slots), node_mask[B*N] (1 if the slot has >=1 incoming edge), slot_of[B*N],
  *   seg_off[B*N+2] (dst-CSR over compact rows: row c's incoming edges are slots
@@ -61,11 +62,16 @@ int gi_abi_version(void);
  *   mu_off[U+1], mu_dst[E], mu_slot[E]   message row -> its edges: destination compact row and
  *               dst-CSR slot of each, ascending destination (backward of the aggregation)
  *   out_perm[U] message rows grouped by source compact row, inside a row by bond type
+ * PASS-0 ROWS.  At the first message pass h = [x | 0..0], so a message row depends only on (feature
+ * row of its source, bond type): D0 rows (atom type x charge x bond type; counts[20]), bond-type-
+ * major with offsets type_off0[GI_MAX_GROUPS+1] in gfix.  d_src[D0] = a compact row of each class
+ * (the MLP's gather index); cmat[S+1, ldc0] fp32 = number of edges into each compact row from each
+ * pass-0 row, so that the pass-0 aggregation is cmat . m0 and its backward cmat^T . d agg.
  * ------------------------------------------------------------------------------------------ */
 #define GI_COUNTS 24
 typedef struct gi_compact_layout_t {
     int total_ints;
-    int counts, type_off, cidx, node_mask, slot_of, seg_off, src_off, scratch;
+    int counts, type_off, cidx, node_mask, slot_of, seg_off, src_off, type_off0, scratch;
 } gi_compact_layout_t;
 
 int gi_compact_layout(int B, int N, int Fe, gi_compact_layout_t* out);
@@ -78,7 +84,8 @@ int gi_compact_count(const void* nodes, const void* edges, int in_dtype, int B, 
  * again in [H, H+Fn) (row S = 0). */
 int gi_compact_fill(const void* nodes, int in_dtype, int B, int N, int Fn, int Fe, const int* gfix,
                     int S, int E, int U, int* u_src, int* in_perm, int* mu_off, int* mu_dst,
-                    int* mu_slot, int* out_perm, float* hx0, int ldhx, int H, void* stream);
+                    int* mu_slot, int* out_perm, float* hx0, int ldhx, int H, int D0, int* d_src,
+                    float* cmat, int ldc0, void* stream);
 
 /* The compacted graph as the fused model calls take it. */
 typedef struct gi_graph {
@@ -87,6 +94,9 @@ typedef struct gi_graph {
     const int* u_src; const int* in_perm; const int* mu_off; const int* mu_dst; const int* mu_slot;
     const int* out_perm;
     const int* Ut;            /* HOST array [Fe]: message rows per bond type (counts[4..4+Fe)) */
+    int D0, ldc0;             /* pass-0 rows (0 = shortcut off) and leading dimension of cmat */
+    const int* d_src;         /* [D0] */
+    const float* cmat;        /* [S+1, ldc0] */
 } gi_graph;
 
 /* ------------------------------------------------------------------------------------------
@@ -139,6 +149,11 @@ int gi_seg_sum(const float* vals, int ldv, const int* perm, const int* off, int 
  * last layer, in place:  y[u, c] = selu'(y[u, c]) * sum_{k in [off[u], off[u+1])} vals[perm[k], c] */
 int gi_seg_sum_dselu(const float* vals, int ldv, const int* perm, const int* off, int rows, int cols,
                      float* y, int ldy, void* stream);
+
+/* y[r, c] = selu'(y[r, c]) * sum_{s < nsplit} slabs[s * stride + r * ld + c]: sums the split-K slabs
+ * of the pass-0 aggregation backward (cmat^T . d agg) with the SELU backward folded in. */
+int gi_slab_sum_dselu(const float* slabs, int nsplit, long long stride, int rows, int cols, int ld,
+                      float* y, int ldy, void* stream);
 
 /* Attention aggregation of AttentionGGNN — replaces `aggregate_message` (gnn/mpnn.py:370-389:
  * mask, Softmax(dim=1) over the padded neighbour axis, weighted sum) on the destination CSR:
@@ -272,17 +287,17 @@ int gi_side_stream_create(void** stream);
 int gi_side_stream_destroy(void* stream);
 
 int gi_ggnn_num_params(const gi_ggnn_dims* d);
-/* S active slots, E directed edges, U message rows (counts[0], [1], [3]) */
-long long gi_ggnn_workspace_floats(const gi_ggnn_dims* d, int S, int E, int U);
+/* S active slots, E directed edges, U message rows, D0 pass-0 rows (counts[0], [1], [3], [20]) */
+long long gi_ggnn_workspace_floats(const gi_ggnn_dims* d, int S, int E, int U, int D0);
 long long gi_ggnn_slab_floats(const gi_ggnn_dims* d, int S, int U, const int* Ut);
 /* ws must hold hx0 (from gi_compact_fill) at offset gi_ggnn_hx0_offset(); forward keeps every
  * activation in ws for backward. */
-long long gi_ggnn_hx0_offset(const gi_ggnn_dims* d, int S, int E, int U);
+long long gi_ggnn_hx0_offset(const gi_ggnn_dims* d, int S, int E, int U, int D0);
 int gi_ggnn_ldhx(const gi_ggnn_dims* d);
 /* test/debug hook: offset (floats) and leading dimension of a named workspace buffer
  * ("hx" i=pass, "eact" i=pass j=layer, "m","agg","gi","gh" i=pass, "att_act" j=layer, "en", ...) */
-int gi_ggnn_ws_query(const gi_ggnn_dims* d, int S, int E, int U, const char* name, int i, int j,
-                     long long* off, int* ld);
+int gi_ggnn_ws_query(const gi_ggnn_dims* d, int S, int E, int U, int D0, const char* name, int i,
+                     int j, long long* off, int* ld);
 int gi_ggnn_forward(const gi_ggnn_dims* d, const float* const* params, const gi_graph* g,
                     float* ws, float* out, int ldout, void* stream);
 /* consumes (overwrites) the activations in ws; y_out = the logits forward returned; grads[i]

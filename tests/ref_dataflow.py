@@ -24,6 +24,9 @@ SELU_SCALE = 1.0507009873554804934193349852946
 # ---------------------------------------------------------------------------------------------
 # graph_compact  (integer work: bit-exact reference for gi_compact_*)
 # ---------------------------------------------------------------------------------------------
+P0_MAX = 256     # GI_P0_MAX_CLASSES
+
+
 def compact(nodes: np.ndarray, edges: np.ndarray) -> Dict[str, np.ndarray]:
     """nodes [B,N,Fn], edges [B,N,N,Fe] (any numeric dtype, one-hot bond types).
 
@@ -80,7 +83,34 @@ def compact(nodes: np.ndarray, edges: np.ndarray) -> Dict[str, np.ndarray]:
     np.add.at(src_off, u_src + 1, 1)
     src_off = np.cumsum(src_off).astype(np.int32)
     node_mask = (rowcnt > 0).astype(np.uint8)
-    return dict(S=S, E=E, U=U, err=err, cidx=cidx, slot_of=slot_of, u_src=u_src,
+    # ---- pass-0 message rows -------------------------------------------------------------------
+    # At the first message pass h = [x | 0 .. 0] (gnn/summation_mpnn.py:121-126), so a message row
+    # depends only on (feature row of its source, bond type): D0 distinct rows, a few dozen on
+    # molecular graphs (atom type x formal charge x bond type).  Classes = distinct 0/1 feature rows
+    # of the source slots, ordered by their bit pattern (bit f = feature f); rows = present (bond
+    # type, class) pairs, bond-type-major.  The pass-0 aggregation is then agg = cmat @ m0 with the
+    # [R, D0] matrix of edge counts.  Disabled (D0 = 0) when features are not 0/1, Fn > 62, more than
+    # P0_MAX classes, or no edges.
+    feat = nodes.reshape(B * N, Fn)
+    D0, d_src, type_off0, cmat = 0, np.zeros(0, np.int32), np.zeros(Fe + 1, np.int32), None
+    binary = bool(np.all((feat == 0) | (feat == 1))) and Fn <= 62
+    if binary and E > 0:
+        keys = (feat != 0).astype(np.uint64) @ (np.uint64(1) << np.arange(Fn, dtype=np.uint64))
+        u_slot = ukeys % (B * N)
+        qkeys = np.unique(keys[u_slot])
+        if qkeys.size <= P0_MAX:
+            cls = np.searchsorted(qkeys, keys[u_slot])
+            dkeys, u2d = np.unique(u_type * P0_MAX + cls, return_inverse=True)
+            D0 = int(dkeys.size)
+            type_off0 = np.concatenate([[0], np.cumsum(np.bincount(dkeys // P0_MAX, minlength=Fe))]
+                                       ).astype(np.int32)
+            rep = np.full(D0, B * N, dtype=np.int64)
+            np.minimum.at(rep, u2d, u_slot)                              # lowest slot of the class
+            d_src = cidx[rep].astype(np.int32)
+            cmat = np.zeros((R, D0), dtype=np.float32)
+            np.add.at(cmat, (dst_c, u2d[in_perm]), 1.0)
+    return dict(S=S, E=E, U=U, D0=D0, d_src=d_src, type_off0=type_off0, cmat=cmat,
+                err=err, cidx=cidx, slot_of=slot_of, u_src=u_src,
                 in_perm=in_perm.astype(np.int32), seg_off=seg_off, mu_off=mu_off, mu_dst=mu_dst,
                 mu_slot=mu_slot, out_perm=out_perm, src_off=src_off, type_off=type_off,
                 node_mask=node_mask)
@@ -258,15 +288,18 @@ def forward(P, cfg, nodes, edges, keep=False, model="GGNN"):
     h[:, :Fn] = x
     has_edge = (T["seg_off"][1:R + 1] - T["seg_off"][:R]) > 0
     tape = dict(g=g, T=T, x=x, has_edge=has_edge, passes=[])
-    for _ in range(cfg["message_passes"]):
+    for pi in range(cfg["message_passes"]):
+        # pass 0 of the sum-aggregating model runs on the D0 (feature class, bond type) rows
+        p0 = pi == 0 and not attn and g["D0"] > 0
+        rows, toff, src = (g["D0"], g["type_off0"], T["d_src"]) if p0 else (U, g["type_off"], T["u_src"])
         acts_t = []
-        m = torch.zeros(U, M, dtype=dtype)           # one row per (source node, bond type)
+        m = torch.zeros(rows, M, dtype=dtype)        # one row per (source node | class, bond type)
         for t in range(Fe):
-            lo, hi = int(g["type_off"][t]), int(g["type_off"][t + 1])
-            a = mlp_fwd(P, f"msg_nns.{t}", h, idx=T["u_src"][lo:hi].long())
+            lo, hi = int(toff[t]), int(toff[t + 1])
+            a = mlp_fwd(P, f"msg_nns.{t}", h, idx=src[lo:hi].long())
             acts_t.append(a)
             m[lo:hi] = a[-1]
-        ps_extra = {}
+        ps_extra = dict(p0=p0)
         if attn:      # second per-bond-type MLP gives the attention energies
             aacts_t = []
             en_e = torch.zeros(U, M, dtype=dtype)
@@ -276,7 +309,9 @@ def forward(P, cfg, nodes, edges, keep=False, model="GGNN"):
                 aacts_t.append(a)
                 en_e[lo:hi] = a[-1]
             agg, att_e = seg_softmax_sum(en_e, m, T["in_perm"], T["seg_off"], R)
-            ps_extra = dict(aacts_t=aacts_t, en_e=en_e, att_e=att_e)
+            ps_extra = dict(p0=False, aacts_t=aacts_t, en_e=en_e, att_e=att_e)
+        elif p0:
+            agg = T["cmat"].to(dtype) @ m                # edge-count matrix [R, D0]
         else:
             agg = seg_sum(m, T["in_perm"], T["seg_off"], R)
         gi = linear(agg, P["gru.weight_ih"], P["gru.bias_ih"], False)
@@ -347,8 +382,16 @@ def backward(P, cfg, tape, d_out) -> Dict[str, torch.Tensor]:
         grads["gru.bias_hh"] = grads.get("gru.bias_hh", 0) + dgh.sum(0)
         dagg = dgi @ P["gru.weight_ih"]
         dh_prev = dh_prev + dgh @ P["gru.weight_hh"]
-        dxe = torch.zeros(g["U"], H, dtype=d_out.dtype)
         U = g["U"]
+        if ps["p0"]:
+            dm = (T["cmat"].to(d_out.dtype).t() @ dagg) * selu_grad_from_out(ps["m"])
+            for t in range(Fe):
+                lo, hi = int(g["type_off0"][t]), int(g["type_off0"][t + 1])
+                mlp_bwd(P, f"msg_nns.{t}", ps["h_prev"], ps["acts_t"][t], dm[lo:hi], grads,
+                        idx=T["d_src"][lo:hi].long(), need_dx=False)
+            dh = dh_prev
+            continue
+        dxe = torch.zeros(g["U"], H, dtype=d_out.dtype)
         if tape["attn"]:
             den, demb = seg_softmax_sum_bwd(dagg, ps["att_e"], ps["en_e"], ps["m"], T["in_perm"],
                                             T["seg_off"], R)

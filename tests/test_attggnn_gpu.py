@@ -166,7 +166,7 @@ def test_full_dims_logits_and_branch_pinned_gradients(shape, B, over):
     l_hip, l32 = float(O.kl_loss(out, tgt)), float(O.kl_loss(o32, t32(a8)))
     assert abs(l_hip - l32) < TOL * abs(l32)
 
-    view = lambda name, rows, i=0, j=0: ops.ws_view(ws, dims, S, E, U, name, rows, i, j).cpu()
+    view = lambda name, rows, i=0, j=0: ops.ws_view(ws, dims, graph, name, rows, i, j).cpu()
     P64 = {k: v.double() for k, v in P.items()}
     t64 = lambda x: torch.from_numpy(x).double()
     out64, tape = D.forward(P64, cfg, t64(n8), t64(e8), keep=True, model=MODEL)

@@ -35,19 +35,19 @@ def test_host_side_planning_functions():
     lay = L.CompactLayout()
     assert lib.gi_compact_layout(1000, 13, 3, C.byref(lay)) == 0 and lay.total_ints > 13000 * 8
     assert lib.gi_compact_layout(4, 200, 3, C.byref(lay)) == -2          # N > GI_MAX_NODES
-    ws = lib.gi_ggnn_workspace_floats(C.byref(d), 6900, 12600, 8000)
-    ws0 = lib.gi_ggnn_workspace_floats(C.byref(d), 0, 0, 0)
+    ws = lib.gi_ggnn_workspace_floats(C.byref(d), 6900, 12600, 8000, 45)
+    ws0 = lib.gi_ggnn_workspace_floats(C.byref(d), 0, 0, 0, 0)
     assert ws > ws0 > 0 and ws % 4 == 0
-    assert lib.gi_ggnn_workspace_floats(C.byref(d), 6900, 12600, 12601) == -1   # U > E
+    assert lib.gi_ggnn_workspace_floats(C.byref(d), 6900, 12600, 12601, 0) == -1   # U > E
     Ut = (C.c_int * 3)(6000, 1900, 100)
     assert lib.gi_ggnn_slab_floats(C.byref(d), 6900, 8000, Ut) > 0
     da = mpnn._dims_from_constants(O.as_constants(O.make_config()), 1000, L.KIND_ATTGGNN)
     assert lib.gi_ggnn_num_params(C.byref(da)) == 134                     # + 3 energy MLPs x 10
-    assert lib.gi_ggnn_workspace_floats(C.byref(da), 6900, 12600, 8000) > ws
+    assert lib.gi_ggnn_workspace_floats(C.byref(da), 6900, 12600, 8000, 0) > ws
     da.kind = 7
     assert lib.gi_ggnn_num_params(C.byref(da)) == -1                      # unknown model kind
     d.Fn = d.H + 1
-    assert lib.gi_ggnn_workspace_floats(C.byref(d), 1, 1, 1) == -1       # GI_EINVAL
+    assert lib.gi_ggnn_workspace_floats(C.byref(d), 1, 1, 1, 0) == -1    # GI_EINVAL
 
 
 def test_state_dict_is_the_reference_wire_format():

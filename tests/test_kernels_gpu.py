@@ -34,6 +34,13 @@ def _compact_case(n8, e8, H=16):
         assert np.array_equal(got, ref[name]), name            # integer work: bit-exact
     for name in ("seg_off", "src_off"):                        # [R + 1] = [S + 2] entries
         assert np.array_equal(getattr(g, name).cpu().numpy(), ref[name]), name
+    # pass-0 rows: (feature class, bond type) pairs, their gather rows and the edge-count matrix
+    assert g.D0 == ref["D0"]
+    if g.D0:
+        assert np.array_equal(g.type_off0.cpu().numpy(), ref["type_off0"])
+        assert np.array_equal(g.d_src.cpu().numpy(), ref["d_src"])
+        assert np.array_equal(g.cmat.cpu().numpy()[:, :g.D0], ref["cmat"])
+        assert float(g.cmat.sum()) == g.E
     assert np.array_equal(g.node_mask.cpu().numpy(), ref["node_mask"].astype(np.int32))
     B, N, Fn = n8.shape
     x = np.zeros((g.S + 1, hx0.shape[1]), dtype=np.float32)
@@ -62,6 +69,14 @@ def test_compact_fixture_and_shapes(golden_dir):
     for shape, B in (("zinc", 300), ("chembl", 64)):
         n8, e8, _ = synthetic.make_batch(B, **synthetic.SHAPES[shape], seed=5)
         _compact_case(n8, e8, H=100)
+
+
+def test_compact_pass0_shortcut_is_switched_off_for_non_binary_features():
+    n8, e8, _ = tiny_inputs()
+    nodes = torch.from_numpy(n8).float().to(DEV)
+    nodes[1, 0, 0] = 0.5                                       # a real-valued feature
+    g, _ = ops.compact(nodes, torch.from_numpy(e8).float().to(DEV), 16)
+    assert g.D0 == 0 and g.cmat is None
 
 
 def test_compact_rejects_non_onehot_edges():

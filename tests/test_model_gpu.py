@@ -75,13 +75,16 @@ def test_forward_stage_by_stage_tiny():
     assert (S, E, U) == (tape["g"]["S"], tape["g"]["E"], tape["g"]["U"]) and U < E
     R, B = S + 1, n8.shape[0]
     H, M, G, Fn = dims.H, dims.M, dims.G, dims.Fn
-    view = lambda name, rows, i=0, j=0: ops.ws_view(ws, dims, S, E, U, name, rows, i, j)
+    view = lambda name, rows, i=0, j=0: ops.ws_view(ws, dims, graph, name, rows, i, j)
+    assert graph.D0 == tape["g"]["D0"] > 0
     for p, ps in enumerate(tape["passes"]):
+        rows = graph.D0 if ps["p0"] else U              # pass 0 runs on the (class, bond type) rows
+        assert ps["p0"] == (p == 0)
         assert rel(view("hx", R, p)[:, :H], ps["h_prev"]) < 1e-5, f"hx[{p}]"
         for l in range(dims.enn_depth):
             want = torch.cat([ps["acts_t"][t][l] for t in range(dims.Fe)], 0)
-            assert rel(view("eact", U, p, l)[:, :dims.enn_hidden], want) < 1e-5, f"eact[{p}][{l}]"
-        assert rel(view("m", U, p)[:, :M], ps["m"]) < 1e-5, f"m[{p}]"
+            assert rel(view("eact", rows, p, l)[:, :dims.enn_hidden], want) < 1e-5, f"eact[{p}][{l}]"
+        assert rel(view("m", rows, p)[:, :M], ps["m"]) < 1e-5, f"m[{p}]"
         assert rel(view("agg", R, p)[:, :M], ps["agg"]) < 1e-5, f"agg[{p}]"
     hxP = view("hx", R, dims.passes)
     assert rel(hxP[:, :H], tape["h"]) < 1e-5
@@ -248,21 +251,22 @@ def test_gradients_strict_with_selu_branch_pinned(shape, B, over):
     dims, graph, ws = tape_hip
     S, E, U, B = graph.S, graph.E, graph.U, n8.shape[0]
     R = S + 1
-    view = lambda name, rows, i=0, j=0: ops.ws_view(ws, dims, S, E, U, name, rows, i, j).cpu()
+    view = lambda name, rows, i=0, j=0: ops.ws_view(ws, dims, graph, name, rows, i, j).cpu()
     # fp64 reference forward on the CPU dataflow model
     P64 = {k: v.double() for k, v in P.items()}
     t64 = lambda x: torch.from_numpy(x).double()
     out64, tape = D.forward(P64, cfg, t64(n8), t64(e8), keep=True)
     assert rel(out, out64) < TOL
     pins = {}
-    toff = graph.type_off.cpu().tolist()
     for p, ps in enumerate(tape["passes"]):
+        rows = graph.D0 if ps["p0"] else U
+        toff = (graph.type_off0 if ps["p0"] else graph.type_off).cpu().tolist()
         for l in range(dims.enn_depth):
-            hv = view("eact", U, p, l)
+            hv = view("eact", rows, p, l)
             for t in range(dims.Fe):
                 a = ps["acts_t"][t][l]
                 pins[id(a)] = hv[toff[t]:toff[t + 1], :a.shape[1]] > 0
-        pins[id(ps["m"])] = view("m", U, p)[:, :dims.M] > 0
+        pins[id(ps["m"])] = view("m", rows, p)[:, :dims.M] > 0
     for key, act_name, out_name, depth in (("att_acts", "att_act", "en", dims.att_depth),
                                            ("emb_acts", "emb_act", "emb", dims.emb_depth),
                                            ("add1", "add1_act", "add1", dims.mlp1_depth),
@@ -397,7 +401,9 @@ def test_training_loop_pieces_on_device(tmp_path):
         for (k, a), b in zip(ref_model.named_parameters(), model.parameters()):
             diff = (b.detach() - a.detach()).double()
             assert float(diff.abs().max()) <= 2 * 1e-3 * 3, k
-            assert float(diff.norm() / a.detach().double().norm().clamp_min(1e-12)) < 5e-4, k
+            # (one noisy element of a 10-element bias is already 1e-3 of its norm)
+            bound = 5e-4 if a.numel() >= 1000 else 5e-3
+            assert float(diff.norm() / a.detach().double().norm().clamp_min(1e-12)) < bound, k
     finally:
         if own_group:
             dist.destroy_process_group()
