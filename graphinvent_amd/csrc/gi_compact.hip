@@ -380,11 +380,16 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
             for (int d = tid; d < D0; d += 256) d_src[d] = gfix[L.cidx + gfix[L.d_slot + d]];
             for (int d = tid; d < ldc0; d += 256) cmat[(long long)S * ldc0 + d] = 0.f;
         }
+        for (int idx = tid; idx < N * ldc0; idx += 256) {       // zero this graph's rows, all threads
+            const int i = idx / ldc0;
+            if (gfix[L.active + b * N + i])
+                cmat[(long long)gfix[L.cidx + b * N + i] * ldc0 + (idx - i * ldc0)] = 0.f;
+        }
+        __syncthreads();
         for (int i = tid; i < N; i += 256) {
             const int slot = b * N + i;
             if (!gfix[L.active + slot]) continue;
             float* crow = cmat + (long long)gfix[L.cidx + slot] * ldc0;
-            for (int d = 0; d < ldc0; ++d) crow[d] = 0.f;
             for (int j = 0; j < N; ++j) {
                 const int t = typ[i * N + j];
                 if (t < 0) continue;

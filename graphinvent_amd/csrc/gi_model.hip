@@ -12,6 +12,7 @@
 //   graph level : B rows
 // Backward runs IN PLACE over the saved activations: the buffer of layer l's SELU output is
 // overwritten by dZ_l (gradient w.r.t. its pre-activation) once nobody needs the activation.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -186,6 +187,7 @@ void wgrad_shape(int n_out, int n_in, int red_rows, double share, int& tn, int& 
     tn = 1;
     const int tiles = gi_cdiv(n_out, 64) * gi_cdiv(n_in + 1, 64);
     const int kt = gi_cdiv(std::max(red_rows, 1), 32);
+    // (96..256 workgroups per problem measured: the step time does not move, 2.76-2.79 ms)
     const int want = (int)(256.0 * share / tiles + 0.5);
     nsplit = std::min(std::max(want, 1), std::max(1, kt / 2));
 }

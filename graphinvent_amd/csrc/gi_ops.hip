@@ -61,17 +61,22 @@ __global__ __launch_bounds__(256) void seg_sum_dselu_kernel(
     *dst = acc * v4f{gi_selu_grad(yv.x), gi_selu_grad(yv.y), gi_selu_grad(yv.z), gi_selu_grad(yv.w)};
 }
 
-// y[r, c] = selu'(y[r, c]) * sum_s slabs[s * stride + r * ld + c]   (pass-0 shortcut, tiny)
+// y[r, c] = selu'(y[r, c]) * sum_s slabs[s * stride + r * ld + c]   (pass-0 shortcut, tiny).
+// 16 lanes share one output: lane q sums splits q, q+16, ... , then a fixed shuffle tree.
 __global__ __launch_bounds__(256) void slab_sum_dselu_kernel(const float* __restrict__ slabs,
                                                              int nsplit, long long stride, int rows,
                                                              int cols, int ld, float* y, int ldy) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.x * 16 + (threadIdx.x >> 4), q = threadIdx.x & 15;
     const int r = t / cols, c = t - r * cols;
-    if (r >= rows) return;
     float acc = 0.f;
-    for (int s = 0; s < nsplit; ++s) acc += slabs[s * stride + (long long)r * ld + c];
-    float* dst = y + (long long)r * ldy + c;
-    *dst = acc * gi_selu_grad(*dst);
+    if (r < rows)
+        for (int s = q; s < nsplit; s += 16) acc += slabs[s * stride + (long long)r * ld + c];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_down(acc, o, 16);
+    if (r < rows && q == 0) {
+        float* dst = y + (long long)r * ldy + c;
+        *dst = acc * gi_selu_grad(*dst);
+    }
 }
 
 // ---- AttGGNN attention aggregation (gnn/mpnn.py:370-389) ------------------------------------------
@@ -579,8 +584,8 @@ extern "C" int gi_slab_sum_dselu(const float* slabs, int nsplit, long long strid
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (rows <= 0 || cols <= 0) return 0;
     if (!slabs || !y || nsplit < 1 || ld < cols || ldy < cols) return GI_EINVAL;
-    const long long threads = (long long)rows * cols;
-    hipLaunchKernelGGL(slab_sum_dselu_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+    const long long outputs = (long long)rows * cols;
+    hipLaunchKernelGGL(slab_sum_dselu_kernel, dim3((unsigned)((outputs + 15) / 16)), dim3(256), 0,
                        (hipStream_t)stream, slabs, nsplit, stride, rows, cols, ld, y, ldy);
     return gi_launch_status();
 }
