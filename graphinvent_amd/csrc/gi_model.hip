@@ -853,10 +853,26 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
     return r.rc;
 }
 
+extern "C" int gi_ggnn_first_readout_param(const gi_ggnn_dims* d) {
+    Model m;
+    const int rc = build_model(d, m);
+    return rc ? rc : m.att.base;
+}
+
 extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* params,
                                 const gi_graph* gp, float* ws, float* slabs, const float* y_out,
                                 int ldout, const float* d_out, int lddout, float* const* grads,
                                 void* stream, void* side_stream) {
+    return gi_ggnn_backward_phase(dp, params, gp, ws, slabs, y_out, ldout, d_out, lddout, grads,
+                                  stream, side_stream, GI_BWD_ALL);
+}
+
+extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const* params,
+                                      const gi_graph* gp, float* ws, float* slabs,
+                                      const float* y_out, int ldout, const float* d_out, int lddout,
+                                      float* const* grads, void* stream, void* side_stream,
+                                      int phase) {
+    if (phase != GI_BWD_ALL && phase != GI_BWD_READOUT && phase != GI_BWD_PASSES) return GI_EINVAL;
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     Model m;
     int rc = build_model(dp, m);
@@ -905,6 +921,20 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
     r.side = side_stream ? &side_obj : nullptr;
     r.sp = &sp; r.slabs = slabs; r.grads = grads;
     const Grp none{0, nullptr, 0};
+    const float* hxP = ws + w.hx[d.passes];
+    float* dh = ws + w.dh;
+    float* dh2 = ws + w.dh2;
+    float* dhb = ws + w.dhb;
+    float* dhc = ws + w.dhc;
+    float* dhd = ws + w.dhd;
+    auto readout_params = [&](auto&& fn) {
+        const Mlp* stacks[] = {&m.att, &m.emb, &m.add1, &m.conn1, &m.add2, &m.conn2, &m.term2};
+        for (const Mlp* q : stacks)
+            for (int l = 0; l < q->layers(); ++l) fn(q->w(l));
+    };
+    if (phase == GI_BWD_PASSES)          // the readout half ran (and was reduced) in an earlier call
+        readout_params([&](int widx) { sp.e[widx].reduced = 1; });
+    if (phase != GI_BWD_PASSES) {
     // ---- tier 2 (gnn/modules.py:265-279) ---------------------------------------------------------
     r.chk(gi_selu_bwd_rows(d_out, lddout, nullptr, y_out, ldout, ws + w.dzA, w.ldNA, d.B, NA, r.st));
     r.chk(gi_selu_bwd_rows(d_out + NA, lddout, nullptr, y_out + NA, ldout, ws + w.dzC, w.ldNC, d.B,
@@ -942,12 +972,6 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
         r.chk(gi_colsum_multi(cs, 4, r.st));
     }
     // ---- node-level readout MLPs -> dh -------------------------------------------------------------
-    const float* hxP = ws + w.hx[d.passes];
-    float* dh = ws + w.dh;
-    float* dh2 = ws + w.dh2;
-    float* dhb = ws + w.dhb;
-    float* dhc = ws + w.dhc;
-    float* dhd = ws + w.dhd;
     {   // every sibling writes its own d h; the GRU-gate backward of the last pass sums the four
         MlpJob jobs[4] = {};
         jobs[0] = {&m.add1, hxP, w.ldhx, R, w.add1_act, w.ldM1, nullptr, 0, w.add1_dz, ws + w.add1o,
@@ -959,6 +983,25 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
         jobs[3] = {&m.att, hxP, w.ldhx, R, w.att_act, w.ldAtt, nullptr, 0, w.att_dz, ws + w.en, w.ldG,
                    dhd, w.ldH, d.H, false};
         mlp_jobs_backward(r, ws, sp, slabs, dq, jobs, 4);
+    }
+    }   // phase != GI_BWD_PASSES
+    if (phase == GI_BWD_READOUT) {
+        // finish the readout parameters now: their weight-gradient GEMMs and slab reductions are
+        // queued (side stream if there is one) so that the caller can start exchanging the gradients
+        // of these parameters while the message passes are still being differentiated
+        if (r.side) {
+            kick_deferred(r, dq, r.side, true);          // also reduces every finished parameter
+        } else {
+            flush_deferred(r, dq);
+            gi_reduce_desc descs[160];
+            int nd = 0;
+            readout_params([&](int widx) {
+                sp.e[widx].reduced = 1;
+                descs[nd++] = reduce_desc(sp.e[widx], slabs, grads, widx);
+            });
+            if (r.ok()) r.chk(gi_reduce_slabs(descs, nd, r.st));
+        }
+        return r.rc;
     }
     // ---- message passes, reversed -------------------------------------------------------------------
     for (int p = d.passes - 1; p >= 0; --p) {

@@ -15,6 +15,11 @@ ONE exchange step per optimizer step:
   (``GGNN._grad_bucket``), so on the GPU path the collective runs in place on that buffer — no
   flatten / unflatten copies.  xGMI is point-to-point, a ring all-reduce is per-link bound: one
   24 MB bucket instead of 104 small tensors keeps it at a single latency term;
+* on the HIP model the exchange OVERLAPS the backward: the readout's gradients (gather + APDReadout,
+  ~86 % of the bucket and its contiguous tail) are final before the message passes are
+  differentiated, so the backward is issued in two calls and the tail's all-reduce starts on a
+  communication stream as soon as an event says it is complete; only the small head (message MLPs +
+  GRU) is exchanged after the backward;
 * identical Adam steps follow on every rank (``batchmean`` loss per rank + gradient mean =
   global-batch mean when the per-rank batch sizes are equal).
 """
@@ -61,13 +66,20 @@ class DataParallel:
 
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer,
                  scheduler=None, loss_fn: Callable = apd_kl_loss,
-                 process_group: Optional[dist.ProcessGroup] = None, always_reduce: bool = False):
+                 process_group: Optional[dist.ProcessGroup] = None, always_reduce: bool = False,
+                 overlap: bool = True):
         self.model, self.optimizer, self.scheduler, self.loss_fn = model, optimizer, scheduler, loss_fn
         self.group = process_group
         self.always_reduce = always_reduce     # run the collective even at world size 1 (tests)
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params: List[torch.nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
         self.last_bucket_zero_copy = False
+        self.last_overlapped = False
+        self._pending = None           # (work handle, split offset) of the early tail all-reduce
+        self._comm_stream = None
+        # overlap needs the HIP model (it exposes the flat bucket and the two-call backward)
+        self.overlap = (overlap and (self.world_size > 1 or always_reduce) and dist.is_initialized()
+                        and hasattr(model, "_grad_bucket") and torch.cuda.is_available())
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """Make every rank start from rank `src`'s weights."""
@@ -88,15 +100,41 @@ class DataParallel:
                 return None
         return bucket
 
+    def _early_allreduce(self, gflat: torch.Tensor, split: int, ready: "torch.cuda.Event") -> None:
+        """Called from inside the HIP backward once gflat[split:] (readout gradients) is queued to
+        be complete at `ready`: start its all-reduce on the communication stream."""
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=gflat.device)
+        comm = self._comm_stream
+        comm.wait_event(ready)
+        with torch.cuda.stream(comm):
+            work = dist.all_reduce(gflat[split:], op=dist.ReduceOp.SUM, group=self.group,
+                                   async_op=True)
+        self._pending = (work, split, gflat.data_ptr())
+
     def allreduce_gradients(self) -> None:
         if self.world_size == 1 and not self.always_reduce:
             return
         bucket = self._model_bucket()
         self.last_bucket_zero_copy = bucket is not None
+        pending, self._pending = self._pending, None
+        self.last_overlapped = False
         if bucket is not None:                      # gradients already live in one flat buffer
-            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+            if pending is not None and pending[2] == bucket.data_ptr():
+                work, split, _ = pending            # tail is already being exchanged: head now
+                if split > 0:
+                    dist.all_reduce(bucket[:split], op=dist.ReduceOp.SUM, group=self.group)
+                work.wait()                         # current stream waits for the tail's collective
+                bucket.record_stream(self._comm_stream)
+                self.last_overlapped = True
+            else:
+                if pending is not None:
+                    pending[0].wait()
+                dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
             bucket.mul_(1.0 / self.world_size)
             return
+        if pending is not None:
+            pending[0].wait()
         grads = [p.grad for p in self.params]
         flat = torch.cat([g.reshape(-1) for g in grads])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
@@ -113,7 +151,15 @@ class DataParallel:
         output = self.model(nodes, edges)
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.loss_fn(output, target)
-        loss.backward()
+        # the early exchange is armed only around this backward: gradients are fresh views of the
+        # backward's own bucket here (zero_grad(set_to_none) above), which the overlap relies on
+        if self.overlap:
+            self.model._grad_ready_hook = self._early_allreduce   # see gnn/mpnn.py ggnn_backward_raw
+        try:
+            loss.backward()
+        finally:
+            if self.overlap:
+                self.model._grad_ready_hook = None
         self.allreduce_gradients()
         self.optimizer.step()
         if self.scheduler is not None:

@@ -113,10 +113,15 @@ def _os_environ_flag(name: str, default: str) -> str:
     return os.environ.get(name, default)
 
 
-def ggnn_backward_raw(tape, out, d_out, params):
+def ggnn_backward_raw(tape, out, d_out, params, early_hook=None):
     """The fused backward; consumes the tape's activations in place.  Returns (grads, gflat):
     per-parameter gradient views into ONE flat fp32 buffer (state_dict order, 16-byte aligned
-    segments) — the bucket a data-parallel all-reduce operates on."""
+    segments) — the bucket a data-parallel all-reduce operates on.
+
+    ``early_hook(gflat, split, ready_event)`` (optional, set by ``dp.DataParallel``): the backward is
+    issued in two calls; after the first, ``gflat[split:]`` — the readout's gradients, ~86 % of the
+    bucket — is complete once ``ready_event`` fires, and the hook may start exchanging it while the
+    second call differentiates the message passes."""
     lib = _L.load()
     dims, graph, ws = tape
     d_out = d_out.contiguous().float()
@@ -133,10 +138,19 @@ def ggnn_backward_raw(tape, out, d_out, params):
         total += (n + 3) & ~3                       # every gradient 16-byte aligned
     gflat = torch.empty(total, dtype=torch.float32, device=dev)
     grads = [gflat[o:o + n].view(p.shape) for o, n, p in zip(offs, sizes, params)]
-    _L.check(lib.gi_ggnn_backward(
-        C.byref(dims), _ptr_table(params), C.byref(gs), ws.data_ptr(), slabs.data_ptr(),
-        out.data_ptr(), out.stride(0), d_out.data_ptr(), d_out.stride(0), _ptr_table(grads),
-        torch.cuda.current_stream().cuda_stream, _side_stream(dev)), "gi_ggnn_backward")
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    args = (C.byref(dims), _ptr_table(params), C.byref(gs), ws.data_ptr(), slabs.data_ptr(),
+            out.data_ptr(), out.stride(0), d_out.data_ptr(), d_out.stride(0), _ptr_table(grads),
+            main.cuda_stream, side)
+    if early_hook is None:
+        _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_ALL), "gi_ggnn_backward")
+        return grads, gflat
+    _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_READOUT), "gi_ggnn_backward(readout)")
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.ExternalStream(side, device=dev) if side else main)
+    early_hook(gflat, offs[lib.gi_ggnn_first_readout_param(C.byref(dims))], ready)
+    _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_PASSES), "gi_ggnn_backward(passes)")
     return grads, gflat
 
 
@@ -158,7 +172,8 @@ class _GGNNFunction(torch.autograd.Function):
                                "activations in place (retain_graph is not supported)")
         tape, ctx.tape = ctx.tape, None
         out, *params = ctx.saved_tensors
-        grads, gflat = ggnn_backward_raw(tape, out, d_out, params)
+        grads, gflat = ggnn_backward_raw(tape, out, d_out, params,
+                                         getattr(ctx.owner, "_grad_ready_hook", None))
         ctx.owner._grad_bucket = gflat          # the flat bucket graphinvent_amd.dp all-reduces
         return (None, None, None, *grads)
 

@@ -25,6 +25,7 @@ GI_MAX_GROUPS = 8
 GI_MAX_NODES = 128
 EPI_BIAS, EPI_SELU, EPI_DSELU, EPI_ACCUM, GEMM_SPLITK = 1, 2, 4, 8, 16
 KIND_GGNN, KIND_ATTGGNN = 0, 1
+BWD_ALL, BWD_READOUT, BWD_PASSES = 0, 1, 2
 COUNTS = 24          # GI_COUNTS
 ABI_VERSION = 2      # GI_ABI_VERSION
 DTYPE_F32, DTYPE_I8 = 0, 1
@@ -115,6 +116,9 @@ SIGNATURES = {
     "gi_ggnn_forward": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), C.POINTER(Graph), vp, vp, ci, vp]),
     "gi_ggnn_backward": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), C.POINTER(Graph), vp, vp, vp, ci,
                               vp, ci, C.POINTER(vp), vp, vp]),
+    "gi_ggnn_backward_phase": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), C.POINTER(Graph), vp, vp, vp,
+                                    ci, vp, ci, C.POINTER(vp), vp, vp, ci]),
+    "gi_ggnn_first_readout_param": (ci, [C.POINTER(GgnnDims)]),
 }
 
 _lib = None

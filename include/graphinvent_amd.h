@@ -309,6 +309,19 @@ int gi_ggnn_forward(const gi_ggnn_dims* d, const float* const* params, const gi_
 int gi_ggnn_backward(const gi_ggnn_dims* d, const float* const* params, const gi_graph* g,
                      float* ws, float* slabs, const float* y_out, int ldout, const float* d_out,
                      int lddout, float* const* grads, void* stream, void* side_stream);
+/* The same in two calls, for overlapping the data-parallel gradient exchange with the backward:
+ * GI_BWD_READOUT differentiates the readout (gather + APDReadout: ~86 % of the parameters) and
+ * completes the gradients of params[gi_ggnn_first_readout_param() ..) — on `side_stream` when given
+ * (record an event there to know when), else on `stream`; GI_BWD_PASSES then differentiates the
+ * message passes and completes the rest.  Same arguments to both calls; GI_BWD_ALL = gi_ggnn_backward. */
+#define GI_BWD_ALL 0
+#define GI_BWD_READOUT 1
+#define GI_BWD_PASSES 2
+int gi_ggnn_backward_phase(const gi_ggnn_dims* d, const float* const* params, const gi_graph* g,
+                           float* ws, float* slabs, const float* y_out, int ldout,
+                           const float* d_out, int lddout, float* const* grads, void* stream,
+                           void* side_stream, int phase);
+int gi_ggnn_first_readout_param(const gi_ggnn_dims* d);
 
 #ifdef __cplusplus
 }

@@ -394,6 +394,7 @@ def test_training_loop_pieces_on_device(tmp_path):
             ref_opt.step()
             l = trainer.step(nodes, edges, tgt)
             assert trainer.last_bucket_zero_copy            # all-reduce ran in place on the flat bucket
+            assert trainer.last_overlapped                  # ... its tail started inside the backward
             assert abs(float(l) - float(l_ref)) < 1e-5 * abs(float(l_ref))
         # Adam divides by sqrt(v): an element whose gradient is ~1e-9 gets an O(lr) update whose
         # sign is decided by rounding noise, so single elements may differ by up to 2*lr per step;
@@ -455,3 +456,29 @@ def test_compaction_prefetched_one_batch_ahead_is_bitwise_identical():
         ops._PREFETCHED.clear()
         assert torch.equal(out, model(nodes, edges))
         assert not torch.equal(out[0], ref[0])
+
+
+def test_two_call_backward_is_bitwise_the_single_call_backward():
+    """gi_ggnn_backward_phase(READOUT) + (PASSES) — what the overlapped data-parallel exchange uses —
+    must give exactly the gradients of the single call, and the hook must see the readout tail."""
+    cfg = O.make_config()
+    P = O.init_params(cfg, seed=2)
+    model = make_model(cfg, P)
+    params = list(model.parameters())
+    n8, e8, a8 = synthetic.make_batch(200, **synthetic.SHAPES["gdb13"], seed=31)
+    nodes, edges, tgt = to_dev(n8, e8, a8)
+    results = []
+    seen = {}
+    for hook in (None, lambda gflat, split, ev: seen.update(split=split, n=gflat.numel(), ev=ev)):
+        out, tape = mpnn.ggnn_forward_raw(model.constants, nodes, edges, params)
+        o = out.detach().clone().requires_grad_(True)
+        O.kl_loss(o, tgt).backward()
+        grads, gflat = mpnn.ggnn_backward_raw(tape, out, o.grad, params, early_hook=hook)
+        torch.cuda.synchronize()
+        results.append([g.clone() for g in grads])            # (the bucket's 16-byte padding is not data)
+    assert all(torch.equal(a, b) for a, b in zip(*results))
+    names = [k for k, _ in model.named_parameters()]
+    first = names.index("gather.att_nn.seq.0.weight")
+    assert seen["split"] == sum((p.numel() + 3) & ~3 for p in params[:first])
+    assert 0.8 < 1 - seen["split"] / seen["n"] < 0.9           # the tail is most of the bucket
+    seen["ev"].synchronize()
