@@ -231,6 +231,15 @@ def main():
     loss_val = float(loss)
     if not np.isfinite(loss_val):
         raise SystemExit("non-finite loss in the timed region")
+    if world > 1:
+        # every rank stepped on different graphs: the weights can only still be identical if the
+        # gradient exchange (incl. its overlap with the backward) delivered the same mean everywhere
+        chk = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum()
+        both = torch.stack([chk, -chk])
+        dist.all_reduce(both, op=dist.ReduceOp.MAX)
+        spread = float(both[0] + both[1])                      # max - min over ranks
+        if not spread <= 1e-9 * max(abs(float(chk)), 1.0):
+            raise SystemExit(f"ranks diverged: parameter checksum spread {spread}")
 
     result = {
         "metric": "training graphs/sec (GGNN, GDB-13 max_n_nodes=13)" if headline else
@@ -247,7 +256,10 @@ def main():
                                 f"{cfg['hidden_node_features']}, 3 MP steps, train step "
                                 "fwd+KL+bwd+allreduce+Adam"),
                    "batch_per_gpu": BATCH, "global_batch": BATCH * world,
-                   "parallelism": f"dp{world}", "loss": round(loss_val, 5)},
+                   "parallelism": f"dp{world}", "loss": round(loss_val, 5),
+                   "allreduce": ("none (1 rank)" if world == 1 else
+                                 "flat fp32 bucket, readout tail overlapped with the backward"
+                                 if trainer.overlap else "flat fp32 bucket after the backward")},
     }
     if args.backend != "nccl":
         result["config"]["backend"] = args.backend + " (control-flow smoke test, not a measurement)"

@@ -25,6 +25,7 @@ ONE exchange step per optimizer step:
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Iterator, List, Optional
 
 import numpy as np
@@ -78,7 +79,8 @@ class DataParallel:
         self._pending = None           # (work handle, split offset) of the early tail all-reduce
         self._comm_stream = None
         # overlap needs the HIP model (it exposes the flat bucket and the two-call backward)
-        self.overlap = (overlap and (self.world_size > 1 or always_reduce) and dist.is_initialized()
+        self.overlap = (overlap and os.environ.get("GI_DP_OVERLAP", "1") != "0"
+                        and (self.world_size > 1 or always_reduce) and dist.is_initialized()
                         and hasattr(model, "_grad_bucket") and torch.cuda.is_available())
 
     def broadcast_parameters(self, src: int = 0) -> None:
