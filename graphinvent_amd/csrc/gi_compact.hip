@@ -343,60 +343,56 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
         reinterpret_cast<const signed char*>(gfix + L.etype) + (long long)b * NN;
     for (int idx = tid; idx < NN; idx += 256) typ[idx] = etype_g[idx];
     __syncthreads();
-    for (int i = tid; i < N; i += 256) {                 // incoming edges of slot i, j ascending
-        int ed = gfix[L.seg_start + b * N + i];
-        for (int j = 0; j < N; ++j) {
-            const int t = typ[i * N + j];
-            if (t < 0) continue;
-            in_perm[ed] = gfix[L.type_off + t] + gfix[L.mstart_t + t * ns + b * N + j];
-            kpos[i * N + j] = ed++;
-        }
-    }
-    __syncthreads();
-    for (int j = tid; j < N; j += 256) {                 // message rows of source slot j, by type
-        const int slot = b * N + j;
-        const int cs = gfix[L.cidx + slot];
-        int ko = gfix[L.srcm_start + slot];
-        for (int t = 0; t < Fe; ++t) {
-            if (gfix[L.colcnt_t + t * ns + slot] == 0) continue;
-            const int u = gfix[L.type_off + t] + gfix[L.mstart_t + t * ns + slot];
-            int mo = gfix[L.etype_off + t] + gfix[L.cstart_t + t * ns + slot];
-            u_src[u] = cs;
-            out_perm[ko++] = u;
-            mu_off[u] = mo;
-            for (int i = 0; i < N; ++i)                  // its edges, destination ascending
-                if (typ[i * N + j] == t) {
-                    mu_dst[mo] = gfix[L.cidx + b * N + i];
-                    mu_slot[mo] = kpos[i * N + j];
-                    ++mo;
-                }
-        }
-    }
-    if (b == 0 && tid == 0) mu_off[U] = E;
-    if (D0 > 0) {
-        // pass-0 edge-count matrix: cmat[c_i, row(bond type, class of j)] = number of such edges
-        // into i.  A destination's row is zeroed and filled by the thread that owns the destination.
+    // One thread per adjacency cell (i <- j): positions come from ranks inside the LDS type table
+    // (<= N reads), so nothing below is a serial per-slot loop over global memory.
+    if (D0 > 0) {                                        // pass-0 edge-count matrix: zero first
         if (b == 0) {
             for (int d = tid; d < D0; d += 256) d_src[d] = gfix[L.cidx + gfix[L.d_slot + d]];
             for (int d = tid; d < ldc0; d += 256) cmat[(long long)S * ldc0 + d] = 0.f;
         }
-        for (int idx = tid; idx < N * ldc0; idx += 256) {       // zero this graph's rows, all threads
+        for (int idx = tid; idx < N * ldc0; idx += 256) {
             const int i = idx / ldc0;
             if (gfix[L.active + b * N + i])
                 cmat[(long long)gfix[L.cidx + b * N + i] * ldc0 + (idx - i * ldc0)] = 0.f;
         }
-        __syncthreads();
-        for (int i = tid; i < N; i += 256) {
-            const int slot = b * N + i;
-            if (!gfix[L.active + slot]) continue;
-            float* crow = cmat + (long long)gfix[L.cidx + slot] * ldc0;
-            for (int j = 0; j < N; ++j) {
-                const int t = typ[i * N + j];
-                if (t < 0) continue;
-                crow[gfix[L.dmap + t * P0Q + gfix[L.cls + b * N + j]]] += 1.f;
-            }
-        }
     }
+    for (int idx = tid; idx < NN; idx += 256) {          // dst-CSR: edges into i, j ascending
+        const int t = typ[idx];
+        if (t < 0) continue;
+        const int i = idx / N, j = idx - i * N;
+        int rank = 0;
+        for (int jj = 0; jj < j; ++jj) rank += typ[i * N + jj] >= 0;
+        const int ed = gfix[L.seg_start + b * N + i] + rank;
+        in_perm[ed] = gfix[L.type_off + t] + gfix[L.mstart_t + t * ns + b * N + j];
+        kpos[idx] = ed;
+    }
+    __syncthreads();                                     // kpos complete, cmat rows zeroed
+    for (int idx = tid; idx < NN; idx += 256) {          // message CSR: edges out of j of type t, i ascending
+        const int t = typ[idx];
+        if (t < 0) continue;
+        const int i = idx / N, j = idx - i * N;
+        const int slot = b * N + j;
+        int rank = 0;
+        for (int ii = 0; ii < i; ++ii) rank += typ[ii * N + j] == t;
+        const int mo = gfix[L.etype_off + t] + gfix[L.cstart_t + t * ns + slot] + rank;
+        mu_dst[mo] = gfix[L.cidx + b * N + i];
+        mu_slot[mo] = kpos[idx];
+        if (D0 > 0)    // counts are small integers: float atomics are exact and order-independent
+            atomicAdd(cmat + (long long)gfix[L.cidx + b * N + i] * ldc0 +
+                          gfix[L.dmap + t * P0Q + gfix[L.cls + slot]], 1.f);
+    }
+    for (int idx = tid; idx < N * Fe; idx += 256) {      // message rows of source slot j, by type
+        const int j = idx / Fe, t = idx - j * Fe;
+        const int slot = b * N + j;
+        if (gfix[L.colcnt_t + t * ns + slot] == 0) continue;
+        int rank = 0;
+        for (int tt = 0; tt < t; ++tt) rank += gfix[L.colcnt_t + tt * ns + slot] > 0;
+        const int u = gfix[L.type_off + t] + gfix[L.mstart_t + t * ns + slot];
+        u_src[u] = gfix[L.cidx + slot];
+        out_perm[gfix[L.srcm_start + slot] + rank] = u;
+        mu_off[u] = gfix[L.etype_off + t] + gfix[L.cstart_t + t * ns + slot];
+    }
+    if (b == 0 && tid == 0) mu_off[U] = E;
     // initial node rows: hx0[c] = [x, 0 .. 0 | x]  (:121-126 zero-padded hidden state; the copy of
     // the raw features at columns [H, H+Fn) feeds the gather attention MLP, gnn/modules.py:45)
     for (int idx = tid; idx < N * ldhx; idx += 256) {
