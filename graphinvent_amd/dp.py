@@ -151,7 +151,8 @@ class DataParallel:
         """forward -> zero_grad -> loss -> backward -> all-reduce -> optimizer (-> scheduler):
         the order of Workflow.py:785-796 with the exchange step inserted before the update."""
         output = self.model(nodes, edges)
-        self.optimizer.zero_grad(set_to_none=True)
+        for p in self.params:                      # optimizer.zero_grad(set_to_none=True), minus its
+            p.grad = None                          # per-call bookkeeping (0.09 ms of host time)
         loss = self.loss_fn(output, target)
         # the early exchange is armed only around this backward: gradients are fresh views of the
         # backward's own bucket here (zero_grad(set_to_none) above), which the overlap relies on

@@ -482,3 +482,55 @@ def test_two_call_backward_is_bitwise_the_single_call_backward():
     assert seen["split"] == sum((p.numel() + 3) & ~3 for p in params[:first])
     assert 0.8 < 1 - seen["split"] / seen["n"] < 0.9           # the tail is most of the bucket
     seen["ev"].synchronize()
+
+
+def test_direct_gradient_writeback_has_autograd_accumulate_semantics():
+    """Default mode: loss.backward() fills param.grad straight from the fused backward (one autograd
+    input instead of 104).  It must behave like the autograd_params=True mode for everything the
+    reference's training loops do: same gradients bit for bit, accumulation over several backward
+    calls, frozen parameters, zero_grad, no_grad, deepcopy, the second-backward error."""
+    cfg = O.make_config(**TINY)
+    P = O.init_params(cfg, seed=11)
+    n8, e8, a8 = _live_only(*tiny_inputs())
+    nodes, edges, tgt = to_dev(n8, e8, a8)
+    fast, slow = make_model(cfg, P), make_model(cfg, P)
+    slow.autograd_params = True
+    for m in (fast, slow):
+        O.kl_loss(m(nodes, edges), tgt).backward()
+    for (k, a), b in zip(fast.named_parameters(), slow.parameters()):
+        assert torch.equal(a.grad, b.grad), k
+    bucket = fast._grad_bucket
+    assert bucket is not None and all(p.grad.untyped_storage().data_ptr() == bucket.untyped_storage().data_ptr()
+                                      for p in fast.parameters())
+    # accumulation: a second backward without zero_grad adds, like AccumulateGrad
+    g1 = [p.grad.clone() for p in fast.parameters()]
+    out = fast(nodes, edges)
+    loss = O.kl_loss(out, tgt)
+    loss.backward()
+    for p, g in zip(fast.parameters(), g1):
+        assert rel(p.grad, 2 * g) < 1e-6
+    with pytest.raises(RuntimeError):                          # the tape is consumed
+        loss.backward()
+    # zero_grad -> fresh bucket again, same values as the first time
+    fast.zero_grad(set_to_none=True)
+    O.kl_loss(fast(nodes, edges), tgt).backward()
+    assert all(torch.equal(p.grad, g) for p, g in zip(fast.parameters(), g1))
+    # frozen parameters get no gradient; the others are unchanged
+    fast.zero_grad(set_to_none=True)
+    frozen = fast.gru.weight_hh
+    frozen.requires_grad_(False)
+    O.kl_loss(fast(nodes, edges), tgt).backward()
+    assert frozen.grad is None
+    assert all(torch.equal(p.grad, g) for p, g in zip(fast.parameters(), g1) if p is not frozen)
+    frozen.requires_grad_(True)
+    # no_grad / deepcopy
+    with torch.no_grad():
+        assert not fast(nodes, edges).requires_grad
+    clone = copy.deepcopy(fast)
+    clone.zero_grad(set_to_none=True)
+    O.kl_loss(clone(nodes, edges), tgt).backward()
+    assert all(torch.equal(p.grad, g) for p, g in zip(clone.parameters(), g1))
+    assert clone._grad_bucket.data_ptr() != fast._grad_bucket.data_ptr()
+    # the full-autograd mode supports torch.autograd.grad on the parameters
+    gs = torch.autograd.grad(O.kl_loss(slow(nodes, edges), tgt), list(slow.parameters()))
+    assert all(torch.equal(a, b) for a, b in zip(gs, g1))
