@@ -120,3 +120,9 @@ def test_drop_in_import_as_top_level_gnn_package():
                                                          os.path.join(ROOT, "graphinvent_amd"))
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
     assert res.returncode == 0 and "ok" in res.stdout, res.stderr[-800:]
+
+
+def test_graft_entry_build_runs_without_a_gpu():
+    """The driver's "does it build" check: compiles every HIP source for gfx950 and binds the ABI."""
+    import __graft_entry__ as entry
+    entry.build()
