@@ -278,19 +278,6 @@ void linear_fwd(Run& r, const Mlp* mlps, int l, const Grp& g, const float* X, in
     r.chk(gi_gemm(&p, r.st));
 }
 
-// plain linear without activation (GRU pre-activations)
-void linear_plain(Run& r, const float* W, const float* b, int in, int out, const float* X, int ldx,
-                  int rows, float* Y, int ldy) {
-    if (!r.ok() || rows <= 0) return;
-    gi_gemm_params p;
-    gemm_defaults(p);
-    p.A = X; p.lda = ldx; p.B = W; p.ldb = in; p.bias = b; p.C = Y; p.ldc = ldy;
-    p.M = rows; p.N = out; p.K = in;
-    p.flags = GI_EPI_BIAS;
-    pick_tile(rows, out, p.tm, p.tn);
-    r.chk(gi_gemm(&p, r.st));
-}
-
 // dX[rows, ncols] (+)= (dZ[rows, n_out] W[n_out, n_in][:, :ncols]) (* selu'(act))
 void linear_dgrad(Run& r, const float* const* Wg, const float* W, const Grp& g, int n_out,
                   int n_in, int ncols, const float* dZ, int lddz, int rows, float* dX, int lddx,
@@ -832,10 +819,12 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
     const float* hx = ws + w.hx[d.passes];
     {   // the four node-level stacks, layer by layer in shared launches
         MlpJob jobs[4] = {};
-        jobs[0] = {&m.att, hx, w.ldhx, R, w.att_act, w.ldAtt, ws + w.en, w.ldG};
-        jobs[1] = {&m.emb, hx, w.ldhx, R, w.emb_act, w.ldEmb, ws + w.embo, w.ldG};
-        jobs[2] = {&m.add1, hx, w.ldhx, R, w.add1_act, w.ldM1, ws + w.add1o, w.ldA};
-        jobs[3] = {&m.conn1, hx, w.ldhx, R, w.conn1_act, w.ldM1, ws + w.conn1o, w.ldC};
+        // widest stacks first: their workgroups run twice as long (K = 500 against 250), so the
+        // launch's last, partially filled round of workgroups consists of the short ones
+        jobs[0] = {&m.add1, hx, w.ldhx, R, w.add1_act, w.ldM1, ws + w.add1o, w.ldA};
+        jobs[1] = {&m.conn1, hx, w.ldhx, R, w.conn1_act, w.ldM1, ws + w.conn1o, w.ldC};
+        jobs[2] = {&m.att, hx, w.ldhx, R, w.att_act, w.ldAtt, ws + w.en, w.ldG};
+        jobs[3] = {&m.emb, hx, w.ldhx, R, w.emb_act, w.ldEmb, ws + w.embo, w.ldG};
         mlp_jobs_forward(r, ws, jobs, 4);
     }
     r.chk(gi_gather_readout_fwd(ws + w.en, ws + w.embo, w.ldG, cidx, mask, d.B, d.N, d.G,

@@ -38,6 +38,10 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(
     *dst = acc;
 }
 
+__device__ __forceinline__ v4f v4_selu_grad(v4f y) {
+    return v4f{gi_selu_grad(y.x), gi_selu_grad(y.y), gi_selu_grad(y.z), gi_selu_grad(y.w)};
+}
+
 // seg_sum over the message CSR with the SELU backward of the destination buffer fused in
 __global__ __launch_bounds__(256) void seg_sum_dselu_kernel(
     const float* __restrict__ vals, int ldv, const int* __restrict__ perm,
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(256) void seg_sum_dselu_kernel(
     if (k < hi) acc += *(const v4f*)(vals + (long long)perm[k] * ldv + 4 * q);
     v4f* dst = (v4f*)(y + (long long)c * ldy + 4 * q);
     const v4f yv = *dst;
-    *dst = acc * v4f{gi_selu_grad(yv.x), gi_selu_grad(yv.y), gi_selu_grad(yv.z), gi_selu_grad(yv.w)};
+    *dst = acc * v4_selu_grad(yv);
 }
 
 // y[r, c] = selu'(y[r, c]) * sum_s slabs[s * stride + r * ld + c]   (pass-0 shortcut, tiny).
@@ -92,9 +96,6 @@ __device__ __forceinline__ v4f v4_exp(v4f a) {
 }
 __device__ __forceinline__ v4f v4_rcp(v4f a) {
     return v4f{1.f / a.x, 1.f / a.y, 1.f / a.z, 1.f / a.w};
-}
-__device__ __forceinline__ v4f v4_selu_grad(v4f y) {
-    return v4f{gi_selu_grad(y.x), gi_selu_grad(y.y), gi_selu_grad(y.z), gi_selu_grad(y.w)};
 }
 
 __global__ __launch_bounds__(256) void seg_softmax_fwd_kernel(

@@ -534,3 +534,32 @@ def test_direct_gradient_writeback_has_autograd_accumulate_semantics():
     # the full-autograd mode supports torch.autograd.grad on the parameters
     gs = torch.autograd.grad(O.kl_loss(slow(nodes, edges), tgt), list(slow.parameters()))
     assert all(torch.equal(a, b) for a, b in zip(gs, g1))
+
+
+@pytest.mark.parametrize("shape", ["gdb13", "chembl"])
+def test_batch_size_extremes_and_row_independence(shape):
+    """B = 1 and B = 3 against the oracle; a B = 3000 batch gives every graph the logits it gets in a
+    batch of its own third (graphs are independent units: only summation orders may differ)."""
+    sh = synthetic.SHAPES[shape]
+    cfg = O.shaped_config(sh["n_atom_types"], sh["n_formal_charge"], sh["max_n_nodes"])
+    P = O.init_params(cfg, seed=8)
+    model = make_model(cfg, P).eval()
+    t = lambda x: torch.from_numpy(x).float()
+    for B in (1, 3):
+        n8, e8, _ = _live_only(*synthetic.make_batch(B + 4, **sh, seed=40 + B))
+        n8, e8 = n8[:B], e8[:B]
+        with torch.no_grad():
+            out = model(*to_dev(n8, e8))
+        assert rel(out, O.ggnn_forward(P, cfg, t(n8), t(e8))) < TOL
+    Bbig = 3000 if shape == "gdb13" else 600
+    n8, e8, a8 = synthetic.make_batch(Bbig, **sh, seed=50)
+    nodes, edges, tgt = to_dev(n8, e8, a8)
+    model.train()
+    out = model(nodes, edges)
+    O.kl_loss(out, tgt).backward()
+    assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+    third = Bbig // 3
+    with torch.no_grad():
+        part = model(nodes[third:2 * third].contiguous(), edges[third:2 * third].contiguous())
+    live = np.setdiff1d(np.arange(third), fully_masked_rows(e8[third:2 * third]))
+    assert rel(out.detach()[third:2 * third][live], part[live]) < 1e-5
