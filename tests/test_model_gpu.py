@@ -563,3 +563,50 @@ def test_batch_size_extremes_and_row_independence(shape):
         part = model(nodes[third:2 * third].contiguous(), edges[third:2 * third].contiguous())
     live = np.setdiff1d(np.arange(third), fully_masked_rows(e8[third:2 * third]))
     assert rel(out.detach()[third:2 * third][live], part[live]) < 1e-5
+
+
+@pytest.mark.parametrize("case", ["asymmetric", "real_valued_features", "many_feature_patterns"])
+def test_inputs_outside_the_preprocessing_contract(case):
+    """Inputs the reference model accepts although DataProcesser never writes them: a directed edge
+    from an empty slot, real-valued node features (pass-0 shortcut must switch itself off), and more
+    distinct 0/1 feature rows than the pass-0 class table holds (overflow path)."""
+    rng = np.random.default_rng(3)
+    if case == "asymmetric":
+        cfg = O.make_config(**TINY)
+        n8, e8, a8 = tiny_inputs()
+        n8[4] = 0; e8[4] = 0
+        n8[4, 0, 0] = 1; n8[4, 0, 3] = 1
+        e8[4, 0, 5, 1] = 1                      # node 0 receives from empty slot 5, nothing back
+        nodes_np, expect_p0 = n8.astype(np.float32), True
+    else:
+        sh = synthetic.SHAPES["zinc"]
+        cfg = O.shaped_config(sh["n_atom_types"], sh["n_formal_charge"], sh["max_n_nodes"])
+        n8, e8, a8 = _live_only(*synthetic.make_batch(40, **sh, seed=9))
+        occupied = n8.any(2)
+        if case == "real_valued_features":
+            nodes_np = n8.astype(np.float32) * rng.uniform(0.5, 1.5, size=n8.shape).astype(np.float32)
+        else:
+            nodes_np = (rng.random(n8.shape) < 0.5).astype(np.float32)
+            nodes_np[..., 0] = 1.0              # keep occupied slots non-zero
+        nodes_np = nodes_np * occupied[..., None]
+        expect_p0 = False
+    P = O.init_params(cfg, seed=6)
+    model = make_model(cfg, P)
+    nodes = torch.from_numpy(nodes_np).to(DEV)
+    edges, tgt = to_dev(e8, a8)
+    out, tape = mpnn.ggnn_forward_raw(model.constants, nodes, edges, list(model.parameters()))
+    assert (tape[1].D0 > 0) == expect_p0
+    if case == "many_feature_patterns":
+        assert len({tuple(r) for r in nodes_np.reshape(-1, nodes_np.shape[2])}) > 256
+    ref = O.ggnn_forward(P, cfg, torch.from_numpy(nodes_np), torch.from_numpy(e8).float())
+    live = np.setdiff1d(np.arange(out.shape[0]), fully_masked_rows(e8))
+    assert rel(out[live], ref[live]) < TOL
+    out2 = model(nodes, edges)
+    O.kl_loss(out2, tgt).backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    O.kl_loss(O.ggnn_forward(leaves, cfg, torch.from_numpy(nodes_np), torch.from_numpy(e8).float()),
+              torch.from_numpy(a8).float()).backward()
+    num = sum(float((p.grad.cpu().double() - leaves[k].grad.double()).pow(2).sum())
+              for k, p in model.named_parameters())
+    den = sum(float(v.grad.double().pow(2).sum()) for v in leaves.values())
+    assert (num / den) ** 0.5 < 5e-3
