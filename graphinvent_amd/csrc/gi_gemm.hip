@@ -64,13 +64,10 @@ template <int TM, int TN, bool A_MAJOR, bool B_MAJOR>
 __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int bx_in,
                                              const int by_in, const int bz, const int gx,
                                              const int gy) {
-    // Optional XCD-aware tile order (flag bit 5, env GI_GEMM_XCD_REMAP=1): the dispatcher deals
-    // consecutive workgroup ids round-robin to the 8 XCDs (private L2 each); the remap makes one XCD
-    // walk consecutive tiles so the column tiles sharing an A row panel hit the same L2 (bijective
-    // for any grid size).  MEASURED on the training step and left OFF: it cuts FETCH_SIZE per GEMM
-    // launch by 42 % (50 -> 29 MB) but the step gets 6 % SLOWER (3.69 -> 3.92 ms, 3 A/B pairs) —
-    // these GEMMs are MFMA/issue-bound, their re-reads are served by the 256 MB Infinity Cache, and
-    // spreading a panel's tiles over all XCDs balances them better.
+    // XCD-aware tile order (flag bit 5, set by the host for launches of many workgroups, see
+    // remap_min_blocks): the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs
+    // (private L2 each); the remap makes one XCD walk consecutive tiles so the column tiles sharing
+    // an A row panel hit the same L2 (bijective for any grid size).
     int bx = bx_in, by = by_in;
     if (p.flags & 32) {
         const int T = gx * gy, id = bx_in + gx * by_in;
@@ -427,9 +424,18 @@ __global__ __launch_bounds__(256) void gi_gemm_batch_kernel(const GemmBatch b) {
     gi_gemm_body<TM, TN, A_MAJOR, B_MAJOR>(b.p[i], rem - by * gx, by, bz, gx, b.gy[i]);
 }
 
-static bool env_remap() {
-    static const bool v = getenv("GI_GEMM_XCD_REMAP") != nullptr;   // A/B switch for measurements
+// XCD-aware tile order for launches of at least this many workgroups (0 = never): more than ~1.3
+// full rounds of 256 CUs x 4 resident workgroups.  Measured on the training step (3 A/B pairs):
+// never 2.74 ms, always 2.76-2.77 ms, >= 1300..2100 workgroups 2.70-2.71 ms.  The small launches lose
+// with the remap (an XCD's share of a 1-round launch is not balanced), the big ones win (column tiles
+// sharing an A row panel hit one L2).  GI_GEMM_XCD_REMAP=<min workgroups> overrides (measurements).
+static int remap_min_blocks() {
+    static const int v = getenv("GI_GEMM_XCD_REMAP") ? atoi(getenv("GI_GEMM_XCD_REMAP")) : 1350;
     return v;
+}
+static bool want_remap(long long blocks) {
+    const int m = remap_min_blocks();
+    return m > 0 && blocks >= m;
 }
 
 // Measurement aid (tools/gemm_launch_report.py): GI_GEMM_LOG=<file> appends one line per launch
@@ -503,11 +509,11 @@ extern "C" int gi_gemm(const gi_gemm_params* pp, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (!pp) return GI_EINVAL;
     gi_gemm_params p = *pp;
-    if (env_remap()) p.flags |= 32;
     const int rc = validate(p);
     if (rc) return rc;
     const dim3 grid = problem_grid(p);
     if (grid.x == 0) return 0;
+    if (want_remap((long long)grid.x * grid.y * grid.z)) p.flags |= 32;
     if (grid.y > 65535u || grid.z > 65535u) return GI_ELIMIT;
     hipStream_t st = (hipStream_t)stream;
     // useful flops of this launch (real dims; for grouped / split launches M resp. K is the total)
@@ -538,7 +544,6 @@ extern "C" int gi_gemm_batch(const gi_gemm_params* probs, int n, void* stream) {
         const dim3 g = problem_grid(p);
         if (g.x == 0) continue;
         b.p[k] = p; b.gx[k] = g.x; b.gy[k] = g.y; b.start[k] = total;
-        if (env_remap()) b.p[k].flags |= 32;
         total += g.x * g.y * g.z;
         flops += 2.0 * (double)p.M * (double)p.N * (double)p.K;
         ++k;
@@ -546,6 +551,8 @@ extern "C" int gi_gemm_batch(const gi_gemm_params* probs, int n, void* stream) {
     if (k == 0) return 0;
     b.start[k] = total;
     b.n = k;
+    if (want_remap(total))
+        for (int i = 0; i < k; ++i) b.p[i].flags |= 32;
     hipStream_t st = (hipStream_t)stream;
     GiProfScope prof(st, GI_PROF_GEMM, flops);
     log_launch(b.p, k, total, flops);
