@@ -16,7 +16,10 @@
  *     are int32;
  *   - `stream` is a hipStream_t; all work is enqueued asynchronously on it;
  *   - return value: 0 = success, >0 = hipError_t from a launch, <0 = argument error (GI_E*);
- *   - no exceptions cross the ABI, no global mutable state, one process per GPU.
+ *   - no exceptions cross the ABI; one process per GPU, calls come from one host thread at a time.
+ *     Process-wide state is limited to: the optional per-launch timing log (gi_prof_*), a pool of
+ *     timing-disabled hipEvents used to order the backward's two streams, and measurement switches
+ *     read once from the environment (GI_GEMM_XCD_REMAP, GI_GEMM_LOG).
  */
 #ifndef GRAPHINVENT_AMD_H
 #define GRAPHINVENT_AMD_H
