@@ -328,6 +328,22 @@ def main():
             "beyond_infinity_cache": {"achieved": probe["GBps"],
                                       "frac": round(probe["GBps"] / PEAK_HBM_GBS, 4), **probe},
         }
+        # forward-only rate: inference on the same resident batches, no_grad
+        model.eval()
+        with torch.no_grad():
+            for i in range(3):
+                model(*batches[i % N_BATCHES][:2])
+            torch.cuda.synchronize()
+            tf0 = time.perf_counter()
+            for i in range(args.steps):
+                ops.prefetch_compact(*batches[(i + 1) % N_BATCHES][:2])
+                model(*batches[i % N_BATCHES][:2])
+            torch.cuda.synchronize()
+            fdt = time.perf_counter() - tf0
+        model.train()
+        result["forward_only"] = {"value": round(BATCH * args.steps / fdt, 1), "unit": "graphs/s",
+                                  "ms_per_step": round(fdt / args.steps * 1e3, 3),
+                                  "note": "this rank only, no_grad forward of the same batches"}
         if world == 1 and not args.no_cpu_baseline and headline:
             result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_threads)
             result["speedup_vs_cpu_baseline"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
