@@ -625,3 +625,32 @@ def test_example_training_loop_learns_the_fixture(model_name):
     hist = mod.train(epochs=25, batch=32, model_name=model_name, verbose=False)
     assert all(np.isfinite(hist))
     assert hist[-1] < 0.6 * hist[0], hist
+
+
+@pytest.mark.parametrize("model_name", ["GGNN", "AttGGNN"])
+def test_four_bond_types_aromatic_preprocessing(model_name):
+    """`use_aromatic_bonds` preprocessing gives n_edge_features = 4 (parameters/constants.py:159-166):
+    four message MLPs / bond-type groups, logits and loss against the oracle, gradients by global L2."""
+    cfg = O.shaped_config(6, 3, 20, n_edge_features=4)
+    kind = "AttGGNN" if model_name == "AttGGNN" else "GGNN"
+    P = O.init_params(cfg, seed=12, model=kind)
+    n8, e8, a8 = _live_only(*synthetic.make_batch(48, 20, 6, 3, n_edge_features=4, seed=77))
+    rng = np.random.default_rng(1)                            # make a fifth of the single bonds aromatic
+    b, i, j = np.nonzero(np.triu(e8[..., 0], 1))
+    pick = rng.random(b.size) < 0.2
+    for bb, ii, jj in zip(b[pick], i[pick], j[pick]):
+        e8[bb, ii, jj, 0] = e8[bb, jj, ii, 0] = 0
+        e8[bb, ii, jj, 3] = e8[bb, jj, ii, 3] = 1
+    assert e8.shape[3] == 4 and e8[..., 3].any()
+    cls = mpnn.AttentionGGNN if kind == "AttGGNN" else mpnn.GGNN
+    model = cls(O.as_constants(dict(cfg, device="cuda")))
+    model.load_state_dict(P)
+    model = model.to("cuda")
+    out, loss, grads = hip_forward_backward(model, n8, e8, a8)
+    t = lambda x: torch.from_numpy(x).float()
+    o32, l32, g32 = O.forward_backward(P, cfg, t(n8), t(e8), t(a8), model=kind)
+    assert rel(out, o32) < TOL
+    assert abs(loss - float(l32)) < TOL * abs(float(l32))
+    num = sum(float((grads[k].double() - g32[k].double()).pow(2).sum()) for k in grads)
+    den = sum(float(g32[k].double().pow(2).sum()) for k in grads)
+    assert (num / den) ** 0.5 < 2e-3, (num / den) ** 0.5

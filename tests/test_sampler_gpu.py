@@ -114,3 +114,30 @@ def test_sampler_statistics_and_large_rows():
     assert counts[~big].sum() <= 3 * n * p[~big].sum() + 50
     with pytest.raises(RuntimeError):
         sampler.sample_actions_raw(logits.cpu(), n_nodes, edges, A)
+
+
+def test_sampler_with_five_add_dimensions():
+    """dim_f_add with implicit-H / chirality style extra factors (parameters/constants.py:56-89): the
+    unravelling of the per-node index must follow torch.nonzero's row-major order."""
+    N, dims, Fe = 9, [4, 3, 2, 3, 3], 3                     # (atom, charge, imp_H, chirality, bond)
+    dim_f_add, dim_f_conn = [N, *dims], [N, Fe]
+    A = int(np.prod(dims))
+    W = N * A + N * Fe + 1
+    B = 200
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    logits = torch.randn(B, W, device=DEV, generator=gen)
+    n_nodes = torch.randint(0, N + 1, (B,), device=DEV, generator=gen).to(torch.int8)
+    edges = torch.zeros((B, N, N, Fe), dtype=torch.int8, device=DEV)
+    u = torch.rand(B, device=DEV, generator=gen)
+    action, like, flags = sampler.sample_actions_raw(logits, n_nodes, edges, A, uniform=u)
+    idx = _flat_index(action.cpu().numpy(), N, A, Fe)
+    out = sampler.sample_actions(logits, n_nodes, edges, dim_f_add, dim_f_conn, uniform=u)
+    ref = SO.get_actions(SO.softmax_rows(logits.cpu().numpy()), idx, n_nodes.cpu().numpy(),
+                         edges.cpu().numpy(), dim_f_add, dim_f_conn)
+    assert len(out[0]) == len(ref["add"]) == 8
+    for k in range(8):
+        assert np.array_equal(out[0][k].cpu().numpy(), ref["add"][k]), k
+    for k in range(4):
+        assert np.array_equal(out[1][k].cpu().numpy(), ref["conn"][k]), k
+    assert np.array_equal(out[2].cpu().numpy(), ref["term"])
+    assert np.array_equal(out[3].cpu().numpy(), ref["invalid"])
