@@ -5,6 +5,7 @@ on torch's current HIP stream and takes/returns CUDA tensors; nothing here compu
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -205,15 +206,20 @@ def prefetch_compact(nodes: torch.Tensor, edges: torch.Tensor,
         done.record(stream)
     while len(_PREFETCHED) >= 4:                             # never-consumed entries do not pile up
         _PREFETCHED.pop(next(iter(_PREFETCHED)))
-    _PREFETCHED[_batch_key(nodes, edges)] = (nodes_c, lay, gfix, Fe, pinned, done)
+    # weak references to the very tensor objects: an address can be recycled by the allocator, an
+    # object identity cannot be confused while the entry is alive
+    _PREFETCHED[_batch_key(nodes, edges)] = (nodes_c, lay, gfix, Fe, pinned, done,
+                                             weakref.ref(nodes), weakref.ref(edges))
 
 
 def compact_count(nodes: torch.Tensor, edges: torch.Tensor):
     """Phase 1; returns (nodes, layout, gfix, S, E, U, D0, Ut).  One host read-back of 24 ints — the only
     synchronisation point of a forward pass, unless `prefetch_compact` already ran for this batch."""
     hit = _PREFETCHED.pop(_batch_key(nodes, edges), None) if _PREFETCHED else None
+    if hit is not None and not (hit[6]() is nodes and hit[7]() is edges):
+        hit = None                                           # same address, different tensors: stale
     if hit is not None:
-        nodes_c, lay, gfix, Fe, pinned, done = hit
+        nodes_c, lay, gfix, Fe, pinned, done = hit[:6]
         done.synchronize()                                   # normally long finished
         cur = torch.cuda.current_stream(nodes_c.device)
         cur.wait_event(done)
