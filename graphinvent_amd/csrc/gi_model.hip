@@ -77,6 +77,40 @@ int build_model(const gi_ggnn_dims* dp, Model& m) {
     return 0;
 }
 
+// ---- transposed weight copies -------------------------------------------------------------------
+// dgrad multiplies by W[n_out][n_in] along n_out: with the row-major weight that is the GEMM's
+// "major" B layout (four ds_read_b32 per fragment, 5-10 % slower per launch than the forward's
+// contiguous-k operand, tools/experiments/dgrad_vs_fwd.py).  A copy WT[n_in][r4(n_out)] of every
+// weight matrix, refreshed once per training step on the idle side stream during the forward, lets
+// every dgrad run as a forward-type GEMM.
+struct WShape { int n_out, n_in; };
+
+int weight_shapes(const Model& m, WShape* ws) {       // indexed by parameter index; biases get {0,0}
+    for (int i = 0; i < m.nparams; ++i) ws[i] = WShape{0, 0};
+    auto mlp = [&](const Mlp& q) {
+        for (int l = 0; l < q.layers(); ++l) ws[q.w(l)] = WShape{q.fan_out(l), q.fan_in(l)};
+    };
+    const gi_ggnn_dims& d = m.d;
+    for (int t = 0; t < d.Fe; ++t) mlp(m.msg[t]);
+    if (d.kind == GI_KIND_ATTGGNN)
+        for (int t = 0; t < d.Fe; ++t) mlp(m.eatt[t]);
+    ws[m.gru_wih] = WShape{3 * d.H, d.M};
+    ws[m.gru_whh] = WShape{3 * d.H, d.H};
+    mlp(m.att); mlp(m.emb); mlp(m.add1); mlp(m.conn1); mlp(m.add2); mlp(m.conn2); mlp(m.term2);
+    return m.nparams;
+}
+
+long long wt_layout(const Model& m, long long* off) {
+    WShape ws[160];
+    weight_shapes(m, ws);
+    long long o = 0;
+    for (int i = 0; i < m.nparams; ++i) {
+        off[i] = o;
+        if (ws[i].n_out) o += gi_r4l((long long)ws[i].n_in * gi_r4(ws[i].n_out));
+    }
+    return o;
+}
+
 // ---- workspace --------------------------------------------------------------------------------
 struct Ws {
     int R, E, U, D0, B;
@@ -235,6 +269,8 @@ struct Run {
     const float* const* P;
     int rc;
     SideStream* side = nullptr;    // optional second stream for the weight-gradient GEMMs
+    const float* wt = nullptr;     // optional transposed weight copies [n_in][r4(n_out)] (dgrad operand)
+    const long long* wt_off = nullptr;
     struct SlabPlan* sp = nullptr; // backward only: where the wgrad slabs go and what they reduce to
     float* slabs = nullptr;
     float* const* grads = nullptr;
@@ -279,21 +315,28 @@ void linear_fwd(Run& r, const Mlp* mlps, int l, const Grp& g, const float* X, in
 }
 
 // dX[rows, ncols] (+)= (dZ[rows, n_out] W[n_out, n_in][:, :ncols]) (* selu'(act))
-void linear_dgrad(Run& r, const float* const* Wg, const float* W, const Grp& g, int n_out,
+// the B operand of a dgrad: the transposed copy (contiguous k) when there is one, else W itself
+const float* dgrad_operand(const Run& r, int widx, int n_out, int n_in, gi_gemm_params& p) {
+    if (r.wt) { p.ldb = gi_r4(n_out); p.b_major = 0; return r.wt + r.wt_off[widx]; }
+    p.ldb = n_in; p.b_major = 1;
+    return r.P[widx];
+}
+
+void linear_dgrad(Run& r, const int* widx, const Grp& g, int n_out,
                   int n_in, int ncols, const float* dZ, int lddz, int rows, float* dX, int lddx,
                   const float* act, int ldact, bool accumulate) {
     if (!r.ok() || rows <= 0) return;
     gi_gemm_params p;
     gemm_defaults(p);
     p.A = dZ; p.lda = lddz; p.C = dX; p.ldc = lddx;
-    p.M = rows; p.N = ncols; p.K = n_out; p.ldb = n_in; p.b_major = 1;
+    p.M = rows; p.N = ncols; p.K = n_out;
     p.act = act; p.ldact = ldact;
     p.flags = (act ? GI_EPI_DSELU : 0) | (accumulate ? GI_EPI_ACCUM : 0);
     if (g.n) {
         p.ngroups = g.n; p.grp_off = g.off; p.max_group_rows = g.max_rows;
-        for (int t = 0; t < g.n; ++t) p.Bg[t] = Wg[t];
+        for (int t = 0; t < g.n; ++t) p.Bg[t] = dgrad_operand(r, widx[t], n_out, n_in, p);
     } else {
-        p.B = W;
+        p.B = dgrad_operand(r, widx[0], n_out, n_in, p);
     }
     pick_tile(g.n ? g.max_rows : rows, ncols, p.tm, p.tn);
     r.chk(gi_gemm(&p, r.st));
@@ -363,11 +406,12 @@ void add_fwd(Batch& b, Run& r, const float* W, const float* bias, int in, int ou
     p.flags = GI_EPI_BIAS | (selu ? GI_EPI_SELU : 0);
 }
 
-void add_dgrad(Batch& b, const float* W, int n_out, int n_in, int ncols, const float* dZ, int lddz,
-               int rows, float* dX, int lddx, const float* act, int ldact, bool accumulate) {
+void add_dgrad(Batch& b, const Run& r, int widx, int n_out, int n_in, int ncols, const float* dZ,
+               int lddz, int rows, float* dX, int lddx, const float* act, int ldact,
+               bool accumulate) {
     if (rows <= 0) return;
     gi_gemm_params& p = b.next();
-    p.A = dZ; p.lda = lddz; p.B = W; p.ldb = n_in; p.b_major = 1; p.C = dX; p.ldc = lddx;
+    p.A = dZ; p.lda = lddz; p.B = dgrad_operand(r, widx, n_out, n_in, p); p.C = dX; p.ldc = lddx;
     p.M = rows; p.N = ncols; p.K = n_out;
     p.act = act; p.ldact = ldact;
     p.flags = (act ? GI_EPI_DSELU : 0) | (accumulate ? GI_EPI_ACCUM : 0);
@@ -520,12 +564,11 @@ void mlp_jobs_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred& 
             const int widx = q.mlp->w(l);
             defer_wgrad(r, dq, sp, slabs, &widx, none, dZ, lddz, Xl, l == 0 ? q.ldx : q.ldh, nullptr,
                         q.rows);
-            const float* W = r.P[widx];
             if (l > 0) {
-                add_dgrad(bd, W, q.mlp->fan_out(l), q.mlp->fan_in(l), q.mlp->fan_in(l), dZ, lddz,
+                add_dgrad(bd, r, widx, q.mlp->fan_out(l), q.mlp->fan_in(l), q.mlp->fan_in(l), dZ, lddz,
                           q.rows, ws + q.dzs[l - 1], q.ldh, ws + q.acts[l - 1], q.ldh, false);
             } else if (q.dX) {
-                add_dgrad(bd, W, q.mlp->fan_out(0), q.mlp->fan_in(0), q.dx_cols, dZ, lddz, q.rows,
+                add_dgrad(bd, r, widx, q.mlp->fan_out(0), q.mlp->fan_in(0), q.dx_cols, dZ, lddz, q.rows,
                           q.dX, q.lddx, nullptr, 0, q.accumulate);
             }
         }
@@ -544,16 +587,15 @@ void msg_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred& dq, c
         const int lddz = (l == L - 1) ? ldz : ldh;
         const float* Xl = (l == 0) ? X : ws + acts[l - 1];
         int widx[GI_MAX_GROUPS];
-        const float* Wg[GI_MAX_GROUPS];
-        for (int t = 0; t < g.n; ++t) { widx[t] = mlps[t].w(l); Wg[t] = r.P[widx[t]]; }
+        for (int t = 0; t < g.n; ++t) widx[t] = mlps[t].w(l);
         defer_wgrad(r, dq, sp, slabs, widx, g, dZ, lddz, Xl, l == 0 ? ldx : ldh,
                     l == 0 ? a_idx : nullptr, rows);
         const Mlp& q = mlps[0];
         if (l > 0)
-            linear_dgrad(r, Wg, Wg[0], g, q.fan_out(l), q.fan_in(l), q.fan_in(l), dZ, lddz, rows,
+            linear_dgrad(r, widx, g, q.fan_out(l), q.fan_in(l), q.fan_in(l), dZ, lddz, rows,
                          ws + dzs[l - 1], ldh, ws + acts[l - 1], ldh, false);
         else if (dX)
-            linear_dgrad(r, Wg, Wg[0], g, q.fan_out(0), q.fan_in(0), dx_cols, dZ, lddz, rows, dX,
+            linear_dgrad(r, widx, g, q.fan_out(0), q.fan_in(0), dx_cols, dZ, lddz, rows, dX,
                          lddx, nullptr, 0, false);
     }
 }
@@ -623,10 +665,10 @@ void edge_chains_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferre
                         l == 0 ? a_idx : nullptr, rows);
             if (l == 0 && !c.dX) continue;
             gi_gemm_params& p = bd.next();
-            p.A = dZ; p.lda = lddz; p.M = rows; p.K = q.fan_out(l); p.ldb = q.fan_in(l);
-            p.b_major = 1;
+            p.A = dZ; p.lda = lddz; p.M = rows; p.K = q.fan_out(l);
             grouped_problem(p, g);
-            for (int t = 0; t < g.n; ++t) p.Bg[t] = r.P[widx[t]];
+            for (int t = 0; t < g.n; ++t)
+                p.Bg[t] = dgrad_operand(r, widx[t], q.fan_out(l), q.fan_in(l), p);
             if (l > 0) {
                 p.C = ws + c.dzs[l - 1]; p.ldc = c.ldh; p.N = q.fan_in(l);
                 p.act = ws + c.acts[l - 1]; p.ldact = c.ldh;
@@ -853,14 +895,41 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
                                 int ldout, const float* d_out, int lddout, float* const* grads,
                                 void* stream, void* side_stream) {
     return gi_ggnn_backward_phase(dp, params, gp, ws, slabs, y_out, ldout, d_out, lddout, grads,
-                                  stream, side_stream, GI_BWD_ALL);
+                                  stream, side_stream, GI_BWD_ALL, nullptr);
+}
+
+extern "C" long long gi_ggnn_wt_floats(const gi_ggnn_dims* d) {
+    Model m;
+    if (build_model(d, m) || m.nparams > 160) return GI_EINVAL;
+    long long off[160];
+    return wt_layout(m, off);
+}
+
+extern "C" int gi_ggnn_transpose_weights(const gi_ggnn_dims* d, const float* const* params,
+                                         float* wt, void* stream) {
+    (void)hipGetLastError();
+    Model m;
+    const int rc = build_model(d, m);
+    if (rc) return rc;
+    if (!params || !wt || m.nparams > 160) return GI_EINVAL;
+    long long off[160];
+    wt_layout(m, off);
+    WShape shp[160];
+    weight_shapes(m, shp);
+    gi_transpose_desc descs[160];
+    int n = 0;
+    for (int i = 0; i < m.nparams; ++i)
+        if (shp[i].n_out)
+            descs[n++] = gi_transpose_desc{params[i], wt + off[i], shp[i].n_out, shp[i].n_in,
+                                           gi_r4(shp[i].n_out)};
+    return gi_transpose_batch(descs, n, stream);
 }
 
 extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const* params,
                                       const gi_graph* gp, float* ws, float* slabs,
                                       const float* y_out, int ldout, const float* d_out, int lddout,
                                       float* const* grads, void* stream, void* side_stream,
-                                      int phase) {
+                                      int phase, const float* wt) {
     if (phase != GI_BWD_ALL && phase != GI_BWD_READOUT && phase != GI_BWD_PASSES) return GI_EINVAL;
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     Model m;
@@ -909,6 +978,8 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
     SideStream side_obj{(hipStream_t)side_stream, 0};
     r.side = side_stream ? &side_obj : nullptr;
     r.sp = &sp; r.slabs = slabs; r.grads = grads;
+    long long wt_off[160];
+    if (wt) { wt_layout(m, wt_off); r.wt = wt; r.wt_off = wt_off; }
     const Grp none{0, nullptr, 0};
     const float* hxP = ws + w.hx[d.passes];
     float* dh = ws + w.dh;
@@ -1009,10 +1080,10 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
             defer_wgrad(r, dq, sp, slabs, &whh, none, gh, w.ld3H, hx, w.ldhx, nullptr, R);
             // d agg = d gi W_ih;  d h_prev += d gh W_hh   (one launch)
             Batch bd;
-            add_dgrad(bd, params[m.gru_wih], 3 * d.H, d.M, d.M, gi, w.ld3H, R, dagg, w.ldM, nullptr, 0,
+            add_dgrad(bd, r, m.gru_wih, 3 * d.H, d.M, d.M, gi, w.ld3H, R, dagg, w.ldM, nullptr, 0,
                       false);
             if (p > 0)
-                add_dgrad(bd, params[m.gru_whh], 3 * d.H, d.H, d.H, gh, w.ld3H, R, dh2, w.ldH, nullptr,
+                add_dgrad(bd, r, m.gru_whh, 3 * d.H, d.H, d.H, gh, w.ld3H, R, dh2, w.ldH, nullptr,
                           0, true);
             flush_batch(r, bd, false);
         }

@@ -130,7 +130,7 @@ def new_grad_bucket(params, device):
     return gflat, grads, offs
 
 
-def ggnn_backward_raw(tape, out, d_out, params, early_hook=None, bucket=None):
+def ggnn_backward_raw(tape, out, d_out, params, early_hook=None, bucket=None, wt=None):
     """The fused backward; consumes the tape's activations in place.  Returns (grads, gflat):
     per-parameter gradient views into ONE flat fp32 buffer (state_dict order, 16-byte aligned
     segments) — the bucket a data-parallel all-reduce operates on.
@@ -154,14 +154,18 @@ def ggnn_backward_raw(tape, out, d_out, params, early_hook=None, bucket=None):
     args = (C.byref(dims), _ptr_table(params), C.byref(gs), ws.data_ptr(), slabs.data_ptr(),
             out.data_ptr(), out.stride(0), d_out.data_ptr(), d_out.stride(0), _ptr_table(grads),
             main.cuda_stream, side)
+    wt_ptr = None
+    if wt is not None:                       # (transposed weight copies, their "ready" event)
+        main.wait_event(wt[1])
+        wt_ptr = wt[0].data_ptr()
     if early_hook is None:
-        _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_ALL), "gi_ggnn_backward")
+        _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_ALL, wt_ptr), "gi_ggnn_backward")
         return grads, gflat
-    _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_READOUT), "gi_ggnn_backward(readout)")
+    _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_READOUT, wt_ptr), "gi_ggnn_backward(readout)")
     ready = torch.cuda.Event()
     ready.record(torch.cuda.ExternalStream(side, device=dev) if side else main)
     early_hook(gflat, offs[lib.gi_ggnn_first_readout_param(C.byref(dims))], ready)
-    _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_PASSES), "gi_ggnn_backward(passes)")
+    _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_PASSES, wt_ptr), "gi_ggnn_backward(passes)")
     return grads, gflat
 
 
@@ -170,7 +174,9 @@ class _GGNNFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, owner, nodes, edges, *params):
+        start = owner._weights_final_event(nodes.device)
         out, tape = ggnn_forward_raw(owner.constants, nodes, edges, params, owner._KIND)
+        ctx.wt = owner._transposed_weights(tape[0], params, start)
         ctx.owner = owner
         ctx.tape = tape
         ctx.save_for_backward(out, *params)
@@ -184,7 +190,7 @@ class _GGNNFunction(torch.autograd.Function):
         tape, ctx.tape = ctx.tape, None
         out, *params = ctx.saved_tensors
         grads, gflat = ggnn_backward_raw(tape, out, d_out, params,
-                                         getattr(ctx.owner, "_grad_ready_hook", None))
+                                         getattr(ctx.owner, "_grad_ready_hook", None), wt=ctx.wt)
         ctx.owner._grad_bucket = gflat          # the flat bucket graphinvent_amd.dp all-reduces
         return (None, None, None, *grads)
 
@@ -199,7 +205,9 @@ class _GGNNDirect(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, nodes, edges, anchor):
         params = owner._params()
+        start = owner._weights_final_event(nodes.device) if anchor is not None else None
         out, tape = ggnn_forward_raw(owner.constants, nodes, edges, params, owner._KIND)
+        ctx.wt = owner._transposed_weights(tape[0], params, start) if anchor is not None else None
         ctx.owner = owner
         ctx.tape = tape
         ctx.save_for_backward(out)
@@ -212,7 +220,7 @@ class _GGNNDirect(torch.autograd.Function):
                                "activations in place (retain_graph is not supported)")
         tape, ctx.tape = ctx.tape, None
         (out,) = ctx.saved_tensors
-        ctx.owner._backward_into_grads(tape, out, d_out)
+        ctx.owner._backward_into_grads(tape, out, d_out, ctx.wt)
         return None, None, None, None
 
 
@@ -246,11 +254,11 @@ class _FusedMPNN(torch.nn.Module):
         cls = self.__class__
         new = cls.__new__(cls)
         memo[id(self)] = new
-        skip = ("_param_cache", "_bucket", "_anchor", "_grad_bucket", "_grad_ready_hook")
+        skip = ("_param_cache", "_bucket", "_anchor", "_grad_bucket", "_grad_ready_hook", "_wt")
         import copy as _copy
         for k, v in self.__dict__.items():
             new.__dict__[k] = None if k in skip else _copy.deepcopy(v, memo)
-        for k in ("_param_cache", "_bucket", "_anchor"):
+        for k in ("_param_cache", "_bucket", "_anchor", "_wt"):
             new.__dict__.pop(k, None)
         return new
 
@@ -270,7 +278,39 @@ class _FusedMPNN(torch.nn.Module):
                 anchor = self.__dict__["_anchor"] = torch.zeros((), requires_grad=True)
         return _GGNNDirect.apply(self, nodes, edges, anchor)
 
-    def _backward_into_grads(self, tape, out, d_out) -> None:
+    # ---- transposed weight copies for the dgrad GEMMs (GI_DGRAD_WT=1) -------------------------------
+    def _weights_final_event(self, device):
+        """An event on the current stream BEFORE the forward is enqueued: the weights are final from
+        here on (the optimizer step was enqueued earlier on this stream)."""
+        if _os_environ_flag("GI_DGRAD_WT", "0") != "1" or not torch.is_grad_enabled():
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        return ev
+
+    def _transposed_weights(self, dims, params, start):
+        """Refresh WT on the (otherwise idle) side stream while the forward runs on the main stream;
+        returns (WT buffer, ready event) for the backward, or None."""
+        if start is None:
+            return None
+        dev = params[0].device
+        side = _side_stream(dev)
+        if not side:
+            return None
+        lib = _L.load()
+        wt = self.__dict__.get("_wt")
+        n = lib.gi_ggnn_wt_floats(C.byref(dims))
+        if wt is None or wt.numel() != n or wt.device != dev:
+            wt = self.__dict__["_wt"] = torch.empty(int(n), dtype=torch.float32, device=dev)
+        st = torch.cuda.ExternalStream(side, device=dev)
+        st.wait_event(start)
+        _L.check(lib.gi_ggnn_transpose_weights(C.byref(dims), _ptr_table(params), wt.data_ptr(), side),
+                 "gi_ggnn_transpose_weights")
+        ready = torch.cuda.Event()
+        ready.record(st)
+        return wt, ready
+
+    def _backward_into_grads(self, tape, out, d_out, wt=None) -> None:
         """Run the fused backward and accumulate into ``param.grad`` like autograd would."""
         params = self._params()
         fresh = all(p.grad is None for p in params)
@@ -282,7 +322,7 @@ class _FusedMPNN(torch.nn.Module):
                     any(g.shape != p.shape for g, p in zip(bucket[1], params)):
                 bucket = self.__dict__["_bucket"] = new_grad_bucket(params, out.device)
         hook = self._grad_ready_hook if fresh else None      # early exchange needs the fresh bucket
-        grads, gflat = ggnn_backward_raw(tape, out, d_out, params, hook, bucket)
+        grads, gflat = ggnn_backward_raw(tape, out, d_out, params, hook, bucket, wt)
         with torch.no_grad():
             if fresh:
                 for p, g in zip(params, grads):

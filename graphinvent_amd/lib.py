@@ -27,7 +27,7 @@ EPI_BIAS, EPI_SELU, EPI_DSELU, EPI_ACCUM, GEMM_SPLITK = 1, 2, 4, 8, 16
 KIND_GGNN, KIND_ATTGGNN = 0, 1
 BWD_ALL, BWD_READOUT, BWD_PASSES = 0, 1, 2
 COUNTS = 24          # GI_COUNTS
-ABI_VERSION = 2      # GI_ABI_VERSION
+ABI_VERSION = 3      # GI_ABI_VERSION
 DTYPE_F32, DTYPE_I8 = 0, 1
 
 vp = C.c_void_p
@@ -117,7 +117,10 @@ SIGNATURES = {
     "gi_ggnn_backward": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), C.POINTER(Graph), vp, vp, vp, ci,
                               vp, ci, C.POINTER(vp), vp, vp]),
     "gi_ggnn_backward_phase": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), C.POINTER(Graph), vp, vp, vp,
-                                    ci, vp, ci, C.POINTER(vp), vp, vp, ci]),
+                                    ci, vp, ci, C.POINTER(vp), vp, vp, ci, vp]),
+    "gi_ggnn_wt_floats": (cll, [C.POINTER(GgnnDims)]),
+    "gi_ggnn_transpose_weights": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), vp, vp]),
+    "gi_transpose_batch": (ci, [vp, ci, vp]),
     "gi_ggnn_first_readout_param": (ci, [C.POINTER(GgnnDims)]),
 }
 

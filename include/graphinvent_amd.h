@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GI_ABI_VERSION 2
+#define GI_ABI_VERSION 3
 #define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
 #define GI_MAX_NODES 128      /* max max_n_nodes */
 #define GI_P0_MAX_CLASSES 256 /* max distinct node feature rows for the pass-0 shortcut */
@@ -323,7 +323,17 @@ int gi_ggnn_backward(const gi_ggnn_dims* d, const float* const* params, const gi
 int gi_ggnn_backward_phase(const gi_ggnn_dims* d, const float* const* params, const gi_graph* g,
                            float* ws, float* slabs, const float* y_out, int ldout,
                            const float* d_out, int lddout, float* const* grads, void* stream,
-                           void* side_stream, int phase);
+                           void* side_stream, int phase, const float* wt);
+/* Optional transposed weight copies for the backward's dgrad GEMMs (`wt` above, may be NULL):
+ * gi_ggnn_wt_floats() floats; gi_ggnn_transpose_weights() writes WT[n_in][r4(n_out)] of every weight
+ * matrix of params (one batched launch sequence, e.g. on a side stream during the forward).  With
+ * them every dgrad runs as a forward-type GEMM (contiguous-k B operand). */
+long long gi_ggnn_wt_floats(const gi_ggnn_dims* d);
+int gi_ggnn_transpose_weights(const gi_ggnn_dims* d, const float* const* params, float* wt,
+                              void* stream);
+typedef struct gi_transpose_desc { const float* src; float* dst; int rows, cols, ldd; } gi_transpose_desc;
+/* dst[c, r] = src[r, c] for n row-major matrices src[rows, cols] -> dst[cols, ldd] */
+int gi_transpose_batch(const gi_transpose_desc* descs, int n, void* stream);
 int gi_ggnn_first_readout_param(const gi_ggnn_dims* d);
 
 #ifdef __cplusplus
