@@ -14,13 +14,16 @@ PER GPU (weak scaling).  fp32 throughout (the reference's dtype and the parity b
 
 Rank 0 prints one JSON line.  Besides the contract fields it carries
   roofline      dominant kernel family (fp32-MFMA GEMM): useful FLOP/s measured with HIP events
-                around every launch on its stream (gi_prof_*), over extra profiled steps of the
-                same workload, against the 157.3 TFLOP/s fp32 matrix peak
+                around every launch on the stream it runs on (gi_prof_*), over extra profiled steps
+                of the same workload, against the 157.3 TFLOP/s fp32 matrix peak; achieved = FLOP /
+                union of the launch intervals (the backward runs GEMMs on two streams at once), the
+                FLOP / sum-of-durations figure is reported next to it
   aggregation   the segmented-sum kernel: GB/s inside the training step (L2/MALL resident at this
-                batch size) and on a 64x replicated graph batch whose working set exceeds the
+                batch size) and on a 128x replicated graph batch whose message rows exceed the
                 256 MB Infinity Cache, against 8 TB/s HBM3E
+  forward_only  no_grad forward rate on the same batches
   cpu_baseline  the oracle (CPU restatement of the reference algorithm, kind "port") on the host
-                cores, same workload, bounded sample; N == 1 only
+                cores at their best thread count, same workload, bounded sample; N == 1 only
 """
 import argparse
 import ctypes as C

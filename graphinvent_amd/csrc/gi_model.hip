@@ -1,4 +1,5 @@
-// Host-side orchestration of the whole GGNN forward / backward on one HIP stream (gfx950).
+// Host-side orchestration of the whole GGNN / AttentionGGNN forward and backward (gfx950): the
+// forward on one HIP stream, the backward on two (dZ chain; weight gradients + their reductions).
 //
 // One call from Python enqueues every kernel of `SummationMPNN.forward`'s message passes and
 // `GGNN.readout` (gnn/summation_mpnn.py:128-149, gnn/mpnn.py:284-303) — no Python between
@@ -10,8 +11,10 @@
 //   message lvl : U rows, one per distinct (source node, bond type) pair, bond-type-major (rows of
 //                 type t = [type_off[t], type_off[t+1])); see gi_compact.hip
 //   graph level : B rows
-// Backward runs IN PLACE over the saved activations: the buffer of layer l's SELU output is
-// overwritten by dZ_l (gradient w.r.t. its pre-activation) once nobody needs the activation.
+//   pass 0      : D0 rows, one per (feature class, bond type) pair, when the shortcut applies
+// Backward: the dZ of a stack's LAST layer overwrites that layer's output in place; the dZ of hidden
+// layers go to their own buffers, so that every weight-gradient GEMM (which needs dZ_l and the
+// activation below it) can be deferred, batched and run on the side stream.
 #include <stdlib.h>
 #include <string.h>
 
