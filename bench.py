@@ -16,8 +16,12 @@ Rank 0 prints one JSON line.  Besides the contract fields it carries
   roofline      dominant kernel family (fp32-MFMA GEMM): useful FLOP/s measured with HIP events
                 around every launch on the stream it runs on (gi_prof_*), over extra profiled steps
                 of the same workload, against the 157.3 TFLOP/s fp32 matrix peak; achieved = FLOP /
-                union of the launch intervals (the backward runs GEMMs on two streams at once), the
-                FLOP / sum-of-durations figure is reported next to it
+                SUM of the launch durations = flop_per_launch / avg_launch_us, the per-launch figure
+                the rocprofv3 kernel stats under profiles/ reproduce (the backward runs GEMMs on two
+                streams at once: the FLOP / union-of-intervals figure is reported next to it)
+  extra_configs the non-headline BASELINE configurations on this GPU (configs[2]: GGNN on
+                ZINC-shaped graphs B=1000; configs[4] per-GPU work: AttentionGGNN on ChEMBL-shaped
+                graphs B=250), a few timed steps each
   aggregation   the segmented-sum kernel: GB/s inside the training step (L2/MALL resident at this
                 batch size) and on a 128x replicated graph batch whose message rows exceed the
                 256 MB Infinity Cache, against 8 TB/s HBM3E
@@ -48,7 +52,7 @@ from graphinvent_amd.loss import apd_kl_loss                 # noqa: E402
 BATCH = 1000
 N_BATCHES = 4                  # distinct resident minibatches cycled through
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PROFILE_DIR = "r01"            # profiles/<dir>/traffic.json = PMC-derived HBM traffic per GEMM launch
+PROFILE_DIR = "r02"            # profiles/<dir>/: rocprofv3 kernel stats + PMC passes of this command
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
 
 
@@ -56,15 +60,16 @@ SHAPE = "gdb13"                # --shape zinc runs BASELINE configs[2] (not the 
 MODEL = "ggnn"                 # --model attggnn --shape chembl --batch 250 = configs[4]'s per-GPU work
 
 
-def workload_constants(device: str):
+def workload_constants(device: str, shape: str = None):
     from collections import namedtuple
-    sh = synthetic.SHAPES[SHAPE]
+    shape = shape or SHAPE
+    sh = synthetic.SHAPES[shape]
     na, nc, N, Fe = sh["n_atom_types"], sh["n_formal_charge"], sh["max_n_nodes"], sh["n_edge_features"]
     cfg = dict(  # parameters/defaults.py:280-300 with hidden/message 128 (BASELINE configs[1])
         device=device, big_positive=1e6, big_negative=-1e6, n_node_features=na + nc,
         n_edge_features=Fe, max_n_nodes=N, len_f_add_per_node=na * nc * Fe, len_f_conn_per_node=Fe,
-        hidden_node_features=128 if SHAPE == "gdb13" else 100,
-        message_size=128 if SHAPE == "gdb13" else 100, message_passes=3, enn_depth=4,
+        hidden_node_features=128 if shape == "gdb13" else 100,
+        message_size=128 if shape == "gdb13" else 100, message_passes=3, enn_depth=4,
         enn_hidden_dim=250, enn_dropout_p=0.0, gather_width=100, gather_att_depth=4,
         gather_att_hidden_dim=250, gather_att_dropout_p=0.0, gather_emb_depth=4,
         gather_emb_hidden_dim=250, gather_emb_dropout_p=0.0, mlp1_depth=4, mlp1_hidden_dim=500,
@@ -75,13 +80,83 @@ def workload_constants(device: str):
     return cfg, namedtuple("CONSTANTS", sorted(cfg))(**cfg)
 
 
-def make_batches(rank: int, device):
-    sh = synthetic.SHAPES[SHAPE]
+def make_batches(rank: int, device, shape: str = None, batch: int = None, n_batches: int = N_BATCHES):
+    sh = synthetic.SHAPES[shape or SHAPE]
     out = []
-    for i in range(N_BATCHES):
-        n8, e8, a8 = synthetic.make_batch(BATCH, **sh, seed=1000 * rank + i)
+    for i in range(n_batches):
+        n8, e8, a8 = synthetic.make_batch(batch or BATCH, **sh, seed=1000 * rank + i)
         out.append(tuple(torch.from_numpy(x).float().to(device) for x in (n8, e8, a8)))
     return out
+
+
+class Workload:
+    """model + optimizer + scheduler + data-parallel trainer + resident synthetic minibatches of one
+    configuration; `run_step()` is one training step in the order of Workflow.py:785-796."""
+
+    def __init__(self, shape, model_name, batch, rank, device, total_steps, prefetch=True,
+                 n_batches=N_BATCHES):
+        self.shape, self.model_name, self.batch, self.prefetch = shape, model_name, batch, prefetch
+        self.cfg, constants = workload_constants("cuda", shape)
+        torch.manual_seed(0)                               # identical initial weights on every rank
+        cls = mpnn.GGNN if model_name == "ggnn" else mpnn.AttentionGGNN
+        self.model = cls(constants).to(device).train()
+        self.batches = make_batches(rank, device, shape, batch, n_batches)
+        self.opt = FusedAdam(self.model.parameters(), lr=1e-4)   # defaults.py:120 init_lr; one launch/step
+        self.sched = torch.optim.lr_scheduler.OneCycleLR(self.opt, max_lr=1e-4,
+                                                         total_steps=total_steps + 1)
+        self.trainer = dp.DataParallel(self.model, self.opt, self.sched, loss_fn=apd_kl_loss)
+        self.trainer.broadcast_parameters()
+        self.i = 0
+
+    # Like the block loader (graphinvent_amd/loader.py), the loop hands the NEXT batch to
+    # ops.prefetch_compact before stepping on the current one: the counting phase of graph_compact
+    # (and its host read-back) for batch k+1 runs on a side stream during step k.  Every step still
+    # compacts its own batch — the result is consumed once, nothing is cached across steps.
+    def run_step(self):
+        nb = len(self.batches)
+        if self.prefetch:
+            nxt = self.batches[(self.i + 1) % nb]
+            ops.prefetch_compact(nxt[0], nxt[1])
+        loss = self.trainer.step(*self.batches[self.i % nb])
+        self.i += 1
+        return loss
+
+
+def timed_steps(wl: Workload, steps: int, warmup: int, world: int, device):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; returns
+    (seconds: max over ranks, last loss)."""
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    for _ in range(warmup):
+        wl.run_step()
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = wl.run_step()
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss_val = float(loss)
+    if not np.isfinite(loss_val):
+        raise SystemExit("non-finite loss in the timed region")
+    return dt, loss_val
+
+
+def workload_text(shape, model_name, cfg):
+    name = {"ggnn": "GGNN", "attggnn": "AttentionGGNN"}[model_name]
+    return (f"{name} hidden={cfg['hidden_node_features']} message={cfg['message_size']} 3 MP steps, "
+            f"{shape}-shaped synthetic graphs max_n_nodes={synthetic.SHAPES[shape]['max_n_nodes']}, "
+            "train step fwd+KL+bwd+allreduce+Adam")
+
+
+EXTRA_CONFIGS = (  # (BASELINE.json entry, shape, model, graphs per GPU per step)
+    ("configs[2]: GGNN on ZINC-250k-shaped graphs, batch=1000", "zinc", "ggnn", 1000),
+    ("configs[4] per-GPU work: AttGGNN on ChEMBL-shaped graphs max_n_nodes=88", "chembl", "attggnn", 250),
+)
 
 
 def seg_sum_hbm_probe(device, M=128, replicas=128):
@@ -116,7 +191,7 @@ def seg_sum_hbm_probe(device, M=128, replicas=128):
                 us=round(ms * 1e3, 2), GBps=round(nbytes / ms / 1e6, 1))
 
 
-def cpu_baseline(cfg, threads: int = 0, timed_steps: int = 2):
+def cpu_baseline(cfg, threads: int = 0, n_timed: int = 3):
     """The oracle (reference algorithm on torch-CPU ops) timed on the host cores.  threads = 0: the
     thread count is chosen by a one-step probe of 8 / 16 / 32 threads — more threads make this
     workload SLOWER on the 256-CPU box (16: ~1130 graphs/s, 64: ~540, 256: 6; the GEMMs are small),
@@ -159,9 +234,9 @@ def cpu_baseline(cfg, threads: int = 0, timed_steps: int = 2):
         probe = f"; thread count picked by a 1-step probe (graphs/s at {probe.strip()})"
     torch.set_num_threads(threads)
     one()
-    dt = timed(timed_steps)
+    dt = timed(n_timed)
     return dict(value=round(BATCH / dt, 1), unit="graphs/s", cores=threads, kind="port",
-                sample=f"{timed_steps} timed steps (+1 warm-up) of the same B={BATCH} GGNN "
+                sample=f"{n_timed} timed steps (+1 warm-up) of the same B={BATCH} GGNN "
                        f"training step (fwd+KL+bwd+Adam), torch-CPU oracle, {threads} threads of "
                        f"{os.cpu_count()} host CPUs{probe}")
 
@@ -184,6 +259,11 @@ def main():
                     help="run graph_compact's counting phase inside the step instead of one batch ahead")
     ap.add_argument("--no-probe", action="store_true",
                     help="skip the beyond-Infinity-Cache seg_sum probe (keeps kernel traces clean)")
+    ap.add_argument("--probe-only", action="store_true",
+                    help="run ONLY the beyond-Infinity-Cache seg_sum probe (for rocprofv3 --pmc passes "
+                         "over the aggregation kernel) and print its JSON")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the non-headline BASELINE configurations (extra_configs)")
     ap.add_argument("--batch", type=int, default=BATCH, help="graphs per GPU per step")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path).  gloo + ranks sharing one GPU is "
@@ -208,6 +288,9 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if args.probe_only:
+        print(json.dumps({"aggregation_probe": seg_sum_hbm_probe(device)}), flush=True)
+        return
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -215,46 +298,15 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    cfg, constants = workload_constants("cuda")
-    torch.manual_seed(0)                                   # identical initial weights on every rank
-    model = (mpnn.GGNN if MODEL == "ggnn" else mpnn.AttentionGGNN)(constants).to(device).train()
-    batches = make_batches(rank, device)
-    total_steps = args.steps + args.warmup + 16
-    opt = FusedAdam(model.parameters(), lr=1e-4)           # Adam, defaults.py:120 init_lr; one HIP launch/step
-    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-4, total_steps=total_steps + 1)
-    trainer = dp.DataParallel(model, opt, sched, loss_fn=apd_kl_loss)
-    trainer.broadcast_parameters()
-
     def barrier():
         if world > 1:
             dist.barrier()
 
-    # Like the block loader (graphinvent_amd/loader.py), the loop hands the NEXT batch to
-    # ops.prefetch_compact before stepping on the current one: the counting phase of graph_compact
-    # (and its host read-back) for batch k+1 runs on a side stream during step k.  Every step still
-    # compacts its own batch — the result is consumed once, nothing is cached across steps.
-    def run_step(i):
-        if not args.no_prefetch_compact:
-            nxt = batches[(i + 1) % N_BATCHES]
-            ops.prefetch_compact(nxt[0], nxt[1])
-        return trainer.step(*batches[i % N_BATCHES])
-
-    step_i = 0
-    for _ in range(args.warmup):
-        run_step(step_i); step_i += 1
-    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = run_step(step_i); step_i += 1
-    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    loss_val = float(loss)
-    if not np.isfinite(loss_val):
-        raise SystemExit("non-finite loss in the timed region")
+    total_steps = args.steps + args.warmup + 64
+    wl = Workload(SHAPE, MODEL, BATCH, rank, device, total_steps,
+                  prefetch=not args.no_prefetch_compact)
+    cfg, model, trainer, batches = wl.cfg, wl.model, wl.trainer, wl.batches
+    dt, loss_val = timed_steps(wl, args.steps, args.warmup, world, device)
     if world > 1:
         # every rank stepped on different graphs: the weights can only still be identical if the
         # gradient exchange (incl. its overlap with the backward) delivered the same mean everywhere
@@ -275,10 +327,7 @@ def main():
         "config": {"workload": ("BASELINE configs[1]: GGNN hidden=128 message=128 3 MP steps, "
                                 "GDB-13-shaped synthetic graphs max_n_nodes=13, train step "
                                 "fwd+KL+bwd+allreduce+Adam") if headline else
-                               (f"NOT the headline config: {MODEL} on {SHAPE}-shaped synthetic graphs "
-                                f"max_n_nodes={synthetic.SHAPES[SHAPE]['max_n_nodes']}, hidden="
-                                f"{cfg['hidden_node_features']}, 3 MP steps, train step "
-                                "fwd+KL+bwd+allreduce+Adam"),
+                               "NOT the headline config: " + workload_text(SHAPE, MODEL, cfg),
                    "batch_per_gpu": BATCH, "global_batch": BATCH * world,
                    "parallelism": f"dp{world}", "loss": round(loss_val, 5),
                    "allreduce": ("none (1 rank)" if world == 1 else
@@ -287,6 +336,35 @@ def main():
     }
     if args.backend != "nccl":
         result["config"]["backend"] = args.backend + " (control-flow smoke test, not a measurement)"
+
+    # ---- N > 1: what the exchange step costs (all ranks run the same extra steps) ----------------
+    if world > 1:
+        import socket
+        seen = [None] * world
+        dist.all_gather_object(seen, f"{socket.gethostname()}:cuda{local_rank}:"
+                                     f"{torch.cuda.get_device_name(local_rank)}")
+        k = 8
+
+        def ms_per_step_now():
+            d, _ = timed_steps(wl, k, 2, world, device)
+            return d / k * 1e3
+        t_overlap = ms_per_step_now()
+        had_overlap = trainer.overlap
+        trainer.overlap = False
+        t_serial = ms_per_step_now()                           # one all-reduce after the backward
+        real_world, trainer.world_size = trainer.world_size, 1
+        t_none = ms_per_step_now()                             # no exchange at all (ranks diverge: last)
+        trainer.world_size, trainer.overlap = real_world, had_overlap
+        result["allreduce"] = {
+            "backend": dist.get_backend(), "ranks_seen": dist.get_world_size(), "ranks": seen,
+            "bucket_MB": round(sum(p.numel() for p in model.parameters()) * 4 / 1e6, 2),
+            "ms_per_step_overlapped": round(t_overlap, 3), "ms_per_step_after_backward": round(t_serial, 3),
+            "ms_per_step_without_exchange": round(t_none, 3),
+            "exposed_ms_overlapped": round(t_overlap - t_none, 3),
+            "exposed_ms_after_backward": round(t_serial - t_none, 3),
+            "method": f"{k} timed steps each (max over ranks): product path; GI_DP_OVERLAP-off "
+                      "equivalent; exchange skipped"}
+        trainer.broadcast_parameters()                         # re-align the ranks for what follows
 
     # ---- roofline leg: per-launch HIP-event timing of the GEMM family + seg_sum -----------------
     # Every rank runs the extra steps (they contain the gradient all-reduce, a collective); only
@@ -313,34 +391,29 @@ def main():
         ms = (C.c_double * 2)(); busy = (C.c_double * 2)(); work = (C.c_double * 2)(); n = (C.c_int * 2)()
         lib.check(handle.gi_prof_collect(ms, busy, work, n), "gi_prof_collect")
         handle.gi_prof_enable(0)
-        # The backward runs its weight-gradient GEMMs on a second stream, concurrently with the dZ
-        # chain: two GEMM launches are in flight at once and each one's own duration stretches.
-        # Family throughput = useful FLOP / time during which at least one GEMM launch was executing
-        # (union of the per-launch event intervals); flop / (sum of durations) is reported next to it.
-        tf = work[0] / (busy[0] * 1e-3) / 1e12 if busy[0] > 0 else 0.0
-        tf_sum = work[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
-        traffic = None                      # HBM-side bytes per launch from the committed PMC passes
-        tpath = os.path.join(ROOT, "profiles", PROFILE_DIR, "traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_side_bytes_per_launch")
+        # Headline: FLOP / SUM of the launch durations (= flop_per_launch / avg_launch_us), the
+        # per-launch figure that `rocprofv3 --kernel-trace --stats` of this command reproduces
+        # (profiles/<round>/).  The backward runs its weight-gradient GEMMs on a second stream
+        # concurrently with the dZ chain, so FLOP / union-of-intervals is higher; reported next to it.
+        tf_union = work[0] / (busy[0] * 1e-3) / 1e12 if busy[0] > 0 else 0.0
+        tf = work[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
         result["roofline"] = {
-            "bound": "mfma", "kernel": "gi_gemm_kernel<TM,TN,A_MAJOR,B_MAJOR> (fp32 MFMA GEMM family)",
+            "bound": "mfma", "kernel": "gi_gemm*/gi_chain* (fp32 MFMA GEMM family, v_mfma_f32_32x32x2_f32)",
             "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-            "traffic_source": f"profiles/{PROFILE_DIR}/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                              "passes, bytes per launch; not re-measured live)",
+            "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "traffic_note": f"not measurable inside bench.py; the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                            f"passes of this command are under profiles/{PROFILE_DIR}/ (traffic.json)",
             "launches_per_step": n[0] // prof_steps,
             "avg_launch_us": round(ms[0] * 1e3 / max(n[0], 1), 2),
             "flop_per_launch": round(work[0] / max(n[0], 1)),
-            "gemm_busy_ms_per_step": round(busy[0] / prof_steps, 3),
             "gemm_sum_of_launch_ms_per_step": round(ms[0] / prof_steps, 3),
-            "achieved_by_sum_of_launch_durations": round(tf_sum, 2),
-            "frac_by_sum_of_launch_durations": round(tf_sum / PEAK_FP32_MFMA_TFLOPS, 4),
+            "gemm_busy_ms_per_step": round(busy[0] / prof_steps, 3),
+            "achieved_union_of_intervals": round(tf_union, 2),
+            "frac_union_of_intervals": round(tf_union / PEAK_FP32_MFMA_TFLOPS, 4),
             "useful_gflop_per_step": round(work[0] / prof_steps / 1e9, 2),
             "step_useful_tflops": round(work[0] / prof_steps / 1e12 / (dt / args.steps), 2),
             "method": f"hipEvent pair around every launch on the stream it runs on, {prof_steps} extra "
-                      "steps; achieved = FLOP / union of launch intervals (two streams overlap in the "
-                      "backward), avg_launch_us = plain mean of the per-launch durations",
+                      "steps; achieved = useful FLOP / sum of the per-launch durations",
         }
         agg_gbs = seg_bytes / (busy[1] * 1e-3) / 1e9 if busy[1] > 0 else 0.0
         probe = dict(GBps=0.0, skipped=True) if args.no_probe else seg_sum_hbm_probe(device)
@@ -368,6 +441,28 @@ def main():
         result["forward_only"] = {"value": round(BATCH * args.steps / fdt, 1), "unit": "graphs/s",
                                   "ms_per_step": round(fdt / args.steps * 1e3, 3),
                                   "note": "this rank only, no_grad forward of the same batches"}
+    barrier()
+
+    # ---- the non-headline BASELINE configurations, observed by the same run ----------------------
+    if headline and not args.no_extra_configs:
+        del wl, model, trainer, batches
+        torch.cuda.empty_cache()
+        extra = []
+        for label, shape, model_name, batch in EXTRA_CONFIGS:
+            k, w = 5, 2
+            ewl = Workload(shape, model_name, batch, rank, device, k + w + 8, n_batches=2)
+            edt, eloss = timed_steps(ewl, k, w, world, device)
+            extra.append({"baseline_config": label,
+                          "workload": workload_text(shape, model_name, ewl.cfg),
+                          "batch_per_gpu": batch, "steps": k, "warmup": w,
+                          "ms_per_step": round(edt / k * 1e3, 3),
+                          "value": round(batch * world * k / edt, 1), "unit": "graphs/s",
+                          "loss": round(eloss, 5)})
+            del ewl
+            torch.cuda.empty_cache()
+        result["extra_configs"] = extra
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline and headline:
             result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_threads)
             result["speedup_vs_cpu_baseline"] = round(result["value"] / result["cpu_baseline"]["value"], 1)

@@ -479,14 +479,20 @@ struct SideStream {
     hipStream_t st;
     int used;
     static constexpr int NEV = 48;
+    // one pool per device (events belong to the device that is current when they are created);
+    // callers hold the GIL / call from one thread per process, like every entry point of this ABI
     static hipEvent_t* pool() {
-        static hipEvent_t ev[NEV];
-        static bool made = false;
-        if (!made) {
-            for (hipEvent_t& e : ev) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-            made = true;
+        constexpr int MAXDEV = 16;
+        static hipEvent_t ev[MAXDEV][NEV];
+        static bool made[MAXDEV] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev = (dev >= 0 && dev < MAXDEV) ? dev : 0;
+        if (!made[dev]) {
+            for (hipEvent_t& e : ev[dev]) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            made[dev] = true;
         }
-        return ev;
+        return ev[dev];
     }
     hipEvent_t next() { return pool()[used++ % NEV]; }
 };

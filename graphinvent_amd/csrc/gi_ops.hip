@@ -488,6 +488,33 @@ __global__ __launch_bounds__(256) void kl_loss_kernel(const float* __restrict__ 
     if (tid == 0) row_loss[b] = loss;
 }
 
+// loss = (sum_b row_loss[b]) * inv_b in a fixed order (one workgroup; deterministic)
+__global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ row, int B,
+                                                        float inv_b, float* __restrict__ out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) acc += row[i];
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = ((red[0] + red[1]) + (red[2] + red[3])) * inv_b;
+}
+
+// x *= *scale (the upstream gradient of the scalar loss, read on the device)
+__global__ __launch_bounds__(256) void scale_by_scalar_kernel(float* __restrict__ x, long long n4,
+                                                              long long n,
+                                                              const float* __restrict__ scale) {
+    const float s = *scale;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        v4f v = ((v4f*)x)[i];
+        ((v4f*)x)[i] = v * s;
+    } else if (i == n4) {
+        for (long long k = 4 * n4; k < n; ++k) x[k] *= s;
+    }
+}
+
 }  // namespace
 
 // ---- profiling registry ---------------------------------------------------------------------------
@@ -792,8 +819,9 @@ extern "C" int gi_adam_step(float* p, const float* g, float* m, float* v, long l
     if (n <= 0) return 0;
     if (!p || !g || !m || !v || step < 1 || (n & 3)) return GI_EINVAL;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return GI_EINVAL;
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    // bias corrections in double like torch.optim.Adam (fp32 powf is ~6e-5 off at step 1)
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     const long long n4 = n / 4;
     const int blocks = (int)std::min<long long>((n4 + 255) / 256, 4096);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4,
@@ -801,19 +829,34 @@ extern "C" int gi_adam_step(float* p, const float* g, float* m, float* v, long l
     return gi_launch_status();
 }
 
+extern "C" int gi_scale_by_scalar(float* x, long long n, const float* scale, void* stream) {
+    (void)hipGetLastError();
+    if (n <= 0) return 0;
+    if (!x || !scale || ((uintptr_t)x & 15)) return GI_EINVAL;
+    const long long n4 = n / 4;
+    hipLaunchKernelGGL(scale_by_scalar_kernel, dim3((unsigned)((n4 + 1 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, n4, n, scale);
+    return gi_launch_status();
+}
+
 extern "C" int gi_kl_loss(const float* out, int ldo, const void* target, int tgt_dtype, int ldt, int B,
-                          int width, float* row_loss, float* d_out, int ldd, void* stream) {
+                          int width, float* row_loss, float* d_out, int ldd, float* loss_mean,
+                          void* stream) {
     (void)hipGetLastError();
     if (B <= 0) return 0;
     if (!out || !target || !row_loss || width <= 0 || ldo < width || ldt < width) return GI_EINVAL;
+    const hipStream_t st = (hipStream_t)stream;
     if (tgt_dtype == GI_DTYPE_F32)
-        hipLaunchKernelGGL(kl_loss_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream, out, ldo,
+        hipLaunchKernelGGL(kl_loss_kernel<float>, dim3(B), dim3(256), 0, st, out, ldo,
                            (const float*)target, ldt, width, 1.f / (float)B, row_loss, d_out, ldd);
     else if (tgt_dtype == GI_DTYPE_I8)
-        hipLaunchKernelGGL(kl_loss_kernel<signed char>, dim3(B), dim3(256), 0, (hipStream_t)stream, out,
-                           ldo, (const signed char*)target, ldt, width, 1.f / (float)B, row_loss,
-                           d_out, ldd);
+        hipLaunchKernelGGL(kl_loss_kernel<signed char>, dim3(B), dim3(256), 0, st, out, ldo,
+                           (const signed char*)target, ldt, width, 1.f / (float)B, row_loss, d_out,
+                           ldd);
     else
         return GI_EINVAL;
+    if (loss_mean)       // the batch mean right behind the row kernel, fixed summation order
+        hipLaunchKernelGGL(mean_rows_kernel, dim3(1), dim3(256), 0, st, row_loss, B, 1.f / (float)B,
+                           loss_mean);
     return gi_launch_status();
 }

@@ -109,10 +109,14 @@ class DataParallel:
             self._comm_stream = torch.cuda.Stream(device=gflat.device)
         comm = self._comm_stream
         comm.wait_event(ready)
+        # single shot: a second backward through the model before the exchange is finished must not
+        # start another collective on (or accumulate into) the buffer this one reduces in place
+        self.model._grad_ready_hook = None
+        self.model._early_exchange_pending = True
         with torch.cuda.stream(comm):
             work = dist.all_reduce(gflat[split:], op=dist.ReduceOp.SUM, group=self.group,
                                    async_op=True)
-        self._pending = (work, split, gflat.data_ptr())
+        self._pending = (work, split, gflat.data_ptr(), gflat)
 
     def allreduce_gradients(self) -> None:
         if self.world_size == 1 and not self.always_reduce:
@@ -121,22 +125,31 @@ class DataParallel:
         self.last_bucket_zero_copy = bucket is not None
         pending, self._pending = self._pending, None
         self.last_overlapped = False
+        if hasattr(self.model, "_early_exchange_pending"):
+            self.model._early_exchange_pending = False
+        if pending is not None and (bucket is None or pending[2] != bucket.data_ptr()):
+            # The early collective has SUM-reduced the tail of ITS buffer in place, but the
+            # gradients the optimizer will read are not (all) views of that buffer any more
+            # (cloned / accumulated / replaced after the backward): reducing them again would count
+            # the tail world_size times.  There is no safe way to merge the two; fail loudly.
+            pending[0].wait()
+            raise RuntimeError("data-parallel overlap: an early all-reduce of the readout gradients "
+                               "is pending, but param.grad are no longer views of the model's flat "
+                               "gradient bucket; construct DataParallel(overlap=False) (or set "
+                               "GI_DP_OVERLAP=0) for training loops that clone, accumulate or "
+                               "replace gradients between backward and the optimizer step")
         if bucket is not None:                      # gradients already live in one flat buffer
-            if pending is not None and pending[2] == bucket.data_ptr():
-                work, split, _ = pending            # tail is already being exchanged: head now
+            if pending is not None:
+                work, split = pending[0], pending[1]   # tail is already being exchanged: head now
                 if split > 0:
                     dist.all_reduce(bucket[:split], op=dist.ReduceOp.SUM, group=self.group)
                 work.wait()                         # current stream waits for the tail's collective
                 bucket.record_stream(self._comm_stream)
                 self.last_overlapped = True
             else:
-                if pending is not None:
-                    pending[0].wait()
                 dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
             bucket.mul_(1.0 / self.world_size)
             return
-        if pending is not None:
-            pending[0].wait()
         grads = [p.grad for p in self.params]
         flat = torch.cat([g.reshape(-1) for g in grads])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)

@@ -143,6 +143,9 @@ def ggnn_backward_raw(tape, out, d_out, params, early_hook=None, bucket=None, wt
     dims, graph, ws = tape
     d_out = d_out.contiguous().float()
     dev = out.device
+    if dev.index != torch.cuda.current_device():     # autograd may run backward on another device
+        with torch.cuda.device(dev):
+            return ggnn_backward_raw(tape, out, d_out, params, early_hook, bucket, wt)
     gs = graph.c_struct()
     n_slab = lib.gi_ggnn_slab_floats(C.byref(dims), graph.S, graph.U, gs.Ut)
     if n_slab < 0:
@@ -189,8 +192,9 @@ class _GGNNFunction(torch.autograd.Function):
                                "activations in place (retain_graph is not supported)")
         tape, ctx.tape = ctx.tape, None
         out, *params = ctx.saved_tensors
-        grads, gflat = ggnn_backward_raw(tape, out, d_out, params,
-                                         getattr(ctx.owner, "_grad_ready_hook", None), wt=ctx.wt)
+        # no early exchange on this path: AccumulateGrad may clone these gradients (or run user
+        # hooks on them) while a collective would still be reducing the bucket in place
+        grads, gflat = ggnn_backward_raw(tape, out, d_out, params, None, wt=ctx.wt)
         ctx.owner._grad_bucket = gflat          # the flat bucket graphinvent_amd.dp all-reduces
         return (None, None, None, *grads)
 
@@ -210,6 +214,9 @@ class _GGNNDirect(torch.autograd.Function):
         ctx.wt = owner._transposed_weights(tape[0], params, start) if anchor is not None else None
         ctx.owner = owner
         ctx.tape = tape
+        # the parameters are not saved tensors here: remember their versions so that an in-place
+        # update between forward and backward is detected like autograd would
+        ctx.versions = [p._version for p in params] if anchor is not None else None
         ctx.save_for_backward(out)
         return out
 
@@ -220,6 +227,10 @@ class _GGNNDirect(torch.autograd.Function):
                                "activations in place (retain_graph is not supported)")
         tape, ctx.tape = ctx.tape, None
         (out,) = ctx.saved_tensors
+        if ctx.versions is not None and \
+                ctx.versions != [p._version for p in ctx.owner._params()]:
+            raise RuntimeError("a GGNN parameter was modified in place between forward and backward: "
+                               "the saved activations no longer match the weights")
         ctx.owner._backward_into_grads(tape, out, d_out, ctx.wt)
         return None, None, None, None
 
@@ -234,6 +245,7 @@ class _FusedMPNN(torch.nn.Module):
     #: hooks and autograd's in-place-modification checks (slower host side).
     autograd_params = False
     _grad_ready_hook = None
+    _early_exchange_pending = False     # set by dp.DataParallel while its early all-reduce runs
 
     def _dropout_active(self) -> bool:
         flag = self.__dict__.get("_has_dropout")
@@ -244,8 +256,13 @@ class _FusedMPNN(torch.nn.Module):
 
     def _params(self) -> List[torch.nn.Parameter]:
         cache = self.__dict__.get("_param_cache")
-        if cache is None:
+        term = self.APDReadout.fTermNet2.seq
+        if cache is None or cache[0] is not getattr(self.msg_nns[0].seq, "0").weight or \
+                cache[-1] is not getattr(term, str(3 * (len(term._modules) - 1))).bias:
+            # (re)built when a Parameter object was replaced: load_state_dict(assign=True),
+            # module surgery, parameter swapping on .to()
             cache = self.__dict__["_param_cache"] = list(self.parameters())
+            self.__dict__.pop("_bucket", None)
         return cache
 
     def __deepcopy__(self, memo):
@@ -254,7 +271,8 @@ class _FusedMPNN(torch.nn.Module):
         cls = self.__class__
         new = cls.__new__(cls)
         memo[id(self)] = new
-        skip = ("_param_cache", "_bucket", "_anchor", "_grad_bucket", "_grad_ready_hook", "_wt")
+        skip = ("_param_cache", "_bucket", "_anchor", "_grad_bucket", "_grad_ready_hook", "_wt",
+                "_early_exchange_pending")
         import copy as _copy
         for k, v in self.__dict__.items():
             new.__dict__[k] = None if k in skip else _copy.deepcopy(v, memo)
@@ -268,6 +286,10 @@ class _FusedMPNN(torch.nn.Module):
                 "AlphaDropout with p > 0 in training mode is not implemented in the MI355X HIP "
                 "path (every reference default is p = 0.0, parameters/defaults.py:280-363)")
         params = self._params()
+        if nodes.is_cuda and nodes.device.index != torch.cuda.current_device():
+            # every launch goes to the current stream of the CURRENT device: make that the inputs'
+            with torch.cuda.device(nodes.device):
+                return self.forward(nodes, edges)
         if self.autograd_params:
             self._grad_bucket = None
             return _GGNNFunction.apply(self, nodes, edges, *params)
@@ -322,6 +344,10 @@ class _FusedMPNN(torch.nn.Module):
                     any(g.shape != p.shape for g, p in zip(bucket[1], params)):
                 bucket = self.__dict__["_bucket"] = new_grad_bucket(params, out.device)
         hook = self._grad_ready_hook if fresh else None      # early exchange needs the fresh bucket
+        if not fresh and getattr(self, "_early_exchange_pending", False):
+            raise RuntimeError("a second backward through the model while the data-parallel early "
+                               "all-reduce of the first one is reducing the gradient bucket in place; "
+                               "use DataParallel(overlap=False) for multiple backwards per step")
         grads, gflat = ggnn_backward_raw(tape, out, d_out, params, hook, bucket, wt)
         with torch.no_grad():
             if fresh:

@@ -27,7 +27,7 @@ EPI_BIAS, EPI_SELU, EPI_DSELU, EPI_ACCUM, GEMM_SPLITK = 1, 2, 4, 8, 16
 KIND_GGNN, KIND_ATTGGNN = 0, 1
 BWD_ALL, BWD_READOUT, BWD_PASSES = 0, 1, 2
 COUNTS = 24          # GI_COUNTS
-ABI_VERSION = 3      # GI_ABI_VERSION
+ABI_VERSION = 4      # GI_ABI_VERSION
 DTYPE_F32, DTYPE_I8 = 0, 1
 
 vp = C.c_void_p
@@ -100,7 +100,8 @@ SIGNATURES = {
     "gi_reduce_slabs": (ci, [C.POINTER(ReduceDesc), ci, vp]),
     "gi_adam_step": (ci, [vp, vp, vp, vp, cll, C.c_float, C.c_float, C.c_float, C.c_float,
                           C.c_float, ci, vp]),
-    "gi_kl_loss": (ci, [vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, vp]),
+    "gi_kl_loss": (ci, [vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp]),
+    "gi_scale_by_scalar": (ci, [vp, cll, vp, vp]),
     "gi_prof_enable": (ci, [ci]),
     "gi_prof_collect": (ci, [vp, vp, vp, vp]),
     "gi_sample_actions": (ci, [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]),

@@ -19,6 +19,9 @@ def apd_kl_loss_torch(output: torch.Tensor, target_output: torch.Tensor) -> torc
 
 
 class _FusedKL(torch.autograd.Function):
+    """Two launches forward (row kernel + fixed-order batch mean), one backward (d_out scaled in place
+    by the upstream scalar, read on the device) — no torch glue kernels on the step's critical path."""
+
     @staticmethod
     def forward(ctx, output, target):
         from . import lib as L
@@ -29,19 +32,28 @@ class _FusedKL(torch.autograd.Function):
         else:
             tgt, tdt = target.contiguous().float(), L.DTYPE_F32
         B, W = out.shape
-        row = torch.empty(B, dtype=torch.float32, device=out.device)
+        buf = torch.empty(B + 1, dtype=torch.float32, device=out.device)    # row losses | mean
         need_grad = ctx.needs_input_grad[0]
         d_out = torch.empty_like(out) if need_grad else None
         L.check(lib.gi_kl_loss(out.data_ptr(), out.stride(0), tgt.data_ptr(), tdt, tgt.stride(0), B, W,
-                               row.data_ptr(), d_out.data_ptr() if need_grad else None,
-                               d_out.stride(0) if need_grad else 0,
-                               torch.cuda.current_stream().cuda_stream), "gi_kl_loss")
+                               buf.data_ptr(), d_out.data_ptr() if need_grad else None,
+                               d_out.stride(0) if need_grad else 0, buf.data_ptr() + 4 * B,
+                               torch.cuda.current_stream(out.device).cuda_stream), "gi_kl_loss")
         ctx.d_out = d_out
-        return row.sum() / B
+        return buf[B]
 
     @staticmethod
     def backward(ctx, grad):
-        return ctx.d_out * grad, None
+        from . import lib as L
+        d_out, ctx.d_out = ctx.d_out, None
+        if d_out is None:
+            raise RuntimeError("fused KL loss: backward called twice (its gradient buffer is "
+                               "scaled in place)")
+        g = grad.contiguous().float()
+        L.check(L.load().gi_scale_by_scalar(d_out.data_ptr(), d_out.numel(), g.data_ptr(),
+                                            torch.cuda.current_stream(d_out.device).cuda_stream),
+                "gi_scale_by_scalar")
+        return d_out, None
 
 
 def apd_kl_loss(output: torch.Tensor, target_output: torch.Tensor) -> torch.Tensor:

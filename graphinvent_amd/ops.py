@@ -175,8 +175,15 @@ _PINNED_NEXT = 0
 _PREFETCH_STREAMS: "dict" = {}
 
 
+def _version(t: torch.Tensor) -> int:
+    try:
+        return t._version
+    except RuntimeError:            # inference-mode tensors do not track versions
+        return -1
+
+
 def _batch_key(nodes: torch.Tensor, edges: torch.Tensor):
-    return (nodes.data_ptr(), edges.data_ptr(), nodes._version, edges._version, tuple(nodes.shape),
+    return (nodes.data_ptr(), edges.data_ptr(), _version(nodes), _version(edges), tuple(nodes.shape),
             tuple(edges.shape), nodes.dtype, edges.dtype)
 
 

@@ -8,7 +8,9 @@ unaffected).  The segment layout is the one the fused GGNN backward uses for its
 (``gnn.mpnn.ggnn_backward_raw``), so when the gradients already live in that bucket the step reads
 them in place; otherwise they are packed first.  Learning-rate schedulers work as usual
 (``group["lr"]`` is read every step).  Semantics: Adam without amsgrad, ``weight_decay`` as L2 term,
-bias correction as in torch.
+bias correction as in torch (computed in double on the host).  Deviation: parameters whose ``grad`` is
+None take part in the step with a zero gradient (moment decay), where torch.optim.Adam skips them —
+the fused GGNN backward always produces every gradient.
 """
 from __future__ import annotations
 
@@ -50,6 +52,52 @@ class FusedAdam(torch.optim.Optimizer):
             self._flat.append(dict(params=ps, offs=offs, total=total, p=flat,
                                    m=torch.zeros_like(flat), v=torch.zeros_like(flat),
                                    g=None, step=0))
+        self._built = True
+
+    def add_param_group(self, param_group):
+        if getattr(self, "_built", False):
+            raise RuntimeError("FusedAdam packs its parameters into flat buckets at construction; "
+                               "adding a parameter group afterwards is not supported")
+        super().add_param_group(param_group)
+
+    # ---- checkpointing: torch.optim.Adam's state layout ------------------------------------------
+    # The moments live in the flat buckets; `state_dict()` exposes them per parameter exactly as
+    # torch.optim.Adam would ({"step", "exp_avg", "exp_avg_sq"}), `load_state_dict()` copies them back,
+    # so a resume keeps the moments and the bias-correction step count (Workflow.py:219-263 restarts).
+    def state_dict(self):
+        for st in self._flat:
+            if st is None or st["step"] == 0:
+                continue
+            for p, o in zip(st["params"], st["offs"]):
+                n = p.numel()
+                self.state[p] = dict(step=torch.tensor(float(st["step"])),
+                                     exp_avg=st["m"][o:o + n].view_as(p).clone(),
+                                     exp_avg_sq=st["v"][o:o + n].view_as(p).clone())
+        try:
+            return super().state_dict()
+        finally:
+            self.state.clear()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        with torch.no_grad():
+            for st in self._flat:
+                if st is None:
+                    continue
+                steps = set()
+                for p, o in zip(st["params"], st["offs"]):
+                    ps = self.state.get(p)
+                    if not ps:
+                        continue
+                    n = p.numel()
+                    st["m"][o:o + n].copy_(ps["exp_avg"].reshape(-1))
+                    st["v"][o:o + n].copy_(ps["exp_avg_sq"].reshape(-1))
+                    steps.add(int(ps["step"]))
+                if len(steps) > 1:
+                    raise RuntimeError("FusedAdam: parameters of one group carry different step counts")
+                if steps:
+                    st["step"] = steps.pop()
+        self.state.clear()
 
     def _grad_bucket(self, st) -> torch.Tensor:
         ps, offs = st["params"], st["offs"]
@@ -88,5 +136,6 @@ class FusedAdam(torch.optim.Optimizer):
             L.check(lib.gi_adam_step(st["p"].data_ptr(), g.data_ptr(), st["m"].data_ptr(),
                                      st["v"].data_ptr(), st["total"], float(group["lr"]), b1, b2,
                                      group["eps"], group["weight_decay"], st["step"],
-                                     torch.cuda.current_stream().cuda_stream), "gi_adam_step")
+                                     torch.cuda.current_stream(st["p"].device).cuda_stream),
+                    "gi_adam_step")
         return loss

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GI_ABI_VERSION 3
+#define GI_ABI_VERSION 4
 #define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
 #define GI_MAX_NODES 128      /* max max_n_nodes */
 #define GI_P0_MAX_CLASSES 256 /* max distinct node feature rows for the pass-0 shortcut */
@@ -236,9 +236,14 @@ int gi_adam_step(float* p, const float* g, float* m, float* v, long long n, floa
 
 /* Workflow.loss (Workflow.py:833-860) forward + gradient in one pass over the logits:
  * row_loss[b] = KL(target_b / sum(target_b) || softmax(out_b)); loss = mean_b row_loss[b];
- * d_out (may be NULL) = d loss / d out.  All-zero target rows give NaN like the reference. */
+ * d_out (may be NULL) = d loss / d out; loss_mean (may be NULL) = the scalar batch mean, summed in a
+ * fixed order.  All-zero target rows give NaN like the reference. */
 int gi_kl_loss(const float* out, int ldo, const void* target, int tgt_dtype, int ldt, int B,
-               int width, float* row_loss, float* d_out, int ldd, void* stream);
+               int width, float* row_loss, float* d_out, int ldd, float* loss_mean, void* stream);
+
+/* x[0:n] *= *scale with the scalar read on the device (the upstream gradient autograd hands to the
+ * loss node: `loss.backward()` passes ones, RL-style callers pass a weight) — no host read-back. */
+int gi_scale_by_scalar(float* x, long long n, const float* scale, void* stream);
 
 /* Sampling step of graph generation — replaces `softmax(model(nodes, edges))` +
  * GraphGenerator.get_actions / get_invalid_actions (GraphGenerator.py:121, 467-657) with one launch:

@@ -185,13 +185,33 @@ def init_params(cfg: dict, seed: int = 0, dtype=torch.float32,
 # building blocks
 # ----------------------------------------------------------------------------------------------
 
+SELU_ALPHA = 1.6732632423543772848170429916717
+SELU_SCALE = 1.0507009873554804934193349852946
+
+#: Test-only hook (tests/pins.py), None in every timed / baseline use.  SELU' jumps from
+#: scale*alpha (1.758) to scale (1.051) at 0, so two correct fp32 implementations that round an
+#: activation of |x| ~ 1e-7 to opposite sides of 0 differ by O(1) in that element's derivative.  A
+#: gradient comparison at the 1e-4 bar therefore pins the branch: the hook is called as
+#: ``hook(prefix, layer, pre_activation)`` and returns a bool mask "take the x > 0 branch" (or None
+#: for the natural ``x > 0``); the oracle's own autograd then differentiates that branch.
+SELU_BRANCH_HOOK = None
+
+
+def _selu(x: torch.Tensor, prefix: str, layer: int) -> torch.Tensor:
+    mask = SELU_BRANCH_HOOK(prefix, layer, x) if SELU_BRANCH_HOOK is not None else None
+    if mask is None:
+        return torch.selu(x)
+    return SELU_SCALE * torch.where(mask, x, SELU_ALPHA * (torch.exp(x) - 1.0))
+
+
 def mlp(P: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor) -> torch.Tensor:
     """gnn/modules.py:111-170 — Linear -> SELU (-> AlphaDropout(p), identity at the default p=0)
     for every layer *including the last*."""
     layer = 0
     while f"{prefix}.seq.{3 * layer}.weight" in P:
-        x = torch.selu(torch.nn.functional.linear(
-            x, P[f"{prefix}.seq.{3 * layer}.weight"], P[f"{prefix}.seq.{3 * layer}.bias"]))
+        x = _selu(torch.nn.functional.linear(
+            x, P[f"{prefix}.seq.{3 * layer}.weight"], P[f"{prefix}.seq.{3 * layer}.bias"]),
+            prefix, layer)
         layer += 1
     return x
 

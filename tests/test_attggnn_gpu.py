@@ -14,6 +14,7 @@ from graphinvent_amd import lib as L
 from graphinvent_amd import ops, synthetic
 from graphinvent_amd.gnn import mpnn
 from oracle import ggnn_oracle as O
+from tests import pins
 from tests import ref_dataflow as D
 from tests.golden.spec import TINY_ATT, tiny_inputs
 
@@ -243,3 +244,44 @@ def test_batch_without_any_edge_and_module_surface():
         assert torch.equal(a, clone(n, e))
     with pytest.raises(RuntimeError):
         model(n.cpu(), e.cpu())
+
+
+@pytest.mark.parametrize("shape,B,over", [
+    ("chembl", 250, {}),                                                     # BASELINE configs[4], per GPU
+    ("gdb13", 1000, dict(hidden_node_features=128, message_size=128)),
+])
+def test_bench_batch_gradients_1e4_vs_fp32_oracle_autograd(shape, B, over):
+    """AttentionGGNN at the bench batches against the oracle itself: logits / loss 1e-4 vs the plain
+    fp32 oracle, every gradient tensor 1e-4 vs the fp32 oracle's own autograd with the SELU branches
+    of the HIP forward (tests/pins.py); the pin touches < 1e-6 of the activations."""
+    old = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    try:
+        sh = synthetic.SHAPES[shape]
+        cfg = O.shaped_config(sh["n_atom_types"], sh["n_formal_charge"], sh["max_n_nodes"], **over)
+        P = O.init_params(cfg, seed=4, model=MODEL)
+        n8, e8, a8 = live_only(*synthetic.make_batch(B + B // 10 + 8, **sh, seed=23))
+        n8, e8, a8 = n8[:B], e8[:B], a8[:B]
+        assert n8.shape[0] == B
+        model = make_model(cfg, P)
+        params = list(model.parameters())
+        nodes, edges, tgt = to_dev(n8, e8, a8)
+        out, tape_hip = mpnn.ggnn_forward_raw(model.constants, nodes, edges, params, L.KIND_ATTGGNN)
+        dims, graph, ws = tape_hip
+        signs = pins.signs_from_hip(dims, graph, ws, out, attn=True)
+        g = pins.graph_arrays(graph)
+        o_leaf = out.detach().clone().requires_grad_(True)
+        loss = O.kl_loss(o_leaf, tgt)
+        loss.backward()
+        grads, _ = mpnn.ggnn_backward_raw(tape_hip, out, o_leaf.grad, params)
+        t = lambda x: torch.from_numpy(x).float()
+        o32, l32, g32, flipped, total = pins.oracle_pinned(O, P, cfg, t(n8), t(e8), t(a8), signs, g,
+                                                           MODEL)
+    finally:
+        torch.set_num_threads(old)
+    assert flipped < 1e-6 * total, (flipped, total)
+    assert rel(out, o32) < TOL
+    assert abs(float(loss) - float(l32)) < TOL * abs(float(l32))
+    names = [k for k, _ in model.named_parameters()]
+    worst = max((rel(gr, g32[k]), k) for k, gr in zip(names, grads))
+    assert worst[0] < TOL, worst

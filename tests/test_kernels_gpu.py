@@ -276,3 +276,23 @@ def test_fused_adam_matches_torch_adam():
     for p, q in zip(ref, mine):
         assert rel(q, p) < 2e-6
     assert mine[0].data_ptr() + 4 * 25000 == mine[1].data_ptr()        # flat, 16-byte segments
+    # checkpoint / resume: the state_dict has torch.optim.Adam's layout (moments + step count) and a
+    # fresh FusedAdam loaded from it continues exactly like the one that kept running
+    sd = o_mine.state_dict()
+    sd_ref = o_ref.state_dict()
+    assert set(sd["state"]) == set(sd_ref["state"])
+    for k in sd_ref["state"]:
+        assert int(sd["state"][k]["step"]) == int(sd_ref["state"][k]["step"]) == 6
+        assert rel(sd["state"][k]["exp_avg"], sd_ref["state"][k]["exp_avg"]) < 2e-6
+        assert rel(sd["state"][k]["exp_avg_sq"], sd_ref["state"][k]["exp_avg_sq"]) < 2e-6
+    resumed = [torch.nn.Parameter(q.detach().clone()) for q in mine]
+    o_res = FusedAdam(resumed, lr=3e-3, weight_decay=1e-2)
+    o_res.load_state_dict(sd)
+    for p, q, r in zip(ref, mine, resumed):
+        gr = torch.randn(p.shape, generator=g).to(DEV)
+        p.grad, q.grad, r.grad = gr.clone(), gr.clone(), gr.clone()
+    o_ref.step(); o_mine.step(); o_res.step()
+    for p, q, r in zip(ref, mine, resumed):
+        assert torch.equal(q, r) and rel(q, p) < 2e-6
+    with pytest.raises(RuntimeError):
+        o_mine.add_param_group({"params": [torch.nn.Parameter(torch.zeros(4, device=DEV))]})
