@@ -263,7 +263,7 @@ void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {   /
 }
 
 // ---- launch helpers -----------------------------------------------------------------------------
-struct Grp { int n; const int* off; int max_rows; };    // n == 0: ungrouped
+struct Grp { int n; const int* off; int max_rows; const int* host_rows = nullptr; };   // n == 0: ungrouped; host_rows: per-group upper bounds (null: max_rows)
 
 struct SideStream;
 
@@ -345,10 +345,21 @@ void linear_dgrad(Run& r, const int* widx, const Grp& g, int n_out,
     r.chk(gi_gemm(&p, r.st));
 }
 
+bool chain_fits(const Mlp& q, int dx_cols);
+void chain_fwd_params(gi_chain_params& c, const Run& r, float* ws, const Mlp* mlps, const Grp& g,
+                      const float* X, int ldx, const int* idx, int rows, const long long* acts,
+                      int ldh, float* final_dst, int ld_final);
+
 void mlp_forward(Run& r, float* ws, const Mlp* mlps, const Grp& g, const float* X, int ldx,
                  const int* a_idx, int rows, const long long* acts, int ldh, float* final_dst,
                  int ld_final) {
     const int L = mlps[0].layers();
+    if (g.n && r.ok() && rows > 0 && chain_fits(mlps[0], 4) && ldx >= gi_r4(mlps[0].in)) {
+        gi_chain_params c;                      // the whole stack in one resident-activation launch
+        chain_fwd_params(c, r, ws, mlps, g, X, ldx, a_idx, rows, acts, ldh, final_dst, ld_final);
+        r.chk(gi_mlp_chain(&c, 1, r.st));
+        return;
+    }
     for (int l = 0; l < L; ++l) {
         const float* src = (l == 0) ? X : ws + acts[l - 1];
         float* dst = (l == L - 1) ? final_dst : ws + acts[l];
@@ -585,12 +596,29 @@ void mlp_jobs_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred& 
     }
 }
 
+int chain_bwd_params(gi_chain_params& c, const Run& r, float* ws, const Mlp* mlps, const Grp& g,
+                     const float* Zlast, int ldz, int rows, const long long* acts,
+                     const long long* dzs, int ldh, float* dX, int lddx, int dx_cols);
+void defer_stack_wgrads(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred& dq, const Mlp* mlps,
+                        const Grp& g, const float* X, int ldx, const int* a_idx, int rows,
+                        const long long* acts, const long long* dzs, int ldh, const float* Zlast,
+                        int ldz);
+
 // The bond-type-grouped message MLP: dZ chain now, weight gradients deferred.
 void msg_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred& dq, const Mlp* mlps,
                   const Grp& g, const float* X, int ldx, const int* a_idx, int rows,
                   const long long* acts, const long long* dzs, int ldh, const float* Zlast, int ldz,
                   float* dX, int lddx, int dx_cols) {
     const int L = mlps[0].layers();
+    if (g.n && r.ok() && rows > 0 && chain_fits(mlps[0], dx_cols) &&
+        (!dX || dx_cols == mlps[0].in) && ldz >= gi_r4(mlps[0].out)) {
+        gi_chain_params c;                      // the whole dZ chain in one launch, then the wgrads
+        if (chain_bwd_params(c, r, ws, mlps, g, Zlast, ldz, rows, acts, dzs, ldh, dX, lddx, dx_cols))
+            r.chk(gi_mlp_chain(&c, 1, r.st));
+        defer_stack_wgrads(r, ws, sp, slabs, dq, mlps, g, X, ldx, a_idx, rows, acts, dzs, ldh, Zlast,
+                           ldz);
+        return;
+    }
     for (int l = L - 1; l >= 0; --l) {
         const float* dZ = (l == L - 1) ? Zlast : ws + dzs[l];
         const int lddz = (l == L - 1) ? ldz : ldh;
@@ -606,6 +634,93 @@ void msg_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred& dq, c
         else if (dX)
             linear_dgrad(r, widx, g, q.fan_out(0), q.fan_in(0), dx_cols, dZ, lddz, rows, dX,
                          lddx, nullptr, 0, false);
+    }
+}
+
+// ---- resident-activation chains (gi_chain.hip) ---------------------------------------------------
+// The per-bond-type message / energy stacks run as ONE launch per direction when every layer fits
+// the chain kernel (<= GI_CHAIN_MAXL layers, widths 4..GI_CHAIN_MAXW); GI_CHAIN=0 or wider stacks
+// take the layer-by-layer GEMM path above (same arithmetic, more launches).
+bool chain_enabled() {
+    static const bool v = !(getenv("GI_CHAIN") && atoi(getenv("GI_CHAIN")) == 0);
+    return v;
+}
+
+bool chain_fits(const Mlp& q, int dx_cols) {
+    if (!chain_enabled() || q.layers() > GI_CHAIN_MAXL) return false;
+    for (int l = 0; l < q.layers(); ++l)
+        if (q.fan_in(l) < 4 || q.fan_in(l) > GI_CHAIN_MAXW || q.fan_out(l) < 4 ||
+            q.fan_out(l) > GI_CHAIN_MAXW)
+            return false;
+    return dx_cols >= 4 && dx_cols <= GI_CHAIN_MAXW;
+}
+
+void chain_groups(gi_chain_params& c, const Grp& g, int rows) {
+    c.grp_off = g.off; c.ngroups = g.n; c.rows = rows;
+    for (int t = 0; t < g.n; ++t) c.group_rows[t] = g.host_rows ? g.host_rows[t] : g.max_rows;
+}
+
+// Y = MLP(X[idx]) for the grouped stacks `mlps`; hidden activations -> acts, last layer -> final_dst
+void chain_fwd_params(gi_chain_params& c, const Run& r, float* ws, const Mlp* mlps, const Grp& g,
+                      const float* X, int ldx, const int* idx, int rows, const long long* acts,
+                      int ldh, float* final_dst, int ld_final) {
+    memset(&c, 0, sizeof(c));
+    const Mlp& q = mlps[0];
+    const int L = q.layers();
+    c.nlayers = L; c.X = X; c.ldx = ldx; c.x_idx = idx; c.backward = 0;
+    chain_groups(c, g, rows);
+    for (int l = 0; l < L; ++l) {
+        gi_chain_layer& y = c.layer[l];
+        y.K = q.fan_in(l); y.N = q.fan_out(l);
+        y.out = (l == L - 1) ? final_dst : ws + acts[l];
+        y.ldo = (l == L - 1) ? ld_final : ldh;
+        for (int t = 0; t < g.n; ++t) { y.W[t] = r.P[mlps[t].w(l)]; y.bias[t] = r.P[mlps[t].b(l)]; }
+    }
+}
+
+// dZ chain of the same stacks: Zlast = dZ of the last layer; dZ of hidden layer l -> dzs[l]; the
+// first layer's input gradient (dx_cols leading columns) -> dX when dX != null.  Returns the number
+// of chain layers (0: nothing to launch).
+int chain_bwd_params(gi_chain_params& c, const Run& r, float* ws, const Mlp* mlps, const Grp& g,
+                     const float* Zlast, int ldz, int rows, const long long* acts,
+                     const long long* dzs, int ldh, float* dX, int lddx, int dx_cols) {
+    memset(&c, 0, sizeof(c));
+    const Mlp& q = mlps[0];
+    const int L = q.layers();
+    c.X = Zlast; c.ldx = ldz; c.x_idx = nullptr; c.backward = 1;
+    chain_groups(c, g, rows);
+    int n = 0;
+    for (int l = L - 1; l >= 0; --l) {
+        if (l == 0 && !dX) break;
+        gi_chain_layer& y = c.layer[n++];
+        y.K = q.fan_out(l);
+        y.N = (l == 0) ? dx_cols : q.fan_in(l);
+        // W_l is [fan_out][fan_in] row-major: for l == 0 only its leading dx_cols columns are used,
+        // which needs fan_in == dx_cols (rows are read with stride N)
+        y.out = (l == 0) ? dX : ws + dzs[l - 1];
+        y.ldo = (l == 0) ? lddx : ldh;
+        y.act = (l == 0) ? nullptr : ws + acts[l - 1];
+        y.ldact = ldh;
+        for (int t = 0; t < g.n; ++t) y.W[t] = r.P[mlps[t].w(l)];
+    }
+    c.nlayers = n;
+    return n;
+}
+
+// weight gradients of every layer of a grouped stack (deferred), after its dZ chain was enqueued
+void defer_stack_wgrads(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred& dq, const Mlp* mlps,
+                        const Grp& g, const float* X, int ldx, const int* a_idx, int rows,
+                        const long long* acts, const long long* dzs, int ldh, const float* Zlast,
+                        int ldz) {
+    const int L = mlps[0].layers();
+    for (int l = L - 1; l >= 0; --l) {
+        const float* dZ = (l == L - 1) ? Zlast : ws + dzs[l];
+        const int lddz = (l == L - 1) ? ldz : ldh;
+        const float* Xl = (l == 0) ? X : ws + acts[l - 1];
+        int widx[GI_MAX_GROUPS];
+        for (int t = 0; t < g.n; ++t) widx[t] = mlps[t].w(l);
+        defer_wgrad(r, dq, sp, slabs, widx, g, dZ, lddz, Xl, l == 0 ? ldx : ldh,
+                    l == 0 ? a_idx : nullptr, rows);
     }
 }
 
@@ -626,6 +741,15 @@ void grouped_problem(gi_gemm_params& p, const Grp& g) {
 
 void edge_chains_forward(Run& r, float* ws, const EdgeChain* ch, int n, const Grp& g,
                          const float* X, int ldx, const int* a_idx, int rows) {
+    if (n == 2 && r.ok() && rows > 0 && chain_fits(ch[0].mlps[0], 4) && chain_fits(ch[1].mlps[0], 4) &&
+        ldx >= gi_r4(ch[0].mlps[0].in)) {
+        gi_chain_params c[2];                   // both stacks' whole forward in ONE launch
+        for (int j = 0; j < 2; ++j)
+            chain_fwd_params(c[j], r, ws, ch[j].mlps, g, X, ldx, a_idx, rows, ch[j].acts, ch[j].ldh,
+                             ch[j].out, ch[j].ldout);
+        r.chk(gi_mlp_chain(c, 2, r.st));
+        return;
+    }
     int maxL = 0;
     for (int j = 0; j < n; ++j) maxL = std::max(maxL, ch[j].mlps[0].layers());
     for (int l = 0; l < maxL; ++l) {
@@ -656,6 +780,23 @@ void edge_chains_forward(Run& r, float* ws, const EdgeChain* ch, int n, const Gr
 void edge_chains_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred& dq,
                           const EdgeChain* ch, int n, const Grp& g, const float* X, int ldx,
                           const int* a_idx, int rows, int lddx, int dx_cols) {
+    if (n == 2 && r.ok() && rows > 0 && chain_fits(ch[0].mlps[0], dx_cols) &&
+        chain_fits(ch[1].mlps[0], dx_cols) && dx_cols == ch[0].mlps[0].in &&
+        dx_cols == ch[1].mlps[0].in && ch[0].ldout >= gi_r4(ch[0].mlps[0].out) &&
+        ch[1].ldout >= gi_r4(ch[1].mlps[0].out)) {
+        gi_chain_params c[2];                   // both dZ chains in ONE launch, then the wgrads
+        int nl[2];
+        for (int j = 0; j < 2; ++j)
+            nl[j] = chain_bwd_params(c[j], r, ws, ch[j].mlps, g, ch[j].out, ch[j].ldout, rows,
+                                     ch[j].acts, ch[j].dzs, ch[j].ldh, ch[j].dX, lddx, dx_cols);
+        if (nl[0] && nl[1]) r.chk(gi_mlp_chain(c, 2, r.st));
+        else if (nl[0]) r.chk(gi_mlp_chain(&c[0], 1, r.st));
+        else if (nl[1]) r.chk(gi_mlp_chain(&c[1], 1, r.st));
+        for (int j = 0; j < 2; ++j)
+            defer_stack_wgrads(r, ws, sp, slabs, dq, ch[j].mlps, g, X, ldx, a_idx, rows, ch[j].acts,
+                               ch[j].dzs, ch[j].ldh, ch[j].out, ch[j].ldout);
+        return;
+    }
     int maxL = 0;
     for (int j = 0; j < n; ++j) maxL = std::max(maxL, ch[j].mlps[0].layers());
     for (int s = 0; s < maxL; ++s) {
@@ -813,7 +954,7 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
     const int R = w.R;
     int maxUt = 0;
     for (int t = 0; t < d.Fe; ++t) maxUt = std::max(maxUt, Ut[t]);
-    const Grp bytype{d.Fe, gfix + L.type_off, maxUt};
+    const Grp bytype{d.Fe, gfix + L.type_off, maxUt, Ut};
     const Grp bytype0{d.Fe, gfix + L.type_off0, w.D0};   // pass-0 rows (upper bound per type: all)
     const int* seg_off = gfix + L.seg_off;
     const int* cidx = gfix + L.cidx;
@@ -821,8 +962,11 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
     const bool attn = d.kind == GI_KIND_ATTGGNN;
 
     // ---- message passes (gnn/summation_mpnn.py:128-144) ----------------------------------------
+    static const bool gru_env = !(getenv("GI_GRU_FUSED") && atoi(getenv("GI_GRU_FUSED")) == 0);
+    const bool gru_fused = gru_env && d.H >= 4 && d.M >= 4 && d.H <= GI_GRU_MAXW && d.M <= GI_GRU_MAXW;
     for (int p = 0; p < d.passes; ++p) {
         const float* hx = ws + w.hx[p];
+        int agg_ready = 1;               // the aggregate is in ws + w.agg[p] before the GRU launch
         if (attn) {
             // AttentionGGNN.aggregate_message (gnn/mpnn.py:370-389): message and energy MLPs of the
             // edge's bond type on h_src(e), softmax over each node's incoming edges, weighted sum
@@ -850,11 +994,28 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
             if (E > 0)   // m_u = MLP_type(u)(h_src(u)), gnn/mpnn.py:284-294, once per message row
                 mlp_forward(r, ws, m.msg, bytype, hx, w.ldhx, u_src, U, w.eact[p], w.ldEh,
                             ws + w.m[p], w.ldM);
-            // a_v = sum of incoming messages (:141)
-            r.chk(gi_seg_sum(ws + w.m[p], w.ldM, in_perm, seg_off, R, d.M, ws + w.agg[p], w.ldM, 0,
-                             r.st));
+            // a_v = sum of incoming messages (:141) — inside the fused GRU launch when there is one
+            if (gru_fused && E > 0) agg_ready = 0;
+            else
+                r.chk(gi_seg_sum(ws + w.m[p], w.ldM, in_perm, seg_off, R, d.M, ws + w.agg[p], w.ldM,
+                                 0, r.st));
         }
-        // GRU update (gnn/mpnn.py:296-297): both input projections in one launch
+        // GRU update (gnn/mpnn.py:296-297): aggregation (when it is a plain segmented sum), both
+        // projections and the gates in one launch when the widths fit (gi_gru.hip) ...
+        if (gru_fused) {
+            gi_gru_params q;
+            memset(&q, 0, sizeof(q));
+            q.m = ws + w.m[p]; q.ldm = w.ldM; q.in_perm = in_perm; q.seg_off = seg_off;
+            q.agg = ws + w.agg[p]; q.ldagg = w.ldM; q.agg_ready = agg_ready;
+            q.hx_prev = hx; q.hx_new = ws + w.hx[p + 1]; q.ldhx = w.ldhx;
+            q.W_ih = params[m.gru_wih]; q.W_hh = params[m.gru_whh];
+            q.b_ih = params[m.gru_bih]; q.b_hh = params[m.gru_bhh];
+            q.gi = ws + w.gi[p]; q.gh = ws + w.gh[p]; q.ldg = w.ld3H;
+            q.R = R; q.H = d.H; q.M = d.M;
+            r.chk(gi_gru_fused_fwd(&q, r.st));
+            continue;
+        }
+        // ... else both input projections in one launch, then the gate kernel
         {
             Batch b;
             add_fwd(b, r, params[m.gru_wih], params[m.gru_bih], d.M, 3 * d.H, ws + w.agg[p], w.ldM, R,
@@ -975,7 +1136,7 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
     const int R = w.R;
     int maxUt = 0;
     for (int t = 0; t < d.Fe; ++t) maxUt = std::max(maxUt, Ut[t]);
-    const Grp bytype{d.Fe, gfix + L.type_off, maxUt};
+    const Grp bytype{d.Fe, gfix + L.type_off, maxUt, Ut};
     const int* seg_off = gfix + L.seg_off;
     const int* src_off = gfix + L.src_off;
     const int* cidx = gfix + L.cidx;

@@ -427,18 +427,19 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceTable tab
 // ---- Adam (torch.optim.Adam semantics, one flat fp32 bucket) ------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
-                                                   long long n4, float lr, float b1, float b2,
-                                                   float eps, float wd, float bc1, float bc2_sqrt) {
+                                                   long long n4, float step_size, float b1,
+                                                   float omb1, float b2, float omb2, float eps,
+                                                   float wd, float bc2_sqrt) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4;
          i += (long long)gridDim.x * 256) {
         v4f pp = ((v4f*)p)[i], gg = ((const v4f*)g)[i], mm = ((v4f*)m)[i], vv = ((v4f*)v)[i];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float gr = gg[c] + wd * pp[c];
-            mm[c] = b1 * mm[c] + (1.f - b1) * gr;
-            vv[c] = b2 * vv[c] + (1.f - b2) * gr * gr;
+            mm[c] = mm[c] + omb1 * (gr - mm[c]);              // lerp_(grad, 1 - beta1)
+            vv[c] = b2 * vv[c] + omb2 * gr * gr;              // mul_(beta2).addcmul_(g, g, 1 - beta2)
             const float denom = sqrtf(vv[c]) / bc2_sqrt + eps;
-            pp[c] -= (lr / bc1) * (mm[c] / denom);
+            pp[c] -= step_size * (mm[c] / denom);
         }
         ((v4f*)p)[i] = pp; ((v4f*)m)[i] = mm; ((v4f*)v)[i] = vv;
     }
@@ -812,20 +813,22 @@ extern "C" int gi_reduce_slabs(const gi_reduce_desc* descs, int n_desc, void* st
     return 0;
 }
 
-extern "C" int gi_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr,
-                            float beta1, float beta2, float eps, float weight_decay, int step,
+extern "C" int gi_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr,
+                            double beta1, double beta2, double eps, double weight_decay, int step,
                             void* stream) {
     (void)hipGetLastError();
     if (n <= 0) return 0;
     if (!p || !g || !m || !v || step < 1 || (n & 3)) return GI_EINVAL;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return GI_EINVAL;
-    // bias corrections in double like torch.optim.Adam (fp32 powf is ~6e-5 off at step 1)
-    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    // every scalar is formed in double like torch.optim.Adam forms it, then rounded once: 1 - beta2
+    // from a float beta2 is 1.3e-5 off, powf(beta, step) ~6e-5 at step 1
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2_sqrt = sqrt(1.0 - pow(beta2, (double)step));
     const long long n4 = n / 4;
     const int blocks = (int)std::min<long long>((n4 + 255) / 256, 4096);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4,
-                       lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
+                       (float)(lr / bc1), (float)beta1, (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)bc2_sqrt);
     return gi_launch_status();
 }
 

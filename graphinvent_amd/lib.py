@@ -52,6 +52,27 @@ class GemmParams(C.Structure):
                 ("Cg", vp * GI_MAX_GROUPS), ("gsplit", ci * GI_MAX_GROUPS)]
 
 
+CHAIN_MAXL, CHAIN_MAXW = 8, 256       # GI_CHAIN_MAXL, GI_CHAIN_MAXW
+
+
+class ChainLayer(C.Structure):
+    _fields_ = [("W", vp * GI_MAX_GROUPS), ("bias", vp * GI_MAX_GROUPS), ("out", vp), ("ldo", ci),
+                ("act", vp), ("ldact", ci), ("K", ci), ("N", ci)]
+
+
+class ChainParams(C.Structure):
+    _fields_ = [("layer", ChainLayer * CHAIN_MAXL), ("nlayers", ci), ("X", vp), ("ldx", ci),
+                ("x_idx", vp), ("grp_off", vp), ("ngroups", ci), ("group_rows", ci * GI_MAX_GROUPS),
+                ("rows", ci), ("backward", ci)]
+
+
+class GruParams(C.Structure):
+    _fields_ = [("m", vp), ("ldm", ci), ("in_perm", vp), ("seg_off", vp), ("agg", vp), ("ldagg", ci),
+                ("agg_ready", ci), ("hx_prev", vp), ("hx_new", vp), ("ldhx", ci), ("W_ih", vp),
+                ("W_hh", vp), ("b_ih", vp), ("b_hh", vp), ("gi", vp), ("gh", vp), ("ldg", ci),
+                ("R", ci), ("H", ci), ("M", ci), ("trace", vp)]
+
+
 class ReduceDesc(C.Structure):
     _fields_ = [("slabs", vp), ("dW", vp), ("db", vp), ("slab_stride", cll),
                 ("n_slabs", ci), ("N", ci), ("K", ci), ("ld", ci)]
@@ -81,12 +102,14 @@ SIGNATURES = {
                              ci, ci, vp, vp, ci, vp]),
     "gi_gemm": (ci, [C.POINTER(GemmParams), vp]),
     "gi_gemm_batch": (ci, [C.POINTER(GemmParams), ci, vp]),
+    "gi_mlp_chain": (ci, [C.POINTER(ChainParams), ci, vp]),
     "gi_seg_sum": (ci, [vp, ci, vp, vp, ci, ci, vp, ci, ci, vp]),
     "gi_seg_softmax_fwd": (ci, [vp, vp, ci, vp, vp, ci, ci, vp, ci, vp]),
     "gi_seg_softmax_bwd": (ci, [vp, vp, ci, vp, vp, ci, ci, vp, ci, vp, vp, ci, vp]),
     "gi_seg_sum_dselu": (ci, [vp, ci, vp, vp, ci, ci, vp, ci, vp]),
     "gi_slab_sum_dselu": (ci, [vp, ci, cll, ci, ci, ci, vp, ci, vp]),
     "gi_selu_bwd_rows": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, vp]),
+    "gi_gru_fused_fwd": (ci, [C.POINTER(GruParams), vp]),
     "gi_gru_gates_fwd": (ci, [vp, vp, ci, vp, vp, ci, vp, ci, ci, ci, vp]),
     "gi_gru_gates_bwd": (ci, [vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, vp]),
     "gi_gather_readout_fwd": (ci, [vp, vp, ci, vp, vp, ci, ci, ci, C.c_float,
@@ -98,8 +121,8 @@ SIGNATURES = {
     "gi_colsum": (ci, [vp, ci, ci, ci, vp, vp, vp]),
     "gi_colsum_multi": (ci, [vp, ci, vp]),
     "gi_reduce_slabs": (ci, [C.POINTER(ReduceDesc), ci, vp]),
-    "gi_adam_step": (ci, [vp, vp, vp, vp, cll, C.c_float, C.c_float, C.c_float, C.c_float,
-                          C.c_float, ci, vp]),
+    "gi_adam_step": (ci, [vp, vp, vp, vp, cll, C.c_double, C.c_double, C.c_double, C.c_double,
+                          C.c_double, ci, vp]),
     "gi_kl_loss": (ci, [vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp]),
     "gi_scale_by_scalar": (ci, [vp, cll, vp, vp]),
     "gi_prof_enable": (ci, [ci]),

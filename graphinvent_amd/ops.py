@@ -323,3 +323,44 @@ def ws_view(ws: torch.Tensor, dims, graph: "CompactGraph", name: str, rows: int,
                                       j, C.byref(off),
                                       C.byref(ld)), f"gi_ggnn_ws_query({name})")
     return ws[off.value:off.value + rows * ld.value].view(rows, ld.value)
+
+
+def mlp_chain(chains, backward=False):
+    """gi_mlp_chain.  chains: list (1 or 2) of dicts with keys
+    X, x_idx (or None), grp_off (int32 tensor [G+1] or None), group_rows (host ints), rows, and
+    layers = list of dicts(W=[per-group tensors], bias=[per-group tensors] (forward), out, act (backward
+    or None), K, N)."""
+    lib = L.load()
+    arr = (L.ChainParams * len(chains))()
+    for c, spec in zip(arr, chains):
+        c.nlayers = len(spec["layers"])
+        c.X, c.ldx = spec["X"].data_ptr(), spec["X"].stride(0)
+        c.x_idx, c.grp_off = _ptr(spec.get("x_idx")), _ptr(spec.get("grp_off"))
+        rows_g = list(spec.get("group_rows") or [spec["rows"]])
+        c.ngroups, c.rows, c.backward = len(rows_g), spec["rows"], int(backward)
+        for t, n in enumerate(rows_g):
+            c.group_rows[t] = n
+        for y, ly in zip(c.layer, spec["layers"]):
+            y.K, y.N = ly["K"], ly["N"]
+            y.out, y.ldo = ly["out"].data_ptr(), ly["out"].stride(0)
+            act = ly.get("act")
+            y.act, y.ldact = _ptr(act), (act.stride(0) if act is not None else 0)
+            for t, w in enumerate(ly["W"]):
+                y.W[t] = w.data_ptr()
+            for t, b in enumerate(ly.get("bias") or ()):
+                y.bias[t] = b.data_ptr()
+    L.check(lib.gi_mlp_chain(arr, len(chains), _stream()), "gi_mlp_chain")
+
+
+def gru_fused_fwd(m, in_perm, seg_off, agg, agg_ready, hx_prev, hx_new, W_ih, W_hh, b_ih, b_hh, gi, gh,
+                  R, H, M):
+    """gi_gru_fused_fwd on [R, ld] tensors (test / tool entry; the model calls it from C++)."""
+    q = L.GruParams()
+    q.m, q.ldm = _ptr(m), (m.stride(0) if m is not None else 0)
+    q.in_perm, q.seg_off = _ptr(in_perm), seg_off.data_ptr()
+    q.agg, q.ldagg, q.agg_ready = agg.data_ptr(), agg.stride(0), int(agg_ready)
+    q.hx_prev, q.hx_new, q.ldhx = hx_prev.data_ptr(), hx_new.data_ptr(), hx_prev.stride(0)
+    q.W_ih, q.W_hh, q.b_ih, q.b_hh = (t.data_ptr() for t in (W_ih, W_hh, b_ih, b_hh))
+    q.gi, q.gh, q.ldg = gi.data_ptr(), gh.data_ptr(), gi.stride(0)
+    q.R, q.H, q.M = R, H, M
+    L.check(L.load().gi_gru_fused_fwd(C.byref(q), _stream()), "gi_gru_fused_fwd")

@@ -140,6 +140,45 @@ int gi_gemm(const gi_gemm_params* p, void* stream);
 int gi_gemm_batch(const gi_gemm_params* problems, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Resident-activation MLP chain — a whole `MLP.forward` (gnn/modules.py:166-170: Linear -> SELU for
+ * every layer including the last) of the per-bond-type message / attention stacks
+ * (`GGNN.message_terms` gnn/mpnn.py:284-294, `AttentionGGNN.aggregate_message` gnn/mpnn.py:370-389),
+ * or the whole dZ chain of its backward, in ONE launch: each workgroup carries 32 rows through all
+ * layers with the activation tile resident in LDS; every layer's output is also written to `out`.
+ *   forward : layer l: out_l[rows, N] = selu(in_l W_l^T + bias_l),   W_l = [N][K] row-major
+ *   backward: layer l: out_l[rows, N] = (in_l W_l) * selu'(act_l),   W_l = [K][N] row-major
+ *             (act_l NULL: no SELU factor — the input gradient of the stack's first Linear)
+ * in_0 = X rows (optionally gathered by x_idx), in_{l+1} = out_l.  Rows are grouped like gi_gemm's
+ * grouped problems (group t uses W[t] / bias[t]; `grp_off` on the device, `group_rows` = host upper
+ * bounds for the grid).  Limits: nlayers <= GI_CHAIN_MAXL, 4 <= K, N <= GI_CHAIN_MAXW (GI_ELIMIT
+ * otherwise — callers then run the stack layer by layer through gi_gemm).
+ * ------------------------------------------------------------------------------------------ */
+#define GI_CHAIN_MAXL 8
+#define GI_CHAIN_MAXW 256
+typedef struct {
+    const float* W[GI_MAX_GROUPS];
+    const float* bias[GI_MAX_GROUPS];     /* forward only */
+    float* out; int ldo;
+    const float* act; int ldact;          /* backward only */
+    int K, N;
+} gi_chain_layer;
+
+typedef struct {
+    gi_chain_layer layer[GI_CHAIN_MAXL];
+    int nlayers;
+    const float* X; int ldx;              /* ldx >= round-up-to-4(layer[0].K) */
+    const int* x_idx;                     /* row gather for X, or NULL */
+    const int* grp_off;                   /* device: ngroups + 1 row offsets (NULL: one group, rows [0, rows)) */
+    int ngroups;
+    int group_rows[GI_MAX_GROUPS];        /* host upper bound of rows per group */
+    int rows;                             /* total rows */
+    int backward;
+} gi_chain_params;
+
+/* nchains (1 or 2, same direction) independent chains in one launch. */
+int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Graph / pointwise kernels
  * ------------------------------------------------------------------------------------------ */
 /* K4 seg_sum — replaces `torch.matmul(message_summation_matrix, message_terms)`
@@ -184,6 +223,26 @@ int gi_selu_bwd_rows(const float* dY, int lddy, const int* idx, const float* Y, 
  * the feature tail [H,H+Fn) copied); gi is overwritten with (r|z|n), gh keeps W_hn h + b_hn. */
 int gi_gru_gates_fwd(float* gi, float* gh, int ldg, const float* hx_prev, float* hx_new, int ldh,
                      const int* seg_off, int rows, int H, int Fn, void* stream);
+/* Fused aggregation + GRU update of one message pass — `torch.matmul(message_summation_matrix,
+ * message_terms)` (gnn/summation_mpnn.py:141) and `self.gru(messages, nodes)` (gnn/mpnn.py:296-297) in
+ * one launch: a_v = sum of the rows m[in_perm[k]] of v's dst-CSR segment (written to `agg`; with
+ * agg_ready != 0 `agg` already holds the aggregate — pass-0 rows, attention), both GRUCell
+ * projections and the gates.  Outputs exactly what gi_gru_gates_fwd leaves behind: hx_new, gi = (r|z|n)
+ * and gh[:, 2H:3H] = W_hn h + b_hn for rows with an incoming edge.  H, M <= GI_GRU_MAXW, else GI_ELIMIT. */
+#define GI_GRU_MAXW 128
+typedef struct {
+    const float* m; int ldm;              /* message rows [U, ldm] (unused when agg_ready) */
+    const int* in_perm; const int* seg_off;
+    float* agg; int ldagg;                /* [R, ldagg] */
+    int agg_ready;
+    const float* hx_prev; float* hx_new; int ldhx;
+    const float* W_ih; const float* W_hh; const float* b_ih; const float* b_hh;
+    float* gi; float* gh; int ldg;        /* [R, ldg >= 3H] */
+    int R, H, M;
+    long long* trace;                     /* measurement aid, set by the library (GI_GRU_TRACE); pass NULL */
+} gi_gru_params;
+int gi_gru_fused_fwd(const gi_gru_params* p, void* stream);
+
 /* In: dh_new (+ up to three more partial gradients dh_b/c/d or NULL, all [rows, lddh]);
  * gi=(r|z|n), gh=(..|..|hn) from forward are overwritten with d gi, d gh;
  * dh_prev = direct part of the gradient to h_prev. */
@@ -231,8 +290,8 @@ int gi_reduce_slabs(const gi_reduce_desc* descs, int n_desc, void* stream);
 
 /* torch.optim.Adam step (no amsgrad) over ONE flat fp32 bucket of n floats (n % 4 == 0, 16-byte
  * aligned): the optimizer the reference builds at Workflow.py:219-263, as a single launch. */
-int gi_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
-                 float beta2, float eps, float weight_decay, int step, void* stream);
+int gi_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1,
+                 double beta2, double eps, double weight_decay, int step, void* stream);
 
 /* Workflow.loss (Workflow.py:833-860) forward + gradient in one pass over the logits:
  * row_loss[b] = KL(target_b / sum(target_b) || softmax(out_b)); loss = mean_b row_loss[b];

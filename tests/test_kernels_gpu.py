@@ -127,6 +127,158 @@ def test_gemm_forward_gather_and_groups():
     assert rel(Y[:, :N], ref) < 2e-5
 
 
+def _chain_case(sizes, off, seed, two=False):
+    """Resident-activation MLP chain (gi_mlp_chain) against fp64 torch, forward and dZ chain: grouped
+    rows (ragged, an empty group, a 1-row group), gathered input, widths that are not multiples of 4
+    or 32, every hidden activation / dZ buffer checked, nothing written outside [rows, N]."""
+    g = torch.Generator().manual_seed(seed)
+    G = len(off) - 1
+    E, R = off[-1], 300
+    K0 = sizes[0]
+    ldx = ops.r4(K0) + 4
+    h = torch.randn(R, ldx, generator=g)
+    idx = torch.randint(0, R, (E,), generator=g, dtype=torch.int32)
+    offt = torch.tensor(off, dtype=torch.int32)
+    rows_g = [off[t + 1] - off[t] for t in range(G)]
+    nchains = 2 if two else 1
+    Ws = [[[torch.randn(o, i, generator=g) / i ** 0.5 for _ in range(G)]
+           for i, o in zip(sizes, sizes[1:])] for _ in range(nchains)]
+    bs = [[[torch.randn(o, generator=g) * 0.3 for _ in range(G)] for o in sizes[1:]]
+          for _ in range(nchains)]
+    dev = lambda t: t.to(DEV)
+    specs, outs = [], []
+    for c in range(nchains):
+        bufs = [torch.full((E, ops.r4(o) + 4), 7.0, device=DEV) for o in sizes[1:]]
+        outs.append(bufs)
+        specs.append(dict(X=dev(h), x_idx=dev(idx), grp_off=dev(offt), group_rows=rows_g, rows=E,
+                          layers=[dict(W=[dev(w) for w in Ws[c][l]], bias=[dev(b) for b in bs[c][l]],
+                                       out=bufs[l], K=sizes[l], N=sizes[l + 1])
+                                  for l in range(len(sizes) - 1)]))
+    ops.mlp_chain(specs, backward=False)
+    refs = []
+    for c in range(nchains):
+        acts = []
+        x = h[idx.long(), :K0].double()
+        for l in range(len(sizes) - 1):
+            y = torch.zeros(E, sizes[l + 1], dtype=torch.float64)
+            for t in range(G):
+                lo, hi = off[t], off[t + 1]
+                y[lo:hi] = D.selu(x[lo:hi] @ Ws[c][l][t].double().t() + bs[c][l][t].double())
+            acts.append(y)
+            x = y
+            assert rel(outs[c][l][:, :sizes[l + 1]], y) < 3e-5, (c, l)
+            assert bool((outs[c][l][:, sizes[l + 1]:] == 7.0).all()), (c, l)
+        refs.append(acts)
+    # ---- dZ chain: dZ_{l-1} = (dZ_l W_l) * selu'(act_{l-1}); first layer: plain input gradient
+    L_ = len(sizes) - 1
+    bspecs, bouts = [], []
+    for c in range(nchains):
+        dZ = torch.randn(E, ops.r4(sizes[-1]), generator=g)
+        douts = [torch.full((E, ops.r4(sizes[l]) + 4), 7.0, device=DEV) for l in range(L_)]
+        layers = []
+        for l in range(L_ - 1, -1, -1):
+            act = None
+            if l > 0:
+                act = refs[c][l - 1].float()
+                pad = torch.zeros(E, ops.r4(sizes[l]) - sizes[l])
+                act = dev(torch.cat([act, pad], 1))
+            layers.append(dict(W=[dev(w) for w in Ws[c][l]], out=douts[l], act=act, K=sizes[l + 1],
+                               N=sizes[l]))
+        bspecs.append(dict(X=dev(dZ), x_idx=None, grp_off=dev(offt), group_rows=rows_g, rows=E,
+                           layers=layers))
+        bouts.append((dZ, douts))
+    ops.mlp_chain(bspecs, backward=True)
+    for c in range(nchains):
+        dZ, douts = bouts[c]
+        z = dZ[:, :sizes[-1]].double()
+        for l in range(L_ - 1, -1, -1):
+            nxt = torch.zeros(E, sizes[l], dtype=torch.float64)
+            for t in range(G):
+                lo, hi = off[t], off[t + 1]
+                nxt[lo:hi] = z[lo:hi] @ Ws[c][l][t].double()
+            if l > 0:
+                nxt = nxt * D.selu_grad_from_out(refs[c][l - 1].float().double())
+            assert rel(douts[l][:, :sizes[l]], nxt) < 3e-5, (c, l)
+            assert bool((douts[l][:, sizes[l]:] == 7.0).all()), (c, l)
+            z = nxt
+
+
+@pytest.mark.parametrize("sizes,off", [
+    ((128, 250, 250, 250, 250, 128), [0, 600, 600, 777]),       # bench config, middle group empty
+    ((100, 250, 250, 250, 250, 100), [0, 33, 34, 131]),         # reference default dims
+    ((16, 24, 24, 12), [0, 5, 7, 8]),                           # tiny config
+    ((37, 256, 7, 130), [0, 64]),                               # one group, awkward widths, depth 2
+    ((128, 100), [0, 31, 95]),                                  # single layer
+])
+def test_mlp_chain_forward_and_dz_chain(sizes, off):
+    _chain_case(sizes, off, seed=sum(sizes))
+
+
+def test_mlp_chain_two_chains_one_launch():
+    _chain_case((100, 250, 250, 100), [0, 90, 130, 131], seed=5, two=True)
+
+
+@pytest.mark.parametrize("H,M,Fn", [(128, 128, 8), (100, 100, 8), (16, 12, 5), (24, 20, 8)])
+@pytest.mark.parametrize("agg_ready", [False, True])
+def test_gru_fused_forward(H, M, Fn, agg_ready):
+    """gi_gru_fused_fwd (segmented sum + both GRUCell projections + gates in one launch) against the
+    fp64 dataflow model on a real graph batch: rows without incoming edges keep their state, the zero
+    row stays zero, (r, z, n) / gh_n are saved for the backward, the feature tail is copied."""
+    n8, e8, _ = synthetic.make_batch(41, **synthetic.SHAPES["gdb13"], seed=9)
+    g = D.compact(n8, e8)
+    S, E, U = g["S"], g["E"], g["U"]
+    R = S + 1
+    gen = torch.Generator().manual_seed(H + M)
+    ldm, ldhx, ldg = ops.r4(M), ops.r4(H + Fn), ops.r4(3 * H)
+    m = torch.randn(U, ldm, generator=gen)
+    hx = torch.randn(R, ldhx, generator=gen)
+    hx[S] = 0
+    W_ih = torch.randn(3 * H, M, generator=gen) / M ** 0.5
+    W_hh = torch.randn(3 * H, H, generator=gen) / H ** 0.5
+    b_ih, b_hh = torch.randn(3 * H, generator=gen) * 0.2, torch.randn(3 * H, generator=gen) * 0.2
+    perm, off = torch.from_numpy(g["in_perm"]), torch.from_numpy(g["seg_off"])
+    agg_ref = D.seg_sum(m[:, :M].double(), perm, off, R)
+    has_edge = (off[1:R + 1] - off[:R]) > 0
+    gi_ref = D.linear(agg_ref, W_ih.double(), b_ih.double(), False)
+    gh_ref = D.linear(hx[:, :H].double(), W_hh.double(), b_hh.double(), False)
+    h_new, (r_, z_, n_, hn_) = D.gru_gates(gi_ref, gh_ref, hx[:, :H].double(), has_edge)
+    dev = lambda t: t.to(DEV)
+    agg = torch.full((R, ldm), 7.0, device=DEV)
+    if agg_ready:
+        agg[:, :M] = agg_ref.float().to(DEV)
+    hx_new = torch.full((R, ldhx), 7.0, device=DEV)
+    gi = torch.full((R, ldg), 7.0, device=DEV)
+    gh = torch.full((R, ldg), 7.0, device=DEV)
+    ops.gru_fused_fwd(dev(m), dev(perm), dev(off), agg, agg_ready, dev(hx), hx_new, dev(W_ih), dev(W_hh),
+                      dev(b_ih), dev(b_hh), gi, gh, R, H, M)
+    assert rel(agg[:, :M], agg_ref) < 1e-6
+    assert rel(hx_new[:, :H], h_new) < 2e-5
+    assert torch.equal(hx_new[:, H:].cpu(), hx[:, H:])                       # feature tail + padding
+    assert float(hx_new[S].abs().max()) == 0.0
+    e = has_edge.numpy()
+    for got, want in ((gi[:, :H], r_), (gi[:, H:2 * H], z_), (gi[:, 2 * H:3 * H], n_),
+                      (gh[:, 2 * H:3 * H], hn_)):
+        assert rel(got[e], want[e]) < 2e-5
+        assert bool((got[~e] == 7.0).all())                                 # untouched without edges
+    assert bool((gh[:, :2 * H] == 7.0).all())
+
+
+def test_gru_fused_limits_are_reported():
+    z = torch.zeros(8, 400, device=DEV)
+    off = torch.zeros(10, dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError, match="GI_ELIMIT"):
+        ops.gru_fused_fwd(z, off, off, z, False, z, z, z, z, z, z, z, z, 8, 129, 100)
+
+
+def test_mlp_chain_limits_are_reported():
+    x = torch.zeros(8, 260, device=DEV)
+    w = torch.zeros(300, 256, device=DEV)
+    spec = dict(X=x, rows=8, layers=[dict(W=[w], bias=[torch.zeros(300, device=DEV)],
+                                         out=torch.zeros(8, 300, device=DEV), K=256, N=300)])
+    with pytest.raises(RuntimeError, match="GI_ELIMIT"):
+        ops.mlp_chain([spec])
+
+
 @pytest.mark.parametrize("tm,tn", TILES)
 def test_gemm_dgrad_dselu_inplace_and_accumulate(tm, tn):
     g = torch.Generator().manual_seed(2)

@@ -55,3 +55,42 @@ def test_hdf_reader_matches_committed_fixture(golden_dir):
     n, e, a = read_hdf_int8(REF_H5)
     fn, fe, fa = _fixture(golden_dir)
     assert np.array_equal(n, fn) and np.array_equal(e, fe) and np.array_equal(a, fa)
+
+
+def test_dropin_blockdatasetloader_module_api(golden_dir):
+    """`BlockDatasetLoader` drop-in: the reference's class names and constructor arguments
+    (BlockDatasetLoader.py:17-31, 122-147; Workflow.get_dataloader, Workflow.py:131-137), importable as
+    the top-level module when graphinvent_amd/ is ahead on sys.path."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import BlockDatasetLoader as B; "
+            "print(B.__file__); print(B.HDFDataset.__name__, B.BlockDataLoader.__name__)"
+            % os.path.join(root, "graphinvent_amd"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/")
+    assert out.returncode == 0, out.stderr
+    assert "graphinvent_amd/BlockDatasetLoader.py" in out.stdout and "HDFDataset BlockDataLoader" in out.stdout
+
+    from graphinvent_amd.BlockDatasetLoader import BlockDataLoader, HDFDataset
+    n, e, a = _fixture(golden_dir, "valid")
+    ds = HDFDataset.from_arrays(n, e, a)
+    assert len(ds) == n.shape[0]
+    x = ds[3]
+    assert all(t.dtype == torch.float32 for t in x) and x[0].shape == (13, 8)        # reference dtype
+    assert all(t.shape[0] == 5 for t in ds[10:15])
+    dl = BlockDataLoader(dataset=ds, batch_size=16, block_size=10000, shuffle=True, n_workers=0,
+                         pin_memory=True)
+    assert len(dl) == n.shape[0] // 16
+    first = [b[2].clone() for b in dl]
+    assert len(first) == len(dl) and all(b.dtype == torch.int8 and b.shape == (16, 625) for b in first)
+    second = [b[2].clone() for b in dl]                                        # next epoch: reshuffled
+    assert not all(torch.equal(p, q) for p, q in zip(first, second))
+
+
+@pytest.mark.skipif(not (os.path.exists(REF_H5) and os.path.exists("/opt/conda/lib/libhdf5.so")),
+                    reason="reference HDF fixture / libhdf5 not on this box")
+def test_dropin_hdfdataset_reads_the_reference_file(golden_dir):
+    from graphinvent_amd.BlockDatasetLoader import HDFDataset
+    ds = HDFDataset(REF_H5)
+    fn, fe, fa = _fixture(golden_dir)
+    assert len(ds) == fn.shape[0] and np.array_equal(ds.apds, fa)
