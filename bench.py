@@ -262,6 +262,8 @@ def main():
     ap.add_argument("--probe-only", action="store_true",
                     help="run ONLY the beyond-Infinity-Cache seg_sum probe (for rocprofv3 --pmc passes "
                          "over the aggregation kernel) and print its JSON")
+    ap.add_argument("--no-forward-only", action="store_true",
+                    help="skip the no_grad forward-rate leg (keeps kernel traces to training steps only)")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the non-headline BASELINE configurations (extra_configs)")
     ap.add_argument("--batch", type=int, default=BATCH, help="graphs per GPU per step")
@@ -425,6 +427,7 @@ def main():
             "beyond_infinity_cache": {"achieved": probe["GBps"],
                                       "frac": round(probe["GBps"] / PEAK_HBM_GBS, 4), **probe},
         }
+    if rank == 0 and not args.no_forward_only:
         # forward-only rate: inference on the same resident batches, no_grad
         model.eval()
         with torch.no_grad():

@@ -5,20 +5,24 @@
 // Why: layer by layer these are K <= 250 GEMMs over ~8 k rows, five dependent launches per message
 // pass (+ five for the dZ chain) that each leave the MFMA pipes 86 % idle (launch ramp, prologue,
 // epilogue; profiles/r01).  A row block's chain depends on nothing but its own rows, so one workgroup
-// can carry 32 rows through all layers:
+// carries 32 rows through all layers:
 //   * the 32 x (<= 256) activation tile lives in LDS (33 KB) and is rewritten in place by each
 //     layer's epilogue — it is the MFMA A operand of the next layer, never re-read from HBM;
 //   * the layer's whole output row (<= 256 columns) is held in accumulators: 8 waves x one 32x32
-//     v_mfma_f32_32x32x2_f32 tile (exact fp32, the parity bar);
-//   * weights stream from L2 through a double-buffered LDS k-tile (32 deep) with two register stages,
-//     and the stream runs AHEAD across layer boundaries (the weights do not depend on activations),
-//     so a layer change costs one barrier pair, not a launch + pipeline refill;
+//     v_mfma_f32_32x32x2_f32 tile (exact fp32, the parity bar); 2 waves per SIMD;
+//   * the weights arrive as a pre-packed IMAGE (gi_mlp_chain_pack, a few microseconds per training
+//     step): per group one linear stream of 32 KB tiles = the exact bytes of a 32-deep LDS weight tile
+//     (zero padded to 256 x 32, forward tiles with the bank swizzle baked in), all layers back to back.
+//     The kernel streams it with LDS-DMA (global_load_lds_dwordx4: L2 -> LDS, no VGPRs, no ds_write,
+//     fully coalesced 1 KB per wave instruction) into a THREE-deep ring, two tiles ahead of the MFMAs
+//     and straight across layer boundaries.  Measured on the first, register-staged version of this
+//     kernel (tools/trace_chain.py): with one tile in flight a step cost MFMA time + load time
+//     (1.8 us against 0.85 us of MFMA work) — the weight stream is latency-bound per CU (bytes in
+//     flight / ~1 us), so the ring depth, not the instruction mix, is what buys the overlap;
 //   * every layer's output is also written to HBM once (activations for the backward / dZ for the
-//     deferred weight-gradient GEMMs).
-// 512 threads = 8 waves = 2 per SIMD: while one wave of a SIMD waits for its LDS fragments the other
-// issues MFMAs.  LDS 107 KB -> one workgroup per CU; U/32 row blocks ~ one per CU at B = 1000.
+//     deferred weight-gradient GEMMs) through a bounds-checked buffer descriptor.
 //
-//   forward  (BWD = false): Y_l = selu(A W_l^T + b_l),  W_l stored [N][K]   (reduction contiguous)
+//   forward  (BWD = false): Y_l = selu(A W_l^T + b_l),  W_l stored [N][K]
 //   backward (BWD = true) : dZ_{l-1} = (dZ_l W_l) * selu'(act_{l-1}),  W_l stored [K][N]
 #include <stdlib.h>
 #include <string.h>
@@ -29,18 +33,10 @@ namespace {
 
 constexpr int CH_ROWS = 32;                 // rows per workgroup
 constexpr int CH_W = GI_CHAIN_MAXW;         // widest layer (8 waves x 32 columns)
+constexpr int CH_KT = 32;                   // reduction depth of one weight tile
 constexpr int CH_ALD = CH_W + 4;            // activation tile row stride (conflict-free ds_read_b128)
-constexpr int CH_BLD_M = CH_W + 4;          // weight tile row stride, reduction-major storage
-// KT = reduction depth of one staged weight tile.  32: 107 KB of LDS, one workgroup per CU, 16 MFMAs
-// per wave between barriers.  16: 74 KB, TWO workgroups per CU — when the row blocks do not divide
-// evenly over the 256 CUs (U / 32 = 264 blocks at the headline batch) the overflow blocks run beside
-// the others instead of as a second round on an otherwise idle chip.
-template <int KT> struct ChainGeom {
-    static constexpr int BLD_C = KT + 4;                    // weight tile row stride, reduction-contiguous
-    static constexpr int BSZ = (CH_W * BLD_C > KT * CH_BLD_M) ? CH_W * BLD_C : KT * CH_BLD_M;
-    static constexpr int NS = KT / 8;                       // float4 staged per thread per tile
-    static constexpr int NG = KT / 8;                       // 8-deep MFMA groups per tile
-};
+constexpr int CH_TILE = CH_W * CH_KT;       // floats per weight tile image (32 KB), either layout
+constexpr int CH_RING = 3;                  // LDS weight buffers
 
 struct ChainArgs {
     gi_chain_params c[2];
@@ -50,14 +46,78 @@ struct ChainArgs {
     long long* trace;                       // measurement aid (GI_CHAIN_TRACE): 16 words per workgroup
 };
 
-template <bool BWD, int CH_KT>
+__host__ __device__ inline int chain_tiles(const gi_chain_params& p) {
+    int t = 0;
+    for (int l = 0; l < p.nlayers; ++l) t += (p.layer[l].K + CH_KT - 1) / CH_KT;
+    return t;
+}
+
+// ---- weight image ------------------------------------------------------------------------------------
+// forward tile (layer l, k tile kt): 256 rows n x 8 chunks of 4 floats; LDS position p of row n holds the
+// k chunk  p ^ ((n >> 1) & 7)  — with 128-byte rows, rows n, n+2, ... would otherwise share banks; the XOR
+// makes every 16-lane group of a ds_read_b128 fragment read conflict-free.
+// backward tile: 32 reduction rows k x 256 columns n (fragments by ds_read_b32, consecutive lanes =
+// consecutive n: conflict-free as is).
+struct PackArgs {
+    gi_chain_params c;
+    int tiles;
+};
+
+__global__ __launch_bounds__(256) void gi_chain_pack_kernel(const PackArgs a) {
+    const gi_chain_params& P = a.c;
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;      // one float4 of the image each
+    const long long per_group = (long long)a.tiles * (CH_TILE / 4);
+    if (id >= per_group * P.ngroups) return;
+    const int g = (int)(id / per_group);
+    const int rem = (int)(id - (long long)g * per_group);
+    int tile = rem / (CH_TILE / 4);
+    const int q = rem - tile * (CH_TILE / 4);
+    int l = 0;
+    for (;;) {                                                            // which layer / k tile
+        const int nk = (P.layer[l].K + CH_KT - 1) / CH_KT;
+        if (tile < nk) break;
+        tile -= nk; ++l;
+    }
+    const gi_chain_layer& Ly = P.layer[l];
+    const float* __restrict__ W = Ly.W[g];
+    const int K = Ly.K, N = Ly.N;
+    v4f v = {0.f, 0.f, 0.f, 0.f};
+    if (!P.backward) {
+        const int n = q >> 3, p = q & 7;
+        const int k = tile * CH_KT + 4 * (p ^ ((n >> 1) & 7));
+        if (n < N) {
+            const float* src = W + (long long)n * K;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (k + j < K) ? src[k + j] : 0.f;
+        }
+    } else {
+        const int kr = q >> 6, n = 4 * (q & 63);
+        const int k = tile * CH_KT + kr;
+        if (k < K) {
+            const float* src = W + (long long)k * N;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (n + j < N) ? src[n + j] : 0.f;
+        }
+    }
+    ((v4f*)P.image)[id] = v;
+}
+
+// LDS-DMA of one 1 KB piece: every lane's 16 bytes land at LDS (m0 base) + 16 * lane.  Invisible to
+// the compiler's s_waitcnt bookkeeping on purpose (its own LDS-DMA handling drains vmcnt(0) at every
+// barrier): the kernel counts these loads itself, see GI_CHAIN_WAIT below.
+__device__ __forceinline__ void lds_dma_1k(const float* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+template <bool BWD>
 __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
-    using Geo = ChainGeom<CH_KT>;
-    constexpr int CH_BLD_C = Geo::BLD_C, CH_BSZ = Geo::BSZ, NS = Geo::NS, NG = Geo::NG;
-    constexpr int CPR = CH_KT / 4;                          // float4 per weight row of a [N][K] tile
-    constexpr int RPP = 512 / CPR;                          // weight rows staged per pass ([N][K] tiles)
     __shared__ __attribute__((aligned(16))) float As[CH_ROWS * CH_ALD];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * CH_BSZ];
+    __shared__ __attribute__((aligned(1024))) float Bs[CH_RING * CH_TILE];
 
     // ---- which (chain, group, row block) -------------------------------------------------------
     const int id = blockIdx.x;
@@ -76,75 +136,34 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
     const long long t_start = args.trace ? (long long)wall_clock64() : 0;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int swid = __builtin_amdgcn_readfirstlane(wid);   // wave-uniform copy for scalar use
     const int l31 = lane & 31, lhi = lane >> 5;
-    // weight staging coordinates: [N][K] storage: CPR float4 per KT-deep row; [K][N]: 64 float4 per row
-    const int cc4 = tid % CPR, crow = tid / CPR;            // rows crow + RPP i
-    const int mc4 = tid & 63, mrow = tid >> 6;              // reduction rows mrow + 8 i
+    const int T = chain_tiles(P);                            // steps = weight tiles of the whole chain
 
-    // Iterator over the (layer, k tile) steps of the chain; the layer's scalars are fetched once per
-    // layer change, so the step body itself is free of scalar loads and branches.  Past the last
-    // tile an iterator stays on it: the weight stream then re-stages that tile, which nobody reads.
-    struct It { int l, kt, nk, K, N; const float* W; };
-    auto load_layer = [&](It& it) {
-        const gi_chain_layer& Ly = P.layer[it.l];
-        it.K = Ly.K; it.N = Ly.N; it.W = Ly.W[g];
-        it.nk = (Ly.K + CH_KT - 1) / CH_KT;
-    };
-    auto advance = [&](It& it) {
-        if (++it.kt == it.nk) {
-            if (it.l + 1 < L) { ++it.l; it.kt = 0; load_layer(it); }
-            else it.kt = it.nk - 1;
-        }
-    };
-
-    // global -> registers (raw, clamped addresses; nothing consumes the data here); `part` of
-    // `nparts` equal shares of the thread's NS vectors, so the loads can be spread over MFMA groups
-    auto gload = [&](v4f (&rw)[NS], const It& it, int part, int nparts) {
-        const float* __restrict__ W = it.W;
-        const int K = it.K, N = it.N, k0 = it.kt * CH_KT;
-        const int per = NS / nparts;
+    // ---- weight stream: tile t of this group -> ring slot t % 3; a wave moves 4 of the 32 pieces ----
+    const float* const img = P.image + (long long)g * (P.image_stride ? P.image_stride : (long long)T * CH_TILE) +
+                             (swid * 4) * 256 + lane * 4;
+    const unsigned bs_lds = (unsigned)(uintptr_t)Bs + (unsigned)(swid * 4) * 1024u;
+    auto dma_tile = [&](int t) {
+        t = min(t, T - 1);                                   // past the end: re-fetch the last tile
+        const float* src = img + (long long)t * CH_TILE;     // (keeps the outstanding-load count fixed)
+        const unsigned dst = bs_lds + (unsigned)(t % CH_RING) * (unsigned)(CH_TILE * 4);
 #pragma unroll
-        for (int i = part * per; i < (part + 1) * per; ++i) {
-            if (!BWD) {
-                const int n = min(crow + RPP * i, N - 1);
-                rw[i] = gi_load4_raw(W + (long long)n * K, k0 + 4 * cc4, K - 4);
-            } else {
-                const int kr = min(k0 + mrow + 8 * i, K - 1);
-                rw[i] = gi_load4_raw(W + (long long)kr * N, 4 * mc4, N - 4);
-            }
-        }
-    };
-    // registers -> LDS; zero fill along the REDUCTION dimension only (garbage along the output
-    // dimension feeds output elements the epilogue discards).  Always through the branch-free fix-up
-    // (a few v_cndmask in the shadow of the MFMAs) so the whole step stays one basic block and the
-    // compiler can count vmcnt instead of draining it.
-    auto sstore = [&](v4f (&rw)[NS], int buf, const It& it, int part, int nparts) {
-        const int K = it.K, N = it.N, k0 = it.kt * CH_KT;
-        float* b = Bs + buf * CH_BSZ;
-        const int per = NS / nparts;
-#pragma unroll
-        for (int i = part * per; i < (part + 1) * per; ++i) {
-            if (!BWD) {
-                *(v4f*)&b[(crow + RPP * i) * CH_BLD_C + 4 * cc4] =
-                    gi_fix4(rw[i], k0 + 4 * cc4, K - 4, K, true);
-            } else {
-                const bool ok = k0 + mrow + 8 * i < K;
-                *(v4f*)&b[(mrow + 8 * i) * CH_BLD_M + 4 * mc4] = gi_fix4(rw[i], 4 * mc4, N - 4, N, ok);
-            }
-        }
+        for (int q = 0; q < 4; ++q) lds_dma_1k(src + q * 256, dst + q * 1024u);
     };
 
     f32x16 acc;
-    auto read_frags = [&](int buf, int kt, int k8, float (&af)[4], float (&bf)[4]) {
+    auto read_frags = [&](int slot, int kt, int k8, float (&af)[4], float (&bf)[4]) {
         const v4f a = *(const v4f*)&As[l31 * CH_ALD + kt * CH_KT + k8 * 8 + 4 * lhi];
         af[0] = a.x; af[1] = a.y; af[2] = a.z; af[3] = a.w;
-        const float* b = Bs + buf * CH_BSZ;
+        const float* b = Bs + slot * CH_TILE;
         if (!BWD) {
-            const v4f v = *(const v4f*)&b[(wid * 32 + l31) * CH_BLD_C + k8 * 8 + 4 * lhi];
+            const int row = wid * 32 + l31;
+            const v4f v = *(const v4f*)&b[row * CH_KT + 4 * ((2 * k8 + lhi) ^ ((row >> 1) & 7))];
             bf[0] = v.x; bf[1] = v.y; bf[2] = v.z; bf[3] = v.w;
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = b[(k8 * 8 + j + 4 * lhi) * CH_BLD_M + wid * 32 + l31];
+            for (int j = 0; j < 4; ++j) bf[j] = b[(k8 * 8 + j + 4 * lhi) * CH_W + wid * 32 + l31];
         }
     };
     auto mma = [&](const float (&af)[4], const float (&bf)[4]) {
@@ -185,6 +204,11 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
             if (dselu) x *= gi_selu_grad(av[r]);
             v[r] = col_ok ? x : 0.f;                         // zero = the next layer's k padding
         }
+        // Drain this wave's DMA queue (the two tiles in flight belong to the next two steps; their
+        // being complete is what lets those steps' waits ignore the stores issued below), then: every
+        // wave is past its last read of the activation tile.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         if (l + 1 < L) {                                     // next layer's A operand, in place
 #pragma unroll
             for (int r = 0; r < 16; ++r) As[((r & 3) + 8 * (r >> 2) + 4 * lhi) * CH_ALD + col] = v[r];
@@ -199,11 +223,11 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        if (l + 1 < L) __syncthreads();
     };
 
-    // ---- prologue: the 32 input rows -> LDS (zero beyond K0), first two weight tiles ------------
+    // ---- prologue: the 32 input rows -> LDS (zero beyond K0); then the first two weight tiles ------
     {
+        const int mc4 = tid & 63, mrow = tid >> 6;
         const int K0 = P.layer[0].K, cmax = ((K0 + 3) & ~3) - 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -217,68 +241,57 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
             *(v4f*)&As[row * CH_ALD + c] = v;
         }
     }
-    v4f rw0[NS], rw1[NS];
-    int T = 0;                                               // steps of the whole chain
-    for (int l = 0; l < L; ++l) T += (P.layer[l].K + CH_KT - 1) / CH_KT;
-    It ic, is, il;
-    ic.l = 0; ic.kt = 0; load_layer(ic);
-    is = ic;
-    gload(rw0, is, 0, 1);
-    advance(is);
-    gload(rw1, is, 0, 1);
-    il = is; advance(il);
-    sstore(rw0, 0, ic, 0, 1);
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    __syncthreads();
+    __syncthreads();                        // the A tile is in LDS (and every plain load has landed)
+    dma_tile(0);
+    dma_tile(1);
     long long t_phase[GI_CHAIN_MAXL + 1];
     if (args.trace) t_phase[0] = (long long)wall_clock64();
 
-    // ---- main loop over (layer, k tile) steps -----------------------------------------------------
-    // Step s computes tile s from LDS buffer s & 1, writes tile s+1 (loaded during step s-1) to the
-    // other buffer and fetches tile s+2 into the register stage that has just been drained; every
-    // memory instruction is pinned between MFMA groups (sched_barrier), see gi_gemm.hip: the loads go
-    // with the first half of the step's 8-deep MFMA groups, the LDS writes with the second half.
-    const int swid = __builtin_amdgcn_readfirstlane(wid);   // wave-uniform: scalar branch below
+    // ---- main loop over the weight tiles -----------------------------------------------------------
+    // Step s: wait until THIS wave's pieces of tile s have landed, barrier (=> the whole tile has, and
+    // every wave is done with tile s-1, whose ring slot is the one tile s+2 goes to), start the DMA of
+    // tile s+2, multiply tile s.  Counting the loads: they complete in issue order, and right before
+    // the wait of step s the youngest four are tile s+1's, so "at most 4 outstanding" means tile s is
+    // complete (other outstanding operations — the epilogue's stores — only make the wait longer).
+    // For the two steps after an epilogue the tiles needed were already drained by its __syncthreads,
+    // and up to 16 stores + 4 loads are younger: waiting for them would only stall.
+    // lgkmcnt(0): this wave's LDS writes (epilogue) are visible before the barrier releases readers.
+#define GI_CHAIN_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
     float af[2][4], bf[2][4];
-    constexpr int HALF = NG / 2;
-#define GI_CHAIN_STEP(BUF, RS, RL)                                                                 \
-    {                                                                                              \
-        const int kt = ic.kt;                                                                      \
-        if (swid * 32 < ic.N) {                    /* this wave owns output columns of the layer */ \
-            read_frags(BUF, kt, 0, af[0], bf[0]);                                                  \
-            _Pragma("unroll") for (int q = 0; q < NG; ++q) {                                       \
-                __builtin_amdgcn_sched_barrier(0);                                                 \
-                mma(af[q & 1], bf[q & 1]);                                                         \
-                if (q + 1 < NG) read_frags(BUF, kt, q + 1, af[(q + 1) & 1], bf[(q + 1) & 1]);      \
-                if (q < HALF) gload(RL, il, q, HALF);                                              \
-                else sstore(RS, (BUF) ^ 1, is, q - HALF, HALF);                                    \
-            }                                                                                      \
-            __builtin_amdgcn_sched_barrier(0);                                                     \
-        } else {                                   /* narrow layer: only stage the weight stream */ \
-            gload(RL, il, 0, 1);                                                                   \
-            sstore(RS, (BUF) ^ 1, is, 0, 1);                                                       \
-        }                                                                                          \
-        __syncthreads();                                                                           \
-        if (kt == ic.nk - 1) {                                                                     \
-            epilogue(ic.l);                                                                        \
-            if (args.trace) t_phase[ic.l + 1] = (long long)wall_clock64();                         \
-        }                                                                                          \
-        advance(ic); advance(is); advance(il);                                                     \
+    int l = 0, kt = 0, nk = (P.layer[0].K + CH_KT - 1) / CH_KT, lN = P.layer[0].N;
+    int since_epi = 2;
+    for (int s = 0; s < T; ++s) {
+        if (since_epi < 2) { GI_CHAIN_WAIT(20); } else { GI_CHAIN_WAIT(4); }
+        ++since_epi;
+        dma_tile(s + 2);
+        const int slot = s % CH_RING;
+        if (swid * 32 < lN) {                      // this wave owns output columns of the layer
+            read_frags(slot, kt, 0, af[0], bf[0]);
+#pragma unroll
+            for (int q = 0; q < CH_KT / 8; ++q) {
+                __builtin_amdgcn_sched_barrier(0);
+                mma(af[q & 1], bf[q & 1]);
+                if (q + 1 < CH_KT / 8) read_frags(slot, kt, q + 1, af[(q + 1) & 1], bf[(q + 1) & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (++kt == nk) {                          // layer done
+            epilogue(l);
+            since_epi = 0;
+            if (args.trace) t_phase[l + 1] = (long long)wall_clock64();
+            if (++l < L) { kt = 0; nk = (P.layer[l].K + CH_KT - 1) / CH_KT; lN = P.layer[l].N; }
+        }
     }
-    for (int s = 0; s < T; s += 2) {
-        GI_CHAIN_STEP(0, rw1, rw0)
-        if (s + 1 >= T) break;
-        GI_CHAIN_STEP(1, rw0, rw1)
-    }
-#undef GI_CHAIN_STEP
+#undef GI_CHAIN_WAIT
     if (args.trace && threadIdx.x == 0) {   // 100 MHz wall clock: start, end, placement, rows, phases
         long long* t = args.trace + 16 * (long long)blockIdx.x;
         t[0] = t_start; t[1] = (long long)wall_clock64();
         t[2] = ((long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) << 8) |
                (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xff);   // HW_ID, XCC_ID
         t[3] = hi - r0;
-        for (int l = 0; l <= L && l <= GI_CHAIN_MAXL; ++l) t[4 + l] = t_phase[l];
+        for (int i = 0; i <= L && i <= GI_CHAIN_MAXL; ++i) t[4 + i] = t_phase[i];
     }
 }
 
@@ -303,6 +316,40 @@ int validate_chain(const gi_chain_params& p) {
 
 }  // namespace
 
+extern "C" long long gi_mlp_chain_image_floats(const gi_chain_params* p) {
+    if (!p) return GI_EINVAL;
+    if (p->nlayers < 1 || p->nlayers > GI_CHAIN_MAXL || p->ngroups < 1 || p->ngroups > GI_MAX_GROUPS)
+        return GI_EINVAL;
+    return (long long)p->ngroups * chain_tiles(*p) * CH_TILE;
+}
+
+extern "C" int gi_mlp_chain_pack(const gi_chain_params* chains, int nchains, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
+    if (!chains || nchains < 1 || nchains > 2) return GI_EINVAL;
+    for (int c = 0; c < nchains; ++c) {
+        const gi_chain_params& p = chains[c];
+        if (p.nlayers < 1 || p.nlayers > GI_CHAIN_MAXL || p.ngroups < 1 || p.ngroups > GI_MAX_GROUPS)
+            return GI_EINVAL;
+        for (int l = 0; l < p.nlayers; ++l) {
+            const gi_chain_layer& q = p.layer[l];
+            if (q.K < 4 || q.N < 4 || q.K > GI_CHAIN_MAXW || q.N > GI_CHAIN_MAXW) return GI_ELIMIT;
+            for (int t = 0; t < p.ngroups; ++t)
+                if (!q.W[t]) return GI_EINVAL;
+        }
+        if (!p.image || ((uintptr_t)p.image & 15)) return GI_EINVAL;
+        if (p.image_stride && p.image_stride != (long long)chain_tiles(p) * CH_TILE) return GI_EINVAL;
+        PackArgs a;
+        a.c = p;
+        a.tiles = chain_tiles(p);
+        const long long n4 = (long long)p.ngroups * a.tiles * (CH_TILE / 4);
+        hipLaunchKernelGGL(gi_chain_pack_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, a);
+        const int e = gi_launch_status();
+        if (e) return e;
+    }
+    return 0;
+}
+
 extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (!chains || nchains < 1 || nchains > 2) return GI_EINVAL;
@@ -315,6 +362,8 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
         const int rc = validate_chain(p);
         if (rc) return rc;
         if (p.backward != chains[0].backward) return GI_EINVAL;
+        if (!p.image || ((uintptr_t)p.image & 15)) return GI_EINVAL;   // gi_mlp_chain_pack'ed weights
+        if (p.image_stride && p.image_stride < (long long)chain_tiles(p) * CH_TILE) return GI_EINVAL;
         a.c[c] = p;
         a.chain_off[c] = total;
         int t = 0;
@@ -333,19 +382,12 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
     if (nchains == 1) a.chain_off[2] = total;
     a.nchains = nchains;
     if (total == 0) return 0;
-    // GI_CHAIN_TRACE=<address of a device buffer of 4 * total int64>: per-workgroup timestamps
+    // GI_CHAIN_TRACE=<address of a device buffer of 16 * total int64>: per-workgroup timestamps
     a.trace = getenv("GI_CHAIN_TRACE") ? (long long*)strtoull(getenv("GI_CHAIN_TRACE"), nullptr, 0) : nullptr;
     hipStream_t st = (hipStream_t)stream;
     GiProfScope prof(st, GI_PROF_GEMM, flops);
-    // 16-deep tiles (two workgroups per CU) unless told otherwise: measured tools/bench_chain.py
-    static const int kt = getenv("GI_CHAIN_KT") ? atoi(getenv("GI_CHAIN_KT")) : 16;
     const dim3 grid(total), block(512);
-    if (chains[0].backward) {
-        if (kt == 32) hipLaunchKernelGGL((gi_chain_kernel<true, 32>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((gi_chain_kernel<true, 16>), grid, block, 0, st, a);
-    } else {
-        if (kt == 32) hipLaunchKernelGGL((gi_chain_kernel<false, 32>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((gi_chain_kernel<false, 16>), grid, block, 0, st, a);
-    }
+    if (chains[0].backward) hipLaunchKernelGGL(gi_chain_kernel<true>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(gi_chain_kernel<false>, grid, block, 0, st, a);
     return gi_launch_status();
 }

@@ -8,9 +8,10 @@
 #define GI_SELU_SCALE 1.0507009873554804934193349852946f
 
 // SELU as torch.nn.SELU (gnn/modules.py:126,164): scale * (x > 0 ? x : alpha * (exp(x) - 1)) —
-// the same exp(x) - 1 form ATen's CPU/GPU elu kernels evaluate (absolute error <= ~1e-7; v_exp_f32).
+// the same exp(x) - 1 form ATen's CPU/GPU elu kernels evaluate, with the full-precision expf (the
+// fast __expf / bare v_exp_f32 is ~2 ulp worse; the epilogues are not where the time goes).
 __device__ __forceinline__ float gi_selu(float x) {
-    return GI_SELU_SCALE * (x > 0.f ? x : GI_SELU_ALPHA * (__expf(x) - 1.f));
+    return GI_SELU_SCALE * (x > 0.f ? x : GI_SELU_ALPHA * (expf(x) - 1.f));
 }
 // d selu(x)/dx through y = selu(x):  y > 0 -> scale,  else y + scale*alpha  (x <= 0 <=> y <= 0)
 __device__ __forceinline__ float gi_selu_grad(float y) {

@@ -328,15 +328,18 @@ __global__ __launch_bounds__(1024) void compact_p0_kernel(int Fe, int* __restric
 }
 
 // ---- fill -----------------------------------------------------------------------------------
-template <typename T>
+// NMAX = compile-time bound of N for the two LDS tables (5 KB at N <= 32 instead of the 80 KB a
+// single GI_MAX_NODES-sized instance reserved: that allowed two workgroups per CU on a kernel that
+// sits on the critical path of every forward).
+template <typename T, int NMAX>
 __global__ __launch_bounds__(256) void compact_fill_kernel(
     const T* __restrict__ nodes, int N, int Fn, int Fe, const int* __restrict__ gfix, Lay L,
     int S, int E, int U, int* __restrict__ u_src, int* __restrict__ in_perm,
     int* __restrict__ mu_off, int* __restrict__ mu_dst, int* __restrict__ mu_slot,
     int* __restrict__ out_perm, float* __restrict__ hx0, int ldhx, int H, int D0,
     int* __restrict__ d_src, float* __restrict__ cmat, int ldc0) {
-    __shared__ signed char typ[GI_MAX_NODES * GI_MAX_NODES];
-    __shared__ int kpos[GI_MAX_NODES * GI_MAX_NODES];   // dst-CSR slot of edge (i <- j)
+    __shared__ signed char typ[NMAX * NMAX];
+    __shared__ int kpos[NMAX * NMAX];                    // dst-CSR slot of edge (i <- j)
     const int b = blockIdx.x, tid = threadIdx.x;
     const int NN = N * N, ns = gridDim.x * N;
     const signed char* etype_g =
@@ -463,16 +466,21 @@ extern "C" int gi_compact_fill(const void* nodes, int in_dtype, int B, int N, in
     if (N > GI_MAX_NODES || Fe > GI_MAX_GROUPS) return GI_ELIMIT;
     if (ldhx < H + Fn || Fn > H) return GI_EINVAL;
     const Lay L = make_layout(B, N, Fe);
-    if (in_dtype == GI_DTYPE_F32)
-        hipLaunchKernelGGL(compact_fill_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)nodes, N, Fn, Fe, gfix, L, S, E, U, u_src, in_perm, mu_off,
-                           mu_dst, mu_slot, out_perm, hx0, ldhx, H, D0, d_src, cmat, ldc0);
-    else if (in_dtype == GI_DTYPE_I8)
-        hipLaunchKernelGGL(compact_fill_kernel<signed char>, dim3(B), dim3(256), 0,
-                           (hipStream_t)stream, (const signed char*)nodes, N, Fn, Fe, gfix, L, S, E,
-                           U, u_src, in_perm, mu_off, mu_dst, mu_slot, out_perm, hx0, ldhx, H, D0,
-                           d_src, cmat, ldc0);
+#define GI_FILL(T_, NMAX_)                                                                         \
+    hipLaunchKernelGGL((compact_fill_kernel<T_, NMAX_>), dim3(B), dim3(256), 0, (hipStream_t)stream, \
+                       (const T_*)nodes, N, Fn, Fe, gfix, L, S, E, U, u_src, in_perm, mu_off, mu_dst, \
+                       mu_slot, out_perm, hx0, ldhx, H, D0, d_src, cmat, ldc0)
+#define GI_FILL_N(T_)                                                                              \
+    do {                                                                                           \
+        if (N <= 32) GI_FILL(T_, 32);                                                              \
+        else if (N <= 64) GI_FILL(T_, 64);                                                         \
+        else GI_FILL(T_, GI_MAX_NODES);                                                            \
+    } while (0)
+    if (in_dtype == GI_DTYPE_F32) GI_FILL_N(float);
+    else if (in_dtype == GI_DTYPE_I8) GI_FILL_N(signed char);
     else
         return GI_EINVAL;
+#undef GI_FILL_N
+#undef GI_FILL
     return gi_launch_status();
 }

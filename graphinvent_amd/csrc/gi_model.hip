@@ -134,8 +134,15 @@ struct Ws {
     // so that every weight-gradient GEMM can be deferred and batched off the critical path
     long long edz[MAXP][MAXL], att_dz[MAXL], emb_dz[MAXL], add1_dz[MAXL], conn1_dz[MAXL],
         add2_dz[MAXL], conn2_dz[MAXL], term2_dz[MAXL], dagg[MAXP];
+    // packed weight images of the resident-activation chains (gi_chain.hip): [msg, energy] stacks,
+    // forward and backward layouts; 0 floats when the stack does not fit the chain kernel
+    long long img_f[2], img_b[2], img_f_n[2], img_b_n[2], img_b_stride[2];
+    long long gru_img;                 // packed W_ih | W_hh image of the fused GRU kernel (-1: not fused)
     long long total;
 };
+
+bool chain_fits(const Mlp& q, int dx_cols);
+long long chain_image_floats(const Mlp& q, int groups, bool backward, long long* stride);
 
 void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
     const gi_ggnn_dims& d = m.d;
@@ -210,6 +217,17 @@ void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
     for (int l = 0; l < d.mlp2_depth; ++l) {
         w.add2_dz[l] = take(B, w.ldM2); w.conn2_dz[l] = take(B, w.ldM2); w.term2_dz[l] = take(B, w.ldM2);
     }
+    w.gru_img = -1;
+    if (d.passes > 0 && gi_gru_image_floats(d.H, d.M) > 0) w.gru_img = take(gi_gru_image_floats(d.H, d.M), 1);
+    for (int k = 0; k < (attn ? 2 : 1); ++k) {
+        const Mlp& q = k ? m.eatt[0] : m.msg[0];
+        if (d.passes > 0 && chain_fits(q, d.H)) {
+            w.img_f_n[k] = chain_image_floats(q, d.Fe, false, nullptr);
+            w.img_b_n[k] = chain_image_floats(q, d.Fe, true, &w.img_b_stride[k]);
+            w.img_f[k] = take(w.img_f_n[k], 1);
+            w.img_b[k] = take(w.img_b_n[k], 1);
+        }
+    }
     w.total = o;
 }
 
@@ -221,6 +239,8 @@ struct SlabPlan { SlabEntry e[160]; long long total; };
 // batches of up to 8 problems, so ONE problem only needs ~256 workgroups (x its share of a
 // type-grouped launch); fewer splits = fewer slabs to write and reduce.
 void wgrad_shape(int n_out, int n_in, int red_rows, double share, int& tn, int& nsplit) {
+    // 64x64 output tiles; 128x128 tiles for the big square weight gradients (a quarter of the slabs)
+    // measured slower: 2.73 against 2.64 ms per step (tools/experiments/README.md)
     tn = 1;
     const int tiles = gi_cdiv(n_out, 64) * gi_cdiv(n_in + 1, 64);
     const int kt = gi_cdiv(std::max(red_rows, 1), 32);
@@ -274,6 +294,10 @@ struct Run {
     SideStream* side = nullptr;    // optional second stream for the weight-gradient GEMMs
     const float* wt = nullptr;     // optional transposed weight copies [n_in][r4(n_out)] (dgrad operand)
     const long long* wt_off = nullptr;
+    float* img_f[2] = {nullptr, nullptr};   // packed chain weight images [msg, energy stack]; null: the
+    float* img_b[2] = {nullptr, nullptr};   // stack runs layer by layer
+    long long img_b_stride[2] = {0, 0};
+    const struct Mlp* eatt0 = nullptr;      // identifies the energy stacks (second image)
     struct SlabPlan* sp = nullptr; // backward only: where the wgrad slabs go and what they reduce to
     float* slabs = nullptr;
     float* const* grads = nullptr;
@@ -354,7 +378,7 @@ void mlp_forward(Run& r, float* ws, const Mlp* mlps, const Grp& g, const float* 
                  const int* a_idx, int rows, const long long* acts, int ldh, float* final_dst,
                  int ld_final) {
     const int L = mlps[0].layers();
-    if (g.n && r.ok() && rows > 0 && chain_fits(mlps[0], 4) && ldx >= gi_r4(mlps[0].in)) {
+    if (g.n && r.ok() && rows > 0 && r.img_f[mlps == r.eatt0 ? 1 : 0] && ldx >= gi_r4(mlps[0].in)) {
         gi_chain_params c;                      // the whole stack in one resident-activation launch
         chain_fwd_params(c, r, ws, mlps, g, X, ldx, a_idx, rows, acts, ldh, final_dst, ld_final);
         r.chk(gi_mlp_chain(&c, 1, r.st));
@@ -453,7 +477,7 @@ void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* wid
     p.ones_col = e0.n_in;
     p.flags = GI_GEMM_SPLITK;
     p.nsplit = e0.nsplit; p.c_split_stride = e0.stride;
-    p.tm = 1; p.tn = 1;
+    p.tm = e0.tn; p.tn = e0.tn;                 // 1x1 (64x64 tiles) or 2x2 (128x128), see wgrad_shape
     const int slot = q.n - 1;
     if (g.n) {
         p.ngroups = g.n; p.grp_off = g.off;
@@ -474,9 +498,21 @@ void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* wid
     if (r.side && q.n >= 8) kick_deferred(r, q, r.side, false);
 }
 
+// one launch per tile class among (up to) 8 consecutive queued problems
+void launch_wgrad_batch(Run& r, const gi_gemm_params* p, int n, hipStream_t st) {
+    gi_gemm_params a[8], b[8];
+    int na = 0, nb = 0;
+    for (int i = 0; i < n; ++i) {
+        if (p[i].tm == 1) a[na++] = p[i];
+        else b[nb++] = p[i];
+    }
+    if (na && r.ok()) r.chk(gi_gemm_batch(a, na, st));
+    if (nb && r.ok()) r.chk(gi_gemm_batch(b, nb, st));
+}
+
 void flush_deferred(Run& r, Deferred& q) {
     for (int base = 0; base < q.n && r.ok(); base += 8)
-        r.chk(gi_gemm_batch(q.p + base, std::min(8, q.n - base), r.st));
+        launch_wgrad_batch(r, q.p + base, std::min(8, q.n - base), r.st);
     q.n = 0;
 }
 
@@ -517,7 +553,7 @@ void kick_deferred(Run& r, Deferred& q, SideStream* side, bool all) {
     r.chk((int)hipEventRecord(ready, r.st));
     r.chk((int)hipStreamWaitEvent(side->st, ready, 0));
     for (int base = 0; base < n && r.ok(); base += 8)
-        r.chk(gi_gemm_batch(q.p + base, std::min(8, n - base), side->st));
+        launch_wgrad_batch(r, q.p + base, std::min(8, n - base), side->st);
     // parameters whose last slab has just been queued: reduce them right behind, on the side stream
     // too, so that only the final pass's gradients are left for the end of the backward
     gi_reduce_desc descs[96 * GI_MAX_GROUPS > 160 ? 160 : 96 * GI_MAX_GROUPS];
@@ -610,8 +646,8 @@ void msg_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred& dq, c
                   const long long* acts, const long long* dzs, int ldh, const float* Zlast, int ldz,
                   float* dX, int lddx, int dx_cols) {
     const int L = mlps[0].layers();
-    if (g.n && r.ok() && rows > 0 && chain_fits(mlps[0], dx_cols) &&
-        (!dX || dx_cols == mlps[0].in) && ldz >= gi_r4(mlps[0].out)) {
+    if (g.n && r.ok() && rows > 0 && r.img_b[mlps == r.eatt0 ? 1 : 0] && dx_cols == mlps[0].in &&
+        ldz >= gi_r4(mlps[0].out)) {
         gi_chain_params c;                      // the whole dZ chain in one launch, then the wgrads
         if (chain_bwd_params(c, r, ws, mlps, g, Zlast, ldz, rows, acts, dzs, ldh, dX, lddx, dx_cols))
             r.chk(gi_mlp_chain(&c, 1, r.st));
@@ -655,6 +691,39 @@ bool chain_fits(const Mlp& q, int dx_cols) {
     return dx_cols >= 4 && dx_cols <= GI_CHAIN_MAXW;
 }
 
+// skeleton (dims only) of a stack's chain, forward or backward order (backward: every layer, the
+// first Linear's input gradient last)
+void chain_dims(gi_chain_params& c, const Mlp& q, int groups, bool backward) {
+    memset(&c, 0, sizeof(c));
+    const int L = q.layers();
+    c.nlayers = L; c.ngroups = groups; c.backward = backward ? 1 : 0;
+    for (int i = 0; i < L; ++i) {
+        const int l = backward ? L - 1 - i : i;
+        c.layer[i].K = backward ? q.fan_out(l) : q.fan_in(l);
+        c.layer[i].N = backward ? q.fan_in(l) : q.fan_out(l);
+    }
+}
+
+long long chain_image_floats(const Mlp& q, int groups, bool backward, long long* stride) {
+    gi_chain_params c;
+    chain_dims(c, q, groups, backward);
+    const long long n = gi_mlp_chain_image_floats(&c);
+    if (stride) *stride = n > 0 ? n / groups : 0;
+    return n > 0 ? n : 0;
+}
+
+// write the packed weight image of the grouped stacks `mlps` (once per forward / backward call)
+void chain_pack(Run& r, const Mlp* mlps, int groups, bool backward, float* image) {
+    if (!r.ok()) return;
+    gi_chain_params c;
+    chain_dims(c, mlps[0], groups, backward);
+    const int L = mlps[0].layers();
+    for (int i = 0; i < L; ++i)
+        for (int t = 0; t < groups; ++t) c.layer[i].W[t] = r.P[mlps[t].w(backward ? L - 1 - i : i)];
+    c.image = image;
+    r.chk(gi_mlp_chain_pack(&c, 1, r.st));
+}
+
 void chain_groups(gi_chain_params& c, const Grp& g, int rows) {
     c.grp_off = g.off; c.ngroups = g.n; c.rows = rows;
     for (int t = 0; t < g.n; ++t) c.group_rows[t] = g.host_rows ? g.host_rows[t] : g.max_rows;
@@ -665,6 +734,7 @@ void chain_fwd_params(gi_chain_params& c, const Run& r, float* ws, const Mlp* ml
                       const float* X, int ldx, const int* idx, int rows, const long long* acts,
                       int ldh, float* final_dst, int ld_final) {
     memset(&c, 0, sizeof(c));
+    c.image = r.img_f[mlps == r.eatt0 ? 1 : 0];
     const Mlp& q = mlps[0];
     const int L = q.layers();
     c.nlayers = L; c.X = X; c.ldx = ldx; c.x_idx = idx; c.backward = 0;
@@ -687,6 +757,8 @@ int chain_bwd_params(gi_chain_params& c, const Run& r, float* ws, const Mlp* mlp
     memset(&c, 0, sizeof(c));
     const Mlp& q = mlps[0];
     const int L = q.layers();
+    c.image = r.img_b[mlps == r.eatt0 ? 1 : 0];
+    c.image_stride = r.img_b_stride[mlps == r.eatt0 ? 1 : 0];
     c.X = Zlast; c.ldx = ldz; c.x_idx = nullptr; c.backward = 1;
     chain_groups(c, g, rows);
     int n = 0;
@@ -741,8 +813,7 @@ void grouped_problem(gi_gemm_params& p, const Grp& g) {
 
 void edge_chains_forward(Run& r, float* ws, const EdgeChain* ch, int n, const Grp& g,
                          const float* X, int ldx, const int* a_idx, int rows) {
-    if (n == 2 && r.ok() && rows > 0 && chain_fits(ch[0].mlps[0], 4) && chain_fits(ch[1].mlps[0], 4) &&
-        ldx >= gi_r4(ch[0].mlps[0].in)) {
+    if (n == 2 && r.ok() && rows > 0 && r.img_f[0] && r.img_f[1] && ldx >= gi_r4(ch[0].mlps[0].in)) {
         gi_chain_params c[2];                   // both stacks' whole forward in ONE launch
         for (int j = 0; j < 2; ++j)
             chain_fwd_params(c[j], r, ws, ch[j].mlps, g, X, ldx, a_idx, rows, ch[j].acts, ch[j].ldh,
@@ -780,8 +851,7 @@ void edge_chains_forward(Run& r, float* ws, const EdgeChain* ch, int n, const Gr
 void edge_chains_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred& dq,
                           const EdgeChain* ch, int n, const Grp& g, const float* X, int ldx,
                           const int* a_idx, int rows, int lddx, int dx_cols) {
-    if (n == 2 && r.ok() && rows > 0 && chain_fits(ch[0].mlps[0], dx_cols) &&
-        chain_fits(ch[1].mlps[0], dx_cols) && dx_cols == ch[0].mlps[0].in &&
+    if (n == 2 && r.ok() && rows > 0 && r.img_b[0] && r.img_b[1] && dx_cols == ch[0].mlps[0].in &&
         dx_cols == ch[1].mlps[0].in && ch[0].ldout >= gi_r4(ch[0].mlps[0].out) &&
         ch[1].ldout >= gi_r4(ch[1].mlps[0].out)) {
         gi_chain_params c[2];                   // both dZ chains in ONE launch, then the wgrads
@@ -961,9 +1031,27 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
     const int* mask = gfix + L.node_mask;
     const bool attn = d.kind == GI_KIND_ATTGGNN;
 
+    r.eatt0 = m.eatt;
+    if (d.passes > 0 && E > 0)          // packed weight images of the chain kernel, once per forward
+        for (int k = 0; k < (attn ? 2 : 1); ++k)
+            if (w.img_f_n[k] > 0) {
+                r.img_f[k] = ws + w.img_f[k];
+                chain_pack(r, k ? m.eatt : m.msg, d.Fe, false, r.img_f[k]);
+            }
     // ---- message passes (gnn/summation_mpnn.py:128-144) ----------------------------------------
-    static const bool gru_env = !(getenv("GI_GRU_FUSED") && atoi(getenv("GI_GRU_FUSED")) == 0);
-    const bool gru_fused = gru_env && d.H >= 4 && d.M >= 4 && d.H <= GI_GRU_MAXW && d.M <= GI_GRU_MAXW;
+    // Off by default: measured on the headline batch (tools/trace_chain.py, bench A/B) the fused launch
+    // takes 39.7 us (prologue 5, weight stream + MFMAs 21, gate epilogue 5; one wave per SIMD on 229
+    // workgroups) against ~35 us for seg_sum + the batched projection GEMM (1380 short workgroups, 4 per
+    // CU) + the gate kernel it replaces, and the training step loses 60 us with it.  GI_GRU_FUSED=1.
+    static const bool gru_env = getenv("GI_GRU_FUSED") && atoi(getenv("GI_GRU_FUSED")) != 0;
+    const bool gru_fused = gru_env && w.gru_img >= 0;
+    if (gru_fused && r.ok()) {          // packed GRU weight image, once per forward
+        gi_gru_params q;
+        memset(&q, 0, sizeof(q));
+        q.W_ih = params[m.gru_wih]; q.W_hh = params[m.gru_whh]; q.H = d.H; q.M = d.M;
+        q.image = ws + w.gru_img;
+        r.chk(gi_gru_pack(&q, r.st));
+    }
     for (int p = 0; p < d.passes; ++p) {
         const float* hx = ws + w.hx[p];
         int agg_ready = 1;               // the aggregate is in ws + w.agg[p] before the GRU launch
@@ -1011,7 +1099,7 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
             q.W_ih = params[m.gru_wih]; q.W_hh = params[m.gru_whh];
             q.b_ih = params[m.gru_bih]; q.b_hh = params[m.gru_bhh];
             q.gi = ws + w.gi[p]; q.gh = ws + w.gh[p]; q.ldg = w.ld3H;
-            q.R = R; q.H = d.H; q.M = d.M;
+            q.R = R; q.H = d.H; q.M = d.M; q.image = ws + w.gru_img;
             r.chk(gi_gru_fused_fwd(&q, r.st));
             continue;
         }
@@ -1233,6 +1321,14 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
         }
         return r.rc;
     }
+    r.eatt0 = m.eatt;
+    if (d.passes > 0 && E > 0)          // packed weight images of the dZ chains, once per backward
+        for (int k = 0; k < (attn ? 2 : 1); ++k)
+            if (w.img_b_n[k] > 0) {
+                r.img_b[k] = ws + w.img_b[k];
+                r.img_b_stride[k] = w.img_b_stride[k];
+                chain_pack(r, k ? m.eatt : m.msg, d.Fe, true, r.img_b[k]);
+            }
     // ---- message passes, reversed -------------------------------------------------------------------
     for (int p = d.passes - 1; p >= 0; --p) {
         const float* hx = ws + w.hx[p];

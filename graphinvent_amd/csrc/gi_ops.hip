@@ -92,7 +92,7 @@ __device__ __forceinline__ v4f v4_max(v4f a, v4f b) {
     return v4f{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)};
 }
 __device__ __forceinline__ v4f v4_exp(v4f a) {
-    return v4f{__expf(a.x), __expf(a.y), __expf(a.z), __expf(a.w)};
+    return v4f{expf(a.x), expf(a.y), expf(a.z), expf(a.w)};
 }
 __device__ __forceinline__ v4f v4_rcp(v4f a) {
     return v4f{1.f / a.x, 1.f / a.y, 1.f / a.z, 1.f / a.w};

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void sample_actions_kernel(
     mx = red[0];
     __syncthreads();
     // pass 2: un-normalised probabilities; sums of 256 contiguous chunks
-    for (int i = tid; i < W; i += 256) e[i] = __expf(e[i] - mx);
+    for (int i = tid; i < W; i += 256) e[i] = expf(e[i] - mx);
     __syncthreads();
     const int L = (W + 255) / 256;
     const int lo = min(tid * L, W), hi = min(lo + L, W);

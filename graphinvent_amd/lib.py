@@ -63,14 +63,14 @@ class ChainLayer(C.Structure):
 class ChainParams(C.Structure):
     _fields_ = [("layer", ChainLayer * CHAIN_MAXL), ("nlayers", ci), ("X", vp), ("ldx", ci),
                 ("x_idx", vp), ("grp_off", vp), ("ngroups", ci), ("group_rows", ci * GI_MAX_GROUPS),
-                ("rows", ci), ("backward", ci)]
+                ("rows", ci), ("backward", ci), ("image", vp), ("image_stride", cll)]
 
 
 class GruParams(C.Structure):
     _fields_ = [("m", vp), ("ldm", ci), ("in_perm", vp), ("seg_off", vp), ("agg", vp), ("ldagg", ci),
                 ("agg_ready", ci), ("hx_prev", vp), ("hx_new", vp), ("ldhx", ci), ("W_ih", vp),
                 ("W_hh", vp), ("b_ih", vp), ("b_hh", vp), ("gi", vp), ("gh", vp), ("ldg", ci),
-                ("R", ci), ("H", ci), ("M", ci), ("trace", vp)]
+                ("R", ci), ("H", ci), ("M", ci), ("trace", vp), ("image", vp)]
 
 
 class ReduceDesc(C.Structure):
@@ -103,6 +103,8 @@ SIGNATURES = {
     "gi_gemm": (ci, [C.POINTER(GemmParams), vp]),
     "gi_gemm_batch": (ci, [C.POINTER(GemmParams), ci, vp]),
     "gi_mlp_chain": (ci, [C.POINTER(ChainParams), ci, vp]),
+    "gi_mlp_chain_pack": (ci, [C.POINTER(ChainParams), ci, vp]),
+    "gi_mlp_chain_image_floats": (cll, [C.POINTER(ChainParams)]),
     "gi_seg_sum": (ci, [vp, ci, vp, vp, ci, ci, vp, ci, ci, vp]),
     "gi_seg_softmax_fwd": (ci, [vp, vp, ci, vp, vp, ci, ci, vp, ci, vp]),
     "gi_seg_softmax_bwd": (ci, [vp, vp, ci, vp, vp, ci, ci, vp, ci, vp, vp, ci, vp]),
@@ -110,6 +112,8 @@ SIGNATURES = {
     "gi_slab_sum_dselu": (ci, [vp, ci, cll, ci, ci, ci, vp, ci, vp]),
     "gi_selu_bwd_rows": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, vp]),
     "gi_gru_fused_fwd": (ci, [C.POINTER(GruParams), vp]),
+    "gi_gru_pack": (ci, [C.POINTER(GruParams), vp]),
+    "gi_gru_image_floats": (cll, [ci, ci]),
     "gi_gru_gates_fwd": (ci, [vp, vp, ci, vp, vp, ci, vp, ci, ci, ci, vp]),
     "gi_gru_gates_bwd": (ci, [vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, vp]),
     "gi_gather_readout_fwd": (ci, [vp, vp, ci, vp, vp, ci, ci, ci, C.c_float,

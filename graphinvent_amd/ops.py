@@ -349,7 +349,17 @@ def mlp_chain(chains, backward=False):
                 y.W[t] = w.data_ptr()
             for t, b in enumerate(ly.get("bias") or ()):
                 y.bias[t] = b.data_ptr()
+    images = []
+    for c, spec in zip(arr, chains):       # packed weight images (kept alive until the launch is queued)
+        n = lib.gi_mlp_chain_image_floats(C.byref(c))
+        if n < 0:
+            L.check(int(n), "gi_mlp_chain_image_floats")
+        images.append(torch.empty(int(n), dtype=torch.float32, device=spec["X"].device))
+        c.image = images[-1].data_ptr()
+    L.check(lib.gi_mlp_chain_pack(arr, len(chains), _stream()), "gi_mlp_chain_pack")
     L.check(lib.gi_mlp_chain(arr, len(chains), _stream()), "gi_mlp_chain")
+    for im in images:
+        im.record_stream(torch.cuda.current_stream(im.device))
 
 
 def gru_fused_fwd(m, in_perm, seg_off, agg, agg_ready, hx_prev, hx_new, W_ih, W_hh, b_ih, b_hh, gi, gh,
@@ -363,4 +373,12 @@ def gru_fused_fwd(m, in_perm, seg_off, agg, agg_ready, hx_prev, hx_new, W_ih, W_
     q.W_ih, q.W_hh, q.b_ih, q.b_hh = (t.data_ptr() for t in (W_ih, W_hh, b_ih, b_hh))
     q.gi, q.gh, q.ldg = gi.data_ptr(), gh.data_ptr(), gi.stride(0)
     q.R, q.H, q.M = R, H, M
-    L.check(L.load().gi_gru_fused_fwd(C.byref(q), _stream()), "gi_gru_fused_fwd")
+    lib = L.load()
+    n = lib.gi_gru_image_floats(H, M)
+    if n < 0:
+        L.check(int(n), "gi_gru_image_floats")
+    image = torch.empty(int(n), dtype=torch.float32, device=W_ih.device)
+    q.image = image.data_ptr()
+    L.check(lib.gi_gru_pack(C.byref(q), _stream()), "gi_gru_pack")
+    L.check(lib.gi_gru_fused_fwd(C.byref(q), _stream()), "gi_gru_fused_fwd")
+    image.record_stream(torch.cuda.current_stream(image.device))

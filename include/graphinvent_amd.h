@@ -173,9 +173,20 @@ typedef struct {
     int group_rows[GI_MAX_GROUPS];        /* host upper bound of rows per group */
     int rows;                             /* total rows */
     int backward;
+    float* image;                         /* packed weight image, gi_mlp_chain_image_floats() floats,
+                                             16-byte aligned; filled by gi_mlp_chain_pack */
+    long long image_stride;               /* floats per group in the image; 0 = that of THESE layers.
+                                             A chain that runs only the first layers of a packed
+                                             stack passes the stride of the full pack. */
 } gi_chain_params;
 
-/* nchains (1 or 2, same direction) independent chains in one launch. */
+/* The kernel streams the weights as a pre-packed image (one linear stream of 32 KB LDS tile images per
+ * group, zero padded, all layers back to back): gi_mlp_chain_pack writes it from layer[].W (needs
+ * nlayers, ngroups, backward, K/N/W of every layer and `image`); it stays valid until the weights
+ * change, for any rows / X / out of the same stack. */
+long long gi_mlp_chain_image_floats(const gi_chain_params* p);
+int gi_mlp_chain_pack(const gi_chain_params* chains, int nchains, void* stream);
+/* nchains (1 or 2, same direction) independent chains in one launch; `image` must be packed. */
 int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -240,7 +251,12 @@ typedef struct {
     float* gi; float* gh; int ldg;        /* [R, ldg >= 3H] */
     int R, H, M;
     long long* trace;                     /* measurement aid, set by the library (GI_GRU_TRACE); pass NULL */
+    float* image;                         /* packed W_ih | W_hh image, gi_gru_image_floats(H, M) floats,
+                                             16-byte aligned, written by gi_gru_pack (needs W_ih, W_hh,
+                                             H, M, image); valid until the weights change */
 } gi_gru_params;
+long long gi_gru_image_floats(int H, int M);
+int gi_gru_pack(const gi_gru_params* p, void* stream);
 int gi_gru_fused_fwd(const gi_gru_params* p, void* stream);
 
 /* In: dh_new (+ up to three more partial gradients dh_b/c/d or NULL, all [rows, lddh]);
