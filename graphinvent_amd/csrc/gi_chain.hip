@@ -19,6 +19,12 @@
 //     kernel (tools/trace_chain.py): with one tile in flight a step cost MFMA time + load time
 //     (1.8 us against 0.85 us of MFMA work) — the weight stream is latency-bound per CU (bytes in
 //     flight / ~1 us), so the ring depth, not the instruction mix, is what buys the overlap;
+//   * row blocks and CUs rarely divide evenly: at the headline batch U/32 = 264 blocks met 256 CUs and
+//     a second, nearly empty round doubled the launch time.  A workgroup therefore takes up to
+//     32 + 4 rows: rows 32.. ride on the otherwise idle VALU (fp32 fma dot products against the same
+//     LDS weight tile, one output column per thread, the reduction split over the two halves of the
+//     workgroup and summed in a fixed order) at ~3 % of the MFMA time per extra row; the host picks
+//     the smallest block height that saves a round;
 //   * every layer's output is also written to HBM once (activations for the backward / dZ for the
 //     deferred weight-gradient GEMMs) through a bounds-checked buffer descriptor.
 //
@@ -27,11 +33,14 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "gi_mfma.h"
 
 namespace {
 
-constexpr int CH_ROWS = 32;                 // rows per workgroup
+constexpr int CH_ROWS = 32;                 // rows per workgroup on the MFMA path
+constexpr int CH_XMAX = 4;                  // + up to this many extra rows on the VALU (see below)
 constexpr int CH_W = GI_CHAIN_MAXW;         // widest layer (8 waves x 32 columns)
 constexpr int CH_KT = 32;                   // reduction depth of one weight tile
 constexpr int CH_ALD = CH_W + 4;            // activation tile row stride (conflict-free ds_read_b128)
@@ -41,6 +50,7 @@ constexpr int CH_RING = 3;                  // LDS weight buffers
 struct ChainArgs {
     gi_chain_params c[2];
     int nchains;
+    int tile_rows;                          // rows per workgroup: 32 .. 32 + CH_XMAX
     int tile_off[2][GI_MAX_GROUPS + 1];     // prefix of 32-row tiles over the groups of a chain
     int chain_off[3];                       // prefix of tiles over the chains
     long long* trace;                       // measurement aid (GI_CHAIN_TRACE): 16 words per workgroup
@@ -116,8 +126,9 @@ __device__ __forceinline__ void lds_dma_1k(const float* gsrc, unsigned lds_dst) 
 
 template <bool BWD>
 __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
-    __shared__ __attribute__((aligned(16))) float As[CH_ROWS * CH_ALD];
+    __shared__ __attribute__((aligned(16))) float As[(CH_ROWS + 8) * CH_ALD];   // 32 MFMA rows + 4 extra (+ 4 scratch)
     __shared__ __attribute__((aligned(1024))) float Bs[CH_RING * CH_TILE];
+    __shared__ float Xs[2 * CH_XMAX * CH_W];                 // extra rows: partial sums of the k halves
 
     // ---- which (chain, group, row block) -------------------------------------------------------
     const int id = blockIdx.x;
@@ -130,8 +141,10 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
     // so everything derived from it — buffer descriptors included — stays scalar)
     const int lo = P.grp_off ? __builtin_amdgcn_readfirstlane(P.grp_off[g]) : 0;
     const int hi = P.grp_off ? __builtin_amdgcn_readfirstlane(P.grp_off[g + 1]) : P.rows;
-    const int r0 = lo + CH_ROWS * (local - args.tile_off[ci][g]);
+    const int r0 = lo + args.tile_rows * (local - args.tile_off[ci][g]);
     if (r0 >= hi) return;                                   // block-uniform, before any barrier
+    const int nvalid = min(hi - r0, args.tile_rows);        // rows of this block
+    const int nx = __builtin_amdgcn_readfirstlane(max(nvalid - CH_ROWS, 0));   // on the VALU path
     const int L = P.nlayers;
     const long long t_start = args.trace ? (long long)wall_clock64() : 0;
 
@@ -153,6 +166,8 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
     };
 
     f32x16 acc;
+    float xacc[CH_XMAX] = {0.f, 0.f, 0.f, 0.f};             // extra rows: column xn, k half xh
+    const int xn = tid & (CH_W - 1), xh = tid >> 8;
     auto read_frags = [&](int slot, int kt, int k8, float (&af)[4], float (&bf)[4]) {
         const v4f a = *(const v4f*)&As[l31 * CH_ALD + kt * CH_KT + k8 * 8 + 4 * lhi];
         af[0] = a.x; af[1] = a.y; af[2] = a.z; af[3] = a.w;
@@ -181,7 +196,7 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
         const int N = Ly.N, ldo = Ly.ldo;
         const int col = wid * 32 + l31;
         const bool col_ok = col < N;
-        const int nrows = min(hi - r0, CH_ROWS);
+        const int nrows = min(nvalid, CH_ROWS);
         const int coff = col_ok ? 4 * col : 0x40000000;     // beyond any tile: dropped / reads 0
         float av[16];
         const bool dselu = BWD && Ly.act != nullptr;
@@ -204,11 +219,41 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
             if (dselu) x *= gi_selu_grad(av[r]);
             v[r] = col_ok ? x : 0.f;                         // zero = the next layer's k padding
         }
+        float xb = 0.f, xact[CH_XMAX];
+        if (nx > 0) {                                        // extra rows: publish both k halves
+#pragma unroll
+            for (int xi = 0; xi < CH_XMAX; ++xi) Xs[(xh * CH_XMAX + xi) * CH_W + xn] = xacc[xi];
+            if (tid < CH_W) {                                // their bias / activation loads: in flight
+                const int nc = tid < N ? tid : N - 1;        // across the barrier below
+                if (!BWD) xb = Ly.bias[g][nc];
+#pragma unroll
+                for (int xi = 0; xi < CH_XMAX; ++xi)
+                    xact[xi] = dselu ? Ly.act[(long long)(r0 + CH_ROWS + min(xi, nx - 1)) * Ly.ldact + nc]
+                                     : 0.f;
+            }
+        }
         // Drain this wave's DMA queue (the two tiles in flight belong to the next two steps; their
         // being complete is what lets those steps' waits ignore the stores issued below), then: every
         // wave is past its last read of the activation tile.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (nx > 0 && tid < CH_W) {                          // one output column per thread
+            const int n = tid;
+#pragma unroll
+            for (int xi = 0; xi < CH_XMAX; ++xi) {
+                if (xi < nx) {
+                    const long long grow = r0 + CH_ROWS + xi;
+                    float x = (Xs[xi * CH_W + n] + Xs[(CH_XMAX + xi) * CH_W + n]) + xb;
+                    if (!BWD) x = gi_selu(x);
+                    if (dselu) x *= gi_selu_grad(xact[xi]);
+                    x = (n < N) ? x : 0.f;
+                    if (l + 1 < L) As[(CH_ROWS + xi) * CH_ALD + n] = x;
+                    if (n < N) Ly.out[grow * ldo + n] = x;
+                }
+            }
+        }
+#pragma unroll
+        for (int xi = 0; xi < CH_XMAX; ++xi) xacc[xi] = 0.f;
         if (l + 1 < L) {                                     // next layer's A operand, in place
 #pragma unroll
             for (int r = 0; r < 16; ++r) As[((r & 3) + 8 * (r >> 2) + 4 * lhi) * CH_ALD + col] = v[r];
@@ -225,20 +270,28 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     };
 
-    // ---- prologue: the 32 input rows -> LDS (zero beyond K0); then the first two weight tiles ------
+    // ---- prologue: the input rows -> LDS (zero beyond K0); then the first two weight tiles ----------
+    // branch-free: all index loads, then all row loads, then all LDS writes (rows 36..39 are scratch)
     {
         const int mc4 = tid & 63, mrow = tid >> 6;
         const int K0 = P.layer[0].K, cmax = ((K0 + 3) & ~3) - 4;
+        const int c = 4 * mc4;
+        long long src[5];
+        v4f v[5];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = mrow + 8 * i;
-            const int grow = min(r0 + row, hi - 1);
-            const long long src = P.x_idx ? P.x_idx[grow] : grow;
-            v4f v = gi_load4_raw(P.X + src * P.ldx, 4 * mc4, cmax);
-            const int c = 4 * mc4;
-            v.x = (c < K0) ? v.x : 0.f; v.y = (c + 1 < K0) ? v.y : 0.f;
-            v.z = (c + 2 < K0) ? v.z : 0.f; v.w = (c + 3 < K0) ? v.w : 0.f;
-            *(v4f*)&As[row * CH_ALD + c] = v;
+        for (int i = 0; i < 5; ++i) src[i] = min(r0 + mrow + 8 * i, hi - 1);
+        if (P.x_idx) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) src[i] = P.x_idx[src[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) v[i] = gi_load4_raw(P.X + src[i] * P.ldx, c, cmax);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            v4f w = v[i];
+            w.x = (c < K0) ? w.x : 0.f; w.y = (c + 1 < K0) ? w.y : 0.f;
+            w.z = (c + 2 < K0) ? w.z : 0.f; w.w = (c + 3 < K0) ? w.w : 0.f;
+            *(v4f*)&As[(mrow + 8 * i) * CH_ALD + c] = w;
         }
     }
 #pragma unroll
@@ -256,18 +309,19 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
     // the wait of step s the youngest four are tile s+1's, so "at most 4 outstanding" means tile s is
     // complete (other outstanding operations — the epilogue's stores — only make the wait longer).
     // For the two steps after an epilogue the tiles needed were already drained by its __syncthreads,
-    // and up to 16 stores + 4 loads are younger: waiting for them would only stall.
+    // and up to 16 + 4 stores + 4 loads are younger: waiting for them would only stall.
     // lgkmcnt(0): this wave's LDS writes (epilogue) are visible before the barrier releases readers.
 #define GI_CHAIN_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
     float af[2][4], bf[2][4];
+    // (loop state kept provably wave-uniform — readfirstlane — so that every branch on it is scalar)
     int l = 0, kt = 0, nk = (P.layer[0].K + CH_KT - 1) / CH_KT, lN = P.layer[0].N;
     int since_epi = 2;
     for (int s = 0; s < T; ++s) {
-        if (since_epi < 2) { GI_CHAIN_WAIT(20); } else { GI_CHAIN_WAIT(4); }
-        ++since_epi;
+        if (__builtin_amdgcn_readfirstlane(since_epi) < 2) { GI_CHAIN_WAIT(24); } else { GI_CHAIN_WAIT(4); }
+        since_epi = __builtin_amdgcn_readfirstlane(since_epi + 1);
         dma_tile(s + 2);
         const int slot = s % CH_RING;
-        if (swid * 32 < lN) {                      // this wave owns output columns of the layer
+        if (swid * 32 < __builtin_amdgcn_readfirstlane(lN)) {   // this wave owns output columns of the layer
             read_frags(slot, kt, 0, af[0], bf[0]);
 #pragma unroll
             for (int q = 0; q < CH_KT / 8; ++q) {
@@ -277,11 +331,45 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (++kt == nk) {                          // layer done
+        if (nx > 0) {                              // rows 32..: fp32 fma dot products on the VALU
+            const float* b = Bs + slot * CH_TILE;
+            float w[16];
+            if (!BWD) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const v4f v = *(const v4f*)&b[xn * CH_KT + 4 * ((4 * xh + c) ^ ((xn >> 1) & 7))];
+                    w[4 * c] = v.x; w[4 * c + 1] = v.y; w[4 * c + 2] = v.z; w[4 * c + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) w[k] = b[(16 * xh + k) * CH_W + xn];
+            }
+#pragma unroll
+            for (int xi = 0; xi < CH_XMAX; ++xi) {
+                if (xi < nx) {
+                    const float* a = &As[(CH_ROWS + xi) * CH_ALD + kt * CH_KT + 16 * xh];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const v4f v = *(const v4f*)&a[4 * c];    // same address in every lane: broadcast
+                        xacc[xi] = fmaf(v.x, w[4 * c], xacc[xi]);
+                        xacc[xi] = fmaf(v.y, w[4 * c + 1], xacc[xi]);
+                        xacc[xi] = fmaf(v.z, w[4 * c + 2], xacc[xi]);
+                        xacc[xi] = fmaf(v.w, w[4 * c + 3], xacc[xi]);
+                    }
+                }
+            }
+        }
+        kt = __builtin_amdgcn_readfirstlane(kt + 1);
+        if (kt == __builtin_amdgcn_readfirstlane(nk)) {       // layer done
             epilogue(l);
             since_epi = 0;
             if (args.trace) t_phase[l + 1] = (long long)wall_clock64();
-            if (++l < L) { kt = 0; nk = (P.layer[l].K + CH_KT - 1) / CH_KT; lN = P.layer[l].N; }
+            l = __builtin_amdgcn_readfirstlane(l + 1);
+            if (l < L) {
+                kt = 0;
+                nk = __builtin_amdgcn_readfirstlane((P.layer[l].K + CH_KT - 1) / CH_KT);
+                lN = __builtin_amdgcn_readfirstlane(P.layer[l].N);
+            }
         }
     }
 #undef GI_CHAIN_WAIT
@@ -290,7 +378,7 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
         t[0] = t_start; t[1] = (long long)wall_clock64();
         t[2] = ((long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) << 8) |
                (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xff);   // HW_ID, XCC_ID
-        t[3] = hi - r0;
+        t[3] = nvalid;
         for (int i = 0; i <= L && i <= GI_CHAIN_MAXL; ++i) t[4 + i] = t_phase[i];
     }
 }
@@ -364,14 +452,41 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
         if (p.backward != chains[0].backward) return GI_EINVAL;
         if (!p.image || ((uintptr_t)p.image & 15)) return GI_EINVAL;   // gi_mlp_chain_pack'ed weights
         if (p.image_stride && p.image_stride < (long long)chain_tiles(p) * CH_TILE) return GI_EINVAL;
+        for (int g = 0; g < p.ngroups; ++g)
+            if ((p.ngroups > 1 ? p.group_rows[g] : p.rows) < 0) return GI_EINVAL;
+    }
+    // Block height: 32 rows, or up to 32 + CH_XMAX when the taller blocks need one round of
+    // workgroups less on this chip (one workgroup per CU: 129 KB of LDS).  GI_CHAIN_XROWS=0: always 32.
+    auto blocks = [&](int h) {
+        int n = 0;
+        for (int c = 0; c < nchains; ++c)
+            for (int g = 0; g < chains[c].ngroups; ++g)
+                n += gi_cdiv(chains[c].ngroups > 1 ? chains[c].group_rows[g] : chains[c].rows, h);
+        return n;
+    };
+    static const int ncu = [] {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    static const bool xrows = !(getenv("GI_CHAIN_XROWS") && atoi(getenv("GI_CHAIN_XROWS")) == 0);
+    int h = CH_ROWS;
+    const int rounds = gi_cdiv(blocks(CH_ROWS), ncu);
+    if (xrows && rounds > 1)
+        for (int hh = CH_ROWS + 1; hh <= CH_ROWS + CH_XMAX; ++hh)
+            if (gi_cdiv(blocks(hh), ncu) < rounds) { h = hh; break; }
+    if (const char* e = getenv("GI_CHAIN_TILE_ROWS"))          // tests / measurements: force a height
+        h = std::min(std::max(atoi(e), CH_ROWS), CH_ROWS + CH_XMAX);
+    a.tile_rows = h;
+    for (int c = 0; c < nchains; ++c) {
+        const gi_chain_params& p = chains[c];
         a.c[c] = p;
         a.chain_off[c] = total;
         int t = 0;
         for (int g = 0; g < p.ngroups; ++g) {
             a.tile_off[c][g] = t;
-            const int rows = p.ngroups > 1 ? p.group_rows[g] : p.rows;
-            if (rows < 0) return GI_EINVAL;
-            t += gi_cdiv(rows, CH_ROWS);
+            t += gi_cdiv(p.ngroups > 1 ? p.group_rows[g] : p.rows, h);
         }
         a.tile_off[c][p.ngroups] = t;
         total += t;

@@ -7,11 +7,20 @@
 #define GI_SELU_ALPHA 1.6732632423543772848170429916717f
 #define GI_SELU_SCALE 1.0507009873554804934193349852946f
 
+// exp(x) for x <= 0 to ~2 ulp in 6 instructions: v_exp_f32 (2^t, 1 ulp) on t = x * log2(e), with the
+// rounding error of that product and the low part of log2(e) folded back in as a first-order factor.
+// (libm expf costs ~25 VALU instructions per value — 1.2 us per layer epilogue of the chain kernel,
+// measured; the bare __expf = v_exp_f32(x * log2e) loses up to |x| ulp to the rounded product.)
+__device__ __forceinline__ float gi_exp_nonpos(float x) {
+    const float l2e_hi = 1.44269502162933349609375f, l2e_lo = 1.925963033500011e-8f;
+    const float t = x * l2e_hi;
+    const float r = fmaf(x, l2e_hi, -t) + x * l2e_lo;          // (exact product - t) + low part
+    return __builtin_amdgcn_exp2f(t) * fmaf(r, 0.693147182464599609375f, 1.f);
+}
 // SELU as torch.nn.SELU (gnn/modules.py:126,164): scale * (x > 0 ? x : alpha * (exp(x) - 1)) —
-// the same exp(x) - 1 form ATen's CPU/GPU elu kernels evaluate, with the full-precision expf (the
-// fast __expf / bare v_exp_f32 is ~2 ulp worse; the epilogues are not where the time goes).
+// the same exp(x) - 1 form ATen's CPU/GPU elu kernels evaluate.
 __device__ __forceinline__ float gi_selu(float x) {
-    return GI_SELU_SCALE * (x > 0.f ? x : GI_SELU_ALPHA * (expf(x) - 1.f));
+    return GI_SELU_SCALE * (x > 0.f ? x : GI_SELU_ALPHA * (gi_exp_nonpos(fminf(x, 0.f)) - 1.f));
 }
 // d selu(x)/dx through y = selu(x):  y > 0 -> scale,  else y + scale*alpha  (x <= 0 <=> y <= 0)
 __device__ __forceinline__ float gi_selu_grad(float y) {

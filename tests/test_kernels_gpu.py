@@ -218,6 +218,21 @@ def test_mlp_chain_two_chains_one_launch():
     _chain_case((100, 250, 250, 100), [0, 90, 130, 131], seed=5, two=True)
 
 
+@pytest.mark.parametrize("tile_rows", [33, 34, 36])
+@pytest.mark.parametrize("sizes,off", [
+    ((128, 250, 250, 250, 250, 128), [0, 600, 600, 777]),
+    ((100, 250, 250, 100), [0, 33, 34, 131]),
+    ((37, 256, 7, 130), [0, 70]),
+])
+def test_mlp_chain_taller_row_blocks(monkeypatch, tile_rows, sizes, off):
+    """Row blocks of 32 + x rows (x <= 4 extra rows computed on the VALU; what the launcher picks when
+    it saves a round of workgroups): forced here so that every height is exercised on ragged groups —
+    blocks with 0, some and all of their extra rows valid."""
+    monkeypatch.setenv("GI_CHAIN_TILE_ROWS", str(tile_rows))
+    _chain_case(sizes, off, seed=tile_rows + sum(sizes))
+    _chain_case(sizes, off, seed=tile_rows, two=True)
+
+
 @pytest.mark.parametrize("H,M,Fn", [(128, 128, 8), (100, 100, 8), (16, 12, 5), (24, 20, 8)])
 @pytest.mark.parametrize("agg_ready", [False, True])
 def test_gru_fused_forward(H, M, Fn, agg_ready):
