@@ -452,7 +452,7 @@ def main():
         torch.cuda.empty_cache()
         extra = []
         for label, shape, model_name, batch in EXTRA_CONFIGS:
-            k, w = 5, 2
+            k, w = 10, 3
             ewl = Workload(shape, model_name, batch, rank, device, k + w + 8, n_batches=2)
             edt, eloss = timed_steps(ewl, k, w, world, device)
             extra.append({"baseline_config": label,

@@ -298,6 +298,7 @@ struct Run {
     float* img_b[2] = {nullptr, nullptr};   // stack runs layer by layer
     long long img_b_stride[2] = {0, 0};
     const struct Mlp* eatt0 = nullptr;      // identifies the energy stacks (second image)
+    bool hold_kicks = false;                // no weight-gradient launches on the side stream for now
     struct SlabPlan* sp = nullptr; // backward only: where the wgrad slabs go and what they reduce to
     float* slabs = nullptr;
     float* const* grads = nullptr;
@@ -495,7 +496,7 @@ void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* wid
         q.widx[slot][0] = widx[0];
         q.nw[slot] = 1;
     }
-    if (r.side && q.n >= 8) kick_deferred(r, q, r.side, false);
+    if (r.side && q.n >= 8 && !r.hold_kicks) kick_deferred(r, q, r.side, false);
 }
 
 // one launch per tile class among (up to) 8 consecutive queued problems
@@ -640,6 +641,20 @@ void defer_stack_wgrads(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred&
                         const long long* acts, const long long* dzs, int ldh, const float* Zlast,
                         int ldz);
 
+void join_side(Run& r, SideStream* side);
+
+// Measurement knob (GI_CHAIN_EXCLUSIVE=1, off by default): the dZ-chain kernel wants every CU to itself
+// (one workgroup per CU, 144 KB of LDS); beside a weight-gradient batch of the side stream its
+// workgroups wait for whole CUs to drain and both launches stretch (traced: 207 + 215 us overlapped
+// against 70 + 127 us apart).  Letting the main stream wait for the side stream before each chain
+// and holding new batches back until the chain is queued raises the per-launch efficiency (GEMM-family
+// 0.29 -> 0.30 of peak) but the step gets SLOWER, 2.56 -> 2.66 ms: the idle wait costs more than the
+// stretched overlap.  Kept as a knob, not as the default.
+void chain_bwd_exclusive(Run& r) {
+    static const bool on = getenv("GI_CHAIN_EXCLUSIVE") && atoi(getenv("GI_CHAIN_EXCLUSIVE")) != 0;
+    if (on && r.side) join_side(r, r.side);
+}
+
 // The bond-type-grouped message MLP: dZ chain now, weight gradients deferred.
 void msg_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred& dq, const Mlp* mlps,
                   const Grp& g, const float* X, int ldx, const int* a_idx, int rows,
@@ -649,8 +664,11 @@ void msg_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred& dq, c
     if (g.n && r.ok() && rows > 0 && r.img_b[mlps == r.eatt0 ? 1 : 0] && dx_cols == mlps[0].in &&
         ldz >= gi_r4(mlps[0].out)) {
         gi_chain_params c;                      // the whole dZ chain in one launch, then the wgrads
-        if (chain_bwd_params(c, r, ws, mlps, g, Zlast, ldz, rows, acts, dzs, ldh, dX, lddx, dx_cols))
+        if (chain_bwd_params(c, r, ws, mlps, g, Zlast, ldz, rows, acts, dzs, ldh, dX, lddx, dx_cols)) {
+            chain_bwd_exclusive(r);
             r.chk(gi_mlp_chain(&c, 1, r.st));
+        }
+        r.hold_kicks = false;
         defer_stack_wgrads(r, ws, sp, slabs, dq, mlps, g, X, ldx, a_idx, rows, acts, dzs, ldh, Zlast,
                            ldz);
         return;
@@ -859,9 +877,11 @@ void edge_chains_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferre
         for (int j = 0; j < 2; ++j)
             nl[j] = chain_bwd_params(c[j], r, ws, ch[j].mlps, g, ch[j].out, ch[j].ldout, rows,
                                      ch[j].acts, ch[j].dzs, ch[j].ldh, ch[j].dX, lddx, dx_cols);
+        if (nl[0] || nl[1]) chain_bwd_exclusive(r);
         if (nl[0] && nl[1]) r.chk(gi_mlp_chain(c, 2, r.st));
         else if (nl[0]) r.chk(gi_mlp_chain(&c[0], 1, r.st));
         else if (nl[1]) r.chk(gi_mlp_chain(&c[1], 1, r.st));
+        r.hold_kicks = false;
         for (int j = 0; j < 2; ++j)
             defer_stack_wgrads(r, ws, sp, slabs, dq, ch[j].mlps, g, X, ldx, a_idx, rows, ch[j].acts,
                                ch[j].dzs, ch[j].ldh, ch[j].out, ch[j].ldout);
@@ -1336,6 +1356,8 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
         float* gh = ws + w.gh[p];
         float* agg = ws + w.agg[p];
         const bool last = (p == d.passes - 1);
+        static const bool excl = getenv("GI_CHAIN_EXCLUSIVE") && atoi(getenv("GI_CHAIN_EXCLUSIVE")) != 0;
+        r.hold_kicks = excl && r.img_b[0] != nullptr && E > 0;   // released right behind the pass's dZ chain
         r.chk(gi_gru_gates_bwd(gi, gh, w.ld3H, hx, w.ldhx, dh, last ? dhb : nullptr,
                                last ? dhc : nullptr, last ? dhd : nullptr, dh2, w.ldH, seg_off, R,
                                d.H, r.st));
@@ -1411,6 +1433,7 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
                     }
                 }
         }
+        r.hold_kicks = false;
         std::swap(dh, dh2);
     }
     // ---- all weight-gradient GEMMs, 8 problems per launch, then slabs -> parameter gradients -------
