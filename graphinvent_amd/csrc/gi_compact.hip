@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
     int S, int E, int U, int* __restrict__ u_src, int* __restrict__ in_perm,
     int* __restrict__ mu_off, int* __restrict__ mu_dst, int* __restrict__ mu_slot,
     int* __restrict__ out_perm, float* __restrict__ hx0, int ldhx, int H, int D0,
-    int* __restrict__ d_src, float* __restrict__ cmat, int ldc0) {
+    int* __restrict__ d_src, float* __restrict__ cmat, int ldc0, int* __restrict__ e2d) {
     __shared__ signed char typ[NMAX * NMAX];
     __shared__ int kpos[NMAX * NMAX];                    // dst-CSR slot of edge (i <- j)
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -380,9 +380,11 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
         const int mo = gfix[L.etype_off + t] + gfix[L.cstart_t + t * ns + slot] + rank;
         mu_dst[mo] = gfix[L.cidx + b * N + i];
         mu_slot[mo] = kpos[idx];
-        if (D0 > 0)    // counts are small integers: float atomics are exact and order-independent
-            atomicAdd(cmat + (long long)gfix[L.cidx + b * N + i] * ldc0 +
-                          gfix[L.dmap + t * P0Q + gfix[L.cls + slot]], 1.f);
+        if (D0 > 0) {  // counts are small integers: float atomics are exact and order-independent
+            const int d = gfix[L.dmap + t * P0Q + gfix[L.cls + slot]];
+            atomicAdd(cmat + (long long)gfix[L.cidx + b * N + i] * ldc0 + d, 1.f);
+            if (e2d) e2d[kpos[idx]] = d;                 // dst-CSR edge slot -> pass-0 row
+        }
     }
     for (int idx = tid; idx < N * Fe; idx += 256) {      // message rows of source slot j, by type
         const int j = idx / Fe, t = idx - j * Fe;
@@ -412,7 +414,60 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
         for (int col = tid; col < ldhx; col += 256) hx0[(long long)S * ldhx + col] = 0.f;
 }
 
+// ---- pass-0 row -> edge slots CSR (AttentionGGNN's pass-0 backward) --------------------------------
+// One workgroup per pass-0 row d scans e2d[0..E) twice: first it counts the slots of the rows below d
+// (its offset) and its own, then it writes its own slots in ascending order — a stable counting sort
+// without atomics or a grid-wide sync, so the summation order of the backward is fixed.  D0 is a few
+// dozen to ~100 rows and E a few 10^4 slots: the scans are L2 hits.
+__global__ __launch_bounds__(256) void class_csr_kernel(const int* __restrict__ e2d, int E, int D0,
+                                                        int* __restrict__ cls_off,
+                                                        int* __restrict__ cls_edges) {
+    __shared__ int red[2][4];
+    __shared__ int base_s;
+    const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    int below = 0, own = 0;
+    for (int k = tid; k < E; k += 256) {
+        const int c = e2d[k];
+        below += c < d;
+        own += c == d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { below += __shfl_xor(below, o); own += __shfl_xor(own, o); }
+    if (lane == 0) { red[0][wid] = below; red[1][wid] = own; }
+    __syncthreads();
+    if (tid == 0) {
+        const int b = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        base_s = b;
+        cls_off[d] = b;
+        if (d == D0 - 1) cls_off[D0] = b + red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+    __syncthreads();
+    int pos = base_s;
+    for (int k0 = 0; k0 < E; k0 += 256) {                    // stable placement, 256 slots per round
+        const int k = k0 + tid;
+        const bool mine = k < E && e2d[k] == d;
+        const unsigned long long m = __ballot(mine);
+        __syncthreads();
+        if (lane == 0) red[0][wid] = __popcll(m);
+        __syncthreads();
+        int before = __popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wid; ++w) before += red[0][w];
+        if (mine) cls_edges[pos + before] = k;
+        pos += red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    }
+}
+
 }  // namespace
+
+extern "C" int gi_compact_class_csr(const int* e2d, int E, int D0, int* cls_off, int* cls_edges,
+                                    void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
+    if (D0 <= 0 || E <= 0) return 0;
+    if (!e2d || !cls_off || !cls_edges) return GI_EINVAL;
+    hipLaunchKernelGGL(class_csr_kernel, dim3(D0), dim3(256), 0, (hipStream_t)stream, e2d, E, D0,
+                       cls_off, cls_edges);
+    return gi_launch_status();
+}
 
 extern "C" int gi_abi_version(void) { return GI_ABI_VERSION; }
 
@@ -455,7 +510,7 @@ extern "C" int gi_compact_count(const void* nodes, const void* edges, int in_dty
 extern "C" int gi_compact_fill(const void* nodes, int in_dtype, int B, int N, int Fn, int Fe,
                                const int* gfix, int S, int E, int U, int* u_src, int* in_perm,
                                int* mu_off, int* mu_dst, int* mu_slot, int* out_perm, float* hx0,
-                               int ldhx, int H, int D0, int* d_src, float* cmat, int ldc0,
+                               int ldhx, int H, int D0, int* d_src, float* cmat, int ldc0, int* e2d,
                                void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (!nodes || !gfix || !hx0 || !mu_off || B <= 0 || N <= 0 || S < 0 || E < 0 || U < 0 || U > E)
@@ -469,7 +524,7 @@ extern "C" int gi_compact_fill(const void* nodes, int in_dtype, int B, int N, in
 #define GI_FILL(T_, NMAX_)                                                                         \
     hipLaunchKernelGGL((compact_fill_kernel<T_, NMAX_>), dim3(B), dim3(256), 0, (hipStream_t)stream, \
                        (const T_*)nodes, N, Fn, Fe, gfix, L, S, E, U, u_src, in_perm, mu_off, mu_dst, \
-                       mu_slot, out_perm, hx0, ldhx, H, D0, d_src, cmat, ldc0)
+                       mu_slot, out_perm, hx0, ldhx, H, D0, d_src, cmat, ldc0, e2d)
 #define GI_FILL_N(T_)                                                                              \
     do {                                                                                           \
         if (N <= 32) GI_FILL(T_, 32);                                                              \

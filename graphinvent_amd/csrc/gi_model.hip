@@ -148,7 +148,7 @@ void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
     const gi_ggnn_dims& d = m.d;
     memset(&w, 0, sizeof(w));
     w.R = S + 1; w.E = E; w.U = U; w.B = d.B;
-    w.D0 = (d.kind == GI_KIND_GGNN && d.passes > 0) ? D0 : 0;   // sum aggregation only
+    w.D0 = d.passes > 0 ? D0 : 0;       // pass-0 class rows (both models)
     w.ldhx = gi_r4(d.H + d.Fn); w.ldH = gi_r4(d.H); w.ldM = gi_r4(d.M); w.ld3H = gi_r4(3 * d.H);
     w.ldG = gi_r4(d.G); w.ldA = gi_r4(d.A); w.ldC = gi_r4(d.C); w.ldEh = gi_r4(d.enn_hidden);
     w.ldAtt = gi_r4(d.att_hidden); w.ldEmb = gi_r4(d.emb_hidden); w.ldM1 = gi_r4(d.mlp1_hidden);
@@ -166,8 +166,8 @@ void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
         for (int l = 0; l < d.enn_depth; ++l) w.eact[p][l] = take(Ep, w.ldEh);
         w.m[p] = take(Ep, w.ldM);
         if (attn) {
-            for (int l = 0; l < d.eatt_depth; ++l) w.aact[p][l] = take(Er, w.ldEa);
-            w.een[p] = take(Er, w.ldM);
+            for (int l = 0; l < d.eatt_depth; ++l) w.aact[p][l] = take(Ep, w.ldEa);
+            w.een[p] = take(Ep, w.ldM);
         }
         w.agg[p] = take(R, w.ldM);
         w.gi[p] = take(R, w.ld3H);
@@ -197,10 +197,10 @@ void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
         const long long Ep = (p == 0 && w.D0 > 0) ? D0r : Er;
         for (int l = 0; l < d.enn_depth; ++l) w.edz[p][l] = take(Ep, w.ldEh);
         if (attn)
-            for (int l = 0; l < d.eatt_depth; ++l) w.adz[p][l] = take(Er, w.ldEa);
+            for (int l = 0; l < d.eatt_depth; ++l) w.adz[p][l] = take(Ep, w.ldEa);
         w.dagg[p] = take(R, w.ldM);
     }
-    if (w.D0 > 0) {          // split-K slabs of dm0 = cmat^T . dagg0: ~256 workgroups over the R rows
+    if (w.D0 > 0 && !attn) { // split-K slabs of dm0 = cmat^T . dagg0: ~256 workgroups over the R rows
         const int tiles = gi_cdiv(w.D0, 64) * gi_cdiv(d.M, 64);
         const int kt = gi_cdiv((int)R, 32);
         w.p0split = std::min(std::max(256 / tiles, 1), std::max(1, kt / 2));
@@ -1039,6 +1039,8 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
     Ws w;
     if (gp->D0 < 0 || gp->D0 > U || (gp->D0 > 0 && (!gp->d_src || !gp->cmat || gp->ldc0 < gp->D0)))
         return GI_EINVAL;
+    if (d.kind == GI_KIND_ATTGGNN && gp->D0 > 0 && (!gp->e2d || !gp->cls_off || !gp->cls_edges))
+        return GI_EINVAL;
     make_ws(m, S, E, U, gp->D0, w);
     Run r{(hipStream_t)stream, params, 0};
     const int R = w.R;
@@ -1078,14 +1080,18 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
         if (attn) {
             // AttentionGGNN.aggregate_message (gnn/mpnn.py:370-389): message and energy MLPs of the
             // edge's bond type on h_src(e), softmax over each node's incoming edges, weighted sum
+            // pass 0 (h = [x | 0]): both MLP families on the D0 (feature class, bond type) rows, the
+            // softmax reads them through the edge -> pass-0 row index
+            const bool p0 = p == 0 && w.D0 > 0;
             if (E > 0) {
                 EdgeChain ch[2] = {
                     {m.msg, w.eact[p], w.edz[p], w.ldEh, ws + w.m[p], w.ldM, nullptr},
                     {m.eatt, w.aact[p], w.adz[p], w.ldEa, ws + w.een[p], w.ldM, nullptr}};
-                edge_chains_forward(r, ws, ch, 2, bytype, hx, w.ldhx, u_src, U);
+                if (p0) edge_chains_forward(r, ws, ch, 2, bytype0, hx, w.ldhx, gp->d_src, w.D0);
+                else edge_chains_forward(r, ws, ch, 2, bytype, hx, w.ldhx, u_src, U);
             }
-            r.chk(gi_seg_softmax_fwd(ws + w.een[p], ws + w.m[p], w.ldM, in_perm, seg_off, R, d.M,
-                                     ws + w.agg[p], w.ldM, r.st));
+            r.chk(gi_seg_softmax_fwd(ws + w.een[p], ws + w.m[p], w.ldM, p0 ? gp->e2d : in_perm, seg_off,
+                                     R, d.M, ws + w.agg[p], w.ldM, r.st));
         } else if (p == 0 && w.D0 > 0) {
             // pass 0: h = [x | 0], one message row per (feature class, bond type); a_v = cmat . m0
             mlp_forward(r, ws, m.msg, bytype0, hx, w.ldhx, gp->d_src, w.D0, w.eact[0], w.ldEh,
@@ -1236,6 +1242,8 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
     Ws w;
     if (gp->D0 < 0 || gp->D0 > U || (gp->D0 > 0 && (!gp->d_src || !gp->cmat || gp->ldc0 < gp->D0)))
         return GI_EINVAL;
+    if (d.kind == GI_KIND_ATTGGNN && gp->D0 > 0 && (!gp->e2d || !gp->cls_off || !gp->cls_edges))
+        return GI_EINVAL;
     make_ws(m, S, E, U, gp->D0, w);
     SlabPlan sp;
     plan_slabs(m, S, U, Ut, sp);
@@ -1378,18 +1386,27 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
         if (E > 0 && attn) {
             // backward of the softmax-weighted aggregation: per-edge contributions, then per message
             // row their sum times the SELU derivative of both stacks' last layer (in place)
-            r.chk(gi_seg_softmax_bwd(ws + w.een[p], ws + w.m[p], w.ldM, in_perm, seg_off, R, d.M,
-                                     dagg, w.ldM, ws + w.tmp_en, ws + w.tmp_emb, w.ldM, r.st));
-            r.chk(gi_seg_sum_dselu(ws + w.tmp_emb, w.ldM, mu_slot, mu_off, U, d.M, ws + w.m[p],
-                                   w.ldM, r.st));
-            r.chk(gi_seg_sum_dselu(ws + w.tmp_en, w.ldM, mu_slot, mu_off, U, d.M, ws + w.een[p],
-                                   w.ldM, r.st));
+            const bool p0 = p == 0 && w.D0 > 0;      // pass 0 ran on the class rows
+            r.chk(gi_seg_softmax_bwd(ws + w.een[p], ws + w.m[p], w.ldM, p0 ? gp->e2d : in_perm, seg_off,
+                                     R, d.M, dagg, w.ldM, ws + w.tmp_en, ws + w.tmp_emb, w.ldM, r.st));
             EdgeChain ch[2] = {
                 {m.msg, w.eact[p], w.edz[p], w.ldEh, ws + w.m[p], w.ldM, p > 0 ? ws + w.dxe : nullptr},
                 {m.eatt, w.aact[p], w.adz[p], w.ldEa, ws + w.een[p], w.ldM,
                  p > 0 ? ws + w.dxa : nullptr}};
-            edge_chains_backward(r, ws, sp, slabs, dq, ch, 2, bytype, hx, w.ldhx, u_src, U, w.ldH,
-                                 d.H);
+            if (p0) {   // per class row: sum over its (hundreds of) edge slots, both stacks in one launch
+                r.chk(gi_class_sum_dselu(ws + w.tmp_emb, ws + w.tmp_en, w.ldM, gp->cls_edges,
+                                         gp->cls_off, w.D0, d.M, ws + w.m[p], ws + w.een[p], w.ldM,
+                                         r.st));
+                edge_chains_backward(r, ws, sp, slabs, dq, ch, 2, bytype0, hx, w.ldhx, gp->d_src, w.D0,
+                                     w.ldH, d.H);
+            } else {
+                r.chk(gi_seg_sum_dselu(ws + w.tmp_emb, w.ldM, mu_slot, mu_off, U, d.M, ws + w.m[p],
+                                       w.ldM, r.st));
+                r.chk(gi_seg_sum_dselu(ws + w.tmp_en, w.ldM, mu_slot, mu_off, U, d.M, ws + w.een[p],
+                                       w.ldM, r.st));
+                edge_chains_backward(r, ws, sp, slabs, dq, ch, 2, bytype, hx, w.ldhx, u_src, U, w.ldH,
+                                     d.H);
+            }
             if (p > 0) {
                 r.chk(gi_seg_sum(ws + w.dxe, w.ldH, out_perm, src_off, R, d.H, dh2, w.ldH, 1, r.st));
                 r.chk(gi_seg_sum(ws + w.dxa, w.ldH, out_perm, src_off, R, d.H, dh2, w.ldH, 1, r.st));

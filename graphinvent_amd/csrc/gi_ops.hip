@@ -367,6 +367,42 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const ColsumTable tab) {
     }
 }
 
+// y[d, c] = selu'(y[d, c]) * sum_{k in [off[d], off[d+1])} vals[idx[k], c]   — long segments (hundreds of
+// rows per output row): one workgroup per (output row, 64 columns), 16 row groups, fixed tree.
+// blockIdx.z selects one of two problems (the message and the energy stack share one launch).
+struct ClassSumArgs {
+    const float* vals[2]; float* y[2];
+    int ldv, ldy, cols;
+    const int* idx; const int* off;
+};
+
+__global__ __launch_bounds__(1024) void class_sum_dselu_kernel(const ClassSumArgs a) {
+    __shared__ float red[16][64];
+    const float* __restrict__ vals = a.vals[blockIdx.z];
+    float* y = a.y[blockIdx.z];
+    const int d = blockIdx.x, cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const int lo = a.off[d], hi = a.off[d + 1];
+    float a0 = 0.f, a1 = 0.f;
+    if (c < a.cols) {
+        int k = lo + rg;
+        for (; k + 16 < hi; k += 32) {                       // two loads in flight; fixed order
+            a0 += vals[(long long)a.idx[k] * a.ldv + c];
+            a1 += vals[(long long)a.idx[k + 16] * a.ldv + c];
+        }
+        if (k < hi) a0 += vals[(long long)a.idx[k] * a.ldv + c];
+    }
+    red[rg][cl] = a0 + a1;
+    __syncthreads();
+    if (rg == 0 && c < a.cols) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += red[i][cl];
+        float* dst = y + (long long)d * a.ldy + c;
+        *dst = s * gi_selu_grad(*dst);
+    }
+}
+
 // ---- batched matrix transpose (weight copies for dgrad) --------------------------------------------
 #define GI_TRANSPOSE_MAX 40
 struct TransposeTable { gi_transpose_desc d[GI_TRANSPOSE_MAX]; int start[GI_TRANSPOSE_MAX + 1]; int n; };
@@ -633,6 +669,20 @@ extern "C" int gi_seg_sum_dselu(const float* vals, int ldv, const int* perm, con
     GiProfScope prof((hipStream_t)stream, GI_PROF_SEGSUM, 0.0);
     hipLaunchKernelGGL(seg_sum_dselu_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, vals, ldv, perm, off, rows, c4n, y, ldy);
+    return gi_launch_status();
+}
+
+extern "C" int gi_class_sum_dselu(const float* vals0, const float* vals1, int ldv, const int* idx,
+                                  const int* off, int rows, int cols, float* y0, float* y1, int ldy,
+                                  void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
+    if (rows <= 0 || cols <= 0) return 0;
+    if (!vals0 || !y0 || !idx || !off || ldv < cols || ldy < cols || (vals1 && !y1)) return GI_EINVAL;
+    ClassSumArgs a;
+    a.vals[0] = vals0; a.vals[1] = vals1; a.y[0] = y0; a.y[1] = y1;
+    a.ldv = ldv; a.ldy = ldy; a.cols = cols; a.idx = idx; a.off = off;
+    hipLaunchKernelGGL(class_sum_dselu_kernel, dim3(rows, (cols + 63) / 64, vals1 ? 2 : 1), dim3(1024), 0,
+                       (hipStream_t)stream, a);
     return gi_launch_status();
 }
 

@@ -63,8 +63,9 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN):
     (dims, CompactGraph, workspace, per-type edge counts) is what backward consumes."""
     lib = _L.load()
     nodes, lay, gfix, S, E, U, D0, Ut = _ops.compact_count(nodes, edges)
-    if kind != _L.KIND_GGNN:
-        D0 = 0                          # the pass-0 shortcut needs a linear (sum) aggregation
+    attn = kind != _L.KIND_GGNN
+    if attn and _os_environ_flag("GI_ATT_PASS0", "1") == "0":
+        D0 = 0                          # AttentionGGNN's pass 0 on message rows (measurement knob)
     B = nodes.shape[0]
     dims = _dims_from_constants(consts, B, kind)
     if lib.gi_ggnn_num_params(C.byref(dims)) != len(params):
@@ -80,7 +81,7 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN):
     ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
     ldhx = lib.gi_ggnn_ldhx(C.byref(dims))
     hx0 = ws[lib.gi_ggnn_hx0_offset(C.byref(dims), S, E, U, D0):]
-    graph = _ops.compact_fill(nodes, lay, gfix, S, E, U, D0, Ut, hx0, ldhx, dims.H)
+    graph = _ops.compact_fill(nodes, lay, gfix, S, E, U, D0, Ut, hx0, ldhx, dims.H, class_csr=attn)
     apd = dims.N * dims.A + dims.N * dims.C + 1
     out = torch.empty((B, apd), dtype=torch.float32, device=dev)
     gs = graph.c_struct()

@@ -27,7 +27,7 @@ EPI_BIAS, EPI_SELU, EPI_DSELU, EPI_ACCUM, GEMM_SPLITK = 1, 2, 4, 8, 16
 KIND_GGNN, KIND_ATTGGNN = 0, 1
 BWD_ALL, BWD_READOUT, BWD_PASSES = 0, 1, 2
 COUNTS = 24          # GI_COUNTS
-ABI_VERSION = 4      # GI_ABI_VERSION
+ABI_VERSION = 5      # GI_ABI_VERSION
 DTYPE_F32, DTYPE_I8 = 0, 1
 
 vp = C.c_void_p
@@ -82,7 +82,8 @@ class Graph(C.Structure):
     """gi_graph: the compacted graph as the fused model calls take it."""
     _fields_ = [("S", ci), ("E", ci), ("U", ci), ("gfix", vp), ("u_src", vp), ("in_perm", vp),
                 ("mu_off", vp), ("mu_dst", vp), ("mu_slot", vp), ("out_perm", vp),
-                ("Ut", C.POINTER(ci)), ("D0", ci), ("ldc0", ci), ("d_src", vp), ("cmat", vp)]
+                ("Ut", C.POINTER(ci)), ("D0", ci), ("ldc0", ci), ("d_src", vp), ("cmat", vp),
+                ("e2d", vp), ("cls_off", vp), ("cls_edges", vp)]
 
 
 class GgnnDims(C.Structure):
@@ -99,7 +100,9 @@ SIGNATURES = {
     "gi_compact_layout": (ci, [ci, ci, ci, C.POINTER(CompactLayout)]),
     "gi_compact_count": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp]),
     "gi_compact_fill": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci,
-                             ci, ci, vp, vp, ci, vp]),
+                             ci, ci, vp, vp, ci, vp, vp]),
+    "gi_compact_class_csr": (ci, [vp, ci, ci, vp, vp, vp]),
+    "gi_class_sum_dselu": (ci, [vp, vp, ci, vp, vp, ci, ci, vp, vp, ci, vp]),
     "gi_gemm": (ci, [C.POINTER(GemmParams), vp]),
     "gi_gemm_batch": (ci, [C.POINTER(GemmParams), ci, vp]),
     "gi_mlp_chain": (ci, [C.POINTER(ChainParams), ci, vp]),

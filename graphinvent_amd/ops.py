@@ -66,6 +66,7 @@ class CompactGraph:
     gfix: torch.Tensor          # int32, fixed-size part (see include/graphinvent_amd.h)
     gvar: torch.Tensor          # int32, variable-size part: u_src | in_perm | mu_off | mu_dst | mu_slot | out_perm | d_src
     cmat: Optional[torch.Tensor] = None   # fp32 [S+1, ldc0] pass-0 edge-count matrix
+    class_csr: bool = False               # e2d / cls_off / cls_edges are filled (AttentionGGNN pass 0)
 
     def view(self, name: str, n: int) -> torch.Tensor:
         o = getattr(self.layout, name)
@@ -93,6 +94,12 @@ class CompactGraph:
     @property
     def d_src(self): return self._var(6, self.D0)
     @property
+    def e2d(self): return self._var(7, self.E)
+    @property
+    def cls_off(self): return self._var(8, self.D0 + 1)
+    @property
+    def cls_edges(self): return self._var(9, self.E)
+    @property
     def type_off0(self): return self.view("type_off0", self.Fe + 1)
     @property
     def cidx(self): return self.view("cidx", self.B * self.N)
@@ -114,7 +121,9 @@ class CompactGraph:
         g.gfix = self.gfix.data_ptr()
         base, offs = self.gvar.data_ptr(), self._offs
         (g.u_src, g.in_perm, g.mu_off, g.mu_dst, g.mu_slot, g.out_perm,
-         g.d_src) = (base + 4 * o for o in offs)
+         g.d_src) = (base + 4 * o for o in offs[:7])
+        if self.class_csr and self.D0 > 0:
+            g.e2d, g.cls_off, g.cls_edges = (base + 4 * o for o in offs[7:10])
         g.D0 = self.D0
         g.ldc0 = r4(self.D0)
         g.cmat = self.cmat.data_ptr() if self.D0 > 0 else None
@@ -125,8 +134,9 @@ class CompactGraph:
 
 def _gvar_offsets(E: int, U: int, D0: int = 0):
     """Offsets (ints, 16-byte aligned) of u_src[U], in_perm[E], mu_off[U+1], mu_dst[E], mu_slot[E],
-    out_perm[U], d_src[D0] inside the variable-size index buffer, and its total length."""
-    sizes = (U, E, U + 1, E, E, U, D0)
+    out_perm[U], d_src[D0], e2d[E], cls_off[D0+1], cls_edges[E] inside the variable-size index buffer,
+    and its total length (the last three are filled only for AttentionGGNN's pass 0)."""
+    sizes = (U, E, U + 1, E, E, U, D0, E, D0 + 1, E)        # + e2d[E], cls_off[D0+1], cls_edges[E]
     offs, o = [], 0
     for n in sizes:
         offs.append(o)
@@ -239,7 +249,7 @@ def compact_count(nodes: torch.Tensor, edges: torch.Tensor):
 
 
 def compact_fill(nodes, lay, gfix, S, E, U, D0, Ut, hx0: torch.Tensor, ldhx: int,
-                 H: int) -> CompactGraph:
+                 H: int, class_csr: bool = False) -> CompactGraph:
     lib = L.load()
     B, N, Fn = nodes.shape
     Fe = len(Ut)
@@ -250,18 +260,22 @@ def compact_fill(nodes, lay, gfix, S, E, U, D0, Ut, hx0: torch.Tensor, ldhx: int
     dt = L.DTYPE_I8 if nodes.dtype == torch.int8 else L.DTYPE_F32
     base = gvar.data_ptr()
     ptrs = [base + 4 * o for o in offs]
+    class_csr = bool(class_csr and D0 > 0 and E > 0)
     L.check(lib.gi_compact_fill(nodes.data_ptr(), dt, B, N, Fn, Fe, gfix.data_ptr(), S, E, U,
                                 *ptrs[:6], hx0.data_ptr(), ldhx, H, D0, ptrs[6], _ptr(cmat), ldc0,
-                                _stream()), "gi_compact_fill")
-    return CompactGraph(B, N, Fn, Fe, S, E, U, D0, list(Ut), lay, gfix, gvar, cmat)
+                                ptrs[7] if class_csr else None, _stream()), "gi_compact_fill")
+    if class_csr:        # pass-0 row -> edge slots CSR (AttentionGGNN's pass-0 backward)
+        L.check(lib.gi_compact_class_csr(ptrs[7], E, D0, ptrs[8], ptrs[9], _stream()),
+                "gi_compact_class_csr")
+    return CompactGraph(B, N, Fn, Fe, S, E, U, D0, list(Ut), lay, gfix, gvar, cmat, class_csr)
 
 
-def compact(nodes: torch.Tensor, edges: torch.Tensor, H: int):
+def compact(nodes: torch.Tensor, edges: torch.Tensor, H: int, class_csr: bool = False):
     """Both phases; returns (CompactGraph, hx0[S+1, ldhx])."""
     nodes, lay, gfix, S, E, U, D0, Ut = compact_count(nodes, edges)
     ldhx = r4(H + nodes.shape[2])
     hx0 = torch.empty((S + 1, ldhx), dtype=torch.float32, device=nodes.device)
-    g = compact_fill(nodes, lay, gfix, S, E, U, D0, Ut, hx0, ldhx, H)
+    g = compact_fill(nodes, lay, gfix, S, E, U, D0, Ut, hx0, ldhx, H, class_csr)
     return g, hx0
 
 
@@ -318,7 +332,7 @@ def ws_view(ws: torch.Tensor, dims, graph: "CompactGraph", name: str, rows: int,
             j: int = 0):
     """Test/debug: a [rows, ld] view of a named workspace buffer (gi_ggnn_ws_query)."""
     off, ld = C.c_longlong(), C.c_int()
-    D0 = graph.D0 if dims.kind == L.KIND_GGNN else 0
+    D0 = graph.D0
     L.check(L.load().gi_ggnn_ws_query(C.byref(dims), graph.S, graph.E, graph.U, D0, name.encode(), i,
                                       j, C.byref(off),
                                       C.byref(ld)), f"gi_ggnn_ws_query({name})")

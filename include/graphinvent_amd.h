@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GI_ABI_VERSION 4
+#define GI_ABI_VERSION 5
 #define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
 #define GI_MAX_NODES 128      /* max max_n_nodes */
 #define GI_P0_MAX_CLASSES 256 /* max distinct node feature rows for the pass-0 shortcut */
@@ -88,7 +88,12 @@ int gi_compact_count(const void* nodes, const void* edges, int in_dtype, int B, 
 int gi_compact_fill(const void* nodes, int in_dtype, int B, int N, int Fn, int Fe, const int* gfix,
                     int S, int E, int U, int* u_src, int* in_perm, int* mu_off, int* mu_dst,
                     int* mu_slot, int* out_perm, float* hx0, int ldhx, int H, int D0, int* d_src,
-                    float* cmat, int ldc0, void* stream);
+                    float* cmat, int ldc0, int* e2d, void* stream);
+/* AttentionGGNN's pass 0 on the D0 class rows: e2d[E] (written by gi_compact_fill when non-NULL and
+ * D0 > 0) = dst-CSR edge slot -> pass-0 row, the index the segment softmax reads its rows through;
+ * gi_compact_class_csr turns it into the CSR pass-0 row -> its edge slots (cls_off[D0+1],
+ * cls_edges[E], slots ascending: fixed summation order) over which the softmax backward is summed. */
+int gi_compact_class_csr(const int* e2d, int E, int D0, int* cls_off, int* cls_edges, void* stream);
 
 /* The compacted graph as the fused model calls take it. */
 typedef struct gi_graph {
@@ -100,6 +105,9 @@ typedef struct gi_graph {
     int D0, ldc0;             /* pass-0 rows (0 = shortcut off) and leading dimension of cmat */
     const int* d_src;         /* [D0] */
     const float* cmat;        /* [S+1, ldc0] */
+    const int* e2d;           /* [E]    AttentionGGNN pass 0 (NULL: that pass runs on message rows) */
+    const int* cls_off;       /* [D0+1] */
+    const int* cls_edges;     /* [E] */
 } gi_graph;
 
 /* ------------------------------------------------------------------------------------------
@@ -205,6 +213,10 @@ int gi_seg_sum_dselu(const float* vals, int ldv, const int* perm, const int* off
 
 /* y[r, c] = selu'(y[r, c]) * sum_{s < nsplit} slabs[s * stride + r * ld + c]: sums the split-K slabs
  * of the pass-0 aggregation backward (cmat^T . d agg) with the SELU backward folded in. */
+/* y_i[d, c] = selu'(y_i[d, c]) * sum_{k in [off[d], off[d+1])} vals_i[idx[k], c] for i = 0 (and 1 when
+ * vals1 != NULL): the per-row sums of AttentionGGNN's pass-0 softmax backward (long segments). */
+int gi_class_sum_dselu(const float* vals0, const float* vals1, int ldv, const int* idx, const int* off,
+                       int rows, int cols, float* y0, float* y1, int ldy, void* stream);
 int gi_slab_sum_dselu(const float* slabs, int nsplit, long long stride, int rows, int cols, int ld,
                       float* y, int ldy, void* stream);
 

@@ -67,14 +67,14 @@ def signs_from_hip(dims, graph, ws, out, attn: bool) -> Signs:
         return (ops.ws_view(ws, dims, graph, name, rows, i, j)[:, :width] > 0).cpu()
 
     for p in range(dims.passes):
-        p0 = (p == 0 and not attn and graph.D0 > 0)
+        p0 = (p == 0 and graph.D0 > 0)                  # pass 0 runs on the class rows (both models)
         rows = graph.D0 if p0 else U
         s.p0.append(p0)
         s.msg.append([view("eact", rows, dims.enn_hidden, p, l) for l in range(dims.enn_depth)] +
                      [view("m", rows, dims.M, p)])
         if attn:
-            s.eatt.append([view("aact", U, dims.eatt_hidden, p, l) for l in range(dims.eatt_depth)] +
-                          [view("een", U, dims.M, p)])
+            s.eatt.append([view("aact", rows, dims.eatt_hidden, p, l) for l in range(dims.eatt_depth)] +
+                          [view("een", rows, dims.M, p)])
     for name, act, last, depth, hid, width in (
             ("gather.att_nn", "att_act", "en", dims.att_depth, dims.att_hidden, dims.G),
             ("gather.emb_nn", "emb_act", "emb", dims.emb_depth, dims.emb_hidden, dims.G),
@@ -157,7 +157,7 @@ class OraclePins:
             t = int(prefix.split(".")[1])
             p = call
             src = self.s.msg if prefix.startswith("msg_nns.") else self.s.eatt
-            rowmap = self.edge_row0 if (self.s.p0[p] and src is self.s.msg) else self.edge_row
+            rowmap = self.edge_row0 if self.s.p0[p] else self.edge_row
             hip = src[p][layer][rowmap]                    # [E, width] in the oracle's edge order
             is_t = torch.from_numpy(self.etype == t)
             if self.model == "AttGGNN":                    # x: [V, maxdeg, width]

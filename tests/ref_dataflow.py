@@ -25,6 +25,11 @@ SELU_SCALE = 1.0507009873554804934193349852946
 # graph_compact  (integer work: bit-exact reference for gi_compact_*)
 # ---------------------------------------------------------------------------------------------
 P0_MAX = 256     # GI_P0_MAX_CLASSES
+ATT_PASS0 = True                 # AttentionGGNN's pass 0 on class rows too (tests may switch it off)
+
+
+def P0_ATT_OK(attn: bool) -> bool:
+    return (not attn) or ATT_PASS0
 
 
 def compact(nodes: np.ndarray, edges: np.ndarray) -> Dict[str, np.ndarray]:
@@ -109,7 +114,15 @@ def compact(nodes: np.ndarray, edges: np.ndarray) -> Dict[str, np.ndarray]:
             d_src = cidx[rep].astype(np.int32)
             cmat = np.zeros((R, D0), dtype=np.float32)
             np.add.at(cmat, (dst_c, u2d[in_perm]), 1.0)
+            # AttentionGGNN's pass 0: dst-CSR edge slot -> pass-0 row, and the pass-0 row -> edge slots
+            # CSR (slots ascending) over which the softmax backward is summed per row
+            e2d = u2d[in_perm].astype(np.int32)
+            cls_edges = np.argsort(e2d, kind="stable").astype(np.int32)
+            cls_off = np.concatenate([[0], np.cumsum(np.bincount(e2d, minlength=D0))]).astype(np.int32)
+    if D0 == 0:
+        e2d, cls_edges, cls_off = (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(1, np.int32))
     return dict(S=S, E=E, U=U, D0=D0, d_src=d_src, type_off0=type_off0, cmat=cmat,
+                e2d=e2d, cls_off=cls_off, cls_edges=cls_edges,
                 err=err, cidx=cidx, slot_of=slot_of, u_src=u_src,
                 in_perm=in_perm.astype(np.int32), seg_off=seg_off, mu_off=mu_off, mu_dst=mu_dst,
                 mu_slot=mu_slot, out_perm=out_perm, src_off=src_off, type_off=type_off,
@@ -290,7 +303,9 @@ def forward(P, cfg, nodes, edges, keep=False, model="GGNN"):
     tape = dict(g=g, T=T, x=x, has_edge=has_edge, passes=[])
     for pi in range(cfg["message_passes"]):
         # pass 0 of the sum-aggregating model runs on the D0 (feature class, bond type) rows
-        p0 = pi == 0 and not attn and g["D0"] > 0
+        # pass 0 runs on the D0 (feature class, bond type) rows: h = [x | 0], so a message row depends
+        # only on its source's feature class and the bond type (both models)
+        p0 = pi == 0 and g["D0"] > 0 and P0_ATT_OK(attn)
         rows, toff, src = (g["D0"], g["type_off0"], T["d_src"]) if p0 else (U, g["type_off"], T["u_src"])
         acts_t = []
         m = torch.zeros(rows, M, dtype=dtype)        # one row per (source node | class, bond type)
@@ -302,14 +317,15 @@ def forward(P, cfg, nodes, edges, keep=False, model="GGNN"):
         ps_extra = dict(p0=p0)
         if attn:      # second per-bond-type MLP gives the attention energies
             aacts_t = []
-            en_e = torch.zeros(U, M, dtype=dtype)
+            en_e = torch.zeros(rows, M, dtype=dtype)
             for t in range(Fe):
-                lo, hi = int(g["type_off"][t]), int(g["type_off"][t + 1])
-                a = mlp_fwd(P, f"att_nns.{t}", h, idx=T["u_src"][lo:hi].long())
+                lo, hi = int(toff[t]), int(toff[t + 1])
+                a = mlp_fwd(P, f"att_nns.{t}", h, idx=src[lo:hi].long())
                 aacts_t.append(a)
                 en_e[lo:hi] = a[-1]
-            agg, att_e = seg_softmax_sum(en_e, m, T["in_perm"], T["seg_off"], R)
-            ps_extra = dict(p0=False, aacts_t=aacts_t, en_e=en_e, att_e=att_e)
+            perm = T["e2d"] if p0 else T["in_perm"]           # edge slot -> row of m / en_e
+            agg, att_e = seg_softmax_sum(en_e, m, perm, T["seg_off"], R)
+            ps_extra = dict(p0=p0, aacts_t=aacts_t, en_e=en_e, att_e=att_e)
         elif p0:
             agg = T["cmat"].to(dtype) @ m                # edge-count matrix [R, D0]
         else:
@@ -383,6 +399,20 @@ def backward(P, cfg, tape, d_out) -> Dict[str, torch.Tensor]:
         dagg = dgi @ P["gru.weight_ih"]
         dh_prev = dh_prev + dgh @ P["gru.weight_hh"]
         U = g["U"]
+        if ps["p0"] and tape["attn"]:
+            den, demb = seg_softmax_sum_bwd(dagg, ps["att_e"], ps["en_e"], ps["m"], T["e2d"],
+                                            T["seg_off"], R)
+            D0 = g["D0"]
+            dm = seg_sum(demb, T["cls_edges"], T["cls_off"], D0) * selu_grad_from_out(ps["m"])
+            da = seg_sum(den, T["cls_edges"], T["cls_off"], D0) * selu_grad_from_out(ps["en_e"])
+            for t in range(Fe):
+                lo, hi = int(g["type_off0"][t]), int(g["type_off0"][t + 1])
+                mlp_bwd(P, f"att_nns.{t}", ps["h_prev"], ps["aacts_t"][t], da[lo:hi], grads,
+                        idx=T["d_src"][lo:hi].long(), need_dx=False)
+                mlp_bwd(P, f"msg_nns.{t}", ps["h_prev"], ps["acts_t"][t], dm[lo:hi], grads,
+                        idx=T["d_src"][lo:hi].long(), need_dx=False)
+            dh = dh_prev
+            continue
         if ps["p0"]:
             dm = (T["cmat"].to(d_out.dtype).t() @ dagg) * selu_grad_from_out(ps["m"])
             for t in range(Fe):

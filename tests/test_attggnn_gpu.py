@@ -173,17 +173,19 @@ def test_full_dims_logits_and_branch_pinned_gradients(shape, B, over):
     out64, tape = D.forward(P64, cfg, t64(n8), t64(e8), keep=True, model=MODEL)
     assert rel(out, out64) < TOL
     pins = {}
-    toff = graph.type_off.cpu().tolist()
+    assert graph.D0 == tape["g"]["D0"] > 0 and tape["passes"][0]["p0"]     # pass 0 on the class rows
     for p, ps in enumerate(tape["passes"]):
+        rows = graph.D0 if ps["p0"] else U
+        toff = (graph.type_off0 if ps["p0"] else graph.type_off).cpu().tolist()
         assert rel(view("agg", R, p)[:, :dims.M], ps["agg"]) < TOL, f"agg[{p}]"
         for key, name, depth in (("acts_t", "eact", dims.enn_depth), ("aacts_t", "aact", dims.eatt_depth)):
             for l in range(depth):
-                hv = view(name, U, p, l)
+                hv = view(name, rows, p, l)
                 for t in range(dims.Fe):
                     a = ps[key][t][l]
                     pins[id(a)] = hv[toff[t]:toff[t + 1], :a.shape[1]] > 0
-        pins[id(ps["m"])] = view("m", U, p)[:, :dims.M] > 0
-        pins[id(ps["en_e"])] = view("een", U, p)[:, :dims.M] > 0
+        pins[id(ps["m"])] = view("m", rows, p)[:, :dims.M] > 0
+        pins[id(ps["en_e"])] = view("een", rows, p)[:, :dims.M] > 0
     for key, act_name, out_name, depth in (("att_acts", "att_act", "en", dims.att_depth),
                                            ("emb_acts", "emb_act", "emb", dims.emb_depth),
                                            ("add1", "add1_act", "add1", dims.mlp1_depth),

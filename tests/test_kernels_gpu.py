@@ -25,7 +25,8 @@ def rel(a, b):
 # ------------------------------------------------------------------------------------------------
 def _compact_case(n8, e8, H=16):
     ref = D.compact(n8, e8)
-    g, hx0 = ops.compact(torch.from_numpy(n8).float().to(DEV), torch.from_numpy(e8).float().to(DEV), H)
+    g, hx0 = ops.compact(torch.from_numpy(n8).float().to(DEV), torch.from_numpy(e8).float().to(DEV), H,
+                         class_csr=True)
     assert (g.S, g.E, g.U) == (ref["S"], ref["E"], ref["U"])
     assert list(g.Ut) == np.diff(ref["type_off"]).tolist()
     for name in ("cidx", "slot_of", "u_src", "in_perm", "mu_off", "mu_dst", "mu_slot", "out_perm",
@@ -41,6 +42,10 @@ def _compact_case(n8, e8, H=16):
         assert np.array_equal(g.d_src.cpu().numpy(), ref["d_src"])
         assert np.array_equal(g.cmat.cpu().numpy()[:, :g.D0], ref["cmat"])
         assert float(g.cmat.sum()) == g.E
+        # AttentionGGNN's pass 0: edge slot -> pass-0 row, and the row -> edge slots CSR (stable order)
+        assert g.class_csr
+        for name in ("e2d", "cls_off", "cls_edges"):
+            assert np.array_equal(getattr(g, name).cpu().numpy(), ref[name]), name
     assert np.array_equal(g.node_mask.cpu().numpy(), ref["node_mask"].astype(np.int32))
     B, N, Fn = n8.shape
     x = np.zeros((g.S + 1, hx0.shape[1]), dtype=np.float32)
@@ -283,6 +288,34 @@ def test_gru_fused_limits_are_reported():
     off = torch.zeros(10, dtype=torch.int32, device=DEV)
     with pytest.raises(RuntimeError, match="GI_ELIMIT"):
         ops.gru_fused_fwd(z, off, off, z, False, z, z, z, z, z, z, z, z, 8, 129, 100)
+
+
+def test_class_sum_dselu_long_segments():
+    """gi_class_sum_dselu: per output row the sum of hundreds of indexed rows, times selu'(y), two
+    problems in one launch, run-to-run bit identical (fixed tree)."""
+    g = torch.Generator().manual_seed(3)
+    E, D0, M = 5000, 37, 100
+    ld = ops.r4(M)
+    cls = torch.randint(0, D0, (E,), generator=g)
+    cls[cls == 5] = 6                                        # an empty segment
+    idx = torch.argsort(cls, stable=True).int()
+    off = torch.cat([torch.zeros(1, dtype=torch.long), torch.bincount(cls, minlength=D0).cumsum(0)]).int()
+    v0, v1 = torch.randn(E, ld, generator=g), torch.randn(E, ld, generator=g)
+    y0, y1 = D.selu(torch.randn(D0, ld, generator=g)), D.selu(torch.randn(D0, ld, generator=g))
+    outs = []
+    v0d, v1d, idxd, offd = v0.to(DEV), v1.to(DEV), idx.to(DEV), off.to(DEV)
+    for _ in range(2):
+        a, b = y0.clone().to(DEV), y1.clone().to(DEV)
+        L.check(L.load().gi_class_sum_dselu(v0d.data_ptr(), v1d.data_ptr(), ld, idxd.data_ptr(),
+                                            offd.data_ptr(), D0, M, a.data_ptr(), b.data_ptr(), ld,
+                                            torch.cuda.current_stream().cuda_stream), "class_sum")
+        torch.cuda.synchronize()
+        outs.append((a.cpu(), b.cpu()))
+    for got, v, y in ((outs[0][0], v0, y0), (outs[0][1], v1, y1)):
+        ref = D.seg_sum(v[:, :M].double(), idx, off, D0) * D.selu_grad_from_out(y[:, :M].double())
+        assert rel(got[:, :M], ref) < 1e-5
+        assert torch.equal(got[:, M:], y[:, M:])
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 def test_mlp_chain_limits_are_reported():
