@@ -30,6 +30,7 @@
 #include "gi_common.h"
 
 #include "gi_mfma.h"
+#include <type_traits>
 
 __device__ float gi_store_sink[256];               // where out-of-range lanes of edge tiles store
 
@@ -152,7 +153,12 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
             }
         }
     };
-    auto gload_b = [&](v4f (&rb)[NB], int k0) {
+    // BIDX (compile time): rows of a major B gathered through b_idx.  The index load is a dependent
+    // load in front of the data load (it drains the load queue once per tile), so the body exists
+    // twice and only the gathered problems (first layer of the message stacks' weight gradients)
+    // run the BIDX version.
+    auto gload_b = [&](v4f (&rb)[NB], int k0, auto bidx) {
+        constexpr bool BIDX = decltype(bidx)::value;
         if (!B_MAJOR) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) rb[i] = gi_load4_raw(Bp + b_off[i], k0 + 4 * cc4, b_cmax);
@@ -160,17 +166,17 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int red = min(k0 + b_mr + i * B_RP, k_end - 1);
-                const long long srow = p.b_idx ? p.b_idx[red] : red;
+                const long long srow = BIDX ? p.b_idx[red] : red;
                 rb[i] = gi_load4_raw(Bp + srow * p.ldb, n0 + 4 * b_mc4, b_cmax);
             }
         }
     };
 
     // (fix-up of the last / padding k tile) + LDS write, A half and B half
-    auto sstore_a = [&](v4f (&ra)[NA], int buf, int k0) {
+    auto sstore_a = [&](v4f (&ra)[NA], int buf, int k0, const bool steady) {
         float* a = As + buf * A_SZ;
         const bool full_k = k0 + BK <= k_end;        // block-uniform
-        if (full_k && a_fast) {
+        if (steady || (full_k && a_fast)) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 if (!A_MAJOR) *(v4f*)&a[(crow + 32 * i) * A_LD + 4 * cc4] = ra[i];
@@ -190,10 +196,10 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
             }
         }
     };
-    auto sstore_b = [&](v4f (&rb)[NB], int buf, int k0) {
+    auto sstore_b = [&](v4f (&rb)[NB], int buf, int k0, const bool steady) {
         float* b = Bs + buf * B_SZ;
         const bool full_k = k0 + BK <= k_end;
-        if (full_k && b_fast) {
+        if (steady || (full_k && b_fast)) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 if (!B_MAJOR) {
@@ -283,36 +289,59 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
     //   - the LDS writes of tile t+1 (loaded during tile t-1) into the other LDS buffer,
     // i.e. every memory instruction sits in the shadow of a 64-cycle MFMA.  The tile count is
     // rounded up to even (a tile past k_end stages zeros) so the two-stage body has no mid exit.
+    //
+    // STEADY = true is the straight-line body for the tiles whose successors are full in k: loads
+    // (clamped, always readable) and LDS writes are unconditional, so the body is ONE basic block
+    // and hipcc's wait-count pass can keep tile t+2's four loads in flight across the LDS write of
+    // tile t+1 (s_waitcnt vmcnt(6) / vmcnt(4)).  With the run-time `more` / partial-tile branches of
+    // the generic body it merges the states of both arms and emits vmcnt(0) before every LDS write
+    // — each tile then waits out the L2 latency of loads issued two MFMA groups earlier (0.70 us per
+    // tile for a lone workgroup against 0.43 us of MFMA work).  The generic body only runs the
+    // last one or two tile pairs (partial / padding tiles).
     const int nk = (k_end > k_begin) ? (((k_end - k_begin + BK - 1) / BK + 1) & ~1) : 0;
     float af0[TM][4], bf0[TN][4], af1[TM][4], bf1[TN][4];
-#define GI_TILE(BUF, SA, SB_, RA, RB, KSTORE, KLOAD, DO_STORE, DO_LOAD)                         \
+#define GI_TILE(BUF, SA, SB_, RA, RB, KSTORE, KLOAD, DO_STORE, DO_LOAD, STEADY)                 \
     {                                                                                             \
         read_frags(BUF, 0, af0, bf0);                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         mma(af0, bf0); read_frags(BUF, 1, af1, bf1); if (DO_LOAD) gload_a(RA, KLOAD);             \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        mma(af1, bf1); read_frags(BUF, 2, af0, bf0); if (DO_LOAD) gload_b(RB, KLOAD);             \
+        mma(af1, bf1); read_frags(BUF, 2, af0, bf0); if (DO_LOAD) gload_b(RB, KLOAD, bidx);           \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        mma(af0, bf0); read_frags(BUF, 3, af1, bf1); if (DO_STORE) sstore_a(SA, (BUF) ^ 1, KSTORE); \
+        mma(af0, bf0); read_frags(BUF, 3, af1, bf1);                                              \
+        if (DO_STORE) sstore_a(SA, (BUF) ^ 1, KSTORE, STEADY);                                    \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        mma(af1, bf1); if (DO_STORE) sstore_b(SB_, (BUF) ^ 1, KSTORE);                            \
+        mma(af1, bf1); if (DO_STORE) sstore_b(SB_, (BUF) ^ 1, KSTORE, STEADY);                    \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         __syncthreads();                                                                          \
     }
-    if (nk > 0) {
-        gload_a(ra0, k_begin); gload_b(rb0, k_begin);
-        gload_a(ra1, k_begin + BK); gload_b(rb1, k_begin + BK);
-        sstore_a(ra0, 0, k_begin); sstore_b(rb0, 0, k_begin);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-        const bool more = kt + 2 < nk;
-        const int k1 = k_begin + (kt + 1) * BK, k2 = k1 + BK, k3 = k2 + BK;
-        // tile kt from LDS buffer 0: store tile kt+1 (stage 1) -> buffer 1, fetch tile kt+2 -> stage 0
-        GI_TILE(0, ra1, rb1, ra0, rb0, k1, k2, true, more)
-        // tile kt+1 from LDS buffer 1: store tile kt+2 (stage 0) -> buffer 0, fetch tile kt+3 -> stage 1
-        GI_TILE(1, ra0, rb0, ra1, rb1, k2, k3, more, more)
-    }
+    auto run = [&](auto bidx) __attribute__((always_inline)) {
+        if (nk > 0) {
+            gload_a(ra0, k_begin); gload_b(rb0, k_begin, bidx);
+            gload_a(ra1, k_begin + BK); gload_b(rb1, k_begin + BK, bidx);
+            sstore_a(ra0, 0, k_begin, false); sstore_b(rb0, 0, k_begin, false);
+        }
+        __syncthreads();
+        // pairs (kt, kt+1) that write tiles kt+1 and kt+2 to LDS: steady while kt+2 is a full tile
+        const int n_full = (k_end - k_begin) / BK;
+        const int kt_steady = (a_fast && b_fast && n_full >= 3) ? (((n_full - 3) & ~1) + 2) : 0;
+        int kt = 0;
+        for (; kt < kt_steady; kt += 2) {
+            const int k1 = k_begin + (kt + 1) * BK, k2 = k1 + BK, k3 = k2 + BK;
+            GI_TILE(0, ra1, rb1, ra0, rb0, k1, k2, true, true, true)
+            GI_TILE(1, ra0, rb0, ra1, rb1, k2, k3, true, true, true)
+        }
+        for (; kt < nk; kt += 2) {
+            const bool more = kt + 2 < nk;
+            const int k1 = k_begin + (kt + 1) * BK, k2 = k1 + BK, k3 = k2 + BK;
+            // tile kt from LDS buffer 0: store tile kt+1 (stage 1) -> buffer 1, fetch tile kt+2 -> stage 0
+            GI_TILE(0, ra1, rb1, ra0, rb0, k1, k2, true, more, false)
+            // tile kt+1 from LDS buffer 1: store tile kt+2 (stage 0) -> buffer 0, fetch tile kt+3 -> stage 1
+            GI_TILE(1, ra0, rb0, ra1, rb1, k2, k3, more, more, false)
+        }
+    };
+    if (B_MAJOR && p.b_idx) run(std::true_type{});
+    else run(std::false_type{});
 #undef GI_TILE
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
