@@ -255,6 +255,8 @@ def main():
                          "graph shape of configs[4] — both for reference, not the headline")
     ap.add_argument("--model", default="ggnn", choices=["ggnn", "attggnn"],
                     help="attggnn = gnn.mpnn.AttentionGGNN (configs[4]'s model class), for reference")
+    ap.add_argument("--no-one-stream", action="store_true",
+                    help="skip the extra roofline leg with the weight-gradient side stream off")
     ap.add_argument("--no-prefetch-compact", action="store_true",
                     help="run graph_compact's counting phase inside the step instead of one batch ahead")
     ap.add_argument("--no-probe", action="store_true",
@@ -427,6 +429,34 @@ def main():
             "beyond_infinity_cache": {"achieved": probe["GBps"],
                                       "frac": round(probe["GBps"] / PEAK_HBM_GBS, 4), **probe},
         }
+    # The same per-launch figure with every launch ALONE on the device: the product path overlaps the
+    # weight-gradient GEMMs (second stream) with the dZ chain, so its launch durations above include
+    # the time two kernels share the CUs.  GI_WGRAD_SIDE_STREAM=0 serialises the step (slower step,
+    # shorter launches) — reported next to the headline, never instead of it.
+    if not args.no_one_stream:
+        os.environ["GI_WGRAD_SIDE_STREAM"] = "0"
+        try:
+            k1 = 8
+            d1, _ = timed_steps(wl, k1, 2, world, device)
+            torch.cuda.synchronize()
+            if rank == 0:
+                handle.gi_prof_enable(1)
+            for i in range(prof_steps):
+                trainer.step(*batches[i % N_BATCHES])
+            torch.cuda.synchronize()
+            if rank == 0:
+                ms1 = (C.c_double * 2)(); busy1 = (C.c_double * 2)(); work1 = (C.c_double * 2)(); n1 = (C.c_int * 2)()
+                lib.check(handle.gi_prof_collect(ms1, busy1, work1, n1), "gi_prof_collect")
+                handle.gi_prof_enable(0)
+                tf1 = work1[0] / (ms1[0] * 1e-3) / 1e12 if ms1[0] > 0 else 0.0
+                result["roofline"]["one_stream"] = {
+                    "achieved": round(tf1, 2), "frac": round(tf1 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "avg_launch_us": round(ms1[0] * 1e3 / max(n1[0], 1), 2),
+                    "ms_per_step": round(d1 / k1 * 1e3, 3),
+                    "note": "GI_WGRAD_SIDE_STREAM=0: no two GEMM launches share the device; the step is "
+                            "slower than the product path (ms_per_step above), the launches are shorter"}
+        finally:
+            del os.environ["GI_WGRAD_SIDE_STREAM"]
     if rank == 0 and not args.no_forward_only:
         # forward-only rate: inference on the same resident batches, no_grad
         model.eval()

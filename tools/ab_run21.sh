@@ -2,7 +2,7 @@
 # GEMM steady-loop (straight-line main loop) check: kernel tests + default bench twice + microbench
 OUT=/root/repo/gpurun_out/run21; mkdir -p $OUT; cd /root/repo
 (timeout 900 python -m pytest tests/test_kernels_gpu.py -q -x 2>&1 | tail -5) > $OUT/tests.log
-B="python bench.py --no-cpu-baseline --no-extra-configs --no-probe --no-forward-only"
+B="python bench.py --no-cpu-baseline --no-extra-configs --no-probe --no-forward-only --no-one-stream"
 for rep in 1 2; do $B 2>/dev/null | tail -1 > $OUT/bench_$rep.json; done
 python bench.py --no-cpu-baseline --no-probe 2>/dev/null | tail -1 > $OUT/bench_full.json
 (timeout 300 python tools/bench_gemm.py 2>&1 | tail -40) > $OUT/bench_gemm.txt

@@ -5,14 +5,14 @@
 TAG=${1:-r02}
 OUT=/root/repo/gpurun_out/$TAG
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-BENCH="python /root/repo/bench.py --no-cpu-baseline --no-extra-configs --no-forward-only --no-probe"
+BENCH="python /root/repo/bench.py --no-cpu-baseline --no-extra-configs --no-forward-only --no-probe --no-one-stream"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $BENCH > $OUT/bench_under_rocprof.log 2>&1
 grep "^{\"metric\"" $OUT/bench_under_rocprof.log > $OUT/bench_under_rocprof.json
 rm -f $OUT/stats/*kernel_trace.csv
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_MFMA" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
   name=$(echo $pass | cut -d' ' -f1)
   rm -rf /tmp/pmc_$name
-  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d /tmp/pmc_$name -o p -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-probe --no-extra-configs > /tmp/pmc_$name.log 2>&1
+  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d /tmp/pmc_$name -o p -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-probe --no-extra-configs --no-one-stream > /tmp/pmc_$name.log 2>&1
   python3 - "$name" <<'PY' > $OUT/pmc_$name.txt
 import csv, collections, glob, sys, re
 f = glob.glob("/tmp/pmc_%s/*counter_collection.csv" % sys.argv[1])
