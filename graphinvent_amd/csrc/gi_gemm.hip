@@ -528,6 +528,14 @@ extern "C" int gi_gemm(const gi_gemm_params* pp, void* stream) {
     return gi_launch_status();
 }
 
+// k tiles one workgroup of the problem walks through (its run time, to first order)
+static int wg_k_tiles(const gi_gemm_params& p) {
+    if (!(p.flags & GI_GEMM_SPLITK)) return gi_cdiv(p.K, 32);
+    const int len = p.ngroups ? p.max_group_rows : p.K;
+    const int nsp = p.ngroups ? p.gsplit[0] : p.nsplit;
+    return gi_cdiv(gi_cdiv(len, nsp > 0 ? nsp : 1), 32);
+}
+
 extern "C" int gi_gemm_batch(const gi_gemm_params* probs, int n, void* stream) {
     (void)hipGetLastError();
     if (!probs || n < 1 || n > GI_GEMM_BATCH_MAX) return GI_EINVAL;
@@ -536,8 +544,16 @@ extern "C" int gi_gemm_batch(const gi_gemm_params* probs, int n, void* stream) {
     memset(&b, 0, sizeof(b));
     double flops = 0;
     int total = 0, k = 0;
-    for (int i = 0; i < n; ++i) {
-        const gi_gemm_params& p = probs[i];
+    // longest reductions first: workgroup ids are dispatched in order, so the short workgroups are
+    // the ones that fill the last, partly empty round of the launch
+    int order[GI_GEMM_BATCH_MAX];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    for (int i = 1; i < n; ++i)                       // stable insertion sort by reduction length
+        for (int j = i; j > 0 && wg_k_tiles(probs[order[j]]) > wg_k_tiles(probs[order[j - 1]]); --j) {
+            const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t;
+        }
+    for (int ii = 0; ii < n; ++ii) {
+        const gi_gemm_params& p = probs[order[ii]];
         const int rc = validate(p);
         if (rc) return rc;
         if (p.tm != probs[0].tm || p.tn != probs[0].tn || p.a_major != probs[0].a_major ||
