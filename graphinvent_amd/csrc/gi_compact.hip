@@ -41,7 +41,7 @@ struct Lay {
     int type_off0, key_lo, key_hi, cls, qkeys, present, rep, dmap, d_slot;
 };
 constexpr int CNT_S = 0, CNT_E = 1, CNT_ERR = 2, CNT_U = 3, CNT_UT = 4, CNT_ET = 12, CNT_D0 = 20,
-              CNT_P0BAD = 21, CNT_Q = 22, CNT_N = 24;
+              CNT_P0BAD = 21, CNT_Q = 22, CNT_NODEDUP = 23, CNT_N = 24;
 constexpr int P0Q = GI_P0_MAX_CLASSES;
 
 inline Lay make_layout(int B, int N, int Fe) {
@@ -83,7 +83,7 @@ inline Lay make_layout(int B, int N, int Fe) {
 template <typename T>
 __global__ __launch_bounds__(256) void compact_count_kernel(
     const T* __restrict__ nodes, const T* __restrict__ edges, int N, int Fn, int Fe,
-    int* __restrict__ gfix, Lay L) {
+    int* __restrict__ gfix, Lay L, int nodedup) {
     __shared__ signed char typ[GI_MAX_NODES * GI_MAX_NODES];
     __shared__ int err_s;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -134,23 +134,27 @@ __global__ __launch_bounds__(256) void compact_count_kernel(
             if (v == 1.f) key |= 1ull << (f & 63);
             else if (v != 0.f) binary = false;
         }
-        if (!binary) gfix[L.counts + CNT_P0BAD] = 1;     // benign race: everybody writes 1
+        if (!binary || nodedup) gfix[L.counts + CNT_P0BAD] = 1;     // benign race: everybody writes 1
         gfix[L.key_lo + slot] = (int)(unsigned)(key & 0xffffffffull);
         gfix[L.key_hi + slot] = (int)(unsigned)(key >> 32);
         gfix[L.rowcnt + slot] = rc;
-        gfix[L.active + slot] = (nz || rc > 0 || cc > 0) ? 1 : 0;
+        gfix[L.active + slot] = (nodedup || nz || rc > 0 || cc > 0) ? 1 : 0;
         gfix[L.node_mask + slot] = rc > 0 ? 1 : 0;                       // :146
 #pragma unroll
         for (int f = 0; f < GI_MAX_GROUPS; ++f)
             if (f < Fe) {
                 gfix[L.colcnt_t + f * ns + slot] = cct[f];
-                gfix[L.mflag_t + f * ns + slot] = cct[f] > 0 ? 1 : 0;   // slot sends a type-f message
-                nm += cct[f] > 0;
+                // message rows of type f sent by the slot: one per (slot, type) pair, or one per
+                // edge without de-duplication
+                const int nrow = nodedup ? cct[f] : (cct[f] > 0 ? 1 : 0);
+                gfix[L.mflag_t + f * ns + slot] = nrow;
+                nm += nrow;
             }
         gfix[L.nmsg + slot] = nm;
     }
     __syncthreads();
     if (tid == 0 && err_s) atomicOr(&gfix[L.counts + CNT_ERR], 1);
+    if (tid == 0 && b == 0) gfix[L.counts + CNT_NODEDUP] = nodedup;
 }
 
 // ---- pass-0 classes: distinct feature patterns of the source slots, sorted (one workgroup) ----
@@ -346,6 +350,9 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
         reinterpret_cast<const signed char*>(gfix + L.etype) + (long long)b * NN;
     for (int idx = tid; idx < NN; idx += 256) typ[idx] = etype_g[idx];
     __syncthreads();
+    // nd: no de-duplication (AlphaDropout training mode) — one message row per EDGE, ordered bond type,
+    // source slot, destination; the message CSR is then the identity (mu_off[u] = u)
+    const bool nd = gfix[L.counts + CNT_NODEDUP] != 0;
     // One thread per adjacency cell (i <- j): positions come from ranks inside the LDS type table
     // (<= N reads), so nothing below is a serial per-slot loop over global memory.
     if (D0 > 0) {                                        // pass-0 edge-count matrix: zero first
@@ -366,7 +373,10 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
         int rank = 0;
         for (int jj = 0; jj < j; ++jj) rank += typ[i * N + jj] >= 0;
         const int ed = gfix[L.seg_start + b * N + i] + rank;
-        in_perm[ed] = gfix[L.type_off + t] + gfix[L.mstart_t + t * ns + b * N + j];
+        int urank = 0;                                   // rank of this edge among j's type-t out-edges
+        if (nd)
+            for (int ii = 0; ii < i; ++ii) urank += typ[ii * N + j] == t;
+        in_perm[ed] = gfix[L.type_off + t] + gfix[L.mstart_t + t * ns + b * N + j] + urank;
         kpos[idx] = ed;
     }
     __syncthreads();                                     // kpos complete, cmat rows zeroed
@@ -380,6 +390,14 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
         const int mo = gfix[L.etype_off + t] + gfix[L.cstart_t + t * ns + slot] + rank;
         mu_dst[mo] = gfix[L.cidx + b * N + i];
         mu_slot[mo] = kpos[idx];
+        if (nd) {                                        // this edge's own message row
+            const int u = gfix[L.type_off + t] + gfix[L.mstart_t + t * ns + slot] + rank;
+            int before = 0;                              // rows of lower bond types sent by the slot
+            for (int tt = 0; tt < t; ++tt) before += gfix[L.colcnt_t + tt * ns + slot];
+            u_src[u] = gfix[L.cidx + slot];
+            out_perm[gfix[L.srcm_start + slot] + before + rank] = u;
+            mu_off[u] = mo;
+        }
         if (D0 > 0) {  // counts are small integers: float atomics are exact and order-independent
             const int d = gfix[L.dmap + t * P0Q + gfix[L.cls + slot]];
             atomicAdd(cmat + (long long)gfix[L.cidx + b * N + i] * ldc0 + d, 1.f);
@@ -389,7 +407,7 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
     for (int idx = tid; idx < N * Fe; idx += 256) {      // message rows of source slot j, by type
         const int j = idx / Fe, t = idx - j * Fe;
         const int slot = b * N + j;
-        if (gfix[L.colcnt_t + t * ns + slot] == 0) continue;
+        if (nd || gfix[L.colcnt_t + t * ns + slot] == 0) continue;
         int rank = 0;
         for (int tt = 0; tt < t; ++tt) rank += gfix[L.colcnt_t + tt * ns + slot] > 0;
         const int u = gfix[L.type_off + t] + gfix[L.mstart_t + t * ns + slot];
@@ -485,6 +503,11 @@ extern "C" int gi_compact_layout(int B, int N, int Fe, gi_compact_layout_t* out)
 
 extern "C" int gi_compact_count(const void* nodes, const void* edges, int in_dtype, int B, int N,
                                 int Fn, int Fe, int* gfix, void* stream) {
+    return gi_compact_count_ex(nodes, edges, in_dtype, B, N, Fn, Fe, gfix, 0, stream);
+}
+
+extern "C" int gi_compact_count_ex(const void* nodes, const void* edges, int in_dtype, int B, int N,
+                                   int Fn, int Fe, int* gfix, int nodedup, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (!nodes || !edges || !gfix || B <= 0 || N <= 0 || Fn <= 0 || Fe <= 0) return GI_EINVAL;
     if (in_dtype != GI_DTYPE_F32 && in_dtype != GI_DTYPE_I8) return GI_EINVAL;
@@ -495,10 +518,12 @@ extern "C" int gi_compact_count(const void* nodes, const void* edges, int in_dty
     if (e != hipSuccess) return (int)e;
     if (in_dtype == GI_DTYPE_F32)
         hipLaunchKernelGGL(compact_count_kernel<float>, dim3(B), dim3(256), 0, st,
-                           (const float*)nodes, (const float*)edges, N, Fn, Fe, gfix, L);
+                           (const float*)nodes, (const float*)edges, N, Fn, Fe, gfix, L,
+                           nodedup ? 1 : 0);
     else
         hipLaunchKernelGGL(compact_count_kernel<signed char>, dim3(B), dim3(256), 0, st,
-                           (const signed char*)nodes, (const signed char*)edges, N, Fn, Fe, gfix, L);
+                           (const signed char*)nodes, (const signed char*)edges, N, Fn, Fe, gfix, L,
+                           nodedup ? 1 : 0);
     hipLaunchKernelGGL(compact_scan_kernel, dim3(3 + 2 * Fe + 1), dim3(1024), 0, st, B * N, Fe, gfix,
                        L);
     hipLaunchKernelGGL(compact_finish_kernel, dim3(gi_cdiv(B * N, 256)), dim3(256), 0, st, B * N, Fe,

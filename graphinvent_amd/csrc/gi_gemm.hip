@@ -360,7 +360,7 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
             const int colc = col_ok ? col : p.N - 1;
             const int row0 = m0 + wm * 32 * TM + tm * 32 + 4 * lhi;
             float av[16], cv[16];
-            if (flags & GI_EPI_DSELU) {
+            if (flags & (GI_EPI_DSELU | GI_EPI_MULACT)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = min(row0 + (r & 3) + 8 * (r >> 2), m_end - 1);
@@ -381,6 +381,7 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
                 float x = acc[tm][tn][r] + bv;
                 if (flags & GI_EPI_SELU) x = gi_selu(x);
                 if (flags & GI_EPI_DSELU) x *= gi_selu_grad(av[r]);
+                if (flags & GI_EPI_MULACT) x *= av[r];
                 if (flags & GI_EPI_ACCUM) x += cv[r];
                 v[r] = x;
             }

@@ -29,6 +29,7 @@ constexpr int MAXP = 16;   // max message passes
 
 struct Mlp {
     int base, in, hidden, depth, out;
+    float drop_p = 0.f;      // AlphaDropout probability of the stack (training mode only)
     int layers() const { return depth + 1; }
     int fan_in(int l) const { return l == 0 ? in : hidden; }
     int fan_out(int l) const { return l == depth ? out : hidden; }
@@ -60,22 +61,26 @@ int build_model(const gi_ggnn_dims* dp, Model& m) {
     m.NA = d.N * d.A;
     m.NC = d.N * d.C;
     int idx = 0;
-    auto mk = [&](int in, int hidden, int depth, int out) {
-        Mlp r{idx, in, hidden, depth, out};
+    const float drops[] = {d.drop_enn, d.drop_eatt, d.drop_att, d.drop_emb, d.drop_mlp1, d.drop_mlp2};
+    for (float x : drops)
+        if (!(x >= 0.f) || !(x < 1.f)) return GI_EINVAL;
+    auto mk = [&](int in, int hidden, int depth, int out, float drop_p) {
+        Mlp r{idx, in, hidden, depth, out, d.dropout ? drop_p : 0.f};
         idx += 2 * (depth + 1);
         return r;
     };
-    for (int t = 0; t < d.Fe; ++t) m.msg[t] = mk(d.H, d.enn_hidden, d.enn_depth, d.M);
+    for (int t = 0; t < d.Fe; ++t) m.msg[t] = mk(d.H, d.enn_hidden, d.enn_depth, d.M, d.drop_enn);
     if (attn)   // AttentionGGNN registers msg_nns before att_nns (gnn/mpnn.py:316-317)
-        for (int t = 0; t < d.Fe; ++t) m.eatt[t] = mk(d.H, d.eatt_hidden, d.eatt_depth, d.M);
+        for (int t = 0; t < d.Fe; ++t)
+            m.eatt[t] = mk(d.H, d.eatt_hidden, d.eatt_depth, d.M, d.drop_eatt);
     m.gru_wih = idx++; m.gru_whh = idx++; m.gru_bih = idx++; m.gru_bhh = idx++;
-    m.att = mk(d.H + d.Fn, d.att_hidden, d.att_depth, d.G);
-    m.emb = mk(d.H, d.emb_hidden, d.emb_depth, d.G);
-    m.add1 = mk(d.H, d.mlp1_hidden, d.mlp1_depth, d.A);
-    m.conn1 = mk(d.H, d.mlp1_hidden, d.mlp1_depth, d.C);
-    m.add2 = mk(m.NA + d.G, d.mlp2_hidden, d.mlp2_depth, m.NA);
-    m.conn2 = mk(m.NC + d.G, d.mlp2_hidden, d.mlp2_depth, m.NC);
-    m.term2 = mk(d.G, d.mlp2_hidden, d.mlp2_depth, 1);
+    m.att = mk(d.H + d.Fn, d.att_hidden, d.att_depth, d.G, d.drop_att);
+    m.emb = mk(d.H, d.emb_hidden, d.emb_depth, d.G, d.drop_emb);
+    m.add1 = mk(d.H, d.mlp1_hidden, d.mlp1_depth, d.A, d.drop_mlp1);
+    m.conn1 = mk(d.H, d.mlp1_hidden, d.mlp1_depth, d.C, d.drop_mlp1);
+    m.add2 = mk(m.NA + d.G, d.mlp2_hidden, d.mlp2_depth, m.NA, d.drop_mlp2);
+    m.conn2 = mk(m.NC + d.G, d.mlp2_hidden, d.mlp2_depth, m.NC, d.drop_mlp2);
+    m.term2 = mk(d.G, d.mlp2_hidden, d.mlp2_depth, 1, d.drop_mlp2);
     m.nparams = idx;
     return 0;
 }
@@ -138,6 +143,9 @@ struct Ws {
     // forward and backward layouts; 0 floats when the stack does not fit the chain kernel
     long long img_f[2], img_b[2], img_f_n[2], img_b_n[2], img_b_stride[2];
     long long gru_img;                 // packed W_ih | W_hh image of the fused GRU kernel (-1: not fused)
+    // AlphaDropout training mode: the workspace is allocated twice; float i of the second half holds
+    // the backward factor d y / d z of activation i of the first (0: mode off)
+    long long fshift;
     long long total;
 };
 
@@ -218,17 +226,19 @@ void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
         w.add2_dz[l] = take(B, w.ldM2); w.conn2_dz[l] = take(B, w.ldM2); w.term2_dz[l] = take(B, w.ldM2);
     }
     w.gru_img = -1;
-    if (d.passes > 0 && gi_gru_image_floats(d.H, d.M) > 0) w.gru_img = take(gi_gru_image_floats(d.H, d.M), 1);
+    if (d.passes > 0 && !d.dropout && gi_gru_image_floats(d.H, d.M) > 0)
+        w.gru_img = take(gi_gru_image_floats(d.H, d.M), 1);
     for (int k = 0; k < (attn ? 2 : 1); ++k) {
         const Mlp& q = k ? m.eatt[0] : m.msg[0];
-        if (d.passes > 0 && chain_fits(q, d.H)) {
+        if (d.passes > 0 && !d.dropout && chain_fits(q, d.H)) {   // (dropout: layer by layer)
             w.img_f_n[k] = chain_image_floats(q, d.Fe, false, nullptr);
             w.img_b_n[k] = chain_image_floats(q, d.Fe, true, &w.img_b_stride[k]);
             w.img_f[k] = take(w.img_f_n[k], 1);
             w.img_b[k] = take(w.img_b_n[k], 1);
         }
     }
-    w.total = o;
+    w.fshift = d.dropout ? gi_r4l(o) : 0;
+    w.total = d.dropout ? 2 * gi_r4l(o) : o;
 }
 
 // ---- wgrad slab plan ----------------------------------------------------------------------------
@@ -299,6 +309,11 @@ struct Run {
     long long img_b_stride[2] = {0, 0};
     const struct Mlp* eatt0 = nullptr;      // identifies the energy stacks (second image)
     bool hold_kicks = false;                // no weight-gradient launches on the side stream for now
+    // AlphaDropout training mode (gnn/modules.py:130-142 with p > 0)
+    bool drop = false;
+    unsigned long long seed = 0;
+    long long fshift = 0;                   // activation -> its stored backward factor (floats)
+    int pass = 0;                           // message pass being evaluated (part of the site id)
     struct SlabPlan* sp = nullptr; // backward only: where the wgrad slabs go and what they reduce to
     float* slabs = nullptr;
     float* const* grads = nullptr;
@@ -319,6 +334,21 @@ void gemm_defaults(gi_gemm_params& p) {
     memset(&p, 0, sizeof(p));
     p.nsplit = 1;
     p.ones_col = -1;
+}
+
+// AlphaDropout behind layer l of a stack, in place on its SELU outputs y[rows, fan_out(l)]; the site id
+// (weight index of the layer, message pass) selects the mask stream.  No-op outside dropout mode.
+void drop_site(Run& r, const Mlp& q, int l, int pass, float* y, int ld, int rows, long long fshift) {
+    if (!r.drop || !r.ok() || rows <= 0) return;
+    gi_dropout_params dp;
+    r.chk(gi_dropout_setup(q.drop_p, r.seed, (unsigned)(q.w(l) * MAXP + pass), &dp));
+    if (r.ok()) r.chk(gi_alpha_dropout_fwd(y, ld, rows, q.fan_out(l), fshift, &dp, r.st));
+}
+
+// dgrad epilogue factor: selu'(through the stored activation), or the stored factor in dropout mode
+void dact(const Run& r, gi_gemm_params& p, const float* act, int ldact, bool accumulate) {
+    p.act = act ? act + r.fshift : nullptr; p.ldact = ldact;
+    p.flags = (act ? (r.drop ? GI_EPI_MULACT : GI_EPI_DSELU) : 0) | (accumulate ? GI_EPI_ACCUM : 0);
 }
 
 // Y[rows, out] = (selu)(X[a_idx][rows, in] W^T + b); group t uses mlps[t]'s layer l
@@ -358,8 +388,7 @@ void linear_dgrad(Run& r, const int* widx, const Grp& g, int n_out,
     gemm_defaults(p);
     p.A = dZ; p.lda = lddz; p.C = dX; p.ldc = lddx;
     p.M = rows; p.N = ncols; p.K = n_out;
-    p.act = act; p.ldact = ldact;
-    p.flags = (act ? GI_EPI_DSELU : 0) | (accumulate ? GI_EPI_ACCUM : 0);
+    dact(r, p, act, ldact, accumulate);
     if (g.n) {
         p.ngroups = g.n; p.grp_off = g.off; p.max_group_rows = g.max_rows;
         for (int t = 0; t < g.n; ++t) p.Bg[t] = dgrad_operand(r, widx[t], n_out, n_in, p);
@@ -390,6 +419,7 @@ void mlp_forward(Run& r, float* ws, const Mlp* mlps, const Grp& g, const float* 
         float* dst = (l == L - 1) ? final_dst : ws + acts[l];
         linear_fwd(r, mlps, l, g, src, l == 0 ? ldx : ldh, l == 0 ? a_idx : nullptr, rows, dst,
                    l == L - 1 ? ld_final : ldh);
+        drop_site(r, mlps[0], l, r.pass, dst, l == L - 1 ? ld_final : ldh, rows, r.fshift);
     }
 }
 
@@ -406,6 +436,7 @@ struct MlpJob {
     const long long* dzs;                        // backward: dZ buffers of the hidden layers
     const float* Zlast; int ldz;                 // backward: dZ of the last layer
     float* dX; int lddx; int dx_cols; bool accumulate;   // backward: first-layer input gradient (or null)
+    long long out_fshift = 0;                    // dropout mode: factor twin of `out` when it is not in ws
 };
 
 struct Batch {
@@ -452,8 +483,7 @@ void add_dgrad(Batch& b, const Run& r, int widx, int n_out, int n_in, int ncols,
     gi_gemm_params& p = b.next();
     p.A = dZ; p.lda = lddz; p.B = dgrad_operand(r, widx, n_out, n_in, p); p.C = dX; p.ldc = lddx;
     p.M = rows; p.N = ncols; p.K = n_out;
-    p.act = act; p.ldact = ldact;
-    p.flags = (act ? GI_EPI_DSELU : 0) | (accumulate ? GI_EPI_ACCUM : 0);
+    dact(r, p, act, ldact, accumulate);
 }
 
 void flush_deferred(Run& r, Deferred& q);
@@ -598,6 +628,14 @@ void mlp_jobs_forward(Run& r, float* ws, const MlpJob* jobs, int n) {
                     l == 0 ? q.ldx : q.ldh, q.rows, dst, l == L - 1 ? q.ldout : q.ldh, true);
         }
         flush_batch(r, b, false);
+        for (int j = 0; j < n && r.drop; ++j) {
+            const MlpJob& q = jobs[j];
+            const int L = q.mlp->layers();
+            if (l >= L) continue;
+            const bool last = l == L - 1;
+            drop_site(r, *q.mlp, l, 0, last ? q.out : ws + q.acts[l], last ? q.ldout : q.ldh, q.rows,
+                      (last && q.out_fshift) ? q.out_fshift : r.fshift);
+        }
     }
 }
 
@@ -862,6 +900,13 @@ void edge_chains_forward(Run& r, float* ws, const EdgeChain* ch, int n, const Gr
             }
         }
         flush_batch(r, b, false);
+        for (int j = 0; j < n && r.drop; ++j) {
+            const EdgeChain& c = ch[j];
+            const int L = c.mlps[0].layers();
+            if (l >= L) continue;
+            drop_site(r, c.mlps[0], l, r.pass, l == L - 1 ? c.out : ws + c.acts[l],
+                      l == L - 1 ? c.ldout : c.ldh, rows, r.fshift);
+        }
     }
 }
 
@@ -911,8 +956,7 @@ void edge_chains_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferre
                 p.Bg[t] = dgrad_operand(r, widx[t], q.fan_out(l), q.fan_in(l), p);
             if (l > 0) {
                 p.C = ws + c.dzs[l - 1]; p.ldc = c.ldh; p.N = q.fan_in(l);
-                p.act = ws + c.acts[l - 1]; p.ldact = c.ldh;
-                p.flags = GI_EPI_DSELU;
+                dact(r, p, ws + c.acts[l - 1], c.ldh, false);
             } else {
                 p.C = c.dX; p.ldc = lddx; p.N = dx_cols;
             }
@@ -1016,6 +1060,14 @@ extern "C" int gi_ggnn_ws_query(const gi_ggnn_dims* d, int S, int E, int U, int 
     return GI_EINVAL;
 }
 
+// AlphaDropout training mode needs the graph without row sharing (gi_compact_count_ex, nodedup): an
+// independent mask per padded slot and per edge
+static int dropout_graph_ok(const gi_ggnn_dims& d, int S, int E, int U, int D0) {
+    if (!d.dropout) return 0;
+    if (S != d.B * d.N || U != E || D0 != 0) return GI_EINVAL;
+    return 0;
+}
+
 extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* params,
                                const gi_graph* gp, float* ws, float* out, int ldout, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
@@ -1041,8 +1093,10 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
         return GI_EINVAL;
     if (d.kind == GI_KIND_ATTGGNN && gp->D0 > 0 && (!gp->e2d || !gp->cls_off || !gp->cls_edges))
         return GI_EINVAL;
+    if (int drc = dropout_graph_ok(d, S, E, U, gp->D0)) return drc;
     make_ws(m, S, E, U, gp->D0, w);
     Run r{(hipStream_t)stream, params, 0};
+    r.drop = d.dropout != 0; r.seed = d.drop_seed; r.fshift = w.fshift;
     const int R = w.R;
     int maxUt = 0;
     for (int t = 0; t < d.Fe; ++t) maxUt = std::max(maxUt, Ut[t]);
@@ -1076,6 +1130,7 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
     }
     for (int p = 0; p < d.passes; ++p) {
         const float* hx = ws + w.hx[p];
+        r.pass = p;
         int agg_ready = 1;               // the aggregate is in ws + w.agg[p] before the GRU launch
         if (attn) {
             // AttentionGGNN.aggregate_message (gnn/mpnn.py:370-389): message and energy MLPs of the
@@ -1163,6 +1218,8 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
         jobs[0] = {&m.add2, ws + w.cat_add, w.ldCA, d.B, w.add2_act, w.ldM2, out, ldout};
         jobs[1] = {&m.conn2, ws + w.cat_conn, w.ldCC, d.B, w.conn2_act, w.ldM2, out + m.NA, ldout};
         jobs[2] = {&m.term2, ws + w.gemb, w.ldG, d.B, w.term2_act, w.ldM2, out + m.NA + m.NC, ldout};
+        // dropout mode: `out` is [2 B, ldout]; rows [B, 2 B) take the factors of the logits
+        for (MlpJob& j : jobs) j.out_fshift = r.drop ? (long long)d.B * ldout : 0;
         mlp_jobs_forward(r, ws, jobs, 3);
     }
     return r.rc;
@@ -1244,11 +1301,14 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
         return GI_EINVAL;
     if (d.kind == GI_KIND_ATTGGNN && gp->D0 > 0 && (!gp->e2d || !gp->cls_off || !gp->cls_edges))
         return GI_EINVAL;
+    if (int drc = dropout_graph_ok(d, S, E, U, gp->D0)) return drc;
     make_ws(m, S, E, U, gp->D0, w);
     SlabPlan sp;
     plan_slabs(m, S, U, Ut, sp);
     const Grp bytype0{d.Fe, gfix + L.type_off0, w.D0};
     Run r{(hipStream_t)stream, params, 0};
+    r.drop = d.dropout != 0; r.seed = d.drop_seed; r.fshift = w.fshift;
+    const long long out_fshift = r.drop ? (long long)d.B * ldout : 0;   // logits -> their factors
     const int R = w.R;
     int maxUt = 0;
     for (int t = 0; t < d.Fe; ++t) maxUt = std::max(maxUt, Ut[t]);
@@ -1282,11 +1342,12 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
         readout_params([&](int widx) { sp.e[widx].reduced = 1; });
     if (phase != GI_BWD_PASSES) {
     // ---- tier 2 (gnn/modules.py:265-279) ---------------------------------------------------------
-    r.chk(gi_selu_bwd_rows(d_out, lddout, nullptr, y_out, ldout, ws + w.dzA, w.ldNA, d.B, NA, r.st));
-    r.chk(gi_selu_bwd_rows(d_out + NA, lddout, nullptr, y_out + NA, ldout, ws + w.dzC, w.ldNC, d.B,
-                           NC, r.st));
-    r.chk(gi_selu_bwd_rows(d_out + NA + NC, lddout, nullptr, y_out + NA + NC, ldout, ws + w.dzT, 4,
-                           d.B, 1, r.st));
+    r.chk(gi_selu_bwd_rows_f(d_out, lddout, nullptr, y_out, ldout, ws + w.dzA, w.ldNA, d.B, NA,
+                             out_fshift, r.st));
+    r.chk(gi_selu_bwd_rows_f(d_out + NA, lddout, nullptr, y_out + NA, ldout, ws + w.dzC, w.ldNC, d.B,
+                             NC, out_fshift, r.st));
+    r.chk(gi_selu_bwd_rows_f(d_out + NA + NC, lddout, nullptr, y_out + NA + NC, ldout, ws + w.dzT, 4,
+                             d.B, 1, out_fshift, r.st));
     {
         MlpJob jobs[3] = {};
         jobs[0] = {&m.add2, ws + w.cat_add, w.ldCA, d.B, w.add2_act, w.ldM2, nullptr, 0, w.add2_dz,
@@ -1298,13 +1359,13 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
         mlp_jobs_backward(r, ws, sp, slabs, dq, jobs, 3);
     }
     // ---- gather + tier-1 glue: dZ of the last att/emb/add1/conn1 layers, in place ----------------
-    r.chk(gi_gather_readout_bwd(ws + w.en, ws + w.embo, w.ldG, cidx, mask, d.B, d.N, d.G, S,
-                                d.big_positive, ws + w.dgemb, w.ldG, ws + w.dcat_add + NA, w.ldCA,
-                                ws + w.dcat_conn + NC, w.ldCC, ws + w.zpart_g, r.st));
-    r.chk(gi_compress_slots(ws + w.add1o, w.ldA, cidx, d.B, d.N, d.A, S, ws + w.dcat_add, w.ldCA,
-                            ws + w.zpart_a, w.ldA, r.st));
-    r.chk(gi_compress_slots(ws + w.conn1o, w.ldC, cidx, d.B, d.N, d.C, S, ws + w.dcat_conn, w.ldCC,
-                            ws + w.zpart_c, w.ldC, r.st));
+    r.chk(gi_gather_readout_bwd_f(ws + w.en, ws + w.embo, w.ldG, cidx, mask, d.B, d.N, d.G, S,
+                                  d.big_positive, ws + w.dgemb, w.ldG, ws + w.dcat_add + NA, w.ldCA,
+                                  ws + w.dcat_conn + NC, w.ldCC, ws + w.zpart_g, r.fshift, r.st));
+    r.chk(gi_compress_slots_f(ws + w.add1o, w.ldA, cidx, d.B, d.N, d.A, S, ws + w.dcat_add, w.ldCA,
+                              ws + w.zpart_a, w.ldA, r.fshift, r.st));
+    r.chk(gi_compress_slots_f(ws + w.conn1o, w.ldC, cidx, d.B, d.N, d.C, S, ws + w.dcat_conn, w.ldCC,
+                              ws + w.zpart_c, w.ldC, r.fshift, r.st));
     {   // zero-row gradients of the four stacks: per-graph partial sums -> row S, one launch
         float* en_z = ws + w.en + (long long)S * w.ldG;
         float* emb_z = ws + w.embo + (long long)S * w.ldG;
@@ -1400,10 +1461,10 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
                 edge_chains_backward(r, ws, sp, slabs, dq, ch, 2, bytype0, hx, w.ldhx, gp->d_src, w.D0,
                                      w.ldH, d.H);
             } else {
-                r.chk(gi_seg_sum_dselu(ws + w.tmp_emb, w.ldM, mu_slot, mu_off, U, d.M, ws + w.m[p],
-                                       w.ldM, r.st));
-                r.chk(gi_seg_sum_dselu(ws + w.tmp_en, w.ldM, mu_slot, mu_off, U, d.M, ws + w.een[p],
-                                       w.ldM, r.st));
+                r.chk(gi_seg_sum_dselu_f(ws + w.tmp_emb, w.ldM, mu_slot, mu_off, U, d.M, ws + w.m[p],
+                                         w.ldM, r.fshift, r.st));
+                r.chk(gi_seg_sum_dselu_f(ws + w.tmp_en, w.ldM, mu_slot, mu_off, U, d.M, ws + w.een[p],
+                                         w.ldM, r.fshift, r.st));
                 edge_chains_backward(r, ws, sp, slabs, dq, ch, 2, bytype, hx, w.ldhx, u_src, U, w.ldH,
                                      d.H);
             }
@@ -1430,7 +1491,8 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
         } else if (E > 0) {
             // d m_u = selu'(m_u) * sum over the edges reading row u of d agg[dst(e)]
             // (backward of the segmented sum + last SELU, over the message CSR)
-            r.chk(gi_seg_sum_dselu(dagg, w.ldM, mu_dst, mu_off, U, d.M, ws + w.m[p], w.ldM, r.st));
+            r.chk(gi_seg_sum_dselu_f(dagg, w.ldM, mu_dst, mu_off, U, d.M, ws + w.m[p], w.ldM, r.fshift,
+                                     r.st));
             msg_backward(r, ws, sp, slabs, dq, m.msg, bytype, hx, w.ldhx, u_src, U, w.eact[p],
                          w.edz[p], w.ldEh, ws + w.m[p], w.ldM, p > 0 ? ws + w.dxe : nullptr, w.ldH,
                          d.H);

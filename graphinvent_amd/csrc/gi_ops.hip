@@ -41,11 +41,20 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(
 __device__ __forceinline__ v4f v4_selu_grad(v4f y) {
     return v4f{gi_selu_grad(y.x), gi_selu_grad(y.y), gi_selu_grad(y.z), gi_selu_grad(y.w)};
 }
+// d(layer output)/d(pre-activation) of the element stored at y: selu'(through its output) normally;
+// in AlphaDropout training mode (fshift != 0) the factor keep * a * selu' that the forward stored
+// `fshift` floats behind the activation (gi_alpha_dropout_fwd).
+__device__ __forceinline__ float gi_dact(const float* y, long long fshift) {
+    return fshift ? y[fshift] : gi_selu_grad(*y);
+}
+__device__ __forceinline__ v4f v4_dact(const float* y, long long fshift) {
+    return fshift ? *(const v4f*)(y + fshift) : v4_selu_grad(*(const v4f*)y);
+}
 
 // seg_sum over the message CSR with the SELU backward of the destination buffer fused in
 __global__ __launch_bounds__(256) void seg_sum_dselu_kernel(
     const float* __restrict__ vals, int ldv, const int* __restrict__ perm,
-    const int* __restrict__ off, int rows, int c4n, float* y, int ldy) {
+    const int* __restrict__ off, int rows, int c4n, float* y, int ldy, long long fshift) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int c = (int)(t / c4n), q = (int)(t - (long long)c * c4n);
     if (c >= rows) return;
@@ -60,9 +69,8 @@ __global__ __launch_bounds__(256) void seg_sum_dselu_kernel(
         acc += b;
     }
     if (k < hi) acc += *(const v4f*)(vals + (long long)perm[k] * ldv + 4 * q);
-    v4f* dst = (v4f*)(y + (long long)c * ldy + 4 * q);
-    const v4f yv = *dst;
-    *dst = acc * v4_selu_grad(yv);
+    float* dst = y + (long long)c * ldy + 4 * q;
+    *(v4f*)dst = acc * v4_dact(dst, fshift);
 }
 
 // y[r, c] = selu'(y[r, c]) * sum_s slabs[s * stride + r * ld + c]   (pass-0 shortcut, tiny).
@@ -158,12 +166,51 @@ __global__ __launch_bounds__(256) void seg_softmax_bwd_kernel(
 
 __global__ __launch_bounds__(256) void selu_bwd_rows_kernel(
     const float* __restrict__ dY, int lddy, const int* __restrict__ idx, const float* Y, int ldy,
-    float* out, int ldo, int rows, int cols) {
+    float* out, int ldo, int rows, int cols, long long fshift) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int r = (int)(t / cols), c = (int)(t - (long long)r * cols);
     if (r >= rows) return;
     const long long sr = idx ? idx[r] : r;
-    out[(long long)r * ldo + c] = dY[sr * lddy + c] * gi_selu_grad(Y[(long long)r * ldy + c]);
+    out[(long long)r * ldo + c] = dY[sr * lddy + c] * gi_dact(Y + (long long)r * ldy + c, fshift);
+}
+
+// ---- AlphaDropout (training mode of gnn/modules.py:130-142, p > 0) ------------------------------
+// torch.nn.AlphaDropout after every Linear+SELU: y = s * (keep * a) + b with b = (keep - 1) * alpha' * a
+// + alpha' * a * p, evaluated exactly like ATen's _dropout_impl (two roundings: fl(fl(s * a) + b));
+// the keep bit is a counter-based hash of (seed, layer id, row, column) — nothing is stored but the
+// factor d y / d z = keep * a * selu'(z), written `fshift` floats behind the activation for the
+// backward (gi_dact above, GI_EPI_MULACT in gi_gemm).
+__device__ __forceinline__ bool gi_dropout_keep(unsigned long long seed, unsigned id, unsigned thresh,
+                                                int row, int col) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)id + 1ull);
+    z ^= ((unsigned long long)(unsigned)row << 32) | (unsigned)col;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;          // splitmix64 finaliser
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 32) >= thresh;
+}
+
+__global__ __launch_bounds__(256) void alpha_dropout_fwd_kernel(float* y, int ldy, int rows, int cols,
+                                                                long long fshift,
+                                                                const gi_dropout_params q) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int r = (int)(t / cols), c = (int)(t - (long long)r * cols);
+    if (r >= rows) return;
+    float* p = y + (long long)r * ldy + c;
+    const float s = *p;
+    const bool keep = gi_dropout_keep(q.seed, q.id, q.thresh, r, c);
+    float sa = s * q.a;                      // ATen: mul, then add — two roundings, never an fma
+    asm volatile("" : "+v"(sa));             // (keeps hipcc from contracting the pair)
+    *p = keep ? sa + q.b_keep : q.b_drop;
+    p[fshift] = keep ? q.a * gi_selu_grad(s) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(const gi_dropout_params q, int rows,
+                                                           int cols, unsigned char* keep, int ld) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int r = (int)(t / cols), c = (int)(t - (long long)r * cols);
+    if (r >= rows) return;
+    keep[(long long)r * ld + c] = gi_dropout_keep(q.seed, q.id, q.thresh, r, c) ? 1 : 0;
 }
 
 // ---- GRU gates --------------------------------------------------------------------------------
@@ -252,7 +299,7 @@ __global__ __launch_bounds__(128) void gather_bwd_kernel(
     float* en, float* emb, int ld, const int* __restrict__ cidx, const int* __restrict__ mask,
     int N, int G, int S, float big, const float* __restrict__ dg0, int ld0,
     const float* __restrict__ dg1, int ld1, const float* __restrict__ dg2, int ld2,
-    float* __restrict__ zpart) {
+    float* __restrict__ zpart, long long fshift) {
     __shared__ int c_s[GI_MAX_NODES];
     __shared__ float pen_s[GI_MAX_NODES];
     const int b = blockIdx.x;
@@ -285,8 +332,8 @@ __global__ __launch_bounds__(128) void gather_bwd_kernel(
             const float de = att * (mv * dg - dot);
             const float dm = att * dg;
             if (c_s[n] < S) {                                    // this slot owns its compact row
-                en[o] = de * gi_selu_grad(ev);
-                emb[o] = dm * gi_selu_grad(mv);
+                en[o] = de * gi_dact(en + o, fshift);
+                emb[o] = dm * gi_dact(emb + o, fshift);
             } else {                                             // shared zero row: per-graph partial
                 zen += de;
                 zemb += dm;
@@ -311,7 +358,7 @@ __global__ __launch_bounds__(256) void expand_slots_kernel(
 
 __global__ __launch_bounds__(64) void compress_slots_kernel(
     float* t1, int ldt, const int* __restrict__ cidx, int N, int W, int S,
-    const float* __restrict__ dcat, int ldc, float* __restrict__ zpart, int ldz) {
+    const float* __restrict__ dcat, int ldc, float* __restrict__ zpart, int ldz, long long fshift) {
     const int b = blockIdx.x;
     for (int w = threadIdx.x; w < W; w += 64) {
         float z = 0.f;
@@ -320,7 +367,7 @@ __global__ __launch_bounds__(64) void compress_slots_kernel(
             const float d = dcat[(long long)b * ldc + n * W + w];
             if (c < S) {
                 float* p = t1 + (long long)c * ldt + w;
-                *p = d * gi_selu_grad(*p);
+                *p = d * gi_dact(p, fshift);
             } else {
                 z += d;
             }
@@ -658,8 +705,15 @@ extern "C" int gi_seg_softmax_bwd(const float* en, const float* emb, int ld, con
 
 extern "C" int gi_seg_sum_dselu(const float* vals, int ldv, const int* perm, const int* off,
                                 int rows, int cols, float* y, int ldy, void* stream) {
+    return gi_seg_sum_dselu_f(vals, ldv, perm, off, rows, cols, y, ldy, 0, stream);
+}
+
+extern "C" int gi_seg_sum_dselu_f(const float* vals, int ldv, const int* perm, const int* off,
+                                  int rows, int cols, float* y, int ldy, long long fshift,
+                                  void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (rows <= 0) return 0;
+    if (fshift & 3) return GI_EINVAL;
     if (!vals || !perm || !off || !y || cols <= 0 || (ldv & 3) || (ldy & 3) || ldv < cols ||
         ldy < cols)
         return GI_EINVAL;
@@ -668,7 +722,7 @@ extern "C" int gi_seg_sum_dselu(const float* vals, int ldv, const int* perm, con
     const long long threads = (long long)rows * c4n;
     GiProfScope prof((hipStream_t)stream, GI_PROF_SEGSUM, 0.0);
     hipLaunchKernelGGL(seg_sum_dselu_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, vals, ldv, perm, off, rows, c4n, y, ldy);
+                       (hipStream_t)stream, vals, ldv, perm, off, rows, c4n, y, ldy, fshift);
     return gi_launch_status();
 }
 
@@ -699,12 +753,56 @@ extern "C" int gi_slab_sum_dselu(const float* slabs, int nsplit, long long strid
 
 extern "C" int gi_selu_bwd_rows(const float* dY, int lddy, const int* idx, const float* Y, int ldy,
                                 float* out, int ldo, int rows, int cols, void* stream) {
+    return gi_selu_bwd_rows_f(dY, lddy, idx, Y, ldy, out, ldo, rows, cols, 0, stream);
+}
+
+extern "C" int gi_selu_bwd_rows_f(const float* dY, int lddy, const int* idx, const float* Y, int ldy,
+                                  float* out, int ldo, int rows, int cols, long long fshift,
+                                  void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (rows <= 0 || cols <= 0) return 0;
     if (!dY || !Y || !out) return GI_EINVAL;
     const long long threads = (long long)rows * cols;
     hipLaunchKernelGGL(selu_bwd_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, dY, lddy, idx, Y, ldy, out, ldo, rows, cols);
+                       (hipStream_t)stream, dY, lddy, idx, Y, ldy, out, ldo, rows, cols, fshift);
+    return gi_launch_status();
+}
+
+// constants of one AlphaDropout site, rounded the way ATen rounds them (double scalars applied to a
+// float tensor: each scalar is cast to float first)
+extern "C" int gi_dropout_setup(double p, unsigned long long seed, unsigned id, gi_dropout_params* out) {
+    if (!out || !(p >= 0.0) || !(p < 1.0)) return GI_EINVAL;
+    const double alpha = 1.7580993408473766;
+    const double a = 1.0 / sqrt((alpha * alpha * p + 1.0) * (1.0 - p));
+    const float c1 = (float)(alpha * a), c2 = (float)(alpha * a * p);
+    out->seed = seed; out->id = id;
+    const double t = floor(p * 4294967296.0);
+    out->thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    out->a = (float)a;
+    out->b_keep = c2;                       // (1 - 1) * c1 + c2
+    out->b_drop = -c1 + c2;                 // (0 - 1) * c1 + c2, one fp32 rounding like add_
+    return 0;
+}
+
+extern "C" int gi_alpha_dropout_fwd(float* y, int ldy, int rows, int cols, long long fshift,
+                                    const gi_dropout_params* q, void* stream) {
+    (void)hipGetLastError();
+    if (rows <= 0 || cols <= 0) return 0;
+    if (!y || !q || ldy < cols || fshift == 0) return GI_EINVAL;
+    const long long threads = (long long)rows * cols;
+    hipLaunchKernelGGL(alpha_dropout_fwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, y, ldy, rows, cols, fshift, *q);
+    return gi_launch_status();
+}
+
+extern "C" int gi_dropout_mask(const gi_dropout_params* q, int rows, int cols, unsigned char* keep,
+                               int ld, void* stream) {
+    (void)hipGetLastError();
+    if (rows <= 0 || cols <= 0) return 0;
+    if (!q || !keep || ld < cols) return GI_EINVAL;
+    const long long threads = (long long)rows * cols;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, *q, rows, cols, keep, ld);
     return gi_launch_status();
 }
 
@@ -753,12 +851,21 @@ extern "C" int gi_gather_readout_bwd(float* en, float* emb, int ld, const int* c
                                      const int* node_mask, int B, int N, int G, int S, float big,
                                      const float* dg0, int ld0, const float* dg1, int ld1,
                                      const float* dg2, int ld2, float* zpart, void* stream) {
+    return gi_gather_readout_bwd_f(en, emb, ld, cidx, node_mask, B, N, G, S, big, dg0, ld0, dg1, ld1,
+                                   dg2, ld2, zpart, 0, stream);
+}
+
+extern "C" int gi_gather_readout_bwd_f(float* en, float* emb, int ld, const int* cidx,
+                                       const int* node_mask, int B, int N, int G, int S, float big,
+                                       const float* dg0, int ld0, const float* dg1, int ld1,
+                                       const float* dg2, int ld2, float* zpart, long long fshift,
+                                       void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (B <= 0) return 0;
     if (!en || !emb || !cidx || !node_mask || !zpart || N <= 0 || N > GI_MAX_NODES || G <= 0)
         return GI_EINVAL;
     hipLaunchKernelGGL(gather_bwd_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, en, emb, ld,
-                       cidx, node_mask, N, G, S, big, dg0, ld0, dg1, ld1, dg2, ld2, zpart);
+                       cidx, node_mask, N, G, S, big, dg0, ld0, dg1, ld1, dg2, ld2, zpart, fshift);
     return gi_launch_status();
 }
 
@@ -775,11 +882,17 @@ extern "C" int gi_expand_slots(const float* t1, int ldt, const int* cidx, int B,
 
 extern "C" int gi_compress_slots(float* t1, int ldt, const int* cidx, int B, int N, int W, int S,
                                  const float* dcat, int ldc, float* zpart, int ldz, void* stream) {
+    return gi_compress_slots_f(t1, ldt, cidx, B, N, W, S, dcat, ldc, zpart, ldz, 0, stream);
+}
+
+extern "C" int gi_compress_slots_f(float* t1, int ldt, const int* cidx, int B, int N, int W, int S,
+                                   const float* dcat, int ldc, float* zpart, int ldz,
+                                   long long fshift, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (B <= 0) return 0;
     if (!t1 || !cidx || !dcat || !zpart || N <= 0 || W <= 0 || ldz < W) return GI_EINVAL;
     hipLaunchKernelGGL(compress_slots_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, t1, ldt,
-                       cidx, N, W, S, dcat, ldc, zpart, ldz);
+                       cidx, N, W, S, dcat, ldc, zpart, ldz, fshift);
     return gi_launch_status();
 }
 

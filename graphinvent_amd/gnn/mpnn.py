@@ -58,16 +58,35 @@ def _ptr_table(tensors) -> "C.Array":
     return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
-def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN):
+def _set_dropout(dims, c, kind: int, seed: int) -> None:
+    """AlphaDropout training mode (gnn/modules.py:130-142): per-stack probabilities + the mask seed."""
+    attn = kind == _L.KIND_ATTGGNN
+    dims.dropout = 1
+    dims.drop_enn = float(c.msg_dropout_p if attn else c.enn_dropout_p)
+    dims.drop_eatt = float(c.att_dropout_p) if attn else 0.0
+    dims.drop_att, dims.drop_emb = float(c.gather_att_dropout_p), float(c.gather_emb_dropout_p)
+    dims.drop_mlp1, dims.drop_mlp2 = float(c.mlp1_dropout_p), float(c.mlp2_dropout_p)
+    dims.drop_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+
+
+def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dropout_seed=None):
     """graph_compact + the fused forward.  Returns (logits, tape); the tape
-    (dims, CompactGraph, workspace, per-type edge counts) is what backward consumes."""
+    (dims, CompactGraph, workspace, per-type edge counts) is what backward consumes.
+
+    ``dropout_seed`` (an int): training mode with AlphaDropout p > 0 — the graph is compacted without
+    row sharing (every edge and every padded slot draws its own mask, as in the reference), every
+    activation gets a stored backward factor (workspace x2), and the logits tensor carries B extra
+    rows for the factors of the logits (the returned tensor is the view of the first B)."""
     lib = _L.load()
-    nodes, lay, gfix, S, E, U, D0, Ut = _ops.compact_count(nodes, edges)
+    drop = dropout_seed is not None
+    nodes, lay, gfix, S, E, U, D0, Ut = _ops.compact_count(nodes, edges, nodedup=drop)
     attn = kind != _L.KIND_GGNN
     if attn and _os_environ_flag("GI_ATT_PASS0", "1") == "0":
         D0 = 0                          # AttentionGGNN's pass 0 on message rows (measurement knob)
     B = nodes.shape[0]
     dims = _dims_from_constants(consts, B, kind)
+    if drop:
+        _set_dropout(dims, consts, kind, dropout_seed)
     if lib.gi_ggnn_num_params(C.byref(dims)) != len(params):
         raise RuntimeError("parameter table does not match the model dimensions")
     for p in params:
@@ -83,12 +102,12 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN):
     hx0 = ws[lib.gi_ggnn_hx0_offset(C.byref(dims), S, E, U, D0):]
     graph = _ops.compact_fill(nodes, lay, gfix, S, E, U, D0, Ut, hx0, ldhx, dims.H, class_csr=attn)
     apd = dims.N * dims.A + dims.N * dims.C + 1
-    out = torch.empty((B, apd), dtype=torch.float32, device=dev)
+    out = torch.empty((2 * B if drop else B, apd), dtype=torch.float32, device=dev)
     gs = graph.c_struct()
     _L.check(lib.gi_ggnn_forward(C.byref(dims), _ptr_table(params), C.byref(gs), ws.data_ptr(),
                                  out.data_ptr(), apd, torch.cuda.current_stream().cuda_stream),
              "gi_ggnn_forward")
-    return out, (dims, graph, ws)
+    return (out[:B] if drop else out), (dims, graph, ws)
 
 
 _SIDE_STREAMS = {}
@@ -179,7 +198,8 @@ class _GGNNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, nodes, edges, *params):
         start = owner._weights_final_event(nodes.device)
-        out, tape = ggnn_forward_raw(owner.constants, nodes, edges, params, owner._KIND)
+        out, tape = ggnn_forward_raw(owner.constants, nodes, edges, params, owner._KIND,
+                                     owner._next_dropout_seed())
         ctx.wt = owner._transposed_weights(tape[0], params, start)
         ctx.owner = owner
         ctx.tape = tape
@@ -211,7 +231,8 @@ class _GGNNDirect(torch.autograd.Function):
     def forward(ctx, owner, nodes, edges, anchor):
         params = owner._params()
         start = owner._weights_final_event(nodes.device) if anchor is not None else None
-        out, tape = ggnn_forward_raw(owner.constants, nodes, edges, params, owner._KIND)
+        out, tape = ggnn_forward_raw(owner.constants, nodes, edges, params, owner._KIND,
+                                     owner._next_dropout_seed())
         ctx.wt = owner._transposed_weights(tape[0], params, start) if anchor is not None else None
         ctx.owner = owner
         ctx.tape = tape
@@ -255,6 +276,22 @@ class _FusedMPNN(torch.nn.Module):
                 m.dropout_p > 0 for m in self.modules() if isinstance(m, _modules.MLP))
         return self.training and flag
 
+    #: tests: fix the mask seed of the next training-mode forwards (None: drawn from torch's CPU
+    #: generator, so ``torch.manual_seed`` makes runs repeatable); the seed used last is kept in
+    #: ``last_dropout_seed``
+    dropout_seed = None
+    last_dropout_seed = None
+
+    def _next_dropout_seed(self):
+        """None outside AlphaDropout's training mode (eval(), or every dropout_p == 0)."""
+        if not self._dropout_active():
+            return None
+        seed = self.dropout_seed
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        self.last_dropout_seed = seed
+        return seed
+
     def _params(self) -> List[torch.nn.Parameter]:
         cache = self.__dict__.get("_param_cache")
         term = self.APDReadout.fTermNet2.seq
@@ -282,10 +319,6 @@ class _FusedMPNN(torch.nn.Module):
         return new
 
     def forward(self, nodes: torch.Tensor, edges: torch.Tensor) -> torch.Tensor:
-        if self._dropout_active():
-            raise NotImplementedError(
-                "AlphaDropout with p > 0 in training mode is not implemented in the MI355X HIP "
-                "path (every reference default is p = 0.0, parameters/defaults.py:280-363)")
         params = self._params()
         if nodes.is_cuda and nodes.device.index != torch.cuda.current_device():
             # every launch goes to the current stream of the CURRENT device: make that the inputs'

@@ -27,7 +27,7 @@ EPI_BIAS, EPI_SELU, EPI_DSELU, EPI_ACCUM, GEMM_SPLITK = 1, 2, 4, 8, 16
 KIND_GGNN, KIND_ATTGGNN = 0, 1
 BWD_ALL, BWD_READOUT, BWD_PASSES = 0, 1, 2
 COUNTS = 24          # GI_COUNTS
-ABI_VERSION = 5      # GI_ABI_VERSION
+ABI_VERSION = 6      # GI_ABI_VERSION
 DTYPE_F32, DTYPE_I8 = 0, 1
 
 vp = C.c_void_p
@@ -91,7 +91,14 @@ class GgnnDims(C.Structure):
                                   "enn_depth", "enn_hidden", "att_depth", "att_hidden",
                                   "emb_depth", "emb_hidden", "mlp1_depth", "mlp1_hidden",
                                   "mlp2_depth", "mlp2_hidden")] + [("big_positive", C.c_float)] + \
-               [(n, ci) for n in ("kind", "eatt_depth", "eatt_hidden")]
+               [(n, ci) for n in ("kind", "eatt_depth", "eatt_hidden", "dropout")] + \
+               [(n, C.c_float) for n in ("drop_enn", "drop_eatt", "drop_att", "drop_emb", "drop_mlp1",
+                                         "drop_mlp2")] + [("drop_seed", C.c_ulonglong)]
+
+
+class DropoutParams(C.Structure):                       # gi_dropout_params
+    _fields_ = [("seed", C.c_ulonglong), ("id", C.c_uint), ("thresh", C.c_uint),
+                ("a", C.c_float), ("b_keep", C.c_float), ("b_drop", C.c_float)]
 
 
 # name -> (restype, argtypes); every symbol include/graphinvent_amd.h declares
@@ -99,6 +106,13 @@ SIGNATURES = {
     "gi_abi_version": (ci, []),
     "gi_compact_layout": (ci, [ci, ci, ci, C.POINTER(CompactLayout)]),
     "gi_compact_count": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp]),
+    "gi_compact_count_ex": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, ci, vp]),
+    "gi_dropout_setup": (ci, [C.c_double, C.c_ulonglong, C.c_uint, C.POINTER(DropoutParams)]),
+    "gi_alpha_dropout_fwd": (ci, [vp, ci, ci, ci, cll, C.POINTER(DropoutParams), vp]),
+    "gi_dropout_mask": (ci, [C.POINTER(DropoutParams), ci, ci, vp, ci, vp]),
+    "gi_seg_sum_dselu_f": (ci, [vp, ci, vp, vp, ci, ci, vp, ci, cll, vp]),
+    "gi_selu_bwd_rows_f": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, cll, vp]),
+    "gi_compress_slots_f": (ci, [vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, ci, cll, vp]),
     "gi_compact_fill": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci,
                              ci, ci, vp, vp, ci, vp, vp]),
     "gi_compact_class_csr": (ci, [vp, ci, ci, vp, vp, vp]),
@@ -123,6 +137,8 @@ SIGNATURES = {
                                    vp, ci, vp, ci, vp, ci, vp]),
     "gi_gather_readout_bwd": (ci, [vp, vp, ci, vp, vp, ci, ci, ci, ci, C.c_float,
                                    vp, ci, vp, ci, vp, ci, vp, vp]),
+    "gi_gather_readout_bwd_f": (ci, [vp, vp, ci, vp, vp, ci, ci, ci, ci, C.c_float,
+                                     vp, ci, vp, ci, vp, ci, vp, cll, vp]),
     "gi_expand_slots": (ci, [vp, ci, vp, ci, ci, ci, vp, ci, vp]),
     "gi_compress_slots": (ci, [vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, ci, vp]),
     "gi_colsum": (ci, [vp, ci, ci, ci, vp, vp, vp]),

@@ -144,9 +144,9 @@ def _gvar_offsets(E: int, U: int, D0: int = 0):
     return offs, o
 
 
-def _count_launch(nodes: torch.Tensor, edges: torch.Tensor):
+def _count_launch(nodes: torch.Tensor, edges: torch.Tensor, nodedup: bool = False):
     """Enqueue gi_compact_count on the current stream; returns (nodes as the kernels read them,
-    layout, gfix)."""
+    layout, gfix).  nodedup: no row sharing (AlphaDropout training mode, gi_compact_count_ex)."""
     lib = L.load()
     nodes, dt_n = _model_input(nodes, "nodes")
     edges, dt_e = _model_input(edges, "edges")
@@ -159,8 +159,9 @@ def _count_launch(nodes: torch.Tensor, edges: torch.Tensor):
     lay = L.CompactLayout()
     L.check(lib.gi_compact_layout(B, N, Fe, C.byref(lay)), "gi_compact_layout")
     gfix = torch.empty(lay.total_ints, dtype=torch.int32, device=nodes.device)
-    L.check(lib.gi_compact_count(nodes.data_ptr(), edges.data_ptr(), dt_n, B, N, Fn, Fe,
-                                 gfix.data_ptr(), _stream()), "gi_compact_count")
+    L.check(lib.gi_compact_count_ex(nodes.data_ptr(), edges.data_ptr(), dt_n, B, N, Fn, Fe,
+                                    gfix.data_ptr(), 1 if nodedup else 0, _stream()),
+            "gi_compact_count")
     return nodes, lay, gfix, Fe
 
 
@@ -229,10 +230,13 @@ def prefetch_compact(nodes: torch.Tensor, edges: torch.Tensor,
                                              weakref.ref(nodes), weakref.ref(edges))
 
 
-def compact_count(nodes: torch.Tensor, edges: torch.Tensor):
+def compact_count(nodes: torch.Tensor, edges: torch.Tensor, nodedup: bool = False):
     """Phase 1; returns (nodes, layout, gfix, S, E, U, D0, Ut).  One host read-back of 24 ints — the only
-    synchronisation point of a forward pass, unless `prefetch_compact` already ran for this batch."""
+    synchronisation point of a forward pass, unless `prefetch_compact` already ran for this batch.
+    nodedup: the layout without row sharing (a prefetched, de-duplicated result is discarded)."""
     hit = _PREFETCHED.pop(_batch_key(nodes, edges), None) if _PREFETCHED else None
+    if nodedup:
+        hit = None
     if hit is not None and not (hit[6]() is nodes and hit[7]() is edges):
         hit = None                                           # same address, different tensors: stale
     if hit is not None:
@@ -243,7 +247,7 @@ def compact_count(nodes: torch.Tensor, edges: torch.Tensor):
         gfix.record_stream(cur)
         nodes_c.record_stream(cur)
         return (nodes_c, lay, gfix) + _unpack_counts(pinned.tolist(), Fe)
-    nodes, lay, gfix, Fe = _count_launch(nodes, edges)
+    nodes, lay, gfix, Fe = _count_launch(nodes, edges, nodedup)
     counts = gfix[lay.counts:lay.counts + L.COUNTS].cpu().tolist()
     return (nodes, lay, gfix) + _unpack_counts(counts, Fe)
 
@@ -270,9 +274,10 @@ def compact_fill(nodes, lay, gfix, S, E, U, D0, Ut, hx0: torch.Tensor, ldhx: int
     return CompactGraph(B, N, Fn, Fe, S, E, U, D0, list(Ut), lay, gfix, gvar, cmat, class_csr)
 
 
-def compact(nodes: torch.Tensor, edges: torch.Tensor, H: int, class_csr: bool = False):
+def compact(nodes: torch.Tensor, edges: torch.Tensor, H: int, class_csr: bool = False,
+            nodedup: bool = False):
     """Both phases; returns (CompactGraph, hx0[S+1, ldhx])."""
-    nodes, lay, gfix, S, E, U, D0, Ut = compact_count(nodes, edges)
+    nodes, lay, gfix, S, E, U, D0, Ut = compact_count(nodes, edges, nodedup)
     ldhx = r4(H + nodes.shape[2])
     hx0 = torch.empty((S + 1, ldhx), dtype=torch.float32, device=nodes.device)
     g = compact_fill(nodes, lay, gfix, S, E, U, D0, Ut, hx0, ldhx, H, class_csr)

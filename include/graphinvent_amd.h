@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GI_ABI_VERSION 5
+#define GI_ABI_VERSION 6
 #define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
 #define GI_MAX_NODES 128      /* max max_n_nodes */
 #define GI_P0_MAX_CLASSES 256 /* max distinct node feature rows for the pass-0 shortcut */
@@ -82,6 +82,13 @@ int gi_compact_layout(int B, int N, int Fe, gi_compact_layout_t* out);
 /* phase 1: per-graph counting + global scans; fills everything in gfix. */
 int gi_compact_count(const void* nodes, const void* edges, int in_dtype, int B, int N, int Fn,
                      int Fe, int* gfix, void* stream);
+/* nodedup != 0: NO row sharing — every slot of the [B, N] grid is a compact row of its own (S = B*N;
+ * padded slots too), every edge its own message row (U = E, ordered bond type, source slot,
+ * destination), no pass-0 rows (D0 = 0).  The layout AlphaDropout's training mode needs (an
+ * independent mask per edge and per padded slot, gnn/modules.py:130-142); counts[23] records the
+ * mode for gi_compact_fill.  nodedup == 0 is gi_compact_count. */
+int gi_compact_count_ex(const void* nodes, const void* edges, int in_dtype, int B, int N, int Fn,
+                        int Fe, int* gfix, int nodedup, void* stream);
 /* phase 2 (after the host has read S, E, U from counts): the variable-size index arrays and the
  * initial node rows hx0[S+1, ldhx] = [x | 0.. | x] with the input features in columns [0,Fn) and
  * again in [H, H+Fn) (row S = 0). */
@@ -124,6 +131,7 @@ typedef struct gi_graph {
 #define GI_EPI_DSELU   4   /* v *= selu'(act[row,col]) (act = selu output)   */
 #define GI_EPI_ACCUM   8   /* v += C[row,col]                                */
 #define GI_GEMM_SPLITK 16  /* reduction range partitioned by groups/splits; C is a slab set */
+#define GI_EPI_MULACT  64  /* v *= act[row,col] (a stored factor: AlphaDropout training mode) */
 
 typedef struct gi_gemm_params {
     const float* A; const float* B; float* C;
@@ -239,6 +247,43 @@ int gi_seg_softmax_bwd(const float* en, const float* emb, int ld, const int* per
 /* out[r, c] = dY[idx ? idx[r] : r, c] * selu'(Y[r, c])  (may run in place on Y) */
 int gi_selu_bwd_rows(const float* dY, int lddy, const int* idx, const float* Y, int ldy,
                      float* out, int ldo, int rows, int cols, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * AlphaDropout, training mode with p > 0 — `torch.nn.AlphaDropout(dropout_p)` behind every
+ * Linear + SELU of gnn/modules.py:130-142 (MLP._linear_block), including the last one.
+ * ------------------------------------------------------------------------------------------
+ * One site = one MLP layer's output buffer.  keep(row, col) is a counter-based hash of (seed, id,
+ * row, col) compared with thresh = p * 2^32; nothing is stored except, `fshift` floats behind every
+ * activation, the factor d y / d z = keep * a * selu'(z) the backward multiplies by
+ * (GI_EPI_MULACT; the *_f variants below).  The arithmetic is ATen's _dropout_impl:
+ *   y = fl(fl(s * (keep ? a : 0)) + (keep ? b_keep : b_drop)),  a = ((alpha'^2 p + 1)(1 - p))^-1/2,
+ *   b = (keep - 1) * alpha' a + alpha' a p,  alpha' = 1.7580993408473766  (every scalar cast to fp32). */
+typedef struct gi_dropout_params {
+    unsigned long long seed;
+    unsigned id, thresh;
+    float a, b_keep, b_drop;
+} gi_dropout_params;
+/* fills `out` for probability p in [0, 1) (p == 0: keep everything, y == s, factor == selu') */
+int gi_dropout_setup(double p, unsigned long long seed, unsigned id, gi_dropout_params* out);
+/* in place on y[rows, 0:cols] (SELU outputs) -> AlphaDropout outputs; factors to y + fshift */
+int gi_alpha_dropout_fwd(float* y, int ldy, int rows, int cols, long long fshift,
+                         const gi_dropout_params* q, void* stream);
+/* test hook: the keep bits of one site as bytes [rows, ld] */
+int gi_dropout_mask(const gi_dropout_params* q, int rows, int cols, unsigned char* keep, int ld,
+                    void* stream);
+/* The SELU-backward sites with the factor read from `fshift` floats behind the activation instead of
+ * derived from it (fshift == 0: exactly the functions without the suffix; fshift % 4 == 0). */
+int gi_seg_sum_dselu_f(const float* vals, int ldv, const int* perm, const int* off, int rows,
+                       int cols, float* y, int ldy, long long fshift, void* stream);
+int gi_selu_bwd_rows_f(const float* dY, int lddy, const int* idx, const float* Y, int ldy,
+                       float* out, int ldo, int rows, int cols, long long fshift, void* stream);
+int gi_gather_readout_bwd_f(float* en, float* emb, int ld, const int* cidx, const int* node_mask,
+                            int B, int N, int G, int S, float big,
+                            const float* dg0, int ld0, const float* dg1, int ld1,
+                            const float* dg2, int ld2, float* zpart, long long fshift, void* stream);
+int gi_compress_slots_f(float* t1, int ldt, const int* cidx, int B, int N, int W, int S,
+                        const float* dcat, int ldc, float* zpart, int ldz, long long fshift,
+                        void* stream);
 
 /* GRU gates — torch.nn.GRUCell as used at gnn/mpnn.py:249-253,296-297, applied only to rows
  * with >=1 incoming edge (gnn/summation_mpnn.py:107,124,143-144 update only those nodes).
@@ -371,6 +416,16 @@ typedef struct gi_ggnn_dims {
      * attention energies, aggregated with gi_seg_softmax_*.  Parameter table order: msg_nns of all
      * bond types, [att_nns of all bond types,] gru, gather, APDReadout (state_dict order). */
     int kind, eatt_depth, eatt_hidden;
+    /* AlphaDropout training mode (gnn/modules.py:130-142 with dropout_p > 0; eval and p == 0: all
+     * zero).  dropout != 0: every MLP layer output goes through torch.nn.AlphaDropout with its
+     * stack's probability (enn/msg stacks, AttentionGGNN's energy stacks, gather att_nn / emb_nn,
+     * fAddNet1+fConnNet1, the three tier-2 stacks) and masks drawn from drop_seed.  Requires a graph
+     * compacted WITHOUT row sharing (gi_compact_count_ex, nodedup = 1); the workspace doubles (every
+     * activation gets a factor twin); the logits buffer `out` must have 2 B rows (rows [B, 2B) take
+     * the factors of the logits) and the same buffer must be handed to the backward as y_out. */
+    int dropout;
+    float drop_enn, drop_eatt, drop_att, drop_emb, drop_mlp1, drop_mlp2;
+    unsigned long long drop_seed;
 } gi_ggnn_dims;
 #define GI_KIND_GGNN 0
 #define GI_KIND_ATTGGNN 1

@@ -204,14 +204,43 @@ def _selu(x: torch.Tensor, prefix: str, layer: int) -> torch.Tensor:
     return SELU_SCALE * torch.where(mask, x, SELU_ALPHA * (torch.exp(x) - 1.0))
 
 
+#: Test-only: ``torch.nn.AlphaDropout(dropout_p)`` in TRAINING mode (gnn/modules.py:142; identity in
+#: eval mode and at the shipped default p = 0).  None, or a callable ``(prefix, layer, x) -> None |
+#: (p, keep)``: ``keep`` a bool tensor shaped like x (the masks an implementation under test drew,
+#: tests/dropout_masks.py) or None for torch's own generator.
+DROPOUT_HOOK = None
+ALPHA_DROPOUT_ALPHA = 1.7580993408473766     # -selu_scale * selu_alpha, ATen Dropout.cpp
+
+
+def _alpha_dropout(x: torch.Tensor, prefix: str, layer: int) -> torch.Tensor:
+    """ATen's ``_dropout_impl<feature=false, alpha=true>`` with a given keep mask, op for op (so the
+    roundings are torch's):  a = ((alpha^2 p + 1)(1 - p))^-1/2,  b = (keep - 1) * alpha a + alpha a p,
+    y = x * (keep * a) + b."""
+    spec = DROPOUT_HOOK(prefix, layer, x) if DROPOUT_HOOK is not None else None
+    if spec is None:
+        return x
+    p, keep = spec
+    if p == 0:
+        return x
+    if keep is None:
+        return torch.nn.functional.alpha_dropout(x, p, training=True)
+    alpha = ALPHA_DROPOUT_ALPHA
+    a = 1.0 / math.sqrt((alpha * alpha * p + 1) * (1 - p))
+    noise = keep.to(x.dtype)
+    b = noise.add(-1).mul_(alpha * a).add_(alpha * a * p)
+    noise = noise.mul(a)
+    return x * noise + b
+
+
 def mlp(P: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor) -> torch.Tensor:
-    """gnn/modules.py:111-170 — Linear -> SELU (-> AlphaDropout(p), identity at the default p=0)
-    for every layer *including the last*."""
+    """gnn/modules.py:111-170 — Linear -> SELU -> AlphaDropout(p) (identity in eval mode and at the
+    default p = 0) for every layer *including the last*."""
     layer = 0
     while f"{prefix}.seq.{3 * layer}.weight" in P:
         x = _selu(torch.nn.functional.linear(
             x, P[f"{prefix}.seq.{3 * layer}.weight"], P[f"{prefix}.seq.{3 * layer}.bias"]),
             prefix, layer)
+        x = _alpha_dropout(x, prefix, layer)
         layer += 1
     return x
 

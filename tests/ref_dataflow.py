@@ -32,8 +32,12 @@ def P0_ATT_OK(attn: bool) -> bool:
     return (not attn) or ATT_PASS0
 
 
-def compact(nodes: np.ndarray, edges: np.ndarray) -> Dict[str, np.ndarray]:
+def compact(nodes: np.ndarray, edges: np.ndarray, nodedup: bool = False) -> Dict[str, np.ndarray]:
     """nodes [B,N,Fn], edges [B,N,N,Fe] (any numeric dtype, one-hot bond types).
+
+    nodedup (AlphaDropout training mode, gi_compact_count_ex): no row sharing — every slot is a compact
+    row of its own (S = B*N), every edge its own message row (U = E, ordered bond type, source slot,
+    destination), no pass-0 rows.
 
     Compact rows 0..S-1 are the *active* slots in ascending slot order (a slot is active when its
     feature row is non-zero, or it has an incoming edge, or it is some edge's neighbour); row S is
@@ -59,6 +63,8 @@ def compact(nodes: np.ndarray, edges: np.ndarray) -> Dict[str, np.ndarray]:
     rowcnt = adj.sum(2).reshape(-1)                                      # incoming per dst slot
     colcnt = adj.sum(1).reshape(-1)                                      # outgoing per src slot
     active = (nodes != 0).any(2).reshape(-1) | (rowcnt > 0) | (colcnt > 0)
+    if nodedup:
+        active = np.ones(B * N, dtype=bool)
     S = int(active.sum())
     R = S + 1
     cidx = np.full(B * N, S, dtype=np.int32)
@@ -70,8 +76,12 @@ def compact(nodes: np.ndarray, edges: np.ndarray) -> Dict[str, np.ndarray]:
     dst_c = cidx[eb * N + ei]
     src_slot = eb * N + ej
     key = et * (B * N) + src_slot
+    if nodedup:                                                          # ... then destination
+        key = key * N + ei
     ukeys, in_perm = np.unique(key, return_inverse=True)                 # type-major, then slot
     U = ukeys.size
+    if nodedup:
+        ukeys = ukeys // N
     u_type = ukeys // (B * N)
     u_src = cidx[ukeys % (B * N)].astype(np.int32)
     type_cnt = np.bincount(u_type, minlength=Fe).astype(np.int32)
@@ -99,7 +109,7 @@ def compact(nodes: np.ndarray, edges: np.ndarray) -> Dict[str, np.ndarray]:
     feat = nodes.reshape(B * N, Fn)
     D0, d_src, type_off0, cmat = 0, np.zeros(0, np.int32), np.zeros(Fe + 1, np.int32), None
     binary = bool(np.all((feat == 0) | (feat == 1))) and Fn <= 62
-    if binary and E > 0:
+    if binary and E > 0 and not nodedup:
         keys = (feat != 0).astype(np.uint64) @ (np.uint64(1) << np.arange(Fn, dtype=np.uint64))
         u_slot = ukeys % (B * N)
         qkeys = np.unique(keys[u_slot])

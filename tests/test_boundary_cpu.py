@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.gi_abi_version() == L.ABI_VERSION == 5
+    assert lib.gi_abi_version() == L.ABI_VERSION == 6
 
 
 def test_host_side_planning_functions():
@@ -96,11 +96,17 @@ def test_forward_fails_loudly_off_gpu():
         model(torch.zeros(2, 13, 8), torch.zeros(2, 13, 13, 3))
 
 
-def test_dropout_in_training_mode_is_rejected_not_ignored():
+def test_dropout_in_training_mode_takes_the_hip_path_too():
+    """AlphaDropout p > 0 is implemented in HIP (tests/test_dropout_gpu.py): no eager fallback here
+    either — off the GPU it fails like every other forward; the seed logic is host-side."""
     cfg = O.make_config(mlp1_dropout_p=0.1)
     model = mpnn.GGNN(O.as_constants(cfg)).train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU"):
         model(torch.zeros(2, 13, 8), torch.zeros(2, 13, 13, 3))
+    model.dropout_seed = 5
+    assert model._next_dropout_seed() == 5 and model.last_dropout_seed == 5
+    assert model.eval()._next_dropout_seed() is None
+    assert mpnn.GGNN(O.as_constants(O.make_config())).train()._next_dropout_seed() is None
 
 
 def test_missing_library_raises(monkeypatch, tmp_path):

@@ -23,10 +23,13 @@ def rel(a, b):
 
 
 # ------------------------------------------------------------------------------------------------
-def _compact_case(n8, e8, H=16):
-    ref = D.compact(n8, e8)
+def _compact_case(n8, e8, H=16, nodedup=False):
+    ref = D.compact(n8, e8, nodedup=nodedup)
     g, hx0 = ops.compact(torch.from_numpy(n8).float().to(DEV), torch.from_numpy(e8).float().to(DEV), H,
-                         class_csr=True)
+                         class_csr=True, nodedup=nodedup)
+    if nodedup:      # every slot its own row, every edge its own message row, no pass-0 rows
+        assert (g.S, g.U, g.D0) == (n8.shape[0] * n8.shape[1], g.E, 0)
+        assert np.array_equal(g.mu_off.cpu().numpy(), np.arange(g.E + 1))
     assert (g.S, g.E, g.U) == (ref["S"], ref["E"], ref["U"])
     assert list(g.Ut) == np.diff(ref["type_off"]).tolist()
     for name in ("cidx", "slot_of", "u_src", "in_perm", "mu_off", "mu_dst", "mu_slot", "out_perm",
@@ -60,6 +63,17 @@ def test_compact_tiny_edge_cases():
     _compact_case(n8, e8)
     n8[4] = 0; e8[4] = 0; n8[4, 0, 0] = 1; e8[4, 0, 5, 1] = 1          # asymmetric, inactive neighbour
     _compact_case(n8, e8)
+
+
+def test_compact_without_row_sharing():
+    """gi_compact_count_ex(nodedup): the layout of AlphaDropout's training mode."""
+    n8, e8, _ = tiny_inputs()
+    _compact_case(n8, e8, nodedup=True)
+    e0 = e8.copy(); e0[:] = 0
+    _compact_case(n8, e0, nodedup=True)
+    for shape, B in (("gdb13", 200), ("chembl", 16)):
+        a, b, _ = synthetic.make_batch(B, **synthetic.SHAPES[shape], seed=7)
+        _compact_case(a, b, H=100, nodedup=True)
 
 
 def test_compact_no_edges_at_all():
