@@ -93,6 +93,7 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
         k_begin = kb;
         Cp += (long long)s * p.c_split_stride;
     }
+    const int split_idx = s, n_splits = nsp;
     const int m0 = m_begin + by * BM;
     const int n0 = bx * BN;
     if (m0 >= m_end) return;
@@ -394,6 +395,56 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
             }
         }
     }
+    // ---- GI_GEMM_REDUCE: the last workgroup of this output tile sums its slabs ---------------------
+    // Every thread releases its slab stores at agent scope (L2 write-back: the 8 XCD L2s are not
+    // coherent with each other), the workgroup takes a ticket on the tile's counter, and the holder of
+    // the last ticket invalidates its own L2 view before it reads the other workgroups' slabs.  The
+    // sum runs over the splits in index order whoever computes it.
+    if constexpr (A_MAJOR && B_MAJOR) {
+        if (flags & GI_GEMM_REDUCE) {
+            __shared__ int last_s;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            if (tid == 0) {
+                int* cnt = p.red_count + ((long long)g * gy + by) * gx + bx;
+                const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last_s = (old == n_splits - 1) ? 1 : 0;
+            }
+            __syncthreads();
+            if (last_s) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const float* base = Cp - (long long)split_idx * p.c_split_stride;     // slab 0
+                float* dW = p.ngroups ? const_cast<float*>(p.Bg[g]) : p.red_dW;
+                float* db = p.ngroups ? const_cast<float*>(p.biasg[g]) : p.red_db;
+                const int wcols = (p.ones_col >= 0) ? p.ones_col : p.N;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        const int col = n0 + wn * 32 * TN + tn * 32 + l31;
+                        const int row0 = m0 + wm * 32 * TM + tm * 32 + 4 * lhi;
+                        if (col >= p.N) continue;
+#pragma unroll 4
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = row0 + (r & 3) + 8 * (r >> 2);
+                            if (row >= m_end) continue;
+                            const float* src = base + (long long)row * p.ldc + col;
+                            float s0 = 0.f, s1 = 0.f;
+                            int j = 0;
+                            for (; j + 1 < n_splits; j += 2) {
+                                s0 += src[(long long)j * p.c_split_stride];
+                                s1 += src[(long long)(j + 1) * p.c_split_stride];
+                            }
+                            if (j < n_splits) s0 += src[(long long)j * p.c_split_stride];
+                            float* dst = (col < wcols) ? dW + (long long)row * p.red_ldw + col
+                                                       : (db ? db + row : nullptr);
+                            if (dst) *dst = p.red_accum ? *dst + (s0 + s1) : (s0 + s1);
+                        }
+                    }
+                }
+            }
+        }
+    }
 }
 
 template <int TM, int TN, bool A_MAJOR, bool B_MAJOR>
@@ -483,6 +534,15 @@ static int validate(const gi_gemm_params& p) {
     if (splitk && p.ngroups)
         for (int g = 0; g < p.ngroups; ++g)
             if (p.gsplit[g] < 1) return GI_EINVAL;
+    if (p.flags & GI_GEMM_REDUCE) {
+        if (!splitk || !p.a_major || !p.b_major || !p.red_count || p.red_ldw < 1) return GI_EINVAL;
+        if (p.ngroups) {
+            for (int g = 0; g < p.ngroups; ++g)
+                if (!p.Bg[g]) return GI_EINVAL;
+        } else if (!p.red_dW) {
+            return GI_EINVAL;
+        }
+    }
     return 0;
 }
 

@@ -243,7 +243,20 @@ void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
 
 // ---- wgrad slab plan ----------------------------------------------------------------------------
 struct SlabEntry { long long off, stride; int nsplit, calls, done, n_out, n_in, ld, tn, bidx, launched, reduced; };
-struct SlabPlan { SlabEntry e[160]; long long total; };
+struct SlabPlan {
+    SlabEntry e[160];
+    long long total;
+    // in-kernel slab reduction (GI_GEMM_REDUCE): arrival counters behind the slabs, one int per output
+    // tile of every weight-gradient problem of the backward; count_next = next free counter
+    long long count_off; int count_ints, count_next;
+};
+
+// Weight-gradient slabs summed by the last workgroup of each output tile inside the GEMM
+// (GI_GEMM_REDUCE) instead of by gi_reduce_slabs launches behind every batch.  GI_WGRAD_REDUCE=0/1.
+bool wgrad_reduce_in_kernel() {
+    static const bool v = getenv("GI_WGRAD_REDUCE") && atoi(getenv("GI_WGRAD_REDUCE")) != 0;
+    return v;
+}
 
 // wgrad launch shape: 64x64 output tiles.  Weight-gradient GEMMs are deferred and launched in
 // batches of up to 8 problems, so ONE problem only needs ~256 workgroups (x its share of a
@@ -259,6 +272,10 @@ void wgrad_shape(int n_out, int n_in, int red_rows, double share, int& tn, int& 
     static const double wgs = getenv("GI_WGRAD_WGS") ? atof(getenv("GI_WGRAD_WGS")) : 192.0;
     const int want = (int)(wgs * share / tiles + 0.5);
     nsplit = std::min(std::max(want, 1), std::max(1, kt / 2));
+}
+
+int entry_tiles(const SlabEntry& e) {                 // output tiles of one weight-gradient problem
+    return gi_cdiv(e.n_out, 64 * e.tn) * gi_cdiv(e.n_in + 1, 64 * e.tn);
 }
 
 void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {   // E, Et: message rows
@@ -291,7 +308,14 @@ void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {   /
     add(m.gru_whh, m.gru_bhh, 3 * d.H, d.H, R, d.passes, 1.0);
     add_mlp(m.att, R, 1); add_mlp(m.emb, R, 1); add_mlp(m.add1, R, 1); add_mlp(m.conn1, R, 1);
     add_mlp(m.add2, d.B, 1); add_mlp(m.conn2, d.B, 1); add_mlp(m.term2, d.B, 1);
-    sp.total = o;
+    // arrival counters: calls x output tiles per weight
+    long long ints = 0;
+    for (int i = 0; i < 160; ++i)
+        if (sp.e[i].calls > 0) ints += (long long)sp.e[i].calls * entry_tiles(sp.e[i]);
+    sp.count_off = gi_r4l(o);
+    sp.count_ints = (int)ints;
+    sp.count_next = 0;
+    sp.total = sp.count_off + gi_r4l(ints);
 }
 
 // ---- launch helpers -----------------------------------------------------------------------------
@@ -512,12 +536,26 @@ void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* wid
     p.nsplit = e0.nsplit; p.c_split_stride = e0.stride;
     p.tm = e0.tn; p.tn = e0.tn;                 // 1x1 (64x64 tiles) or 2x2 (128x128), see wgrad_shape
     const int slot = q.n - 1;
+    if (wgrad_reduce_in_kernel()) {
+        // the last workgroup of every output tile sums the tile's slabs into the gradient itself;
+        // later calls for the same weight (message passes) add to it — in launch order, which is why
+        // two calls for one weight never share a launch (launch_wgrad_batches)
+        const int tiles = entry_tiles(e0);
+        p.flags |= GI_GEMM_REDUCE;
+        p.red_count = reinterpret_cast<int*>(slabs + sp.count_off) + sp.count_next;
+        sp.count_next += tiles * std::max(g.n, 1);
+        p.red_ldw = e0.n_in;
+        p.red_accum = e0.done > 0 ? 1 : 0;
+        p.red_dW = r.grads[widx[0]];
+        p.red_db = r.grads[e0.bidx];
+    }
     if (g.n) {
         p.ngroups = g.n; p.grp_off = g.off;
         for (int t = 0; t < g.n; ++t) {
             SlabEntry& e = sp.e[widx[t]];
             p.Cg[t] = slabs + e.off + (long long)e.done * e.nsplit * e.stride;
             p.gsplit[t] = e.nsplit;
+            if (p.flags & GI_GEMM_REDUCE) { p.Bg[t] = r.grads[widx[t]]; p.biasg[t] = r.grads[e.bidx]; }
             e.done++;
             q.widx[slot][t] = widx[t];
         }
@@ -543,9 +581,35 @@ void launch_wgrad_batch(Run& r, const gi_gemm_params* p, int n, hipStream_t st) 
     if (nb && r.ok()) r.chk(gi_gemm_batch(b, nb, st));
 }
 
+// consecutive queued problems, up to 8 per launch; with the in-kernel reduction two problems that write
+// the same gradient (the same weight in two message passes) never share a launch — the later one adds
+// to what the earlier one wrote
+void launch_wgrad_batches(Run& r, const gi_gemm_params* p, int n, hipStream_t st) {
+    int base = 0;
+    while (base < n && r.ok()) {
+        const float* seen[8 * GI_MAX_GROUPS];
+        int cnt = 0, ns = 0;
+        while (base + cnt < n && cnt < 8) {
+            const gi_gemm_params& q = p[base + cnt];
+            if (q.flags & GI_GEMM_REDUCE) {
+                const int ng = std::max(q.ngroups, 1);
+                bool dup = false;
+                for (int t = 0; t < ng && !dup; ++t) {
+                    const float* d = q.ngroups ? q.Bg[t] : q.red_dW;
+                    for (int i = 0; i < ns && !dup; ++i) dup = seen[i] == d;
+                }
+                if (dup) break;                       // (cnt > 0: nothing has been seen before the first)
+                for (int t = 0; t < ng; ++t) seen[ns++] = q.ngroups ? q.Bg[t] : q.red_dW;
+            }
+            ++cnt;
+        }
+        launch_wgrad_batch(r, p + base, cnt, st);
+        base += cnt;
+    }
+}
+
 void flush_deferred(Run& r, Deferred& q) {
-    for (int base = 0; base < q.n && r.ok(); base += 8)
-        launch_wgrad_batch(r, q.p + base, std::min(8, q.n - base), r.st);
+    launch_wgrad_batches(r, q.p, q.n, r.st);
     q.n = 0;
 }
 
@@ -585,18 +649,19 @@ void kick_deferred(Run& r, Deferred& q, SideStream* side, bool all) {
     hipEvent_t ready = side->next();
     r.chk((int)hipEventRecord(ready, r.st));
     r.chk((int)hipStreamWaitEvent(side->st, ready, 0));
-    for (int base = 0; base < n && r.ok(); base += 8)
-        launch_wgrad_batch(r, q.p + base, std::min(8, n - base), side->st);
+    launch_wgrad_batches(r, q.p, n, side->st);
     // parameters whose last slab has just been queued: reduce them right behind, on the side stream
     // too, so that only the final pass's gradients are left for the end of the backward
+    // (nothing to launch when the GEMM reduced its own slabs)
     gi_reduce_desc descs[96 * GI_MAX_GROUPS > 160 ? 160 : 96 * GI_MAX_GROUPS];
     int nd = 0;
+    const bool in_kernel = wgrad_reduce_in_kernel();
     for (int i = 0; i < n; ++i)
         for (int k = 0; k < q.nw[i]; ++k) {
             SlabEntry& e = r.sp->e[q.widx[i][k]];
             if (++e.launched == e.calls && !e.reduced && nd < 160) {
                 e.reduced = 1;
-                descs[nd++] = reduce_desc(e, r.slabs, r.grads, q.widx[i][k]);
+                if (!in_kernel) descs[nd++] = reduce_desc(e, r.slabs, r.grads, q.widx[i][k]);
             }
         }
     if (nd && r.ok()) r.chk(gi_reduce_slabs(descs, nd, side->st));
@@ -1341,7 +1406,12 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
             for (int l = 0; l < q->layers(); ++l) fn(q->w(l));
     };
     if (phase == GI_BWD_PASSES)          // the readout half ran (and was reduced) in an earlier call
-        readout_params([&](int widx) { sp.e[widx].reduced = 1; });
+        readout_params([&](int widx) {
+            sp.e[widx].reduced = 1;
+            sp.count_next += sp.e[widx].calls * entry_tiles(sp.e[widx]);   // its arrival counters are spent
+        });
+    else if (wgrad_reduce_in_kernel() && sp.count_ints > 0)
+        r.chk((int)hipMemsetAsync(slabs + sp.count_off, 0, sizeof(int) * sp.count_ints, r.st));
     if (phase != GI_BWD_PASSES) {
     // ---- tier 2 (gnn/modules.py:265-279) ---------------------------------------------------------
     r.chk(gi_selu_bwd_rows_f(d_out, lddout, nullptr, y_out, ldout, ws + w.dzA, w.ldNA, d.B, NA,
@@ -1408,7 +1478,7 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
                 sp.e[widx].reduced = 1;
                 descs[nd++] = reduce_desc(sp.e[widx], slabs, grads, widx);
             });
-            if (r.ok()) r.chk(gi_reduce_slabs(descs, nd, r.st));
+            if (r.ok() && !wgrad_reduce_in_kernel()) r.chk(gi_reduce_slabs(descs, nd, r.st));
         }
         return r.rc;
     }
@@ -1510,6 +1580,11 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
                         r.chk((int)hipMemsetAsync(
                             slabs + e.off + (long long)e.done * e.nsplit * e.stride, 0,
                             sizeof(float) * e.nsplit * e.stride, r.st));
+                        if (wgrad_reduce_in_kernel() && e.done == 0) {   // nothing will ever write them
+                            r.chk((int)hipMemsetAsync(grads[q.w(l)], 0,
+                                                      sizeof(float) * e.n_out * e.n_in, r.st));
+                            r.chk((int)hipMemsetAsync(grads[e.bidx], 0, sizeof(float) * e.n_out, r.st));
+                        }
                         e.done++;
                     }
                 }
@@ -1542,6 +1617,6 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
     add_desc(m.gru_whh, m.gru_bhh);
     add_mlp_desc(m.att); add_mlp_desc(m.emb); add_mlp_desc(m.add1); add_mlp_desc(m.conn1);
     add_mlp_desc(m.add2); add_mlp_desc(m.conn2); add_mlp_desc(m.term2);
-    if (r.ok()) r.chk(gi_reduce_slabs(descs, nd, r.st));
+    if (r.ok() && !wgrad_reduce_in_kernel()) r.chk(gi_reduce_slabs(descs, nd, r.st));
     return r.rc;
 }

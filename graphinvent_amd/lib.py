@@ -24,6 +24,7 @@ CSRC = os.path.join(_HERE, "csrc")
 GI_MAX_GROUPS = 8
 GI_MAX_NODES = 128
 EPI_BIAS, EPI_SELU, EPI_DSELU, EPI_ACCUM, GEMM_SPLITK = 1, 2, 4, 8, 16
+EPI_MULACT, GEMM_REDUCE = 64, 128
 KIND_GGNN, KIND_ATTGGNN = 0, 1
 BWD_ALL, BWD_READOUT, BWD_PASSES = 0, 1, 2
 COUNTS = 24          # GI_COUNTS
@@ -49,7 +50,8 @@ class GemmParams(C.Structure):
                 ("ngroups", ci), ("nsplit", ci), ("max_group_rows", ci), ("ones_col", ci),
                 ("c_split_stride", cll),
                 ("Bg", vp * GI_MAX_GROUPS), ("biasg", vp * GI_MAX_GROUPS),
-                ("Cg", vp * GI_MAX_GROUPS), ("gsplit", ci * GI_MAX_GROUPS)]
+                ("Cg", vp * GI_MAX_GROUPS), ("gsplit", ci * GI_MAX_GROUPS),
+                ("red_dW", vp), ("red_db", vp), ("red_count", vp), ("red_ldw", ci), ("red_accum", ci)]
 
 
 CHAIN_MAXL, CHAIN_MAXW = 8, 256       # GI_CHAIN_MAXL, GI_CHAIN_MAXW

@@ -132,6 +132,13 @@ typedef struct gi_graph {
 #define GI_EPI_ACCUM   8   /* v += C[row,col]                                */
 #define GI_GEMM_SPLITK 16  /* reduction range partitioned by groups/splits; C is a slab set */
 #define GI_EPI_MULACT  64  /* v *= act[row,col] (a stored factor: AlphaDropout training mode) */
+#define GI_GEMM_REDUCE 128 /* with GI_GEMM_SPLITK: the workgroup that finishes an output tile LAST (per-tile
+                            * arrival counter red_count, zero before the launch) sums the tile's slabs in
+                            * split order and writes the result: column ones_col to red_db[row], the others
+                            * to red_dW[row * red_ldw + col]; added to what is there when red_accum.
+                            * Deterministic (the order of arrival only decides who sums).  Grouped
+                            * problems pass the per-group destinations in Bg[g] (dW) and biasg[g] (db),
+                            * which carry no operands in split-K mode. */
 
 typedef struct gi_gemm_params {
     const float* A; const float* B; float* C;
@@ -149,6 +156,9 @@ typedef struct gi_gemm_params {
     long long c_split_stride;             /* floats between split slabs */
     const float* Bg[GI_MAX_GROUPS]; const float* biasg[GI_MAX_GROUPS]; float* Cg[GI_MAX_GROUPS];
     int gsplit[GI_MAX_GROUPS];            /* grouped split-K: slabs of group g (>= 1 each); nsplit ignored */
+    /* GI_GEMM_REDUCE (see the flag): destinations, arrival counters [groups * row tiles * col tiles] */
+    float* red_dW; float* red_db; int* red_count;
+    int red_ldw, red_accum;
 } gi_gemm_params;
 
 int gi_gemm(const gi_gemm_params* p, void* stream);

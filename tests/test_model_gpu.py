@@ -713,3 +713,36 @@ def test_four_bond_types_aromatic_preprocessing(model_name):
     num = sum(float((grads[k].double() - g32[k].double()).pow(2).sum()) for k in grads)
     den = sum(float(g32[k].double().pow(2).sum()) for k in grads)
     assert (num / den) ** 0.5 < 2e-3, (num / den) ** 0.5
+
+
+def test_in_kernel_slab_reduction_is_equivalent(tmp_path):
+    """GI_WGRAD_REDUCE=1 (the last workgroup of each weight-gradient tile sums the slabs inside the
+    GEMM; off by default, tools/experiments/README.md): same gradients as the gi_reduce_slabs path
+    up to the association of the sums, and bit-identical from run to run.  The knob is read once per
+    process, so the other mode runs in a child process."""
+    import subprocess
+    import sys
+    script = tmp_path / "grads.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from tests.test_model_gpu import make_model, hip_forward_backward\n"
+        "from oracle import ggnn_oracle as O\n"
+        "from graphinvent_amd import synthetic\n"
+        "cfg = O.make_config(); P = O.init_params(cfg, seed=4)\n"
+        "n8, e8, a8 = synthetic.make_batch(96, **synthetic.SHAPES['gdb13'], seed=3)\n"
+        "m = make_model(cfg, P)\n"
+        "a = hip_forward_backward(m, n8, e8, a8)[2]; b = hip_forward_backward(m, n8, e8, a8)[2]\n"
+        "assert all(torch.equal(a[k], b[k]) for k in a), 'not deterministic'\n"
+        "np.savez(sys.argv[1], **{k: v.numpy() for k, v in a.items()})\n"
+        % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = {}
+    for mode in ("0", "1"):
+        out = tmp_path / f"g{mode}.npz"
+        env = dict(os.environ, GI_WGRAD_REDUCE=mode)
+        r = subprocess.run([sys.executable, str(script), str(out)], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = np.load(out)
+    for k in outs["0"].files:
+        assert rel(outs["1"][k], outs["0"][k]) < 1e-5, k
