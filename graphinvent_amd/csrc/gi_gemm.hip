@@ -396,16 +396,19 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
         }
     }
     // ---- GI_GEMM_REDUCE: the last workgroup of this output tile sums its slabs ---------------------
-    // Every thread releases its slab stores at agent scope (L2 write-back: the 8 XCD L2s are not
-    // coherent with each other), the workgroup takes a ticket on the tile's counter, and the holder of
-    // the last ticket invalidates its own L2 view before it reads the other workgroups' slabs.  The
-    // sum runs over the splits in index order whoever computes it.
+    // The workgroup's slab stores are released at agent scope (L2 write-back: the 8 XCD L2s are not
+    // coherent with each other), it takes a ticket on the tile's counter, and the holder of the last
+    // ticket invalidates its own L2 view before it reads the other workgroups' slabs.  The sum runs
+    // over the splits in index order whoever computes it.
     if constexpr (A_MAJOR && B_MAJOR) {
         if (flags & GI_GEMM_REDUCE) {
             __shared__ int last_s;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            // every wave's slab stores are in this XCD's L2 before the barrier (workgroup-scope release);
+            // ONE agent-scope release (L2 write-back) by the ticket taker then covers them all
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
             if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 int* cnt = p.red_count + ((long long)g * gy + by) * gx + bx;
                 const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 last_s = (old == n_splits - 1) ? 1 : 0;
