@@ -348,8 +348,27 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
     const int NN = N * N, ns = gridDim.x * N;
     const signed char* etype_g =
         reinterpret_cast<const signed char*>(gfix + L.etype) + (long long)b * NN;
+    // Adjacency as bit masks (N <= 128 = two 64-bit words): rowmask[i] = sources j of edges into i,
+    // colmask[t][j] = destinations i of j's type-t edges.  A rank inside a row / column is then one
+    // popcount instead of a loop over up to N table entries (N = 88: 161 -> 40 us per launch).
+    __shared__ unsigned long long rowmask[NMAX][2];
+    __shared__ unsigned long long colmask[GI_MAX_GROUPS][NMAX][2];
+    for (int idx = tid; idx < NMAX * 2; idx += 256) (&rowmask[0][0])[idx] = 0ull;
+    for (int idx = tid; idx < GI_MAX_GROUPS * NMAX * 2; idx += 256) (&colmask[0][0][0])[idx] = 0ull;
     for (int idx = tid; idx < NN; idx += 256) typ[idx] = etype_g[idx];
     __syncthreads();
+    for (int idx = tid; idx < NN; idx += 256) {
+        const int t = typ[idx];
+        if (t < 0) continue;
+        const int i = idx / N, j = idx - i * N;
+        atomicOr(&rowmask[i][j >> 6], 1ull << (j & 63));
+        atomicOr(&colmask[t][j][i >> 6], 1ull << (i & 63));
+    }
+    __syncthreads();
+    auto rank128 = [](const unsigned long long* m, int pos) {       // set bits below position pos
+        return pos < 64 ? __popcll(m[0] & ((1ull << pos) - 1ull))
+                        : __popcll(m[0]) + __popcll(m[1] & ((1ull << (pos - 64)) - 1ull));
+    };
     // nd: no de-duplication (AlphaDropout training mode) — one message row per EDGE, ordered bond type,
     // source slot, destination; the message CSR is then the identity (mu_off[u] = u)
     const bool nd = gfix[L.counts + CNT_NODEDUP] != 0;
@@ -370,12 +389,10 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
         const int t = typ[idx];
         if (t < 0) continue;
         const int i = idx / N, j = idx - i * N;
-        int rank = 0;
-        for (int jj = 0; jj < j; ++jj) rank += typ[i * N + jj] >= 0;
+        const int rank = rank128(rowmask[i], j);
         const int ed = gfix[L.seg_start + b * N + i] + rank;
-        int urank = 0;                                   // rank of this edge among j's type-t out-edges
-        if (nd)
-            for (int ii = 0; ii < i; ++ii) urank += typ[ii * N + j] == t;
+        // rank of this edge among j's type-t out-edges
+        const int urank = nd ? rank128(colmask[t][j], i) : 0;
         in_perm[ed] = gfix[L.type_off + t] + gfix[L.mstart_t + t * ns + b * N + j] + urank;
         kpos[idx] = ed;
     }
@@ -385,8 +402,7 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
         if (t < 0) continue;
         const int i = idx / N, j = idx - i * N;
         const int slot = b * N + j;
-        int rank = 0;
-        for (int ii = 0; ii < i; ++ii) rank += typ[ii * N + j] == t;
+        const int rank = rank128(colmask[t][j], i);
         const int mo = gfix[L.etype_off + t] + gfix[L.cstart_t + t * ns + slot] + rank;
         mu_dst[mo] = gfix[L.cidx + b * N + i];
         mu_slot[mo] = kpos[idx];

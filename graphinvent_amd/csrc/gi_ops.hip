@@ -267,81 +267,107 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_kernel(
 }
 
 // ---- K7 gather readout ------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void gather_fwd_kernel(
+// One workgroup per (graph, chunk of GI_GATHER_GC feature columns); the graph's energy / embedding rows of
+// the chunk are first staged in LDS by all threads (coalesced row gathers, many loads in flight) —
+// the three passes over the node axis then run out of LDS, one thread per column, in the same node
+// order as before (a thread used to walk the N rows three times through global memory with one load
+// in flight: 38 us per launch at N = 88, latency bound).  Dynamic LDS: 2 * N * GC floats (GC = 64
+// columns per workgroup, 32 for N > 112: at most 56 KB).
+template <int GI_GATHER_GC>
+__global__ __launch_bounds__(GI_GATHER_GC) void gather_fwd_kernel(
     const float* __restrict__ en, const float* __restrict__ emb, int ld,
     const int* __restrict__ cidx, const int* __restrict__ mask, int N, int G, float big,
     float* out0, int ld0, float* out1, int ld1, float* out2, int ld2) {
+    extern __shared__ float gather_lds[];
     __shared__ int c_s[GI_MAX_NODES];
     __shared__ float pen_s[GI_MAX_NODES];
-    const int b = blockIdx.x;
-    for (int n = threadIdx.x; n < N; n += 128) {
+    float* e_s = gather_lds;                               // [N][GC] energies minus the mask penalty
+    float* m_s = gather_lds + N * GI_GATHER_GC;            // [N][GC] embeddings
+    const int b = blockIdx.x, g0 = blockIdx.y * GI_GATHER_GC, tid = threadIdx.x;
+    for (int n = tid; n < N; n += GI_GATHER_GC) {
         c_s[n] = cidx[b * N + n];
         pen_s[n] = mask[b * N + n] ? 0.f : big;       // (node_mask == 0) * big_positive, modules.py:46
     }
     __syncthreads();
-    for (int g = threadIdx.x; g < G; g += 128) {
-        float m = -INFINITY;
-        for (int n = 0; n < N; ++n) m = fmaxf(m, en[(long long)c_s[n] * ld + g] - pen_s[n]);
-        float s = 0.f;
-        for (int n = 0; n < N; ++n) s += expf((en[(long long)c_s[n] * ld + g] - pen_s[n]) - m);
-        float acc = 0.f;
+    const int g = g0 + tid;
+    if (g < G) {
+#pragma unroll 4
         for (int n = 0; n < N; ++n) {
             const long long o = (long long)c_s[n] * ld + g;
-            acc += (expf((en[o] - pen_s[n]) - m) / s) * emb[o];
+            e_s[n * GI_GATHER_GC + tid] = en[o] - pen_s[n];
+            m_s[n * GI_GATHER_GC + tid] = emb[o];
         }
+        float m = -INFINITY;
+        for (int n = 0; n < N; ++n) m = fmaxf(m, e_s[n * GI_GATHER_GC + tid]);
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += expf(e_s[n * GI_GATHER_GC + tid] - m);
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n)
+            acc += (expf(e_s[n * GI_GATHER_GC + tid] - m) / s) * m_s[n * GI_GATHER_GC + tid];
         if (out0) out0[(long long)b * ld0 + g] = acc;
         if (out1) out1[(long long)b * ld1 + g] = acc;
         if (out2) out2[(long long)b * ld2 + g] = acc;
     }
 }
 
-__global__ __launch_bounds__(128) void gather_bwd_kernel(
+template <int GI_GATHER_GC>
+__global__ __launch_bounds__(GI_GATHER_GC) void gather_bwd_kernel(
     float* en, float* emb, int ld, const int* __restrict__ cidx, const int* __restrict__ mask,
     int N, int G, int S, float big, const float* __restrict__ dg0, int ld0,
     const float* __restrict__ dg1, int ld1, const float* __restrict__ dg2, int ld2,
     float* __restrict__ zpart, long long fshift) {
+    extern __shared__ float gather_lds[];
     __shared__ int c_s[GI_MAX_NODES];
     __shared__ float pen_s[GI_MAX_NODES];
-    const int b = blockIdx.x;
-    for (int n = threadIdx.x; n < N; n += 128) {
+    float* e_s = gather_lds;                               // raw energies
+    float* m_s = gather_lds + N * GI_GATHER_GC;
+    const int b = blockIdx.x, g0 = blockIdx.y * GI_GATHER_GC, tid = threadIdx.x;
+    for (int n = tid; n < N; n += GI_GATHER_GC) {
         c_s[n] = cidx[b * N + n];
         pen_s[n] = mask[b * N + n] ? 0.f : big;
     }
     __syncthreads();
     const int ldz = 2 * G;
-    for (int g = threadIdx.x; g < G; g += 128) {
-        float dg = 0.f;
-        if (dg0) dg += dg0[(long long)b * ld0 + g];
-        if (dg1) dg += dg1[(long long)b * ld1 + g];
-        if (dg2) dg += dg2[(long long)b * ld2 + g];
-        float m = -INFINITY;
-        for (int n = 0; n < N; ++n) m = fmaxf(m, en[(long long)c_s[n] * ld + g] - pen_s[n]);
-        float s = 0.f, sd = 0.f;                                 // sum p, sum p * (emb*dg)
-        for (int n = 0; n < N; ++n) {
-            const long long o = (long long)c_s[n] * ld + g;
-            const float p = expf((en[o] - pen_s[n]) - m);
-            s += p;
-            sd += p * (emb[o] * dg);
-        }
-        const float dot = sd / s;                                // sum_n att_n * datt_n
-        float zen = 0.f, zemb = 0.f;
-        for (int n = 0; n < N; ++n) {
-            const long long o = (long long)c_s[n] * ld + g;
-            const float ev = en[o], mv = emb[o];
-            const float att = expf((ev - pen_s[n]) - m) / s;
-            const float de = att * (mv * dg - dot);
-            const float dm = att * dg;
-            if (c_s[n] < S) {                                    // this slot owns its compact row
-                en[o] = de * gi_dact(en + o, fshift);
-                emb[o] = dm * gi_dact(emb + o, fshift);
-            } else {                                             // shared zero row: per-graph partial
-                zen += de;
-                zemb += dm;
-            }
-        }
-        zpart[(long long)b * ldz + g] = zen;
-        zpart[(long long)b * ldz + G + g] = zemb;
+    const int g = g0 + tid;
+    if (g >= G) return;
+    // each thread stages and later overwrites only its own column: the slots of a graph that share the
+    // zero row (c >= S) read the same, never written, row
+#pragma unroll 4
+    for (int n = 0; n < N; ++n) {
+        const long long o = (long long)c_s[n] * ld + g;
+        e_s[n * GI_GATHER_GC + tid] = en[o];
+        m_s[n * GI_GATHER_GC + tid] = emb[o];
     }
+    float dg = 0.f;
+    if (dg0) dg += dg0[(long long)b * ld0 + g];
+    if (dg1) dg += dg1[(long long)b * ld1 + g];
+    if (dg2) dg += dg2[(long long)b * ld2 + g];
+    float m = -INFINITY;
+    for (int n = 0; n < N; ++n) m = fmaxf(m, e_s[n * GI_GATHER_GC + tid] - pen_s[n]);
+    float s = 0.f, sd = 0.f;                                 // sum p, sum p * (emb*dg)
+    for (int n = 0; n < N; ++n) {
+        const float p = expf((e_s[n * GI_GATHER_GC + tid] - pen_s[n]) - m);
+        s += p;
+        sd += p * (m_s[n * GI_GATHER_GC + tid] * dg);
+    }
+    const float dot = sd / s;                                // sum_n att_n * datt_n
+    float zen = 0.f, zemb = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const long long o = (long long)c_s[n] * ld + g;
+        const float ev = e_s[n * GI_GATHER_GC + tid], mv = m_s[n * GI_GATHER_GC + tid];
+        const float att = expf((ev - pen_s[n]) - m) / s;
+        const float de = att * (mv * dg - dot);
+        const float dm = att * dg;
+        if (c_s[n] < S) {                                    // this slot owns its compact row
+            en[o] = de * gi_dact(en + o, fshift);
+            emb[o] = dm * gi_dact(emb + o, fshift);
+        } else {                                             // shared zero row: per-graph partial
+            zen += de;
+            zemb += dm;
+        }
+    }
+    zpart[(long long)b * ldz + g] = zen;
+    zpart[(long long)b * ldz + G + g] = zemb;
 }
 
 // ---- tier-1 <-> tier-2 glue ------------------------------------------------------------------
@@ -356,24 +382,34 @@ __global__ __launch_bounds__(256) void expand_slots_kernel(
     cat[(long long)b * ldc + r] = t1[(long long)cidx[b * N + n] * ldt + w];
 }
 
-__global__ __launch_bounds__(64) void compress_slots_kernel(
+// One workgroup per (graph, quarter of its N*W elements): the slots that own a compact row are
+// independent elementwise work (the old kernel walked the N slots of a column serially from 64 threads:
+// 45 us per launch at N = 88, B = 250); the per-graph sums over the slots sharing the zero row stay a
+// serial loop in slot order, done by the first workgroup of the graph.
+__global__ __launch_bounds__(256) void compress_slots_kernel(
     float* t1, int ldt, const int* __restrict__ cidx, int N, int W, int S,
     const float* __restrict__ dcat, int ldc, float* __restrict__ zpart, int ldz, long long fshift) {
-    const int b = blockIdx.x;
-    for (int w = threadIdx.x; w < W; w += 64) {
-        float z = 0.f;
-        for (int n = 0; n < N; ++n) {
-            const int c = cidx[b * N + n];
-            const float d = dcat[(long long)b * ldc + n * W + w];
-            if (c < S) {
-                float* p = t1 + (long long)c * ldt + w;
-                *p = d * gi_dact(p, fshift);
-            } else {
-                z += d;
-            }
+    __shared__ int c_s[GI_MAX_NODES];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int n = tid; n < N; n += 256) c_s[n] = cidx[b * N + n];
+    __syncthreads();
+    const int total = N * W, chunk = (total + gridDim.y - 1) / gridDim.y;
+    const int lo = blockIdx.y * chunk, hi = min(lo + chunk, total);
+    for (int idx = lo + tid; idx < hi; idx += 256) {
+        const int n = idx / W, w = idx - n * W;
+        const int c = c_s[n];
+        if (c < S) {
+            float* p = t1 + (long long)c * ldt + w;
+            *p = dcat[(long long)b * ldc + idx] * gi_dact(p, fshift);
         }
-        zpart[(long long)b * ldz + w] = z;
     }
+    if (blockIdx.y == 0)
+        for (int w = tid; w < W; w += 256) {
+            float z = 0.f;
+            for (int n = 0; n < N; ++n)
+                if (c_s[n] >= S) z += dcat[(long long)b * ldc + n * W + w];
+            zpart[(long long)b * ldz + w] = z;
+        }
 }
 
 // out[c] = (sum_r part[r, c]) * selu'(y[c]); 64 columns per block, 16 row groups, fixed tree.
@@ -531,13 +567,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // ---- KL-divergence training loss (Workflow.py:850-858), forward + gradient in one pass ----------
 // one workgroup per graph: t = target / sum(target); logp = log_softmax(out);
 // row_loss = sum_j xlogy(t_j, t_j) - t_j * logp_j;  d_out_j = (softmax_j * sum(t) - t_j) / B
-template <typename T>
-__global__ __launch_bounds__(256) void kl_loss_kernel(const float* __restrict__ out, int ldo,
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void kl_loss_kernel(const float* __restrict__ out, int ldo,
                                                       const T* __restrict__ tgt, int ldt,
                                                       int width, float inv_b,
                                                       float* __restrict__ row_loss,
                                                       float* __restrict__ d_out, int ldd) {
-    __shared__ float red[4];
+    __shared__ float red[NT / 64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float* o = out + (long long)b * ldo;
     const T* t = tgt + (long long)b * ldt;
@@ -550,19 +586,24 @@ __global__ __launch_bounds__(256) void kl_loss_kernel(const float* __restrict__ 
         __syncthreads();
         if (lane == 0) red[wid] = x;
         __syncthreads();
-        return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))
-                      : (red[0] + red[1]) + (red[2] + red[3]);
+        if (NT == 256)
+            return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))
+                          : (red[0] + red[1]) + (red[2] + red[3]);
+        float r = red[0];                                     // wide rows: the waves' partials in order
+#pragma unroll
+        for (int i = 1; i < NT / 64; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+        return r;
     };
     float mx = -INFINITY, ts = 0.f;
-    for (int j = tid; j < width; j += 256) { mx = fmaxf(mx, o[j]); ts += (float)t[j]; }
+    for (int j = tid; j < width; j += NT) { mx = fmaxf(mx, o[j]); ts += (float)t[j]; }
     mx = block_reduce(mx, true);
     ts = block_reduce(ts, false);
     float se = 0.f;
-    for (int j = tid; j < width; j += 256) se += expf(o[j] - mx);
+    for (int j = tid; j < width; j += NT) se += expf(o[j] - mx);
     se = block_reduce(se, false);
     const float lse = logf(se);
     float loss = 0.f;
-    for (int j = tid; j < width; j += 256) {
+    for (int j = tid; j < width; j += NT) {
         const float logp = (o[j] - mx) - lse;
         const float tn = (float)t[j] / ts;                // 0/0 = NaN on all-zero rows, as the reference
         loss += ((tn > 0.f) ? tn * logf(tn) : (tn == 0.f ? 0.f : tn)) - tn * logp;
@@ -842,8 +883,14 @@ extern "C" int gi_gather_readout_fwd(const float* en, const float* emb, int ld, 
     if (B <= 0) return 0;
     if (!en || !emb || !cidx || !node_mask || N <= 0 || N > GI_MAX_NODES || G <= 0 || ld < G)
         return GI_EINVAL;
-    hipLaunchKernelGGL(gather_fwd_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, en, emb, ld,
-                       cidx, node_mask, N, G, big, out0, ld0, out1, ld1, out2, ld2);
+    if (N > 112)
+        hipLaunchKernelGGL(gather_fwd_kernel<32>, dim3(B, gi_cdiv(G, 32)), dim3(32),
+                           sizeof(float) * 2 * N * 32, (hipStream_t)stream, en, emb, ld, cidx, node_mask,
+                           N, G, big, out0, ld0, out1, ld1, out2, ld2);
+    else
+        hipLaunchKernelGGL(gather_fwd_kernel<64>, dim3(B, gi_cdiv(G, 64)), dim3(64),
+                           sizeof(float) * 2 * N * 64, (hipStream_t)stream, en, emb, ld, cidx, node_mask,
+                           N, G, big, out0, ld0, out1, ld1, out2, ld2);
     return gi_launch_status();
 }
 
@@ -864,8 +911,14 @@ extern "C" int gi_gather_readout_bwd_f(float* en, float* emb, int ld, const int*
     if (B <= 0) return 0;
     if (!en || !emb || !cidx || !node_mask || !zpart || N <= 0 || N > GI_MAX_NODES || G <= 0)
         return GI_EINVAL;
-    hipLaunchKernelGGL(gather_bwd_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, en, emb, ld,
-                       cidx, node_mask, N, G, S, big, dg0, ld0, dg1, ld1, dg2, ld2, zpart, fshift);
+    if (N > 112)
+        hipLaunchKernelGGL(gather_bwd_kernel<32>, dim3(B, gi_cdiv(G, 32)), dim3(32),
+                           sizeof(float) * 2 * N * 32, (hipStream_t)stream, en, emb, ld, cidx, node_mask,
+                           N, G, S, big, dg0, ld0, dg1, ld1, dg2, ld2, zpart, fshift);
+    else
+        hipLaunchKernelGGL(gather_bwd_kernel<64>, dim3(B, gi_cdiv(G, 64)), dim3(64),
+                           sizeof(float) * 2 * N * 64, (hipStream_t)stream, en, emb, ld, cidx, node_mask,
+                           N, G, S, big, dg0, ld0, dg1, ld1, dg2, ld2, zpart, fshift);
     return gi_launch_status();
 }
 
@@ -891,7 +944,9 @@ extern "C" int gi_compress_slots_f(float* t1, int ldt, const int* cidx, int B, i
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (B <= 0) return 0;
     if (!t1 || !cidx || !dcat || !zpart || N <= 0 || W <= 0 || ldz < W) return GI_EINVAL;
-    hipLaunchKernelGGL(compress_slots_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, t1, ldt,
+    if (N > GI_MAX_NODES) return GI_ELIMIT;
+    const int parts = (long long)N * W >= 4096 ? 4 : 1;
+    hipLaunchKernelGGL(compress_slots_kernel, dim3(B, parts), dim3(256), 0, (hipStream_t)stream, t1, ldt,
                        cidx, N, W, S, dcat, ldc, zpart, ldz, fshift);
     return gi_launch_status();
 }
@@ -1012,13 +1067,16 @@ extern "C" int gi_kl_loss(const float* out, int ldo, const void* target, int tgt
     if (B <= 0) return 0;
     if (!out || !target || !row_loss || width <= 0 || ldo < width || ldt < width) return GI_EINVAL;
     const hipStream_t st = (hipStream_t)stream;
-    if (tgt_dtype == GI_DTYPE_F32)
-        hipLaunchKernelGGL(kl_loss_kernel<float>, dim3(B), dim3(256), 0, st, out, ldo,
-                           (const float*)target, ldt, width, 1.f / (float)B, row_loss, d_out, ldd);
-    else if (tgt_dtype == GI_DTYPE_I8)
-        hipLaunchKernelGGL(kl_loss_kernel<signed char>, dim3(B), dim3(256), 0, st, out, ldo,
-                           (const signed char*)target, ldt, width, 1.f / (float)B, row_loss, d_out,
-                           ldd);
+    // rows wider than 2048 logits (ZINC / ChEMBL shapes: 4 k - 10 k) get 1024 threads each
+#define GI_KL_LAUNCH(T_, NT_)                                                                     \
+    hipLaunchKernelGGL((kl_loss_kernel<T_, NT_>), dim3(B), dim3(NT_), 0, st, out, ldo,            \
+                       (const T_*)target, ldt, width, 1.f / (float)B, row_loss, d_out, ldd)
+    if (tgt_dtype == GI_DTYPE_F32) {
+        if (width > 2048) GI_KL_LAUNCH(float, 1024); else GI_KL_LAUNCH(float, 256);
+    } else if (tgt_dtype == GI_DTYPE_I8) {
+        if (width > 2048) GI_KL_LAUNCH(signed char, 1024); else GI_KL_LAUNCH(signed char, 256);
+    }
+#undef GI_KL_LAUNCH
     else
         return GI_EINVAL;
     if (loss_mean)       // the batch mean right behind the row kernel, fixed summation order
