@@ -146,11 +146,27 @@ struct Ws {
     // AlphaDropout training mode: the workspace is allocated twice; float i of the second half holds
     // the backward factor d y / d z of activation i of the first (0: mode off)
     long long fshift;
+    // split-K slabs of the skinny, long-reduction layers of the graph-level stacks (skinny_splits)
+    long long skinny, skinny_floats;
     long long total;
 };
 
 bool chain_fits(const Mlp& q, int dx_cols);
 long long chain_image_floats(const Mlp& q, int groups, bool backward, long long* stride);
+
+// A forward / dgrad problem with few output tiles and a long reduction (the first layer of fAddNet2 at
+// the ChEMBL shape: 250 x 500 outputs, K = N*A + G = 9 252 — 32 workgroups walking 290 k tiles each,
+// 165 us) runs split-K into slabs and gets its epilogue from gi_slab_epilogue: 16 x 32 workgroups of
+// 18 k tiles.  Returns the number of splits (1: leave the problem alone).
+int skinny_splits(int rows, int cols, int K) {
+    const int tiles = gi_cdiv(rows, 64) * gi_cdiv(cols, 64);
+    if (tiles >= 256 || K < 2048) return 1;
+    return std::min(16, std::max(2, std::min(K / 512, 768 / tiles)));
+}
+long long skinny_floats(int rows, int cols, int K) {
+    const int n = skinny_splits(rows, cols, K);
+    return n > 1 ? (long long)n * gi_r4l((long long)rows * gi_r4(cols)) : 0;
+}
 
 void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
     const gi_ggnn_dims& d = m.d;
@@ -224,6 +240,21 @@ void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
     for (int l = 0; l < d.mlp1_depth; ++l) { w.add1_dz[l] = take(R, w.ldM1); w.conn1_dz[l] = take(R, w.ldM1); }
     for (int l = 0; l < d.mlp2_depth; ++l) {
         w.add2_dz[l] = take(B, w.ldM2); w.conn2_dz[l] = take(B, w.ldM2); w.term2_dz[l] = take(B, w.ldM2);
+    }
+    {   // graph-level stacks: forward layers (K = fan_in) and dgrad layers (K = fan_out), B rows each;
+        // one launch holds at most one problem per stack
+        const Mlp* t2[3] = {&m.add2, &m.conn2, &m.term2};
+        long long need = 0;
+        for (const Mlp* q : t2) {
+            long long worst = 0;
+            for (int l = 0; l < q->layers(); ++l) {
+                worst = std::max(worst, skinny_floats(d.B, q->fan_out(l), q->fan_in(l)));
+                worst = std::max(worst, skinny_floats(d.B, q->fan_in(l), q->fan_out(l)));
+            }
+            need += worst;
+        }
+        w.skinny_floats = need;
+        w.skinny = take(std::max(need, 4LL), 1);
     }
     w.gru_img = -1;
     if (d.passes > 0 && !d.dropout && gi_gru_image_floats(d.H, d.M) > 0)
@@ -340,6 +371,9 @@ struct Run {
     unsigned long long seed = 0;
     long long fshift = 0;                   // activation -> its stored backward factor (floats)
     int pass = 0;                           // message pass being evaluated (part of the site id)
+    // scratch for split-K slabs of skinny problems inside one batched launch (reset by flush_batch)
+    float* skinny = nullptr;
+    long long skinny_floats = 0, skinny_used = 0;
     struct SlabPlan* sp = nullptr; // backward only: where the wgrad slabs go and what they reduce to
     float* slabs = nullptr;
     float* const* grads = nullptr;
@@ -465,11 +499,35 @@ struct MlpJob {
     long long out_fshift = 0;                    // dropout mode: factor twin of `out` when it is not in ws
 };
 
+struct SlabEpilogue {               // gi_slab_epilogue arguments of a problem that went split-K
+    const float* slabs; int nsplit; long long stride; int rows, cols, ld, flags;
+    const float* bias; const float* act; int ldact; float* out; int ldo;
+};
+
 struct Batch {
     gi_gemm_params p[8];
-    int n = 0;
+    SlabEpilogue post[8];
+    int n = 0, npost = 0;
     gi_gemm_params& next() { gemm_defaults(p[n]); return p[n++]; }
 };
+
+// Turns the forward / dgrad problem p (output p.C[M, N], epilogue p.flags) into a split-K problem
+// writing slabs when it is skinny and long (skinny_splits) and scratch is left; the epilogue moves to
+// a gi_slab_epilogue launch behind the batch.
+void maybe_split_k(Batch& b, Run& r, gi_gemm_params& p) {
+    const int ns = skinny_splits(p.M, p.N, p.K);
+    if (ns <= 1 || p.ngroups || p.a_idx || b.npost >= 8) return;
+    const int ld = gi_r4(p.N);
+    const long long stride = gi_r4l((long long)p.M * ld), need = stride * ns;
+    if (!r.skinny || r.skinny_used + need > r.skinny_floats) return;
+    SlabEpilogue& e = b.post[b.npost++];
+    e = SlabEpilogue{r.skinny + r.skinny_used, ns, stride, p.M, p.N, ld, p.flags, p.bias, p.act, p.ldact,
+                     p.C, p.ldc};
+    p.C = r.skinny + r.skinny_used; p.ldc = ld;
+    p.flags = GI_GEMM_SPLITK; p.bias = nullptr; p.act = nullptr;
+    p.nsplit = ns; p.c_split_stride = stride;
+    r.skinny_used += need;
+}
 
 // Weight-gradient GEMMs only feed the final slab reduction, so they are collected here while the
 // dZ chain (the critical path) runs and launched afterwards in batches of 8 problems.
@@ -482,7 +540,7 @@ struct Deferred {
 };
 
 void flush_batch(Run& r, Batch& b, bool wgrad) {
-    if (!r.ok() || b.n == 0) { b.n = 0; return; }
+    if (!r.ok() || b.n == 0) { b.n = 0; b.npost = 0; r.skinny_used = 0; return; }
     if (!wgrad) {                               // common tile for the whole launch
         long long b11 = 0;
         for (int i = 0; i < b.n; ++i) b11 += (long long)gi_cdiv(b.p[i].M, 64) * gi_cdiv(b.p[i].N, 64);
@@ -490,7 +548,13 @@ void flush_batch(Run& r, Batch& b, bool wgrad) {
         for (int i = 0; i < b.n; ++i) { b.p[i].tm = 1; b.p[i].tn = tn; }
     }
     r.chk(gi_gemm_batch(b.p, b.n, r.st));
-    b.n = 0;
+    for (int i = 0; i < b.npost && r.ok(); ++i) {
+        const SlabEpilogue& e = b.post[i];
+        r.chk(gi_slab_epilogue(e.slabs, e.nsplit, e.stride, e.rows, e.cols, e.ld, e.flags, e.bias, e.act,
+                               e.ldact, e.out, e.ldo, r.st));
+    }
+    b.n = 0; b.npost = 0;
+    r.skinny_used = 0;          // (the next batch's slabs are written behind these epilogues in stream order)
 }
 
 void add_fwd(Batch& b, Run& r, const float* W, const float* bias, int in, int out, const float* X,
@@ -500,9 +564,10 @@ void add_fwd(Batch& b, Run& r, const float* W, const float* bias, int in, int ou
     p.A = X; p.lda = ldx; p.B = W; p.ldb = in; p.bias = bias; p.C = Y; p.ldc = ldy;
     p.M = rows; p.N = out; p.K = in;
     p.flags = GI_EPI_BIAS | (selu ? GI_EPI_SELU : 0);
+    maybe_split_k(b, r, p);
 }
 
-void add_dgrad(Batch& b, const Run& r, int widx, int n_out, int n_in, int ncols, const float* dZ,
+void add_dgrad(Batch& b, Run& r, int widx, int n_out, int n_in, int ncols, const float* dZ,
                int lddz, int rows, float* dX, int lddx, const float* act, int ldact,
                bool accumulate) {
     if (rows <= 0) return;
@@ -510,6 +575,7 @@ void add_dgrad(Batch& b, const Run& r, int widx, int n_out, int n_in, int ncols,
     p.A = dZ; p.lda = lddz; p.B = dgrad_operand(r, widx, n_out, n_in, p); p.C = dX; p.ldc = lddx;
     p.M = rows; p.N = ncols; p.K = n_out;
     dact(r, p, act, ldact, accumulate);
+    maybe_split_k(b, r, p);
 }
 
 void flush_deferred(Run& r, Deferred& q);
@@ -1164,6 +1230,7 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
     make_ws(m, S, E, U, gp->D0, w);
     Run r{(hipStream_t)stream, params, 0};
     r.drop = d.dropout != 0; r.seed = d.drop_seed; r.fshift = w.fshift;
+    r.skinny = ws + w.skinny; r.skinny_floats = w.skinny_floats;
     const int R = w.R;
     int maxUt = 0;
     for (int t = 0; t < d.Fe; ++t) maxUt = std::max(maxUt, Ut[t]);
@@ -1375,6 +1442,7 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
     const Grp bytype0{d.Fe, gfix + L.type_off0, w.D0};
     Run r{(hipStream_t)stream, params, 0};
     r.drop = d.dropout != 0; r.seed = d.drop_seed; r.fshift = w.fshift;
+    r.skinny = ws + w.skinny; r.skinny_floats = w.skinny_floats;
     const long long out_fshift = r.drop ? (long long)d.B * ldout : 0;   // logits -> their factors
     const int R = w.R;
     int maxUt = 0;

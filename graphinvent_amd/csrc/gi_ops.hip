@@ -91,6 +91,34 @@ __global__ __launch_bounds__(256) void slab_sum_dselu_kernel(const float* __rest
     }
 }
 
+// out[r, c] = epilogue(sum_s slabs[s * stride + r * ld + c]): finishes a split-K GEMM whose epilogue could
+// not run per slab (bias + SELU of a forward layer; the SELU-backward factor of a dgrad).  Splits are
+// summed in index order, two accumulators (even / odd), like gi_reduce_slabs.
+__global__ __launch_bounds__(256) void slab_epilogue_kernel(
+    const float* __restrict__ slabs, int nsplit, long long stride, int rows, int cols, int ld,
+    int flags, const float* __restrict__ bias, const float* __restrict__ act, int ldact,
+    float* __restrict__ out, int ldo) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int r = (int)(t / cols), c = (int)(t - (long long)r * cols);
+    if (r >= rows) return;
+    const float* src = slabs + (long long)r * ld + c;
+    float s0 = 0.f, s1 = 0.f;
+    int j = 0;
+    for (; j + 1 < nsplit; j += 2) {
+        s0 += src[(long long)j * stride];
+        s1 += src[(long long)(j + 1) * stride];
+    }
+    if (j < nsplit) s0 += src[(long long)j * stride];
+    float x = s0 + s1;
+    if (flags & GI_EPI_BIAS) x += bias[c];
+    if (flags & GI_EPI_SELU) x = gi_selu(x);
+    if (flags & GI_EPI_DSELU) x *= gi_selu_grad(act[(long long)r * ldact + c]);
+    if (flags & GI_EPI_MULACT) x *= act[(long long)r * ldact + c];
+    float* dst = out + (long long)r * ldo + c;
+    if (flags & GI_EPI_ACCUM) x += *dst;
+    *dst = x;
+}
+
 // ---- AttGGNN attention aggregation (gnn/mpnn.py:370-389) ------------------------------------------
 // One thread per (destination row, 16-byte feature group).  The reference pads every node's
 // neighbour list to the batch's maximum degree and masks with -1e6; here the softmax runs over the
@@ -789,6 +817,21 @@ extern "C" int gi_slab_sum_dselu(const float* slabs, int nsplit, long long strid
     const long long outputs = (long long)rows * cols;
     hipLaunchKernelGGL(slab_sum_dselu_kernel, dim3((unsigned)((outputs + 15) / 16)), dim3(256), 0,
                        (hipStream_t)stream, slabs, nsplit, stride, rows, cols, ld, y, ldy);
+    return gi_launch_status();
+}
+
+extern "C" int gi_slab_epilogue(const float* slabs, int nsplit, long long stride, int rows, int cols,
+                                int ld, int flags, const float* bias, const float* act, int ldact,
+                                float* out, int ldo, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
+    if (rows <= 0 || cols <= 0) return 0;
+    if (!slabs || !out || nsplit < 1 || ld < cols || ldo < cols) return GI_EINVAL;
+    if ((flags & GI_EPI_BIAS) && !bias) return GI_EINVAL;
+    if ((flags & (GI_EPI_DSELU | GI_EPI_MULACT)) && (!act || ldact < cols)) return GI_EINVAL;
+    const long long threads = (long long)rows * cols;
+    hipLaunchKernelGGL(slab_epilogue_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, slabs, nsplit, stride, rows, cols, ld, flags, bias, act, ldact,
+                       out, ldo);
     return gi_launch_status();
 }
 

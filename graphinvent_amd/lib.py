@@ -28,7 +28,7 @@ EPI_MULACT, GEMM_REDUCE = 64, 128
 KIND_GGNN, KIND_ATTGGNN = 0, 1
 BWD_ALL, BWD_READOUT, BWD_PASSES = 0, 1, 2
 COUNTS = 24          # GI_COUNTS
-ABI_VERSION = 6      # GI_ABI_VERSION
+ABI_VERSION = 7      # GI_ABI_VERSION
 DTYPE_F32, DTYPE_I8 = 0, 1
 
 vp = C.c_void_p
@@ -129,6 +129,7 @@ SIGNATURES = {
     "gi_seg_softmax_bwd": (ci, [vp, vp, ci, vp, vp, ci, ci, vp, ci, vp, vp, ci, vp]),
     "gi_seg_sum_dselu": (ci, [vp, ci, vp, vp, ci, ci, vp, ci, vp]),
     "gi_slab_sum_dselu": (ci, [vp, ci, cll, ci, ci, ci, vp, ci, vp]),
+    "gi_slab_epilogue": (ci, [vp, ci, cll, ci, ci, ci, ci, vp, vp, ci, vp, ci, vp]),
     "gi_selu_bwd_rows": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, vp]),
     "gi_gru_fused_fwd": (ci, [C.POINTER(GruParams), vp]),
     "gi_gru_pack": (ci, [C.POINTER(GruParams), vp]),

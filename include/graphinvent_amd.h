@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GI_ABI_VERSION 6
+#define GI_ABI_VERSION 7
 #define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
 #define GI_MAX_NODES 128      /* max max_n_nodes */
 #define GI_P0_MAX_CLASSES 256 /* max distinct node feature rows for the pass-0 shortcut */
@@ -237,6 +237,14 @@ int gi_class_sum_dselu(const float* vals0, const float* vals1, int ldv, const in
                        int rows, int cols, float* y0, float* y1, int ldy, void* stream);
 int gi_slab_sum_dselu(const float* slabs, int nsplit, long long stride, int rows, int cols, int ld,
                       float* y, int ldy, void* stream);
+
+/* out[r, c] = epilogue(sum_{s < nsplit} slabs[s * stride + r * ld + c]), epilogue = GI_EPI_* flags as in
+ * gi_gemm (BIAS, SELU, DSELU / MULACT through act, ACCUM): finishes a GI_GEMM_SPLITK forward / dgrad
+ * problem — the skinny, long-reduction layers of the graph-level stacks (B rows, K = N*A + G: 9 252 at the
+ * ChEMBL shape) run split-K so that more than a handful of workgroups share the reduction. */
+int gi_slab_epilogue(const float* slabs, int nsplit, long long stride, int rows, int cols, int ld,
+                     int flags, const float* bias, const float* act, int ldact, float* out, int ldo,
+                     void* stream);
 
 /* Attention aggregation of AttentionGGNN — replaces `aggregate_message` (gnn/mpnn.py:370-389:
  * mask, Softmax(dim=1) over the padded neighbour axis, weighted sum) on the destination CSR:

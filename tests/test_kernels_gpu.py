@@ -127,6 +127,35 @@ def test_gemm_forward_bias_selu(M, N, K, tm, tn):
     assert bool((Y[:, N:] == 7.0).all())                # nothing written outside [M, N]
 
 
+@pytest.mark.parametrize("b_major", [False, True])
+def test_gemm_split_k_forward_and_dgrad_with_slab_epilogue(b_major):
+    """The skinny, long-reduction layers of the graph-level stacks (B x 500 outputs, K = N*A + G): split-K into
+    slabs + gi_slab_epilogue (bias + SELU, or the SELU-backward factor) against the fp64 product."""
+    import ctypes as C
+    lib = L.load()
+    M, N, K, ns = 250, 500, 9252, 16
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(M, ops.r4(K), generator=g)
+    W = (torch.randn(K, N, generator=g) if b_major else torch.randn(N, K, generator=g)) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    act = torch.selu(torch.randn(M, ops.r4(N), generator=g))
+    ld = ops.r4(N)
+    stride = ops.r4(M * ld)
+    slabs = torch.full((ns * stride,), float("nan"), device=DEV)
+    ops.gemm(X.to(DEV), W.to(DEV), slabs, M, N, K, X.shape[1], W.shape[1], ld, flags=L.GEMM_SPLITK,
+             b_major=b_major, nsplit=ns, c_split_stride=stride)
+    out = torch.full((M, ld + 4), 7.0, device=DEV)
+    flags = L.EPI_DSELU if b_major else (L.EPI_BIAS | L.EPI_SELU)
+    bd, ad = b.to(DEV), act.to(DEV)
+    L.check(lib.gi_slab_epilogue(slabs.data_ptr(), ns, stride, M, N, ld, flags, bd.data_ptr(),
+                                 ad.data_ptr(), ad.shape[1], out.data_ptr(), out.shape[1],
+                                 torch.cuda.current_stream().cuda_stream), "gi_slab_epilogue")
+    prod = X[:, :K].double() @ (W.double() if b_major else W.double().t())
+    ref = prod * D.selu_grad_from_out(act[:, :N].double()) if b_major else D.selu(prod + b.double())
+    assert rel(out[:, :N], ref) < 2e-5
+    assert bool((out[:, N:] == 7.0).all())
+
+
 def test_gemm_forward_gather_and_groups():
     g = torch.Generator().manual_seed(1)
     R, K, N, E = 200, 100, 250, 777
