@@ -353,6 +353,22 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
     // popcount instead of a loop over up to N table entries (N = 88: 161 -> 40 us per launch).
     __shared__ unsigned long long rowmask[NMAX][2];
     __shared__ unsigned long long colmask[GI_MAX_GROUPS][NMAX][2];
+    // per-slot scalars of this graph, read once (the cell loops below used to fetch them from global
+    // memory per cell, one dependent load after another)
+    __shared__ int seg_s[NMAX], cidx_s[NMAX], cls_s[NMAX];
+    __shared__ int mstart_s[GI_MAX_GROUPS][NMAX], cstart_s[GI_MAX_GROUPS][NMAX];
+    __shared__ int toff_s[GI_MAX_GROUPS], etoff_s[GI_MAX_GROUPS];
+    for (int i = tid; i < N; i += 256) {
+        seg_s[i] = gfix[L.seg_start + b * N + i];
+        cidx_s[i] = gfix[L.cidx + b * N + i];
+        cls_s[i] = D0 > 0 ? gfix[L.cls + b * N + i] : 0;
+    }
+    for (int idx = tid; idx < Fe * N; idx += 256) {
+        const int t = idx / N, i = idx - t * N;
+        mstart_s[t][i] = gfix[L.mstart_t + t * ns + b * N + i];
+        cstart_s[t][i] = gfix[L.cstart_t + t * ns + b * N + i];
+    }
+    if (tid < Fe) { toff_s[tid] = gfix[L.type_off + tid]; etoff_s[tid] = gfix[L.etype_off + tid]; }
     for (int idx = tid; idx < NMAX * 2; idx += 256) (&rowmask[0][0])[idx] = 0ull;
     for (int idx = tid; idx < GI_MAX_GROUPS * NMAX * 2; idx += 256) (&colmask[0][0][0])[idx] = 0ull;
     for (int idx = tid; idx < NN; idx += 256) typ[idx] = etype_g[idx];
@@ -390,10 +406,10 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
         if (t < 0) continue;
         const int i = idx / N, j = idx - i * N;
         const int rank = rank128(rowmask[i], j);
-        const int ed = gfix[L.seg_start + b * N + i] + rank;
+        const int ed = seg_s[i] + rank;
         // rank of this edge among j's type-t out-edges
         const int urank = nd ? rank128(colmask[t][j], i) : 0;
-        in_perm[ed] = gfix[L.type_off + t] + gfix[L.mstart_t + t * ns + b * N + j] + urank;
+        in_perm[ed] = toff_s[t] + mstart_s[t][j] + urank;
         kpos[idx] = ed;
     }
     __syncthreads();                                     // kpos complete, cmat rows zeroed
@@ -403,20 +419,20 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
         const int i = idx / N, j = idx - i * N;
         const int slot = b * N + j;
         const int rank = rank128(colmask[t][j], i);
-        const int mo = gfix[L.etype_off + t] + gfix[L.cstart_t + t * ns + slot] + rank;
-        mu_dst[mo] = gfix[L.cidx + b * N + i];
+        const int mo = etoff_s[t] + cstart_s[t][j] + rank;
+        mu_dst[mo] = cidx_s[i];
         mu_slot[mo] = kpos[idx];
         if (nd) {                                        // this edge's own message row
-            const int u = gfix[L.type_off + t] + gfix[L.mstart_t + t * ns + slot] + rank;
+            const int u = toff_s[t] + mstart_s[t][j] + rank;
             int before = 0;                              // rows of lower bond types sent by the slot
             for (int tt = 0; tt < t; ++tt) before += gfix[L.colcnt_t + tt * ns + slot];
-            u_src[u] = gfix[L.cidx + slot];
+            u_src[u] = cidx_s[j];
             out_perm[gfix[L.srcm_start + slot] + before + rank] = u;
             mu_off[u] = mo;
         }
         if (D0 > 0) {  // counts are small integers: float atomics are exact and order-independent
-            const int d = gfix[L.dmap + t * P0Q + gfix[L.cls + slot]];
-            atomicAdd(cmat + (long long)gfix[L.cidx + b * N + i] * ldc0 + d, 1.f);
+            const int d = gfix[L.dmap + t * P0Q + cls_s[j]];
+            atomicAdd(cmat + (long long)cidx_s[i] * ldc0 + d, 1.f);
             if (e2d) e2d[kpos[idx]] = d;                 // dst-CSR edge slot -> pass-0 row
         }
     }

@@ -387,8 +387,8 @@ __global__ __launch_bounds__(GI_GATHER_GC) void gather_bwd_kernel(
         const float de = att * (mv * dg - dot);
         const float dm = att * dg;
         if (c_s[n] < S) {                                    // this slot owns its compact row
-            en[o] = de * gi_dact(en + o, fshift);
-            emb[o] = dm * gi_dact(emb + o, fshift);
+            en[o] = de * (fshift ? en[o + fshift] : gi_selu_grad(ev));
+            emb[o] = dm * (fshift ? emb[o + fshift] : gi_selu_grad(mv));
         } else {                                             // shared zero row: per-graph partial
             zen += de;
             zemb += dm;
