@@ -1529,7 +1529,16 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
                    w.ldG, dhc, w.ldH, d.H, false};
         jobs[3] = {&m.att, hxP, w.ldhx, R, w.att_act, w.ldAtt, nullptr, 0, w.att_dz, ws + w.en, w.ldG,
                    dhd, w.ldH, d.H, false};
+        // No weight-gradient batches beside the node-level dgrad launches: those fill the device by
+        // themselves (2 760 workgroups each at the headline batch), two streams only contend there;
+        // everything queued goes out behind them, under the message passes' short launches.  Step
+        // 2.362 -> 2.344 ms, GEMM-family per-launch figure 0.349 -> 0.374 of peak (GI_HOLD_NODE_WGRADS=0
+        // restores the old schedule).
+        static const bool hold = !(getenv("GI_HOLD_NODE_WGRADS") && atoi(getenv("GI_HOLD_NODE_WGRADS")) == 0);
+        r.hold_kicks = hold;
         mlp_jobs_backward(r, ws, sp, slabs, dq, jobs, 4);
+        r.hold_kicks = false;
+        if (hold && r.side) kick_deferred(r, dq, r.side, false);
     }
     }   // phase != GI_BWD_PASSES
     if (phase == GI_BWD_READOUT) {
