@@ -129,7 +129,7 @@ def _side_stream(device: torch.device) -> int:
 
 
 def _side_stream_max_rows() -> int:
-    return int(_os_environ_flag("GI_SIDE_MAX_ROWS", "18000"))
+    return int(_os_environ_flag("GI_SIDE_MAX_ROWS", str(1 << 62)))
 
 
 def _os_environ_flag(name: str, default: str) -> str:
@@ -177,10 +177,11 @@ def ggnn_backward_raw(tape, out, d_out, params, early_hook=None, bucket=None, wt
     slabs = torch.empty(max(int(n_slab), 4), dtype=torch.float32, device=dev)
     gflat, grads, offs = bucket if bucket is not None else new_grad_bucket(params, dev)
     main = torch.cuda.current_stream(dev)
-    # The weight-gradient GEMMs overlap the dZ chain on a second stream only while the chain's launches
-    # leave the device partly idle: up to ~18 k compact node rows the step gains 1-4 %, beyond that the
-    # chain fills the CUs by itself and two streams only contend (GDB-13 shape B=3000, ZINC shape
-    # B=1000, 22-23 k rows: 3-4 % slower with the side stream; tools/ab_run35.sh, ab_run36.sh).
+    # The weight-gradient GEMMs overlap the dZ chain on a second stream (gi_ggnn_backward holds them back
+    # while the node-level dgrad launches fill the device by themselves).  GI_SIDE_MAX_ROWS=<rows>
+    # (measurements) turns the second stream off for batches with at least that many compact node rows:
+    # before the hold the overlap LOST 3-4 % beyond ~18 k rows (ZINC shape B=1000), with it it gains
+    # 1-2 % there too (tools/ab_run35.sh, ab_run36.sh).
     side = _side_stream(dev) if graph.S < _side_stream_max_rows() else 0
     args = (C.byref(dims), _ptr_table(params), C.byref(gs), ws.data_ptr(), slabs.data_ptr(),
             out.data_ptr(), out.stride(0), d_out.data_ptr(), d_out.stride(0), _ptr_table(grads),
