@@ -299,7 +299,7 @@ void wgrad_shape(int n_out, int n_in, int red_rows, double share, int& tn, int& 
     const int tiles = gi_cdiv(n_out, 64) * gi_cdiv(n_in + 1, 64);
     const int kt = gi_cdiv(std::max(red_rows, 1), 32);
     // workgroups per problem (GI_WGRAD_WGS, measurements): 96 -> 2.44-2.51 ms per step, 128 -> 2.39-2.40,
-    // 192 -> 2.34-2.35, 256 -> 2.37, 384 -> 2.40-2.41 (tools/ab_run28.sh)
+    // 192 -> 2.34-2.35, 256 -> 2.37, 384 -> 2.40-2.41 (tools/ab/ab_run28.sh)
     static const double wgs = getenv("GI_WGRAD_WGS") ? atof(getenv("GI_WGRAD_WGS")) : 192.0;
     const int want = (int)(wgs * share / tiles + 0.5);
     nsplit = std::min(std::max(want, 1), std::max(1, kt / 2));

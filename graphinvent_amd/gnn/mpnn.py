@@ -181,7 +181,7 @@ def ggnn_backward_raw(tape, out, d_out, params, early_hook=None, bucket=None, wt
     # while the node-level dgrad launches fill the device by themselves).  GI_SIDE_MAX_ROWS=<rows>
     # (measurements) turns the second stream off for batches with at least that many compact node rows:
     # before the hold the overlap LOST 3-4 % beyond ~18 k rows (ZINC shape B=1000), with it it gains
-    # 1-2 % there too (tools/ab_run35.sh, ab_run36.sh).
+    # 1-2 % there too (tools/ab/ab_run35.sh, ab/ab_run36.sh).
     side = _side_stream(dev) if graph.S < _side_stream_max_rows() else 0
     args = (C.byref(dims), _ptr_table(params), C.byref(gs), ws.data_ptr(), slabs.data_ptr(),
             out.data_ptr(), out.stride(0), d_out.data_ptr(), d_out.stride(0), _ptr_table(grads),
