@@ -469,41 +469,43 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
 // (its offset) and its own, then it writes its own slots in ascending order — a stable counting sort
 // without atomics or a grid-wide sync, so the summation order of the backward is fixed.  D0 is a few
 // dozen to ~100 rows and E a few 10^4 slots: the scans are L2 hits.
-__global__ __launch_bounds__(256) void class_csr_kernel(const int* __restrict__ e2d, int E, int D0,
-                                                        int* __restrict__ cls_off,
-                                                        int* __restrict__ cls_edges) {
-    __shared__ int red[2][4];
-    __shared__ int base_s;
+__global__ __launch_bounds__(1024) void class_csr_kernel(const int* __restrict__ e2d, int E, int D0,
+                                                         int* __restrict__ cls_off,
+                                                         int* __restrict__ cls_edges) {
+    __shared__ int wbelow[16], wown[16];
     const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    int below = 0, own = 0;
-    for (int k = tid; k < E; k += 256) {
-        const int c = e2d[k];
-        below += c < d;
-        own += c == d;
-    }
+    // (1) slots of the rows below d = this row's offset (coalesced count)
+    int below = 0;
+    for (int k = tid; k < E; k += 1024) below += e2d[k] < d;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { below += __shfl_xor(below, o); own += __shfl_xor(own, o); }
-    if (lane == 0) { red[0][wid] = below; red[1][wid] = own; }
-    __syncthreads();
-    if (tid == 0) {
-        const int b = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        base_s = b;
-        cls_off[d] = b;
-        if (d == D0 - 1) cls_off[D0] = b + red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
+    // (2) every thread owns a contiguous chunk of the slots: its matches, an exclusive scan over the
+    // threads (one barrier), then it writes them in ascending order — stable, no per-round barriers
+    const int C = (E + 1023) / 1024, lo = min(tid * C, E), hi = min(lo + C, E);
+    int own = 0;
+    for (int k = lo; k < hi; ++k) own += e2d[k] == d;
+    int x = own;                                              // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o);
+        if (lane >= o) x += y;
     }
+    if (lane == 0) wbelow[wid] = below;
+    if (lane == 63) wown[wid] = x;
     __syncthreads();
-    int pos = base_s;
-    for (int k0 = 0; k0 < E; k0 += 256) {                    // stable placement, 256 slots per round
-        const int k = k0 + tid;
-        const bool mine = k < E && e2d[k] == d;
-        const unsigned long long m = __ballot(mine);
-        __syncthreads();
-        if (lane == 0) red[0][wid] = __popcll(m);
-        __syncthreads();
-        int before = __popcll(m & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wid; ++w) before += red[0][w];
-        if (mine) cls_edges[pos + before] = k;
-        pos += red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    int base = 0, woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        base += wbelow[w];
+        woff += (w < wid) ? wown[w] : 0;
+        total += wown[w];
+    }
+    int pos = base + woff + x - own;
+    for (int k = lo; k < hi; ++k)
+        if (e2d[k] == d) cls_edges[pos++] = k;
+    if (tid == 0) {
+        cls_off[d] = base;
+        if (d == D0 - 1) cls_off[D0] = base + total;
     }
 }
 
@@ -514,7 +516,7 @@ extern "C" int gi_compact_class_csr(const int* e2d, int E, int D0, int* cls_off,
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (D0 <= 0 || E <= 0) return 0;
     if (!e2d || !cls_off || !cls_edges) return GI_EINVAL;
-    hipLaunchKernelGGL(class_csr_kernel, dim3(D0), dim3(256), 0, (hipStream_t)stream, e2d, E, D0,
+    hipLaunchKernelGGL(class_csr_kernel, dim3(D0), dim3(1024), 0, (hipStream_t)stream, e2d, E, D0,
                        cls_off, cls_edges);
     return gi_launch_status();
 }
