@@ -124,10 +124,16 @@ __device__ __forceinline__ void lds_dma_1k(const float* gsrc, unsigned lds_dst) 
                  : "memory");
 }
 
-template <bool BWD>
+// RB = 32-row MFMA blocks per workgroup, RING = weight tiles in LDS.  <1, 3>: the kernel described above.
+// <2, 2>: 64 rows per workgroup for batches of several rounds of row blocks (ZINC / ChEMBL shapes): every
+// streamed weight byte feeds twice the MFMA work, so the workgroup is MFMA-bound instead of bound by its
+// weight stream (the second activation tile takes the LDS of the third ring slot: one tile of look-ahead,
+// hidden behind 2 x the MFMA time per tile); no VALU rows in this variant.
+template <bool BWD, int RB, int RING>
 __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
-    __shared__ __attribute__((aligned(16))) float As[(CH_ROWS + 8) * CH_ALD];   // 32 MFMA rows + 4 extra (+ 4 scratch)
-    __shared__ __attribute__((aligned(1024))) float Bs[CH_RING * CH_TILE];
+    constexpr int MROWS = CH_ROWS * RB;                       // rows on the MFMA path
+    __shared__ __attribute__((aligned(16))) float As[(MROWS + 8) * CH_ALD];   // MFMA rows + 4 extra (+ 4 scratch)
+    __shared__ __attribute__((aligned(1024))) float Bs[RING * CH_TILE];
     __shared__ float Xs[2 * CH_XMAX * CH_W];                 // extra rows: partial sums of the k halves
 
     // ---- which (chain, group, row block) -------------------------------------------------------
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
     const int r0 = lo + args.tile_rows * (local - args.tile_off[ci][g]);
     if (r0 >= hi) return;                                   // block-uniform, before any barrier
     const int nvalid = min(hi - r0, args.tile_rows);        // rows of this block
-    const int nx = __builtin_amdgcn_readfirstlane(max(nvalid - CH_ROWS, 0));   // on the VALU path
+    const int nx = __builtin_amdgcn_readfirstlane(max(nvalid - MROWS, 0));     // on the VALU path
     const int L = P.nlayers;
     const long long t_start = args.trace ? (long long)wall_clock64() : 0;
 
@@ -160,17 +166,20 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
     auto dma_tile = [&](int t) {
         t = min(t, T - 1);                                   // past the end: re-fetch the last tile
         const float* src = img + (long long)t * CH_TILE;     // (keeps the outstanding-load count fixed)
-        const unsigned dst = bs_lds + (unsigned)(t % CH_RING) * (unsigned)(CH_TILE * 4);
+        const unsigned dst = bs_lds + (unsigned)(t % RING) * (unsigned)(CH_TILE * 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) lds_dma_1k(src + q * 256, dst + q * 1024u);
     };
 
-    f32x16 acc;
+    f32x16 acc[RB];
     float xacc[CH_XMAX] = {0.f, 0.f, 0.f, 0.f};             // extra rows: column xn, k half xh
     const int xn = tid & (CH_W - 1), xh = tid >> 8;
-    auto read_frags = [&](int slot, int kt, int k8, float (&af)[4], float (&bf)[4]) {
-        const v4f a = *(const v4f*)&As[l31 * CH_ALD + kt * CH_KT + k8 * 8 + 4 * lhi];
-        af[0] = a.x; af[1] = a.y; af[2] = a.z; af[3] = a.w;
+    auto read_frags = [&](int slot, int kt, int k8, float (&af)[RB][4], float (&bf)[4]) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const v4f a = *(const v4f*)&As[(rb * CH_ROWS + l31) * CH_ALD + kt * CH_KT + k8 * 8 + 4 * lhi];
+            af[rb][0] = a.x; af[rb][1] = a.y; af[rb][2] = a.z; af[rb][3] = a.w;
+        }
         const float* b = Bs + slot * CH_TILE;
         if (!BWD) {
             const int row = wid * 32 + l31;
@@ -181,10 +190,12 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
             for (int j = 0; j < 4; ++j) bf[j] = b[(k8 * 8 + j + 4 * lhi) * CH_W + wid * 32 + l31];
         }
     };
-    auto mma = [&](const float (&af)[4], const float (&bf)[4]) {
+    auto mma = [&](const float (&af)[RB][4], const float (&bf)[4]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf[j], acc, 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rb][j], bf[j], acc[rb], 0, 0, 0);
     };
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
@@ -196,29 +207,33 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
         const int N = Ly.N, ldo = Ly.ldo;
         const int col = wid * 32 + l31;
         const bool col_ok = col < N;
-        const int nrows = min(nvalid, CH_ROWS);
+        const int nrows = min(nvalid, MROWS);
         const int coff = col_ok ? 4 * col : 0x40000000;     // beyond any tile: dropped / reads 0
-        float av[16];
+        float av[RB][16];
         const bool dselu = BWD && Ly.act != nullptr;
         if (dselu) {
             const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(Ly.act + (long long)r0 * Ly.ldact), 0, nrows * Ly.ldact * 4, 0x00020000);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                av[r] = __builtin_bit_cast(
-                    float, __builtin_amdgcn_raw_buffer_load_b32(ra, row * Ly.ldact * 4 + coff, 0, 0));
-            }
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rb * CH_ROWS + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    av[rb][r] = __builtin_bit_cast(
+                        float, __builtin_amdgcn_raw_buffer_load_b32(ra, row * Ly.ldact * 4 + coff, 0, 0));
+                }
         }
         const float bv = BWD ? 0.f : Ly.bias[g][col_ok ? col : N - 1];
-        float v[16];
+        float v[RB][16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float x = acc[r] + bv;
-            if (!BWD) x = gi_selu(x);
-            if (dselu) x *= gi_selu_grad(av[r]);
-            v[r] = col_ok ? x : 0.f;                         // zero = the next layer's k padding
-        }
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = acc[rb][r] + bv;
+                if (!BWD) x = gi_selu(x);
+                if (dselu) x *= gi_selu_grad(av[rb][r]);
+                v[rb][r] = col_ok ? x : 0.f;                 // zero = the next layer's k padding
+            }
         float xb = 0.f, xact[CH_XMAX];
         if (nx > 0) {                                        // extra rows: publish both k halves
 #pragma unroll
@@ -228,7 +243,7 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
                 if (!BWD) xb = Ly.bias[g][nc];
 #pragma unroll
                 for (int xi = 0; xi < CH_XMAX; ++xi)
-                    xact[xi] = dselu ? Ly.act[(long long)(r0 + CH_ROWS + min(xi, nx - 1)) * Ly.ldact + nc]
+                    xact[xi] = dselu ? Ly.act[(long long)(r0 + MROWS + min(xi, nx - 1)) * Ly.ldact + nc]
                                      : 0.f;
             }
         }
@@ -242,12 +257,12 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
 #pragma unroll
             for (int xi = 0; xi < CH_XMAX; ++xi) {
                 if (xi < nx) {
-                    const long long grow = r0 + CH_ROWS + xi;
+                    const long long grow = r0 + MROWS + xi;
                     float x = (Xs[xi * CH_W + n] + Xs[(CH_XMAX + xi) * CH_W + n]) + xb;
                     if (!BWD) x = gi_selu(x);
                     if (dselu) x *= gi_selu_grad(xact[xi]);
                     x = (n < N) ? x : 0.f;
-                    if (l + 1 < L) As[(CH_ROWS + xi) * CH_ALD + n] = x;
+                    if (l + 1 < L) As[(MROWS + xi) * CH_ALD + n] = x;
                     if (n < N) Ly.out[grow * ldo + n] = x;
                 }
             }
@@ -256,18 +271,25 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
         for (int xi = 0; xi < CH_XMAX; ++xi) xacc[xi] = 0.f;
         if (l + 1 < L) {                                     // next layer's A operand, in place
 #pragma unroll
-            for (int r = 0; r < 16; ++r) As[((r & 3) + 8 * (r >> 2) + 4 * lhi) * CH_ALD + col] = v[r];
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    As[(rb * CH_ROWS + (r & 3) + 8 * (r >> 2) + 4 * lhi) * CH_ALD + col] = v[rb][r];
         }
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(Ly.out + (long long)r0 * ldo), 0, nrows * ldo * 4, 0x00020000);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), ro,
-                                                  row * ldo * 4 + coff, 0, 0);
-        }
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb * CH_ROWS + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[rb][r]), ro,
+                                                      row * ldo * 4 + coff, 0, 0);
+            }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
     };
 
     // ---- prologue: the input rows -> LDS (zero beyond K0); then the first two weight tiles ----------
@@ -276,18 +298,19 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
         const int mc4 = tid & 63, mrow = tid >> 6;
         const int K0 = P.layer[0].K, cmax = ((K0 + 3) & ~3) - 4;
         const int c = 4 * mc4;
-        long long src[5];
-        v4f v[5];
+        constexpr int NP = 4 * RB + 1;                      // passes of 8 rows: MROWS + 8
+        long long src[NP];
+        v4f v[NP];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) src[i] = min(r0 + mrow + 8 * i, hi - 1);
+        for (int i = 0; i < NP; ++i) src[i] = min(r0 + mrow + 8 * i, hi - 1);
         if (P.x_idx) {
 #pragma unroll
-            for (int i = 0; i < 5; ++i) src[i] = P.x_idx[src[i]];
+            for (int i = 0; i < NP; ++i) src[i] = P.x_idx[src[i]];
         }
 #pragma unroll
-        for (int i = 0; i < 5; ++i) v[i] = gi_load4_raw(P.X + src[i] * P.ldx, c, cmax);
+        for (int i = 0; i < NP; ++i) v[i] = gi_load4_raw(P.X + src[i] * P.ldx, c, cmax);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < NP; ++i) {
             v4f w = v[i];
             w.x = (c < K0) ? w.x : 0.f; w.y = (c + 1 < K0) ? w.y : 0.f;
             w.z = (c + 2 < K0) ? w.z : 0.f; w.w = (c + 3 < K0) ? w.w : 0.f;
@@ -295,10 +318,12 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
         }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
     __syncthreads();                        // the A tile is in LDS (and every plain load has landed)
     dma_tile(0);
-    dma_tile(1);
+    if (RING == 3) dma_tile(1);
     long long t_phase[GI_CHAIN_MAXL + 1];
     if (args.trace) t_phase[0] = (long long)wall_clock64();
 
@@ -312,15 +337,21 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
     // and up to 16 + 4 stores + 4 loads are younger: waiting for them would only stall.
     // lgkmcnt(0): this wave's LDS writes (epilogue) are visible before the barrier releases readers.
 #define GI_CHAIN_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
-    float af[2][4], bf[2][4];
+    float af[2][RB][4], bf[2][4];
     // (loop state kept provably wave-uniform — readfirstlane — so that every branch on it is scalar)
     int l = 0, kt = 0, nk = (P.layer[0].K + CH_KT - 1) / CH_KT, lN = P.layer[0].N;
     int since_epi = 2;
     for (int s = 0; s < T; ++s) {
-        if (__builtin_amdgcn_readfirstlane(since_epi) < 2) { GI_CHAIN_WAIT(24); } else { GI_CHAIN_WAIT(4); }
+        if (RING == 3) {
+            if (__builtin_amdgcn_readfirstlane(since_epi) < 2) { GI_CHAIN_WAIT(24); } else { GI_CHAIN_WAIT(4); }
+        } else {
+            // two slots: tile s is the youngest load (issued in step s-1) unless an epilogue came after it
+            // — which drained it (vmcnt(0) + barrier) and left only its own stores (<= 16 RB + 4) in flight
+            if (__builtin_amdgcn_readfirstlane(since_epi) < 1) { GI_CHAIN_WAIT(40); } else { GI_CHAIN_WAIT(0); }
+        }
         since_epi = __builtin_amdgcn_readfirstlane(since_epi + 1);
-        dma_tile(s + 2);
-        const int slot = s % CH_RING;
+        dma_tile(s + RING - 1);
+        const int slot = s % RING;
         if (swid * 32 < __builtin_amdgcn_readfirstlane(lN)) {   // this wave owns output columns of the layer
             read_frags(slot, kt, 0, af[0], bf[0]);
 #pragma unroll
@@ -347,7 +378,7 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
 #pragma unroll
             for (int xi = 0; xi < CH_XMAX; ++xi) {
                 if (xi < nx) {
-                    const float* a = &As[(CH_ROWS + xi) * CH_ALD + kt * CH_KT + 16 * xh];
+                    const float* a = &As[(MROWS + xi) * CH_ALD + kt * CH_KT + 16 * xh];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const v4f v = *(const v4f*)&a[4 * c];    // same address in every lane: broadcast
@@ -472,12 +503,28 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
     }();
     static const bool xrows = !(getenv("GI_CHAIN_XROWS") && atoi(getenv("GI_CHAIN_XROWS")) == 0);
     int h = CH_ROWS;
-    const int rounds = gi_cdiv(blocks(CH_ROWS), ncu);
+    int rounds = gi_cdiv(blocks(CH_ROWS), ncu);
     if (xrows && rounds > 1)
         for (int hh = CH_ROWS + 1; hh <= CH_ROWS + CH_XMAX; ++hh)
-            if (gi_cdiv(blocks(hh), ncu) < rounds) { h = hh; break; }
-    if (const char* e = getenv("GI_CHAIN_TILE_ROWS"))          // tests / measurements: force a height
+            if (gi_cdiv(blocks(hh), ncu) < rounds) { h = hh; rounds = gi_cdiv(blocks(hh), ncu); break; }
+    // 64-row workgroups (two MFMA row blocks, <2, 2>: half the weight stream per row) when they need fewer
+    // rounds AND the weight images of the launch do not fit one XCD's 4 MB L2 — AttentionGGNN's two stacks
+    // in one launch: 6.9 MB, ChEMBL shape B=250 3.95 -> 3.81 ms per step.  A single stack (3.5 MB) streams
+    // from L2 fast enough that the 32-row blocks' three full rounds tie with two rounds of 64-row blocks
+    // (ZINC shape: 4.92 vs 4.98 ms; tools/ab/ab_run38.sh).
+    const int rows64 = getenv("GI_CHAIN_ROWS64") ? atoi(getenv("GI_CHAIN_ROWS64")) : -1;   // -1 auto, 0 / 1 forced
+    bool big = rows64 > 0;
+    if (rows64 < 0) {
+        long long image_bytes = 0;
+        for (int c = 0; c < nchains; ++c)
+            image_bytes += (long long)chains[c].ngroups * chain_tiles(chains[c]) * CH_TILE * 4;
+        big = image_bytes > (4LL << 20) && 1.15 * gi_cdiv(blocks(2 * CH_ROWS), ncu) < 0.9 * rounds;
+    }
+    if (const char* e = getenv("GI_CHAIN_TILE_ROWS")) {        // tests / measurements: force a height
         h = std::min(std::max(atoi(e), CH_ROWS), CH_ROWS + CH_XMAX);
+        big = false;
+    }
+    if (big) h = 2 * CH_ROWS;
     a.tile_rows = h;
     for (int c = 0; c < nchains; ++c) {
         const gi_chain_params& p = chains[c];
@@ -502,7 +549,12 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
     hipStream_t st = (hipStream_t)stream;
     GiProfScope prof(st, GI_PROF_GEMM, flops);
     const dim3 grid(total), block(512);
-    if (chains[0].backward) hipLaunchKernelGGL(gi_chain_kernel<true>, grid, block, 0, st, a);
-    else hipLaunchKernelGGL(gi_chain_kernel<false>, grid, block, 0, st, a);
+    if (big) {
+        if (chains[0].backward) hipLaunchKernelGGL((gi_chain_kernel<true, 2, 2>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((gi_chain_kernel<false, 2, 2>), grid, block, 0, st, a);
+    } else {
+        if (chains[0].backward) hipLaunchKernelGGL((gi_chain_kernel<true, 1, CH_RING>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((gi_chain_kernel<false, 1, CH_RING>), grid, block, 0, st, a);
+    }
     return gi_launch_status();
 }

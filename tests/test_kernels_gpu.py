@@ -281,6 +281,21 @@ def test_mlp_chain_taller_row_blocks(monkeypatch, tile_rows, sizes, off):
     _chain_case(sizes, off, seed=tile_rows, two=True)
 
 
+@pytest.mark.parametrize("sizes,off", [
+    ((128, 250, 250, 250, 250, 128), [0, 600, 600, 777]),
+    ((100, 250, 250, 100), [0, 33, 34, 131]),
+    ((100, 250, 250, 250, 250, 100), [0, 1000, 1001, 2500]),
+    ((37, 256, 7, 130), [0, 70]),
+])
+def test_mlp_chain_64_row_blocks(monkeypatch, sizes, off):
+    """The <2, 2> variant (64 rows per workgroup, two weight tiles in LDS; what the launcher picks for
+    batches of several rounds of row blocks), forced here on ragged groups: full blocks, a 1-row group, an
+    empty group, blocks whose second half is partly / completely out of range — forward and dZ chain."""
+    monkeypatch.setenv("GI_CHAIN_ROWS64", "1")
+    _chain_case(sizes, off, seed=64 + sum(sizes))
+    _chain_case(sizes, off, seed=64, two=True)
+
+
 @pytest.mark.parametrize("H,M,Fn", [(128, 128, 8), (100, 100, 8), (16, 12, 5), (24, 20, 8)])
 @pytest.mark.parametrize("agg_ready", [False, True])
 def test_gru_fused_forward(H, M, Fn, agg_ready):
