@@ -338,6 +338,7 @@ def main():
                                  "flat fp32 bucket, readout tail overlapped with the backward"
                                  if trainer.overlap else "flat fp32 bucket after the backward")},
     }
+    result["config"]["fuse_flags"] = int(lib.load().gi_fuse_flags())     # GI_FUSE_* variants in use
     if args.backend != "nccl":
         result["config"]["backend"] = args.backend + " (control-flow smoke test, not a measurement)"
 
@@ -388,7 +389,8 @@ def main():
             # the index + index + offsets + output
             seg_bytes += P * (E * Mm * 4 + E * 4 + (R + 1) * 4 + R * Mm * 4)              # aggregation
             seg_bytes += P * (E * Mm * 4 + E * 4 + (U + 1) * 4 + 2 * U * Mm * 4)          # its backward
-            seg_bytes += (P - 1) * (U * H * 4 + U * 4 + (R + 1) * 4 + 2 * R * H * 4)      # d h scatter
+            if not (handle.gi_fuse_flags() & lib.FUSE_DH_SCATTER):      # (else inside the gate backward)
+                seg_bytes += (P - 1) * (U * H * 4 + U * 4 + (R + 1) * 4 + 2 * R * H * 4)  # d h scatter
         trainer.step(*b)
     torch.cuda.synchronize()
     if rank == 0:

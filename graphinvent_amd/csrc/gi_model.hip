@@ -1345,8 +1345,13 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
     r.chk(gi_gather_readout_fwd(ws + w.en, ws + w.embo, w.ldG, cidx, mask, d.B, d.N, d.G,
                                 d.big_positive, ws + w.cat_add + m.NA, w.ldCA,
                                 ws + w.cat_conn + m.NC, w.ldCC, ws + w.gemb, w.ldG, r.st));
-    r.chk(gi_expand_slots(ws + w.add1o, w.ldA, cidx, d.B, d.N, d.A, ws + w.cat_add, w.ldCA, r.st));
-    r.chk(gi_expand_slots(ws + w.conn1o, w.ldC, cidx, d.B, d.N, d.C, ws + w.cat_conn, w.ldCC, r.st));
+    if (gi_fuse_flags() & GI_FUSE_SLOTS) {
+        r.chk(gi_expand_slots2(ws + w.add1o, w.ldA, d.A, ws + w.cat_add, w.ldCA, ws + w.conn1o, w.ldC, d.C,
+                               ws + w.cat_conn, w.ldCC, cidx, d.B, d.N, r.st));
+    } else {
+        r.chk(gi_expand_slots(ws + w.add1o, w.ldA, cidx, d.B, d.N, d.A, ws + w.cat_add, w.ldCA, r.st));
+        r.chk(gi_expand_slots(ws + w.conn1o, w.ldC, cidx, d.B, d.N, d.C, ws + w.cat_conn, w.ldCC, r.st));
+    }
     {   // the three graph-level stacks write straight into the logits
         MlpJob jobs[3] = {};
         jobs[0] = {&m.add2, ws + w.cat_add, w.ldCA, d.B, w.add2_act, w.ldM2, out, ldout};
@@ -1482,12 +1487,17 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
         r.chk((int)hipMemsetAsync(slabs + sp.count_off, 0, sizeof(int) * sp.count_ints, r.st));
     if (phase != GI_BWD_PASSES) {
     // ---- tier 2 (gnn/modules.py:265-279) ---------------------------------------------------------
-    r.chk(gi_selu_bwd_rows_f(d_out, lddout, nullptr, y_out, ldout, ws + w.dzA, w.ldNA, d.B, NA,
-                             out_fshift, r.st));
-    r.chk(gi_selu_bwd_rows_f(d_out + NA, lddout, nullptr, y_out + NA, ldout, ws + w.dzC, w.ldNC, d.B,
-                             NC, out_fshift, r.st));
-    r.chk(gi_selu_bwd_rows_f(d_out + NA + NC, lddout, nullptr, y_out + NA + NC, ldout, ws + w.dzT, 4,
-                             d.B, 1, out_fshift, r.st));
+    if (gi_fuse_flags() & GI_FUSE_TIER2_DSELU) {
+        r.chk(gi_selu_bwd_cols3_f(d_out, lddout, y_out, ldout, out_fshift, d.B, NA, ws + w.dzA, w.ldNA, NC,
+                                  ws + w.dzC, w.ldNC, 1, ws + w.dzT, 4, r.st));
+    } else {
+        r.chk(gi_selu_bwd_rows_f(d_out, lddout, nullptr, y_out, ldout, ws + w.dzA, w.ldNA, d.B, NA,
+                                 out_fshift, r.st));
+        r.chk(gi_selu_bwd_rows_f(d_out + NA, lddout, nullptr, y_out + NA, ldout, ws + w.dzC, w.ldNC, d.B,
+                                 NC, out_fshift, r.st));
+        r.chk(gi_selu_bwd_rows_f(d_out + NA + NC, lddout, nullptr, y_out + NA + NC, ldout, ws + w.dzT, 4,
+                                 d.B, 1, out_fshift, r.st));
+    }
     {
         MlpJob jobs[3] = {};
         jobs[0] = {&m.add2, ws + w.cat_add, w.ldCA, d.B, w.add2_act, w.ldM2, nullptr, 0, w.add2_dz,
@@ -1502,10 +1512,16 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
     r.chk(gi_gather_readout_bwd_f(ws + w.en, ws + w.embo, w.ldG, cidx, mask, d.B, d.N, d.G, S,
                                   d.big_positive, ws + w.dgemb, w.ldG, ws + w.dcat_add + NA, w.ldCA,
                                   ws + w.dcat_conn + NC, w.ldCC, ws + w.zpart_g, r.fshift, r.st));
-    r.chk(gi_compress_slots_f(ws + w.add1o, w.ldA, cidx, d.B, d.N, d.A, S, ws + w.dcat_add, w.ldCA,
-                              ws + w.zpart_a, w.ldA, r.fshift, r.st));
-    r.chk(gi_compress_slots_f(ws + w.conn1o, w.ldC, cidx, d.B, d.N, d.C, S, ws + w.dcat_conn, w.ldCC,
-                              ws + w.zpart_c, w.ldC, r.fshift, r.st));
+    if (gi_fuse_flags() & GI_FUSE_SLOTS) {
+        r.chk(gi_compress_slots2_f(ws + w.add1o, w.ldA, d.A, ws + w.dcat_add, w.ldCA, ws + w.zpart_a, w.ldA,
+                                   ws + w.conn1o, w.ldC, d.C, ws + w.dcat_conn, w.ldCC, ws + w.zpart_c,
+                                   w.ldC, cidx, d.B, d.N, S, r.fshift, r.st));
+    } else {
+        r.chk(gi_compress_slots_f(ws + w.add1o, w.ldA, cidx, d.B, d.N, d.A, S, ws + w.dcat_add, w.ldCA,
+                                  ws + w.zpart_a, w.ldA, r.fshift, r.st));
+        r.chk(gi_compress_slots_f(ws + w.conn1o, w.ldC, cidx, d.B, d.N, d.C, S, ws + w.dcat_conn, w.ldCC,
+                                  ws + w.zpart_c, w.ldC, r.fshift, r.st));
+    }
     {   // zero-row gradients of the four stacks: per-graph partial sums -> row S, one launch
         float* en_z = ws + w.en + (long long)S * w.ldG;
         float* emb_z = ws + w.embo + (long long)S * w.ldG;
@@ -1568,6 +1584,12 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
                 chain_pack(r, k ? m.eatt : m.msg, d.Fe, true, r.img_b[k]);
             }
     // ---- message passes, reversed -------------------------------------------------------------------
+    // d h scatter (segmented sum of the message stacks' input gradients over the source CSR): its own
+    // launch(es) behind the pass's dZ chain, or — GI_FUSE_DH_SCATTER, vector gate kernel (H % 4 == 0) —
+    // folded into the gate backward of the next iteration, which is the only reader of that sum
+    const bool fuse_scatter = (gi_fuse_flags() & GI_FUSE_DH_SCATTER) && (d.H & 3) == 0 && d.H >= 4;
+    const float* scat0 = nullptr;
+    const float* scat1 = nullptr;
     for (int p = d.passes - 1; p >= 0; --p) {
         const float* hx = ws + w.hx[p];
         float* gi = ws + w.gi[p];
@@ -1576,9 +1598,16 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
         const bool last = (p == d.passes - 1);
         static const bool excl = getenv("GI_CHAIN_EXCLUSIVE") && atoi(getenv("GI_CHAIN_EXCLUSIVE")) != 0;
         r.hold_kicks = excl && r.img_b[0] != nullptr && E > 0;   // released right behind the pass's dZ chain
-        r.chk(gi_gru_gates_bwd(gi, gh, w.ld3H, hx, w.ldhx, dh, last ? dhb : nullptr,
-                               last ? dhc : nullptr, last ? dhd : nullptr, dh2, w.ldH, seg_off, R,
-                               d.H, r.st));
+        if (scat0) {    // the later pass's d h scatter rides in this launch (GI_FUSE_DH_SCATTER)
+            r.chk(gi_gru_gates_bwd_ex(gi, gh, w.ld3H, hx, w.ldhx, dh, last ? dhb : nullptr,
+                                      last ? dhc : nullptr, last ? dhd : nullptr, dh2, w.ldH, seg_off, R,
+                                      d.H, scat0, scat1, w.ldH, out_perm, src_off, r.st));
+            scat0 = scat1 = nullptr;
+        } else {
+            r.chk(gi_gru_gates_bwd(gi, gh, w.ld3H, hx, w.ldhx, dh, last ? dhb : nullptr,
+                                   last ? dhc : nullptr, last ? dhd : nullptr, dh2, w.ldH, seg_off, R,
+                                   d.H, r.st));
+        }
         float* dagg = ws + w.dagg[p];
         {
             const int wih = m.gru_wih, whh = m.gru_whh;
@@ -1617,7 +1646,9 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
                 edge_chains_backward(r, ws, sp, slabs, dq, ch, 2, bytype, hx, w.ldhx, u_src, U, w.ldH,
                                      d.H);
             }
-            if (p > 0) {
+            if (p > 0 && fuse_scatter) {
+                scat0 = ws + w.dxe; scat1 = ws + w.dxa;
+            } else if (p > 0) {
                 r.chk(gi_seg_sum(ws + w.dxe, w.ldH, out_perm, src_off, R, d.H, dh2, w.ldH, 1, r.st));
                 r.chk(gi_seg_sum(ws + w.dxa, w.ldH, out_perm, src_off, R, d.H, dh2, w.ldH, 1, r.st));
             }
@@ -1645,7 +1676,9 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
             msg_backward(r, ws, sp, slabs, dq, m.msg, bytype, hx, w.ldhx, u_src, U, w.eact[p],
                          w.edz[p], w.ldEh, ws + w.m[p], w.ldM, p > 0 ? ws + w.dxe : nullptr, w.ldH,
                          d.H);
-            if (p > 0)   // scatter d h_src back to nodes: segmented sum over the source CSR
+            if (p > 0 && fuse_scatter)
+                scat0 = ws + w.dxe;
+            else if (p > 0)   // scatter d h_src back to nodes: segmented sum over the source CSR
                 r.chk(gi_seg_sum(ws + w.dxe, w.ldH, out_perm, src_off, R, d.H, dh2, w.ldH, 1, r.st));
         } else {
             // no edges: the message MLP weights still need zeroed slabs

@@ -2,6 +2,7 @@
 // streaming kernels: coalesced row reads, 16-byte vectors where the layout allows, no atomics,
 // deterministic summation order.
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -202,6 +203,22 @@ __global__ __launch_bounds__(256) void selu_bwd_rows_kernel(
     out[(long long)r * ldo + c] = dY[sr * lddy + c] * gi_dact(Y + (long long)r * ldy + c, fshift);
 }
 
+// The three column ranges of the logits (fAddNet2 | fConnNet2 | fTermNet2 outputs, gnn/modules.py:265-279)
+// in one launch: out_k[r, c - start_k] = dY[r, c] * dact(Y[r, c]) for c in range k.
+__global__ __launch_bounds__(256) void selu_bwd_cols3_kernel(
+    const float* __restrict__ dY, int lddy, const float* Y, int ldy, long long fshift, int rows, int n0,
+    int n1, int n2, float* __restrict__ o0, int ld0, float* __restrict__ o1, int ld1,
+    float* __restrict__ o2, int ld2) {
+    const int W = n0 + n1 + n2;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int r = (int)(t / W), c = (int)(t - (long long)r * W);
+    if (r >= rows) return;
+    const float x = dY[(long long)r * lddy + c] * gi_dact(Y + (long long)r * ldy + c, fshift);
+    if (c < n0) o0[(long long)r * ld0 + c] = x;
+    else if (c < n0 + n1) o1[(long long)r * ld1 + (c - n0)] = x;
+    else o2[(long long)r * ld2 + (c - n0 - n1)] = x;
+}
+
 // ---- AlphaDropout (training mode of gnn/modules.py:130-142, p > 0) ------------------------------
 // torch.nn.AlphaDropout after every Linear+SELU: y = s * (keep * a) + b with b = (keep - 1) * alpha' * a
 // + alpha' * a * p, evaluated exactly like ATen's _dropout_impl (two roundings: fl(fl(s * a) + b));
@@ -291,6 +308,98 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_kernel(
         g[j] = 0.f; g[H + j] = 0.f; g[2 * H + j] = 0.f;
         h[j] = 0.f; h[H + j] = 0.f; h[2 * H + j] = 0.f;
         dh_prev[(long long)row * lddh + j] = d;
+    }
+}
+
+// Four hidden units per thread (16-byte accesses) — same arithmetic per element as the scalar kernels
+// above, which stay the fallback for H % 4 != 0 (the three gate blocks of a row then do not start on
+// 16-byte boundaries).
+__device__ __forceinline__ v4f v4_sigmoid(v4f a) {
+    return v4f{gi_sigmoid(a.x), gi_sigmoid(a.y), gi_sigmoid(a.z), gi_sigmoid(a.w)};
+}
+__device__ __forceinline__ v4f v4_tanh(v4f a) {
+    return v4f{tanhf(a.x), tanhf(a.y), tanhf(a.z), tanhf(a.w)};
+}
+
+__global__ __launch_bounds__(256) void gru_gates_fwd_v4_kernel(
+    float* gi, const float* __restrict__ gh, int ldg, const float* __restrict__ hx_prev,
+    float* __restrict__ hx_new, int ldh, const int* __restrict__ seg_off, int rows, int H) {
+    const int q4 = ldh >> 2;                             // ldh is a multiple of 4
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int row = (int)(t / q4), j = 4 * (int)(t - (long long)row * q4);
+    if (row >= rows) return;
+    const v4f hp = *(const v4f*)(hx_prev + (long long)row * ldh + j);
+    v4f hn_out = hp;                                    // feature tail / padding: plain copy
+    if (j < H && seg_off[row + 1] > seg_off[row]) {     // H % 4 == 0: a group never straddles H
+        float* g = gi + (long long)row * ldg;
+        const float* h = gh + (long long)row * ldg;
+        const v4f r = v4_sigmoid(*(const v4f*)(g + j) + *(const v4f*)(h + j));
+        const v4f z = v4_sigmoid(*(const v4f*)(g + H + j) + *(const v4f*)(h + H + j));
+        const v4f n = v4_tanh(*(const v4f*)(g + 2 * H + j) + r * *(const v4f*)(h + 2 * H + j));
+        hn_out = (1.f - z) * n + z * hp;
+        *(v4f*)(g + j) = r; *(v4f*)(g + H + j) = z; *(v4f*)(g + 2 * H + j) = n;
+    }
+    *(v4f*)(hx_new + (long long)row * ldh + j) = hn_out;
+}
+
+// The backward, with — optionally — the scatter of the message stacks' input gradients back to their
+// source nodes folded into the load of d h: otherwise its own launch in front of this one,
+// gi_seg_sum(sc, sc_perm, sc_off, ..., dh_new, accumulate) over the source CSR (one per stack;
+// AttentionGGNN has two).  The sums are formed exactly like seg_sum_kernel forms them (pairs, tail,
+// then + the destination), so the fused and the two-launch paths agree bit for bit.
+__global__ __launch_bounds__(256) void gru_gates_bwd_v4_kernel(
+    float* gi, float* gh, int ldg, const float* __restrict__ hx_prev, int ldh,
+    const float* __restrict__ dh_new, const float* __restrict__ dh_b, const float* __restrict__ dh_c,
+    const float* __restrict__ dh_d, float* __restrict__ dh_prev, int lddh,
+    const int* __restrict__ seg_off, int rows, int H, const float* __restrict__ sc0,
+    const float* __restrict__ sc1, int ldsc, const int* __restrict__ sc_perm,
+    const int* __restrict__ sc_off) {
+    const int q4 = H >> 2;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int row = (int)(t / q4), j = 4 * (int)(t - (long long)row * q4);
+    if (row >= rows) return;
+    float* g = gi + (long long)row * ldg;
+    float* h = gh + (long long)row * ldg;
+    v4f d = *(const v4f*)(dh_new + (long long)row * lddh + j);
+    if (sc0) {
+        const int lo = sc_off[row], hi = sc_off[row + 1];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float* sc = s ? sc1 : sc0;
+            if (!sc) break;
+            v4f acc = {0.f, 0.f, 0.f, 0.f};
+            int k = lo;
+            for (; k + 1 < hi; k += 2) {
+                const int p0 = sc_perm[k], p1 = sc_perm[k + 1];
+                const v4f a = *(const v4f*)(sc + (long long)p0 * ldsc + j);
+                const v4f b = *(const v4f*)(sc + (long long)p1 * ldsc + j);
+                acc += a;
+                acc += b;
+            }
+            if (k < hi) acc += *(const v4f*)(sc + (long long)sc_perm[k] * ldsc + j);
+            d = acc + d;
+        }
+    }
+    if (dh_b) d += *(const v4f*)(dh_b + (long long)row * lddh + j);   // + the sibling stacks' contributions
+    if (dh_c) d += *(const v4f*)(dh_c + (long long)row * lddh + j);
+    if (dh_d) d += *(const v4f*)(dh_d + (long long)row * lddh + j);
+    if (seg_off[row + 1] > seg_off[row]) {
+        const v4f r = *(const v4f*)(g + j), z = *(const v4f*)(g + H + j), n = *(const v4f*)(g + 2 * H + j);
+        const v4f hn = *(const v4f*)(h + 2 * H + j);
+        const v4f hp = *(const v4f*)(hx_prev + (long long)row * ldh + j);
+        const v4f dn = d * (1.f - z);
+        const v4f dz = d * (hp - n);
+        const v4f dpn = dn * (1.f - n * n);
+        const v4f dpr = dpn * hn * r * (1.f - r);
+        const v4f dpz = dz * z * (1.f - z);
+        *(v4f*)(g + j) = dpr; *(v4f*)(g + H + j) = dpz; *(v4f*)(g + 2 * H + j) = dpn;
+        *(v4f*)(h + j) = dpr; *(v4f*)(h + H + j) = dpz; *(v4f*)(h + 2 * H + j) = dpn * r;
+        *(v4f*)(dh_prev + (long long)row * lddh + j) = d * z;
+    } else {
+        const v4f zero = {0.f, 0.f, 0.f, 0.f};
+        *(v4f*)(g + j) = zero; *(v4f*)(g + H + j) = zero; *(v4f*)(g + 2 * H + j) = zero;
+        *(v4f*)(h + j) = zero; *(v4f*)(h + H + j) = zero; *(v4f*)(h + 2 * H + j) = zero;
+        *(v4f*)(dh_prev + (long long)row * lddh + j) = d;
     }
 }
 
@@ -410,6 +519,21 @@ __global__ __launch_bounds__(256) void expand_slots_kernel(
     cat[(long long)b * ldc + r] = t1[(long long)cidx[b * N + n] * ldt + w];
 }
 
+// both tier-1 outputs (fAddNet1 / fConnNet1) in one launch: elements [0, total_a) belong to problem a
+struct ExpandPair { const float* t1[2]; int ldt[2]; int W[2]; float* cat[2]; int ldc[2]; };
+
+__global__ __launch_bounds__(256) void expand_slots2_kernel(const ExpandPair a, const int* __restrict__ cidx,
+                                                            int N, long long total_a, long long total) {
+    long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int k = t >= total_a ? 1 : 0;
+    t -= k ? total_a : 0;
+    const int W = a.W[k], NW = N * W;
+    const int b = (int)(t / NW), r = (int)(t - (long long)b * NW);
+    const int n = r / W, w = r - n * W;
+    a.cat[k][(long long)b * a.ldc[k] + r] = a.t1[k][(long long)cidx[b * N + n] * a.ldt[k] + w];
+}
+
 // One workgroup per (graph, quarter of its N*W elements): the slots that own a compact row are
 // independent elementwise work (the old kernel walked the N slots of a column serially from 64 threads:
 // 45 us per launch at N = 88, B = 250); the per-graph sums over the slots sharing the zero row stay a
@@ -418,6 +542,39 @@ __global__ __launch_bounds__(256) void compress_slots_kernel(
     float* t1, int ldt, const int* __restrict__ cidx, int N, int W, int S,
     const float* __restrict__ dcat, int ldc, float* __restrict__ zpart, int ldz, long long fshift) {
     __shared__ int c_s[GI_MAX_NODES];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int n = tid; n < N; n += 256) c_s[n] = cidx[b * N + n];
+    __syncthreads();
+    const int total = N * W, chunk = (total + gridDim.y - 1) / gridDim.y;
+    const int lo = blockIdx.y * chunk, hi = min(lo + chunk, total);
+    for (int idx = lo + tid; idx < hi; idx += 256) {
+        const int n = idx / W, w = idx - n * W;
+        const int c = c_s[n];
+        if (c < S) {
+            float* p = t1 + (long long)c * ldt + w;
+            *p = dcat[(long long)b * ldc + idx] * gi_dact(p, fshift);
+        }
+    }
+    if (blockIdx.y == 0)
+        for (int w = tid; w < W; w += 256) {
+            float z = 0.f;
+            for (int n = 0; n < N; ++n)
+                if (c_s[n] >= S) z += dcat[(long long)b * ldc + n * W + w];
+            zpart[(long long)b * ldz + w] = z;
+        }
+}
+
+// the same for the two tier-1 stacks in one launch (blockIdx.z = problem)
+struct CompressPair { float* t1[2]; int ldt[2]; int W[2]; const float* dcat[2]; int ldc[2]; float* zpart[2]; int ldz[2]; };
+
+__global__ __launch_bounds__(256) void compress_slots2_kernel(const CompressPair a, const int* __restrict__ cidx,
+                                                              int N, int S, long long fshift) {
+    __shared__ int c_s[GI_MAX_NODES];
+    const int k = blockIdx.z;
+    float* t1 = a.t1[k];
+    const float* __restrict__ dcat = a.dcat[k];
+    float* __restrict__ zpart = a.zpart[k];
+    const int ldt = a.ldt[k], W = a.W[k], ldc = a.ldc[k], ldz = a.ldz[k];
     const int b = blockIdx.x, tid = threadIdx.x;
     for (int n = tid; n < N; n += 256) c_s[n] = cidx[b * N + n];
     __syncthreads();
@@ -852,6 +1009,21 @@ extern "C" int gi_selu_bwd_rows_f(const float* dY, int lddy, const int* idx, con
     return gi_launch_status();
 }
 
+extern "C" int gi_selu_bwd_cols3_f(const float* dY, int lddy, const float* Y, int ldy, long long fshift,
+                                   int rows, int n0, float* out0, int ld0, int n1, float* out1, int ld1,
+                                   int n2, float* out2, int ld2, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
+    if (rows <= 0) return 0;
+    if (n0 < 0 || n1 < 0 || n2 < 0 || n0 + n1 + n2 <= 0) return GI_EINVAL;
+    if (!dY || !Y || (n0 && !out0) || (n1 && !out1) || (n2 && !out2)) return GI_EINVAL;
+    if (lddy < n0 + n1 + n2 || ldy < n0 + n1 + n2 || ld0 < n0 || ld1 < n1 || ld2 < n2) return GI_EINVAL;
+    const long long threads = (long long)rows * (n0 + n1 + n2);
+    hipLaunchKernelGGL(selu_bwd_cols3_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, dY, lddy, Y, ldy, fshift, rows, n0, n1, n2, out0, ld0, out1,
+                       ld1, out2, ld2);
+    return gi_launch_status();
+}
+
 // constants of one AlphaDropout site, rounded the way ATen rounds them (double scalars applied to a
 // float tensor: each scalar is cast to float first)
 extern "C" int gi_dropout_setup(double p, unsigned long long seed, unsigned id, gi_dropout_params* out) {
@@ -890,6 +1062,23 @@ extern "C" int gi_dropout_mask(const gi_dropout_params* q, int rows, int cols, u
     return gi_launch_status();
 }
 
+// ---- launch-count reductions of the training step (GI_FUSE) ------------------------------------------
+// Bit mask, read once from the environment (GI_FUSE=<int>; default GI_FUSE_DEFAULT): which of the fused /
+// vectorised variants of the small kernels around the GEMMs the model uses.  Every variant computes
+// exactly what the launches it replaces compute (tests/test_kernels_gpu.py compares them bit for bit).
+extern "C" int gi_fuse_flags(void) {
+    static const int v = getenv("GI_FUSE") ? atoi(getenv("GI_FUSE")) : GI_FUSE_DEFAULT;
+    return v;
+}
+
+// 16-byte accesses of the vectorised GRU gate kernels: H and every leading dimension a multiple of 4
+// floats, every base pointer 16-byte aligned
+static bool gates_v4_ok(int H, int ldg, int ldh, int lddh, const void* a, const void* b, const void* c,
+                        const void* d) {
+    if ((H & 3) || (ldg & 3) || (ldh & 3) || (lddh & 3) || H < 4) return false;
+    return !(((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15);
+}
+
 extern "C" int gi_gru_gates_fwd(float* gi, float* gh, int ldg, const float* hx_prev, float* hx_new,
                                 int ldh, const int* seg_off, int rows, int H, int Fn,
                                 void* stream) {
@@ -897,6 +1086,12 @@ extern "C" int gi_gru_gates_fwd(float* gi, float* gh, int ldg, const float* hx_p
     if (rows <= 0) return 0;
     if (!gi || !gh || !hx_prev || !hx_new || !seg_off || ldg < 3 * H || ldh < H + Fn)
         return GI_EINVAL;
+    if ((gi_fuse_flags() & GI_FUSE_GATES_V4) && gates_v4_ok(H, ldg, ldh, ldh, gi, gh, hx_prev, hx_new)) {
+        const long long threads = (long long)rows * (ldh / 4);
+        hipLaunchKernelGGL(gru_gates_fwd_v4_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, gi, gh, ldg, hx_prev, hx_new, ldh, seg_off, rows, H);
+        return gi_launch_status();
+    }
     const long long threads = (long long)rows * ldh;
     hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, gi, gh, ldg, hx_prev, hx_new, ldh, seg_off, rows, H);
@@ -911,10 +1106,43 @@ extern "C" int gi_gru_gates_bwd(float* gi, float* gh, int ldg, const float* hx_p
     if (rows <= 0) return 0;
     if (!gi || !gh || !hx_prev || !dh_new || !dh_prev || !seg_off || ldg < 3 * H || lddh < H)
         return GI_EINVAL;
+    if (gi_fuse_flags() & GI_FUSE_GATES_V4)
+        return gi_gru_gates_bwd_ex(gi, gh, ldg, hx_prev, ldh, dh_new, dh_b, dh_c, dh_d, dh_prev, lddh,
+                                   seg_off, rows, H, nullptr, nullptr, 0, nullptr, nullptr, stream);
     const long long threads = (long long)rows * H;
     hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, gi, gh, ldg, hx_prev, ldh, dh_new, dh_b, dh_c, dh_d,
                        dh_prev, lddh, seg_off, rows, H);
+    return gi_launch_status();
+}
+
+extern "C" int gi_gru_gates_bwd_ex(float* gi, float* gh, int ldg, const float* hx_prev, int ldh,
+                                   const float* dh_new, const float* dh_b, const float* dh_c,
+                                   const float* dh_d, float* dh_prev, int lddh, const int* seg_off,
+                                   int rows, int H, const float* sc0, const float* sc1, int ldsc,
+                                   const int* sc_perm, const int* sc_off, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
+    if (rows <= 0) return 0;
+    if (!gi || !gh || !hx_prev || !dh_new || !dh_prev || !seg_off || ldg < 3 * H || lddh < H || ldh < H)
+        return GI_EINVAL;
+    if (sc1 && !sc0) return GI_EINVAL;
+    if (sc0 && (!sc_perm || !sc_off || ldsc < H || (ldsc & 3) || ((uintptr_t)sc0 & 15) ||
+                ((uintptr_t)sc1 & 15)))
+        return GI_EINVAL;
+    bool v4 = gates_v4_ok(H, ldg, ldh, lddh, gi, gh, hx_prev, dh_new) && !((uintptr_t)dh_prev & 15) &&
+              !(((uintptr_t)dh_b | (uintptr_t)dh_c | (uintptr_t)dh_d) & 15);
+    if (!v4) {
+        if (sc0) return GI_EINVAL;          // the fused scatter exists in the vector kernel only
+        const long long threads = (long long)rows * H;
+        hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, gi, gh, ldg, hx_prev, ldh, dh_new, dh_b, dh_c, dh_d,
+                           dh_prev, lddh, seg_off, rows, H);
+        return gi_launch_status();
+    }
+    const long long threads = (long long)rows * (H / 4);
+    hipLaunchKernelGGL(gru_gates_bwd_v4_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, gi, gh, ldg, hx_prev, ldh, dh_new, dh_b, dh_c, dh_d, dh_prev,
+                       lddh, seg_off, rows, H, sc0, sc1, ldsc, sc_perm, sc_off);
     return gi_launch_status();
 }
 
@@ -991,6 +1219,44 @@ extern "C" int gi_compress_slots_f(float* t1, int ldt, const int* cidx, int B, i
     const int parts = (long long)N * W >= 4096 ? 4 : 1;
     hipLaunchKernelGGL(compress_slots_kernel, dim3(B, parts), dim3(256), 0, (hipStream_t)stream, t1, ldt,
                        cidx, N, W, S, dcat, ldc, zpart, ldz, fshift);
+    return gi_launch_status();
+}
+
+extern "C" int gi_expand_slots2(const float* t1a, int ldta, int Wa, float* cata, int ldca,
+                                const float* t1b, int ldtb, int Wb, float* catb, int ldcb,
+                                const int* cidx, int B, int N, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
+    if (B <= 0) return 0;
+    if (!t1a || !t1b || !cata || !catb || !cidx || N <= 0 || Wa <= 0 || Wb <= 0 || ldta < Wa ||
+        ldtb < Wb || ldca < N * Wa || ldcb < N * Wb)
+        return GI_EINVAL;
+    ExpandPair a;
+    a.t1[0] = t1a; a.t1[1] = t1b; a.ldt[0] = ldta; a.ldt[1] = ldtb; a.W[0] = Wa; a.W[1] = Wb;
+    a.cat[0] = cata; a.cat[1] = catb; a.ldc[0] = ldca; a.ldc[1] = ldcb;
+    const long long total_a = (long long)B * N * Wa, total = total_a + (long long)B * N * Wb;
+    hipLaunchKernelGGL(expand_slots2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, a, cidx, N, total_a, total);
+    return gi_launch_status();
+}
+
+extern "C" int gi_compress_slots2_f(float* t1a, int ldta, int Wa, const float* dcata, int ldca,
+                                    float* zparta, int ldza, float* t1b, int ldtb, int Wb,
+                                    const float* dcatb, int ldcb, float* zpartb, int ldzb,
+                                    const int* cidx, int B, int N, int S, long long fshift, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
+    if (B <= 0) return 0;
+    if (!t1a || !t1b || !dcata || !dcatb || !zparta || !zpartb || !cidx || N <= 0 || Wa <= 0 || Wb <= 0 ||
+        ldza < Wa || ldzb < Wb)
+        return GI_EINVAL;
+    if (N > GI_MAX_NODES) return GI_ELIMIT;
+    CompressPair a;
+    a.t1[0] = t1a; a.t1[1] = t1b; a.ldt[0] = ldta; a.ldt[1] = ldtb; a.W[0] = Wa; a.W[1] = Wb;
+    a.dcat[0] = dcata; a.dcat[1] = dcatb; a.ldc[0] = ldca; a.ldc[1] = ldcb;
+    a.zpart[0] = zparta; a.zpart[1] = zpartb; a.ldz[0] = ldza; a.ldz[1] = ldzb;
+    const int Wmax = Wa > Wb ? Wa : Wb;
+    const int parts = (long long)N * Wmax >= 4096 ? 4 : 1;
+    hipLaunchKernelGGL(compress_slots2_kernel, dim3(B, parts, 2), dim3(256), 0, (hipStream_t)stream, a,
+                       cidx, N, S, fshift);
     return gi_launch_status();
 }
 

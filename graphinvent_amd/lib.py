@@ -28,7 +28,7 @@ EPI_MULACT, GEMM_REDUCE = 64, 128
 KIND_GGNN, KIND_ATTGGNN = 0, 1
 BWD_ALL, BWD_READOUT, BWD_PASSES = 0, 1, 2
 COUNTS = 24          # GI_COUNTS
-ABI_VERSION = 7      # GI_ABI_VERSION
+ABI_VERSION = 8      # GI_ABI_VERSION
 DTYPE_F32, DTYPE_I8 = 0, 1
 
 vp = C.c_void_p
@@ -172,7 +172,15 @@ SIGNATURES = {
     "gi_ggnn_transpose_weights": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), vp, vp]),
     "gi_transpose_batch": (ci, [vp, ci, vp]),
     "gi_ggnn_first_readout_param": (ci, [C.POINTER(GgnnDims)]),
+    "gi_fuse_flags": (ci, []),
+    "gi_gru_gates_bwd_ex": (ci, [vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, vp, vp, ci, vp, vp,
+                                 vp]),
+    "gi_selu_bwd_cols3_f": (ci, [vp, ci, vp, ci, cll, ci, ci, vp, ci, ci, vp, ci, ci, vp, ci, vp]),
+    "gi_expand_slots2": (ci, [vp, ci, ci, vp, ci, vp, ci, ci, vp, ci, vp, ci, ci, vp]),
+    "gi_compress_slots2_f": (ci, [vp, ci, ci, vp, ci, vp, ci, vp, ci, ci, vp, ci, vp, ci, vp, ci, ci, ci,
+                                  cll, vp]),
 }
+FUSE_GATES_V4, FUSE_DH_SCATTER, FUSE_TIER2_DSELU, FUSE_SLOTS = 1, 2, 4, 8     # GI_FUSE_*
 
 _lib = None
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GI_ABI_VERSION 7
+#define GI_ABI_VERSION 8
 #define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
 #define GI_MAX_NODES 128      /* max max_n_nodes */
 #define GI_P0_MAX_CLASSES 256 /* max distinct node feature rows for the pass-0 shortcut */
@@ -340,6 +340,46 @@ int gi_gru_fused_fwd(const gi_gru_params* p, void* stream);
 int gi_gru_gates_bwd(float* gi, float* gh, int ldg, const float* hx_prev, int ldh,
                      const float* dh_new, const float* dh_b, const float* dh_c, const float* dh_d,
                      float* dh_prev, int lddh, const int* seg_off, int rows, int H, void* stream);
+
+/* Launch-count reductions of the training step.  gi_fuse_flags() = the bit mask (environment GI_FUSE,
+ * default GI_FUSE_DEFAULT) of the fused / vectorised variants gi_ggnn_forward / gi_ggnn_backward use;
+ * each computes exactly what the launches it replaces compute (same summation orders):
+ *   GATES_V4     gi_gru_gates_fwd / _bwd on 16-byte vectors (4 hidden units per thread) when H % 4 == 0
+ *   DH_SCATTER   the scatter of the message stacks' input gradients to their source nodes
+ *                (gi_seg_sum over the source CSR, accumulating into d h; backward of
+ *                `nodes[edge_batch_nghb_idc]`, gnn/summation_mpnn.py:131-133) folded into the
+ *                gi_gru_gates_bwd_ex launch of the next (earlier) message pass
+ *   TIER2_DSELU  the SELU backward of the three logit column ranges in one launch (gi_selu_bwd_cols3_f)
+ *   SLOTS        fAddNet1 / fConnNet1 glue in one launch each way (gi_expand_slots2, gi_compress_slots2_f) */
+#define GI_FUSE_GATES_V4    1
+#define GI_FUSE_DH_SCATTER  2
+#define GI_FUSE_TIER2_DSELU 4
+#define GI_FUSE_SLOTS       8
+#define GI_FUSE_DEFAULT     0
+int gi_fuse_flags(void);
+/* gi_gru_gates_bwd with d h = dh_new + sum over the source-CSR segment [sc_off[r], sc_off[r+1]) of the rows
+ * sc0[sc_perm[k]] (+ the same over sc1 when non-NULL; both [*, ldsc >= H]) — what gi_seg_sum(sc, sc_perm,
+ * sc_off, ..., dh_new, accumulate) launches in front of gi_gru_gates_bwd would have left in dh_new, bit for
+ * bit.  sc0 == NULL: plain gi_gru_gates_bwd on the vector kernel (scalar kernel when H % 4 != 0 or a
+ * pointer / leading dimension is not 16-byte aligned; with sc0 that case is GI_EINVAL). */
+int gi_gru_gates_bwd_ex(float* gi, float* gh, int ldg, const float* hx_prev, int ldh,
+                        const float* dh_new, const float* dh_b, const float* dh_c, const float* dh_d,
+                        float* dh_prev, int lddh, const int* seg_off, int rows, int H,
+                        const float* sc0, const float* sc1, int ldsc, const int* sc_perm,
+                        const int* sc_off, void* stream);
+/* out_k[r, c] = dY[r, s_k + c] * selu'(Y[r, s_k + c]) for the three consecutive column ranges of widths
+ * n0, n1, n2 (s_0 = 0, s_1 = n0, s_2 = n0 + n1): three gi_selu_bwd_rows_f calls in one launch
+ * (backward entry of the tier-2 stacks, gnn/modules.py:265-279).  fshift as in gi_selu_bwd_rows_f. */
+int gi_selu_bwd_cols3_f(const float* dY, int lddy, const float* Y, int ldy, long long fshift, int rows,
+                        int n0, float* out0, int ld0, int n1, float* out1, int ld1,
+                        int n2, float* out2, int ld2, void* stream);
+/* gi_expand_slots for two tier-1 outputs (a, b) sharing cidx in one launch; gi_compress_slots_f likewise */
+int gi_expand_slots2(const float* t1a, int ldta, int Wa, float* cata, int ldca,
+                     const float* t1b, int ldtb, int Wb, float* catb, int ldcb,
+                     const int* cidx, int B, int N, void* stream);
+int gi_compress_slots2_f(float* t1a, int ldta, int Wa, const float* dcata, int ldca, float* zparta, int ldza,
+                         float* t1b, int ldtb, int Wb, const float* dcatb, int ldcb, float* zpartb, int ldzb,
+                         const int* cidx, int B, int N, int S, long long fshift, void* stream);
 
 /* K7 gather readout — gnn/modules.py:44-52: g[b,:] = sum_n softmax_n(en[cidx[b,n]] - big*[mask==0]) * emb[cidx[b,n]],
  * written to up to three destinations (tier-2 concat inputs). */

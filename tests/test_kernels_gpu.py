@@ -484,6 +484,168 @@ def test_seg_sum_and_accumulate():
         assert rel(buf[:, :cols], want[:, :cols]) < 1e-6
 
 
+# ---- GI_FUSE variants (launch-count reductions): each against the launches it replaces -----------
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _gates_case(H, Fn, seed):
+    """A real graph batch's CSRs plus random GRU tensors; rows without incoming edges included."""
+    n8, e8, _ = synthetic.make_batch(37, **synthetic.SHAPES["gdb13"], seed=seed)
+    g = D.compact(n8, e8)
+    S, U = g["S"], g["U"]
+    R = S + 1
+    gen = torch.Generator().manual_seed(seed)
+    ldg, ldhx, ldH = ops.r4(3 * H), ops.r4(H + Fn), ops.r4(H)
+    gi = torch.randn(R, ldg, generator=gen)
+    gh = torch.randn(R, ldg, generator=gen)
+    hx = torch.randn(R, ldhx, generator=gen)
+    seg = torch.from_numpy(g["seg_off"])
+    has_edge = (seg[1:R + 1] - seg[:R]) > 0
+    assert bool(has_edge.any()) and not bool(has_edge.all())
+    return g, R, U, gi, gh, hx, seg, has_edge, ldg, ldhx, ldH, gen
+
+
+@pytest.mark.parametrize("H,Fn", [(128, 8), (100, 8), (16, 5), (18, 5)])
+def test_gru_gates_forward_and_backward_kernels(H, Fn):
+    """gi_gru_gates_fwd / gi_gru_gates_bwd / gi_gru_gates_bwd_ex (16-byte vector kernels when H % 4 == 0,
+    scalar otherwise — H = 18) against the fp64 dataflow model; the vector and the scalar backward agree."""
+    lib = L.load()
+    g, R, U, gi, gh, hx, seg, has_edge, ldg, ldhx, ldH, gen = _gates_case(H, Fn, 3)
+    h_new, saved = D.gru_gates(gi[:, :3 * H].double(), gh[:, :3 * H].double(), hx[:, :H].double(), has_edge)
+    gi_d, gh_d, hx_d, seg_d = gi.to(DEV), gh.to(DEV), hx.to(DEV), seg.to(DEV)
+    hx_new = torch.full((R, ldhx), 7.0, device=DEV)
+    L.check(lib.gi_gru_gates_fwd(gi_d.data_ptr(), gh_d.data_ptr(), ldg, hx_d.data_ptr(), hx_new.data_ptr(),
+                                 ldhx, seg_d.data_ptr(), R, H, Fn, _stream()), "gates_fwd")
+    assert rel(hx_new[:, :H], h_new) < 2e-6
+    assert torch.equal(hx_new[:, H:].cpu(), hx[:, H:])                      # feature tail + padding copied
+    e = has_edge.numpy()
+    for got, want in ((gi_d[:, :H], saved[0]), (gi_d[:, H:2 * H], saved[1]), (gi_d[:, 2 * H:3 * H], saved[2])):
+        assert rel(got[e], want[e]) < 2e-6
+    assert torch.equal(gi_d[~has_edge.to(DEV)].cpu(), gi[~has_edge])       # untouched without edges
+    assert torch.equal(gh_d.cpu(), gh)
+    # backward: d h = dh + dhb + dhc + dhd
+    dhs = [torch.randn(R, ldH, generator=gen) for _ in range(4)]
+    want_gi, want_gh, want_dh = D.gru_gates_bwd(sum(t[:, :H].double() for t in dhs),
+                                                tuple(t.double() for t in saved), hx[:, :H].double(), has_edge)
+    outs = []
+    for entry in ("gi_gru_gates_bwd", "gi_gru_gates_bwd_ex"):
+        a, b = gi_d.clone(), gh_d.clone()
+        dprev = torch.full((R, ldH), 7.0, device=DEV)
+        dd = [t.to(DEV) for t in dhs]
+        args = [a.data_ptr(), b.data_ptr(), ldg, hx_d.data_ptr(), ldhx] + [t.data_ptr() for t in dd] + \
+               [dprev.data_ptr(), ldH, seg_d.data_ptr(), R, H]
+        if entry.endswith("_ex"):
+            args += [None, None, 0, None, None]
+        L.check(getattr(lib, entry)(*args, _stream()), entry)
+        assert rel(a[:, :3 * H], want_gi) < 2e-6 and rel(b[:, :3 * H], want_gh) < 2e-6
+        assert rel(dprev[:, :H], want_dh) < 2e-6
+        outs.append((a, b, dprev))
+    for x, y in zip(*outs):
+        assert rel(x[:, :3 * H] if x.shape[1] >= 3 * H else x[:, :H],
+                   y[:, :3 * H] if y.shape[1] >= 3 * H else y[:, :H]) < 1e-6
+
+
+@pytest.mark.parametrize("two", [False, True])
+def test_gru_gates_backward_with_fused_scatter_is_bit_exact(two):
+    """gi_gru_gates_bwd_ex(sc0[, sc1]) == gi_seg_sum(sc, out_perm, src_off, dh, accumulate) launches in front
+    of the plain gate backward, bit for bit (same summation order)."""
+    lib = L.load()
+    H, Fn = 100, 8
+    g, R, U, gi, gh, hx, seg, has_edge, ldg, ldhx, ldH, gen = _gates_case(H, Fn, 5)
+    perm, off = torch.from_numpy(g["out_perm"]).to(DEV), torch.from_numpy(g["src_off"]).to(DEV)
+    sc = [torch.randn(U, ldH, generator=gen).to(DEV) for _ in range(2 if two else 1)]
+    dh = torch.randn(R, ldH, generator=gen)
+    hx_d, seg_d = hx.to(DEV), seg.to(DEV)
+    res = []
+    for fused in (False, True):
+        a, b, d = gi.to(DEV), gh.to(DEV), dh.to(DEV)
+        dprev = torch.full((R, ldH), 7.0, device=DEV)
+        if not fused:
+            for t in sc:
+                ops.seg_sum(t, perm, off, R, H, d, accumulate=True)
+        tail = [None, None, 0, None, None] if not fused else \
+            [sc[0].data_ptr(), sc[1].data_ptr() if two else None, ldH, perm.data_ptr(), off.data_ptr()]
+        L.check(lib.gi_gru_gates_bwd_ex(a.data_ptr(), b.data_ptr(), ldg, hx_d.data_ptr(), ldhx, d.data_ptr(),
+                                        None, None, None, dprev.data_ptr(), ldH, seg_d.data_ptr(), R, H,
+                                        *tail, _stream()), "gates_bwd_ex")
+        res.append((a[:, :3 * H], b[:, :3 * H], dprev[:, :H]))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+    # the scalar-kernel shapes cannot take the fused scatter: reported, not silently ignored
+    assert lib.gi_gru_gates_bwd_ex(gi.to(DEV).data_ptr(), gh.to(DEV).data_ptr(), ldg, hx_d.data_ptr(), ldhx,
+                                   dh.to(DEV).data_ptr(), None, None, None, dprev.data_ptr(), ldH,
+                                   seg_d.data_ptr(), R, 98, sc[0].data_ptr(), None, ldH, perm.data_ptr(),
+                                   off.data_ptr(), _stream()) == -1
+
+
+def test_selu_bwd_cols3_matches_three_launches():
+    lib = L.load()
+    gen = torch.Generator().manual_seed(8)
+    B, n0, n1, n2 = 57, 585, 39, 1
+    W = n0 + n1 + n2
+    Y = D.selu(torch.randn(B, W, generator=gen)).to(DEV)
+    dY = torch.randn(B, W + 3, generator=gen).to(DEV)
+    lds = (ops.r4(n0), ops.r4(n1), 4)
+    a = [torch.full((B, ld), 7.0, device=DEV) for ld in lds]
+    b = [torch.full((B, ld), 7.0, device=DEV) for ld in lds]
+    start = 0
+    for t, n in zip(a, (n0, n1, n2)):
+        L.check(lib.gi_selu_bwd_rows(dY.data_ptr() + 4 * start, dY.stride(0), None, Y.data_ptr() + 4 * start,
+                                     Y.stride(0), t.data_ptr(), t.stride(0), B, n, _stream()), "selu_bwd_rows")
+        start += n
+    L.check(lib.gi_selu_bwd_cols3_f(dY.data_ptr(), dY.stride(0), Y.data_ptr(), Y.stride(0), 0, B, n0,
+                                    b[0].data_ptr(), lds[0], n1, b[1].data_ptr(), lds[1], n2, b[2].data_ptr(),
+                                    lds[2], _stream()), "selu_bwd_cols3")
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert rel(b[1][:, :n1], dY[:, n0:n0 + n1].double() * D.selu_grad_from_out(Y[:, n0:n0 + n1].double().cpu()).to(DEV)) < 1e-6
+
+
+@pytest.mark.parametrize("shape,B", [("gdb13", 61), ("chembl", 9)])
+def test_slot_glue_pairs_match_single_launches(shape, B):
+    """gi_expand_slots2 / gi_compress_slots2_f == two gi_expand_slots / gi_compress_slots launches."""
+    lib = L.load()
+    sh = synthetic.SHAPES[shape]
+    n8, e8, _ = synthetic.make_batch(B, **sh, seed=12)
+    ref = D.compact(n8, e8)
+    S, N = ref["S"], sh["max_n_nodes"]
+    cidx = torch.from_numpy(ref["cidx"]).to(DEV)
+    gen = torch.Generator().manual_seed(13)
+    Wa, Wb = sh["n_atom_types"] * sh["n_formal_charge"] * sh["n_edge_features"], sh["n_edge_features"]
+    t1 = [D.selu(torch.randn(S + 1, ops.r4(W), generator=gen)).to(DEV) for W in (Wa, Wb)]
+    ldc = [ops.r4(N * W + 100) for W in (Wa, Wb)]
+    cat_a = [torch.full((B, ld), 7.0, device=DEV) for ld in ldc]
+    cat_b = [torch.full((B, ld), 7.0, device=DEV) for ld in ldc]
+    for t, c, W in zip(t1, cat_a, (Wa, Wb)):
+        L.check(lib.gi_expand_slots(t.data_ptr(), t.stride(0), cidx.data_ptr(), B, N, W, c.data_ptr(),
+                                    c.stride(0), _stream()), "expand")
+    L.check(lib.gi_expand_slots2(t1[0].data_ptr(), t1[0].stride(0), Wa, cat_b[0].data_ptr(), ldc[0],
+                                 t1[1].data_ptr(), t1[1].stride(0), Wb, cat_b[1].data_ptr(), ldc[1],
+                                 cidx.data_ptr(), B, N, _stream()), "expand2")
+    for x, y in zip(cat_a, cat_b):
+        assert torch.equal(x, y)
+    assert torch.equal(cat_b[1][:, :N * Wb].reshape(B, N, Wb), t1[1][cidx.view(B, N).long(), :Wb])
+    dcat = [torch.randn(B, ld, generator=gen).to(DEV) for ld in ldc]
+    outs = []
+    for pair in (False, True):
+        y = [t.clone() for t in t1]
+        z = [torch.full((B, ops.r4(W)), 7.0, device=DEV) for W in (Wa, Wb)]
+        if pair:
+            L.check(lib.gi_compress_slots2_f(y[0].data_ptr(), y[0].stride(0), Wa, dcat[0].data_ptr(), ldc[0],
+                                             z[0].data_ptr(), z[0].stride(0), y[1].data_ptr(), y[1].stride(0),
+                                             Wb, dcat[1].data_ptr(), ldc[1], z[1].data_ptr(), z[1].stride(0),
+                                             cidx.data_ptr(), B, N, S, 0, _stream()), "compress2")
+        else:
+            for k, W in enumerate((Wa, Wb)):
+                L.check(lib.gi_compress_slots(y[k].data_ptr(), y[k].stride(0), cidx.data_ptr(), B, N, W, S,
+                                              dcat[k].data_ptr(), ldc[k], z[k].data_ptr(), z[k].stride(0),
+                                              _stream()), "compress")
+        outs.append(y + z)
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+
+
 def test_selu_bwd_rows_gather():
     g = torch.Generator().manual_seed(5)
     dA = torch.randn(50, 128, generator=g)
