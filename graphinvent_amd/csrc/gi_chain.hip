@@ -293,8 +293,71 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
     };
 
     // ---- prologue: the input rows -> LDS (zero beyond K0); then the first two weight tiles ----------
-    // branch-free: all index loads, then all row loads, then all LDS writes (rows 36..39 are scratch)
-    {
+    // Backward with seg_vals: the input rows are FORMED here — the backward of the aggregation onto message
+    // rows, d m_u = selu'(m_u) * sum over the row's CSR segment of seg_vals rows (gi_seg_sum_dselu, otherwise
+    // its own launch in front of this one) — written back to X (the last layer's weight gradient reads
+    // them) and to LDS.  A wave owns whole rows (row = wave + 8 i), so segment bounds and indices are
+    // wave-uniform; all offset loads, then all index loads, then all row loads are issued back to back
+    // (two segment entries per row up front; longer segments — rare — loop), sums in segment order
+    // like seg_sum_dselu_kernel: bit-identical results.
+    if (BWD && P.seg_vals != nullptr) {
+        const int c = 4 * (tid & 63);
+        const int K0 = P.layer[0].K;
+        float* const Xw = const_cast<float*>(P.X);
+        constexpr int NP = 4 * RB + 1, CHUNK = 5;
+#pragma unroll
+        for (int base = 0; base < NP; base += CHUNK) {
+            v4f w[CHUNK];
+#pragma unroll
+            for (int i = 0; i < CHUNK; ++i) w[i] = v4f{0.f, 0.f, 0.f, 0.f};
+            if (c < K0) {                                    // lanes beyond the input width only write zeros
+                int lo[CHUNK], cnt[CHUNK], e0[CHUNK], e1[CHUNK];
+                long long xrow[CHUNK];
+#pragma unroll
+                for (int i = 0; i < CHUNK; ++i) {
+                    const int lr = swid + 8 * (base + i);
+                    const bool live = (base + i < NP) && lr < nvalid;
+                    xrow[i] = (long long)r0 + (live ? lr : 0);
+                    lo[i] = P.seg_off[xrow[i]];
+                    cnt[i] = live ? P.seg_off[xrow[i] + 1] : 0;
+                }
+#pragma unroll
+                for (int i = 0; i < CHUNK; ++i) {
+                    lo[i] = __builtin_amdgcn_readfirstlane(lo[i]);
+                    cnt[i] = max(__builtin_amdgcn_readfirstlane(cnt[i]) - lo[i], 0);
+                    const int k0 = cnt[i] > 0 ? lo[i] : max(lo[i] - 1, 0);     // always a readable entry
+                    e0[i] = P.seg_idx[k0];
+                    e1[i] = P.seg_idx[cnt[i] > 1 ? lo[i] + 1 : k0];
+                }
+                v4f y[CHUNK], a0[CHUNK], a1[CHUNK];
+#pragma unroll
+                for (int i = 0; i < CHUNK; ++i) {
+                    y[i] = *(const v4f*)(Xw + xrow[i] * P.ldx + c);
+                    a0[i] = *(const v4f*)(P.seg_vals + (long long)e0[i] * P.ld_seg + c);
+                    a1[i] = *(const v4f*)(P.seg_vals + (long long)e1[i] * P.ld_seg + c);
+                }
+#pragma unroll
+                for (int i = 0; i < CHUNK; ++i) {
+                    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+                    v4f acc = zero;
+                    acc += cnt[i] > 0 ? a0[i] : zero;
+                    acc += cnt[i] > 1 ? a1[i] : zero;        // (acc is never -0: + 0 leaves it unchanged)
+                    for (int k = 2; k < cnt[i]; ++k)
+                        acc += *(const v4f*)(P.seg_vals + (long long)P.seg_idx[lo[i] + k] * P.ld_seg + c);
+                    const v4f yy = y[i];
+                    w[i] = acc * v4f{gi_selu_grad(yy.x), gi_selu_grad(yy.y), gi_selu_grad(yy.z),
+                                     gi_selu_grad(yy.w)};
+                    if (base + i < NP && swid + 8 * (base + i) < nvalid)    // (rows beyond alias row r0)
+                        *(v4f*)(Xw + xrow[i] * P.ldx + c) = w[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < CHUNK; ++i)
+                if (base + i < NP) *(v4f*)&As[(swid + 8 * (base + i)) * CH_ALD + c] = w[i];
+        }
+        // the stores above are not part of the main loop's load counting: drained here, once
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
         const int mc4 = tid & 63, mrow = tid >> 6;
         const int K0 = P.layer[0].K, cmax = ((K0 + 3) & ~3) - 4;
         const int c = 4 * mc4;
@@ -419,6 +482,11 @@ int validate_chain(const gi_chain_params& p) {
     if (p.ngroups < 1 || p.ngroups > GI_MAX_GROUPS) return GI_EINVAL;
     if (p.ngroups > 1 && !p.grp_off) return GI_EINVAL;
     if (p.ldx < ((p.layer[0].K + 3) & ~3)) return GI_EINVAL;   // 16-byte reads end inside the row
+    if (p.seg_vals) {                       // input formed in place by the fused segmented sum (backward)
+        if (!p.backward || p.x_idx || !p.seg_idx || !p.seg_off) return GI_EINVAL;
+        if ((p.layer[0].K & 3) || (p.ldx & 3) || (p.ld_seg & 3) || p.ld_seg < p.layer[0].K) return GI_EINVAL;
+        if (((uintptr_t)p.X & 15) || ((uintptr_t)p.seg_vals & 15)) return GI_EINVAL;
+    }
     for (int l = 0; l < p.nlayers; ++l) {
         const gi_chain_layer& q = p.layer[l];
         if (q.K < 4 || q.N < 4 || q.K > GI_CHAIN_MAXW || q.N > GI_CHAIN_MAXW) return GI_ELIMIT;

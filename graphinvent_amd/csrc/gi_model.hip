@@ -580,6 +580,8 @@ void add_dgrad(Batch& b, Run& r, int widx, int n_out, int n_in, int ncols, const
 
 void flush_deferred(Run& r, Deferred& q);
 void kick_deferred(Run& r, Deferred& q, SideStream* side, bool all);
+void kick_inline(Run& r, Deferred& q, bool all);
+int wgrad_inline();
 
 gi_reduce_desc reduce_desc(const SlabEntry& e, float* slabs, float* const* grads, int widx) {
     gi_reduce_desc q;
@@ -739,6 +741,44 @@ void kick_deferred(Run& r, Deferred& q, SideStream* side, bool all) {
     q.n -= n;
 }
 
+// The same bookkeeping with the launches on the MAIN stream (no events needed): every complete batch of
+// 8 queued problems (all of them when `all`), then the slab reduction of every parameter that is finished.
+// Used by the GI_WGRAD_INLINE schedules below.
+void kick_inline(Run& r, Deferred& q, bool all) {
+    if (!r.ok()) return;
+    const int n = all ? q.n : (q.n / 8) * 8;
+    if (n == 0) return;
+    launch_wgrad_batches(r, q.p, n, r.st);
+    gi_reduce_desc descs[96 * GI_MAX_GROUPS > 160 ? 160 : 96 * GI_MAX_GROUPS];
+    int nd = 0;
+    const bool in_kernel = wgrad_reduce_in_kernel();
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < q.nw[i]; ++k) {
+            SlabEntry& e = r.sp->e[q.widx[i][k]];
+            if (++e.launched == e.calls && !e.reduced && nd < 160) {
+                e.reduced = 1;
+                if (!in_kernel) descs[nd++] = reduce_desc(e, r.slabs, r.grads, q.widx[i][k]);
+            }
+        }
+    if (nd && r.ok()) r.chk(gi_reduce_slabs(descs, nd, r.st));
+    for (int i = n; i < q.n; ++i) {
+        q.p[i - n] = q.p[i];
+        q.nw[i - n] = q.nw[i];
+        for (int k = 0; k < q.nw[i]; ++k) q.widx[i - n][k] = q.widx[i][k];
+    }
+    q.n -= n;
+}
+
+// Measurement knob GI_WGRAD_INLINE (bit mask, default 0): weight-gradient batches that are NOT handed to
+// the side stream but run on the main stream where they are queued.  Bit 0: the node-level readout stacks'
+// (20 problems with the longest reductions: on the side stream they are still running when the message
+// passes' dZ-chain launches arrive, and a chain workgroup needs a CU free of their workgroups — 145 KB of
+// LDS); bit 1: the graph-level stacks' as well.
+int wgrad_inline() {
+    static const int v = getenv("GI_WGRAD_INLINE") ? atoi(getenv("GI_WGRAD_INLINE")) : 0;
+    return v;
+}
+
 void join_side(Run& r, SideStream* side) {
     if (!side || !r.ok()) return;
     hipEvent_t done = side->next();
@@ -827,23 +867,51 @@ void chain_bwd_exclusive(Run& r) {
 }
 
 // The bond-type-grouped message MLP: dZ chain now, weight gradients deferred.
+// Zlast of a message stack = selu'(m) * (segmented sum of `vals` rows over the message CSR), formed in
+// place over the stack's forward output: its own launch (gi_seg_sum_dselu_f), or — GI_FUSE_CHAIN_DM — inside
+// the dZ-chain launch that reads it (gi_chain_params.seg_vals)
+struct SegIn { const float* vals; int ld; const int* idx; const int* off; };
+
+bool seg_fusable(const Run& r, const SegIn* seg, const Mlp& q, const float* Zlast, int ldz) {
+    return seg && seg->vals && !r.drop && (gi_fuse_flags() & GI_FUSE_CHAIN_DM) && (q.out & 3) == 0 &&
+           (ldz & 3) == 0 && (seg->ld & 3) == 0 && seg->ld >= q.out && !((uintptr_t)Zlast & 15) &&
+           !((uintptr_t)seg->vals & 15);
+}
+
+void seg_attach(gi_chain_params& c, const SegIn* seg) {
+    c.seg_vals = seg->vals; c.ld_seg = seg->ld; c.seg_idx = seg->idx; c.seg_off = seg->off;
+}
+
+void seg_launch(Run& r, const SegIn* seg, int rows, int cols, float* y, int ldy) {
+    if (seg && seg->vals && r.ok())
+        r.chk(gi_seg_sum_dselu_f(seg->vals, seg->ld, seg->idx, seg->off, rows, cols, y, ldy, r.fshift, r.st));
+}
+
 void msg_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred& dq, const Mlp* mlps,
                   const Grp& g, const float* X, int ldx, const int* a_idx, int rows,
                   const long long* acts, const long long* dzs, int ldh, const float* Zlast, int ldz,
-                  float* dX, int lddx, int dx_cols) {
+                  float* dX, int lddx, int dx_cols, const SegIn* seg = nullptr) {
     const int L = mlps[0].layers();
     if (g.n && r.ok() && rows > 0 && r.img_b[mlps == r.eatt0 ? 1 : 0] && dx_cols == mlps[0].in &&
         ldz >= gi_r4(mlps[0].out)) {
         gi_chain_params c;                      // the whole dZ chain in one launch, then the wgrads
         if (chain_bwd_params(c, r, ws, mlps, g, Zlast, ldz, rows, acts, dzs, ldh, dX, lddx, dx_cols)) {
+            if (seg_fusable(r, seg, mlps[0], Zlast, ldz)) {
+                seg_attach(c, seg);
+            } else {
+                seg_launch(r, seg, rows, mlps[0].out, const_cast<float*>(Zlast), ldz);
+            }
             chain_bwd_exclusive(r);
             r.chk(gi_mlp_chain(&c, 1, r.st));
+        } else {
+            seg_launch(r, seg, rows, mlps[0].out, const_cast<float*>(Zlast), ldz);
         }
         r.hold_kicks = false;
         defer_stack_wgrads(r, ws, sp, slabs, dq, mlps, g, X, ldx, a_idx, rows, acts, dzs, ldh, Zlast,
                            ldz);
         return;
     }
+    seg_launch(r, seg, rows, mlps[0].out, const_cast<float*>(Zlast), ldz);
     for (int l = L - 1; l >= 0; --l) {
         const float* dZ = (l == L - 1) ? Zlast : ws + dzs[l];
         const int lddz = (l == L - 1) ? ldz : ldh;
@@ -987,6 +1055,11 @@ void defer_stack_wgrads(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred&
 
 // ---- AttGGNN: the message MLP and the energy MLP of a pass are siblings (same input rows, same
 // bond-type grouping): layer l of both goes into one launch, like the readout's sibling stacks.
+struct SegIn;
+bool seg_fusable(const Run& r, const SegIn* seg, const Mlp& q, const float* Zlast, int ldz);
+void seg_launch(Run& r, const SegIn* seg, int rows, int cols, float* y, int ldy);
+void seg_attach(gi_chain_params& c, const SegIn* seg);
+
 struct EdgeChain {
     const Mlp* mlps;               // [Fe] per-bond-type stacks
     const long long* acts;         // hidden activations (ws offsets)
@@ -994,6 +1067,7 @@ struct EdgeChain {
     int ldh;
     float* out; int ldout;         // forward: last layer's output; backward: its dZ (in place)
     float* dX;                     // backward: first-layer input gradient [E, ldH] or null
+    const struct SegIn* seg = nullptr;   // backward: `out` is first formed in place from these (see SegIn)
 };
 
 void grouped_problem(gi_gemm_params& p, const Grp& g) {
@@ -1052,9 +1126,14 @@ void edge_chains_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferre
         ch[1].ldout >= gi_r4(ch[1].mlps[0].out)) {
         gi_chain_params c[2];                   // both dZ chains in ONE launch, then the wgrads
         int nl[2];
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
             nl[j] = chain_bwd_params(c[j], r, ws, ch[j].mlps, g, ch[j].out, ch[j].ldout, rows,
                                      ch[j].acts, ch[j].dzs, ch[j].ldh, ch[j].dX, lddx, dx_cols);
+            if (nl[j] && seg_fusable(r, ch[j].seg, ch[j].mlps[0], ch[j].out, ch[j].ldout))
+                seg_attach(c[j], ch[j].seg);
+            else
+                seg_launch(r, ch[j].seg, rows, ch[j].mlps[0].out, ch[j].out, ch[j].ldout);
+        }
         if (nl[0] || nl[1]) chain_bwd_exclusive(r);
         if (nl[0] && nl[1]) r.chk(gi_mlp_chain(c, 2, r.st));
         else if (nl[0]) r.chk(gi_mlp_chain(&c[0], 1, r.st));
@@ -1065,6 +1144,7 @@ void edge_chains_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferre
                                ch[j].dzs, ch[j].ldh, ch[j].out, ch[j].ldout);
         return;
     }
+    for (int j = 0; j < n; ++j) seg_launch(r, ch[j].seg, rows, ch[j].mlps[0].out, ch[j].out, ch[j].ldout);
     int maxL = 0;
     for (int j = 0; j < n; ++j) maxL = std::max(maxL, ch[j].mlps[0].layers());
     for (int s = 0; s < maxL; ++s) {
@@ -1506,7 +1586,10 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
                    w.conn2_dz, ws + w.dzC, w.ldNC, ws + w.dcat_conn, w.ldCC, NC + d.G, false};
         jobs[2] = {&m.term2, ws + w.gemb, w.ldG, d.B, w.term2_act, w.ldM2, nullptr, 0, w.term2_dz,
                    ws + w.dzT, 4, ws + w.dgemb, w.ldG, d.G, false};
+        const bool inl = r.side && (wgrad_inline() & 2);
+        if (inl) r.hold_kicks = true;
         mlp_jobs_backward(r, ws, sp, slabs, dq, jobs, 3);
+        if (inl) { r.hold_kicks = false; kick_inline(r, dq, true); }
     }
     // ---- gather + tier-1 glue: dZ of the last att/emb/add1/conn1 layers, in place ----------------
     r.chk(gi_gather_readout_bwd_f(ws + w.en, ws + w.embo, w.ldG, cidx, mask, d.B, d.N, d.G, S,
@@ -1551,10 +1634,12 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
         // 2.362 -> 2.344 ms, GEMM-family per-launch figure 0.349 -> 0.374 of peak (GI_HOLD_NODE_WGRADS=0
         // restores the old schedule).
         static const bool hold = !(getenv("GI_HOLD_NODE_WGRADS") && atoi(getenv("GI_HOLD_NODE_WGRADS")) == 0);
-        r.hold_kicks = hold;
+        const bool inl = r.side && (wgrad_inline() & 1);
+        r.hold_kicks = hold || inl;
         mlp_jobs_backward(r, ws, sp, slabs, dq, jobs, 4);
         r.hold_kicks = false;
-        if (hold && r.side) kick_deferred(r, dq, r.side, false);
+        if (inl) kick_inline(r, dq, true);          // everything queued so far, on the main stream
+        else if (hold && r.side) kick_deferred(r, dq, r.side, false);
     }
     }   // phase != GI_BWD_PASSES
     if (phase == GI_BWD_READOUT) {
@@ -1562,6 +1647,11 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
         // queued (side stream if there is one) so that the caller can start exchanging the gradients
         // of these parameters while the message passes are still being differentiated
         if (r.side) {
+            if (wgrad_inline()) {   // readout gradients finished on the MAIN stream: the caller's "ready"
+                hipEvent_t ev = r.side->next();     // event is recorded on the side stream, which must see them
+                r.chk((int)hipEventRecord(ev, r.st));
+                r.chk((int)hipStreamWaitEvent(r.side->st, ev, 0));
+            }
             kick_deferred(r, dq, r.side, true);          // also reduces every finished parameter
         } else {
             flush_deferred(r, dq);
@@ -1639,10 +1729,11 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
                 edge_chains_backward(r, ws, sp, slabs, dq, ch, 2, bytype0, hx, w.ldhx, gp->d_src, w.D0,
                                      w.ldH, d.H);
             } else {
-                r.chk(gi_seg_sum_dselu_f(ws + w.tmp_emb, w.ldM, mu_slot, mu_off, U, d.M, ws + w.m[p],
-                                         w.ldM, r.fshift, r.st));
-                r.chk(gi_seg_sum_dselu_f(ws + w.tmp_en, w.ldM, mu_slot, mu_off, U, d.M, ws + w.een[p],
-                                         w.ldM, r.fshift, r.st));
+                // per message row: the sum of its edges' contributions times the SELU derivative of the
+                // stack's last layer — own launches, or inside the dZ-chain launch (edge_chains_backward)
+                const SegIn seg_m{ws + w.tmp_emb, w.ldM, mu_slot, mu_off};
+                const SegIn seg_e{ws + w.tmp_en, w.ldM, mu_slot, mu_off};
+                ch[0].seg = &seg_m; ch[1].seg = &seg_e;
                 edge_chains_backward(r, ws, sp, slabs, dq, ch, 2, bytype, hx, w.ldhx, u_src, U, w.ldH,
                                      d.H);
             }
@@ -1671,11 +1762,11 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
         } else if (E > 0) {
             // d m_u = selu'(m_u) * sum over the edges reading row u of d agg[dst(e)]
             // (backward of the segmented sum + last SELU, over the message CSR)
-            r.chk(gi_seg_sum_dselu_f(dagg, w.ldM, mu_dst, mu_off, U, d.M, ws + w.m[p], w.ldM, r.fshift,
-                                     r.st));
+            // (the segmented sum runs as its own launch or inside the dZ chain: msg_backward decides)
+            const SegIn seg{dagg, w.ldM, mu_dst, mu_off};
             msg_backward(r, ws, sp, slabs, dq, m.msg, bytype, hx, w.ldhx, u_src, U, w.eact[p],
                          w.edz[p], w.ldEh, ws + w.m[p], w.ldM, p > 0 ? ws + w.dxe : nullptr, w.ldH,
-                         d.H);
+                         d.H, &seg);
             if (p > 0 && fuse_scatter)
                 scat0 = ws + w.dxe;
             else if (p > 0)   // scatter d h_src back to nodes: segmented sum over the source CSR

@@ -65,7 +65,8 @@ class ChainLayer(C.Structure):
 class ChainParams(C.Structure):
     _fields_ = [("layer", ChainLayer * CHAIN_MAXL), ("nlayers", ci), ("X", vp), ("ldx", ci),
                 ("x_idx", vp), ("grp_off", vp), ("ngroups", ci), ("group_rows", ci * GI_MAX_GROUPS),
-                ("rows", ci), ("backward", ci), ("image", vp), ("image_stride", cll)]
+                ("rows", ci), ("backward", ci), ("image", vp), ("image_stride", cll),
+                ("seg_vals", vp), ("ld_seg", ci), ("seg_idx", vp), ("seg_off", vp)]
 
 
 class GruParams(C.Structure):
@@ -180,7 +181,7 @@ SIGNATURES = {
     "gi_compress_slots2_f": (ci, [vp, ci, ci, vp, ci, vp, ci, vp, ci, ci, vp, ci, vp, ci, vp, ci, ci, ci,
                                   cll, vp]),
 }
-FUSE_GATES_V4, FUSE_DH_SCATTER, FUSE_TIER2_DSELU, FUSE_SLOTS = 1, 2, 4, 8     # GI_FUSE_*
+FUSE_GATES_V4, FUSE_DH_SCATTER, FUSE_TIER2_DSELU, FUSE_SLOTS, FUSE_CHAIN_DM = 1, 2, 4, 8, 16  # GI_FUSE_*
 
 _lib = None
 

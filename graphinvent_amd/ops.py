@@ -346,7 +346,8 @@ def ws_view(ws: torch.Tensor, dims, graph: "CompactGraph", name: str, rows: int,
 
 def mlp_chain(chains, backward=False):
     """gi_mlp_chain.  chains: list (1 or 2) of dicts with keys
-    X, x_idx (or None), grp_off (int32 tensor [G+1] or None), group_rows (host ints), rows, and
+    X, x_idx (or None), grp_off (int32 tensor [G+1] or None), group_rows (host ints), rows,
+    seg (backward, optional: dict(vals, idx, off) — gi_chain_params.seg_vals: X is formed in place) and
     layers = list of dicts(W=[per-group tensors], bias=[per-group tensors] (forward), out, act (backward
     or None), K, N)."""
     lib = L.load()
@@ -357,6 +358,10 @@ def mlp_chain(chains, backward=False):
         c.x_idx, c.grp_off = _ptr(spec.get("x_idx")), _ptr(spec.get("grp_off"))
         rows_g = list(spec.get("group_rows") or [spec["rows"]])
         c.ngroups, c.rows, c.backward = len(rows_g), spec["rows"], int(backward)
+        seg = spec.get("seg")              # backward: X formed in place by the fused segmented sum
+        if seg is not None:
+            c.seg_vals, c.ld_seg = seg["vals"].data_ptr(), seg["vals"].stride(0)
+            c.seg_idx, c.seg_off = seg["idx"].data_ptr(), seg["off"].data_ptr()
         for t, n in enumerate(rows_g):
             c.group_rows[t] = n
         for y, ly in zip(c.layer, spec["layers"]):

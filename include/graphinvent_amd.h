@@ -204,6 +204,14 @@ typedef struct {
     long long image_stride;               /* floats per group in the image; 0 = that of THESE layers.
                                              A chain that runs only the first layers of a packed
                                              stack passes the stride of the full pack. */
+    /* backward only, optional (seg_vals != NULL): the chain's input is first FORMED in place,
+     *   X[r, c] = selu'(X[r, c]) * sum_{k in [seg_off[r], seg_off[r+1])} seg_vals[seg_idx[k], c],  c < layer[0].K
+     * — exactly gi_seg_sum_dselu(seg_vals, ld_seg, seg_idx, seg_off, rows, K, X, ldx) in front of the chain (same
+     * summation order, bit for bit), folded into the workgroup's input load; X is WRITTEN (the last layer's
+     * weight gradient reads it).  Needs x_idx == NULL, layer[0].K % 4 == 0, ldx % 4 == 0, ld_seg % 4 == 0,
+     * ld_seg >= K, X and seg_vals 16-byte aligned (GI_EINVAL otherwise). */
+    const float* seg_vals; int ld_seg;
+    const int* seg_idx; const int* seg_off;
 } gi_chain_params;
 
 /* The kernel streams the weights as a pre-packed image (one linear stream of 32 KB LDS tile images per
@@ -350,11 +358,15 @@ int gi_gru_gates_bwd(float* gi, float* gh, int ldg, const float* hx_prev, int ld
  *                `nodes[edge_batch_nghb_idc]`, gnn/summation_mpnn.py:131-133) folded into the
  *                gi_gru_gates_bwd_ex launch of the next (earlier) message pass
  *   TIER2_DSELU  the SELU backward of the three logit column ranges in one launch (gi_selu_bwd_cols3_f)
- *   SLOTS        fAddNet1 / fConnNet1 glue in one launch each way (gi_expand_slots2, gi_compress_slots2_f) */
+ *   SLOTS        fAddNet1 / fConnNet1 glue in one launch each way (gi_expand_slots2, gi_compress_slots2_f)
+ *   CHAIN_DM     the backward of the aggregation onto message rows (gi_seg_sum_dselu) inside the dZ-chain
+ *                launch that consumes it (gi_chain_params.seg_vals) */
 #define GI_FUSE_GATES_V4    1
 #define GI_FUSE_DH_SCATTER  2
 #define GI_FUSE_TIER2_DSELU 4
 #define GI_FUSE_SLOTS       8
+#define GI_FUSE_CHAIN_DM    16   /* gi_seg_sum_dselu in front of a dZ chain folded into the chain launch
+                                    (gi_chain_params.seg_vals) */
 #define GI_FUSE_DEFAULT     0
 int gi_fuse_flags(void);
 /* gi_gru_gates_bwd with d h = dh_new + sum over the source-CSR segment [sc_off[r], sc_off[r+1]) of the rows

@@ -296,6 +296,96 @@ def test_mlp_chain_64_row_blocks(monkeypatch, sizes, off):
     _chain_case(sizes, off, seed=64, two=True)
 
 
+def _chain_seg_case(sizes, off, seed, two=False):
+    """dZ chain whose input is formed in place by the fused segmented sum (gi_chain_params.seg_vals)
+    against gi_seg_sum_dselu + the plain dZ chain: every dZ buffer, the first-layer input gradient AND the
+    written-back input rows bit-identical.  Segments of 0..5 entries, an empty last segment."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(seed)
+    G = len(off) - 1
+    E, V = off[-1], 211
+    offt = torch.tensor(off, dtype=torch.int32).to(DEV)
+    rows_g = [off[t + 1] - off[t] for t in range(G)]
+    L_ = len(sizes) - 1
+    K0 = sizes[-1]
+    ldz = ops.r4(K0)
+    lens = torch.randint(0, 6, (E,), generator=g)
+    lens[-1] = 0
+    seg_off = torch.zeros(E + 1, dtype=torch.int32)
+    seg_off[1:] = torch.cumsum(lens, 0).int()
+    nnz = int(seg_off[-1])
+    seg_idx = torch.randint(0, V, (max(nnz, 1),), generator=g, dtype=torch.int32)
+    seg_off_d, seg_idx_d = seg_off.to(DEV), seg_idx.to(DEV)
+    nchains = 2 if two else 1
+    results = []
+    chains = []
+    for c in range(nchains):
+        Ws = [[(torch.randn(o, i, generator=g) / i ** 0.5).to(DEV) for _ in range(G)]
+              for i, o in zip(sizes, sizes[1:])]
+        acts = [D.selu(torch.randn(E, ops.r4(sizes[l]), generator=g)).to(DEV) for l in range(1, L_)]
+        vals = torch.randn(V, ldz + 4, generator=g)[:, :ldz + 4].to(DEV)
+        y = D.selu(torch.randn(E, ldz, generator=g))
+        chains.append((Ws, acts, vals, y))
+    for fused in (False, True):
+        specs, keep = [], []
+        for Ws, acts, vals, y in chains:
+            X = y.clone().to(DEV)
+            if not fused:
+                L.check(lib.gi_seg_sum_dselu(vals.data_ptr(), vals.stride(0), seg_idx_d.data_ptr(),
+                                             seg_off_d.data_ptr(), E, K0, X.data_ptr(), X.stride(0),
+                                             _stream()), "seg_sum_dselu")
+            douts = [torch.full((E, ops.r4(sizes[l]) + 4), 7.0, device=DEV) for l in range(L_)]
+            layers = [dict(W=Ws[l], out=douts[l], act=acts[l - 1] if l > 0 else None, K=sizes[l + 1],
+                           N=sizes[l]) for l in range(L_ - 1, -1, -1)]
+            spec = dict(X=X, x_idx=None, grp_off=offt, group_rows=rows_g, rows=E, layers=layers)
+            if fused:
+                spec["seg"] = dict(vals=vals, idx=seg_idx_d, off=seg_off_d)
+            specs.append(spec)
+            keep.append([X] + douts)
+        ops.mlp_chain(specs, backward=True)
+        results.append(keep)
+    for ka, kb in zip(*results):
+        for i, (a, b) in enumerate(zip(ka, kb)):
+            assert torch.equal(a, b), i
+    # the segmented sum itself against fp64 (first chain)
+    _, _, vals, y = chains[0]
+    want = D.seg_sum(vals[:, :K0].double().cpu(), seg_idx[:max(nnz, 1)], seg_off, E) * \
+        D.selu_grad_from_out(y[:, :K0].double())
+    assert rel(results[1][0][0][:, :K0], want) < 1e-6
+
+
+@pytest.mark.parametrize("sizes,off", [
+    ((128, 250, 250, 250, 250, 128), [0, 600, 600, 777]),
+    ((100, 250, 250, 100), [0, 33, 34, 131]),
+    ((16, 24, 12), [0, 5, 7, 8]),
+])
+def test_mlp_chain_backward_with_fused_segmented_sum(sizes, off):
+    _chain_seg_case(sizes, off, seed=sum(sizes))
+    _chain_seg_case(sizes, off, seed=7, two=True)
+
+
+@pytest.mark.parametrize("knob,value", [("GI_CHAIN_TILE_ROWS", "34"), ("GI_CHAIN_TILE_ROWS", "36"),
+                                        ("GI_CHAIN_ROWS64", "1")])
+def test_mlp_chain_fused_segmented_sum_block_heights(monkeypatch, knob, value):
+    monkeypatch.setenv(knob, value)
+    _chain_seg_case((128, 250, 250, 250, 250, 128), [0, 600, 600, 777], seed=11)
+    _chain_seg_case((100, 250, 250, 100), [0, 1000, 1001, 2500], seed=12, two=True)
+
+
+def test_mlp_chain_fused_segmented_sum_argument_checks():
+    lib = L.load()
+    z = torch.zeros(128, 132, device=DEV)       # big enough for the weight pack of a 128 x 100 layer
+    i32 = torch.zeros(65, dtype=torch.int32, device=DEV)
+    spec = dict(X=z, x_idx=None, grp_off=None, group_rows=None, rows=64,
+                layers=[dict(W=[z], bias=[z], out=z, act=None, K=126, N=100)],
+                seg=dict(vals=z, idx=i32, off=i32))
+    with pytest.raises(RuntimeError):            # first K not a multiple of 4
+        ops.mlp_chain([spec], backward=True)
+    spec["layers"][0]["K"] = 128
+    with pytest.raises(RuntimeError):            # forward chains take no segmented input
+        ops.mlp_chain([spec], backward=False)
+
+
 @pytest.mark.parametrize("H,M,Fn", [(128, 128, 8), (100, 100, 8), (16, 12, 5), (24, 20, 8)])
 @pytest.mark.parametrize("agg_ready", [False, True])
 def test_gru_fused_forward(H, M, Fn, agg_ready):
