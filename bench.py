@@ -383,13 +383,18 @@ def main():
     for i in range(prof_steps):
         b = batches[i % N_BATCHES]
         if rank == 0:
-            _, _, _, S, E, U, _, _ = ops.compact_count(b[0], b[1])
+            _, _, _, S, E, U, D0, _ = ops.compact_count(b[0], b[1])
             R, Mm, H, P = S + 1, cfg["message_size"], cfg["hidden_node_features"], cfg["message_passes"]
-            # algorithmic bytes of the three segmented sums (SURVEY.md §8d form): values read through
-            # the index + index + offsets + output
-            seg_bytes += P * (E * Mm * 4 + E * 4 + (R + 1) * 4 + R * Mm * 4)              # aggregation
-            seg_bytes += P * (E * Mm * 4 + E * 4 + (U + 1) * 4 + 2 * U * Mm * 4)          # its backward
-            if not (handle.gi_fuse_flags() & lib.FUSE_DH_SCATTER):      # (else inside the gate backward)
+            # algorithmic bytes of the segmented-sum LAUNCHES of this step (SURVEY.md §8d form: values
+            # read through the index + index + offsets + output).  Pass 0 aggregates through the
+            # edge-count matrix (a GEMM) when the pass-0 rows are on; the backward sums that GI_FUSE folds
+            # into the dZ chain / the gate backward are no launches of their own.
+            fuse = handle.gi_fuse_flags()
+            Pm = P - 1 if D0 > 0 else P                       # passes that run on message rows
+            seg_bytes += Pm * (E * Mm * 4 + E * 4 + (R + 1) * 4 + R * Mm * 4)             # aggregation
+            if not (fuse & lib.FUSE_CHAIN_DM):
+                seg_bytes += Pm * (E * Mm * 4 + E * 4 + (U + 1) * 4 + 2 * U * Mm * 4)     # its backward
+            if not (fuse & lib.FUSE_DH_SCATTER):
                 seg_bytes += (P - 1) * (U * H * 4 + U * 4 + (R + 1) * 4 + 2 * R * H * 4)  # d h scatter
         trainer.step(*b)
     torch.cuda.synchronize()

@@ -32,7 +32,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .loss import apd_kl_loss
+from .loss import apd_kl_loss, register_unit_gradient
 
 
 class ShardedBatchSampler:
@@ -77,6 +77,7 @@ class DataParallel:
         self.last_bucket_zero_copy = False
         self.last_overlapped = False
         self._pending = None           # (work handle, split offset) of the early tail all-reduce
+        self._one = None               # cached root gradient (see step)
         self._comm_stream = None
         # overlap needs the HIP model (it exposes the flat bucket and the two-call backward)
         self.overlap = (overlap and os.environ.get("GI_DP_OVERLAP", "1") != "0"
@@ -172,7 +173,13 @@ class DataParallel:
         if self.overlap:
             self.model._grad_ready_hook = self._early_allreduce   # see gnn/mpnn.py ggnn_backward_raw
         try:
-            loss.backward()
+            # the root gradient is a cached device scalar: autograd would otherwise launch a fill kernel
+            # for ones_like(loss) every step
+            one = self._one
+            if one is None or one.device != loss.device or one.dtype != loss.dtype:
+                one = self._one = register_unit_gradient(
+                    torch.ones((), dtype=loss.dtype, device=loss.device))
+            loss.backward(one)
         finally:
             if self.overlap:
                 self.model._grad_ready_hook = None

@@ -49,11 +49,28 @@ class _FusedKL(torch.autograd.Function):
         if d_out is None:
             raise RuntimeError("fused KL loss: backward called twice (its gradient buffer is "
                                "scaled in place)")
+        if grad.data_ptr() in _UNIT_GRADS:     # a registered constant 1.0: scaling would change nothing
+            return d_out, None
         g = grad.contiguous().float()
         L.check(L.load().gi_scale_by_scalar(d_out.data_ptr(), d_out.numel(), g.data_ptr(),
                                             torch.cuda.current_stream(d_out.device).cuda_stream),
                 "gi_scale_by_scalar")
         return d_out, None
+
+
+#: data pointers of device scalars that are known to hold exactly 1.0 for their whole life (kept alive
+#: and never written by whoever registers them: ``dp.DataParallel``'s cached root gradient).  For these the
+#: in-place scaling of the loss gradient — one launch per step — is skipped; the result is bit-identical.
+_UNIT_GRADS = set()
+
+
+def register_unit_gradient(t: torch.Tensor) -> torch.Tensor:
+    """Declare `t` (a scalar tensor the caller keeps alive and never modifies) to be the constant 1.0."""
+    import weakref
+    ptr = t.data_ptr()
+    _UNIT_GRADS.add(ptr)
+    weakref.finalize(t, _UNIT_GRADS.discard, ptr)      # the address may be recycled once `t` is gone
+    return t
 
 
 def apd_kl_loss(output: torch.Tensor, target_output: torch.Tensor) -> torch.Tensor:
