@@ -292,6 +292,8 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if os.environ.get("GI_BENCH_HIPRIO") == "1":      # measurement knob: the step on a high-priority stream
+        torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=-1))
     if args.probe_only:
         print(json.dumps({"aggregation_probe": seg_sum_hbm_probe(device)}), flush=True)
         return

@@ -582,6 +582,15 @@ void flush_deferred(Run& r, Deferred& q);
 void kick_deferred(Run& r, Deferred& q, SideStream* side, bool all);
 void kick_inline(Run& r, Deferred& q, bool all);
 int wgrad_inline();
+// Measurement knob GI_WGRAD_KICK=<1..8> (default 8): queued weight-gradient problems that make up one hand-over
+// to the side stream (one launch of up to 8 problems): smaller = earlier, shorter side-stream launches.
+int wgrad_kick_n() {
+    static const int v = [] {
+        const int x = getenv("GI_WGRAD_KICK") ? atoi(getenv("GI_WGRAD_KICK")) : 8;
+        return x < 1 ? 1 : (x > 8 ? 8 : x);
+    }();
+    return v;
+}
 
 gi_reduce_desc reduce_desc(const SlabEntry& e, float* slabs, float* const* grads, int widx) {
     gi_reduce_desc q;
@@ -634,7 +643,7 @@ void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* wid
         q.widx[slot][0] = widx[0];
         q.nw[slot] = 1;
     }
-    if (r.side && q.n >= 8 && !r.hold_kicks) kick_deferred(r, q, r.side, false);
+    if (r.side && q.n >= wgrad_kick_n() && !r.hold_kicks) kick_deferred(r, q, r.side, false);
 }
 
 // one launch per tile class among (up to) 8 consecutive queued problems
@@ -712,7 +721,8 @@ struct SideStream {
 // launch every complete batch of 8 queued problems (all of them when `all`) on the side stream
 void kick_deferred(Run& r, Deferred& q, SideStream* side, bool all) {
     if (!side || !r.ok()) return;
-    const int n = all ? q.n : (q.n / 8) * 8;
+    const int kn = wgrad_kick_n();
+    const int n = all ? q.n : (q.n / kn) * kn;
     if (n == 0) return;
     hipEvent_t ready = side->next();
     r.chk((int)hipEventRecord(ready, r.st));

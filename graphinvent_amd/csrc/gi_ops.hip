@@ -1064,8 +1064,9 @@ extern "C" int gi_dropout_mask(const gi_dropout_params* q, int rows, int cols, u
 
 // ---- launch-count reductions of the training step (GI_FUSE) ------------------------------------------
 // Bit mask, read once from the environment (GI_FUSE=<int>; default GI_FUSE_DEFAULT): which of the fused /
-// vectorised variants of the small kernels around the GEMMs the model uses.  Every variant computes
-// exactly what the launches it replaces compute (tests/test_kernels_gpu.py compares them bit for bit).
+// vectorised variants of the small kernels around the GEMMs the model uses (include/graphinvent_amd.h:
+// the fusions are bit-identical to the launches they replace, the vector gate kernels agree with the scalar
+// ones to rounding; tests/test_kernels_gpu.py).
 extern "C" int gi_fuse_flags(void) {
     static const int v = getenv("GI_FUSE") ? atoi(getenv("GI_FUSE")) : GI_FUSE_DEFAULT;
     return v;

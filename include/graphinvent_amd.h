@@ -350,8 +350,11 @@ int gi_gru_gates_bwd(float* gi, float* gh, int ldg, const float* hx_prev, int ld
                      float* dh_prev, int lddh, const int* seg_off, int rows, int H, void* stream);
 
 /* Launch-count reductions of the training step.  gi_fuse_flags() = the bit mask (environment GI_FUSE,
- * default GI_FUSE_DEFAULT) of the fused / vectorised variants gi_ggnn_forward / gi_ggnn_backward use;
- * each computes exactly what the launches it replaces compute (same summation orders):
+ * default GI_FUSE_DEFAULT) of the fused / vectorised variants gi_ggnn_forward / gi_ggnn_backward use.
+ * DH_SCATTER, TIER2_DSELU, SLOTS and CHAIN_DM reproduce the launches they replace bit for bit (same
+ * operations, same summation orders; tests/test_kernels_gpu.py compares them with torch.equal); GATES_V4
+ * evaluates the same formulas four hidden units at a time and agrees with the scalar kernels to rounding
+ * (hipcc contracts the multiply-adds of the vector code differently: <= 1e-6 relative, same test file).
  *   GATES_V4     gi_gru_gates_fwd / _bwd on 16-byte vectors (4 hidden units per thread) when H % 4 == 0
  *   DH_SCATTER   the scatter of the message stacks' input gradients to their source nodes
  *                (gi_seg_sum over the source CSR, accumulating into d h; backward of
@@ -367,7 +370,11 @@ int gi_gru_gates_bwd(float* gi, float* gh, int ldg, const float* hx_prev, int ld
 #define GI_FUSE_SLOTS       8
 #define GI_FUSE_CHAIN_DM    16   /* gi_seg_sum_dselu in front of a dZ chain folded into the chain launch
                                     (gi_chain_params.seg_vals) */
-#define GI_FUSE_DEFAULT     0
+/* Measured on the headline step (tools/ab/ab_run39.sh, two A/B pairs): 15 -> 2.319 / 2.325 ms against
+ * 2.359 / 2.353 with everything off; + CHAIN_DM 2.328 / 2.352 (its three dependent loads per row lengthen the
+ * chain workgroup's prologue by about what the saved launch cost; ZINC shape 5.01 vs 4.98 ms, ChEMBL shape
+ * 3.82 vs 3.85) -> CHAIN_DM stays opt-in. */
+#define GI_FUSE_DEFAULT     15
 int gi_fuse_flags(void);
 /* gi_gru_gates_bwd with d h = dh_new + sum over the source-CSR segment [sc_off[r], sc_off[r+1]) of the rows
  * sc0[sc_perm[k]] (+ the same over sc1 when non-NULL; both [*, ldsc >= H]) — what gi_seg_sum(sc, sc_perm,

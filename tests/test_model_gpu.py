@@ -377,7 +377,16 @@ def test_full_batch_properties():
     perm = np.random.default_rng(0).permutation(1000)
     op, _, gp = hip_forward_backward(model, n8[perm], e8[perm], a8[perm])
     assert rel(op, o1[perm]) < 1e-5
-    assert max(rel(gp[k], g1[k]) for k in g1) < 1e-3
+    # Gradients: the permuted batch sums the weight gradients in another row order (rounding) AND moves a
+    # few of the ~1e7 SELU outputs that sit within rounding of 0 to the other side of the kink, each of
+    # which changes single gradient entries by O(1) of their size (up to 5.6e-3 of a tensor's
+    # max|g| between two correct fp32 evaluations).  So: the gradient as a whole agrees tightly, single
+    # tensors within the kink-flip magnitude.  (A fixed 1e-3 per tensor passed / failed — 0.9e-3 .. 1.1e-3 —
+    # with ulp-level changes in unrelated kernels.)
+    num = sum(float((gp[k].double() - g1[k].double()).pow(2).sum()) for k in g1)
+    den = sum(float(g1[k].double().pow(2).sum()) for k in g1)
+    assert (num / den) ** 0.5 < 1e-3
+    assert max(rel(gp[k], g1[k]) for k in g1) < 1e-2
     model.eval()
     with torch.no_grad():
         halves = [model(*to_dev(n8[s], e8[s])).cpu() for s in (slice(0, 400), slice(400, 1000))]
