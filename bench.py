@@ -341,6 +341,8 @@ def main():
                                  if trainer.overlap else "flat fp32 bucket after the backward")},
     }
     result["config"]["fuse_flags"] = int(lib.load().gi_fuse_flags())     # GI_FUSE_* variants in use
+    if trainer.pipeline_readout:      # opt-in (GI_PIPELINE_READOUT=1): readout update under the next forward
+        result["config"]["pipeline_readout"] = True
     if args.backend != "nccl":
         result["config"]["backend"] = args.backend + " (control-flow smoke test, not a measurement)"
 

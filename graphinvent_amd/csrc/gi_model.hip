@@ -1293,6 +1293,12 @@ static int dropout_graph_ok(const gi_ggnn_dims& d, int S, int E, int U, int D0) 
 
 extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* params,
                                const gi_graph* gp, float* ws, float* out, int ldout, void* stream) {
+    return gi_ggnn_forward_ex(dp, params, gp, ws, out, ldout, stream, nullptr);
+}
+
+extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* params,
+                                  const gi_graph* gp, float* ws, float* out, int ldout, void* stream,
+                                  void* readout_ready) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     Model m;
     int rc = build_model(dp, m);
@@ -1421,6 +1427,9 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
                                seg_off, R, d.H, d.Fn, r.st));
     }
     // ---- readout (gnn/mpnn.py:299-303) -----------------------------------------------------------
+    // Pipelined readout update (gi_ggnn_backward_ex): the previous step's Adam over the readout parameters
+    // may still be running on another stream — the message passes above never read them, the readout does.
+    if (readout_ready) r.chk((int)hipStreamWaitEvent(r.st, (hipEvent_t)readout_ready, 0));
     const float* hx = ws + w.hx[d.passes];
     {   // the four node-level stacks, layer by layer in shared launches
         MlpJob jobs[4] = {};
@@ -1500,7 +1509,17 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
                                       const float* y_out, int ldout, const float* d_out, int lddout,
                                       float* const* grads, void* stream, void* side_stream,
                                       int phase, const float* wt) {
+    return gi_ggnn_backward_ex(dp, params, gp, ws, slabs, y_out, ldout, d_out, lddout, grads, stream,
+                               side_stream, nullptr, phase, wt);
+}
+
+extern "C" int gi_ggnn_backward_ex(const gi_ggnn_dims* dp, const float* const* params,
+                                   const gi_graph* gp, float* ws, float* slabs,
+                                   const float* y_out, int ldout, const float* d_out, int lddout,
+                                   float* const* grads, void* stream, void* side_stream,
+                                   void* readout_stream, int phase, const float* wt) {
     if (phase != GI_BWD_ALL && phase != GI_BWD_READOUT && phase != GI_BWD_PASSES) return GI_EINVAL;
+    if (readout_stream && phase != GI_BWD_ALL) return GI_EINVAL;
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     Model m;
     int rc = build_model(dp, m);
@@ -1552,7 +1571,13 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
 
     Deferred dq;
     SideStream side_obj{(hipStream_t)side_stream, 0};
-    r.side = side_stream ? &side_obj : nullptr;
+    // Pipelined readout update: the readout's weight gradients and their slab reductions go to a THIRD
+    // stream that `stream` never waits for — the caller runs Adam over the readout parameters there and
+    // hands the event behind it to the next gi_ggnn_forward_ex.  (Its events come from the second half
+    // of the pool: both helper streams record on the main stream independently.)
+    SideStream ro_obj{(hipStream_t)readout_stream, SideStream::NEV / 2};
+    SideStream* const passes_side = side_stream ? &side_obj : nullptr;
+    r.side = readout_stream ? &ro_obj : passes_side;
     r.sp = &sp; r.slabs = slabs; r.grads = grads;
     long long wt_off[160];
     if (wt) { wt_layout(m, wt_off); r.wt = wt; r.wt_off = wt_off; }
@@ -1649,9 +1674,11 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
         mlp_jobs_backward(r, ws, sp, slabs, dq, jobs, 4);
         r.hold_kicks = false;
         if (inl) kick_inline(r, dq, true);          // everything queued so far, on the main stream
+        else if (readout_stream) kick_deferred(r, dq, &ro_obj, true);   // all of it: every readout parameter
         else if (hold && r.side) kick_deferred(r, dq, r.side, false);
     }
     }   // phase != GI_BWD_PASSES
+    r.side = passes_side;               // (pipelined mode: the message passes' weight gradients as usual)
     if (phase == GI_BWD_READOUT) {
         // finish the readout parameters now: their weight-gradient GEMMs and slab reductions are
         // queued (side stream if there is one) so that the caller can start exchanging the gradients

@@ -69,14 +69,18 @@ def _set_dropout(dims, c, kind: int, seed: int) -> None:
     dims.drop_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
 
 
-def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dropout_seed=None):
+def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dropout_seed=None,
+                     readout_ready=None):
     """graph_compact + the fused forward.  Returns (logits, tape); the tape
     (dims, CompactGraph, workspace, per-type edge counts) is what backward consumes.
 
     ``dropout_seed`` (an int): training mode with AlphaDropout p > 0 — the graph is compacted without
     row sharing (every edge and every padded slot draws its own mask, as in the reference), every
     activation gets a stored backward factor (workspace x2), and the logits tensor carries B extra
-    rows for the factors of the logits (the returned tensor is the view of the first B)."""
+    rows for the factors of the logits (the returned tensor is the view of the first B).
+
+    ``readout_ready`` (a recorded ``torch.cuda.Event`` or None): pipelined readout update — the stream
+    waits for it in front of the readout, after the message passes (``gi_ggnn_forward_ex``)."""
     lib = _L.load()
     drop = dropout_seed is not None
     nodes, lay, gfix, S, E, U, D0, Ut = _ops.compact_count(nodes, edges, nodedup=drop)
@@ -104,8 +108,9 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dro
     apd = dims.N * dims.A + dims.N * dims.C + 1
     out = torch.empty((2 * B if drop else B, apd), dtype=torch.float32, device=dev)
     gs = graph.c_struct()
-    _L.check(lib.gi_ggnn_forward(C.byref(dims), _ptr_table(params), C.byref(gs), ws.data_ptr(),
-                                 out.data_ptr(), apd, torch.cuda.current_stream().cuda_stream),
+    _L.check(lib.gi_ggnn_forward_ex(C.byref(dims), _ptr_table(params), C.byref(gs), ws.data_ptr(),
+                                    out.data_ptr(), apd, torch.cuda.current_stream().cuda_stream,
+                                    readout_ready.cuda_event if readout_ready is not None else None),
              "gi_ggnn_forward")
     return (out[:B] if drop else out), (dims, graph, ws)
 
@@ -125,6 +130,22 @@ def _side_stream(device: torch.device) -> int:
         with torch.cuda.device(key):
             _L.check(_L.load().gi_side_stream_create(C.byref(handle)), "gi_side_stream_create")
         st = _SIDE_STREAMS[key] = handle.value      # lives as long as the process
+    return st
+
+
+_READOUT_STREAMS = {}
+
+
+def _readout_stream(device: torch.device) -> "torch.cuda.Stream":
+    """Third HIP stream (one per device, lowest priority) of the pipelined readout update: the readout's
+    weight gradients, their slab reductions and the optimizer step over the readout parameters."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _READOUT_STREAMS.get(key)
+    if st is None:
+        handle = C.c_void_p()
+        with torch.cuda.device(key):
+            _L.check(_L.load().gi_side_stream_create(C.byref(handle)), "gi_side_stream_create")
+        st = _READOUT_STREAMS[key] = torch.cuda.ExternalStream(handle.value, device=torch.device("cuda", key))
     return st
 
 
@@ -154,7 +175,8 @@ def new_grad_bucket(params, device):
     return gflat, grads, offs
 
 
-def ggnn_backward_raw(tape, out, d_out, params, early_hook=None, bucket=None, wt=None):
+def ggnn_backward_raw(tape, out, d_out, params, early_hook=None, bucket=None, wt=None,
+                      readout_stream=None):
     """The fused backward; consumes the tape's activations in place.  Returns (grads, gflat):
     per-parameter gradient views into ONE flat fp32 buffer (state_dict order, 16-byte aligned
     segments) — the bucket a data-parallel all-reduce operates on.
@@ -162,14 +184,18 @@ def ggnn_backward_raw(tape, out, d_out, params, early_hook=None, bucket=None, wt
     ``early_hook(gflat, split, ready_event)`` (optional, set by ``dp.DataParallel``): the backward is
     issued in two calls; after the first, ``gflat[split:]`` — the readout's gradients, ~86 % of the
     bucket — is complete once ``ready_event`` fires, and the hook may start exchanging it while the
-    second call differentiates the message passes."""
+    second call differentiates the message passes.
+
+    ``readout_stream`` (optional ``torch.cuda.Stream``, not together with ``early_hook``): pipelined
+    readout update (``gi_ggnn_backward_ex``) — the gradients of the readout parameters are completed on that
+    stream and are NOT ordered before later work on the current stream."""
     lib = _L.load()
     dims, graph, ws = tape
     d_out = d_out.contiguous().float()
     dev = out.device
     if dev.index != torch.cuda.current_device():     # autograd may run backward on another device
         with torch.cuda.device(dev):
-            return ggnn_backward_raw(tape, out, d_out, params, early_hook, bucket, wt)
+            return ggnn_backward_raw(tape, out, d_out, params, early_hook, bucket, wt, readout_stream)
     gs = graph.c_struct()
     n_slab = lib.gi_ggnn_slab_floats(C.byref(dims), graph.S, graph.U, gs.Ut)
     if n_slab < 0:
@@ -190,6 +216,14 @@ def ggnn_backward_raw(tape, out, d_out, params, early_hook=None, bucket=None, wt
     if wt is not None:                       # (transposed weight copies, their "ready" event)
         main.wait_event(wt[1])
         wt_ptr = wt[0].data_ptr()
+    if readout_stream is not None:
+        if early_hook is not None:
+            raise RuntimeError("pipelined readout update and the early gradient exchange exclude each other")
+        _L.check(lib.gi_ggnn_backward_ex(*args, readout_stream.cuda_stream, _L.BWD_ALL, wt_ptr),
+                 "gi_ggnn_backward_ex")
+        for t in (ws, slabs, gflat):             # read / written there after this call returns
+            t.record_stream(readout_stream)
+        return grads, gflat
     if early_hook is None:
         _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_ALL, wt_ptr), "gi_ggnn_backward")
         return grads, gflat
@@ -208,7 +242,7 @@ class _GGNNFunction(torch.autograd.Function):
     def forward(ctx, owner, nodes, edges, *params):
         start = owner._weights_final_event(nodes.device)
         out, tape = ggnn_forward_raw(owner.constants, nodes, edges, params, owner._KIND,
-                                     owner._next_dropout_seed())
+                                     owner._next_dropout_seed(), owner._readout_ready)
         ctx.wt = owner._transposed_weights(tape[0], params, start)
         ctx.owner = owner
         ctx.tape = tape
@@ -241,7 +275,7 @@ class _GGNNDirect(torch.autograd.Function):
         params = owner._params()
         start = owner._weights_final_event(nodes.device) if anchor is not None else None
         out, tape = ggnn_forward_raw(owner.constants, nodes, edges, params, owner._KIND,
-                                     owner._next_dropout_seed())
+                                     owner._next_dropout_seed(), owner._readout_ready)
         ctx.wt = owner._transposed_weights(tape[0], params, start) if anchor is not None else None
         ctx.owner = owner
         ctx.tape = tape
@@ -277,6 +311,15 @@ class _FusedMPNN(torch.nn.Module):
     autograd_params = False
     _grad_ready_hook = None
     _early_exchange_pending = False     # set by dp.DataParallel while its early all-reduce runs
+    #: Pipelined readout update (dp.DataParallel(pipeline_readout=True), one process): the backward completes
+    #: the readout parameters' gradients on `_readout_stream` without the main stream waiting for them; the
+    #: trainer runs the optimizer for them there and leaves the event behind it in `_readout_ready`, which every
+    #: later forward waits for in front of its readout.  `_pipelined_split` = float offset of the readout
+    #: tail in the gradient bucket after a pipelined backward (None after an ordinary one).
+    _pipeline_readout = False
+    _readout_ready = None
+    _pipelined_split = None
+    _pipelined_stream = None
 
     def _dropout_active(self) -> bool:
         flag = self.__dict__.get("_has_dropout")
@@ -319,7 +362,7 @@ class _FusedMPNN(torch.nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         skip = ("_param_cache", "_bucket", "_anchor", "_grad_bucket", "_grad_ready_hook", "_wt",
-                "_early_exchange_pending")
+                "_early_exchange_pending", "_readout_ready", "_pipelined_split", "_pipelined_stream")
         import copy as _copy
         for k, v in self.__dict__.items():
             new.__dict__[k] = None if k in skip else _copy.deepcopy(v, memo)
@@ -391,7 +434,16 @@ class _FusedMPNN(torch.nn.Module):
             raise RuntimeError("a second backward through the model while the data-parallel early "
                                "all-reduce of the first one is reducing the gradient bucket in place; "
                                "use DataParallel(overlap=False) for multiple backwards per step")
-        grads, gflat = ggnn_backward_raw(tape, out, d_out, params, hook, bucket, wt)
+        ro = None
+        self._pipelined_split = None
+        if self._pipeline_readout and fresh and hook is None and wt is None:
+            ro = _readout_stream(out.device)
+        grads, gflat = ggnn_backward_raw(tape, out, d_out, params, hook, bucket, wt, ro)
+        if ro is not None:
+            dims = tape[0]
+            offs = bucket[2]
+            self._pipelined_split = offs[_L.load().gi_ggnn_first_readout_param(C.byref(dims))]
+            self._pipelined_stream = ro          # the stream the trainer continues the tail on
         with torch.no_grad():
             if fresh:
                 for p, g in zip(params, grads):

@@ -173,6 +173,9 @@ SIGNATURES = {
     "gi_ggnn_transpose_weights": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), vp, vp]),
     "gi_transpose_batch": (ci, [vp, ci, vp]),
     "gi_ggnn_first_readout_param": (ci, [C.POINTER(GgnnDims)]),
+    "gi_ggnn_forward_ex": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), C.POINTER(Graph), vp, vp, ci, vp, vp]),
+    "gi_ggnn_backward_ex": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), C.POINTER(Graph), vp, vp, vp,
+                                 ci, vp, ci, C.POINTER(vp), vp, vp, vp, ci, vp]),
     "gi_fuse_flags": (ci, []),
     "gi_gru_gates_bwd_ex": (ci, [vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, vp, vp, ci, vp, vp,
                                  vp]),

@@ -121,6 +121,35 @@ class FusedAdam(torch.optim.Optimizer):
         return st["g"]
 
     @torch.no_grad()
+    def step_split(self, split: int, tail_stream: "torch.cuda.Stream") -> None:
+        """One Adam step in two launches: floats [0, split) of the bucket on the current stream, floats
+        [split, total) on ``tail_stream`` — the pipelined readout update (``gnn.mpnn``, ``dp.DataParallel``),
+        where the gradients of the tail are completed on that stream.  Needs a single parameter group whose
+        gradients ARE the flat bucket of the fused backward (zero-copy), ``split`` a multiple of 4."""
+        if len(self._flat) != 1 or self._flat[0] is None:
+            raise RuntimeError("FusedAdam.step_split needs exactly one parameter group")
+        group, st = self.param_groups[0], self._flat[0]
+        if split % 4 or not 0 <= split <= st["total"]:
+            raise ValueError("split must be a multiple of 4 inside the bucket")
+        ps, offs = st["params"], st["offs"]
+        g0 = ps[0].grad
+        if g0 is None or not all(p.grad is not None and p.grad.data_ptr() == g0.data_ptr() + 4 * o
+                                 for p, o in zip(ps, offs)):
+            raise RuntimeError("FusedAdam.step_split: the gradients are not the fused backward's flat bucket")
+        g = torch.as_strided(g0, (st["total"],), (1,))
+        st["step"] += 1
+        self._opt_called = True             # (what lr_scheduler's wrapper of `step` would have noted)
+        b1, b2 = group["betas"]
+        lib = L.load()
+        for lo, hi, stream in ((0, split, torch.cuda.current_stream(st["p"].device)),
+                               (split, st["total"], tail_stream)):
+            if hi > lo:
+                L.check(lib.gi_adam_step(st["p"].data_ptr() + 4 * lo, g.data_ptr() + 4 * lo,
+                                         st["m"].data_ptr() + 4 * lo, st["v"].data_ptr() + 4 * lo, hi - lo,
+                                         float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
+                                         st["step"], stream.cuda_stream), "gi_adam_step")
+
+    @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:

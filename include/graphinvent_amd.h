@@ -548,6 +548,23 @@ int gi_ggnn_backward_phase(const gi_ggnn_dims* d, const float* const* params, co
                            float* ws, float* slabs, const float* y_out, int ldout,
                            const float* d_out, int lddout, float* const* grads, void* stream,
                            void* side_stream, int phase, const float* wt);
+/* Pipelined readout update (opt-in, single process): the readout's parameters (gather + APDReadout, the
+ * contiguous tail params[gi_ggnn_first_readout_param() ..), 86 % of the weights) are read by neither the
+ * backward's message passes nor the NEXT forward's message passes, and their weight gradients only feed the
+ * optimizer.  gi_ggnn_backward_ex with readout_stream != NULL (phase must be GI_BWD_ALL) enqueues those
+ * weight-gradient GEMMs and their slab reductions on `readout_stream` — ordered after their operands by
+ * events, never waited for by `stream` — so on return only the gradients of params[0 .. first_readout_param)
+ * are ordered before later work on `stream`; the caller runs the optimizer for the tail on `readout_stream`,
+ * records an event there and passes it to the next gi_ggnn_forward_ex, which makes `stream` wait for it in
+ * front of the readout (after the message passes).  Buffers the tail work reads (ws, slabs, grads) must stay
+ * alive until that event.  readout_stream == NULL / readout_ready == NULL: exactly gi_ggnn_backward_phase /
+ * gi_ggnn_forward. */
+int gi_ggnn_forward_ex(const gi_ggnn_dims* d, const float* const* params, const gi_graph* g,
+                       float* ws, float* out, int ldout, void* stream, void* readout_ready);
+int gi_ggnn_backward_ex(const gi_ggnn_dims* d, const float* const* params, const gi_graph* g,
+                        float* ws, float* slabs, const float* y_out, int ldout,
+                        const float* d_out, int lddout, float* const* grads, void* stream,
+                        void* side_stream, void* readout_stream, int phase, const float* wt);
 /* Optional transposed weight copies for the backward's dgrad GEMMs (`wt` above, may be NULL):
  * gi_ggnn_wt_floats() floats; gi_ggnn_transpose_weights() writes WT[n_in][r4(n_out)] of every weight
  * matrix of params (one batched launch sequence, e.g. on a side stream during the forward).  With

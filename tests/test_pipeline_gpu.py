@@ -1,0 +1,70 @@
+"""-m gpu: the pipelined readout update (dp.DataParallel(pipeline_readout=True), gi_ggnn_backward_ex /
+gi_ggnn_forward_ex): the readout's weight gradients, their reductions and Adam over the readout parameters
+run on a third stream under the NEXT step's message passes.  Only the ORDER of independent work changes,
+so after any number of steps parameters, optimizer moments and losses must be bit-identical to the
+ordinary trainer's."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(model_name, pipeline, steps, shape="gdb13", batch=96):
+    from graphinvent_amd import dp, synthetic
+    from graphinvent_amd.gnn import mpnn
+    from graphinvent_amd.loss import apd_kl_loss
+    from graphinvent_amd.optim import FusedAdam
+    from oracle import ggnn_oracle as O
+    sh = synthetic.SHAPES[shape]
+    cfg = O.shaped_config(sh["n_atom_types"], sh["n_formal_charge"], sh["max_n_nodes"],
+                          hidden_node_features=64, message_size=64, enn_hidden_dim=96,
+                          gather_att_hidden_dim=96, gather_emb_hidden_dim=96, mlp1_hidden_dim=128,
+                          mlp2_hidden_dim=128, msg_hidden_dim=96, att_hidden_dim=96)
+    cfg["device"] = "cuda"
+    torch.manual_seed(3)
+    cls = mpnn.GGNN if model_name == "ggnn" else mpnn.AttentionGGNN
+    model = cls(O.as_constants(cfg)).cuda().train()
+    batches = []
+    for i in range(3):
+        n8, e8, a8 = synthetic.make_batch(batch, **sh, seed=20 + i)
+        batches.append(tuple(torch.from_numpy(x).float().cuda() for x in (n8, e8, a8)))
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=steps + 2)
+    tr = dp.DataParallel(model, opt, sched, loss_fn=apd_kl_loss, pipeline_readout=pipeline)
+    assert tr.pipeline_readout == pipeline
+    losses = []
+    for k in range(steps):
+        losses.append(tr.step(*batches[k % 3]))
+        if pipeline:
+            assert model._pipelined_split is not None and model._readout_ready is not None
+    model.eval()                                   # an inference forward in between waits for the tail too
+    with torch.no_grad():
+        logits = model(*batches[0][:2])
+    tr.flush()
+    torch.cuda.synchronize()
+    st = opt._flat[0]
+    return ([float(x) for x in losses], [p.detach().clone() for p in model.parameters()],
+            st["m"].clone(), st["v"].clone(), logits.clone())
+
+
+@pytest.mark.parametrize("model_name,shape,batch", [("ggnn", "gdb13", 96), ("attggnn", "gdb13", 64),
+                                                    ("ggnn", "zinc", 48)])
+def test_pipelined_readout_update_is_bit_identical(model_name, shape, batch):
+    ref = _run(model_name, False, 7, shape, batch)
+    got = _run(model_name, True, 7, shape, batch)
+    assert got[0] == ref[0]                                              # every step's loss
+    for a, b in zip(got[1], ref[1]):
+        assert torch.equal(a, b)
+    assert torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3])   # Adam moments
+    assert torch.equal(got[4], ref[4])
+
+
+def test_pipelined_trainer_falls_back_without_the_fused_optimizer():
+    """torch.optim.Adam reads param.grad right after backward(): no pipelining then (same results as ever)."""
+    from graphinvent_amd import dp
+    from graphinvent_amd.gnn import mpnn
+    from oracle import ggnn_oracle as O
+    cfg = O.make_config(device="cuda")
+    model = mpnn.GGNN(O.as_constants(cfg)).cuda().train()
+    tr = dp.DataParallel(model, torch.optim.Adam(model.parameters(), lr=1e-3), pipeline_readout=True)
+    assert tr.pipeline_readout is False
