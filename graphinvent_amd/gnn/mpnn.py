@@ -170,7 +170,7 @@ def grad_bucket_layout(params):
 def new_grad_bucket(params, device):
     """A flat fp32 gradient bucket and its per-parameter views."""
     offs, total = grad_bucket_layout(params)
-    gflat = torch.empty(total, dtype=torch.float32, device=device)
+    gflat = torch.zeros(total, dtype=torch.float32, device=device)   # (alignment gaps stay 0, not garbage)
     grads = [gflat[o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
     return gflat, grads, offs
 

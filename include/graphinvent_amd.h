@@ -18,8 +18,9 @@
  *   - return value: 0 = success, >0 = hipError_t from a launch, <0 = argument error (GI_E*);
  *   - no exceptions cross the ABI; one process per GPU, calls come from one host thread at a time.
  *     Process-wide state is limited to: the optional per-launch timing log (gi_prof_*), a pool of
- *     timing-disabled hipEvents used to order the backward's two streams, and measurement switches
- *     read once from the environment (GI_GEMM_XCD_REMAP, GI_GEMM_LOG).
+ *     timing-disabled hipEvents used to order the backward's streams, and switches read once from the
+ *     environment (GI_FUSE — see gi_fuse_flags; measurement knobs: GI_GEMM_XCD_REMAP, GI_GEMM_LOG,
+ *     GI_WGRAD_WGS, GI_WGRAD_KICK, GI_WGRAD_INLINE, GI_HOLD_NODE_WGRADS, GI_CHAIN*, GI_GRU_FUSED).
  */
 #ifndef GRAPHINVENT_AMD_H
 #define GRAPHINVENT_AMD_H
