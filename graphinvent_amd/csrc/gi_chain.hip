@@ -617,9 +617,17 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
     hipStream_t st = (hipStream_t)stream;
     GiProfScope prof(st, GI_PROF_GEMM, flops);
     const dim3 grid(total), block(512);
+    // Experiment knob GI_CHAIN_RING=2 (not validated on hardware yet — next round): 32-row blocks with a
+    // two-slot weight ring, 114 KB of LDS instead of 146 KB, so that one workgroup of the GEMM family (37 KB)
+    // fits on the CU beside a chain workgroup.  Every overlap schedule measured so far was bounded by the
+    // chain workgroups owning their CU; the price is one weight tile of look-ahead less.
+    const bool ring2 = !big && getenv("GI_CHAIN_RING") && atoi(getenv("GI_CHAIN_RING")) == 2;
     if (big) {
         if (chains[0].backward) hipLaunchKernelGGL((gi_chain_kernel<true, 2, 2>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((gi_chain_kernel<false, 2, 2>), grid, block, 0, st, a);
+    } else if (ring2) {
+        if (chains[0].backward) hipLaunchKernelGGL((gi_chain_kernel<true, 1, 2>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((gi_chain_kernel<false, 1, 2>), grid, block, 0, st, a);
     } else {
         if (chains[0].backward) hipLaunchKernelGGL((gi_chain_kernel<true, 1, CH_RING>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((gi_chain_kernel<false, 1, CH_RING>), grid, block, 0, st, a);
