@@ -1,0 +1,22 @@
+"""CPU: the analysis tools that produce tables quoted in DESIGN.md run on the committed profile data."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_critical_path_on_the_committed_traces():
+    for tag in ("default", "onestream", "zinc", "chembl"):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "critical_path.py"),
+                              os.path.join(ROOT, "profiles", "r02", f"trace_{tag}.csv"), "0"],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        rows = {l[:28].strip(): l[28:].split() for l in out.stdout.splitlines()[1:]}
+        assert "bwd: message passes" in rows and "step (from compact_fill)" in rows
+        span, main, side = (float(x) for x in rows["step (from compact_fill)"])
+        assert 1500 < span < 8000 and main <= span + 1
+        if tag == "onestream":
+            assert side == 0.0                      # weight gradients on the main queue
+        else:
+            assert side > 0.2 * span                # a second queue overlaps the backward
