@@ -28,6 +28,8 @@ Rank 0 prints one JSON line.  Besides the contract fields it carries
   forward_only  no_grad forward rate on the same batches
   cpu_baseline  the oracle (CPU restatement of the reference algorithm, kind "port") on the host
                 cores at their best thread count, same workload, bounded sample; N == 1 only
+config.fuse_flags = the GI_FUSE launch-count reductions in use (include/graphinvent_amd.h, default 15);
+config.pipeline_readout appears only with the opt-in GI_PIPELINE_READOUT=1 (one process).
 """
 import argparse
 import ctypes as C

@@ -159,12 +159,13 @@ class FusedAdam(torch.optim.Optimizer):
         for group, st in zip(self.param_groups, self._flat):
             if st is None:
                 continue
-            g = self._grad_bucket(st)
-            st["step"] += 1
-            b1, b2 = group["betas"]
-            L.check(lib.gi_adam_step(st["p"].data_ptr(), g.data_ptr(), st["m"].data_ptr(),
-                                     st["v"].data_ptr(), st["total"], float(group["lr"]), b1, b2,
-                                     group["eps"], group["weight_decay"], st["step"],
-                                     torch.cuda.current_stream(st["p"].device).cuda_stream),
-                    "gi_adam_step")
+            with torch.cuda.device(st["p"].device):       # launch on the bucket's device, whichever is current
+                g = self._grad_bucket(st)
+                st["step"] += 1
+                b1, b2 = group["betas"]
+                L.check(lib.gi_adam_step(st["p"].data_ptr(), g.data_ptr(), st["m"].data_ptr(),
+                                         st["v"].data_ptr(), st["total"], float(group["lr"]), b1, b2,
+                                         group["eps"], group["weight_decay"], st["step"],
+                                         torch.cuda.current_stream(st["p"].device).cuda_stream),
+                        "gi_adam_step")
         return loss
