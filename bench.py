@@ -133,11 +133,13 @@ def timed_steps(wl: Workload, steps: int, warmup: int, world: int, device):
     for _ in range(warmup):
         wl.run_step()
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    rb0 = dict(ops.READBACKS)
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = wl.run_step()
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    wl.readbacks = {k: ops.READBACKS[k] - rb0[k] for k in rb0}     # of the timed steps' forwards
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -315,6 +317,7 @@ def main():
                   prefetch=not args.no_prefetch_compact)
     cfg, model, trainer, batches = wl.cfg, wl.model, wl.trainer, wl.batches
     dt, loss_val = timed_steps(wl, args.steps, args.warmup, world, device)
+    first_readbacks = dict(wl.readbacks)
     if world > 1:
         # every rank stepped on different graphs: the weights can only still be identical if the
         # gradient exchange (incl. its overlap with the backward) delivered the same mean everywhere
@@ -343,6 +346,8 @@ def main():
                                  if trainer.overlap else "flat fp32 bucket after the backward")},
     }
     result["config"]["fuse_flags"] = int(lib.load().gi_fuse_flags())     # GI_FUSE_* variants in use
+    # graph_compact's sizes: found on the host (counting phase one batch ahead) / read back behind the stream
+    result["config"]["compact_readbacks_timed_steps"] = first_readbacks
     if trainer.pipeline_readout:      # opt-in (GI_PIPELINE_READOUT=1): readout update under the next forward
         result["config"]["pipeline_readout"] = True
     if args.backend != "nccl":

@@ -180,6 +180,9 @@ def _unpack_counts(counts, Fe: int):
 # counting phase for it on a side stream while the current training step occupies the main stream;
 # the forward then finds the result here, already on the host, and neither waits for the device nor
 # puts the three counting kernels on its critical path.  Entries are consumed once.
+#: how forward passes got their sizes so far: from a finished prefetch (no wait on the step's stream) or by a
+#: blocking read-back behind everything queued on it (bench.py reports the split over its timed region)
+READBACKS = {"prefetched": 0, "blocking": 0}
 _PREFETCHED: "dict" = {}
 _PINNED: "list" = []
 _PINNED_NEXT = 0
@@ -246,7 +249,9 @@ def compact_count(nodes: torch.Tensor, edges: torch.Tensor, nodedup: bool = Fals
         cur.wait_event(done)
         gfix.record_stream(cur)
         nodes_c.record_stream(cur)
+        READBACKS["prefetched"] += 1
         return (nodes_c, lay, gfix) + _unpack_counts(pinned.tolist(), Fe)
+    READBACKS["blocking"] += 1
     nodes, lay, gfix, Fe = _count_launch(nodes, edges, nodedup)
     counts = gfix[lay.counts:lay.counts + L.COUNTS].cpu().tolist()
     return (nodes, lay, gfix) + _unpack_counts(counts, Fe)
