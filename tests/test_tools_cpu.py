@@ -20,3 +20,17 @@ def test_critical_path_on_the_committed_traces():
             assert side == 0.0                      # weight gradients on the main queue
         else:
             assert side > 0.2 * span                # a second queue overlaps the backward
+
+
+def test_gemm_class_report_on_the_committed_trace_and_launch_log():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_class_report.py"),
+                          os.path.join(ROOT, "profiles", "r02", "trace_onestream.csv"),
+                          os.path.join(ROOT, "profiles", "r02", "gemm_launch_log.txt")],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    hidden = [float(l.split()[-1]) for l in lines if l.startswith("forward  4 problem(s)") and "K <= 500" in l
+              and "N <= 500" in l]
+    assert len(hidden) == 3 and all(0.5 < f < 0.75 for f in hidden)       # 0.60-0.62 of peak
+    wgrad = float([l for l in lines if l.startswith("wgrad")][0].split()[-1])
+    assert 0.4 < wgrad < 0.65
