@@ -21,35 +21,92 @@
 //
 // Pipeline: global -> registers for tile t+1 is issued before the MFMAs of tile t, written to the
 // other LDS buffer after them; one __syncthreads per 32-deep tile.
+//
+// ONE kernel runs every launch: a workgroup walks the output tiles id = blockIdx.x, + gridDim.x, ...
+// of a (batched) launch.  With gridDim.x = number of tiles that is the ordinary one-tile-per-
+// workgroup launch; big launches get a PERSISTENT grid instead (as many workgroups as the device
+// holds at once), and a workgroup issues the first global loads of its NEXT tile in front of the
+// epilogue of the current one.  Measured on the hot launches (tools/gemm_lab.hip per-workgroup trace,
+// round 3): a workgroup spent 12 % of its life in the prologue waiting for those loads and 17 % in
+// the epilogue, holding one of its CU's four slots while feeding nothing to the MFMA pipe.
 #include <stdlib.h>
 #include <string.h>
-
 #include <stdio.h>
-#include <stdlib.h>
 
 #include "gi_common.h"
 
 #include "gi_mfma.h"
 #include <type_traits>
 
+// compile-time experiment switches (tools/gemm_lab.hip builds variants; product values below)
+#ifndef GI_EXP_PRIO
+#define GI_EXP_PRIO 0          // s_setprio level of a wave outside its main loop (epilogue, tile setup, prefetch)
+#endif
+#ifndef GI_EXP_FAST
+#define GI_EXP_FAST 0          // interior tiles: epilogue without bounds checks
+#endif
+
 __device__ float gi_store_sink[256];               // where out-of-range lanes of edge tiles store
 
-template <int TM, int TN, bool A_MAJOR, bool B_MAJOR>
-__device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int bx_in,
-                                             const int by_in, const int bz, const int gx,
-                                             const int gy) {
-    // XCD-aware tile order (flag bit 5, set by the host for launches of many workgroups, see
-    // remap_min_blocks): the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs
-    // (private L2 each); the remap makes one XCD walk consecutive tiles so the column tiles sharing
-    // an A row panel hit the same L2 (bijective for any grid size).
-    int bx = bx_in, by = by_in;
-    if (p.flags & 32) {
-        const int T = gx * gy, id = bx_in + gx * by_in;
-        const int q = T >> 3, r = T & 7, xcd = id & 7, i = id >> 3;
-        const int nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-        by = nid / gx;
-        bx = nid - by * gx;
-    }
+// Operand addressing: block-uniform base pointer + 32-bit BYTE offset per lane (`global_load ... v_off,
+// s[base]`): one address VGPR and 32-bit integer arithmetic per access instead of a 64-bit pointer per
+// lane.  Every matrix handed to gi_gemm must therefore span less than 4 GB (checked by validate()).
+__device__ __forceinline__ v4f gi_load4_at(const float* base, unsigned row_bytes, int col, int cmax) {
+    const unsigned off = row_bytes + 4u * (unsigned)max(min(col, cmax), 0);
+    return *(const v4f_u*)((const char*)base + off);
+}
+
+// tools/gemm_lab.hip (-DGI_GEMM_TRACE): per-tile shader-clock stamps + hardware placement
+#ifdef GI_GEMM_TRACE
+__device__ unsigned long long* gi_trace_buf;       // [tiles][8]
+#define GI_TRACE(id, slot)                                                                        \
+    do { if (gi_trace_buf && threadIdx.x == 0)                                                     \
+        gi_trace_buf[(size_t)(id) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define GI_TRACE_HW(id)                                                                            \
+    do { if (gi_trace_buf && threadIdx.x == 0) {                                                   \
+        gi_trace_buf[(size_t)(id) * 8 + 4] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   \
+        gi_trace_buf[(size_t)(id) * 8 + 5] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   \
+        gi_trace_buf[(size_t)(id) * 8 + 6] = blockIdx.x; } } while (0)
+#else
+#define GI_TRACE(id, slot) do {} while (0)
+#define GI_TRACE_HW(id) do {} while (0)
+#endif
+
+// Several independent GEMMs of the same tile/layout class in ONE launch ("horizontal fusion"):
+// the sibling MLPs of the readout (4 node-level stacks, 3 graph-level stacks) and the two GRU
+// projections have 16..450 workgroups each — together they fill the 256 CUs and halve the number of
+// launch ramps on the critical path.  Tile id -> (problem, x, y, z) through a prefix table.
+#define GI_GEMM_BATCH_MAX 8
+struct GemmBatch {
+    gi_gemm_params p[GI_GEMM_BATCH_MAX];
+    int start[GI_GEMM_BATCH_MAX + 1];          // first tile id of every problem
+    int gx[GI_GEMM_BATCH_MAX], gy[GI_GEMM_BATCH_MAX];
+    int n, total;
+};
+
+// Block-uniform description of one output tile (SGPRs) + the per-thread stored rows of a contig A
+// (the only per-thread state a tile carries: everything else is recomputed from the scalars).
+template <int NA>
+struct GemmTile {
+    int pi;                                // problem of the batch (kernel argument, indexed: never its address)
+    const float* Ap; const float* Bp; const float* biasp; float* Cp;
+    int id, m_end, k_begin, k_end, m0, n0;
+    int lda, ldb, a_cmax, b_cmax;
+    bool a_fast, b_fast, valid, empty;
+    int a_row[NA];                         // contig A: stored row of staging slot i (gathered / clamped)
+};
+// What the epilogue of a finished tile needs while the NEXT tile's description and first loads are live.
+struct GemmEpi {
+    int pi; const float* biasp; float* Cp;
+    int m_end, m0, n0;
+    bool empty;
+};
+
+// EPI: 0 = epilogue from the run-time flags; 1 = the epilogue of the layout's own launch class, known at
+// compile time (forward: bias + SELU; dgrad: * selu'(act); weight-gradient slabs: plain store) — the
+// launcher picks it when every problem of the launch has exactly those flags.
+template <int TM, int TN, bool A_MAJOR, bool B_MAJOR, int EPI>
+__global__ __launch_bounds__(256) void gi_gemm_tiles_kernel(const GemmBatch b) {
     constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32;
     constexpr int A_LD = A_MAJOR ? BM + 4 : BK + 4;
     constexpr int A_ROWS = A_MAJOR ? BK : BM;
@@ -57,6 +114,7 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
     constexpr int B_ROWS = B_MAJOR ? BK : BN;
     constexpr int A_SZ = A_ROWS * A_LD, B_SZ = B_ROWS * B_LD;
     constexpr int NA = 2 * TM, NB = 2 * TN;          // float4 staged per thread per tile
+    typedef GemmTile<NA> Tile;
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
     float* const As = smem;
     float* const Bs = smem + 2 * A_SZ;
@@ -64,40 +122,6 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
-
-    // ---- group / split resolution (block-uniform) -------------------------------------------
-    const bool splitk = (p.flags & GI_GEMM_SPLITK) != 0;
-    int g = bz, s = 0, nsp = p.nsplit;
-    if (splitk) {
-        g = 0; s = bz;
-        if (p.ngroups) {                                  // per-group slab counts (work-proportional)
-            while (g < p.ngroups - 1 && s >= p.gsplit[g]) { s -= p.gsplit[g]; ++g; }
-            nsp = p.gsplit[g];
-        }
-    }
-    const float* __restrict__ Ap = p.A;
-    const float* __restrict__ Bp = (p.ngroups && !splitk) ? p.Bg[g] : p.B;
-    const float* __restrict__ biasp = (p.ngroups && !splitk) ? p.biasg[g] : p.bias;
-    float* Cp = (p.ngroups && splitk) ? p.Cg[g] : p.C;
-
-    int m_begin = 0, m_end = p.M, k_begin = 0, k_end = p.K;
-    if (p.grp_off) {
-        const int lo = p.grp_off[g], hi = p.grp_off[g + 1];
-        if (splitk) { k_begin = lo; k_end = hi; } else { m_begin = lo; m_end = hi; }
-    }
-    if (splitk) {
-        const int len = k_end - k_begin;
-        const int chunk = (((len + nsp - 1) / nsp) + 31) & ~31;
-        const int kb = k_begin + s * chunk;
-        k_end = min(kb + chunk, k_end);
-        k_begin = kb;
-        Cp += (long long)s * p.c_split_stride;
-    }
-    const int split_idx = s, n_splits = nsp;
-    const int m0 = m_begin + by * BM;
-    const int n0 = bx * BN;
-    if (m0 >= m_end) return;
-    const int bcols = (p.ones_col >= 0) ? p.ones_col : p.N;     // real stored columns of a major B
 
     // ---- per-thread staging coordinates -----------------------------------------------------
     // contig operand: 8 float4 per 32-wide row -> c4 = tid&7, row = (tid>>3) + 32*i
@@ -108,76 +132,125 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
     const int a_mc4 = tid % A_C4, a_mr = tid / A_C4;
     const int b_mc4 = tid % B_C4, b_mr = tid / B_C4;
 
-    long long a_off[NA], b_off[NB];        // element offsets of the fixed (contig) rows; invalid rows -> row 0
-    bool a_ok[NA], b_ok[NB];
-    if (!A_MAJOR) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int row = m0 + crow + 32 * i;
-            a_ok[i] = row < m_end;
-            const int rr = a_ok[i] ? row : m0;
-            a_off[i] = (long long)(p.a_idx ? p.a_idx[rr] : rr) * p.lda;
+    // ---- tile id -> problem, tile coordinates, group / split resolution (block-uniform) -------
+    auto setup = [&](Tile& t, int id) __attribute__((always_inline)) {
+        t.id = id;
+        t.valid = id < b.total;
+        if (!t.valid) return;
+        int i = 0;
+        while (i < b.n - 1 && id >= b.start[i + 1]) ++i;
+        const gi_gemm_params& p = b.p[i];
+        t.pi = i;
+        const int gx = b.gx[i], gy = b.gy[i], gxy = gx * gy;
+        const int local = id - b.start[i];
+        const int bz = local / gxy;
+        int rem = local - bz * gxy;
+        // XCD-aware tile order (flag bit 5, set by the host for launches of many workgroups, see
+        // remap_min_blocks): the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs
+        // (private L2 each) and a persistent workgroup's stride is a multiple of 8; the remap makes one
+        // XCD walk consecutive tiles so the column tiles sharing an A row panel hit the same L2
+        // (bijective for any grid size).
+        if (p.flags & 32) {
+            const int q = gxy >> 3, r = gxy & 7, xcd = rem & 7, j = rem >> 3;
+            rem = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
         }
-    }
-    if (!B_MAJOR) {
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int row = n0 + crow + 32 * i;
-            b_ok[i] = row < p.N;
-            b_off[i] = (long long)(b_ok[i] ? row : 0) * p.ldb;
+        const int by = rem / gx, bx = rem - by * gx;
+        const bool splitk = (p.flags & GI_GEMM_SPLITK) != 0;
+        int g = bz, s = 0, nsp = p.nsplit;
+        if (splitk) {
+            g = 0; s = bz;
+            if (p.ngroups) {                                  // per-group slab counts (work-proportional)
+                while (g < p.ngroups - 1 && s >= p.gsplit[g]) { s -= p.gsplit[g]; ++g; }
+                nsp = p.gsplit[g];
+            }
         }
-    }
+        t.Ap = p.A;
+        t.Bp = (p.ngroups && !splitk) ? p.Bg[g] : p.B;
+        t.biasp = (p.ngroups && !splitk) ? p.biasg[g] : p.bias;
+        t.Cp = (p.ngroups && splitk) ? p.Cg[g] : p.C;
+        int m_begin = 0;
+        t.m_end = p.M; t.k_begin = 0; t.k_end = p.K;
+        if (p.grp_off) {
+            const int lo = p.grp_off[g], hi = p.grp_off[g + 1];
+            if (splitk) { t.k_begin = lo; t.k_end = hi; } else { m_begin = lo; t.m_end = hi; }
+        }
+        if (splitk) {
+            const int len = t.k_end - t.k_begin;
+            const int chunk = (((len + nsp - 1) / nsp) + 31) & ~31;
+            const int kb = t.k_begin + s * chunk;
+            t.k_end = min(kb + chunk, t.k_end);
+            t.k_begin = kb;
+            t.Cp += (long long)s * p.c_split_stride;
+        }
+        t.m0 = m_begin + by * BM;
+        t.n0 = bx * BN;
+        t.empty = t.m0 >= t.m_end;                          // tile beyond the rows of a short group
+        if (t.empty) { t.k_end = t.k_begin; t.m0 = 0; t.m_end = 1; }
+        t.lda = p.lda; t.ldb = p.ldb;
+        if (!A_MAJOR) {
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                const int row = min(t.m0 + crow + 32 * q, t.m_end - 1);     // rows past the end: any readable row
+                t.a_row[q] = p.a_idx ? p.a_idx[row] : row;
+            }
+        }
+        // Only the REDUCTION dimension needs zero fill (garbage there would reach valid outputs).  Along
+        // the output dimensions out-of-range rows/columns are merely clamped to readable addresses:
+        // whatever they hold only feeds output elements the epilogue discards.  So every tile that is
+        // full in k stores the raw vectors ("fast"); the last, partial k tile takes the fix-up path.
+        const int bcols = (p.ones_col >= 0) ? p.ones_col : p.N;     // real stored columns of a major B
+        const int bc4 = (bcols + 3) & ~3, m4 = (p.M + 3) & ~3;
+        t.a_cmax = A_MAJOR ? ((p.lda >= m4) ? m4 - 4 : p.M - 4) : t.k_end - 4;
+        t.b_cmax = B_MAJOR ? ((p.ldb >= bc4) ? bc4 - 4 : bcols - 4) : t.k_end - 4;
+        t.a_fast = A_MAJOR ? (p.lda >= m4) : true;
+        t.b_fast = B_MAJOR ? (p.ldb >= bc4) : true;
+    };
 
     v4f ra0[NA], rb0[NB], ra1[NA], rb1[NB];    // two register stages: k tiles t+1 and t+2 in flight
 
-    // Only the REDUCTION dimension needs zero fill (garbage there would reach valid outputs).  Along
-    // the output dimensions out-of-range rows/columns are merely clamped to readable addresses:
-    // whatever they hold only feeds output elements the epilogue discards.  So every tile that is
-    // full in k stores the raw vectors ("fast"); the last, partial k tile takes the fix-up path.
-    const int a_cmax = A_MAJOR ? ((p.lda >= ((p.M + 3) & ~3)) ? ((p.M + 3) & ~3) - 4 : p.M - 4) : k_end - 4;
-    const int b_cmax = B_MAJOR ? ((p.ldb >= ((bcols + 3) & ~3)) ? ((bcols + 3) & ~3) - 4 : bcols - 4)
-                               : k_end - 4;
-    const bool a_fast = A_MAJOR ? (p.lda >= ((p.M + 3) & ~3)) : true;
-    const bool b_fast = B_MAJOR ? (p.ldb >= ((bcols + 3) & ~3)) : true;
-
     // raw loads only (nothing consumes the data here); A half and B half are issued separately so
     // they can be spread between MFMA groups
-    auto gload_a = [&](v4f (&ra)[NA], int k0) {
+    auto gload_a = [&](const Tile& t, v4f (&ra)[NA], int k0) {
         if (!A_MAJOR) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) ra[i] = gi_load4_raw(Ap + a_off[i], k0 + 4 * cc4, a_cmax);
+            for (int i = 0; i < NA; ++i)
+                ra[i] = gi_load4_at(t.Ap, (unsigned)t.a_row[i] * (unsigned)t.lda * 4u, k0 + 4 * cc4, t.a_cmax);
         } else {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int red = min(k0 + a_mr + i * A_RP, k_end - 1);
-                ra[i] = gi_load4_raw(Ap + (long long)red * p.lda, m0 + 4 * a_mc4, a_cmax);
+                const int red = min(k0 + a_mr + i * A_RP, t.k_end - 1);
+                ra[i] = gi_load4_at(t.Ap, (unsigned)red * (unsigned)t.lda * 4u, t.m0 + 4 * a_mc4, t.a_cmax);
             }
         }
     };
     // BIDX (compile time): rows of a major B gathered through b_idx.  The index load is a dependent
     // load in front of the data load (it drains the load queue once per tile), so the body exists
-    // twice and only the gathered problems (first layer of the message stacks' weight gradients)
-    // run the BIDX version.
-    auto gload_b = [&](v4f (&rb)[NB], int k0, auto bidx) {
+    // twice and only launches with a gathered problem (first layer of the message stacks' weight
+    // gradients) run the BIDX version.
+    auto gload_b = [&](const Tile& t, v4f (&rb)[NB], int k0, auto bidx) {
         constexpr bool BIDX = decltype(bidx)::value;
         if (!B_MAJOR) {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) rb[i] = gi_load4_raw(Bp + b_off[i], k0 + 4 * cc4, b_cmax);
+            for (int i = 0; i < NB; ++i) {
+                const int row = min(t.n0 + crow + 32 * i, b.p[t.pi].N - 1);
+                rb[i] = gi_load4_at(t.Bp, (unsigned)row * (unsigned)t.ldb * 4u, k0 + 4 * cc4, t.b_cmax);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int red = min(k0 + b_mr + i * B_RP, k_end - 1);
-                const long long srow = BIDX ? p.b_idx[red] : red;
-                rb[i] = gi_load4_raw(Bp + srow * p.ldb, n0 + 4 * b_mc4, b_cmax);
+                const int red = min(k0 + b_mr + i * B_RP, t.k_end - 1);
+                int srow = red;
+                if (BIDX) { if (b.p[t.pi].b_idx) srow = b.p[t.pi].b_idx[red]; }
+                rb[i] = gi_load4_at(t.Bp, (unsigned)srow * (unsigned)t.ldb * 4u, t.n0 + 4 * b_mc4, t.b_cmax);
             }
         }
     };
 
     // (fix-up of the last / padding k tile) + LDS write, A half and B half
-    auto sstore_a = [&](v4f (&ra)[NA], int buf, int k0, const bool steady) {
+    auto sstore_a = [&](const Tile& t, v4f (&ra)[NA], int buf, int k0, const bool steady) {
         float* a = As + buf * A_SZ;
-        const bool full_k = k0 + BK <= k_end;        // block-uniform
-        if (steady || (full_k && a_fast)) {
+        const bool full_k = k0 + BK <= t.k_end;        // block-uniform
+        if (steady || (full_k && t.a_fast)) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 if (!A_MAJOR) *(v4f*)&a[(crow + 32 * i) * A_LD + 4 * cc4] = ra[i];
@@ -188,65 +261,61 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
             for (int i = 0; i < NA; ++i) {
                 if (!A_MAJOR) {
                     *(v4f*)&a[(crow + 32 * i) * A_LD + 4 * cc4] =
-                        gi_fix4(ra[i], k0 + 4 * cc4, a_cmax, k_end, a_ok[i]);
+                        gi_fix4(ra[i], k0 + 4 * cc4, t.a_cmax, t.k_end, t.m0 + crow + 32 * i < t.m_end);
                 } else {
-                    const bool ok = k0 + a_mr + i * A_RP < k_end;
+                    const bool ok = k0 + a_mr + i * A_RP < t.k_end;
                     *(v4f*)&a[(a_mr + i * A_RP) * A_LD + 4 * a_mc4] =
-                        gi_fix4(ra[i], m0 + 4 * a_mc4, a_cmax, p.M, ok);
+                        gi_fix4(ra[i], t.m0 + 4 * a_mc4, t.a_cmax, b.p[t.pi].M, ok);
                 }
             }
         }
     };
-    auto sstore_b = [&](v4f (&rb)[NB], int buf, int k0, const bool steady) {
-        float* b = Bs + buf * B_SZ;
-        const bool full_k = k0 + BK <= k_end;
-        if (steady || (full_k && b_fast)) {
+    auto sstore_b = [&](const Tile& t, v4f (&rb)[NB], int buf, int k0, const bool steady) {
+        float* bb = Bs + buf * B_SZ;
+        const bool full_k = k0 + BK <= t.k_end;
+        const int ones_col = b.p[t.pi].ones_col;
+        if (steady || (full_k && t.b_fast)) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 if (!B_MAJOR) {
-                    *(v4f*)&b[(crow + 32 * i) * B_LD + 4 * cc4] = rb[i];
+                    *(v4f*)&bb[(crow + 32 * i) * B_LD + 4 * cc4] = rb[i];
                 } else {
-                    const int col = n0 + 4 * b_mc4;
+                    const int col = t.n0 + 4 * b_mc4;
                     v4f v = rb[i];                   // bias-gradient column of wgrad (-1 never matches)
-                    v.x = (col == p.ones_col) ? 1.f : v.x;
-                    v.y = (col + 1 == p.ones_col) ? 1.f : v.y;
-                    v.z = (col + 2 == p.ones_col) ? 1.f : v.z;
-                    v.w = (col + 3 == p.ones_col) ? 1.f : v.w;
-                    *(v4f*)&b[(b_mr + i * B_RP) * B_LD + 4 * b_mc4] = v;
+                    v.x = (col == ones_col) ? 1.f : v.x;
+                    v.y = (col + 1 == ones_col) ? 1.f : v.y;
+                    v.z = (col + 2 == ones_col) ? 1.f : v.z;
+                    v.w = (col + 3 == ones_col) ? 1.f : v.w;
+                    *(v4f*)&bb[(b_mr + i * B_RP) * B_LD + 4 * b_mc4] = v;
                 }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 if (!B_MAJOR) {
-                    *(v4f*)&b[(crow + 32 * i) * B_LD + 4 * cc4] =
-                        gi_fix4(rb[i], k0 + 4 * cc4, b_cmax, k_end, b_ok[i]);
+                    *(v4f*)&bb[(crow + 32 * i) * B_LD + 4 * cc4] =
+                        gi_fix4(rb[i], k0 + 4 * cc4, t.b_cmax, t.k_end, t.n0 + crow + 32 * i < b.p[t.pi].N);
                 } else {
-                    const bool ok = k0 + b_mr + i * B_RP < k_end;
-                    const int col = n0 + 4 * b_mc4;
-                    v4f v = gi_fix4(rb[i], col, b_cmax, bcols, ok);
-                    v.x = (ok & (col == p.ones_col)) ? 1.f : v.x;
-                    v.y = (ok & (col + 1 == p.ones_col)) ? 1.f : v.y;
-                    v.z = (ok & (col + 2 == p.ones_col)) ? 1.f : v.z;
-                    v.w = (ok & (col + 3 == p.ones_col)) ? 1.f : v.w;
-                    *(v4f*)&b[(b_mr + i * B_RP) * B_LD + 4 * b_mc4] = v;
+                    const bool ok = k0 + b_mr + i * B_RP < t.k_end;
+                    const int col = t.n0 + 4 * b_mc4;
+                    const int bcols = ones_col >= 0 ? ones_col : b.p[t.pi].N;
+                    v4f v = gi_fix4(rb[i], col, t.b_cmax, bcols, ok);
+                    v.x = (ok & (col == ones_col)) ? 1.f : v.x;
+                    v.y = (ok & (col + 1 == ones_col)) ? 1.f : v.y;
+                    v.z = (ok & (col + 2 == ones_col)) ? 1.f : v.z;
+                    v.w = (ok & (col + 3 == ones_col)) ? 1.f : v.w;
+                    *(v4f*)&bb[(b_mr + i * B_RP) * B_LD + 4 * b_mc4] = v;
                 }
             }
         }
     };
 
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // fragments of one 8-deep reduction group
     auto read_frags = [&](int buf, int k8, float (&af)[TM][4], float (&bf)[TN][4]) {
         const float* a = As + buf * A_SZ;
-        const float* b = Bs + buf * B_SZ;
+        const float* bb = Bs + buf * B_SZ;
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
             const int row = wm * 32 * TM + t * 32 + l31;
@@ -262,11 +331,11 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
         for (int t = 0; t < TN; ++t) {
             const int row = wn * 32 * TN + t * 32 + l31;
             if (!B_MAJOR) {
-                const v4f v = *(const v4f*)&b[row * B_LD + k8 * 8 + 4 * lhi];
+                const v4f v = *(const v4f*)&bb[row * B_LD + k8 * 8 + 4 * lhi];
                 bf[t][0] = v.x; bf[t][1] = v.y; bf[t][2] = v.z; bf[t][3] = v.w;
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bf[t][j] = b[(k8 * 8 + j + 4 * lhi) * B_LD + row];
+                for (int j = 0; j < 4; ++j) bf[t][j] = bb[(k8 * 8 + j + 4 * lhi) * B_LD + row];
             }
         }
     };
@@ -281,7 +350,7 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
                                                                        acc[tm][tn], 0, 0, 0);
     };
 
-    // ---- main loop ----------------------------------------------------------------------------
+    // ---- main loop of one tile ------------------------------------------------------------------
     // Software pipeline, pinned with sched_barrier(0) (hipcc otherwise parks every non-MFMA
     // instruction after the tile's MFMA block, where nothing hides it — a lone wave then reaches only
     // 54 % MFMA duty, measured).  While the MFMAs of tile t run, the wave also issues
@@ -299,51 +368,54 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
     // — each tile then waits out the L2 latency of loads issued two MFMA groups earlier (0.70 us per
     // tile for a lone workgroup against 0.43 us of MFMA work).  The generic body only runs the
     // last one or two tile pairs (partial / padding tiles).
-    const int nk = (k_end > k_begin) ? (((k_end - k_begin + BK - 1) / BK + 1) & ~1) : 0;
     float af0[TM][4], bf0[TN][4], af1[TM][4], bf1[TN][4];
-#define GI_TILE(BUF, SA, SB_, RA, RB, KSTORE, KLOAD, DO_STORE, DO_LOAD, STEADY)                 \
+#define GI_TILE(T, BUF, SA, SB_, RA, RB, KSTORE, KLOAD, DO_STORE, DO_LOAD, STEADY)              \
     {                                                                                             \
         read_frags(BUF, 0, af0, bf0);                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        mma(af0, bf0); read_frags(BUF, 1, af1, bf1); if (DO_LOAD) gload_a(RA, KLOAD);             \
+        mma(af0, bf0); read_frags(BUF, 1, af1, bf1); if (DO_LOAD) gload_a(T, RA, KLOAD);          \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        mma(af1, bf1); read_frags(BUF, 2, af0, bf0); if (DO_LOAD) gload_b(RB, KLOAD, bidx);           \
+        mma(af1, bf1); read_frags(BUF, 2, af0, bf0); if (DO_LOAD) gload_b(T, RB, KLOAD, bidx);    \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         mma(af0, bf0); read_frags(BUF, 3, af1, bf1);                                              \
-        if (DO_STORE) sstore_a(SA, (BUF) ^ 1, KSTORE, STEADY);                                    \
+        if (DO_STORE) sstore_a(T, SA, (BUF) ^ 1, KSTORE, STEADY);                                 \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        mma(af1, bf1); if (DO_STORE) sstore_b(SB_, (BUF) ^ 1, KSTORE, STEADY);                    \
+        mma(af1, bf1); if (DO_STORE) sstore_b(T, SB_, (BUF) ^ 1, KSTORE, STEADY);                 \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         __syncthreads();                                                                          \
     }
-    auto run = [&](auto bidx) __attribute__((always_inline)) {
-        if (nk > 0) {
-            gload_a(ra0, k_begin); gload_b(rb0, k_begin, bidx);
-            gload_a(ra1, k_begin + BK); gload_b(rb1, k_begin + BK, bidx);
-            sstore_a(ra0, 0, k_begin, false); sstore_b(rb0, 0, k_begin, false);
+    // first two k tiles of a tile into the register stages (the prologue loads; for every tile but a
+    // workgroup's first they are issued in front of the PREVIOUS tile's epilogue)
+    auto prefetch = [&](const Tile& t, auto bidx) __attribute__((always_inline)) {
+        if (t.k_end > t.k_begin) {
+            gload_a(t, ra0, t.k_begin); gload_b(t, rb0, t.k_begin, bidx);
+            gload_a(t, ra1, t.k_begin + BK); gload_b(t, rb1, t.k_begin + BK, bidx);
         }
+    };
+    auto mainloop = [&](const Tile& t, auto bidx) __attribute__((always_inline)) {
+        const int k_begin = t.k_begin, k_end = t.k_end;
+        const int nk = (k_end > k_begin) ? (((k_end - k_begin + BK - 1) / BK + 1) & ~1) : 0;
+        if (nk > 0) { sstore_a(t, ra0, 0, k_begin, false); sstore_b(t, rb0, 0, k_begin, false); }
         __syncthreads();
+        GI_TRACE(t.id, 1);
         // pairs (kt, kt+1) that write tiles kt+1 and kt+2 to LDS: steady while kt+2 is a full tile
         const int n_full = (k_end - k_begin) / BK;
-        const int kt_steady = (a_fast && b_fast && n_full >= 3) ? (((n_full - 3) & ~1) + 2) : 0;
+        const int kt_steady = (t.a_fast && t.b_fast && n_full >= 3) ? (((n_full - 3) & ~1) + 2) : 0;
         int kt = 0;
         for (; kt < kt_steady; kt += 2) {
             const int k1 = k_begin + (kt + 1) * BK, k2 = k1 + BK, k3 = k2 + BK;
-            GI_TILE(0, ra1, rb1, ra0, rb0, k1, k2, true, true, true)
-            GI_TILE(1, ra0, rb0, ra1, rb1, k2, k3, true, true, true)
+            GI_TILE(t, 0, ra1, rb1, ra0, rb0, k1, k2, true, true, true)
+            GI_TILE(t, 1, ra0, rb0, ra1, rb1, k2, k3, true, true, true)
         }
         for (; kt < nk; kt += 2) {
             const bool more = kt + 2 < nk;
             const int k1 = k_begin + (kt + 1) * BK, k2 = k1 + BK, k3 = k2 + BK;
             // tile kt from LDS buffer 0: store tile kt+1 (stage 1) -> buffer 1, fetch tile kt+2 -> stage 0
-            GI_TILE(0, ra1, rb1, ra0, rb0, k1, k2, true, more, false)
+            GI_TILE(t, 0, ra1, rb1, ra0, rb0, k1, k2, true, more, false)
             // tile kt+1 from LDS buffer 1: store tile kt+2 (stage 0) -> buffer 0, fetch tile kt+3 -> stage 1
-            GI_TILE(1, ra0, rb0, ra1, rb1, k2, k3, more, more, false)
+            GI_TILE(t, 1, ra0, rb0, ra1, rb1, k2, k3, more, more, false)
         }
     };
-    if (B_MAJOR && p.b_idx) run(std::true_type{});
-    else run(std::false_type{});
-#undef GI_TILE
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     // Per 32x32 tile: ALL loads (activation for selu', old C for accumulate) are issued first from
@@ -351,134 +423,141 @@ __device__ __forceinline__ void gi_gemm_body(const gi_gemm_params& p, const int 
     // a sink instead of branched around.  A predicated store is a basic-block boundary at which
     // hipcc drains vmcnt(0) (stores count in vmcnt on gfx950): that was one serial ~450-cycle memory
     // round trip per output element, a quarter of a K=500 wave's lifetime (tools/gemm_timing.hip).
-    const int flags = p.flags;
+    auto epilogue = [&](const GemmEpi& t) __attribute__((always_inline)) {
+        const gi_gemm_params& p = b.p[t.pi];
+        constexpr int own = (!A_MAJOR && !B_MAJOR) ? (GI_EPI_BIAS | GI_EPI_SELU) : (!A_MAJOR ? GI_EPI_DSELU : 0);
+        const int flags = EPI ? own : p.flags;
+        const int m_end = t.m_end;
+        float* const Cp = t.Cp;
+        const bool need_act = (flags & (GI_EPI_DSELU | GI_EPI_MULACT)) != 0;
+        const bool need_c = (flags & GI_EPI_ACCUM) != 0;
+        // four rows per step (r = 4c .. 4c+3 are rows row0 + 8c + 0..3), the loads of step c+1 in flight
+        // under the arithmetic and stores of step c; the steps are fenced for the scheduler so the
+        // epilogue's registers stay a few rows' worth (the next tile's prefetched operands are live here)
+        auto load_rows = [&](int row0, int colc, int c, float (&av)[4], float (&cv)[4]) {
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int col = n0 + wn * 32 * TN + tn * 32 + l31;
-            const bool col_ok = col < p.N;
-            const int colc = col_ok ? col : p.N - 1;
-            const int row0 = m0 + wm * 32 * TM + tm * 32 + 4 * lhi;
-            float av[16], cv[16];
-            if (flags & (GI_EPI_DSELU | GI_EPI_MULACT)) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = min(row0 + (r & 3) + 8 * (r >> 2), m_end - 1);
-                    av[r] = p.act[(long long)row * p.ldact + colc];
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int row = min(row0 + 8 * c + r, m_end - 1);
+                if (need_act) av[r] = *(const float*)((const char*)p.act + ((unsigned)row * (unsigned)p.ldact + (unsigned)colc) * 4u);
+                if (need_c) cv[r] = *(const float*)((const char*)Cp + ((unsigned)row * (unsigned)p.ldc + (unsigned)colc) * 4u);
             }
-            if (flags & GI_EPI_ACCUM) {
+        };
+        if (GI_EXP_FAST && t.m0 + BM <= m_end && t.n0 + BN <= p.N) {       // interior tile (block-uniform)
+            const unsigned ldc4 = (unsigned)p.ldc * 4u, lda4 = (unsigned)p.ldact * 4u;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = min(row0 + (r & 3) + 8 * (r >> 2), m_end - 1);
-                    cv[r] = Cp[(long long)row * p.ldc + colc];
-                }
-            }
-            const float bv = (flags & GI_EPI_BIAS) ? biasp[colc] : 0.f;
-            float v[16];
+            for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float x = acc[tm][tn][r] + bv;
-                if (flags & GI_EPI_SELU) x = gi_selu(x);
-                if (flags & GI_EPI_DSELU) x *= gi_selu_grad(av[r]);
-                if (flags & GI_EPI_MULACT) x *= av[r];
-                if (flags & GI_EPI_ACCUM) x += cv[r];
-                v[r] = x;
-            }
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int col = t.n0 + wn * 32 * TN + tn * 32 + l31;
+                    const int row0 = t.m0 + wm * 32 * TM + tm * 32 + 4 * lhi;
+                    const float bv = (flags & GI_EPI_BIAS) ? t.biasp[col] : 0.f;
+                    const unsigned c0 = (unsigned)row0 * ldc4 + (unsigned)col * 4u;
+                    const unsigned a0 = (unsigned)row0 * lda4 + (unsigned)col * 4u;
+                    float av[16], cv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + (r & 3) + 8 * (r >> 2);
-                float* dst = (col_ok & (row < m_end)) ? Cp + (long long)row * p.ldc + col
-                                                      : gi_store_sink + tid;
-                *dst = v[r];
-            }
-        }
-    }
-    // ---- GI_GEMM_REDUCE: the last workgroup of this output tile sums its slabs ---------------------
-    // The workgroup's slab stores are released at agent scope (L2 write-back: the 8 XCD L2s are not
-    // coherent with each other), it takes a ticket on the tile's counter, and the holder of the last
-    // ticket invalidates its own L2 view before it reads the other workgroups' slabs.  The sum runs
-    // over the splits in index order whoever computes it.
-    if constexpr (A_MAJOR && B_MAJOR) {
-        if (flags & GI_GEMM_REDUCE) {
-            __shared__ int last_s;
-            // every wave's slab stores are in this XCD's L2 before the barrier (workgroup-scope release);
-            // ONE agent-scope release (L2 write-back) by the ticket taker then covers them all
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __syncthreads();
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                int* cnt = p.red_count + ((long long)g * gy + by) * gx + bx;
-                const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last_s = (old == n_splits - 1) ? 1 : 0;
-            }
-            __syncthreads();
-            if (last_s) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                const float* base = Cp - (long long)split_idx * p.c_split_stride;     // slab 0
-                float* dW = p.ngroups ? const_cast<float*>(p.Bg[g]) : p.red_dW;
-                float* db = p.ngroups ? const_cast<float*>(p.biasg[g]) : p.red_db;
-                const int wcols = (p.ones_col >= 0) ? p.ones_col : p.N;
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned k = (r & 3) + 8 * (r >> 2);
+                        if (need_act) av[r] = *(const float*)((const char*)p.act + (a0 + k * lda4));
+                        if (need_c) cv[r] = *(const float*)((const char*)Cp + (c0 + k * ldc4));
+                    }
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) {
-                        const int col = n0 + wn * 32 * TN + tn * 32 + l31;
-                        const int row0 = m0 + wm * 32 * TM + tm * 32 + 4 * lhi;
-                        if (col >= p.N) continue;
-#pragma unroll 4
-                        for (int r = 0; r < 16; ++r) {
-                            const int row = row0 + (r & 3) + 8 * (r >> 2);
-                            if (row >= m_end) continue;
-                            const float* src = base + (long long)row * p.ldc + col;
-                            float s0 = 0.f, s1 = 0.f;
-                            int j = 0;
-                            for (; j + 1 < n_splits; j += 2) {
-                                s0 += src[(long long)j * p.c_split_stride];
-                                s1 += src[(long long)(j + 1) * p.c_split_stride];
-                            }
-                            if (j < n_splits) s0 += src[(long long)j * p.c_split_stride];
-                            float* dst = (col < wcols) ? dW + (long long)row * p.red_ldw + col
-                                                       : (db ? db + row : nullptr);
-                            if (dst) *dst = p.red_accum ? *dst + (s0 + s1) : (s0 + s1);
-                        }
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned k = (r & 3) + 8 * (r >> 2);
+                        float x = acc[tm][tn][r] + bv;
+                        if (flags & GI_EPI_SELU) x = gi_selu(x);
+                        if (flags & GI_EPI_DSELU) x *= gi_selu_grad(av[r]);
+                        if (flags & GI_EPI_MULACT) x *= av[r];
+                        if (flags & GI_EPI_ACCUM) x += cv[r];
+                        *(float*)((char*)Cp + (c0 + k * ldc4)) = x;
                     }
                 }
             }
+            return;
         }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int col = t.n0 + wn * 32 * TN + tn * 32 + l31;
+                const bool col_ok = col < p.N;
+                const int colc = col_ok ? col : p.N - 1;
+                const int row0 = t.m0 + wm * 32 * TM + tm * 32 + 4 * lhi;
+                const float bv = (flags & GI_EPI_BIAS) ? t.biasp[colc] : 0.f;
+                float av[2][4], cv[2][4];
+                if (need_act | need_c) load_rows(row0, colc, 0, av[0], cv[0]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c < 3 && (need_act | need_c)) load_rows(row0, colc, c + 1, av[(c + 1) & 1], cv[(c + 1) & 1]);
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float x = acc[tm][tn][4 * c + r] + bv;
+                        if (flags & GI_EPI_SELU) x = gi_selu(x);
+                        if (flags & GI_EPI_DSELU) x *= gi_selu_grad(av[c & 1][r]);
+                        if (flags & GI_EPI_MULACT) x *= av[c & 1][r];
+                        if (flags & GI_EPI_ACCUM) x += cv[c & 1][r];
+                        v[r] = x;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = row0 + 8 * c + r;
+                        float* dst = (col_ok & (row < m_end))
+                            ? (float*)((char*)Cp + ((unsigned)row * (unsigned)p.ldc + (unsigned)col) * 4u)
+                            : gi_store_sink + tid;
+                        *dst = v[r];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    };
+
+    // ---- tile loop ------------------------------------------------------------------------------
+    auto run = [&](auto bidx) __attribute__((always_inline)) {
+        Tile cur;
+        GemmEpi done;
+        const int stride = gridDim.x;
+        if (GI_EXP_PRIO) __builtin_amdgcn_s_setprio(GI_EXP_PRIO);
+        setup(cur, blockIdx.x);
+        if (!cur.valid) return;
+        GI_TRACE_HW(cur.id);
+        GI_TRACE(cur.id, 0);
+        prefetch(cur, bidx);
+        while (true) {
+            // zero the accumulators from ONE register the optimiser cannot see through: as a constant the
+            // zero tile is hoisted out of the tile loop and lives in 16 VGPRs for the whole kernel
+            float zero;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = zero;
+            if (GI_EXP_PRIO) __builtin_amdgcn_s_setprio(0);
+            mainloop(cur, bidx);
+            GI_TRACE(cur.id, 2);
+            if (GI_EXP_PRIO) __builtin_amdgcn_s_setprio(GI_EXP_PRIO);
+            done.pi = cur.pi; done.biasp = cur.biasp; done.Cp = cur.Cp;
+            done.m_end = cur.m_end; done.m0 = cur.m0; done.n0 = cur.n0; done.empty = cur.empty;
+            const int did = cur.id;
+            setup(cur, did + stride);
+            if (cur.valid) prefetch(cur, bidx);       // the next tile's first loads fly under this epilogue
+            __builtin_amdgcn_sched_barrier(0);
+            if (!done.empty) epilogue(done);
+            GI_TRACE(did, 3);
+            if (!cur.valid) break;
+            GI_TRACE_HW(cur.id);
+            GI_TRACE(cur.id, 0);
+        }
+    };
+    bool any_bidx = false;
+    if (B_MAJOR) {
+        for (int i = 0; i < b.n; ++i) any_bidx |= b.p[i].b_idx != nullptr;
     }
-}
-
-template <int TM, int TN, bool A_MAJOR, bool B_MAJOR>
-__global__ __launch_bounds__(256) void gi_gemm_kernel(const gi_gemm_params p) {
-    gi_gemm_body<TM, TN, A_MAJOR, B_MAJOR>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x,
-                                           gridDim.y);
-}
-
-// Several independent GEMMs of the same tile/layout class in ONE launch ("horizontal fusion"):
-// the sibling MLPs of the readout (4 node-level stacks, 3 graph-level stacks) and the two GRU
-// projections have 16..450 workgroups each — together they fill the 256 CUs and halve the number of
-// launch ramps on the critical path.  Workgroup id -> (problem, x, y, z) through a prefix table.
-#define GI_GEMM_BATCH_MAX 8
-struct GemmBatch {
-    gi_gemm_params p[GI_GEMM_BATCH_MAX];
-    int start[GI_GEMM_BATCH_MAX + 1];          // first workgroup id of every problem
-    int gx[GI_GEMM_BATCH_MAX], gy[GI_GEMM_BATCH_MAX];
-    int n;
-};
-
-template <int TM, int TN, bool A_MAJOR, bool B_MAJOR>
-__global__ __launch_bounds__(256) void gi_gemm_batch_kernel(const GemmBatch b) {
-    int i = 0;
-    const int id = blockIdx.x;
-    while (i < b.n - 1 && id >= b.start[i + 1]) ++i;
-    const int local = id - b.start[i];
-    const int gx = b.gx[i], gxy = gx * b.gy[i];
-    const int bz = local / gxy;
-    const int rem = local - bz * gxy;
-    const int by = rem / gx;
-    gi_gemm_body<TM, TN, A_MAJOR, B_MAJOR>(b.p[i], rem - by * gx, by, bz, gx, b.gy[i]);
+    if (B_MAJOR && any_bidx) run(std::true_type{});
+    else run(std::false_type{});
+#undef GI_TILE
 }
 
 // XCD-aware tile order for launches of at least this many workgroups (0 = never): more than ~1.3
@@ -537,15 +616,16 @@ static int validate(const gi_gemm_params& p) {
     if (splitk && p.ngroups)
         for (int g = 0; g < p.ngroups; ++g)
             if (p.gsplit[g] < 1) return GI_EINVAL;
-    if (p.flags & GI_GEMM_REDUCE) {
-        if (!splitk || !p.a_major || !p.b_major || !p.red_count || p.red_ldw < 1) return GI_EINVAL;
-        if (p.ngroups) {
-            for (int g = 0; g < p.ngroups; ++g)
-                if (!p.Bg[g]) return GI_EINVAL;
-        } else if (!p.red_dW) {
-            return GI_EINVAL;
-        }
-    }
+    // 32-bit byte offsets inside every matrix (gi_load4_at)
+    const long long lim = 0xffffffffLL / 4;
+    const bool splitk2 = (p.flags & GI_GEMM_SPLITK) != 0;
+    const long long a_rows = p.a_major ? p.K : p.M, b_rows = p.b_major ? p.K : p.N;
+    if (!p.a_idx && a_rows * (long long)p.lda > lim) return GI_ELIMIT;
+    if (!p.b_idx && b_rows * (long long)p.ldb > lim) return GI_ELIMIT;
+    if ((long long)p.M * p.ldc > lim || (p.act && (long long)p.M * p.ldact > lim)) return GI_ELIMIT;
+    (void)splitk2;
+    if (p.flags & ~(GI_EPI_BIAS | GI_EPI_SELU | GI_EPI_DSELU | GI_EPI_ACCUM | GI_GEMM_SPLITK | GI_EPI_MULACT))
+        return GI_EINVAL;                               // bit 5 (tile order) is the launcher's
     return 0;
 }
 
@@ -564,34 +644,6 @@ static dim3 problem_grid(const gi_gemm_params& p) {
     return dim3(gi_cdiv(p.N, BN), gi_cdiv(rows, BM), splitk ? zsplit : groups);
 }
 
-#define GI_DISPATCH(KERNEL, TMV, TNV, GRID, ARG)                                                   \
-    do {                                                                                           \
-        if (!am && !bm) hipLaunchKernelGGL((KERNEL<TMV, TNV, false, false>), GRID, dim3(256), 0, st, ARG); \
-        else if (!am && bm) hipLaunchKernelGGL((KERNEL<TMV, TNV, false, true>), GRID, dim3(256), 0, st, ARG); \
-        else hipLaunchKernelGGL((KERNEL<TMV, TNV, true, true>), GRID, dim3(256), 0, st, ARG);      \
-    } while (0)
-
-extern "C" int gi_gemm(const gi_gemm_params* pp, void* stream) {
-    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
-    if (!pp) return GI_EINVAL;
-    gi_gemm_params p = *pp;
-    const int rc = validate(p);
-    if (rc) return rc;
-    const dim3 grid = problem_grid(p);
-    if (grid.x == 0) return 0;
-    if (want_remap((long long)grid.x * grid.y * grid.z)) p.flags |= 32;
-    if (grid.y > 65535u || grid.z > 65535u) return GI_ELIMIT;
-    hipStream_t st = (hipStream_t)stream;
-    // useful flops of this launch (real dims; for grouped / split launches M resp. K is the total)
-    GiProfScope prof(st, GI_PROF_GEMM, 2.0 * (double)p.M * (double)p.N * (double)p.K);
-    log_launch(&p, 1, grid.x * grid.y * grid.z, 2.0 * (double)p.M * (double)p.N * (double)p.K);
-    const bool am = p.a_major, bm = p.b_major;
-    if (p.tm == 1 && p.tn == 1) GI_DISPATCH(gi_gemm_kernel, 1, 1, grid, p);
-    else if (p.tm == 1 && p.tn == 2) GI_DISPATCH(gi_gemm_kernel, 1, 2, grid, p);
-    else GI_DISPATCH(gi_gemm_kernel, 2, 2, grid, p);
-    return gi_launch_status();
-}
-
 // k tiles one workgroup of the problem walks through (its run time, to first order)
 static int wg_k_tiles(const gi_gemm_params& p) {
     if (!(p.flags & GI_GEMM_SPLITK)) return gi_cdiv(p.K, 32);
@@ -600,16 +652,89 @@ static int wg_k_tiles(const gi_gemm_params& p) {
     return gi_cdiv(gi_cdiv(len, nsp > 0 ? nsp : 1), 32);
 }
 
+typedef void (*gi_tiles_fn)(const GemmBatch);
+static gi_tiles_fn tiles_kernel(int tm, int tn, bool am, bool bm, int epi) {
+#define GI_PICK2(TMV, TNV, E)                                                                      \
+    return (!am && !bm) ? gi_gemm_tiles_kernel<TMV, TNV, false, false, E>                         \
+         : (!am && bm)  ? gi_gemm_tiles_kernel<TMV, TNV, false, true, E>                          \
+                        : gi_gemm_tiles_kernel<TMV, TNV, true, true, E>
+#define GI_PICK(TMV, TNV) do { if (epi) { GI_PICK2(TMV, TNV, 1); } else { GI_PICK2(TMV, TNV, 0); } } while (0)
+    if (tm == 1 && tn == 1) GI_PICK(1, 1);
+    if (tm == 1 && tn == 2) GI_PICK(1, 2);
+    GI_PICK(2, 2);
+#undef GI_PICK
+#undef GI_PICK2
+}
+// the epilogue flags of a layout's own launch class (kernel template EPI = 1)
+static int own_epilogue(bool am, bool bm) {
+    return (!am && !bm) ? (GI_EPI_BIAS | GI_EPI_SELU) : (!am ? GI_EPI_DSELU : 0);
+}
+
+// Persistent grid: the number of workgroups of this kernel variant the device holds at once
+// (occupancy x CUs, from the runtime, cached per variant).  A launch with at least
+// GI_GEMM_PERSIST / 10 times that many tiles runs as that many workgroups walking the tile list
+// (stride = grid); smaller launches keep one workgroup per tile.  GI_GEMM_PERSIST=0 disables
+// (default 11: every launch that needs a second round of workgroups).
+static int g_persist_tenths = -1, g_grid_cap = 0;
+static int persist_tenths() {
+    if (g_persist_tenths < 0) g_persist_tenths = getenv("GI_GEMM_PERSIST") ? atoi(getenv("GI_GEMM_PERSIST")) : 11;
+    return g_persist_tenths;
+}
+// Measurement / test hook: persist_tenths >= 0 replaces the GI_GEMM_PERSIST threshold; grid_cap > 0 runs
+// every launch with more tiles than that as grid_cap workgroups walking the tile list (tests use a tiny
+// cap to push small problems through the tile loop), 0 removes the cap.
+extern "C" int gi_gemm_config(int persist_tenths_, int grid_cap) {
+    if (persist_tenths_ >= 0) g_persist_tenths = persist_tenths_;
+    g_grid_cap = grid_cap > 0 ? grid_cap : 0;
+    return 0;
+}
+static int resident_blocks(gi_tiles_fn fn, int tm, int tn, bool am, bool bm, int epi) {
+    static int cache[2][2][2][2][2];                    // [tm-1][tn-1][am][bm][epi]
+    int& c = cache[tm - 1][tn - 1][am ? 1 : 0][bm ? 1 : 0][epi];
+    if (c == 0) {
+        int dev = 0, cus = 0, per_cu = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, 256, 0) != hipSuccess ||
+            per_cu < 1)
+            per_cu = 1;
+        c = (cus > 0 ? cus : 256) * per_cu;
+        (void)hipGetLastError();
+    }
+    return c;
+}
+
+static int launch_tiles(GemmBatch& b, double flops, hipStream_t st) {
+    const gi_gemm_params& p0 = b.p[0];
+    const bool am = p0.a_major, bm = p0.b_major;
+    int epi = 1;                                        // every problem has the layout's own epilogue?
+    for (int i = 0; i < b.n; ++i)
+        if ((b.p[i].flags & ~GI_GEMM_SPLITK) != own_epilogue(am, bm)) epi = 0;
+    gi_tiles_fn fn = tiles_kernel(p0.tm, p0.tn, am, bm, epi);
+    if (want_remap(b.total))
+        for (int i = 0; i < b.n; ++i) b.p[i].flags |= 32;
+    int grid = b.total;
+    const int pt = persist_tenths();
+    if (pt > 0) {
+        const int res = resident_blocks(fn, p0.tm, p0.tn, am, bm, epi);
+        if ((long long)b.total * 10 >= (long long)res * pt) grid = res;
+    }
+    if (g_grid_cap > 0 && grid > g_grid_cap) grid = g_grid_cap;
+    GiProfScope prof(st, GI_PROF_GEMM, flops);
+    log_launch(b.p, b.n, b.total, flops);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, st, b);
+    return gi_launch_status();
+}
+
 extern "C" int gi_gemm_batch(const gi_gemm_params* probs, int n, void* stream) {
-    (void)hipGetLastError();
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (!probs || n < 1 || n > GI_GEMM_BATCH_MAX) return GI_EINVAL;
-    if (n == 1) return gi_gemm(probs, stream);
     GemmBatch b;
     memset(&b, 0, sizeof(b));
     double flops = 0;
     int total = 0, k = 0;
-    // longest reductions first: workgroup ids are dispatched in order, so the short workgroups are
-    // the ones that fill the last, partly empty round of the launch
+    // longest reductions first: tile ids are handed out in order, so the short tiles are the ones
+    // that fill the last, partly empty round of the launch
     int order[GI_GEMM_BATCH_MAX];
     for (int i = 0; i < n; ++i) order[i] = i;
     for (int i = 1; i < n; ++i)                       // stable insertion sort by reduction length
@@ -625,6 +750,7 @@ extern "C" int gi_gemm_batch(const gi_gemm_params* probs, int n, void* stream) {
             return GI_EINVAL;
         const dim3 g = problem_grid(p);
         if (g.x == 0) continue;
+        if ((long long)g.x * g.y * g.z + total > 0x3fffffff) return GI_ELIMIT;
         b.p[k] = p; b.gx[k] = g.x; b.gy[k] = g.y; b.start[k] = total;
         total += g.x * g.y * g.z;
         flops += 2.0 * (double)p.M * (double)p.N * (double)p.K;
@@ -632,16 +758,11 @@ extern "C" int gi_gemm_batch(const gi_gemm_params* probs, int n, void* stream) {
     }
     if (k == 0) return 0;
     b.start[k] = total;
-    b.n = k;
-    if (want_remap(total))
-        for (int i = 0; i < k; ++i) b.p[i].flags |= 32;
-    hipStream_t st = (hipStream_t)stream;
-    GiProfScope prof(st, GI_PROF_GEMM, flops);
-    log_launch(b.p, k, total, flops);
-    const bool am = probs[0].a_major, bm = probs[0].b_major;
-    const dim3 grid(total);
-    if (probs[0].tm == 1 && probs[0].tn == 1) GI_DISPATCH(gi_gemm_batch_kernel, 1, 1, grid, b);
-    else if (probs[0].tm == 1 && probs[0].tn == 2) GI_DISPATCH(gi_gemm_batch_kernel, 1, 2, grid, b);
-    else GI_DISPATCH(gi_gemm_batch_kernel, 2, 2, grid, b);
-    return gi_launch_status();
+    b.n = k; b.total = total;
+    return launch_tiles(b, flops, (hipStream_t)stream);
+}
+
+extern "C" int gi_gemm(const gi_gemm_params* pp, void* stream) {
+    if (!pp) return GI_EINVAL;
+    return gi_gemm_batch(pp, 1, stream);
 }

@@ -122,6 +122,7 @@ SIGNATURES = {
     "gi_class_sum_dselu": (ci, [vp, vp, ci, vp, vp, ci, ci, vp, vp, ci, vp]),
     "gi_gemm": (ci, [C.POINTER(GemmParams), vp]),
     "gi_gemm_batch": (ci, [C.POINTER(GemmParams), ci, vp]),
+    "gi_gemm_config": (ci, [ci, ci]),
     "gi_mlp_chain": (ci, [C.POINTER(ChainParams), ci, vp]),
     "gi_mlp_chain_pack": (ci, [C.POINTER(ChainParams), ci, vp]),
     "gi_mlp_chain_image_floats": (cll, [C.POINTER(ChainParams)]),

@@ -20,7 +20,9 @@ def apd_kl_loss_torch(output: torch.Tensor, target_output: torch.Tensor) -> torc
 
 class _FusedKL(torch.autograd.Function):
     """Two launches forward (row kernel + fixed-order batch mean), one backward (d_out scaled in place
-    by the upstream scalar, read on the device) — no torch glue kernels on the step's critical path."""
+    by the upstream scalar, read on the device) — no torch glue kernels on the step's critical path.
+    Single backward only: the gradient buffer is consumed (a second `backward(retain_graph=True)` raises
+    instead of returning a doubly scaled gradient)."""
 
     @staticmethod
     def forward(ctx, output, target):
@@ -32,6 +34,9 @@ class _FusedKL(torch.autograd.Function):
         else:
             tgt, tdt = target.contiguous().float(), L.DTYPE_F32
         B, W = out.shape
+        if B == 0:               # the torch expression divides 0 by the batch size 0: NaN, zero-size gradient
+            ctx.d_out = torch.empty_like(out) if ctx.needs_input_grad[0] else None
+            return torch.full((), float("nan"), dtype=torch.float32, device=out.device)
         buf = torch.empty(B + 1, dtype=torch.float32, device=out.device)    # row losses | mean
         need_grad = ctx.needs_input_grad[0]
         d_out = torch.empty_like(out) if need_grad else None
@@ -49,7 +54,12 @@ class _FusedKL(torch.autograd.Function):
         if d_out is None:
             raise RuntimeError("fused KL loss: backward called twice (its gradient buffer is "
                                "scaled in place)")
+        if d_out.numel() == 0:
+            return d_out, None
         if grad.data_ptr() in _UNIT_GRADS:     # a registered constant 1.0: scaling would change nothing
+            if __debug__ and _CHECK_UNIT_GRADS and float(grad) != 1.0:
+                raise RuntimeError("fused KL loss: a tensor registered with register_unit_gradient no "
+                                   "longer holds 1.0")
             return d_out, None
         g = grad.contiguous().float()
         L.check(L.load().gi_scale_by_scalar(d_out.data_ptr(), d_out.numel(), g.data_ptr(),
@@ -62,6 +72,10 @@ class _FusedKL(torch.autograd.Function):
 #: and never written by whoever registers them: ``dp.DataParallel``'s cached root gradient).  For these the
 #: in-place scaling of the loss gradient — one launch per step — is skipped; the result is bit-identical.
 _UNIT_GRADS = set()
+#: GI_CHECK_UNIT_GRADS=1: read every registered scalar back in backward and fail if it is not 1.0 (a host
+#: sync per step — for debugging a training loop that might write to its cached root gradient)
+import os as _os
+_CHECK_UNIT_GRADS = _os.environ.get("GI_CHECK_UNIT_GRADS", "0") == "1"
 
 
 def register_unit_gradient(t: torch.Tensor) -> torch.Tensor:

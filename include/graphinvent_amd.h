@@ -163,8 +163,16 @@ typedef struct gi_gemm_params {
 } gi_gemm_params;
 
 int gi_gemm(const gi_gemm_params* p, void* stream);
-/* n (<= 8) independent problems of the same tile shape and operand layouts in ONE launch. */
+/* n (<= 8) independent problems of the same tile shape and operand layouts in ONE launch.
+ * Every launch is a tile loop: launches with more output tiles than the device holds workgroups at once
+ * run as a persistent grid (each workgroup walks tiles id, id + grid, ...; the next tile's first operand
+ * loads are issued in front of the current tile's epilogue).  Operands are addressed with 32-bit byte
+ * offsets from their base pointers: every matrix must span less than 4 GB (GI_ELIMIT otherwise). */
 int gi_gemm_batch(const gi_gemm_params* problems, int n, void* stream);
+/* Measurement / test hook (process-wide): persist_tenths >= 0 sets the persistent-grid threshold in tenths of
+ * a full round of resident workgroups (default 11, environment GI_GEMM_PERSIST; 0 = one workgroup per tile);
+ * grid_cap > 0 caps every launch at that many workgroups (0 = no cap). */
+int gi_gemm_config(int persist_tenths, int grid_cap);   /* returns 0 */
 
 /* ------------------------------------------------------------------------------------------
  * Resident-activation MLP chain — a whole `MLP.forward` (gnn/modules.py:166-170: Linear -> SELU for

@@ -109,10 +109,22 @@ def test_compact_rejects_non_onehot_edges():
 TILES = [(1, 1), (1, 2), (2, 2)]
 
 
+@pytest.fixture(params=[0, 3], ids=["wg-per-tile", "tile-loop-3wgs"])
+def gemm_grid(request):
+    """Every gi_gemm launch is a tile loop; launches with more tiles than the device holds workgroups run as a
+    persistent grid.  The unit-test problems are far too small for that, so each GEMM test also runs with the
+    grid capped at 3 workgroups (gi_gemm_config): every workgroup then walks many tiles — of different
+    problems / groups / split-K slabs — through the prefetch-under-epilogue path."""
+    lib = L.load()
+    lib.gi_gemm_config(-1, request.param)
+    yield request.param
+    lib.gi_gemm_config(-1, 0)
+
+
 @pytest.mark.parametrize("tm,tn", TILES)
 @pytest.mark.parametrize("M,N,K", [(1000, 250, 100), (333, 500, 685), (130, 45, 500), (64, 1, 500),
                                    (300, 128, 136), (5, 3, 7)])
-def test_gemm_forward_bias_selu(M, N, K, tm, tn):
+def test_gemm_forward_bias_selu(M, N, K, tm, tn, gemm_grid):
     g = torch.Generator().manual_seed(M + N + K)
     lda = ops.r4(K) + 4
     X = torch.randn(M, lda, generator=g)
@@ -128,7 +140,7 @@ def test_gemm_forward_bias_selu(M, N, K, tm, tn):
 
 
 @pytest.mark.parametrize("b_major", [False, True])
-def test_gemm_split_k_forward_and_dgrad_with_slab_epilogue(b_major):
+def test_gemm_split_k_forward_and_dgrad_with_slab_epilogue(b_major, gemm_grid):
     """The skinny, long-reduction layers of the graph-level stacks (B x 500 outputs, K = N*A + G): split-K into
     slabs + gi_slab_epilogue (bias + SELU, or the SELU-backward factor) against the fp64 product."""
     import ctypes as C
@@ -156,7 +168,7 @@ def test_gemm_split_k_forward_and_dgrad_with_slab_epilogue(b_major):
     assert bool((out[:, N:] == 7.0).all())
 
 
-def test_gemm_forward_gather_and_groups():
+def test_gemm_forward_gather_and_groups(gemm_grid):
     g = torch.Generator().manual_seed(1)
     R, K, N, E = 200, 100, 250, 777
     h = torch.randn(R, 104, generator=g)
@@ -494,7 +506,7 @@ def test_mlp_chain_limits_are_reported():
 
 
 @pytest.mark.parametrize("tm,tn", TILES)
-def test_gemm_dgrad_dselu_inplace_and_accumulate(tm, tn):
+def test_gemm_dgrad_dselu_inplace_and_accumulate(tm, tn, gemm_grid):
     g = torch.Generator().manual_seed(2)
     R, n_out, n_in = 517, 250, 500
     dZ = torch.randn(R, 252, generator=g)
@@ -516,7 +528,7 @@ def test_gemm_dgrad_dselu_inplace_and_accumulate(tm, tn):
 @pytest.mark.parametrize("tn", [1, 2])
 @pytest.mark.parametrize("R,n_out,n_in,nsplit", [(1000, 250, 100, 4), (999, 45, 500, 7),
                                                  (70, 500, 128, 1), (33, 1, 500, 3)])
-def test_gemm_wgrad_slabs_and_reduce(R, n_out, n_in, nsplit, tn):
+def test_gemm_wgrad_slabs_and_reduce(R, n_out, n_in, nsplit, tn, gemm_grid):
     g = torch.Generator().manual_seed(R)
     dZ = torch.randn(R, ops.r4(n_out), generator=g)
     X = torch.randn(R, ops.r4(n_in) + 4, generator=g)
@@ -533,7 +545,7 @@ def test_gemm_wgrad_slabs_and_reduce(R, n_out, n_in, nsplit, tn):
     assert rel(db, dZ[:, :n_out].double().sum(0)) < 2e-5
 
 
-def test_gemm_wgrad_grouped_gather():
+def test_gemm_wgrad_grouped_gather(gemm_grid):
     g = torch.Generator().manual_seed(3)
     Rn, E, n_out, n_in, nsplit = 150, 901, 250, 100, 3
     h = torch.randn(Rn, 104, generator=g)
@@ -765,24 +777,38 @@ def test_selu_bwd_rows_gather():
 
 
 # ------------------------------------------------------------------------------------------------
-def test_fused_kl_loss_matches_torch_expression():
+@pytest.mark.parametrize("W", [625, 3193, 9769])          # GDB-13 / ZINC-shaped / ChEMBL-shaped APD widths:
+@pytest.mark.parametrize("tdtype", ["f32", "i8"])          # > 2048 logits runs kl_loss_kernel<., 1024>
+def test_fused_kl_loss_matches_torch_expression(W, tdtype):
+    """`Workflow.loss` (Workflow.py:850-858) — the fused kernel against the torch expression (`O.kl_loss`'s
+    formula), both instantiations (rows up to / wider than 2 048 logits), fp32 and int8 (HDF dtype) targets."""
     from graphinvent_amd.loss import apd_kl_loss, apd_kl_loss_torch
-    g = torch.Generator().manual_seed(6)
-    out = (torch.randn(257, 625, generator=g) * 3).to(DEV)
-    tgt = torch.randint(0, 4, (257, 625), generator=g).float()
+    import oracle.ggnn_oracle as O
+    g = torch.Generator().manual_seed(6 + W)
+    B = 257 if W == 625 else 67
+    out = (torch.randn(B, W, generator=g) * 3).to(DEV)
+    tgt = torch.randint(0, 4, (B, W), generator=g)
+    tgt = tgt * (torch.rand(B, W, generator=g) < 0.02)       # sparse like real APDs
     tgt[:, 0] += 1                                           # every row has mass
-    tgt = tgt.to(DEV)
+    tgt_ref = tgt.float().to(DEV)
+    tgt = tgt.to(torch.int8).to(DEV) if tdtype == "i8" else tgt_ref
     a = out.clone().requires_grad_(True)
     b = out.clone().requires_grad_(True)
-    la, lb = apd_kl_loss(a, tgt), apd_kl_loss_torch(b, tgt)
+    la, lb = apd_kl_loss(a, tgt), apd_kl_loss_torch(b, tgt_ref)
     (2.5 * la).backward()
     (2.5 * lb).backward()
     assert abs(float(la) - float(lb)) < 1e-5 * abs(float(lb))
     assert rel(a.grad, b.grad) < 1e-5
-    tgt[3] = 0                                               # all-zero row: NaN like the reference
-    assert torch.isnan(apd_kl_loss(out, tgt)) and torch.isnan(apd_kl_loss_torch(out, tgt))
+    # the oracle's restatement of the loss on CPU (what every model-level parity test compares with)
+    lo = O.kl_loss(out.cpu(), tgt_ref.cpu())
+    assert abs(float(la) - float(lo)) < 1e-5 * abs(float(lo))
+    tz = tgt.clone(); tz[3] = 0                              # all-zero row: NaN like the reference
+    tz_ref = tgt_ref.clone(); tz_ref[3] = 0
+    assert torch.isnan(apd_kl_loss(out, tz)) and torch.isnan(apd_kl_loss_torch(out, tz_ref))
     with torch.no_grad():
-        assert abs(float(apd_kl_loss(out[:3], tgt[:3])) - float(apd_kl_loss_torch(out[:3], tgt[:3]))) < 1e-5
+        assert abs(float(apd_kl_loss(out[:3], tz[:3])) - float(apd_kl_loss_torch(out[:3], tz_ref[:3]))) < 1e-5
+    # empty batch: NaN (0 / 0 like the torch expression), never uninitialised memory
+    assert torch.isnan(apd_kl_loss(out[:0], tgt[:0]))
 
 
 def test_fused_adam_matches_torch_adam():

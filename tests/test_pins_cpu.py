@@ -67,3 +67,68 @@ def test_a_wrong_mapping_is_detected():
     g["in_perm"] = np.roll(g["in_perm"], 1)
     _, _, _, flipped, total = pins.oracle_pinned(O, P, cfg, nodes, edges, tgt, signs, g)
     assert flipped > 1e-3 * total
+
+
+# ---- fl32(e - 1e6) quanta of fully-masked graphs (tests/pins.MaskQuantumPin) ---------------------------
+def _masked_graph_rows(tape, e8):
+    """Compact rows whose energies only fully-masked graphs use unmasked: their own slots (+ the zero row)."""
+    g = tape["g"]
+    B = e8.shape[0]
+    N = e8.shape[1]
+    full = ~e8.reshape(B, -1).any(1)
+    cidx = np.asarray(g["cidx"]).reshape(B, N)
+    return full, np.unique(cidx[full])
+
+
+@pytest.mark.parametrize("model", ["GGNN", "AttGGNN"])
+def test_mask_quantum_pin_accounts_for_every_masked_row_difference(model, monkeypatch):
+    """An implementation whose attention energies differ from the oracle's on the rows of fully-masked graphs
+    (here: by 0.02, far more than rounding, to move many quanta) disagrees with the plain fp32 oracle on those
+    graphs only — and agrees with the oracle at 1e-5 once the oracle is handed its fl32(e - 1e6) quanta."""
+    cfg = O.make_config(**(TINY if model == "GGNN" else TINY_ATT))
+    n8, e8, a8 = tiny_inputs()
+    P = O.init_params(cfg, seed=5, model=model)
+    nodes, edges = torch.from_numpy(n8).float(), torch.from_numpy(e8).float()
+    _, tape0 = D.forward(P, cfg, nodes, edges, keep=True, model=model)
+    full, rows = _masked_graph_rows(tape0, e8)
+    assert full.sum() >= 2                                         # the empty graph and the single atom
+    en0 = tape0["att_acts"][-1]
+    delta = torch.zeros_like(en0)
+    delta[torch.from_numpy(rows)] = 0.02 * torch.randn(len(rows), en0.shape[1],
+                                                       generator=torch.Generator().manual_seed(1))
+    orig = D.gather_readout
+    monkeypatch.setattr(D, "gather_readout", lambda en, *a: orig(en + delta, *a))
+    out_impl, tape = D.forward(P, cfg, nodes, edges, keep=True, model=model)
+    monkeypatch.setattr(D, "gather_readout", orig)
+    B, N = n8.shape[0], n8.shape[1]
+    pin = pins.MaskQuantumPin(en0 + delta, tape["g"]["cidx"], B, N, cfg["big_positive"])
+    o_plain = O.FORWARDS[model](P, cfg, nodes, edges)
+    o_pin = pins.oracle_quantum_pinned_logits(O, P, cfg, nodes, edges, pin, model)
+    assert O.MASK_QUANTUM_HOOK is None
+    scale = float(o_plain.abs().max())
+    live = torch.from_numpy(~full)
+    assert float((out_impl - o_plain)[live].abs().max()) < 1e-5 * scale        # untouched graphs
+    assert float((out_impl - o_plain)[~live].abs().max()) > 1e-4 * scale       # the test has teeth
+    assert float((out_impl - o_pin).abs().max()) < 1e-5 * scale                # every difference = quanta
+    assert pin.graphs == int(full.sum()) and pin.quanta == pin.graphs * N * en0.shape[1]
+    assert 0 < pin.moved <= pin.quanta and pin.max_steps >= 1 and abs(pin.max_de - float(delta.abs().max())) < 1e-5
+
+
+def test_mask_quantum_pin_is_a_no_op_on_consistent_energies_and_on_fp64():
+    cfg = O.make_config(**TINY)
+    n8, e8, a8 = tiny_inputs()
+    P = O.init_params(cfg, seed=5)
+    nodes, edges = torch.from_numpy(n8).float(), torch.from_numpy(e8).float()
+    out, tape = D.forward(P, cfg, nodes, edges, keep=True)
+    B, N = n8.shape[0], n8.shape[1]
+    pin = pins.MaskQuantumPin(tape["att_acts"][-1], tape["g"]["cidx"], B, N, cfg["big_positive"])
+    o_plain = O.ggnn_forward(P, cfg, nodes, edges)
+    o_pin = pins.oracle_quantum_pinned_logits(O, P, cfg, nodes, edges, pin)
+    assert pin.max_de < 1e-5 and pin.max_steps <= 1                # same arithmetic up to BLAS rounding
+    assert pin.moved <= 1e-2 * pin.quanta
+    if pin.moved == 0:
+        assert torch.equal(o_pin, o_plain)
+    P64 = {k: v.double() for k, v in P.items()}
+    pin64 = pins.MaskQuantumPin(tape["att_acts"][-1], tape["g"]["cidx"], B, N, cfg["big_positive"])
+    a = pins.oracle_quantum_pinned_logits(O, P64, cfg, nodes.double(), edges.double(), pin64)
+    assert pin64.quanta == 0 and torch.equal(a, O.ggnn_forward(P64, cfg, nodes.double(), edges.double()))

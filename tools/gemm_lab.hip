@@ -1,0 +1,158 @@
+// GEMM lab: the batched launches of the training step as a standalone program (no torch), for
+// kernel experiments and per-workgroup timelines.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Igraphinvent_amd/csrc tools/gemm_lab.hip -o tools/gemm_lab
+//   (add -DGI_GEMM_TRACE for the per-tile trace: tools/gemm_lab_trace <class> <tm> <tn> <persist> trace.csv)
+// usage: gemm_lab <fwd|dgrad|wgrad|fwd1|tier2> <tm> <tn> [persist_tenths [trace.csv]]
+//   fwd   : the node-level hidden-layer launch  (2 x 7258x500x500 + 2 x 7258x250x250, contig/contig)
+//   dgrad : its backward                         (the same, B operand reduction-major)
+//   wgrad : a weight-gradient batch              (3 x 500x501 + 2 x 250x251 + 3x501 + 2 x 100x251 over 7258 rows, split-K slabs)
+//   fwd1  : one 7258x500x500 problem
+//   tier2 : the graph-level hidden-layer launch (3 x 1000x500x500)
+// persist_tenths: 0 = one workgroup per tile, 11 = library default (persistent grid for launches of more
+// than 1.1 rounds of resident workgroups), 1 = always persistent.  Every run checks 64 random outputs per
+// problem against a double-precision dot product.
+#ifdef LAB_OLD       // round-2 kernel (one workgroup per tile), for A/B in the same call
+#include "experiments/gi_gemm_r2.hip.txt"
+extern "C" int gi_gemm_config(int, int) { return 0; }
+#else
+#include "../graphinvent_amd/csrc/gi_gemm.hip"
+#endif
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+#include <math.h>
+#include <vector>
+bool gi_prof_on() { return false; }
+void gi_prof_push(int, double, hipEvent_t, hipEvent_t) {}
+
+struct Mat { std::vector<float> h; float* d; };
+static float g_fill = 1.f;                         // GI_LAB_FILL=0: zero-filled operands (DVFS probe)
+static Mat make(size_t n, unsigned seed, float scale) {
+    Mat m; m.h.resize(n);
+    scale *= g_fill;
+    unsigned s = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; m.h[i] = scale * ((int)(s >> 8) / 8388608.f - 1.f); }
+    (void)hipMalloc(&m.d, n * 4); (void)hipMemcpy(m.d, m.h.data(), n * 4, hipMemcpyHostToDevice);
+    return m;
+}
+static inline int r4(int x) { return (x + 3) & ~3; }
+static double selu(double x) { return 1.0507009873554804934193349852946 * (x > 0 ? x : 1.6732632423543772848170429916717 * (exp(x) - 1)); }
+
+int main(int argc, char** argv) {
+    const char* cls = argc > 1 ? argv[1] : "fwd";
+    const int tm = argc > 2 ? atoi(argv[2]) : 1, tn = argc > 3 ? atoi(argv[3]) : 1;
+    const int persist = argc > 4 ? atoi(argv[4]) : 11;
+    const char* trace_path = argc > 5 ? argv[5] : nullptr;
+    if (getenv("GI_LAB_FILL")) g_fill = (float)atof(getenv("GI_LAB_FILL"));
+    gi_gemm_config(persist, 0);
+    int M = 7258, n = 4, dims[8][3] = {{500, 500, 0}, {500, 500, 0}, {250, 250, 0}, {250, 250, 0}};
+    const bool dgrad = !strcmp(cls, "dgrad"), wgrad = !strcmp(cls, "wgrad");
+    if (!strcmp(cls, "fwd1")) n = 1;
+    if (!strcmp(cls, "tier2")) { M = 1000; n = 3; dims[2][0] = dims[2][1] = 500; }
+    if (wgrad) {
+        n = 8;
+        const int w[8][3] = {{500, 500, 3}, {500, 500, 3}, {500, 500, 3}, {250, 250, 12}, {250, 250, 12}, {3, 500, 24}, {100, 250, 24}, {100, 250, 24}};
+        memcpy(dims, w, sizeof(w));
+    }
+    gi_gemm_params probs[8];
+    Mat A[8], B[8], Cm[8], bias[8], act[8];
+    double flops = 0;
+    for (int i = 0; i < n; ++i) {
+        gi_gemm_params& p = probs[i];
+        memset(&p, 0, sizeof(p));
+        p.nsplit = 1; p.ones_col = -1; p.tm = tm; p.tn = tn;
+        if (!wgrad) {
+            const int N = dims[i][0], K = dims[i][1], ldk = r4(K), ldn = r4(N);
+            A[i] = make((size_t)M * ldk, 11 + i, 1.f); p.A = A[i].d; p.lda = ldk;
+            Cm[i] = make((size_t)M * ldn, 21 + i, 1.f); p.C = Cm[i].d; p.ldc = ldn;
+            p.M = M; p.N = N; p.K = K;
+            if (!dgrad) {
+                B[i] = make((size_t)N * K, 31 + i, 0.06f); p.B = B[i].d; p.ldb = K;
+                bias[i] = make(N, 41 + i, 0.1f); p.bias = bias[i].d;
+                p.flags = GI_EPI_BIAS | GI_EPI_SELU;
+            } else {                                   // dX[M, N] = dZ[M, K] W[K, N] * selu'(act)
+                B[i] = make((size_t)K * N, 31 + i, 0.06f); p.B = B[i].d; p.ldb = N; p.b_major = 1;
+                act[i] = make((size_t)M * ldn, 51 + i, 1.f); p.act = act[i].d; p.ldact = ldn;
+                p.flags = GI_EPI_DSELU;
+            }
+            flops += 2.0 * M * N * K;
+        } else {                                       // [dW | db] = dZ^T [X | 1], reduction over M rows
+            const int no = dims[i][0], ni = dims[i][1], ns = dims[i][2];
+            A[i] = make((size_t)M * r4(no), 11 + i, 1.f); p.A = A[i].d; p.lda = r4(no); p.a_major = 1;
+            B[i] = make((size_t)M * r4(ni), 31 + i, 1.f); p.B = B[i].d; p.ldb = r4(ni); p.b_major = 1;
+            p.M = no; p.N = ni + 1; p.K = M; p.ones_col = ni; p.ldc = r4(ni + 1);
+            p.nsplit = ns; p.c_split_stride = r4(no * p.ldc); p.flags = GI_GEMM_SPLITK;
+            Cm[i] = make((size_t)ns * p.c_split_stride, 21 + i, 1.f); p.C = Cm[i].d;
+            flops += 2.0 * M * no * (ni + 1);
+        }
+    }
+    auto launch = [&] { const int rc = gi_gemm_batch(probs, n, 0); if (rc) { printf("rc %d\n", rc); exit(1); } };
+    for (int i = 0; i < 5; ++i) launch();
+    (void)hipDeviceSynchronize();
+    // ---- spot check against double-precision dot products ------------------------------------------
+    double worst = 0;
+    for (int i = 0; i < n; ++i) {
+        const gi_gemm_params& p = probs[i];
+        const size_t csz = wgrad ? (size_t)p.nsplit * p.c_split_stride : (size_t)M * p.ldc;
+        std::vector<float> c(csz);
+        (void)hipMemcpy(c.data(), p.C, csz * 4, hipMemcpyDeviceToHost);
+        unsigned s = 777 + i;
+        for (int t = 0; t < 64; ++t) {
+            s = s * 1664525u + 1013904223u; const int r = (t < 2 ? (t ? p.M - 1 : 0) : (s >> 8) % p.M);
+            s = s * 1664525u + 1013904223u; const int cidx = (t < 2 ? (t ? p.N - 1 : 0) : (s >> 8) % p.N);
+            double ref = 0, got = 0, scale = 1;
+            if (!wgrad && !dgrad) {
+                for (int k = 0; k < p.K; ++k) ref += (double)A[i].h[(size_t)r * p.lda + k] * B[i].h[(size_t)cidx * p.ldb + k];
+                ref = selu(ref + bias[i].h[cidx]); got = c[(size_t)r * p.ldc + cidx];
+            } else if (dgrad) {
+                for (int k = 0; k < p.K; ++k) ref += (double)A[i].h[(size_t)r * p.lda + k] * B[i].h[(size_t)k * p.ldb + cidx];
+                const double y = act[i].h[(size_t)r * p.ldact + cidx];
+                ref *= (y > 0 ? 1.0507009873554804934193349852946 : y + 1.0507009873554804934193349852946 * 1.6732632423543772848170429916717);
+                got = c[(size_t)r * p.ldc + cidx];
+            } else {
+                for (int k = 0; k < p.K; ++k)
+                    ref += (double)A[i].h[(size_t)k * p.lda + r] * (cidx == p.ones_col ? 1.0 : (double)B[i].h[(size_t)k * p.ldb + cidx]);
+                for (int sp = 0; sp < p.nsplit; ++sp) got += c[(size_t)sp * p.c_split_stride + (size_t)r * p.ldc + cidx];
+                scale = sqrt((double)p.K);
+            }
+            const double err = fabs(got - ref) / (scale * 1.0 + fabs(ref));
+            if (err > worst) worst = err;
+        }
+    }
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e9f, sum = 0.f;
+    const int rounds = 7, reps = 20;
+    for (int r = 0; r < rounds; ++r) {
+        (void)hipEventRecord(e0);
+        for (int i = 0; i < reps; ++i) launch();
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best; sum += ms;
+    }
+    printf("%s tile=(%d,%d) persist=%d: %.2f us per launch (best %.2f), %.1f TF (best %.1f) = %.3f of 157.3   max rel err %.2e %s\n",
+           cls, tm, tn, persist, sum / rounds / reps * 1e3, best / reps * 1e3, flops * reps * rounds / (sum * 1e-3) / 1e12,
+           flops * reps / (best * 1e-3) / 1e12, flops * reps * rounds / (sum * 1e-3) / 1e12 / 157.3, worst,
+           worst < 2e-5 ? "OK" : "MISMATCH");
+#ifdef GI_GEMM_TRACE
+    if (trace_path) {
+        int total = 0;
+        for (int i = 0; i < n; ++i) {
+            const gi_gemm_params& p = probs[i];
+            total += ((p.N + 64 * tn - 1) / (64 * tn)) * ((p.M + 64 * tm - 1) / (64 * tm)) * (wgrad ? p.nsplit : 1);
+        }
+        unsigned long long* buf; (void)hipMalloc(&buf, (size_t)total * 64); (void)hipMemset(buf, 0, (size_t)total * 64);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(gi_trace_buf), &buf, sizeof(buf));
+        launch(); (void)hipDeviceSynchronize();
+        std::vector<unsigned long long> h((size_t)total * 8);
+        (void)hipMemcpy(h.data(), buf, (size_t)total * 64, hipMemcpyDeviceToHost);
+        FILE* f = fopen(trace_path, "w");
+        fprintf(f, "wg,t_start,t_prologue,t_loop,t_end,hw_id,xcc_id,block\n");
+        for (int w = 0; w < total; ++w)
+            fprintf(f, "%d,%llu,%llu,%llu,%llu,%llu,%llu,%llu\n", w, h[w * 8], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3],
+                    h[w * 8 + 4], h[w * 8 + 5], h[w * 8 + 6]);
+        fclose(f);
+        printf("trace of %d tiles -> %s\n", total, trace_path);
+    }
+#endif
+    return worst < 2e-5 ? 0 : 2;
+}
