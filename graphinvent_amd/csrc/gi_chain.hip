@@ -617,11 +617,13 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
     hipStream_t st = (hipStream_t)stream;
     GiProfScope prof(st, GI_PROF_GEMM, flops);
     const dim3 grid(total), block(512);
-    // Experiment knob GI_CHAIN_RING=2 (not validated on hardware yet — next round): 32-row blocks with a
-    // two-slot weight ring, 114 KB of LDS instead of 146 KB, so that one workgroup of the GEMM family (37 KB)
-    // fits on the CU beside a chain workgroup.  Every overlap schedule measured so far was bounded by the
-    // chain workgroups owning their CU; the price is one weight tile of look-ahead less.
-    const bool ring2 = !big && getenv("GI_CHAIN_RING") && atoi(getenv("GI_CHAIN_RING")) == 2;
+    // 32-row blocks stream their weights through a TWO-slot ring (114 KB of LDS instead of 146 KB with three):
+    // one workgroup of the GEMM family (37 KB) fits on the CU beside a chain workgroup, which is what the
+    // weight-gradient stream needs to overlap with the chains (every overlap schedule of round 2 was bounded by
+    // chain workgroups owning their CU).  One weight tile of look-ahead less costs nothing measurable alone;
+    // the step gains 1.6 % (headline 2.312 / 2.332 -> 2.277 / 2.295 ms, ZINC shape 5.044 -> 4.957, ChEMBL shape
+    // 3.854 -> 3.813; profiles/r03/chain_ring_ab.txt).  GI_CHAIN_RING=3: the three-slot ring (measurements).
+    const bool ring2 = !big && !(getenv("GI_CHAIN_RING") && atoi(getenv("GI_CHAIN_RING")) == 3);
     if (big) {
         if (chains[0].backward) hipLaunchKernelGGL((gi_chain_kernel<true, 2, 2>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((gi_chain_kernel<false, 2, 2>), grid, block, 0, st, a);

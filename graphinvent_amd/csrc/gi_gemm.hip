@@ -38,13 +38,6 @@
 #include "gi_mfma.h"
 #include <type_traits>
 
-// compile-time experiment switches (tools/gemm_lab.hip builds variants; product values below)
-#ifndef GI_EXP_PRIO
-#define GI_EXP_PRIO 0          // s_setprio level of a wave outside its main loop (epilogue, tile setup, prefetch)
-#endif
-#ifndef GI_EXP_FAST
-#define GI_EXP_FAST 0          // interior tiles: epilogue without bounds checks
-#endif
 
 __device__ float gi_store_sink[256];               // where out-of-range lanes of edge tiles store
 
@@ -95,17 +88,17 @@ struct GemmTile {
     bool a_fast, b_fast, valid, empty;
     int a_row[NA];                         // contig A: stored row of staging slot i (gathered / clamped)
 };
-// What the epilogue of a finished tile needs while the NEXT tile's description and first loads are live.
+// What the epilogue of a finished tile needs while the NEXT tile is being computed.
 struct GemmEpi {
     int pi; const float* biasp; float* Cp;
     int m_end, m0, n0;
-    bool empty;
+    bool valid;
 };
 
 // EPI: 0 = epilogue from the run-time flags; 1 = the epilogue of the layout's own launch class, known at
 // compile time (forward: bias + SELU; dgrad: * selu'(act); weight-gradient slabs: plain store) — the
 // launcher picks it when every problem of the launch has exactly those flags.
-template <int TM, int TN, bool A_MAJOR, bool B_MAJOR, int EPI>
+template <int TM, int TN, bool A_MAJOR, bool B_MAJOR, int EPI, bool PERSIST>
 __global__ __launch_bounds__(256) void gi_gemm_tiles_kernel(const GemmBatch b) {
     constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32;
     constexpr int A_LD = A_MAJOR ? BM + 4 : BK + 4;
@@ -350,90 +343,76 @@ __global__ __launch_bounds__(256) void gi_gemm_tiles_kernel(const GemmBatch b) {
                                                                        acc[tm][tn], 0, 0, 0);
     };
 
-    // ---- main loop of one tile ------------------------------------------------------------------
+    // ---- the k-tile stream of a workgroup --------------------------------------------------------
     // Software pipeline, pinned with sched_barrier(0) (hipcc otherwise parks every non-MFMA
     // instruction after the tile's MFMA block, where nothing hides it — a lone wave then reaches only
-    // 54 % MFMA duty, measured).  While the MFMAs of tile t run, the wave also issues
+    // 54 % MFMA duty, measured).  While the MFMAs of k tile t run, the wave also issues
     //   - the LDS fragment reads of the NEXT 8-deep group,
-    //   - the global loads of tile t+2 into the register stage that has just been drained,
-    //   - the LDS writes of tile t+1 (loaded during tile t-1) into the other LDS buffer,
-    // i.e. every memory instruction sits in the shadow of a 64-cycle MFMA.  The tile count is
-    // rounded up to even (a tile past k_end stages zeros) so the two-stage body has no mid exit.
+    //   - the global loads of k tile t+2 into the register stage that has just been drained,
+    //   - the LDS writes of k tile t+1 (loaded during k tile t-1) into the other LDS buffer,
+    // i.e. every memory instruction sits in the shadow of a 64-cycle MFMA.  A tile's k-tile count is
+    // rounded up to even (a k tile past k_end stages zeros), the unit is a PAIR of k tiles (LDS buffer
+    // 0 then 1, register stage 0 then 1), and the stream does not stop at output-tile boundaries: the
+    // last pair of a tile loads the first two k tiles of the workgroup's NEXT tile and stages its first
+    // one, so a new tile starts with its operands in LDS (no prologue; measured before: 12 % of a
+    // workgroup's life).  Loads and LDS writes are unconditional (clamped addresses; what nobody needs is
+    // garbage nobody reads), so a pair is branch free apart from the partial-k-tile fix-up:
     //
-    // STEADY = true is the straight-line body for the tiles whose successors are full in k: loads
-    // (clamped, always readable) and LDS writes are unconditional, so the body is ONE basic block
-    // and hipcc's wait-count pass can keep tile t+2's four loads in flight across the LDS write of
-    // tile t+1 (s_waitcnt vmcnt(6) / vmcnt(4)).  With the run-time `more` / partial-tile branches of
-    // the generic body it merges the states of both arms and emits vmcnt(0) before every LDS write
-    // — each tile then waits out the L2 latency of loads issued two MFMA groups earlier (0.70 us per
-    // tile for a lone workgroup against 0.43 us of MFMA work).  The generic body only runs the
-    // last one or two tile pairs (partial / padding tiles).
+    // STEADY pairs (every k tile they stage is full in k) are ONE basic block: hipcc's wait-count pass
+    // keeps the next k tile's loads in flight across the LDS write of the current one (s_waitcnt
+    // vmcnt(6) / vmcnt(4)).  With run-time branches in the body it merges the states of both arms and
+    // emits vmcnt(0) before every LDS write — each k tile then waits out the L2 latency of loads issued
+    // two MFMA groups earlier.  The generic pair (fix-up decided at run time) only runs a tile's last
+    // one or two pairs.
+    //
+    constexpr int own_flags = (!A_MAJOR && !B_MAJOR) ? (GI_EPI_BIAS | GI_EPI_SELU) : (!A_MAJOR ? GI_EPI_DSELU : 0);
     float af0[TM][4], bf0[TN][4], af1[TM][4], bf1[TN][4];
-#define GI_TILE(T, BUF, SA, SB_, RA, RB, KSTORE, KLOAD, DO_STORE, DO_LOAD, STEADY)              \
-    {                                                                                             \
-        read_frags(BUF, 0, af0, bf0);                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        mma(af0, bf0); read_frags(BUF, 1, af1, bf1); if (DO_LOAD) gload_a(T, RA, KLOAD);          \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        mma(af1, bf1); read_frags(BUF, 2, af0, bf0); if (DO_LOAD) gload_b(T, RB, KLOAD, bidx);    \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        mma(af0, bf0); read_frags(BUF, 3, af1, bf1);                                              \
-        if (DO_STORE) sstore_a(T, SA, (BUF) ^ 1, KSTORE, STEADY);                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        mma(af1, bf1); if (DO_STORE) sstore_b(T, SB_, (BUF) ^ 1, KSTORE, STEADY);                 \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        __syncthreads();                                                                          \
-    }
-    // first two k tiles of a tile into the register stages (the prologue loads; for every tile but a
-    // workgroup's first they are issued in front of the PREVIOUS tile's epilogue)
-    auto prefetch = [&](const Tile& t, auto bidx) __attribute__((always_inline)) {
-        if (t.k_end > t.k_begin) {
-            gload_a(t, ra0, t.k_begin); gload_b(t, rb0, t.k_begin, bidx);
-            gload_a(t, ra1, t.k_begin + BK); gload_b(t, rb1, t.k_begin + BK, bidx);
-        }
-    };
-    auto mainloop = [&](const Tile& t, auto bidx) __attribute__((always_inline)) {
-        const int k_begin = t.k_begin, k_end = t.k_end;
-        const int nk = (k_end > k_begin) ? (((k_end - k_begin + BK - 1) / BK + 1) & ~1) : 0;
-        if (nk > 0) { sstore_a(t, ra0, 0, k_begin, false); sstore_b(t, rb0, 0, k_begin, false); }
+
+    // one pair of k tiles.  TS1 @ ks1: the k tile staged from register stage 1 into LDS buffer 1, TS2 @ ks2: the
+    // one staged from stage 0 into buffer 0 afterwards, TL @ kl0 / kl1: the two k tiles loaded (stage 0, then 1).
+    // Inside a tile all three are the tile itself; in its last pair TS2 and TL are the workgroup's next tile.
+    // `follow` (block-uniform; always true in a STEADY pair): false in the last pair of a workgroup's last
+    // tile — nothing follows, so it loads and stages nothing more.
+    auto pair = [&](auto steady_c, const bool follow, const Tile& TS1, int ks1, const Tile& TS2, int ks2,
+                    const Tile& TL, int kl0, int kl1, auto bidx) __attribute__((always_inline)) {
+        constexpr bool STEADY = decltype(steady_c)::value;
+        const bool FINAL = !STEADY && !follow;
+        read_frags(0, 0, af0, bf0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(af0, bf0); read_frags(0, 1, af1, bf1); if (!FINAL) gload_a(TL, ra0, kl0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(af1, bf1); read_frags(0, 2, af0, bf0); if (!FINAL) gload_b(TL, rb0, kl0, bidx);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(af0, bf0); read_frags(0, 3, af1, bf1); sstore_a(TS1, ra1, 1, ks1, STEADY);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(af1, bf1); sstore_b(TS1, rb1, 1, ks1, STEADY);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-        GI_TRACE(t.id, 1);
-        // pairs (kt, kt+1) that write tiles kt+1 and kt+2 to LDS: steady while kt+2 is a full tile
-        const int n_full = (k_end - k_begin) / BK;
-        const int kt_steady = (t.a_fast && t.b_fast && n_full >= 3) ? (((n_full - 3) & ~1) + 2) : 0;
-        int kt = 0;
-        for (; kt < kt_steady; kt += 2) {
-            const int k1 = k_begin + (kt + 1) * BK, k2 = k1 + BK, k3 = k2 + BK;
-            GI_TILE(t, 0, ra1, rb1, ra0, rb0, k1, k2, true, true, true)
-            GI_TILE(t, 1, ra0, rb0, ra1, rb1, k2, k3, true, true, true)
-        }
-        for (; kt < nk; kt += 2) {
-            const bool more = kt + 2 < nk;
-            const int k1 = k_begin + (kt + 1) * BK, k2 = k1 + BK, k3 = k2 + BK;
-            // tile kt from LDS buffer 0: store tile kt+1 (stage 1) -> buffer 1, fetch tile kt+2 -> stage 0
-            GI_TILE(t, 0, ra1, rb1, ra0, rb0, k1, k2, true, more, false)
-            // tile kt+1 from LDS buffer 1: store tile kt+2 (stage 0) -> buffer 0, fetch tile kt+3 -> stage 1
-            GI_TILE(t, 1, ra0, rb0, ra1, rb1, k2, k3, more, more, false)
-        }
+        read_frags(1, 0, af0, bf0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(af0, bf0); read_frags(1, 1, af1, bf1); if (!FINAL) gload_a(TL, ra1, kl1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(af1, bf1); read_frags(1, 2, af0, bf0); if (!FINAL) gload_b(TL, rb1, kl1, bidx);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(af0, bf0); read_frags(1, 3, af1, bf1); if (!FINAL) sstore_a(TS2, ra0, 0, ks2, STEADY);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(af1, bf1); if (!FINAL) sstore_b(TS2, rb0, 0, ks2, STEADY);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
     };
 
-    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    // Per 32x32 tile: ALL loads (activation for selu', old C for accumulate) are issued first from
-    // clamped addresses, then the arithmetic, then ALL stores, with out-of-range lanes redirected to
-    // a sink instead of branched around.  A predicated store is a basic-block boundary at which
-    // hipcc drains vmcnt(0) (stores count in vmcnt on gfx950): that was one serial ~450-cycle memory
-    // round trip per output element, a quarter of a K=500 wave's lifetime (tools/gemm_timing.hip).
+    // ---- epilogue in one piece: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // Four rows per step (r = 4c .. 4c+3 are rows row0 + 8c + 0..3), the loads of step c+1 in flight under the
+    // arithmetic and stores of step c; out-of-range lanes store to a sink instead of being branched around (a
+    // predicated store is a basic-block boundary at which hipcc drains vmcnt(0) — stores count in vmcnt on
+    // gfx950 — i.e. one serial memory round trip per output element).
     auto epilogue = [&](const GemmEpi& t) __attribute__((always_inline)) {
         const gi_gemm_params& p = b.p[t.pi];
-        constexpr int own = (!A_MAJOR && !B_MAJOR) ? (GI_EPI_BIAS | GI_EPI_SELU) : (!A_MAJOR ? GI_EPI_DSELU : 0);
-        const int flags = EPI ? own : p.flags;
+        const int flags = EPI ? own_flags : p.flags;
         const int m_end = t.m_end;
         float* const Cp = t.Cp;
         const bool need_act = (flags & (GI_EPI_DSELU | GI_EPI_MULACT)) != 0;
         const bool need_c = (flags & GI_EPI_ACCUM) != 0;
-        // four rows per step (r = 4c .. 4c+3 are rows row0 + 8c + 0..3), the loads of step c+1 in flight
-        // under the arithmetic and stores of step c; the steps are fenced for the scheduler so the
-        // epilogue's registers stay a few rows' worth (the next tile's prefetched operands are live here)
         auto load_rows = [&](int row0, int colc, int c, float (&av)[4], float (&cv)[4]) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -442,38 +421,6 @@ __global__ __launch_bounds__(256) void gi_gemm_tiles_kernel(const GemmBatch b) {
                 if (need_c) cv[r] = *(const float*)((const char*)Cp + ((unsigned)row * (unsigned)p.ldc + (unsigned)colc) * 4u);
             }
         };
-        if (GI_EXP_FAST && t.m0 + BM <= m_end && t.n0 + BN <= p.N) {       // interior tile (block-uniform)
-            const unsigned ldc4 = (unsigned)p.ldc * 4u, lda4 = (unsigned)p.ldact * 4u;
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    const int col = t.n0 + wn * 32 * TN + tn * 32 + l31;
-                    const int row0 = t.m0 + wm * 32 * TM + tm * 32 + 4 * lhi;
-                    const float bv = (flags & GI_EPI_BIAS) ? t.biasp[col] : 0.f;
-                    const unsigned c0 = (unsigned)row0 * ldc4 + (unsigned)col * 4u;
-                    const unsigned a0 = (unsigned)row0 * lda4 + (unsigned)col * 4u;
-                    float av[16], cv[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const unsigned k = (r & 3) + 8 * (r >> 2);
-                        if (need_act) av[r] = *(const float*)((const char*)p.act + (a0 + k * lda4));
-                        if (need_c) cv[r] = *(const float*)((const char*)Cp + (c0 + k * ldc4));
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const unsigned k = (r & 3) + 8 * (r >> 2);
-                        float x = acc[tm][tn][r] + bv;
-                        if (flags & GI_EPI_SELU) x = gi_selu(x);
-                        if (flags & GI_EPI_DSELU) x *= gi_selu_grad(av[r]);
-                        if (flags & GI_EPI_MULACT) x *= av[r];
-                        if (flags & GI_EPI_ACCUM) x += cv[r];
-                        *(float*)((char*)Cp + (c0 + k * ldc4)) = x;
-                    }
-                }
-            }
-            return;
-        }
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -511,42 +458,77 @@ __global__ __launch_bounds__(256) void gi_gemm_tiles_kernel(const GemmBatch b) {
             }
         }
     };
+    auto epi_of = [&](const Tile& t) __attribute__((always_inline)) {
+        GemmEpi e;
+        e.pi = t.pi; e.biasp = t.biasp; e.Cp = t.Cp; e.m_end = t.m_end; e.m0 = t.m0; e.n0 = t.n0;
+        e.valid = true;
+        return e;
+    };
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+        // from ONE register the optimiser cannot see through: as a constant the zero tile is hoisted out of
+        // the tile loop and lives in 16 VGPRs for the whole kernel
+        float zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = zero;
+    };
+    // the workgroup's next tile WITH a reduction range from `id` on; tiles without one (an empty group, a
+    // trailing split-K slice) are finished on the way: their epilogue of zeros (needs acc == 0)
+    auto advance = [&](Tile& t, int id, int stride) __attribute__((always_inline)) {
+        while (true) {
+            setup(t, id);
+            if (!t.valid || t.k_end > t.k_begin) break;
+            if (!t.empty) epilogue(epi_of(t));
+            id += stride;
+        }
+    };
 
     // ---- tile loop ------------------------------------------------------------------------------
     auto run = [&](auto bidx) __attribute__((always_inline)) {
-        Tile cur;
-        GemmEpi done;
+        Tile cur, nxt;
         const int stride = gridDim.x;
-        if (GI_EXP_PRIO) __builtin_amdgcn_s_setprio(GI_EXP_PRIO);
-        setup(cur, blockIdx.x);
+        zero_acc();
+        advance(cur, blockIdx.x, stride);
         if (!cur.valid) return;
         GI_TRACE_HW(cur.id);
         GI_TRACE(cur.id, 0);
-        prefetch(cur, bidx);
+        // the only prologue of the workgroup: first two k tiles -> register stages, the first one -> LDS
+        gload_a(cur, ra0, cur.k_begin); gload_b(cur, rb0, cur.k_begin, bidx);
+        gload_a(cur, ra1, cur.k_begin + BK); gload_b(cur, rb1, cur.k_begin + BK, bidx);
+        sstore_a(cur, ra0, 0, cur.k_begin, false); sstore_b(cur, rb0, 0, cur.k_begin, false);
+        __syncthreads();
         while (true) {
-            // zero the accumulators from ONE register the optimiser cannot see through: as a constant the
-            // zero tile is hoisted out of the tile loop and lives in 16 VGPRs for the whole kernel
-            float zero;
-            asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = zero;
-            if (GI_EXP_PRIO) __builtin_amdgcn_s_setprio(0);
-            mainloop(cur, bidx);
+            GI_TRACE(cur.id, 1);
+            if (PERSIST) advance(nxt, cur.id + stride, stride);            // acc == 0 here
+            else nxt.valid = false;
+            const bool more = PERSIST && nxt.valid;
+            const int k_begin = cur.k_begin, k_end = cur.k_end;
+            const int npairs = ((k_end - k_begin + BK - 1) / BK + 1) >> 1;
+            // pairs q < n_steady stage only k tiles that are full in k (k tiles 2q+1 and 2q+2)
+            const int n_full = (k_end - k_begin) / BK;
+            const int n_steady = (cur.a_fast && cur.b_fast) ? min(max((n_full - 1) >> 1, 0), npairs - 1) : 0;
+            int q = 0;
+            for (; q < n_steady; ++q) {
+                const int k1 = k_begin + (2 * q + 1) * BK;
+                pair(std::true_type{}, true, cur, k1, cur, k1 + BK, cur, k1 + BK, k1 + 2 * BK, bidx);
+            }
+            for (; q < npairs; ++q) {                          // the last pair hands over to the next tile, if any
+                const int k1 = k_begin + (2 * q + 1) * BK;
+                const bool last = q == npairs - 1;
+                const Tile& nx = (PERSIST && last && more) ? nxt : cur;
+                const int k2 = (PERSIST && last && more) ? nxt.k_begin : k1 + BK;
+                pair(std::false_type{}, !last || more, cur, k1, nx, k2, nx, k2, k2 + BK, bidx);
+            }
             GI_TRACE(cur.id, 2);
-            if (GI_EXP_PRIO) __builtin_amdgcn_s_setprio(GI_EXP_PRIO);
-            done.pi = cur.pi; done.biasp = cur.biasp; done.Cp = cur.Cp;
-            done.m_end = cur.m_end; done.m0 = cur.m0; done.n0 = cur.n0; done.empty = cur.empty;
-            const int did = cur.id;
-            setup(cur, did + stride);
-            if (cur.valid) prefetch(cur, bidx);       // the next tile's first loads fly under this epilogue
-            __builtin_amdgcn_sched_barrier(0);
-            if (!done.empty) epilogue(done);
-            GI_TRACE(did, 3);
-            if (!cur.valid) break;
+            epilogue(epi_of(cur));
+            GI_TRACE(cur.id, 3);
+            if (!more) break;
+            zero_acc();
+            cur = nxt;
             GI_TRACE_HW(cur.id);
             GI_TRACE(cur.id, 0);
         }
@@ -557,7 +539,7 @@ __global__ __launch_bounds__(256) void gi_gemm_tiles_kernel(const GemmBatch b) {
     }
     if (B_MAJOR && any_bidx) run(std::true_type{});
     else run(std::false_type{});
-#undef GI_TILE
+
 }
 
 // XCD-aware tile order for launches of at least this many workgroups (0 = never): more than ~1.3
@@ -653,17 +635,20 @@ static int wg_k_tiles(const gi_gemm_params& p) {
 }
 
 typedef void (*gi_tiles_fn)(const GemmBatch);
-static gi_tiles_fn tiles_kernel(int tm, int tn, bool am, bool bm, int epi) {
-#define GI_PICK2(TMV, TNV, E)                                                                      \
-    return (!am && !bm) ? gi_gemm_tiles_kernel<TMV, TNV, false, false, E>                         \
-         : (!am && bm)  ? gi_gemm_tiles_kernel<TMV, TNV, false, true, E>                          \
-                        : gi_gemm_tiles_kernel<TMV, TNV, true, true, E>
-#define GI_PICK(TMV, TNV) do { if (epi) { GI_PICK2(TMV, TNV, 1); } else { GI_PICK2(TMV, TNV, 0); } } while (0)
+// variants: tile (3) x layout (3) x {run-time epilogue | the layout's own epilogue x {one tile per workgroup, tile stream}}
+static gi_tiles_fn tiles_kernel(int tm, int tn, bool am, bool bm, int epi, bool persist) {
+#define GI_PICK3(TMV, TNV, E, P)                                                                   \
+    return (!am && !bm) ? gi_gemm_tiles_kernel<TMV, TNV, false, false, E, P>                      \
+         : (!am && bm)  ? gi_gemm_tiles_kernel<TMV, TNV, false, true, E, P>                       \
+                        : gi_gemm_tiles_kernel<TMV, TNV, true, true, E, P>
+#define GI_PICK2(TMV, TNV, E) do { if (persist) { GI_PICK3(TMV, TNV, E, true); } else { GI_PICK3(TMV, TNV, E, false); } } while (0)
+#define GI_PICK(TMV, TNV) do { if (epi) GI_PICK2(TMV, TNV, 1); else { GI_PICK3(TMV, TNV, 0, false); } } while (0)
     if (tm == 1 && tn == 1) GI_PICK(1, 1);
     if (tm == 1 && tn == 2) GI_PICK(1, 2);
     GI_PICK(2, 2);
 #undef GI_PICK
 #undef GI_PICK2
+#undef GI_PICK3
 }
 // the epilogue flags of a layout's own launch class (kernel template EPI = 1)
 static int own_epilogue(bool am, bool bm) {
@@ -674,10 +659,10 @@ static int own_epilogue(bool am, bool bm) {
 // (occupancy x CUs, from the runtime, cached per variant).  A launch with at least
 // GI_GEMM_PERSIST / 10 times that many tiles runs as that many workgroups walking the tile list
 // (stride = grid); smaller launches keep one workgroup per tile.  GI_GEMM_PERSIST=0 disables
-// (default 11: every launch that needs a second round of workgroups).
+// (default 0, see DESIGN.md: measured a tie on the device alone and a loss beside the weight-gradient stream).
 static int g_persist_tenths = -1, g_grid_cap = 0;
 static int persist_tenths() {
-    if (g_persist_tenths < 0) g_persist_tenths = getenv("GI_GEMM_PERSIST") ? atoi(getenv("GI_GEMM_PERSIST")) : 11;
+    if (g_persist_tenths < 0) g_persist_tenths = getenv("GI_GEMM_PERSIST") ? atoi(getenv("GI_GEMM_PERSIST")) : 0;
     return g_persist_tenths;
 }
 // Measurement / test hook: persist_tenths >= 0 replaces the GI_GEMM_PERSIST threshold; grid_cap > 0 runs
@@ -710,19 +695,18 @@ static int launch_tiles(GemmBatch& b, double flops, hipStream_t st) {
     int epi = 1;                                        // every problem has the layout's own epilogue?
     for (int i = 0; i < b.n; ++i)
         if ((b.p[i].flags & ~GI_GEMM_SPLITK) != own_epilogue(am, bm)) epi = 0;
-    gi_tiles_fn fn = tiles_kernel(p0.tm, p0.tn, am, bm, epi);
     if (want_remap(b.total))
         for (int i = 0; i < b.n; ++i) b.p[i].flags |= 32;
     int grid = b.total;
-    const int pt = persist_tenths();
+    const int pt = epi ? persist_tenths() : 0;          // the tile stream exists for the compile-time epilogues only
     if (pt > 0) {
-        const int res = resident_blocks(fn, p0.tm, p0.tn, am, bm, epi);
+        const int res = resident_blocks(tiles_kernel(p0.tm, p0.tn, am, bm, epi, true), p0.tm, p0.tn, am, bm, epi);
         if ((long long)b.total * 10 >= (long long)res * pt) grid = res;
     }
-    if (g_grid_cap > 0 && grid > g_grid_cap) grid = g_grid_cap;
+    if (epi && g_grid_cap > 0 && grid > g_grid_cap) grid = g_grid_cap;
     GiProfScope prof(st, GI_PROF_GEMM, flops);
     log_launch(b.p, b.n, b.total, flops);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(tiles_kernel(p0.tm, p0.tn, am, bm, epi, grid < b.total), dim3(grid), dim3(256), 0, st, b);
     return gi_launch_status();
 }
 

@@ -308,18 +308,17 @@ def test_mlp_chain_64_row_blocks(monkeypatch, sizes, off):
     _chain_case(sizes, off, seed=64, two=True)
 
 
-@pytest.mark.skipif(os.environ.get("GI_TEST_EXPERIMENTAL") != "1",
-                    reason="GI_CHAIN_RING=2 is an experiment knob that has not run on hardware yet "
-                           "(set GI_TEST_EXPERIMENTAL=1 to try it)")
 @pytest.mark.parametrize("tile_rows", [None, 34])
 @pytest.mark.parametrize("sizes,off", [
     ((128, 250, 250, 250, 250, 128), [0, 600, 600, 777]),
     ((100, 250, 250, 100), [0, 33, 34, 131]),
     ((37, 256, 7, 130), [0, 70]),
 ])
-def test_mlp_chain_two_slot_ring_experiment(monkeypatch, tile_rows, sizes, off):
-    """gi_chain_kernel<BWD, 1, 2>: 32-row blocks with the two-slot weight ring (114 KB of LDS)."""
-    monkeypatch.setenv("GI_CHAIN_RING", "2")
+def test_mlp_chain_three_slot_ring(monkeypatch, tile_rows, sizes, off):
+    """gi_chain_kernel<BWD, 1, 3>: 32-row blocks with the three-slot weight ring (146 KB of LDS) — the default
+    until round 3, now the GI_CHAIN_RING=3 measurement knob (the two-slot ring, 114 KB, lets a GEMM workgroup
+    share the CU and is what every other chain test runs)."""
+    monkeypatch.setenv("GI_CHAIN_RING", "3")
     if tile_rows:
         monkeypatch.setenv("GI_CHAIN_TILE_ROWS", str(tile_rows))
     _chain_case(sizes, off, seed=2 + sum(sizes))
