@@ -28,8 +28,7 @@ Rank 0 prints one JSON line.  Besides the contract fields it carries
   forward_only  no_grad forward rate on the same batches
   cpu_baseline  the oracle (CPU restatement of the reference algorithm, kind "port") on the host
                 cores at their best thread count, same workload, bounded sample; N == 1 only
-config.fuse_flags = the GI_FUSE launch-count reductions in use (include/graphinvent_amd.h, default 15);
-config.pipeline_readout appears only with the opt-in GI_PIPELINE_READOUT=1 (one process).
+config.fuse_flags = the GI_FUSE launch-count reductions in use (include/graphinvent_amd.h, default 15).
 """
 import argparse
 import ctypes as C
@@ -54,7 +53,7 @@ from graphinvent_amd.loss import apd_kl_loss                 # noqa: E402
 BATCH = 1000
 N_BATCHES = 4                  # distinct resident minibatches cycled through
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PROFILE_DIR = "r02"            # profiles/<dir>/: rocprofv3 kernel stats + PMC passes of this command
+PROFILE_DIR = "r03"            # profiles/<dir>/: rocprofv3 kernel stats + PMC passes of this command
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
 
 
@@ -296,8 +295,6 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if os.environ.get("GI_BENCH_HIPRIO") == "1":      # measurement knob: the step on a high-priority stream
-        torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=-1))
     if args.probe_only:
         print(json.dumps({"aggregation_probe": seg_sum_hbm_probe(device)}), flush=True)
         return
@@ -348,8 +345,6 @@ def main():
     result["config"]["fuse_flags"] = int(lib.load().gi_fuse_flags())     # GI_FUSE_* variants in use
     # graph_compact's sizes: found on the host (counting phase one batch ahead) / read back behind the stream
     result["config"]["compact_readbacks_timed_steps"] = first_readbacks
-    if trainer.pipeline_readout:      # opt-in (GI_PIPELINE_READOUT=1): readout update under the next forward
-        result["config"]["pipeline_readout"] = True
     if args.backend != "nccl":
         result["config"]["backend"] = args.backend + " (control-flow smoke test, not a measurement)"
 
@@ -398,13 +393,12 @@ def main():
             R, Mm, H, P = S + 1, cfg["message_size"], cfg["hidden_node_features"], cfg["message_passes"]
             # algorithmic bytes of the segmented-sum LAUNCHES of this step (SURVEY.md §8d form: values
             # read through the index + index + offsets + output).  Pass 0 aggregates through the
-            # edge-count matrix (a GEMM) when the pass-0 rows are on; the backward sums that GI_FUSE folds
-            # into the dZ chain / the gate backward are no launches of their own.
+            # edge-count matrix (a GEMM) when the pass-0 rows are on; the d h scatter that GI_FUSE folds
+            # into the gate backward is no launch of its own.
             fuse = handle.gi_fuse_flags()
             Pm = P - 1 if D0 > 0 else P                       # passes that run on message rows
             seg_bytes += Pm * (E * Mm * 4 + E * 4 + (R + 1) * 4 + R * Mm * 4)             # aggregation
-            if not (fuse & lib.FUSE_CHAIN_DM):
-                seg_bytes += Pm * (E * Mm * 4 + E * 4 + (U + 1) * 4 + 2 * U * Mm * 4)     # its backward
+            seg_bytes += Pm * (E * Mm * 4 + E * 4 + (U + 1) * 4 + 2 * U * Mm * 4)         # its backward
             if not (fuse & lib.FUSE_DH_SCATTER):
                 seg_bytes += (P - 1) * (U * H * 4 + U * 4 + (R + 1) * 4 + 2 * R * H * 4)  # d h scatter
         trainer.step(*b)

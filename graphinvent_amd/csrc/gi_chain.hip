@@ -293,71 +293,7 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
     };
 
     // ---- prologue: the input rows -> LDS (zero beyond K0); then the first two weight tiles ----------
-    // Backward with seg_vals: the input rows are FORMED here — the backward of the aggregation onto message
-    // rows, d m_u = selu'(m_u) * sum over the row's CSR segment of seg_vals rows (gi_seg_sum_dselu, otherwise
-    // its own launch in front of this one) — written back to X (the last layer's weight gradient reads
-    // them) and to LDS.  A wave owns whole rows (row = wave + 8 i), so segment bounds and indices are
-    // wave-uniform; all offset loads, then all index loads, then all row loads are issued back to back
-    // (two segment entries per row up front; longer segments — rare — loop), sums in segment order
-    // like seg_sum_dselu_kernel: bit-identical results.
-    if (BWD && P.seg_vals != nullptr) {
-        const int c = 4 * (tid & 63);
-        const int K0 = P.layer[0].K;
-        float* const Xw = const_cast<float*>(P.X);
-        constexpr int NP = 4 * RB + 1, CHUNK = 5;
-#pragma unroll
-        for (int base = 0; base < NP; base += CHUNK) {
-            v4f w[CHUNK];
-#pragma unroll
-            for (int i = 0; i < CHUNK; ++i) w[i] = v4f{0.f, 0.f, 0.f, 0.f};
-            if (c < K0) {                                    // lanes beyond the input width only write zeros
-                int lo[CHUNK], cnt[CHUNK], e0[CHUNK], e1[CHUNK];
-                long long xrow[CHUNK];
-#pragma unroll
-                for (int i = 0; i < CHUNK; ++i) {
-                    const int lr = swid + 8 * (base + i);
-                    const bool live = (base + i < NP) && lr < nvalid;
-                    xrow[i] = (long long)r0 + (live ? lr : 0);
-                    lo[i] = P.seg_off[xrow[i]];
-                    cnt[i] = live ? P.seg_off[xrow[i] + 1] : 0;
-                }
-#pragma unroll
-                for (int i = 0; i < CHUNK; ++i) {
-                    lo[i] = __builtin_amdgcn_readfirstlane(lo[i]);
-                    cnt[i] = max(__builtin_amdgcn_readfirstlane(cnt[i]) - lo[i], 0);
-                    const int k0 = cnt[i] > 0 ? lo[i] : max(lo[i] - 1, 0);     // always a readable entry
-                    e0[i] = P.seg_idx[k0];
-                    e1[i] = P.seg_idx[cnt[i] > 1 ? lo[i] + 1 : k0];
-                }
-                v4f y[CHUNK], a0[CHUNK], a1[CHUNK];
-#pragma unroll
-                for (int i = 0; i < CHUNK; ++i) {
-                    y[i] = *(const v4f*)(Xw + xrow[i] * P.ldx + c);
-                    a0[i] = *(const v4f*)(P.seg_vals + (long long)e0[i] * P.ld_seg + c);
-                    a1[i] = *(const v4f*)(P.seg_vals + (long long)e1[i] * P.ld_seg + c);
-                }
-#pragma unroll
-                for (int i = 0; i < CHUNK; ++i) {
-                    const v4f zero = {0.f, 0.f, 0.f, 0.f};
-                    v4f acc = zero;
-                    acc += cnt[i] > 0 ? a0[i] : zero;
-                    acc += cnt[i] > 1 ? a1[i] : zero;        // (acc is never -0: + 0 leaves it unchanged)
-                    for (int k = 2; k < cnt[i]; ++k)
-                        acc += *(const v4f*)(P.seg_vals + (long long)P.seg_idx[lo[i] + k] * P.ld_seg + c);
-                    const v4f yy = y[i];
-                    w[i] = acc * v4f{gi_selu_grad(yy.x), gi_selu_grad(yy.y), gi_selu_grad(yy.z),
-                                     gi_selu_grad(yy.w)};
-                    if (base + i < NP && swid + 8 * (base + i) < nvalid)    // (rows beyond alias row r0)
-                        *(v4f*)(Xw + xrow[i] * P.ldx + c) = w[i];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < CHUNK; ++i)
-                if (base + i < NP) *(v4f*)&As[(swid + 8 * (base + i)) * CH_ALD + c] = w[i];
-        }
-        // the stores above are not part of the main loop's load counting: drained here, once
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
+    {
         const int mc4 = tid & 63, mrow = tid >> 6;
         const int K0 = P.layer[0].K, cmax = ((K0 + 3) & ~3) - 4;
         const int c = 4 * mc4;
@@ -482,11 +418,6 @@ int validate_chain(const gi_chain_params& p) {
     if (p.ngroups < 1 || p.ngroups > GI_MAX_GROUPS) return GI_EINVAL;
     if (p.ngroups > 1 && !p.grp_off) return GI_EINVAL;
     if (p.ldx < ((p.layer[0].K + 3) & ~3)) return GI_EINVAL;   // 16-byte reads end inside the row
-    if (p.seg_vals) {                       // input formed in place by the fused segmented sum (backward)
-        if (!p.backward || p.x_idx || !p.seg_idx || !p.seg_off) return GI_EINVAL;
-        if ((p.layer[0].K & 3) || (p.ldx & 3) || (p.ld_seg & 3) || p.ld_seg < p.layer[0].K) return GI_EINVAL;
-        if (((uintptr_t)p.X & 15) || ((uintptr_t)p.seg_vals & 15)) return GI_EINVAL;
-    }
     for (int l = 0; l < p.nlayers; ++l) {
         const gi_chain_layer& q = p.layer[l];
         if (q.K < 4 || q.N < 4 || q.K > GI_CHAIN_MAXW || q.N > GI_CHAIN_MAXW) return GI_ELIMIT;
@@ -537,6 +468,17 @@ extern "C" int gi_mlp_chain_pack(const gi_chain_params* chains, int nchains, voi
     return 0;
 }
 
+// Test / measurement hook (process-wide), see the header
+static struct { int tile_rows, rows64, ring; long long* trace; } g_chain_cfg = {0, -1, 2, nullptr};
+extern "C" int gi_mlp_chain_config(int tile_rows, int rows64, int ring, void* trace) {
+    if (ring != 2 && ring != 3) return GI_EINVAL;
+    g_chain_cfg.tile_rows = tile_rows > 0 ? tile_rows : 0;
+    g_chain_cfg.rows64 = rows64 < 0 ? -1 : (rows64 ? 1 : 0);
+    g_chain_cfg.ring = ring;
+    g_chain_cfg.trace = (long long*)trace;
+    return 0;
+}
+
 extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (!chains || nchains < 1 || nchains > 2) return GI_EINVAL;
@@ -555,7 +497,7 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
             if ((p.ngroups > 1 ? p.group_rows[g] : p.rows) < 0) return GI_EINVAL;
     }
     // Block height: 32 rows, or up to 32 + CH_XMAX when the taller blocks need one round of
-    // workgroups less on this chip (one workgroup per CU: 129 KB of LDS).  GI_CHAIN_XROWS=0: always 32.
+    // workgroups less on this chip (one workgroup per CU).
     auto blocks = [&](int h) {
         int n = 0;
         for (int c = 0; c < nchains; ++c)
@@ -569,18 +511,17 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return n;
     }();
-    static const bool xrows = !(getenv("GI_CHAIN_XROWS") && atoi(getenv("GI_CHAIN_XROWS")) == 0);
     int h = CH_ROWS;
     int rounds = gi_cdiv(blocks(CH_ROWS), ncu);
-    if (xrows && rounds > 1)
+    if (rounds > 1)
         for (int hh = CH_ROWS + 1; hh <= CH_ROWS + CH_XMAX; ++hh)
             if (gi_cdiv(blocks(hh), ncu) < rounds) { h = hh; rounds = gi_cdiv(blocks(hh), ncu); break; }
     // 64-row workgroups (two MFMA row blocks, <2, 2>: half the weight stream per row) when they need fewer
     // rounds AND the weight images of the launch do not fit one XCD's 4 MB L2 — AttentionGGNN's two stacks
     // in one launch: 6.9 MB, ChEMBL shape B=250 3.95 -> 3.81 ms per step.  A single stack (3.5 MB) streams
     // from L2 fast enough that the 32-row blocks' three full rounds tie with two rounds of 64-row blocks
-    // (ZINC shape: 4.92 vs 4.98 ms; tools/ab/ab_run38.sh).
-    const int rows64 = getenv("GI_CHAIN_ROWS64") ? atoi(getenv("GI_CHAIN_ROWS64")) : -1;   // -1 auto, 0 / 1 forced
+    // (ZINC shape: 4.92 vs 4.98 ms; forced everywhere in round 3: headline 2.46 against 2.31 ms).
+    const int rows64 = g_chain_cfg.rows64;                 // -1 auto, 0 / 1 forced (gi_mlp_chain_config)
     bool big = rows64 > 0;
     if (rows64 < 0) {
         long long image_bytes = 0;
@@ -588,8 +529,8 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
             image_bytes += (long long)chains[c].ngroups * chain_tiles(chains[c]) * CH_TILE * 4;
         big = image_bytes > (4LL << 20) && 1.15 * gi_cdiv(blocks(2 * CH_ROWS), ncu) < 0.9 * rounds;
     }
-    if (const char* e = getenv("GI_CHAIN_TILE_ROWS")) {        // tests / measurements: force a height
-        h = std::min(std::max(atoi(e), CH_ROWS), CH_ROWS + CH_XMAX);
+    if (g_chain_cfg.tile_rows > 0) {                        // tests / measurements: force a height
+        h = std::min(std::max(g_chain_cfg.tile_rows, CH_ROWS), CH_ROWS + CH_XMAX);
         big = false;
     }
     if (big) h = 2 * CH_ROWS;
@@ -612,8 +553,7 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
     if (nchains == 1) a.chain_off[2] = total;
     a.nchains = nchains;
     if (total == 0) return 0;
-    // GI_CHAIN_TRACE=<address of a device buffer of 16 * total int64>: per-workgroup timestamps
-    a.trace = getenv("GI_CHAIN_TRACE") ? (long long*)strtoull(getenv("GI_CHAIN_TRACE"), nullptr, 0) : nullptr;
+    a.trace = g_chain_cfg.trace;                            // per-workgroup timestamps (tools/trace_chain.py)
     hipStream_t st = (hipStream_t)stream;
     GiProfScope prof(st, GI_PROF_GEMM, flops);
     const dim3 grid(total), block(512);
@@ -622,8 +562,8 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
     // weight-gradient stream needs to overlap with the chains (every overlap schedule of round 2 was bounded by
     // chain workgroups owning their CU).  One weight tile of look-ahead less costs nothing measurable alone;
     // the step gains 1.6 % (headline 2.312 / 2.332 -> 2.277 / 2.295 ms, ZINC shape 5.044 -> 4.957, ChEMBL shape
-    // 3.854 -> 3.813; profiles/r03/chain_ring_ab.txt).  GI_CHAIN_RING=3: the three-slot ring (measurements).
-    const bool ring2 = !big && !(getenv("GI_CHAIN_RING") && atoi(getenv("GI_CHAIN_RING")) == 3);
+    // 3.854 -> 3.813; profiles/r03/chain_ring_ab.txt).  gi_mlp_chain_config(ring = 3): the three-slot ring.
+    const bool ring2 = !big && g_chain_cfg.ring != 3;
     if (big) {
         if (chains[0].backward) hipLaunchKernelGGL((gi_chain_kernel<true, 2, 2>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((gi_chain_kernel<false, 2, 2>), grid, block, 0, st, a);

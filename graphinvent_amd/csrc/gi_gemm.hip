@@ -546,11 +546,8 @@ __global__ __launch_bounds__(256) void gi_gemm_tiles_kernel(const GemmBatch b) {
 // full rounds of 256 CUs x 4 resident workgroups.  Measured on the training step (3 A/B pairs):
 // never 2.74 ms, always 2.76-2.77 ms, >= 1300..2100 workgroups 2.70-2.71 ms.  The small launches lose
 // with the remap (an XCD's share of a 1-round launch is not balanced), the big ones win (column tiles
-// sharing an A row panel hit one L2).  GI_GEMM_XCD_REMAP=<min workgroups> overrides (measurements).
-static int remap_min_blocks() {
-    static const int v = getenv("GI_GEMM_XCD_REMAP") ? atoi(getenv("GI_GEMM_XCD_REMAP")) : 1350;
-    return v;
-}
+// sharing an A row panel hit one L2).
+static int remap_min_blocks() { return 1350; }
 static bool want_remap(long long blocks) {
     const int m = remap_min_blocks();
     return m > 0 && blocks >= m;

@@ -85,40 +85,6 @@ int build_model(const gi_ggnn_dims* dp, Model& m) {
     return 0;
 }
 
-// ---- transposed weight copies -------------------------------------------------------------------
-// dgrad multiplies by W[n_out][n_in] along n_out: with the row-major weight that is the GEMM's
-// "major" B layout (four ds_read_b32 per fragment, 5-10 % slower per launch than the forward's
-// contiguous-k operand, tools/experiments/dgrad_vs_fwd.py).  A copy WT[n_in][r4(n_out)] of every
-// weight matrix, refreshed once per training step on the idle side stream during the forward, lets
-// every dgrad run as a forward-type GEMM.
-struct WShape { int n_out, n_in; };
-
-int weight_shapes(const Model& m, WShape* ws) {       // indexed by parameter index; biases get {0,0}
-    for (int i = 0; i < m.nparams; ++i) ws[i] = WShape{0, 0};
-    auto mlp = [&](const Mlp& q) {
-        for (int l = 0; l < q.layers(); ++l) ws[q.w(l)] = WShape{q.fan_out(l), q.fan_in(l)};
-    };
-    const gi_ggnn_dims& d = m.d;
-    for (int t = 0; t < d.Fe; ++t) mlp(m.msg[t]);
-    if (d.kind == GI_KIND_ATTGGNN)
-        for (int t = 0; t < d.Fe; ++t) mlp(m.eatt[t]);
-    ws[m.gru_wih] = WShape{3 * d.H, d.M};
-    ws[m.gru_whh] = WShape{3 * d.H, d.H};
-    mlp(m.att); mlp(m.emb); mlp(m.add1); mlp(m.conn1); mlp(m.add2); mlp(m.conn2); mlp(m.term2);
-    return m.nparams;
-}
-
-long long wt_layout(const Model& m, long long* off) {
-    WShape ws[160];
-    weight_shapes(m, ws);
-    long long o = 0;
-    for (int i = 0; i < m.nparams; ++i) {
-        off[i] = o;
-        if (ws[i].n_out) o += gi_r4l((long long)ws[i].n_in * gi_r4(ws[i].n_out));
-    }
-    return o;
-}
-
 // ---- workspace --------------------------------------------------------------------------------
 struct Ws {
     int R, E, U, D0, B;
@@ -142,7 +108,6 @@ struct Ws {
     // packed weight images of the resident-activation chains (gi_chain.hip): [msg, energy] stacks,
     // forward and backward layouts; 0 floats when the stack does not fit the chain kernel
     long long img_f[2], img_b[2], img_f_n[2], img_b_n[2], img_b_stride[2];
-    long long gru_img;                 // packed W_ih | W_hh image of the fused GRU kernel (-1: not fused)
     // AlphaDropout training mode: the workspace is allocated twice; float i of the second half holds
     // the backward factor d y / d z of activation i of the first (0: mode off)
     long long fshift;
@@ -256,9 +221,6 @@ void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
         w.skinny_floats = need;
         w.skinny = take(std::max(need, 4LL), 1);
     }
-    w.gru_img = -1;
-    if (d.passes > 0 && !d.dropout && gi_gru_image_floats(d.H, d.M) > 0)
-        w.gru_img = take(gi_gru_image_floats(d.H, d.M), 1);
     for (int k = 0; k < (attn ? 2 : 1); ++k) {
         const Mlp& q = k ? m.eatt[0] : m.msg[0];
         if (d.passes > 0 && !d.dropout && chain_fits(q, d.H)) {   // (dropout: layer by layer)
@@ -277,17 +239,7 @@ struct SlabEntry { long long off, stride; int nsplit, calls, done, n_out, n_in, 
 struct SlabPlan {
     SlabEntry e[160];
     long long total;
-    // in-kernel slab reduction (GI_GEMM_REDUCE): arrival counters behind the slabs, one int per output
-    // tile of every weight-gradient problem of the backward; count_next = next free counter
-    long long count_off; int count_ints, count_next;
 };
-
-// Weight-gradient slabs summed by the last workgroup of each output tile inside the GEMM
-// (GI_GEMM_REDUCE) instead of by gi_reduce_slabs launches behind every batch.  GI_WGRAD_REDUCE=0/1.
-bool wgrad_reduce_in_kernel() {
-    static const bool v = getenv("GI_WGRAD_REDUCE") && atoi(getenv("GI_WGRAD_REDUCE")) != 0;
-    return v;
-}
 
 // wgrad launch shape: 64x64 output tiles.  Weight-gradient GEMMs are deferred and launched in
 // batches of up to 8 problems, so ONE problem only needs ~256 workgroups (x its share of a
@@ -298,15 +250,11 @@ void wgrad_shape(int n_out, int n_in, int red_rows, double share, int& tn, int& 
     tn = 1;
     const int tiles = gi_cdiv(n_out, 64) * gi_cdiv(n_in + 1, 64);
     const int kt = gi_cdiv(std::max(red_rows, 1), 32);
-    // workgroups per problem (GI_WGRAD_WGS, measurements): 96 -> 2.44-2.51 ms per step, 128 -> 2.39-2.40,
-    // 192 -> 2.34-2.35, 256 -> 2.37, 384 -> 2.40-2.41 (tools/ab/ab_run28.sh)
-    static const double wgs = getenv("GI_WGRAD_WGS") ? atof(getenv("GI_WGRAD_WGS")) : 192.0;
+    // workgroups per problem, measured in round 2: 96 -> 2.44-2.51 ms per step, 128 -> 2.39-2.40,
+    // 192 -> 2.34-2.35, 256 -> 2.37, 384 -> 2.40-2.41
+    const double wgs = 192.0;
     const int want = (int)(wgs * share / tiles + 0.5);
     nsplit = std::min(std::max(want, 1), std::max(1, kt / 2));
-}
-
-int entry_tiles(const SlabEntry& e) {                 // output tiles of one weight-gradient problem
-    return gi_cdiv(e.n_out, 64 * e.tn) * gi_cdiv(e.n_in + 1, 64 * e.tn);
 }
 
 void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {   // E, Et: message rows
@@ -339,14 +287,7 @@ void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {   /
     add(m.gru_whh, m.gru_bhh, 3 * d.H, d.H, R, d.passes, 1.0);
     add_mlp(m.att, R, 1); add_mlp(m.emb, R, 1); add_mlp(m.add1, R, 1); add_mlp(m.conn1, R, 1);
     add_mlp(m.add2, d.B, 1); add_mlp(m.conn2, d.B, 1); add_mlp(m.term2, d.B, 1);
-    // arrival counters: calls x output tiles per weight
-    long long ints = 0;
-    for (int i = 0; i < 160; ++i)
-        if (sp.e[i].calls > 0) ints += (long long)sp.e[i].calls * entry_tiles(sp.e[i]);
-    sp.count_off = gi_r4l(o);
-    sp.count_ints = (int)ints;
-    sp.count_next = 0;
-    sp.total = sp.count_off + gi_r4l(ints);
+    sp.total = o;
 }
 
 // ---- launch helpers -----------------------------------------------------------------------------
@@ -359,8 +300,6 @@ struct Run {
     const float* const* P;
     int rc;
     SideStream* side = nullptr;    // optional second stream for the weight-gradient GEMMs
-    const float* wt = nullptr;     // optional transposed weight copies [n_in][r4(n_out)] (dgrad operand)
-    const long long* wt_off = nullptr;
     float* img_f[2] = {nullptr, nullptr};   // packed chain weight images [msg, energy stack]; null: the
     float* img_b[2] = {nullptr, nullptr};   // stack runs layer by layer
     long long img_b_stride[2] = {0, 0};
@@ -432,10 +371,10 @@ void linear_fwd(Run& r, const Mlp* mlps, int l, const Grp& g, const float* X, in
     r.chk(gi_gemm(&p, r.st));
 }
 
-// dX[rows, ncols] (+)= (dZ[rows, n_out] W[n_out, n_in][:, :ncols]) (* selu'(act))
-// the B operand of a dgrad: the transposed copy (contiguous k) when there is one, else W itself
+// dX[rows, ncols] (+)= (dZ[rows, n_out] W[n_out, n_in][:, :ncols]) (* selu'(act)); W itself is the B operand
+// (reduction-major: the GEMM's "major" layout)
 const float* dgrad_operand(const Run& r, int widx, int n_out, int n_in, gi_gemm_params& p) {
-    if (r.wt) { p.ldb = gi_r4(n_out); p.b_major = 0; return r.wt + r.wt_off[widx]; }
+    (void)n_out;
     p.ldb = n_in; p.b_major = 1;
     return r.P[widx];
 }
@@ -580,17 +519,8 @@ void add_dgrad(Batch& b, Run& r, int widx, int n_out, int n_in, int ncols, const
 
 void flush_deferred(Run& r, Deferred& q);
 void kick_deferred(Run& r, Deferred& q, SideStream* side, bool all);
-void kick_inline(Run& r, Deferred& q, bool all);
-int wgrad_inline();
-// Measurement knob GI_WGRAD_KICK=<1..8> (default 8): queued weight-gradient problems that make up one hand-over
-// to the side stream (one launch of up to 8 problems): smaller = earlier, shorter side-stream launches.
-int wgrad_kick_n() {
-    static const int v = [] {
-        const int x = getenv("GI_WGRAD_KICK") ? atoi(getenv("GI_WGRAD_KICK")) : 8;
-        return x < 1 ? 1 : (x > 8 ? 8 : x);
-    }();
-    return v;
-}
+// queued weight-gradient problems that make up one hand-over to the side stream (one launch)
+constexpr int wgrad_kick_n() { return 8; }
 
 gi_reduce_desc reduce_desc(const SlabEntry& e, float* slabs, float* const* grads, int widx) {
     gi_reduce_desc q;
@@ -613,26 +543,12 @@ void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* wid
     p.nsplit = e0.nsplit; p.c_split_stride = e0.stride;
     p.tm = e0.tn; p.tn = e0.tn;                 // 1x1 (64x64 tiles) or 2x2 (128x128), see wgrad_shape
     const int slot = q.n - 1;
-    if (wgrad_reduce_in_kernel()) {
-        // the last workgroup of every output tile sums the tile's slabs into the gradient itself;
-        // later calls for the same weight (message passes) add to it — in launch order, which is why
-        // two calls for one weight never share a launch (launch_wgrad_batches)
-        const int tiles = entry_tiles(e0);
-        p.flags |= GI_GEMM_REDUCE;
-        p.red_count = reinterpret_cast<int*>(slabs + sp.count_off) + sp.count_next;
-        sp.count_next += tiles * std::max(g.n, 1);
-        p.red_ldw = e0.n_in;
-        p.red_accum = e0.done > 0 ? 1 : 0;
-        p.red_dW = r.grads[widx[0]];
-        p.red_db = r.grads[e0.bidx];
-    }
     if (g.n) {
         p.ngroups = g.n; p.grp_off = g.off;
         for (int t = 0; t < g.n; ++t) {
             SlabEntry& e = sp.e[widx[t]];
             p.Cg[t] = slabs + e.off + (long long)e.done * e.nsplit * e.stride;
             p.gsplit[t] = e.nsplit;
-            if (p.flags & GI_GEMM_REDUCE) { p.Bg[t] = r.grads[widx[t]]; p.biasg[t] = r.grads[e.bidx]; }
             e.done++;
             q.widx[slot][t] = widx[t];
         }
@@ -658,31 +574,9 @@ void launch_wgrad_batch(Run& r, const gi_gemm_params* p, int n, hipStream_t st) 
     if (nb && r.ok()) r.chk(gi_gemm_batch(b, nb, st));
 }
 
-// consecutive queued problems, up to 8 per launch; with the in-kernel reduction two problems that write
-// the same gradient (the same weight in two message passes) never share a launch — the later one adds
-// to what the earlier one wrote
+// consecutive queued problems, up to 8 per launch
 void launch_wgrad_batches(Run& r, const gi_gemm_params* p, int n, hipStream_t st) {
-    int base = 0;
-    while (base < n && r.ok()) {
-        const float* seen[8 * GI_MAX_GROUPS];
-        int cnt = 0, ns = 0;
-        while (base + cnt < n && cnt < 8) {
-            const gi_gemm_params& q = p[base + cnt];
-            if (q.flags & GI_GEMM_REDUCE) {
-                const int ng = std::max(q.ngroups, 1);
-                bool dup = false;
-                for (int t = 0; t < ng && !dup; ++t) {
-                    const float* d = q.ngroups ? q.Bg[t] : q.red_dW;
-                    for (int i = 0; i < ns && !dup; ++i) dup = seen[i] == d;
-                }
-                if (dup) break;                       // (cnt > 0: nothing has been seen before the first)
-                for (int t = 0; t < ng; ++t) seen[ns++] = q.ngroups ? q.Bg[t] : q.red_dW;
-            }
-            ++cnt;
-        }
-        launch_wgrad_batch(r, p + base, cnt, st);
-        base += cnt;
-    }
+    for (int base = 0; base < n && r.ok(); base += 8) launch_wgrad_batch(r, p + base, std::min(8, n - base), st);
 }
 
 void flush_deferred(Run& r, Deferred& q) {
@@ -730,16 +624,14 @@ void kick_deferred(Run& r, Deferred& q, SideStream* side, bool all) {
     launch_wgrad_batches(r, q.p, n, side->st);
     // parameters whose last slab has just been queued: reduce them right behind, on the side stream
     // too, so that only the final pass's gradients are left for the end of the backward
-    // (nothing to launch when the GEMM reduced its own slabs)
     gi_reduce_desc descs[96 * GI_MAX_GROUPS > 160 ? 160 : 96 * GI_MAX_GROUPS];
     int nd = 0;
-    const bool in_kernel = wgrad_reduce_in_kernel();
     for (int i = 0; i < n; ++i)
         for (int k = 0; k < q.nw[i]; ++k) {
             SlabEntry& e = r.sp->e[q.widx[i][k]];
             if (++e.launched == e.calls && !e.reduced && nd < 160) {
                 e.reduced = 1;
-                if (!in_kernel) descs[nd++] = reduce_desc(e, r.slabs, r.grads, q.widx[i][k]);
+                descs[nd++] = reduce_desc(e, r.slabs, r.grads, q.widx[i][k]);
             }
         }
     if (nd && r.ok()) r.chk(gi_reduce_slabs(descs, nd, side->st));
@@ -749,44 +641,6 @@ void kick_deferred(Run& r, Deferred& q, SideStream* side, bool all) {
         for (int k = 0; k < q.nw[i]; ++k) q.widx[i - n][k] = q.widx[i][k];
     }
     q.n -= n;
-}
-
-// The same bookkeeping with the launches on the MAIN stream (no events needed): every complete batch of
-// 8 queued problems (all of them when `all`), then the slab reduction of every parameter that is finished.
-// Used by the GI_WGRAD_INLINE schedules below.
-void kick_inline(Run& r, Deferred& q, bool all) {
-    if (!r.ok()) return;
-    const int n = all ? q.n : (q.n / 8) * 8;
-    if (n == 0) return;
-    launch_wgrad_batches(r, q.p, n, r.st);
-    gi_reduce_desc descs[96 * GI_MAX_GROUPS > 160 ? 160 : 96 * GI_MAX_GROUPS];
-    int nd = 0;
-    const bool in_kernel = wgrad_reduce_in_kernel();
-    for (int i = 0; i < n; ++i)
-        for (int k = 0; k < q.nw[i]; ++k) {
-            SlabEntry& e = r.sp->e[q.widx[i][k]];
-            if (++e.launched == e.calls && !e.reduced && nd < 160) {
-                e.reduced = 1;
-                if (!in_kernel) descs[nd++] = reduce_desc(e, r.slabs, r.grads, q.widx[i][k]);
-            }
-        }
-    if (nd && r.ok()) r.chk(gi_reduce_slabs(descs, nd, r.st));
-    for (int i = n; i < q.n; ++i) {
-        q.p[i - n] = q.p[i];
-        q.nw[i - n] = q.nw[i];
-        for (int k = 0; k < q.nw[i]; ++k) q.widx[i - n][k] = q.widx[i][k];
-    }
-    q.n -= n;
-}
-
-// Measurement knob GI_WGRAD_INLINE (bit mask, default 0): weight-gradient batches that are NOT handed to
-// the side stream but run on the main stream where they are queued.  Bit 0: the node-level readout stacks'
-// (20 problems with the longest reductions: on the side stream they are still running when the message
-// passes' dZ-chain launches arrive, and a chain workgroup needs a CU free of their workgroups — 145 KB of
-// LDS); bit 1: the graph-level stacks' as well.
-int wgrad_inline() {
-    static const int v = getenv("GI_WGRAD_INLINE") ? atoi(getenv("GI_WGRAD_INLINE")) : 0;
-    return v;
 }
 
 void join_side(Run& r, SideStream* side) {
@@ -864,33 +718,11 @@ void defer_stack_wgrads(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred&
 
 void join_side(Run& r, SideStream* side);
 
-// Measurement knob (GI_CHAIN_EXCLUSIVE=1, off by default): the dZ-chain kernel wants every CU to itself
-// (one workgroup per CU, 144 KB of LDS); beside a weight-gradient batch of the side stream its
-// workgroups wait for whole CUs to drain and both launches stretch (traced: 207 + 215 us overlapped
-// against 70 + 127 us apart).  Letting the main stream wait for the side stream before each chain
-// and holding new batches back until the chain is queued raises the per-launch efficiency (GEMM-family
-// 0.29 -> 0.30 of peak) but the step gets SLOWER, 2.56 -> 2.66 ms: the idle wait costs more than the
-// stretched overlap.  Kept as a knob, not as the default.
-void chain_bwd_exclusive(Run& r) {
-    static const bool on = getenv("GI_CHAIN_EXCLUSIVE") && atoi(getenv("GI_CHAIN_EXCLUSIVE")) != 0;
-    if (on && r.side) join_side(r, r.side);
-}
-
 // The bond-type-grouped message MLP: dZ chain now, weight gradients deferred.
 // Zlast of a message stack = selu'(m) * (segmented sum of `vals` rows over the message CSR), formed in
-// place over the stack's forward output: its own launch (gi_seg_sum_dselu_f), or — GI_FUSE_CHAIN_DM — inside
-// the dZ-chain launch that reads it (gi_chain_params.seg_vals)
+// place over the stack's forward output by its own launch (gi_seg_sum_dselu_f) in front of the dZ chain
+// (folding it into the chain launch was built and measured a tie in round 2: tools/experiments/README.md)
 struct SegIn { const float* vals; int ld; const int* idx; const int* off; };
-
-bool seg_fusable(const Run& r, const SegIn* seg, const Mlp& q, const float* Zlast, int ldz) {
-    return seg && seg->vals && !r.drop && (gi_fuse_flags() & GI_FUSE_CHAIN_DM) && (q.out & 3) == 0 &&
-           (ldz & 3) == 0 && (seg->ld & 3) == 0 && seg->ld >= q.out && !((uintptr_t)Zlast & 15) &&
-           !((uintptr_t)seg->vals & 15);
-}
-
-void seg_attach(gi_chain_params& c, const SegIn* seg) {
-    c.seg_vals = seg->vals; c.ld_seg = seg->ld; c.seg_idx = seg->idx; c.seg_off = seg->off;
-}
 
 void seg_launch(Run& r, const SegIn* seg, int rows, int cols, float* y, int ldy) {
     if (seg && seg->vals && r.ok())
@@ -905,17 +737,9 @@ void msg_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred& dq, c
     if (g.n && r.ok() && rows > 0 && r.img_b[mlps == r.eatt0 ? 1 : 0] && dx_cols == mlps[0].in &&
         ldz >= gi_r4(mlps[0].out)) {
         gi_chain_params c;                      // the whole dZ chain in one launch, then the wgrads
-        if (chain_bwd_params(c, r, ws, mlps, g, Zlast, ldz, rows, acts, dzs, ldh, dX, lddx, dx_cols)) {
-            if (seg_fusable(r, seg, mlps[0], Zlast, ldz)) {
-                seg_attach(c, seg);
-            } else {
-                seg_launch(r, seg, rows, mlps[0].out, const_cast<float*>(Zlast), ldz);
-            }
-            chain_bwd_exclusive(r);
+        seg_launch(r, seg, rows, mlps[0].out, const_cast<float*>(Zlast), ldz);
+        if (chain_bwd_params(c, r, ws, mlps, g, Zlast, ldz, rows, acts, dzs, ldh, dX, lddx, dx_cols))
             r.chk(gi_mlp_chain(&c, 1, r.st));
-        } else {
-            seg_launch(r, seg, rows, mlps[0].out, const_cast<float*>(Zlast), ldz);
-        }
         r.hold_kicks = false;
         defer_stack_wgrads(r, ws, sp, slabs, dq, mlps, g, X, ldx, a_idx, rows, acts, dzs, ldh, Zlast,
                            ldz);
@@ -1066,9 +890,7 @@ void defer_stack_wgrads(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred&
 // ---- AttGGNN: the message MLP and the energy MLP of a pass are siblings (same input rows, same
 // bond-type grouping): layer l of both goes into one launch, like the readout's sibling stacks.
 struct SegIn;
-bool seg_fusable(const Run& r, const SegIn* seg, const Mlp& q, const float* Zlast, int ldz);
 void seg_launch(Run& r, const SegIn* seg, int rows, int cols, float* y, int ldy);
-void seg_attach(gi_chain_params& c, const SegIn* seg);
 
 struct EdgeChain {
     const Mlp* mlps;               // [Fe] per-bond-type stacks
@@ -1139,12 +961,8 @@ void edge_chains_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferre
         for (int j = 0; j < 2; ++j) {
             nl[j] = chain_bwd_params(c[j], r, ws, ch[j].mlps, g, ch[j].out, ch[j].ldout, rows,
                                      ch[j].acts, ch[j].dzs, ch[j].ldh, ch[j].dX, lddx, dx_cols);
-            if (nl[j] && seg_fusable(r, ch[j].seg, ch[j].mlps[0], ch[j].out, ch[j].ldout))
-                seg_attach(c[j], ch[j].seg);
-            else
-                seg_launch(r, ch[j].seg, rows, ch[j].mlps[0].out, ch[j].out, ch[j].ldout);
+            seg_launch(r, ch[j].seg, rows, ch[j].mlps[0].out, ch[j].out, ch[j].ldout);
         }
-        if (nl[0] || nl[1]) chain_bwd_exclusive(r);
         if (nl[0] && nl[1]) r.chk(gi_mlp_chain(c, 2, r.st));
         else if (nl[0]) r.chk(gi_mlp_chain(&c[0], 1, r.st));
         else if (nl[1]) r.chk(gi_mlp_chain(&c[1], 1, r.st));
@@ -1293,12 +1111,6 @@ static int dropout_graph_ok(const gi_ggnn_dims& d, int S, int E, int U, int D0) 
 
 extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* params,
                                const gi_graph* gp, float* ws, float* out, int ldout, void* stream) {
-    return gi_ggnn_forward_ex(dp, params, gp, ws, out, ldout, stream, nullptr);
-}
-
-extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* params,
-                                  const gi_graph* gp, float* ws, float* out, int ldout, void* stream,
-                                  void* readout_ready) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     Model m;
     int rc = build_model(dp, m);
@@ -1345,23 +1157,9 @@ extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* pa
                 chain_pack(r, k ? m.eatt : m.msg, d.Fe, false, r.img_f[k]);
             }
     // ---- message passes (gnn/summation_mpnn.py:128-144) ----------------------------------------
-    // Off by default: measured on the headline batch (tools/trace_chain.py, bench A/B) the fused launch
-    // takes 39.7 us (prologue 5, weight stream + MFMAs 21, gate epilogue 5; one wave per SIMD on 229
-    // workgroups) against ~35 us for seg_sum + the batched projection GEMM (1380 short workgroups, 4 per
-    // CU) + the gate kernel it replaces, and the training step loses 60 us with it.  GI_GRU_FUSED=1.
-    static const bool gru_env = getenv("GI_GRU_FUSED") && atoi(getenv("GI_GRU_FUSED")) != 0;
-    const bool gru_fused = gru_env && w.gru_img >= 0;
-    if (gru_fused && r.ok()) {          // packed GRU weight image, once per forward
-        gi_gru_params q;
-        memset(&q, 0, sizeof(q));
-        q.W_ih = params[m.gru_wih]; q.W_hh = params[m.gru_whh]; q.H = d.H; q.M = d.M;
-        q.image = ws + w.gru_img;
-        r.chk(gi_gru_pack(&q, r.st));
-    }
     for (int p = 0; p < d.passes; ++p) {
         const float* hx = ws + w.hx[p];
         r.pass = p;
-        int agg_ready = 1;               // the aggregate is in ws + w.agg[p] before the GRU launch
         if (attn) {
             // AttentionGGNN.aggregate_message (gnn/mpnn.py:370-389): message and energy MLPs of the
             // edge's bond type on h_src(e), softmax over each node's incoming edges, weighted sum
@@ -1393,28 +1191,10 @@ extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* pa
             if (E > 0)   // m_u = MLP_type(u)(h_src(u)), gnn/mpnn.py:284-294, once per message row
                 mlp_forward(r, ws, m.msg, bytype, hx, w.ldhx, u_src, U, w.eact[p], w.ldEh,
                             ws + w.m[p], w.ldM);
-            // a_v = sum of incoming messages (:141) — inside the fused GRU launch when there is one
-            if (gru_fused && E > 0) agg_ready = 0;
-            else
-                r.chk(gi_seg_sum(ws + w.m[p], w.ldM, in_perm, seg_off, R, d.M, ws + w.agg[p], w.ldM,
-                                 0, r.st));
+            // a_v = sum of incoming messages (:141)
+            r.chk(gi_seg_sum(ws + w.m[p], w.ldM, in_perm, seg_off, R, d.M, ws + w.agg[p], w.ldM, 0, r.st));
         }
-        // GRU update (gnn/mpnn.py:296-297): aggregation (when it is a plain segmented sum), both
-        // projections and the gates in one launch when the widths fit (gi_gru.hip) ...
-        if (gru_fused) {
-            gi_gru_params q;
-            memset(&q, 0, sizeof(q));
-            q.m = ws + w.m[p]; q.ldm = w.ldM; q.in_perm = in_perm; q.seg_off = seg_off;
-            q.agg = ws + w.agg[p]; q.ldagg = w.ldM; q.agg_ready = agg_ready;
-            q.hx_prev = hx; q.hx_new = ws + w.hx[p + 1]; q.ldhx = w.ldhx;
-            q.W_ih = params[m.gru_wih]; q.W_hh = params[m.gru_whh];
-            q.b_ih = params[m.gru_bih]; q.b_hh = params[m.gru_bhh];
-            q.gi = ws + w.gi[p]; q.gh = ws + w.gh[p]; q.ldg = w.ld3H;
-            q.R = R; q.H = d.H; q.M = d.M; q.image = ws + w.gru_img;
-            r.chk(gi_gru_fused_fwd(&q, r.st));
-            continue;
-        }
-        // ... else both input projections in one launch, then the gate kernel
+        // GRU update (gnn/mpnn.py:296-297): both input projections in one launch, then the gate kernel
         {
             Batch b;
             add_fwd(b, r, params[m.gru_wih], params[m.gru_bih], d.M, 3 * d.H, ws + w.agg[p], w.ldM, R,
@@ -1427,9 +1207,6 @@ extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* pa
                                seg_off, R, d.H, d.Fn, r.st));
     }
     // ---- readout (gnn/mpnn.py:299-303) -----------------------------------------------------------
-    // Pipelined readout update (gi_ggnn_backward_ex): the previous step's Adam over the readout parameters
-    // may still be running on another stream — the message passes above never read them, the readout does.
-    if (readout_ready) r.chk((int)hipStreamWaitEvent(r.st, (hipEvent_t)readout_ready, 0));
     const float* hx = ws + w.hx[d.passes];
     {   // the four node-level stacks, layer by layer in shared launches
         MlpJob jobs[4] = {};
@@ -1474,52 +1251,14 @@ extern "C" int gi_ggnn_backward(const gi_ggnn_dims* dp, const float* const* para
                                 int ldout, const float* d_out, int lddout, float* const* grads,
                                 void* stream, void* side_stream) {
     return gi_ggnn_backward_phase(dp, params, gp, ws, slabs, y_out, ldout, d_out, lddout, grads,
-                                  stream, side_stream, GI_BWD_ALL, nullptr);
-}
-
-extern "C" long long gi_ggnn_wt_floats(const gi_ggnn_dims* d) {
-    Model m;
-    if (build_model(d, m) || m.nparams > 160) return GI_EINVAL;
-    long long off[160];
-    return wt_layout(m, off);
-}
-
-extern "C" int gi_ggnn_transpose_weights(const gi_ggnn_dims* d, const float* const* params,
-                                         float* wt, void* stream) {
-    (void)hipGetLastError();
-    Model m;
-    const int rc = build_model(d, m);
-    if (rc) return rc;
-    if (!params || !wt || m.nparams > 160) return GI_EINVAL;
-    long long off[160];
-    wt_layout(m, off);
-    WShape shp[160];
-    weight_shapes(m, shp);
-    gi_transpose_desc descs[160];
-    int n = 0;
-    for (int i = 0; i < m.nparams; ++i)
-        if (shp[i].n_out)
-            descs[n++] = gi_transpose_desc{params[i], wt + off[i], shp[i].n_out, shp[i].n_in,
-                                           gi_r4(shp[i].n_out)};
-    return gi_transpose_batch(descs, n, stream);
+                                  stream, side_stream, GI_BWD_ALL);
 }
 
 extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const* params,
                                       const gi_graph* gp, float* ws, float* slabs,
                                       const float* y_out, int ldout, const float* d_out, int lddout,
-                                      float* const* grads, void* stream, void* side_stream,
-                                      int phase, const float* wt) {
-    return gi_ggnn_backward_ex(dp, params, gp, ws, slabs, y_out, ldout, d_out, lddout, grads, stream,
-                               side_stream, nullptr, phase, wt);
-}
-
-extern "C" int gi_ggnn_backward_ex(const gi_ggnn_dims* dp, const float* const* params,
-                                   const gi_graph* gp, float* ws, float* slabs,
-                                   const float* y_out, int ldout, const float* d_out, int lddout,
-                                   float* const* grads, void* stream, void* side_stream,
-                                   void* readout_stream, int phase, const float* wt) {
+                                      float* const* grads, void* stream, void* side_stream, int phase) {
     if (phase != GI_BWD_ALL && phase != GI_BWD_READOUT && phase != GI_BWD_PASSES) return GI_EINVAL;
-    if (readout_stream && phase != GI_BWD_ALL) return GI_EINVAL;
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     Model m;
     int rc = build_model(dp, m);
@@ -1571,16 +1310,9 @@ extern "C" int gi_ggnn_backward_ex(const gi_ggnn_dims* dp, const float* const* p
 
     Deferred dq;
     SideStream side_obj{(hipStream_t)side_stream, 0};
-    // Pipelined readout update: the readout's weight gradients and their slab reductions go to a THIRD
-    // stream that `stream` never waits for — the caller runs Adam over the readout parameters there and
-    // hands the event behind it to the next gi_ggnn_forward_ex.  (Its events come from the second half
-    // of the pool: both helper streams record on the main stream independently.)
-    SideStream ro_obj{(hipStream_t)readout_stream, SideStream::NEV / 2};
     SideStream* const passes_side = side_stream ? &side_obj : nullptr;
-    r.side = readout_stream ? &ro_obj : passes_side;
+    r.side = passes_side;
     r.sp = &sp; r.slabs = slabs; r.grads = grads;
-    long long wt_off[160];
-    if (wt) { wt_layout(m, wt_off); r.wt = wt; r.wt_off = wt_off; }
     const Grp none{0, nullptr, 0};
     const float* hxP = ws + w.hx[d.passes];
     float* dh = ws + w.dh;
@@ -1594,12 +1326,7 @@ extern "C" int gi_ggnn_backward_ex(const gi_ggnn_dims* dp, const float* const* p
             for (int l = 0; l < q->layers(); ++l) fn(q->w(l));
     };
     if (phase == GI_BWD_PASSES)          // the readout half ran (and was reduced) in an earlier call
-        readout_params([&](int widx) {
-            sp.e[widx].reduced = 1;
-            sp.count_next += sp.e[widx].calls * entry_tiles(sp.e[widx]);   // its arrival counters are spent
-        });
-    else if (wgrad_reduce_in_kernel() && sp.count_ints > 0)
-        r.chk((int)hipMemsetAsync(slabs + sp.count_off, 0, sizeof(int) * sp.count_ints, r.st));
+        readout_params([&](int widx) { sp.e[widx].reduced = 1; });
     if (phase != GI_BWD_PASSES) {
     // ---- tier 2 (gnn/modules.py:265-279) ---------------------------------------------------------
     if (gi_fuse_flags() & GI_FUSE_TIER2_DSELU) {
@@ -1621,10 +1348,7 @@ extern "C" int gi_ggnn_backward_ex(const gi_ggnn_dims* dp, const float* const* p
                    w.conn2_dz, ws + w.dzC, w.ldNC, ws + w.dcat_conn, w.ldCC, NC + d.G, false};
         jobs[2] = {&m.term2, ws + w.gemb, w.ldG, d.B, w.term2_act, w.ldM2, nullptr, 0, w.term2_dz,
                    ws + w.dzT, 4, ws + w.dgemb, w.ldG, d.G, false};
-        const bool inl = r.side && (wgrad_inline() & 2);
-        if (inl) r.hold_kicks = true;
         mlp_jobs_backward(r, ws, sp, slabs, dq, jobs, 3);
-        if (inl) { r.hold_kicks = false; kick_inline(r, dq, true); }
     }
     // ---- gather + tier-1 glue: dZ of the last att/emb/add1/conn1 layers, in place ----------------
     r.chk(gi_gather_readout_bwd_f(ws + w.en, ws + w.embo, w.ldG, cidx, mask, d.B, d.N, d.G, S,
@@ -1665,30 +1389,19 @@ extern "C" int gi_ggnn_backward_ex(const gi_ggnn_dims* dp, const float* const* p
                    dhd, w.ldH, d.H, false};
         // No weight-gradient batches beside the node-level dgrad launches: those fill the device by
         // themselves (2 760 workgroups each at the headline batch), two streams only contend there;
-        // everything queued goes out behind them, under the message passes' short launches.  Step
-        // 2.362 -> 2.344 ms, GEMM-family per-launch figure 0.349 -> 0.374 of peak (GI_HOLD_NODE_WGRADS=0
-        // restores the old schedule).
-        static const bool hold = !(getenv("GI_HOLD_NODE_WGRADS") && atoi(getenv("GI_HOLD_NODE_WGRADS")) == 0);
-        const bool inl = r.side && (wgrad_inline() & 1);
-        r.hold_kicks = hold || inl;
+        // everything queued goes out behind them, under the message passes' short launches (round 2: step
+        // 2.362 -> 2.344 ms, GEMM-family per-launch figure 0.349 -> 0.374 of peak).
+        r.hold_kicks = true;
         mlp_jobs_backward(r, ws, sp, slabs, dq, jobs, 4);
         r.hold_kicks = false;
-        if (inl) kick_inline(r, dq, true);          // everything queued so far, on the main stream
-        else if (readout_stream) kick_deferred(r, dq, &ro_obj, true);   // all of it: every readout parameter
-        else if (hold && r.side) kick_deferred(r, dq, r.side, false);
+        if (r.side) kick_deferred(r, dq, r.side, false);
     }
     }   // phase != GI_BWD_PASSES
-    r.side = passes_side;               // (pipelined mode: the message passes' weight gradients as usual)
     if (phase == GI_BWD_READOUT) {
         // finish the readout parameters now: their weight-gradient GEMMs and slab reductions are
         // queued (side stream if there is one) so that the caller can start exchanging the gradients
         // of these parameters while the message passes are still being differentiated
         if (r.side) {
-            if (wgrad_inline()) {   // readout gradients finished on the MAIN stream: the caller's "ready"
-                hipEvent_t ev = r.side->next();     // event is recorded on the side stream, which must see them
-                r.chk((int)hipEventRecord(ev, r.st));
-                r.chk((int)hipStreamWaitEvent(r.side->st, ev, 0));
-            }
             kick_deferred(r, dq, r.side, true);          // also reduces every finished parameter
         } else {
             flush_deferred(r, dq);
@@ -1698,7 +1411,7 @@ extern "C" int gi_ggnn_backward_ex(const gi_ggnn_dims* dp, const float* const* p
                 sp.e[widx].reduced = 1;
                 descs[nd++] = reduce_desc(sp.e[widx], slabs, grads, widx);
             });
-            if (r.ok() && !wgrad_reduce_in_kernel()) r.chk(gi_reduce_slabs(descs, nd, r.st));
+            if (r.ok()) r.chk(gi_reduce_slabs(descs, nd, r.st));
         }
         return r.rc;
     }
@@ -1723,8 +1436,6 @@ extern "C" int gi_ggnn_backward_ex(const gi_ggnn_dims* dp, const float* const* p
         float* gh = ws + w.gh[p];
         float* agg = ws + w.agg[p];
         const bool last = (p == d.passes - 1);
-        static const bool excl = getenv("GI_CHAIN_EXCLUSIVE") && atoi(getenv("GI_CHAIN_EXCLUSIVE")) != 0;
-        r.hold_kicks = excl && r.img_b[0] != nullptr && E > 0;   // released right behind the pass's dZ chain
         if (scat0) {    // the later pass's d h scatter rides in this launch (GI_FUSE_DH_SCATTER)
             r.chk(gi_gru_gates_bwd_ex(gi, gh, w.ld3H, hx, w.ldhx, dh, last ? dhb : nullptr,
                                       last ? dhc : nullptr, last ? dhd : nullptr, dh2, w.ldH, seg_off, R,
@@ -1767,7 +1478,7 @@ extern "C" int gi_ggnn_backward_ex(const gi_ggnn_dims* dp, const float* const* p
                                      w.ldH, d.H);
             } else {
                 // per message row: the sum of its edges' contributions times the SELU derivative of the
-                // stack's last layer — own launches, or inside the dZ-chain launch (edge_chains_backward)
+                // stack's last layer (own launches in front of the dZ chains, edge_chains_backward)
                 const SegIn seg_m{ws + w.tmp_emb, w.ldM, mu_slot, mu_off};
                 const SegIn seg_e{ws + w.tmp_en, w.ldM, mu_slot, mu_off};
                 ch[0].seg = &seg_m; ch[1].seg = &seg_e;
@@ -1799,7 +1510,6 @@ extern "C" int gi_ggnn_backward_ex(const gi_ggnn_dims* dp, const float* const* p
         } else if (E > 0) {
             // d m_u = selu'(m_u) * sum over the edges reading row u of d agg[dst(e)]
             // (backward of the segmented sum + last SELU, over the message CSR)
-            // (the segmented sum runs as its own launch or inside the dZ chain: msg_backward decides)
             const SegIn seg{dagg, w.ldM, mu_dst, mu_off};
             msg_backward(r, ws, sp, slabs, dq, m.msg, bytype, hx, w.ldhx, u_src, U, w.eact[p],
                          w.edz[p], w.ldEh, ws + w.m[p], w.ldM, p > 0 ? ws + w.dxe : nullptr, w.ldH,
@@ -1818,11 +1528,6 @@ extern "C" int gi_ggnn_backward_ex(const gi_ggnn_dims* dp, const float* const* p
                         r.chk((int)hipMemsetAsync(
                             slabs + e.off + (long long)e.done * e.nsplit * e.stride, 0,
                             sizeof(float) * e.nsplit * e.stride, r.st));
-                        if (wgrad_reduce_in_kernel() && e.done == 0) {   // nothing will ever write them
-                            r.chk((int)hipMemsetAsync(grads[q.w(l)], 0,
-                                                      sizeof(float) * e.n_out * e.n_in, r.st));
-                            r.chk((int)hipMemsetAsync(grads[e.bidx], 0, sizeof(float) * e.n_out, r.st));
-                        }
                         e.done++;
                     }
                 }
@@ -1855,6 +1560,6 @@ extern "C" int gi_ggnn_backward_ex(const gi_ggnn_dims* dp, const float* const* p
     add_desc(m.gru_whh, m.gru_bhh);
     add_mlp_desc(m.att); add_mlp_desc(m.emb); add_mlp_desc(m.add1); add_mlp_desc(m.conn1);
     add_mlp_desc(m.add2); add_mlp_desc(m.conn2); add_mlp_desc(m.term2);
-    if (r.ok() && !wgrad_reduce_in_kernel()) r.chk(gi_reduce_slabs(descs, nd, r.st));
+    if (r.ok()) r.chk(gi_reduce_slabs(descs, nd, r.st));
     return r.rc;
 }

@@ -671,34 +671,6 @@ __global__ __launch_bounds__(1024) void class_sum_dselu_kernel(const ClassSumArg
     }
 }
 
-// ---- batched matrix transpose (weight copies for dgrad) --------------------------------------------
-#define GI_TRANSPOSE_MAX 40
-struct TransposeTable { gi_transpose_desc d[GI_TRANSPOSE_MAX]; int start[GI_TRANSPOSE_MAX + 1]; int n; };
-
-// 32x32 tiles through LDS (padded: conflict-free), 256 threads; blocks dealt through a prefix table
-__global__ __launch_bounds__(256) void transpose_kernel(const TransposeTable tab) {
-    __shared__ float tile[32][33];
-    int i = 0;
-    const int id = blockIdx.x;
-    while (i < tab.n - 1 && id >= tab.start[i + 1]) ++i;
-    const gi_transpose_desc& q = tab.d[i];
-    const int local = id - tab.start[i];
-    const int tcols = (q.cols + 31) / 32;
-    const int tr = local / tcols, tc = local - tr * tcols;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int r = tr * 32 + ty + 8 * k, c = tc * 32 + tx;
-        tile[ty + 8 * k][tx] = (r < q.rows && c < q.cols) ? q.src[(long long)r * q.cols + c] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = tc * 32 + ty + 8 * k, r = tr * 32 + tx;       // dst row = source column
-        if (c < q.cols && r < q.ldd) q.dst[(long long)c * q.ldd + r] = tile[tx][ty + 8 * k];
-    }
-}
-
 // ---- wgrad slab reduction ----------------------------------------------------------------------
 #define GI_REDUCE_MAX 40
 struct ReduceTable { gi_reduce_desc d[GI_REDUCE_MAX]; int start[GI_REDUCE_MAX + 1]; int n; };
@@ -1290,31 +1262,6 @@ extern "C" int gi_colsum_multi(const gi_colsum_desc* descs, int n, void* stream)
     hipLaunchKernelGGL(colsum_kernel, dim3((maxcols + 63) / 64, n), dim3(1024), 0,
                        (hipStream_t)stream, tab);
     return gi_launch_status();
-}
-
-extern "C" int gi_transpose_batch(const gi_transpose_desc* descs, int n_desc, void* stream) {
-    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
-    if (n_desc <= 0) return 0;
-    if (!descs) return GI_EINVAL;
-    for (int base = 0; base < n_desc; base += GI_TRANSPOSE_MAX) {
-        const int n = (n_desc - base < GI_TRANSPOSE_MAX) ? n_desc - base : GI_TRANSPOSE_MAX;
-        TransposeTable tab;
-        int total = 0;
-        for (int i = 0; i < n; ++i) {
-            const gi_transpose_desc& q = descs[base + i];
-            if (!q.src || !q.dst || q.rows <= 0 || q.cols <= 0 || q.ldd < q.rows) return GI_EINVAL;
-            tab.d[i] = q;
-            tab.start[i] = total;
-            total += ((q.rows + 31) / 32) * ((q.cols + 31) / 32);
-        }
-        for (int i = n; i < GI_TRANSPOSE_MAX; ++i) tab.d[i] = descs[base];
-        tab.start[n] = total;
-        tab.n = n;
-        hipLaunchKernelGGL(transpose_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, tab);
-        const int rc = gi_launch_status();
-        if (rc) return rc;
-    }
-    return 0;
 }
 
 extern "C" int gi_reduce_slabs(const gi_reduce_desc* descs, int n_desc, void* stream) {

@@ -68,7 +68,7 @@ class DataParallel:
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer,
                  scheduler=None, loss_fn: Callable = apd_kl_loss,
                  process_group: Optional[dist.ProcessGroup] = None, always_reduce: bool = False,
-                 overlap: bool = True, pipeline_readout: Optional[bool] = None):
+                 overlap: bool = True):
         self.model, self.optimizer, self.scheduler, self.loss_fn = model, optimizer, scheduler, loss_fn
         self.group = process_group
         self.always_reduce = always_reduce     # run the collective even at world size 1 (tests)
@@ -78,16 +78,6 @@ class DataParallel:
         self.last_overlapped = False
         self._pending = None           # (work handle, split offset) of the early tail all-reduce
         self._one = None               # cached root gradient (see step)
-        # Pipelined readout update (one process, HIP model, FusedAdam with one group; opt-in, also
-        # GI_PIPELINE_READOUT=1): the readout's weight gradients, their reductions and Adam over the readout
-        # parameters run on a third stream under the NEXT step's message passes (gnn/mpnn.py,
-        # gi_ggnn_backward_ex); the next forward waits for them in front of its readout.  Same arithmetic,
-        # bit-identical parameters; `flush()` before reading parameters or gradients outside `step`.
-        if pipeline_readout is None:
-            pipeline_readout = os.environ.get("GI_PIPELINE_READOUT", "0") == "1"
-        self.pipeline_readout = bool(pipeline_readout and self.world_size == 1 and not always_reduce
-                                     and hasattr(model, "_pipeline_readout")
-                                     and hasattr(optimizer, "step_split") and torch.cuda.is_available())
         self._comm_stream = None
         # overlap needs the HIP model (it exposes the flat bucket and the two-call backward)
         self.overlap = (overlap and os.environ.get("GI_DP_OVERLAP", "1") != "0"
@@ -171,18 +161,9 @@ class DataParallel:
             g.copy_(flat[off:off + n].view_as(g))
             off += n
 
-    def flush(self) -> None:
-        """Pipelined readout update: make the current stream wait for the readout parameters' pending
-        optimizer step (call before reading parameters / gradients or checkpointing)."""
-        ev = getattr(self.model, "_readout_ready", None)
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
-
     def step(self, nodes: torch.Tensor, edges: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """forward -> zero_grad -> loss -> backward -> all-reduce -> optimizer (-> scheduler):
         the order of Workflow.py:785-796 with the exchange step inserted before the update."""
-        if hasattr(self.model, "_pipeline_readout"):
-            self.model._pipeline_readout = self.pipeline_readout
         output = self.model(nodes, edges)
         for p in self.params:                      # optimizer.zero_grad(set_to_none=True), minus its
             p.grad = None                          # per-call bookkeeping (0.09 ms of host time)
@@ -202,18 +183,8 @@ class DataParallel:
         finally:
             if self.overlap:
                 self.model._grad_ready_hook = None
-        split = getattr(self.model, "_pipelined_split", None) if self.pipeline_readout else None
-        if split is not None:
-            # the backward left the readout gradients to its third stream: Adam over the head here, over
-            # the readout tail there, and the event every later forward waits for in front of its readout
-            ro = self.model._pipelined_stream
-            self.optimizer.step_split(split, ro)
-            ready = torch.cuda.Event()
-            ready.record(ro)
-            self.model._readout_ready = ready
-        else:
-            self.allreduce_gradients()
-            self.optimizer.step()
+        self.allreduce_gradients()
+        self.optimizer.step()
         if self.scheduler is not None:
             self.scheduler.step()
         return loss.detach()

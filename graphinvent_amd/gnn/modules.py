@@ -31,7 +31,8 @@ class _LinearStack(torch.nn.Module):
 
 class MLP(torch.nn.Module):
     """depth+1 Linear layers, SELU after every one including the last (gnn/modules.py:111-170).
-    AlphaDropout with p > 0 is not implemented in the HIP path; the default p = 0.0 is identity."""
+    ``dropout_p`` > 0: ``torch.nn.AlphaDropout`` behind every Linear + SELU in ``train()`` mode, on the HIP path
+    (gi_alpha_dropout_fwd); the shipped default p = 0.0 and ``eval()`` are the identity."""
 
     def __init__(self, in_features: int, hidden_layer_sizes: list, out_features: int,
                  dropout_p: float) -> None:

@@ -69,24 +69,18 @@ def _set_dropout(dims, c, kind: int, seed: int) -> None:
     dims.drop_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
 
 
-def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dropout_seed=None,
-                     readout_ready=None):
+def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dropout_seed=None):
     """graph_compact + the fused forward.  Returns (logits, tape); the tape
     (dims, CompactGraph, workspace, per-type edge counts) is what backward consumes.
 
     ``dropout_seed`` (an int): training mode with AlphaDropout p > 0 — the graph is compacted without
     row sharing (every edge and every padded slot draws its own mask, as in the reference), every
     activation gets a stored backward factor (workspace x2), and the logits tensor carries B extra
-    rows for the factors of the logits (the returned tensor is the view of the first B).
-
-    ``readout_ready`` (a recorded ``torch.cuda.Event`` or None): pipelined readout update — the stream
-    waits for it in front of the readout, after the message passes (``gi_ggnn_forward_ex``)."""
+    rows for the factors of the logits (the returned tensor is the view of the first B)."""
     lib = _L.load()
     drop = dropout_seed is not None
     nodes, lay, gfix, S, E, U, D0, Ut = _ops.compact_count(nodes, edges, nodedup=drop)
     attn = kind != _L.KIND_GGNN
-    if attn and _os_environ_flag("GI_ATT_PASS0", "1") == "0":
-        D0 = 0                          # AttentionGGNN's pass 0 on message rows (measurement knob)
     B = nodes.shape[0]
     dims = _dims_from_constants(consts, B, kind)
     if drop:
@@ -108,9 +102,8 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dro
     apd = dims.N * dims.A + dims.N * dims.C + 1
     out = torch.empty((2 * B if drop else B, apd), dtype=torch.float32, device=dev)
     gs = graph.c_struct()
-    _L.check(lib.gi_ggnn_forward_ex(C.byref(dims), _ptr_table(params), C.byref(gs), ws.data_ptr(),
-                                    out.data_ptr(), apd, torch.cuda.current_stream().cuda_stream,
-                                    readout_ready.cuda_event if readout_ready is not None else None),
+    _L.check(lib.gi_ggnn_forward(C.byref(dims), _ptr_table(params), C.byref(gs), ws.data_ptr(),
+                                 out.data_ptr(), apd, torch.cuda.current_stream(dev).cuda_stream),
              "gi_ggnn_forward")
     return (out[:B] if drop else out), (dims, graph, ws)
 
@@ -131,26 +124,6 @@ def _side_stream(device: torch.device) -> int:
             _L.check(_L.load().gi_side_stream_create(C.byref(handle)), "gi_side_stream_create")
         st = _SIDE_STREAMS[key] = handle.value      # lives as long as the process
     return st
-
-
-_READOUT_STREAMS = {}
-
-
-def _readout_stream(device: torch.device) -> "torch.cuda.Stream":
-    """Third HIP stream (one per device, lowest priority) of the pipelined readout update: the readout's
-    weight gradients, their slab reductions and the optimizer step over the readout parameters."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    st = _READOUT_STREAMS.get(key)
-    if st is None:
-        handle = C.c_void_p()
-        with torch.cuda.device(key):
-            _L.check(_L.load().gi_side_stream_create(C.byref(handle)), "gi_side_stream_create")
-        st = _READOUT_STREAMS[key] = torch.cuda.ExternalStream(handle.value, device=torch.device("cuda", key))
-    return st
-
-
-def _side_stream_max_rows() -> int:
-    return int(_os_environ_flag("GI_SIDE_MAX_ROWS", str(1 << 62)))
 
 
 def _os_environ_flag(name: str, default: str) -> str:
@@ -175,8 +148,7 @@ def new_grad_bucket(params, device):
     return gflat, grads, offs
 
 
-def ggnn_backward_raw(tape, out, d_out, params, early_hook=None, bucket=None, wt=None,
-                      readout_stream=None):
+def ggnn_backward_raw(tape, out, d_out, params, early_hook=None, bucket=None):
     """The fused backward; consumes the tape's activations in place.  Returns (grads, gflat):
     per-parameter gradient views into ONE flat fp32 buffer (state_dict order, 16-byte aligned
     segments) — the bucket a data-parallel all-reduce operates on.
@@ -184,18 +156,14 @@ def ggnn_backward_raw(tape, out, d_out, params, early_hook=None, bucket=None, wt
     ``early_hook(gflat, split, ready_event)`` (optional, set by ``dp.DataParallel``): the backward is
     issued in two calls; after the first, ``gflat[split:]`` — the readout's gradients, ~86 % of the
     bucket — is complete once ``ready_event`` fires, and the hook may start exchanging it while the
-    second call differentiates the message passes.
-
-    ``readout_stream`` (optional ``torch.cuda.Stream``, not together with ``early_hook``): pipelined
-    readout update (``gi_ggnn_backward_ex``) — the gradients of the readout parameters are completed on that
-    stream and are NOT ordered before later work on the current stream."""
+    second call differentiates the message passes."""
     lib = _L.load()
     dims, graph, ws = tape
     d_out = d_out.contiguous().float()
     dev = out.device
     if dev.index != torch.cuda.current_device():     # autograd may run backward on another device
         with torch.cuda.device(dev):
-            return ggnn_backward_raw(tape, out, d_out, params, early_hook, bucket, wt, readout_stream)
+            return ggnn_backward_raw(tape, out, d_out, params, early_hook, bucket)
     gs = graph.c_struct()
     n_slab = lib.gi_ggnn_slab_floats(C.byref(dims), graph.S, graph.U, gs.Ut)
     if n_slab < 0:
@@ -204,34 +172,19 @@ def ggnn_backward_raw(tape, out, d_out, params, early_hook=None, bucket=None, wt
     gflat, grads, offs = bucket if bucket is not None else new_grad_bucket(params, dev)
     main = torch.cuda.current_stream(dev)
     # The weight-gradient GEMMs overlap the dZ chain on a second stream (gi_ggnn_backward holds them back
-    # while the node-level dgrad launches fill the device by themselves).  GI_SIDE_MAX_ROWS=<rows>
-    # (measurements) turns the second stream off for batches with at least that many compact node rows:
-    # before the hold the overlap LOST 3-4 % beyond ~18 k rows (ZINC shape B=1000), with it it gains
-    # 1-2 % there too (tools/ab/ab_run35.sh, ab/ab_run36.sh).
-    side = _side_stream(dev) if graph.S < _side_stream_max_rows() else 0
+    # while the node-level dgrad launches fill the device by themselves).
+    side = _side_stream(dev)
     args = (C.byref(dims), _ptr_table(params), C.byref(gs), ws.data_ptr(), slabs.data_ptr(),
             out.data_ptr(), out.stride(0), d_out.data_ptr(), d_out.stride(0), _ptr_table(grads),
             main.cuda_stream, side)
-    wt_ptr = None
-    if wt is not None:                       # (transposed weight copies, their "ready" event)
-        main.wait_event(wt[1])
-        wt_ptr = wt[0].data_ptr()
-    if readout_stream is not None:
-        if early_hook is not None:
-            raise RuntimeError("pipelined readout update and the early gradient exchange exclude each other")
-        _L.check(lib.gi_ggnn_backward_ex(*args, readout_stream.cuda_stream, _L.BWD_ALL, wt_ptr),
-                 "gi_ggnn_backward_ex")
-        for t in (ws, slabs, gflat):             # read / written there after this call returns
-            t.record_stream(readout_stream)
-        return grads, gflat
     if early_hook is None:
-        _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_ALL, wt_ptr), "gi_ggnn_backward")
+        _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_ALL), "gi_ggnn_backward")
         return grads, gflat
-    _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_READOUT, wt_ptr), "gi_ggnn_backward(readout)")
+    _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_READOUT), "gi_ggnn_backward(readout)")
     ready = torch.cuda.Event()
     ready.record(torch.cuda.ExternalStream(side, device=dev) if side else main)
     early_hook(gflat, offs[lib.gi_ggnn_first_readout_param(C.byref(dims))], ready)
-    _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_PASSES, wt_ptr), "gi_ggnn_backward(passes)")
+    _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_PASSES), "gi_ggnn_backward(passes)")
     return grads, gflat
 
 
@@ -240,10 +193,8 @@ class _GGNNFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, owner, nodes, edges, *params):
-        start = owner._weights_final_event(nodes.device)
         out, tape = ggnn_forward_raw(owner.constants, nodes, edges, params, owner._KIND,
-                                     owner._next_dropout_seed(), owner._readout_ready)
-        ctx.wt = owner._transposed_weights(tape[0], params, start)
+                                     owner._next_dropout_seed())
         ctx.owner = owner
         ctx.tape = tape
         ctx.save_for_backward(out, *params)
@@ -258,7 +209,7 @@ class _GGNNFunction(torch.autograd.Function):
         out, *params = ctx.saved_tensors
         # no early exchange on this path: AccumulateGrad may clone these gradients (or run user
         # hooks on them) while a collective would still be reducing the bucket in place
-        grads, gflat = ggnn_backward_raw(tape, out, d_out, params, None, wt=ctx.wt)
+        grads, gflat = ggnn_backward_raw(tape, out, d_out, params, None)
         ctx.owner._grad_bucket = gflat          # the flat bucket graphinvent_amd.dp all-reduces
         return (None, None, None, *grads)
 
@@ -273,10 +224,8 @@ class _GGNNDirect(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, nodes, edges, anchor):
         params = owner._params()
-        start = owner._weights_final_event(nodes.device) if anchor is not None else None
         out, tape = ggnn_forward_raw(owner.constants, nodes, edges, params, owner._KIND,
-                                     owner._next_dropout_seed(), owner._readout_ready)
-        ctx.wt = owner._transposed_weights(tape[0], params, start) if anchor is not None else None
+                                     owner._next_dropout_seed())
         ctx.owner = owner
         ctx.tape = tape
         # the parameters are not saved tensors here: remember their versions so that an in-place
@@ -296,7 +245,7 @@ class _GGNNDirect(torch.autograd.Function):
                 ctx.versions != [p._version for p in ctx.owner._params()]:
             raise RuntimeError("a GGNN parameter was modified in place between forward and backward: "
                                "the saved activations no longer match the weights")
-        ctx.owner._backward_into_grads(tape, out, d_out, ctx.wt)
+        ctx.owner._backward_into_grads(tape, out, d_out)
         return None, None, None, None
 
 
@@ -311,16 +260,6 @@ class _FusedMPNN(torch.nn.Module):
     autograd_params = False
     _grad_ready_hook = None
     _early_exchange_pending = False     # set by dp.DataParallel while its early all-reduce runs
-    #: Pipelined readout update (dp.DataParallel(pipeline_readout=True), one process): the backward completes
-    #: the readout parameters' gradients on `_readout_stream` without the main stream waiting for them; the
-    #: trainer runs the optimizer for them there and leaves the event behind it in `_readout_ready`, which every
-    #: later forward waits for in front of its readout.  `_pipelined_split` = float offset of the readout
-    #: tail in the gradient bucket after a pipelined backward (None after an ordinary one).
-    _pipeline_readout = False
-    _readout_ready = None
-    _pipelined_split = None
-    _pipelined_stream = None
-
     def _dropout_active(self) -> bool:
         flag = self.__dict__.get("_has_dropout")
         if flag is None:                         # dropout probabilities are fixed at construction
@@ -361,12 +300,12 @@ class _FusedMPNN(torch.nn.Module):
         cls = self.__class__
         new = cls.__new__(cls)
         memo[id(self)] = new
-        skip = ("_param_cache", "_bucket", "_anchor", "_grad_bucket", "_grad_ready_hook", "_wt",
-                "_early_exchange_pending", "_readout_ready", "_pipelined_split", "_pipelined_stream")
+        skip = ("_param_cache", "_bucket", "_anchor", "_grad_bucket", "_grad_ready_hook",
+                "_early_exchange_pending")
         import copy as _copy
         for k, v in self.__dict__.items():
             new.__dict__[k] = None if k in skip else _copy.deepcopy(v, memo)
-        for k in ("_param_cache", "_bucket", "_anchor", "_wt"):
+        for k in ("_param_cache", "_bucket", "_anchor"):
             new.__dict__.pop(k, None)
         return new
 
@@ -386,39 +325,7 @@ class _FusedMPNN(torch.nn.Module):
                 anchor = self.__dict__["_anchor"] = torch.zeros((), requires_grad=True)
         return _GGNNDirect.apply(self, nodes, edges, anchor)
 
-    # ---- transposed weight copies for the dgrad GEMMs (GI_DGRAD_WT=1) -------------------------------
-    def _weights_final_event(self, device):
-        """An event on the current stream BEFORE the forward is enqueued: the weights are final from
-        here on (the optimizer step was enqueued earlier on this stream)."""
-        if _os_environ_flag("GI_DGRAD_WT", "0") != "1" or not torch.is_grad_enabled():
-            return None
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(device))
-        return ev
-
-    def _transposed_weights(self, dims, params, start):
-        """Refresh WT on the (otherwise idle) side stream while the forward runs on the main stream;
-        returns (WT buffer, ready event) for the backward, or None."""
-        if start is None:
-            return None
-        dev = params[0].device
-        side = _side_stream(dev)
-        if not side:
-            return None
-        lib = _L.load()
-        wt = self.__dict__.get("_wt")
-        n = lib.gi_ggnn_wt_floats(C.byref(dims))
-        if wt is None or wt.numel() != n or wt.device != dev:
-            wt = self.__dict__["_wt"] = torch.empty(int(n), dtype=torch.float32, device=dev)
-        st = torch.cuda.ExternalStream(side, device=dev)
-        st.wait_event(start)
-        _L.check(lib.gi_ggnn_transpose_weights(C.byref(dims), _ptr_table(params), wt.data_ptr(), side),
-                 "gi_ggnn_transpose_weights")
-        ready = torch.cuda.Event()
-        ready.record(st)
-        return wt, ready
-
-    def _backward_into_grads(self, tape, out, d_out, wt=None) -> None:
+    def _backward_into_grads(self, tape, out, d_out) -> None:
         """Run the fused backward and accumulate into ``param.grad`` like autograd would."""
         params = self._params()
         fresh = all(p.grad is None for p in params)
@@ -434,16 +341,7 @@ class _FusedMPNN(torch.nn.Module):
             raise RuntimeError("a second backward through the model while the data-parallel early "
                                "all-reduce of the first one is reducing the gradient bucket in place; "
                                "use DataParallel(overlap=False) for multiple backwards per step")
-        ro = None
-        self._pipelined_split = None
-        if self._pipeline_readout and fresh and hook is None and wt is None:
-            ro = _readout_stream(out.device)
-        grads, gflat = ggnn_backward_raw(tape, out, d_out, params, hook, bucket, wt, ro)
-        if ro is not None:
-            dims = tape[0]
-            offs = bucket[2]
-            self._pipelined_split = offs[_L.load().gi_ggnn_first_readout_param(C.byref(dims))]
-            self._pipelined_stream = ro          # the stream the trainer continues the tail on
+        grads, gflat = ggnn_backward_raw(tape, out, d_out, params, hook, bucket)
         with torch.no_grad():
             if fresh:
                 for p, g in zip(params, grads):

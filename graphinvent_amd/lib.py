@@ -24,11 +24,11 @@ CSRC = os.path.join(_HERE, "csrc")
 GI_MAX_GROUPS = 8
 GI_MAX_NODES = 128
 EPI_BIAS, EPI_SELU, EPI_DSELU, EPI_ACCUM, GEMM_SPLITK = 1, 2, 4, 8, 16
-EPI_MULACT, GEMM_REDUCE = 64, 128
+EPI_MULACT = 64
 KIND_GGNN, KIND_ATTGGNN = 0, 1
 BWD_ALL, BWD_READOUT, BWD_PASSES = 0, 1, 2
 COUNTS = 24          # GI_COUNTS
-ABI_VERSION = 8      # GI_ABI_VERSION
+ABI_VERSION = 9      # GI_ABI_VERSION
 DTYPE_F32, DTYPE_I8 = 0, 1
 
 vp = C.c_void_p
@@ -50,8 +50,7 @@ class GemmParams(C.Structure):
                 ("ngroups", ci), ("nsplit", ci), ("max_group_rows", ci), ("ones_col", ci),
                 ("c_split_stride", cll),
                 ("Bg", vp * GI_MAX_GROUPS), ("biasg", vp * GI_MAX_GROUPS),
-                ("Cg", vp * GI_MAX_GROUPS), ("gsplit", ci * GI_MAX_GROUPS),
-                ("red_dW", vp), ("red_db", vp), ("red_count", vp), ("red_ldw", ci), ("red_accum", ci)]
+                ("Cg", vp * GI_MAX_GROUPS), ("gsplit", ci * GI_MAX_GROUPS)]
 
 
 CHAIN_MAXL, CHAIN_MAXW = 8, 256       # GI_CHAIN_MAXL, GI_CHAIN_MAXW
@@ -65,15 +64,7 @@ class ChainLayer(C.Structure):
 class ChainParams(C.Structure):
     _fields_ = [("layer", ChainLayer * CHAIN_MAXL), ("nlayers", ci), ("X", vp), ("ldx", ci),
                 ("x_idx", vp), ("grp_off", vp), ("ngroups", ci), ("group_rows", ci * GI_MAX_GROUPS),
-                ("rows", ci), ("backward", ci), ("image", vp), ("image_stride", cll),
-                ("seg_vals", vp), ("ld_seg", ci), ("seg_idx", vp), ("seg_off", vp)]
-
-
-class GruParams(C.Structure):
-    _fields_ = [("m", vp), ("ldm", ci), ("in_perm", vp), ("seg_off", vp), ("agg", vp), ("ldagg", ci),
-                ("agg_ready", ci), ("hx_prev", vp), ("hx_new", vp), ("ldhx", ci), ("W_ih", vp),
-                ("W_hh", vp), ("b_ih", vp), ("b_hh", vp), ("gi", vp), ("gh", vp), ("ldg", ci),
-                ("R", ci), ("H", ci), ("M", ci), ("trace", vp), ("image", vp)]
+                ("rows", ci), ("backward", ci), ("image", vp), ("image_stride", cll)]
 
 
 class ReduceDesc(C.Structure):
@@ -124,6 +115,7 @@ SIGNATURES = {
     "gi_gemm_batch": (ci, [C.POINTER(GemmParams), ci, vp]),
     "gi_gemm_config": (ci, [ci, ci]),
     "gi_mlp_chain": (ci, [C.POINTER(ChainParams), ci, vp]),
+    "gi_mlp_chain_config": (ci, [ci, ci, ci, vp]),
     "gi_mlp_chain_pack": (ci, [C.POINTER(ChainParams), ci, vp]),
     "gi_mlp_chain_image_floats": (cll, [C.POINTER(ChainParams)]),
     "gi_seg_sum": (ci, [vp, ci, vp, vp, ci, ci, vp, ci, ci, vp]),
@@ -133,9 +125,6 @@ SIGNATURES = {
     "gi_slab_sum_dselu": (ci, [vp, ci, cll, ci, ci, ci, vp, ci, vp]),
     "gi_slab_epilogue": (ci, [vp, ci, cll, ci, ci, ci, ci, vp, vp, ci, vp, ci, vp]),
     "gi_selu_bwd_rows": (ci, [vp, ci, vp, vp, ci, vp, ci, ci, ci, vp]),
-    "gi_gru_fused_fwd": (ci, [C.POINTER(GruParams), vp]),
-    "gi_gru_pack": (ci, [C.POINTER(GruParams), vp]),
-    "gi_gru_image_floats": (cll, [ci, ci]),
     "gi_gru_gates_fwd": (ci, [vp, vp, ci, vp, vp, ci, vp, ci, ci, ci, vp]),
     "gi_gru_gates_bwd": (ci, [vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, vp]),
     "gi_gather_readout_fwd": (ci, [vp, vp, ci, vp, vp, ci, ci, ci, C.c_float,
@@ -169,14 +158,8 @@ SIGNATURES = {
     "gi_ggnn_backward": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), C.POINTER(Graph), vp, vp, vp, ci,
                               vp, ci, C.POINTER(vp), vp, vp]),
     "gi_ggnn_backward_phase": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), C.POINTER(Graph), vp, vp, vp,
-                                    ci, vp, ci, C.POINTER(vp), vp, vp, ci, vp]),
-    "gi_ggnn_wt_floats": (cll, [C.POINTER(GgnnDims)]),
-    "gi_ggnn_transpose_weights": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), vp, vp]),
-    "gi_transpose_batch": (ci, [vp, ci, vp]),
+                                    ci, vp, ci, C.POINTER(vp), vp, vp, ci]),
     "gi_ggnn_first_readout_param": (ci, [C.POINTER(GgnnDims)]),
-    "gi_ggnn_forward_ex": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), C.POINTER(Graph), vp, vp, ci, vp, vp]),
-    "gi_ggnn_backward_ex": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), C.POINTER(Graph), vp, vp, vp,
-                                 ci, vp, ci, C.POINTER(vp), vp, vp, vp, ci, vp]),
     "gi_fuse_flags": (ci, []),
     "gi_gru_gates_bwd_ex": (ci, [vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, vp, vp, ci, vp, vp,
                                  vp]),
@@ -185,7 +168,7 @@ SIGNATURES = {
     "gi_compress_slots2_f": (ci, [vp, ci, ci, vp, ci, vp, ci, vp, ci, ci, vp, ci, vp, ci, vp, ci, ci, ci,
                                   cll, vp]),
 }
-FUSE_GATES_V4, FUSE_DH_SCATTER, FUSE_TIER2_DSELU, FUSE_SLOTS, FUSE_CHAIN_DM = 1, 2, 4, 8, 16  # GI_FUSE_*
+FUSE_GATES_V4, FUSE_DH_SCATTER, FUSE_TIER2_DSELU, FUSE_SLOTS = 1, 2, 4, 8  # GI_FUSE_*
 
 _lib = None
 

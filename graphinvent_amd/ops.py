@@ -14,8 +14,33 @@ import torch
 from . import lib as L
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(t: Optional[torch.Tensor] = None) -> int:
+    """The current stream of `t`'s device (of the current device without `t`)."""
+    return torch.cuda.current_stream(t.device if t is not None else None).cuda_stream
+
+
+def _on_device_of(argname: str):
+    """Run the wrapped op with the device of its tensor argument `argname` current: kernels go to the current
+    device's stream, which must be the device the tensors live on (multi-GPU processes, advisor finding)."""
+    import functools
+    import inspect
+
+    def deco(fn):
+        sig = inspect.signature(fn)
+
+        @functools.wraps(fn)
+        def wrapper(*args, **kwargs):
+            t = sig.bind(*args, **kwargs).arguments.get(argname)
+            if isinstance(t, (list, tuple)) and t:
+                t = t[0]
+            if isinstance(t, dict):
+                t = next((v for v in t.values() if torch.is_tensor(v)), None)
+            if torch.is_tensor(t) and t.is_cuda and t.device.index != torch.cuda.current_device():
+                with torch.cuda.device(t.device):
+                    return fn(*args, **kwargs)
+            return fn(*args, **kwargs)
+        return wrapper
+    return deco
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -144,6 +169,7 @@ def _gvar_offsets(E: int, U: int, D0: int = 0):
     return offs, o
 
 
+@_on_device_of("nodes")
 def _count_launch(nodes: torch.Tensor, edges: torch.Tensor, nodedup: bool = False):
     """Enqueue gi_compact_count on the current stream; returns (nodes as the kernels read them,
     layout, gfix).  nodedup: no row sharing (AlphaDropout training mode, gi_compact_count_ex)."""
@@ -257,6 +283,7 @@ def compact_count(nodes: torch.Tensor, edges: torch.Tensor, nodedup: bool = Fals
     return (nodes, lay, gfix) + _unpack_counts(counts, Fe)
 
 
+@_on_device_of("nodes")
 def compact_fill(nodes, lay, gfix, S, E, U, D0, Ut, hx0: torch.Tensor, ldhx: int,
                  H: int, class_csr: bool = False) -> CompactGraph:
     lib = L.load()
@@ -292,6 +319,7 @@ def compact(nodes: torch.Tensor, edges: torch.Tensor, H: int, class_csr: bool = 
 # ------------------------------------------------------------------------------------------------
 # GEMM family
 # ------------------------------------------------------------------------------------------------
+@_on_device_of("A")
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, flags=0, bias=None, act=None, ldact=0,
          a_idx=None, b_idx=None, a_major=False, b_major=False, tm=1, tn=1, grp_off=None,
          ngroups=0, max_group_rows=0, Bg=(), biasg=(), Cg=(), nsplit=1, c_split_stride=0,
@@ -316,12 +344,14 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, flags=0, bias=None, act=None, l
     L.check(lib.gi_gemm(C.byref(p), _stream()), "gi_gemm")
 
 
+@_on_device_of("vals")
 def seg_sum(vals, perm, off, rows, cols, out, accumulate=False):
     L.check(L.load().gi_seg_sum(vals.data_ptr(), vals.stride(0), _ptr(perm), off.data_ptr(), rows,
                                 cols, out.data_ptr(), out.stride(0), int(accumulate), _stream()),
             "gi_seg_sum")
 
 
+@_on_device_of("dY")
 def selu_bwd_rows(dY, idx, Y, out, rows, cols):
     L.check(L.load().gi_selu_bwd_rows(dY.data_ptr(), dY.stride(0), _ptr(idx), Y.data_ptr(),
                                       Y.stride(0), out.data_ptr(), out.stride(0), rows, cols,
@@ -389,25 +419,3 @@ def mlp_chain(chains, backward=False):
     L.check(lib.gi_mlp_chain(arr, len(chains), _stream()), "gi_mlp_chain")
     for im in images:
         im.record_stream(torch.cuda.current_stream(im.device))
-
-
-def gru_fused_fwd(m, in_perm, seg_off, agg, agg_ready, hx_prev, hx_new, W_ih, W_hh, b_ih, b_hh, gi, gh,
-                  R, H, M):
-    """gi_gru_fused_fwd on [R, ld] tensors (test / tool entry; the model calls it from C++)."""
-    q = L.GruParams()
-    q.m, q.ldm = _ptr(m), (m.stride(0) if m is not None else 0)
-    q.in_perm, q.seg_off = _ptr(in_perm), seg_off.data_ptr()
-    q.agg, q.ldagg, q.agg_ready = agg.data_ptr(), agg.stride(0), int(agg_ready)
-    q.hx_prev, q.hx_new, q.ldhx = hx_prev.data_ptr(), hx_new.data_ptr(), hx_prev.stride(0)
-    q.W_ih, q.W_hh, q.b_ih, q.b_hh = (t.data_ptr() for t in (W_ih, W_hh, b_ih, b_hh))
-    q.gi, q.gh, q.ldg = gi.data_ptr(), gh.data_ptr(), gi.stride(0)
-    q.R, q.H, q.M = R, H, M
-    lib = L.load()
-    n = lib.gi_gru_image_floats(H, M)
-    if n < 0:
-        L.check(int(n), "gi_gru_image_floats")
-    image = torch.empty(int(n), dtype=torch.float32, device=W_ih.device)
-    q.image = image.data_ptr()
-    L.check(lib.gi_gru_pack(C.byref(q), _stream()), "gi_gru_pack")
-    L.check(lib.gi_gru_fused_fwd(C.byref(q), _stream()), "gi_gru_fused_fwd")
-    image.record_stream(torch.cuda.current_stream(image.device))

@@ -8,9 +8,11 @@ unaffected).  The segment layout is the one the fused GGNN backward uses for its
 (``gnn.mpnn.ggnn_backward_raw``), so when the gradients already live in that bucket the step reads
 them in place; otherwise they are packed first.  Learning-rate schedulers work as usual
 (``group["lr"]`` is read every step).  Semantics: Adam without amsgrad, ``weight_decay`` as L2 term,
-bias correction as in torch (computed in double on the host).  Deviation: parameters whose ``grad`` is
-None take part in the step with a zero gradient (moment decay), where torch.optim.Adam skips them —
-the fused GGNN backward always produces every gradient.
+bias correction as in torch (computed in double on the host).  Parameters with ``requires_grad=False`` are
+not part of the bucket; parameters whose ``grad`` is None at a step are skipped like torch.optim.Adam skips
+them (no moment decay, no weight decay: the step then runs as one launch per run of parameters that do have
+gradients).  One deviation remains: the bias-correction step count is kept per GROUP, not per parameter, so
+a parameter that skipped steps is corrected with the group's count (torch: with its own).
 """
 from __future__ import annotations
 
@@ -121,35 +123,6 @@ class FusedAdam(torch.optim.Optimizer):
         return st["g"]
 
     @torch.no_grad()
-    def step_split(self, split: int, tail_stream: "torch.cuda.Stream") -> None:
-        """One Adam step in two launches: floats [0, split) of the bucket on the current stream, floats
-        [split, total) on ``tail_stream`` — the pipelined readout update (``gnn.mpnn``, ``dp.DataParallel``),
-        where the gradients of the tail are completed on that stream.  Needs a single parameter group whose
-        gradients ARE the flat bucket of the fused backward (zero-copy), ``split`` a multiple of 4."""
-        if len(self._flat) != 1 or self._flat[0] is None:
-            raise RuntimeError("FusedAdam.step_split needs exactly one parameter group")
-        group, st = self.param_groups[0], self._flat[0]
-        if split % 4 or not 0 <= split <= st["total"]:
-            raise ValueError("split must be a multiple of 4 inside the bucket")
-        ps, offs = st["params"], st["offs"]
-        g0 = ps[0].grad
-        if g0 is None or not all(p.grad is not None and p.grad.data_ptr() == g0.data_ptr() + 4 * o
-                                 for p, o in zip(ps, offs)):
-            raise RuntimeError("FusedAdam.step_split: the gradients are not the fused backward's flat bucket")
-        g = torch.as_strided(g0, (st["total"],), (1,))
-        st["step"] += 1
-        self._opt_called = True             # (what lr_scheduler's wrapper of `step` would have noted)
-        b1, b2 = group["betas"]
-        lib = L.load()
-        for lo, hi, stream in ((0, split, torch.cuda.current_stream(st["p"].device)),
-                               (split, st["total"], tail_stream)):
-            if hi > lo:
-                L.check(lib.gi_adam_step(st["p"].data_ptr() + 4 * lo, g.data_ptr() + 4 * lo,
-                                         st["m"].data_ptr() + 4 * lo, st["v"].data_ptr() + 4 * lo, hi - lo,
-                                         float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
-                                         st["step"], stream.cuda_stream), "gi_adam_step")
-
-    @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
@@ -160,12 +133,30 @@ class FusedAdam(torch.optim.Optimizer):
             if st is None:
                 continue
             with torch.cuda.device(st["p"].device):       # launch on the bucket's device, whichever is current
+                ps, offs = st["params"], st["offs"]
+                have = [p.grad is not None for p in ps]
+                if not any(have):
+                    continue
                 g = self._grad_bucket(st)
                 st["step"] += 1
                 b1, b2 = group["betas"]
-                L.check(lib.gi_adam_step(st["p"].data_ptr(), g.data_ptr(), st["m"].data_ptr(),
-                                         st["v"].data_ptr(), st["total"], float(group["lr"]), b1, b2,
-                                         group["eps"], group["weight_decay"], st["step"],
-                                         torch.cuda.current_stream(st["p"].device).cuda_stream),
-                        "gi_adam_step")
+                stream = torch.cuda.current_stream(st["p"].device).cuda_stream
+                # one launch over the whole bucket, or one per run of consecutive parameters with gradients
+                runs = [(0, st["total"])] if all(have) else []
+                if not runs:
+                    i = 0
+                    while i < len(ps):
+                        if have[i]:
+                            j = i
+                            while j + 1 < len(ps) and have[j + 1]:
+                                j += 1
+                            runs.append((offs[i], offs[j] + ((ps[j].numel() + 3) & ~3)))
+                            i = j + 1
+                        else:
+                            i += 1
+                for lo, hi in runs:
+                    L.check(lib.gi_adam_step(st["p"].data_ptr() + 4 * lo, g.data_ptr() + 4 * lo,
+                                             st["m"].data_ptr() + 4 * lo, st["v"].data_ptr() + 4 * lo, hi - lo,
+                                             float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
+                                             st["step"], stream), "gi_adam_step")
         return loss

@@ -47,10 +47,12 @@ def sample_actions_raw(logits: torch.Tensor, n_nodes: torch.Tensor, edges: torch
     action = torch.empty((B, 4), dtype=torch.int32, device=logits.device)
     like = torch.empty(B, dtype=torch.float32, device=logits.device)
     flags = torch.empty(B, dtype=torch.int32, device=logits.device)
-    L.check(lib.gi_sample_actions(logits.data_ptr(), logits.stride(0), uniform.data_ptr(),
-                                  nn32.data_ptr(), edges.data_ptr(), dt, B, N, n_add_per_node, Fe,
-                                  action.data_ptr(), like.data_ptr(), flags.data_ptr(),
-                                  torch.cuda.current_stream().cuda_stream), "gi_sample_actions")
+    with torch.cuda.device(logits.device):       # launch on the logits' device, whichever is current
+        L.check(lib.gi_sample_actions(logits.data_ptr(), logits.stride(0), uniform.data_ptr(),
+                                      nn32.data_ptr(), edges.data_ptr(), dt, B, N, n_add_per_node, Fe,
+                                      action.data_ptr(), like.data_ptr(), flags.data_ptr(),
+                                      torch.cuda.current_stream(logits.device).cuda_stream),
+                "gi_sample_actions")
     return action, like, flags
 
 

@@ -18,9 +18,12 @@
  *   - return value: 0 = success, >0 = hipError_t from a launch, <0 = argument error (GI_E*);
  *   - no exceptions cross the ABI; one process per GPU, calls come from one host thread at a time.
  *     Process-wide state is limited to: the optional per-launch timing log (gi_prof_*), a pool of
- *     timing-disabled hipEvents used to order the backward's streams, and switches read once from the
- *     environment (GI_FUSE — see gi_fuse_flags; measurement knobs: GI_GEMM_XCD_REMAP, GI_GEMM_LOG,
- *     GI_WGRAD_WGS, GI_WGRAD_KICK, GI_WGRAD_INLINE, GI_HOLD_NODE_WGRADS, GI_CHAIN*, GI_GRU_FUSED).
+ *     timing-disabled hipEvents used to order the backward's two streams, the test / measurement hooks
+ *     gi_gemm_config and gi_mlp_chain_config, and four switches read once from the environment:
+ *       GI_FUSE=<mask>          launch-count reductions (gi_fuse_flags, default 15)
+ *       GI_CHAIN=0              per-bond-type stacks layer by layer through gi_gemm instead of gi_mlp_chain
+ *       GI_GEMM_PERSIST=<t>     persistent tile-stream grid for GEMM launches of >= t/10 rounds (default 0: off)
+ *       GI_GEMM_LOG=<file>      one line per GEMM launch (tools/gemm_launch_report.py)
  */
 #ifndef GRAPHINVENT_AMD_H
 #define GRAPHINVENT_AMD_H
@@ -29,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GI_ABI_VERSION 8
+#define GI_ABI_VERSION 9
 #define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
 #define GI_MAX_NODES 128      /* max max_n_nodes */
 #define GI_P0_MAX_CLASSES 256 /* max distinct node feature rows for the pass-0 shortcut */
@@ -133,13 +136,6 @@ typedef struct gi_graph {
 #define GI_EPI_ACCUM   8   /* v += C[row,col]                                */
 #define GI_GEMM_SPLITK 16  /* reduction range partitioned by groups/splits; C is a slab set */
 #define GI_EPI_MULACT  64  /* v *= act[row,col] (a stored factor: AlphaDropout training mode) */
-#define GI_GEMM_REDUCE 128 /* with GI_GEMM_SPLITK: the workgroup that finishes an output tile LAST (per-tile
-                            * arrival counter red_count, zero before the launch) sums the tile's slabs in
-                            * split order and writes the result: column ones_col to red_db[row], the others
-                            * to red_dW[row * red_ldw + col]; added to what is there when red_accum.
-                            * Deterministic (the order of arrival only decides who sums).  Grouped
-                            * problems pass the per-group destinations in Bg[g] (dW) and biasg[g] (db),
-                            * which carry no operands in split-K mode. */
 
 typedef struct gi_gemm_params {
     const float* A; const float* B; float* C;
@@ -157,9 +153,6 @@ typedef struct gi_gemm_params {
     long long c_split_stride;             /* floats between split slabs */
     const float* Bg[GI_MAX_GROUPS]; const float* biasg[GI_MAX_GROUPS]; float* Cg[GI_MAX_GROUPS];
     int gsplit[GI_MAX_GROUPS];            /* grouped split-K: slabs of group g (>= 1 each); nsplit ignored */
-    /* GI_GEMM_REDUCE (see the flag): destinations, arrival counters [groups * row tiles * col tiles] */
-    float* red_dW; float* red_db; int* red_count;
-    int red_ldw, red_accum;
 } gi_gemm_params;
 
 int gi_gemm(const gi_gemm_params* p, void* stream);
@@ -213,14 +206,6 @@ typedef struct {
     long long image_stride;               /* floats per group in the image; 0 = that of THESE layers.
                                              A chain that runs only the first layers of a packed
                                              stack passes the stride of the full pack. */
-    /* backward only, optional (seg_vals != NULL): the chain's input is first FORMED in place,
-     *   X[r, c] = selu'(X[r, c]) * sum_{k in [seg_off[r], seg_off[r+1])} seg_vals[seg_idx[k], c],  c < layer[0].K
-     * — exactly gi_seg_sum_dselu(seg_vals, ld_seg, seg_idx, seg_off, rows, K, X, ldx) in front of the chain (same
-     * summation order, bit for bit), folded into the workgroup's input load; X is WRITTEN (the last layer's
-     * weight gradient reads it).  Needs x_idx == NULL, layer[0].K % 4 == 0, ldx % 4 == 0, ld_seg % 4 == 0,
-     * ld_seg >= K, X and seg_vals 16-byte aligned (GI_EINVAL otherwise). */
-    const float* seg_vals; int ld_seg;
-    const int* seg_idx; const int* seg_off;
 } gi_chain_params;
 
 /* The kernel streams the weights as a pre-packed image (one linear stream of 32 KB LDS tile images per
@@ -231,6 +216,12 @@ long long gi_mlp_chain_image_floats(const gi_chain_params* p);
 int gi_mlp_chain_pack(const gi_chain_params* chains, int nchains, void* stream);
 /* nchains (1 or 2, same direction) independent chains in one launch; `image` must be packed. */
 int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* stream);
+/* Test / measurement hook (process-wide; the launcher's own choices are tile_rows = 0, rows64 = -1, ring = 2,
+ * trace = NULL): tile_rows in 32..36 forces the row-block height (32 MFMA rows + extra rows on the VALU);
+ * rows64 = 1 / 0 forces / forbids the 64-row variant (-1: where it pays); ring = 3 streams the weights of
+ * 32-row blocks through a three-slot ring (146 KB of LDS; 2: two slots, 114 KB, a GEMM workgroup fits beside it);
+ * trace = device buffer of 16 int64 per workgroup for per-phase timestamps (tools/trace_chain.py). */
+int gi_mlp_chain_config(int tile_rows, int rows64, int ring, void* trace);
 
 /* ------------------------------------------------------------------------------------------
  * Graph / pointwise kernels
@@ -326,31 +317,6 @@ int gi_compress_slots_f(float* t1, int ldt, const int* cidx, int B, int N, int W
  * the feature tail [H,H+Fn) copied); gi is overwritten with (r|z|n), gh keeps W_hn h + b_hn. */
 int gi_gru_gates_fwd(float* gi, float* gh, int ldg, const float* hx_prev, float* hx_new, int ldh,
                      const int* seg_off, int rows, int H, int Fn, void* stream);
-/* Fused aggregation + GRU update of one message pass — `torch.matmul(message_summation_matrix,
- * message_terms)` (gnn/summation_mpnn.py:141) and `self.gru(messages, nodes)` (gnn/mpnn.py:296-297) in
- * one launch: a_v = sum of the rows m[in_perm[k]] of v's dst-CSR segment (written to `agg`; with
- * agg_ready != 0 `agg` already holds the aggregate — pass-0 rows, attention), both GRUCell
- * projections and the gates.  Outputs exactly what gi_gru_gates_fwd leaves behind: hx_new, gi = (r|z|n)
- * and gh[:, 2H:3H] = W_hn h + b_hn for rows with an incoming edge.  H, M <= GI_GRU_MAXW, else GI_ELIMIT. */
-#define GI_GRU_MAXW 128
-typedef struct {
-    const float* m; int ldm;              /* message rows [U, ldm] (unused when agg_ready) */
-    const int* in_perm; const int* seg_off;
-    float* agg; int ldagg;                /* [R, ldagg] */
-    int agg_ready;
-    const float* hx_prev; float* hx_new; int ldhx;
-    const float* W_ih; const float* W_hh; const float* b_ih; const float* b_hh;
-    float* gi; float* gh; int ldg;        /* [R, ldg >= 3H] */
-    int R, H, M;
-    long long* trace;                     /* measurement aid, set by the library (GI_GRU_TRACE); pass NULL */
-    float* image;                         /* packed W_ih | W_hh image, gi_gru_image_floats(H, M) floats,
-                                             16-byte aligned, written by gi_gru_pack (needs W_ih, W_hh,
-                                             H, M, image); valid until the weights change */
-} gi_gru_params;
-long long gi_gru_image_floats(int H, int M);
-int gi_gru_pack(const gi_gru_params* p, void* stream);
-int gi_gru_fused_fwd(const gi_gru_params* p, void* stream);
-
 /* In: dh_new (+ up to three more partial gradients dh_b/c/d or NULL, all [rows, lddh]);
  * gi=(r|z|n), gh=(..|..|hn) from forward are overwritten with d gi, d gh;
  * dh_prev = direct part of the gradient to h_prev. */
@@ -360,7 +326,7 @@ int gi_gru_gates_bwd(float* gi, float* gh, int ldg, const float* hx_prev, int ld
 
 /* Launch-count reductions of the training step.  gi_fuse_flags() = the bit mask (environment GI_FUSE,
  * default GI_FUSE_DEFAULT) of the fused / vectorised variants gi_ggnn_forward / gi_ggnn_backward use.
- * DH_SCATTER, TIER2_DSELU, SLOTS and CHAIN_DM reproduce the launches they replace bit for bit (same
+ * DH_SCATTER, TIER2_DSELU and SLOTS reproduce the launches they replace bit for bit (same
  * operations, same summation orders; tests/test_kernels_gpu.py compares them with torch.equal); GATES_V4
  * evaluates the same formulas four hidden units at a time and agrees with the scalar kernels to rounding
  * (hipcc contracts the multiply-adds of the vector code differently: <= 1e-6 relative, same test file).
@@ -370,19 +336,13 @@ int gi_gru_gates_bwd(float* gi, float* gh, int ldg, const float* hx_prev, int ld
  *                `nodes[edge_batch_nghb_idc]`, gnn/summation_mpnn.py:131-133) folded into the
  *                gi_gru_gates_bwd_ex launch of the next (earlier) message pass
  *   TIER2_DSELU  the SELU backward of the three logit column ranges in one launch (gi_selu_bwd_cols3_f)
- *   SLOTS        fAddNet1 / fConnNet1 glue in one launch each way (gi_expand_slots2, gi_compress_slots2_f)
- *   CHAIN_DM     the backward of the aggregation onto message rows (gi_seg_sum_dselu) inside the dZ-chain
- *                launch that consumes it (gi_chain_params.seg_vals) */
+ *   SLOTS        fAddNet1 / fConnNet1 glue in one launch each way (gi_expand_slots2, gi_compress_slots2_f) */
 #define GI_FUSE_GATES_V4    1
 #define GI_FUSE_DH_SCATTER  2
 #define GI_FUSE_TIER2_DSELU 4
 #define GI_FUSE_SLOTS       8
-#define GI_FUSE_CHAIN_DM    16   /* gi_seg_sum_dselu in front of a dZ chain folded into the chain launch
-                                    (gi_chain_params.seg_vals) */
-/* Measured on the headline step (tools/ab/ab_run39.sh, two A/B pairs): 15 -> 2.319 / 2.325 ms against
- * 2.359 / 2.353 with everything off; + CHAIN_DM 2.328 / 2.352 (its three dependent loads per row lengthen the
- * chain workgroup's prologue by about what the saved launch cost; ZINC shape 5.01 vs 4.98 ms, ChEMBL shape
- * 3.82 vs 3.85) -> CHAIN_DM stays opt-in. */
+/* Measured on the headline step (round 2, two A/B pairs): 15 -> 2.319 / 2.325 ms against 2.359 / 2.353 with
+ * everything off. */
 #define GI_FUSE_DEFAULT     15
 int gi_fuse_flags(void);
 /* gi_gru_gates_bwd with d h = dh_new + sum over the source-CSR segment [sc_off[r], sc_off[r+1]) of the rows
@@ -556,34 +516,7 @@ int gi_ggnn_backward(const gi_ggnn_dims* d, const float* const* params, const gi
 int gi_ggnn_backward_phase(const gi_ggnn_dims* d, const float* const* params, const gi_graph* g,
                            float* ws, float* slabs, const float* y_out, int ldout,
                            const float* d_out, int lddout, float* const* grads, void* stream,
-                           void* side_stream, int phase, const float* wt);
-/* Pipelined readout update (opt-in, single process): the readout's parameters (gather + APDReadout, the
- * contiguous tail params[gi_ggnn_first_readout_param() ..), 86 % of the weights) are read by neither the
- * backward's message passes nor the NEXT forward's message passes, and their weight gradients only feed the
- * optimizer.  gi_ggnn_backward_ex with readout_stream != NULL (phase must be GI_BWD_ALL) enqueues those
- * weight-gradient GEMMs and their slab reductions on `readout_stream` — ordered after their operands by
- * events, never waited for by `stream` — so on return only the gradients of params[0 .. first_readout_param)
- * are ordered before later work on `stream`; the caller runs the optimizer for the tail on `readout_stream`,
- * records an event there and passes it to the next gi_ggnn_forward_ex, which makes `stream` wait for it in
- * front of the readout (after the message passes).  Buffers the tail work reads (ws, slabs, grads) must stay
- * alive until that event.  readout_stream == NULL / readout_ready == NULL: exactly gi_ggnn_backward_phase /
- * gi_ggnn_forward. */
-int gi_ggnn_forward_ex(const gi_ggnn_dims* d, const float* const* params, const gi_graph* g,
-                       float* ws, float* out, int ldout, void* stream, void* readout_ready);
-int gi_ggnn_backward_ex(const gi_ggnn_dims* d, const float* const* params, const gi_graph* g,
-                        float* ws, float* slabs, const float* y_out, int ldout,
-                        const float* d_out, int lddout, float* const* grads, void* stream,
-                        void* side_stream, void* readout_stream, int phase, const float* wt);
-/* Optional transposed weight copies for the backward's dgrad GEMMs (`wt` above, may be NULL):
- * gi_ggnn_wt_floats() floats; gi_ggnn_transpose_weights() writes WT[n_in][r4(n_out)] of every weight
- * matrix of params (one batched launch sequence, e.g. on a side stream during the forward).  With
- * them every dgrad runs as a forward-type GEMM (contiguous-k B operand). */
-long long gi_ggnn_wt_floats(const gi_ggnn_dims* d);
-int gi_ggnn_transpose_weights(const gi_ggnn_dims* d, const float* const* params, float* wt,
-                              void* stream);
-typedef struct gi_transpose_desc { const float* src; float* dst; int rows, cols, ldd; } gi_transpose_desc;
-/* dst[c, r] = src[r, c] for n row-major matrices src[rows, cols] -> dst[cols, ldd] */
-int gi_transpose_batch(const gi_transpose_desc* descs, int n, void* stream);
+                           void* side_stream, int phase);
 int gi_ggnn_first_readout_param(const gi_ggnn_dims* d);
 
 #ifdef __cplusplus

@@ -258,3 +258,32 @@ def mask_pin_from_hip(dims, graph, ws, B: int, big: float) -> MaskQuantumPin:
     from graphinvent_amd import ops
     en = ops.ws_view(ws, dims, graph, "en", graph.S + 1)[:, :dims.G].cpu()
     return MaskQuantumPin(en, graph.cidx.cpu().numpy(), B, dims.N, big)
+
+
+def assert_masked_rows_are_quantum_ties(O, model, cfg, P, n8, e8, out, model_name: str = "GGNN", tol: float = 1e-4):
+    """For a forward of the HIP `model` on (n8, e8) with logits `out`: the rows of fully-masked graphs, which the
+    goldens / the plain oracle only bound at 5e-3 (fl32(e - 1e6) energy quantisation, gnn/modules.py:47-48), agree
+    with the oracle at `tol` once the oracle takes the quanta the HIP forward computed (MaskQuantumPin): every
+    difference beyond 1e-4 on those rows is a 1/16 quantum tie and nothing else.  Runs one more (no_grad) HIP
+    forward through ggnn_forward_raw to read the energies back.  Returns the pin (books)."""
+    from graphinvent_amd import lib as L
+    from graphinvent_amd.gnn import mpnn
+    kind = L.KIND_ATTGGNN if model_name == "AttGGNN" else L.KIND_GGNN
+    dev = next(model.parameters()).device
+    nodes = torch.from_numpy(np.ascontiguousarray(n8)).float().to(dev)
+    edges = torch.from_numpy(np.ascontiguousarray(e8)).float().to(dev)
+    with torch.no_grad():
+        out2, (dims, graph, ws) = mpnn.ggnn_forward_raw(model.constants, nodes, edges, list(model.parameters()), kind)
+    out = torch.as_tensor(out).detach().float().cpu()
+    assert torch.equal(out2.cpu(), out), "the HIP forward is deterministic: same logits as the caller's"
+    pin = mask_pin_from_hip(dims, graph, ws, n8.shape[0], cfg["big_positive"])
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).float()
+    ref = oracle_quantum_pinned_logits(O, P, cfg, t(n8), t(e8), pin, model_name)
+    masked = np.nonzero(~e8.reshape(e8.shape[0], -1).any(1))[0]
+    assert pin.graphs == len(masked)
+    if len(masked):
+        scale = max(float(ref.abs().max()), 1e-30)
+        err = float((out[masked] - ref[masked]).abs().max()) / scale
+        assert err < tol, err
+        assert pin.max_steps <= 1 and pin.max_de < 2e-5, (pin.max_steps, pin.max_de)
+    return pin

@@ -117,6 +117,7 @@ def test_golden_att_tiny_vs_reference_outputs(golden_dir):
     live = np.setdiff1d(np.arange(out.shape[0]), masked)
     assert rel(out[live], g["logits"][live]) < TOL
     assert rel(out[masked], g["logits"][masked]) < 5e-3       # fl32(e - 1e6) quantisation, SURVEY §7
+    pins.assert_masked_rows_are_quantum_ties(O, model, cfg, P, g["nodes"], g["edges"], out, MODEL)   # pinned: 1e-4
     assert abs(loss - float(g["loss"])) < 1e-3 * abs(float(g["loss"]))
     worst = max((rel(grads[k], g["grad." + k]), k) for k in grads)
     assert worst[0] < 2e-3, worst
@@ -232,6 +233,7 @@ def test_batch_without_any_edge_and_module_surface():
     t = lambda x: torch.from_numpy(x).float()
     o32, l32, g32 = O.forward_backward(P, cfg, t(n8), t(e8), t(a8), model=MODEL)
     assert rel(out, o32) < 5e-3                                # fully masked graphs only
+    pins.assert_masked_rows_are_quantum_ties(O, model, cfg, P, n8, e8, out, MODEL)
     for k in grads:
         if k.startswith(("msg_nns", "att_nns", "gru")):
             assert float(grads[k].abs().max()) == 0.0, k       # untouched weights: exactly zero
@@ -253,37 +255,30 @@ def test_batch_without_any_edge_and_module_surface():
     ("gdb13", 1000, dict(hidden_node_features=128, message_size=128)),
 ])
 def test_bench_batch_gradients_1e4_vs_fp32_oracle_autograd(shape, B, over):
-    """AttentionGGNN at the bench batches against the oracle itself: logits / loss 1e-4 vs the plain
-    fp32 oracle, every gradient tensor 1e-4 vs the fp32 oracle's own autograd with the SELU branches
-    of the HIP forward (tests/pins.py); the pin touches < 1e-6 of the activations."""
+    """AttentionGGNN on the benchmark's own batches (fully-masked graphs included) against the oracle itself with
+    the SELU-branch and masked-energy-quantum pins: tests/test_model_gpu.py::assert_parity_with_both_pins."""
+    from tests.test_model_gpu import assert_parity_with_both_pins
     old = torch.get_num_threads()
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
     try:
         sh = synthetic.SHAPES[shape]
         cfg = O.shaped_config(sh["n_atom_types"], sh["n_formal_charge"], sh["max_n_nodes"], **over)
         P = O.init_params(cfg, seed=4, model=MODEL)
-        n8, e8, a8 = live_only(*synthetic.make_batch(B + B // 10 + 8, **sh, seed=23))
-        n8, e8, a8 = n8[:B], e8[:B], a8[:B]
-        assert n8.shape[0] == B
+        n8, e8, a8 = synthetic.make_batch(B, **sh, seed=0)      # bench.py's batch 0 of rank 0, as it is
+        assert len(fully_masked_rows(e8)) >= B // 50
         model = make_model(cfg, P)
         params = list(model.parameters())
         nodes, edges, tgt = to_dev(n8, e8, a8)
         out, tape_hip = mpnn.ggnn_forward_raw(model.constants, nodes, edges, params, L.KIND_ATTGGNN)
         dims, graph, ws = tape_hip
         signs = pins.signs_from_hip(dims, graph, ws, out, attn=True)
+        mask_pin = pins.mask_pin_from_hip(dims, graph, ws, n8.shape[0], cfg["big_positive"])
         g = pins.graph_arrays(graph)
         o_leaf = out.detach().clone().requires_grad_(True)
         loss = O.kl_loss(o_leaf, tgt)
         loss.backward()
         grads, _ = mpnn.ggnn_backward_raw(tape_hip, out, o_leaf.grad, params)
-        t = lambda x: torch.from_numpy(x).float()
-        o32, l32, g32, flipped, total = pins.oracle_pinned(O, P, cfg, t(n8), t(e8), t(a8), signs, g,
-                                                           MODEL)
+        names = [k for k, _ in model.named_parameters()]
+        assert_parity_with_both_pins(O, P, cfg, MODEL, n8, e8, a8, out, loss, names, grads, signs, g, mask_pin)
     finally:
         torch.set_num_threads(old)
-    assert flipped < 1e-6 * total, (flipped, total)
-    assert rel(out, o32) < TOL
-    assert abs(float(loss) - float(l32)) < TOL * abs(float(l32))
-    names = [k for k, _ in model.named_parameters()]
-    worst = max((rel(gr, g32[k]), k) for k, gr in zip(names, grads))
-    assert worst[0] < TOL, worst

@@ -1,0 +1,64 @@
+"""-m gpu: `bench.py --gpus N` as the driver launches it (python -m torch.distributed.run, one rank per GPU), so
+that the first 8-GPU execution of the multi-rank branch is a re-run: the `allreduce` report, the cross-rank
+weight checksum and the three extra timed legs that toggle the exchange.  On a 1-GPU box the two ranks share the
+device over gloo (a control-flow test, not a measurement); with >= 2 devices the same scenario runs over nccl
+(RCCL), one rank per device.  Reference counterpart: none (Workflow.py:289-290 trains in one process)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_bench(world: int, backend: str, extra=()):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", backend, "--steps", "3",
+           "--warmup", "1", "--no-extra-configs", "--no-one-stream", "--no-cpu-baseline", "--no-probe",
+           "--no-forward-only", *extra]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]                # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def _check(d, world: int, backend: str):
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["warmup"] == 1
+    assert d["scaling"] == "weak" and d["unit"] == "graphs/s" and d["higher_is_better"] is True
+    assert d["config"]["global_batch"] == 1000 * world and d["config"]["parallelism"] == f"dp{world}"
+    assert d["value"] > 0 and abs(d["value"] - 1000 * world * 3 / (d["ms_per_step"] * 3e-3)) < 0.01 * d["value"]
+    loss = d["config"]["loss"]
+    assert loss == loss and 0 < loss < 100                   # finite (the run aborts on a diverged checksum)
+    ar = d["allreduce"]
+    assert ar["ranks_seen"] == world and len(ar["ranks"]) == world and ar["backend"] == backend
+    for k in ("ms_per_step_overlapped", "ms_per_step_after_backward", "ms_per_step_without_exchange",
+              "exposed_ms_overlapped", "exposed_ms_after_backward"):
+        assert isinstance(ar[k], float) and ar[k] == ar[k], k
+    assert ar["bucket_MB"] > 20
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["bound"] == "mfma"
+    assert "overlapped" in d["config"]["allreduce"]
+
+
+def test_bench_two_ranks_gloo_sharing_the_gpu():
+    d = _run_bench(2, "gloo")
+    _check(d, 2, "gloo")
+    assert "smoke test" in d["config"]["backend"]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL, one rank per device)")
+def test_bench_two_ranks_rccl():
+    _check(_run_bench(2, "nccl"), 2, "nccl")

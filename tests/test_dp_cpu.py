@@ -78,30 +78,6 @@ def test_sharded_sampler_covers_block_in_lockstep():
     assert not np.array_equal(np.concatenate(list(samplers[0])), seen[0])
 
 
-def test_pipelined_readout_update_is_gated_off_without_the_hip_model(monkeypatch):
-    """GI_PIPELINE_READOUT=1 / pipeline_readout=True only take effect for the HIP model with FusedAdam in one
-    process (dp.DataParallel): any other model / optimizer trains exactly as before, flush() is a no-op."""
-    monkeypatch.setenv("GI_PIPELINE_READOUT", "1")
-    cfg = O.make_config(**TINY)
-    nodes, edges, tgt = _batch(7)
-    ref = O.OracleGGNN(cfg, seed=3)
-    opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
-    for _ in range(2):
-        out = ref(nodes, edges)
-        opt.zero_grad()
-        apd_kl_loss(out, tgt).backward()
-        opt.step()
-    model = O.OracleGGNN(cfg, seed=3)
-    tr = dp.DataParallel(model, torch.optim.Adam(model.parameters(), lr=1e-3), loss_fn=apd_kl_loss,
-                         pipeline_readout=True)
-    assert tr.pipeline_readout is False
-    for _ in range(2):
-        tr.step(nodes, edges, tgt)
-    tr.flush()
-    for a, b in zip(model.parameters(), ref.parameters()):
-        assert torch.equal(a, b)
-
-
 def test_registered_unit_gradient_is_forgotten_with_its_tensor():
     import gc
     from graphinvent_amd import loss as gl

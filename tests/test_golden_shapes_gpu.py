@@ -47,6 +47,8 @@ def test_hip_models_match_reference_outputs(golden_dir, name):
     assert rel(out[live], g["logits"][live]) < TOL
     if masked.size:
         assert rel(out[masked], g["logits"][masked]) < 5e-3
+        from tests import pins
+        pins.assert_masked_rows_are_quantum_ties(O, model, cfg, P, g["nodes"], g["edges"], out, kind)
     assert abs(float(loss) - float(g["loss"])) < 1e-3 * abs(float(g["loss"]))
     num = den = 0.0
     worst = (0.0, "")

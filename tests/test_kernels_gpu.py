@@ -109,6 +109,17 @@ def test_compact_rejects_non_onehot_edges():
 TILES = [(1, 1), (1, 2), (2, 2)]
 
 
+@pytest.fixture
+def chain_cfg():
+    """gi_mlp_chain_config for one test (row-block height, 64-row variant, weight ring), reset afterwards."""
+    lib = L.load()
+
+    def set_cfg(tile_rows=0, rows64=-1, ring=2):
+        L.check(lib.gi_mlp_chain_config(tile_rows, rows64, ring, None), "gi_mlp_chain_config")
+    yield set_cfg
+    lib.gi_mlp_chain_config(0, -1, 2, None)
+
+
 @pytest.fixture(params=[0, 3], ids=["wg-per-tile", "tile-loop-3wgs"])
 def gemm_grid(request):
     """Every gi_gemm launch is a tile loop; launches with more tiles than the device holds workgroups run as a
@@ -284,11 +295,11 @@ def test_mlp_chain_two_chains_one_launch():
     ((100, 250, 250, 100), [0, 33, 34, 131]),
     ((37, 256, 7, 130), [0, 70]),
 ])
-def test_mlp_chain_taller_row_blocks(monkeypatch, tile_rows, sizes, off):
+def test_mlp_chain_taller_row_blocks(chain_cfg, tile_rows, sizes, off):
     """Row blocks of 32 + x rows (x <= 4 extra rows computed on the VALU; what the launcher picks when
     it saves a round of workgroups): forced here so that every height is exercised on ragged groups —
     blocks with 0, some and all of their extra rows valid."""
-    monkeypatch.setenv("GI_CHAIN_TILE_ROWS", str(tile_rows))
+    chain_cfg(tile_rows=tile_rows)
     _chain_case(sizes, off, seed=tile_rows + sum(sizes))
     _chain_case(sizes, off, seed=tile_rows, two=True)
 
@@ -299,11 +310,11 @@ def test_mlp_chain_taller_row_blocks(monkeypatch, tile_rows, sizes, off):
     ((100, 250, 250, 250, 250, 100), [0, 1000, 1001, 2500]),
     ((37, 256, 7, 130), [0, 70]),
 ])
-def test_mlp_chain_64_row_blocks(monkeypatch, sizes, off):
+def test_mlp_chain_64_row_blocks(chain_cfg, sizes, off):
     """The <2, 2> variant (64 rows per workgroup, two weight tiles in LDS; what the launcher picks for
     batches of several rounds of row blocks), forced here on ragged groups: full blocks, a 1-row group, an
     empty group, blocks whose second half is partly / completely out of range — forward and dZ chain."""
-    monkeypatch.setenv("GI_CHAIN_ROWS64", "1")
+    chain_cfg(rows64=1)
     _chain_case(sizes, off, seed=64 + sum(sizes))
     _chain_case(sizes, off, seed=64, two=True)
 
@@ -314,157 +325,13 @@ def test_mlp_chain_64_row_blocks(monkeypatch, sizes, off):
     ((100, 250, 250, 100), [0, 33, 34, 131]),
     ((37, 256, 7, 130), [0, 70]),
 ])
-def test_mlp_chain_three_slot_ring(monkeypatch, tile_rows, sizes, off):
+def test_mlp_chain_three_slot_ring(chain_cfg, tile_rows, sizes, off):
     """gi_chain_kernel<BWD, 1, 3>: 32-row blocks with the three-slot weight ring (146 KB of LDS) — the default
-    until round 3, now the GI_CHAIN_RING=3 measurement knob (the two-slot ring, 114 KB, lets a GEMM workgroup
-    share the CU and is what every other chain test runs)."""
-    monkeypatch.setenv("GI_CHAIN_RING", "3")
-    if tile_rows:
-        monkeypatch.setenv("GI_CHAIN_TILE_ROWS", str(tile_rows))
+    until round 3, now gi_mlp_chain_config(ring = 3) for measurements (the two-slot ring, 114 KB, lets a GEMM
+    workgroup share the CU and is what every other chain test runs)."""
+    chain_cfg(ring=3, tile_rows=tile_rows or 0)
     _chain_case(sizes, off, seed=2 + sum(sizes))
     _chain_case(sizes, off, seed=2, two=True)
-
-
-def _chain_seg_case(sizes, off, seed, two=False):
-    """dZ chain whose input is formed in place by the fused segmented sum (gi_chain_params.seg_vals)
-    against gi_seg_sum_dselu + the plain dZ chain: every dZ buffer, the first-layer input gradient AND the
-    written-back input rows bit-identical.  Segments of 0..5 entries, an empty last segment."""
-    lib = L.load()
-    g = torch.Generator().manual_seed(seed)
-    G = len(off) - 1
-    E, V = off[-1], 211
-    offt = torch.tensor(off, dtype=torch.int32).to(DEV)
-    rows_g = [off[t + 1] - off[t] for t in range(G)]
-    L_ = len(sizes) - 1
-    K0 = sizes[-1]
-    ldz = ops.r4(K0)
-    lens = torch.randint(0, 6, (E,), generator=g)
-    lens[-1] = 0
-    seg_off = torch.zeros(E + 1, dtype=torch.int32)
-    seg_off[1:] = torch.cumsum(lens, 0).int()
-    nnz = int(seg_off[-1])
-    seg_idx = torch.randint(0, V, (max(nnz, 1),), generator=g, dtype=torch.int32)
-    seg_off_d, seg_idx_d = seg_off.to(DEV), seg_idx.to(DEV)
-    nchains = 2 if two else 1
-    results = []
-    chains = []
-    for c in range(nchains):
-        Ws = [[(torch.randn(o, i, generator=g) / i ** 0.5).to(DEV) for _ in range(G)]
-              for i, o in zip(sizes, sizes[1:])]
-        acts = [D.selu(torch.randn(E, ops.r4(sizes[l]), generator=g)).to(DEV) for l in range(1, L_)]
-        vals = torch.randn(V, ldz + 4, generator=g)[:, :ldz + 4].to(DEV)
-        y = D.selu(torch.randn(E, ldz, generator=g))
-        chains.append((Ws, acts, vals, y))
-    for fused in (False, True):
-        specs, keep = [], []
-        for Ws, acts, vals, y in chains:
-            X = y.clone().to(DEV)
-            if not fused:
-                L.check(lib.gi_seg_sum_dselu(vals.data_ptr(), vals.stride(0), seg_idx_d.data_ptr(),
-                                             seg_off_d.data_ptr(), E, K0, X.data_ptr(), X.stride(0),
-                                             _stream()), "seg_sum_dselu")
-            douts = [torch.full((E, ops.r4(sizes[l]) + 4), 7.0, device=DEV) for l in range(L_)]
-            layers = [dict(W=Ws[l], out=douts[l], act=acts[l - 1] if l > 0 else None, K=sizes[l + 1],
-                           N=sizes[l]) for l in range(L_ - 1, -1, -1)]
-            spec = dict(X=X, x_idx=None, grp_off=offt, group_rows=rows_g, rows=E, layers=layers)
-            if fused:
-                spec["seg"] = dict(vals=vals, idx=seg_idx_d, off=seg_off_d)
-            specs.append(spec)
-            keep.append([X] + douts)
-        ops.mlp_chain(specs, backward=True)
-        results.append(keep)
-    for ka, kb in zip(*results):
-        for i, (a, b) in enumerate(zip(ka, kb)):
-            assert torch.equal(a, b), i
-    # the segmented sum itself against fp64 (first chain)
-    _, _, vals, y = chains[0]
-    want = D.seg_sum(vals[:, :K0].double().cpu(), seg_idx[:max(nnz, 1)], seg_off, E) * \
-        D.selu_grad_from_out(y[:, :K0].double())
-    assert rel(results[1][0][0][:, :K0], want) < 1e-6
-
-
-@pytest.mark.parametrize("sizes,off", [
-    ((128, 250, 250, 250, 250, 128), [0, 600, 600, 777]),
-    ((100, 250, 250, 100), [0, 33, 34, 131]),
-    ((16, 24, 12), [0, 5, 7, 8]),
-])
-def test_mlp_chain_backward_with_fused_segmented_sum(sizes, off):
-    _chain_seg_case(sizes, off, seed=sum(sizes))
-    _chain_seg_case(sizes, off, seed=7, two=True)
-
-
-@pytest.mark.parametrize("knob,value", [("GI_CHAIN_TILE_ROWS", "34"), ("GI_CHAIN_TILE_ROWS", "36"),
-                                        ("GI_CHAIN_ROWS64", "1")])
-def test_mlp_chain_fused_segmented_sum_block_heights(monkeypatch, knob, value):
-    monkeypatch.setenv(knob, value)
-    _chain_seg_case((128, 250, 250, 250, 250, 128), [0, 600, 600, 777], seed=11)
-    _chain_seg_case((100, 250, 250, 100), [0, 1000, 1001, 2500], seed=12, two=True)
-
-
-def test_mlp_chain_fused_segmented_sum_argument_checks():
-    lib = L.load()
-    z = torch.zeros(128, 132, device=DEV)       # big enough for the weight pack of a 128 x 100 layer
-    i32 = torch.zeros(65, dtype=torch.int32, device=DEV)
-    spec = dict(X=z, x_idx=None, grp_off=None, group_rows=None, rows=64,
-                layers=[dict(W=[z], bias=[z], out=z, act=None, K=126, N=100)],
-                seg=dict(vals=z, idx=i32, off=i32))
-    with pytest.raises(RuntimeError):            # first K not a multiple of 4
-        ops.mlp_chain([spec], backward=True)
-    spec["layers"][0]["K"] = 128
-    with pytest.raises(RuntimeError):            # forward chains take no segmented input
-        ops.mlp_chain([spec], backward=False)
-
-
-@pytest.mark.parametrize("H,M,Fn", [(128, 128, 8), (100, 100, 8), (16, 12, 5), (24, 20, 8)])
-@pytest.mark.parametrize("agg_ready", [False, True])
-def test_gru_fused_forward(H, M, Fn, agg_ready):
-    """gi_gru_fused_fwd (segmented sum + both GRUCell projections + gates in one launch) against the
-    fp64 dataflow model on a real graph batch: rows without incoming edges keep their state, the zero
-    row stays zero, (r, z, n) / gh_n are saved for the backward, the feature tail is copied."""
-    n8, e8, _ = synthetic.make_batch(41, **synthetic.SHAPES["gdb13"], seed=9)
-    g = D.compact(n8, e8)
-    S, E, U = g["S"], g["E"], g["U"]
-    R = S + 1
-    gen = torch.Generator().manual_seed(H + M)
-    ldm, ldhx, ldg = ops.r4(M), ops.r4(H + Fn), ops.r4(3 * H)
-    m = torch.randn(U, ldm, generator=gen)
-    hx = torch.randn(R, ldhx, generator=gen)
-    hx[S] = 0
-    W_ih = torch.randn(3 * H, M, generator=gen) / M ** 0.5
-    W_hh = torch.randn(3 * H, H, generator=gen) / H ** 0.5
-    b_ih, b_hh = torch.randn(3 * H, generator=gen) * 0.2, torch.randn(3 * H, generator=gen) * 0.2
-    perm, off = torch.from_numpy(g["in_perm"]), torch.from_numpy(g["seg_off"])
-    agg_ref = D.seg_sum(m[:, :M].double(), perm, off, R)
-    has_edge = (off[1:R + 1] - off[:R]) > 0
-    gi_ref = D.linear(agg_ref, W_ih.double(), b_ih.double(), False)
-    gh_ref = D.linear(hx[:, :H].double(), W_hh.double(), b_hh.double(), False)
-    h_new, (r_, z_, n_, hn_) = D.gru_gates(gi_ref, gh_ref, hx[:, :H].double(), has_edge)
-    dev = lambda t: t.to(DEV)
-    agg = torch.full((R, ldm), 7.0, device=DEV)
-    if agg_ready:
-        agg[:, :M] = agg_ref.float().to(DEV)
-    hx_new = torch.full((R, ldhx), 7.0, device=DEV)
-    gi = torch.full((R, ldg), 7.0, device=DEV)
-    gh = torch.full((R, ldg), 7.0, device=DEV)
-    ops.gru_fused_fwd(dev(m), dev(perm), dev(off), agg, agg_ready, dev(hx), hx_new, dev(W_ih), dev(W_hh),
-                      dev(b_ih), dev(b_hh), gi, gh, R, H, M)
-    assert rel(agg[:, :M], agg_ref) < 1e-6
-    assert rel(hx_new[:, :H], h_new) < 2e-5
-    assert torch.equal(hx_new[:, H:].cpu(), hx[:, H:])                       # feature tail + padding
-    assert float(hx_new[S].abs().max()) == 0.0
-    e = has_edge.numpy()
-    for got, want in ((gi[:, :H], r_), (gi[:, H:2 * H], z_), (gi[:, 2 * H:3 * H], n_),
-                      (gh[:, 2 * H:3 * H], hn_)):
-        assert rel(got[e], want[e]) < 2e-5
-        assert bool((got[~e] == 7.0).all())                                 # untouched without edges
-    assert bool((gh[:, :2 * H] == 7.0).all())
-
-
-def test_gru_fused_limits_are_reported():
-    z = torch.zeros(8, 400, device=DEV)
-    off = torch.zeros(10, dtype=torch.int32, device=DEV)
-    with pytest.raises(RuntimeError, match="GI_ELIMIT"):
-        ops.gru_fused_fwd(z, off, off, z, False, z, z, z, z, z, z, z, z, 8, 129, 100)
 
 
 def test_class_sum_dselu_long_segments():
