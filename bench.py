@@ -26,6 +26,10 @@ Rank 0 prints one JSON line.  Besides the contract fields it carries
                 batch size) and on a 128x replicated graph batch whose message rows exceed the
                 256 MB Infinity Cache, against 8 TB/s HBM3E
   forward_only  no_grad forward rate on the same batches
+  generation_loop  forward + sampling step (softmax + draw + decode + validity: gi_sample_actions) per round on
+                ONE pair of input tensors rewritten in place between rounds — the GraphGenerator.build_graphs
+                pattern (GraphGenerator.py:118-157), which cannot prefetch graph_compact: host-sync-free
+                forward (model.sync_free) against the forward with the blocking 24-int read-back
   cpu_baseline  the oracle (CPU restatement of the reference algorithm, kind "port") on the host
                 cores at their best thread count, same workload, bounded sample; N == 1 only
 config.fuse_flags = the GI_FUSE launch-count reductions in use (include/graphinvent_amd.h, default 15).
@@ -192,6 +196,76 @@ def seg_sum_hbm_probe(device, M=128, replicas=128):
     nbytes = mrows * M * 4 + nnz * 4 + (rows + 1) * 4 + rows * M * 4
     return dict(rows=rows, nnz=nnz, message_rows=mrows, working_set_MB=round(mrows * M * 4 / 1e6, 1),
                 us=round(ms * 1e3, 2), GBps=round(nbytes / ms / 1e6, 1))
+
+
+def generation_loop(model, cfg, batches, device, rounds: int):
+    """One generation round = forward of the whole batch + one sampling launch, with the inputs MUTATED IN PLACE
+    between rounds (the generator keeps one `nodes` / `edges` pair and edits it, GraphGenerator.py:118-157), so
+    graph_compact cannot run one batch ahead.  Timed twice on the same rounds: model.sync_free (no read-back,
+    sizes on the device) and the ordinary forward (blocking read-back of graph_compact's 24 ints per round)."""
+    from graphinvent_amd.sampler import sample_actions_raw
+    nodes = batches[0][0].clone()
+    edges = batches[0][1].clone()
+    A = cfg["len_f_add_per_node"]
+    out = {}
+    model.eval()
+    with torch.no_grad():
+        for mode in ("sync_free", "blocking_readback"):
+            model.sync_free = mode == "sync_free"
+            rb0 = dict(ops.READBACKS)
+            for i in range(rounds + 3):
+                if i == 3:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                src = batches[i % len(batches)]
+                nodes.copy_(src[0]); edges.copy_(src[1])          # in place: the generator's own tensors
+                logits = model(nodes, edges)
+                n_nodes = (nodes.sum(2) != 0).sum(1).int()
+                sample_actions_raw(logits, n_nodes, edges, A)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            err = model.last_bounded_error() if model.sync_free else 0
+            out[mode] = {"ms_per_round": round(dt / rounds * 1e3, 3),
+                         "graphs_per_s": round(nodes.shape[0] * rounds / dt, 1),
+                         "readbacks": {k: ops.READBACKS[k] - rb0[k] for k in rb0}, "input_error_bits": err}
+        # the same round recorded ONCE as a hipGraph (possible because nothing in it waits for the device) and
+        # replayed: the host cost of a round drops to one graph launch
+        try:
+            model.sync_free = True
+            src_n, src_e = batches[0][0], batches[0][1]
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                n_nodes = (nodes.sum(2) != 0).sum(1).int()
+                sample_actions_raw(model(nodes, edges), n_nodes, edges, A)       # warm-up on the capture stream
+            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                logits = model(nodes, edges)
+                n_nodes = (nodes.sum(2) != 0).sum(1).int()
+                action, like, flags = sample_actions_raw(logits, n_nodes, edges, A)
+            for i in range(rounds + 3):
+                if i == 3:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                src = batches[i % len(batches)]
+                nodes.copy_(src[0]); edges.copy_(src[1])
+                g.replay()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out["sync_free_hipgraph"] = {"ms_per_round": round(dt / rounds * 1e3, 3),
+                                         "graphs_per_s": round(nodes.shape[0] * rounds / dt, 1),
+                                         "finite": bool(torch.isfinite(logits).all())}
+        except Exception as e:                                   # capture support differs between ROCm builds
+            out["sync_free_hipgraph"] = {"error": repr(e)[:200]}
+    model.sync_free = False
+    model.train()
+    out["rounds"] = rounds
+    out["note"] = ("forward (no_grad) + gi_sample_actions per round, B=%d, inputs rewritten in place between "
+                   "rounds; this rank only.  sync_free: no read-back, buffers sized for 4 B N directed edges "
+                   "(1.8x / 4x the real node / edge rows of these batches)" % nodes.shape[0])
+    return out
 
 
 def cpu_baseline(cfg, threads: int = 0, n_timed: int = 3):
@@ -486,6 +560,8 @@ def main():
         result["forward_only"] = {"value": round(BATCH * args.steps / fdt, 1), "unit": "graphs/s",
                                   "ms_per_step": round(fdt / args.steps * 1e3, 3),
                                   "note": "this rank only, no_grad forward of the same batches"}
+    if rank == 0 and not args.no_forward_only:
+        result["generation_loop"] = generation_loop(model, cfg, batches, device, rounds=max(args.steps, 10))
     barrier()
 
     # ---- the non-headline BASELINE configurations, observed by the same run ----------------------

@@ -53,7 +53,11 @@ struct ChainArgs {
     int tile_rows;                          // rows per workgroup: 32 .. 32 + CH_XMAX
     int tile_off[2][GI_MAX_GROUPS + 1];     // prefix of 32-row tiles over the groups of a chain
     int chain_off[3];                       // prefix of tiles over the chains
-    long long* trace;                       // measurement aid (GI_CHAIN_TRACE): 16 words per workgroup
+    long long* trace;                       // measurement aid (gi_mlp_chain_config): 16 words per workgroup
+    // bounded (host-sync-free) launch: the grid is sized from row BOUNDS, the block -> (group, row block) map
+    // is computed here from grp_off, and the row-block height comes from the device (gfix dims[1], 0: tile_rows)
+    int dev_tiles;
+    const int* tile_rows_dev;
 };
 
 __host__ __device__ inline int chain_tiles(const gi_chain_params& p) {
@@ -136,20 +140,37 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
     __shared__ __attribute__((aligned(1024))) float Bs[RING * CH_TILE];
     __shared__ float Xs[2 * CH_XMAX * CH_W];                 // extra rows: partial sums of the k halves
 
+    // A workgroup walks row blocks id = blockIdx.x, + gridDim.x, ...: ONE each in an ordinary launch (the grid is
+    // the number of row blocks); in a bounded launch the grid is capped at the number of CUs and the bound's
+    // surplus blocks cost an iteration of a few scalar loads instead of a 114 KB-LDS workgroup launch each
+    // (measured: 1 364 surplus workgroups per chain launch made the bounded forward 0.3 ms slower).
+    for (int id = blockIdx.x; id < args.chain_off[args.nchains]; id += gridDim.x) {
     // ---- which (chain, group, row block) -------------------------------------------------------
-    const int id = blockIdx.x;
     const int ci = (args.nchains > 1 && id >= args.chain_off[1]) ? 1 : 0;
     const gi_chain_params& P = args.c[ci];
     const int local = id - args.chain_off[ci];
-    int g = 0;
-    while (g < P.ngroups - 1 && local >= args.tile_off[ci][g + 1]) ++g;
+    int g = 0, first = 0;
+    const int tile_rows = args.tile_rows_dev ? __builtin_amdgcn_readfirstlane(max(*args.tile_rows_dev, CH_ROWS))
+                                             : args.tile_rows;
+    if (args.dev_tiles) {                                    // row blocks of the groups, counted on the device
+        for (; g < P.ngroups; ++g) {
+            const int rows = __builtin_amdgcn_readfirstlane(P.grp_off[g + 1] - P.grp_off[g]);
+            const int nb = (rows + tile_rows - 1) / tile_rows;
+            if (local < first + nb) break;
+            first += nb;
+        }
+        if (g == P.ngroups) continue;                        // beyond the real row blocks
+    } else {
+        while (g < P.ngroups - 1 && local >= args.tile_off[ci][g + 1]) ++g;
+        first = args.tile_off[ci][g];
+    }
     // (device loads land in VGPRs; readfirstlane tells the compiler the row range is wave-uniform,
     // so everything derived from it — buffer descriptors included — stays scalar)
     const int lo = P.grp_off ? __builtin_amdgcn_readfirstlane(P.grp_off[g]) : 0;
     const int hi = P.grp_off ? __builtin_amdgcn_readfirstlane(P.grp_off[g + 1]) : P.rows;
-    const int r0 = lo + args.tile_rows * (local - args.tile_off[ci][g]);
-    if (r0 >= hi) return;                                   // block-uniform, before any barrier
-    const int nvalid = min(hi - r0, args.tile_rows);        // rows of this block
+    const int r0 = lo + tile_rows * (local - first);
+    if (r0 >= hi) continue;                                 // block-uniform, before any barrier
+    const int nvalid = min(hi - r0, tile_rows);             // rows of this block
     const int nx = __builtin_amdgcn_readfirstlane(max(nvalid - MROWS, 0));     // on the VALU path
     const int L = P.nlayers;
     const long long t_start = args.trace ? (long long)wall_clock64() : 0;
@@ -404,12 +425,14 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
     }
 #undef GI_CHAIN_WAIT
     if (args.trace && threadIdx.x == 0) {   // 100 MHz wall clock: start, end, placement, rows, phases
-        long long* t = args.trace + 16 * (long long)blockIdx.x;
+        long long* t = args.trace + 16 * (long long)id;
         t[0] = t_start; t[1] = (long long)wall_clock64();
         t[2] = ((long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) << 8) |
                (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xff);   // HW_ID, XCC_ID
         t[3] = nvalid;
         for (int i = 0; i <= L && i <= GI_CHAIN_MAXL; ++i) t[4 + i] = t_phase[i];
+    }
+    __syncthreads();                        // every wave is done with this block's LDS before the next one's
     }
 }
 
@@ -533,6 +556,15 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
         h = std::min(std::max(g_chain_cfg.tile_rows, CH_ROWS), CH_ROWS + CH_XMAX);
         big = false;
     }
+    // bounded launch (tile_rows_dev != NULL): `rows` is the bound of the rows of all groups together; the grid
+    // covers cdiv(bound, 32) + ngroups row blocks and each workgroup finds its group and block on the device
+    const bool bounded = chains[0].tile_rows_dev != nullptr;
+    if (bounded) {
+        for (int c = 0; c < nchains; ++c)
+            if (!chains[c].tile_rows_dev || !chains[c].grp_off) return GI_EINVAL;
+        big = false; h = CH_ROWS;
+        a.dev_tiles = 1; a.tile_rows_dev = chains[0].tile_rows_dev;
+    }
     if (big) h = 2 * CH_ROWS;
     a.tile_rows = h;
     for (int c = 0; c < nchains; ++c) {
@@ -542,8 +574,9 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
         int t = 0;
         for (int g = 0; g < p.ngroups; ++g) {
             a.tile_off[c][g] = t;
-            t += gi_cdiv(p.ngroups > 1 ? p.group_rows[g] : p.rows, h);
+            if (!bounded) t += gi_cdiv(p.ngroups > 1 ? p.group_rows[g] : p.rows, h);
         }
+        if (bounded) t = gi_cdiv(p.rows, CH_ROWS) + p.ngroups;
         a.tile_off[c][p.ngroups] = t;
         total += t;
         for (int l = 0; l < p.nlayers; ++l)
@@ -556,7 +589,7 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
     a.trace = g_chain_cfg.trace;                            // per-workgroup timestamps (tools/trace_chain.py)
     hipStream_t st = (hipStream_t)stream;
     GiProfScope prof(st, GI_PROF_GEMM, flops);
-    const dim3 grid(total), block(512);
+    const dim3 grid(bounded ? std::min(total, ncu) : total), block(512);
     // 32-row blocks stream their weights through a TWO-slot ring (114 KB of LDS instead of 146 KB with three):
     // one workgroup of the GEMM family (37 KB) fits on the CU beside a chain workgroup, which is what the
     // weight-gradient stream needs to overlap with the chains (every overlap schedule of round 2 was bounded by

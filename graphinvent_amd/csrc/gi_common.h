@@ -36,6 +36,15 @@ static inline int gi_r4(int x) { return (x + 3) & ~3; }
 static inline long long gi_r4l(long long x) { return (x + 3) & ~3LL; }
 static inline int gi_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// ---- library-internal launchers of the bounded (host-sync-free) forward: the exported functions with the real
+// row count read on the device (rows_dev != NULL: `rows` only sizes the grid) ------------------------------
+int gi_seg_sum_n(const float* vals, int ldv, const int* perm, const int* off, int rows, int cols, float* out,
+                 int ldo, int accumulate, const int* rows_dev, void* stream);
+int gi_seg_softmax_fwd_n(const float* en, const float* emb, int ld, const int* perm, const int* off, int rows,
+                         int cols, float* out, int ldo, const int* rows_dev, void* stream);
+int gi_gru_gates_fwd_n(float* gi, float* gh, int ldg, const float* hx_prev, float* hx_new, int ldh,
+                       const int* seg_off, int rows, int H, int Fn, const int* rows_dev, void* stream);
+
 // ---- optional per-launch timing (bench.py roofline leg) -----------------------------------------
 // When enabled, gi_gemm / gi_seg_sum bracket each kernel launch with hipEvents on the launch
 // stream; gi_prof_collect synchronises and sums the elapsed times.  Off by default (zero cost).

@@ -34,6 +34,7 @@ namespace {
 
 struct Lay {
     int counts, type_off, cidx, node_mask, slot_of, seg_off, src_off, scratch, total;
+    int dims;           // device-side launch dimensions of a bounded (host-sync-free) forward, see gi_compact_bound
     // scratch sub-arrays (ints)
     int rowcnt, nmsg, active, seg_start, srcm_start, colcnt_t, cstart_t, mflag_t, mstart_t,
         etype_off, etype;
@@ -57,6 +58,7 @@ inline Lay make_layout(int B, int N, int Fe) {
     L.seg_off = take(ns + 2);
     L.src_off = take(ns + 2);
     L.type_off0 = take(GI_MAX_GROUPS + 1);
+    L.dims = take(GI_DIMS);
     L.scratch = o;
     L.rowcnt = take(ns);
     L.nmsg = take(ns);
@@ -338,10 +340,23 @@ __global__ __launch_bounds__(1024) void compact_p0_kernel(int Fe, int* __restric
 template <typename T, int NMAX>
 __global__ __launch_bounds__(256) void compact_fill_kernel(
     const T* __restrict__ nodes, int N, int Fn, int Fe, const int* __restrict__ gfix, Lay L,
-    int S, int E, int U, int* __restrict__ u_src, int* __restrict__ in_perm,
+    int S_in, int E_in, int U_in, int* __restrict__ u_src, int* __restrict__ in_perm,
     int* __restrict__ mu_off, int* __restrict__ mu_dst, int* __restrict__ mu_slot,
-    int* __restrict__ out_perm, float* __restrict__ hx0, int ldhx, int H, int D0,
+    int* __restrict__ out_perm, float* __restrict__ hx0, int ldhx, int H, int D0_in,
     int* __restrict__ d_src, float* __restrict__ cmat, int ldc0, int* __restrict__ e2d) {
+    // S_in < 0: bounded mode — the sizes are read from the counts on the device (gi_compact_bound has
+    // checked them against the bounds the buffers were sized with; after an overflow they are all 0 and
+    // only the zero rows are written)
+    const bool bounded = S_in < 0;
+    const int S = bounded ? gfix[L.counts + CNT_S] : S_in, E = bounded ? gfix[L.counts + CNT_E] : E_in;
+    const int U = bounded ? gfix[L.counts + CNT_U] : U_in, D0 = bounded ? gfix[L.counts + CNT_D0] : D0_in;
+    if (bounded && (gfix[L.counts + CNT_ERR] & 6)) {
+        if (blockIdx.x == 0) {
+            for (int col = threadIdx.x; col < ldhx; col += 256) hx0[col] = 0.f;     // row S = row 0
+            if (threadIdx.x == 0) mu_off[0] = 0;
+        }
+        return;
+    }
     __shared__ signed char typ[NMAX * NMAX];
     __shared__ int kpos[NMAX * NMAX];                    // dst-CSR slot of edge (i <- j)
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -395,10 +410,11 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
             for (int d = tid; d < D0; d += 256) d_src[d] = gfix[L.cidx + gfix[L.d_slot + d]];
             for (int d = tid; d < ldc0; d += 256) cmat[(long long)S * ldc0 + d] = 0.f;
         }
-        for (int idx = tid; idx < N * ldc0; idx += 256) {
-            const int i = idx / ldc0;
+        const int zc = bounded ? min(ldc0, (D0 + 3) & ~3) : ldc0;   // (bounded: ldc0 is sized for the class bound)
+        for (int idx = tid; idx < N * zc; idx += 256) {
+            const int i = idx / zc;
             if (gfix[L.active + b * N + i])
-                cmat[(long long)gfix[L.cidx + b * N + i] * ldc0 + (idx - i * ldc0)] = 0.f;
+                cmat[(long long)gfix[L.cidx + b * N + i] * ldc0 + (idx - i * zc)] = 0.f;
         }
     }
     for (int idx = tid; idx < NN; idx += 256) {          // dst-CSR: edges into i, j ascending
@@ -532,6 +548,7 @@ extern "C" int gi_compact_layout(int B, int N, int Fe, gi_compact_layout_t* out)
     out->counts = L.counts; out->type_off = L.type_off; out->cidx = L.cidx;
     out->node_mask = L.node_mask; out->slot_of = L.slot_of; out->seg_off = L.seg_off;
     out->src_off = L.src_off; out->type_off0 = L.type_off0; out->scratch = L.scratch;
+    out->dims = L.dims;
     return 0;
 }
 
@@ -566,14 +583,65 @@ extern "C" int gi_compact_count_ex(const void* nodes, const void* edges, int in_
     return gi_launch_status();
 }
 
+// ---- bounded (host-sync-free) forward: sizes stay on the device -----------------------------------------
+// One thread checks the counts against the bounds the caller sized its buffers with and derives the launch
+// dimensions the forward's kernels read from the device (gfix + layout.dims):
+//   dims[0] = R = S + 1 (compact node rows incl. the zero row), dims[1] = row-block height of the message
+//   chains (32..36: the height that saves a round of workgroups on `ncu` CUs, like the host-side choice),
+//   dims[2] = 32 (row-block height of the pass-0 chains).
+// Overflow (E > e_bound or D0 > d0_bound: counts[2] |= 2) and a batch whose pass-0 shortcut is unavailable
+// although it has edges (non-0/1 node features or > GI_P0_MAX_CLASSES classes: counts[2] |= 4) cannot run
+// bounded: every size is set to 0, the forward then touches nothing beyond its buffers and returns garbage
+// logits; the caller reads counts[2] when it next synchronises.
+__global__ void compact_bound_kernel(int Fe, int* __restrict__ gfix, Lay L, int e_bound, int d0_bound, int ncu) {
+    if (threadIdx.x || blockIdx.x) return;
+    int* c = gfix + L.counts;
+    int* d = gfix + L.dims;
+    const bool over = c[CNT_E] > e_bound || c[CNT_D0] > d0_bound;
+    const bool p0bad = c[CNT_P0BAD] != 0 && c[CNT_E] > 0;
+    if (over || p0bad) {
+        c[CNT_ERR] |= over ? 2 : 4;
+        c[CNT_S] = c[CNT_E] = c[CNT_U] = c[CNT_D0] = 0;
+        for (int t = 0; t < GI_MAX_GROUPS; ++t) { c[CNT_UT + t] = 0; c[CNT_ET + t] = 0; }
+        for (int t = 0; t <= GI_MAX_GROUPS; ++t) { gfix[L.type_off + t] = 0; gfix[L.type_off0 + t] = 0; }
+    }
+    d[0] = c[CNT_S] + 1;
+    auto blocks = [&](int h) { int n = 0; for (int t = 0; t < Fe; ++t) n += (c[CNT_UT + t] + h - 1) / h; return n; };
+    int h = 32, rounds = (blocks(32) + ncu - 1) / ncu;
+    if (rounds > 1)
+        for (int hh = 33; hh <= 36; ++hh)
+            if ((blocks(hh) + ncu - 1) / ncu < rounds) { h = hh; break; }
+    d[1] = h;
+    d[2] = 32;                                   // row-block height of the pass-0 chains (a few dozen rows)
+    for (int i = 3; i < GI_DIMS; ++i) d[i] = 0;
+}
+
+extern "C" int gi_compact_bound(int* gfix, int B, int N, int Fe, int e_bound, int d0_bound, void* stream) {
+    (void)hipGetLastError();
+    if (!gfix || B <= 0 || N <= 0 || Fe <= 0 || e_bound < 0 || d0_bound < 0) return GI_EINVAL;
+    if (N > GI_MAX_NODES || Fe > GI_MAX_GROUPS) return GI_ELIMIT;
+    const Lay L = make_layout(B, N, Fe);
+    static const int ncu = [] {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    hipLaunchKernelGGL(compact_bound_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, Fe, gfix, L, e_bound,
+                       d0_bound, ncu);
+    return gi_launch_status();
+}
+
 extern "C" int gi_compact_fill(const void* nodes, int in_dtype, int B, int N, int Fn, int Fe,
                                const int* gfix, int S, int E, int U, int* u_src, int* in_perm,
                                int* mu_off, int* mu_dst, int* mu_slot, int* out_perm, float* hx0,
                                int ldhx, int H, int D0, int* d_src, float* cmat, int ldc0, int* e2d,
                                void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
-    if (!nodes || !gfix || !hx0 || !mu_off || B <= 0 || N <= 0 || S < 0 || E < 0 || U < 0 || U > E)
-        return GI_EINVAL;
+    if (!nodes || !gfix || !hx0 || !mu_off || B <= 0 || N <= 0) return GI_EINVAL;
+    const bool bounded = S < 0;            // sizes on the device; E, U, D0 are then the BOUNDS of the buffers
+    if (!bounded && (E < 0 || U < 0 || U > E)) return GI_EINVAL;
+    if (bounded && (E < 0 || U < 0)) return GI_EINVAL;
     if (E > 0 && (!u_src || !in_perm || !mu_dst || !mu_slot || !out_perm)) return GI_EINVAL;
     if (D0 < 0 || D0 > GI_MAX_GROUPS * GI_P0_MAX_CLASSES) return GI_EINVAL;
     if (D0 > 0 && (!d_src || !cmat || ldc0 < D0 || (ldc0 & 3))) return GI_EINVAL;
@@ -582,8 +650,8 @@ extern "C" int gi_compact_fill(const void* nodes, int in_dtype, int B, int N, in
     const Lay L = make_layout(B, N, Fe);
 #define GI_FILL(T_, NMAX_)                                                                         \
     hipLaunchKernelGGL((compact_fill_kernel<T_, NMAX_>), dim3(B), dim3(256), 0, (hipStream_t)stream, \
-                       (const T_*)nodes, N, Fn, Fe, gfix, L, S, E, U, u_src, in_perm, mu_off, mu_dst, \
-                       mu_slot, out_perm, hx0, ldhx, H, D0, d_src, cmat, ldc0, e2d)
+                       (const T_*)nodes, N, Fn, Fe, gfix, L, bounded ? -1 : S, E, U, u_src, in_perm,  \
+                       mu_off, mu_dst, mu_slot, out_perm, hx0, ldhx, H, D0, d_src, cmat, ldc0, e2d)
 #define GI_FILL_N(T_)                                                                              \
     do {                                                                                           \
         if (N <= 32) GI_FILL(T_, 32);                                                              \

@@ -291,7 +291,7 @@ void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {   /
 }
 
 // ---- launch helpers -----------------------------------------------------------------------------
-struct Grp { int n; const int* off; int max_rows; const int* host_rows = nullptr; };   // n == 0: ungrouped; host_rows: per-group upper bounds (null: max_rows)
+struct Grp { int n; const int* off; int max_rows; const int* host_rows = nullptr; int dim_slot = 1; };   // dim_slot: which device dim holds the row-block height of a bounded chain launch (1: message rows, 2: pass-0 rows)   // n == 0: ungrouped; host_rows: per-group upper bounds (null: max_rows)
 
 struct SideStream;
 
@@ -305,6 +305,12 @@ struct Run {
     long long img_b_stride[2] = {0, 0};
     const struct Mlp* eatt0 = nullptr;      // identifies the energy stacks (second image)
     bool hold_kicks = false;                // no weight-gradient launches on the side stream for now
+    // bounded (host-sync-free) forward: the sizes of the graph are on the device (gi_compact_bound) —
+    // dims[0] = R, dims[1] / dims[2] = row-block heights of the message / pass-0 chains; d0_dev = D0.
+    // Host-side S, E, U, D0 are then BOUNDS that size buffers and grids only.
+    const int* dims = nullptr;
+    const int* d0_dev = nullptr;
+    int R_bound = 0;
     // AlphaDropout training mode (gnn/modules.py:130-142 with p > 0)
     bool drop = false;
     unsigned long long seed = 0;
@@ -503,6 +509,7 @@ void add_fwd(Batch& b, Run& r, const float* W, const float* bias, int in, int ou
     p.A = X; p.lda = ldx; p.B = W; p.ldb = in; p.bias = bias; p.C = Y; p.ldc = ldy;
     p.M = rows; p.N = out; p.K = in;
     p.flags = GI_EPI_BIAS | (selu ? GI_EPI_SELU : 0);
+    if (r.dims && rows == r.R_bound) { p.m_dev = r.dims; return; }     // node-level rows: counted on the device
     maybe_split_k(b, r, p);
 }
 
@@ -830,6 +837,7 @@ void chain_fwd_params(gi_chain_params& c, const Run& r, float* ws, const Mlp* ml
     const int L = q.layers();
     c.nlayers = L; c.X = X; c.ldx = ldx; c.x_idx = idx; c.backward = 0;
     chain_groups(c, g, rows);
+    if (r.dims) c.tile_rows_dev = r.dims + g.dim_slot;
     for (int l = 0; l < L; ++l) {
         gi_chain_layer& y = c.layer[l];
         y.K = q.fan_in(l); y.N = q.fan_out(l);
@@ -1135,15 +1143,18 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
     if (d.kind == GI_KIND_ATTGGNN && gp->D0 > 0 && (!gp->e2d || !gp->cls_off || !gp->cls_edges))
         return GI_EINVAL;
     if (int drc = dropout_graph_ok(d, S, E, U, gp->D0)) return drc;
+    if (gp->bounded && (d.dropout || gp->D0 <= 0)) return GI_EINVAL;   // (bounded: S, E, U, D0 are bounds)
     make_ws(m, S, E, U, gp->D0, w);
     Run r{(hipStream_t)stream, params, 0};
     r.drop = d.dropout != 0; r.seed = d.drop_seed; r.fshift = w.fshift;
     r.skinny = ws + w.skinny; r.skinny_floats = w.skinny_floats;
     const int R = w.R;
+    if (gp->bounded) { r.dims = gfix + L.dims; r.d0_dev = gfix + L.counts + 20; r.R_bound = R; }
     int maxUt = 0;
     for (int t = 0; t < d.Fe; ++t) maxUt = std::max(maxUt, Ut[t]);
     const Grp bytype{d.Fe, gfix + L.type_off, maxUt, Ut};
-    const Grp bytype0{d.Fe, gfix + L.type_off0, w.D0};   // pass-0 rows (upper bound per type: all)
+    Grp bytype0{d.Fe, gfix + L.type_off0, w.D0};   // pass-0 rows (upper bound per type: all)
+    bytype0.dim_slot = 2;
     const int* seg_off = gfix + L.seg_off;
     const int* cidx = gfix + L.cidx;
     const int* mask = gfix + L.node_mask;
@@ -1173,8 +1184,8 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
                 if (p0) edge_chains_forward(r, ws, ch, 2, bytype0, hx, w.ldhx, gp->d_src, w.D0);
                 else edge_chains_forward(r, ws, ch, 2, bytype, hx, w.ldhx, u_src, U);
             }
-            r.chk(gi_seg_softmax_fwd(ws + w.een[p], ws + w.m[p], w.ldM, p0 ? gp->e2d : in_perm, seg_off,
-                                     R, d.M, ws + w.agg[p], w.ldM, r.st));
+            r.chk(gi_seg_softmax_fwd_n(ws + w.een[p], ws + w.m[p], w.ldM, p0 ? gp->e2d : in_perm, seg_off,
+                                       R, d.M, ws + w.agg[p], w.ldM, r.dims, r.st));
         } else if (p == 0 && w.D0 > 0) {
             // pass 0: h = [x | 0], one message row per (feature class, bond type); a_v = cmat . m0
             mlp_forward(r, ws, m.msg, bytype0, hx, w.ldhx, gp->d_src, w.D0, w.eact[0], w.ldEh,
@@ -1184,6 +1195,7 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
                 gemm_defaults(q);
                 q.A = gp->cmat; q.lda = gp->ldc0; q.B = ws + w.m[0]; q.ldb = w.ldM; q.b_major = 1;
                 q.C = ws + w.agg[0]; q.ldc = w.ldM; q.M = R; q.N = d.M; q.K = w.D0;
+                q.m_dev = r.dims; q.k_dev = r.d0_dev;      // (bounded forward: R and D0 live on the device)
                 q.tm = 1; q.tn = 1;
                 r.chk(gi_gemm(&q, r.st));
             }
@@ -1192,7 +1204,8 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
                 mlp_forward(r, ws, m.msg, bytype, hx, w.ldhx, u_src, U, w.eact[p], w.ldEh,
                             ws + w.m[p], w.ldM);
             // a_v = sum of incoming messages (:141)
-            r.chk(gi_seg_sum(ws + w.m[p], w.ldM, in_perm, seg_off, R, d.M, ws + w.agg[p], w.ldM, 0, r.st));
+            r.chk(gi_seg_sum_n(ws + w.m[p], w.ldM, in_perm, seg_off, R, d.M, ws + w.agg[p], w.ldM, 0, r.dims,
+                               r.st));
         }
         // GRU update (gnn/mpnn.py:296-297): both input projections in one launch, then the gate kernel
         {
@@ -1203,8 +1216,8 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
                     ws + w.gh[p], w.ld3H, false);
             flush_batch(r, b, false);
         }
-        r.chk(gi_gru_gates_fwd(ws + w.gi[p], ws + w.gh[p], w.ld3H, hx, ws + w.hx[p + 1], w.ldhx,
-                               seg_off, R, d.H, d.Fn, r.st));
+        r.chk(gi_gru_gates_fwd_n(ws + w.gi[p], ws + w.gh[p], w.ld3H, hx, ws + w.hx[p + 1], w.ldhx,
+                                 seg_off, R, d.H, d.Fn, r.dims, r.st));
     }
     // ---- readout (gnn/mpnn.py:299-303) -----------------------------------------------------------
     const float* hx = ws + w.hx[d.passes];

@@ -19,9 +19,11 @@ namespace {
 // load) and read one contiguous row of `vals` -> fully coalesced row gathers.
 __global__ __launch_bounds__(256) void seg_sum_kernel(
     const float* __restrict__ vals, int ldv, const int* __restrict__ perm,
-    const int* __restrict__ off, int rows, int c4n, float* out, int ldo, int accumulate) {
+    const int* __restrict__ off, int rows, int c4n, float* out, int ldo, int accumulate,
+    const int* __restrict__ rows_dev) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int c = (int)(t / c4n), q = (int)(t - (long long)c * c4n);
+    if (rows_dev) rows = min(rows, *rows_dev);          // bounded launch: the real row count is on the device
     if (c >= rows) return;
     const int lo = off[c], hi = off[c + 1];
     v4f acc = {0.f, 0.f, 0.f, 0.f};
@@ -138,9 +140,10 @@ __device__ __forceinline__ v4f v4_rcp(v4f a) {
 __global__ __launch_bounds__(256) void seg_softmax_fwd_kernel(
     const float* __restrict__ en, const float* __restrict__ emb, int ld,
     const int* __restrict__ perm, const int* __restrict__ off, int rows, int c4n,
-    float* __restrict__ out, int ldo) {
+    float* __restrict__ out, int ldo, const int* __restrict__ rows_dev) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int c = (int)(t / c4n), q = (int)(t - (long long)c * c4n);
+    if (rows_dev) rows = min(rows, *rows_dev);
     if (c >= rows) return;
     const int lo = off[c], hi = off[c + 1];
     v4f acc = {0.f, 0.f, 0.f, 0.f};
@@ -261,9 +264,11 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(const gi_dropout_para
 // ---- GRU gates --------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gru_gates_fwd_kernel(
     float* gi, const float* __restrict__ gh, int ldg, const float* __restrict__ hx_prev,
-    float* __restrict__ hx_new, int ldh, const int* __restrict__ seg_off, int rows, int H) {
+    float* __restrict__ hx_new, int ldh, const int* __restrict__ seg_off, int rows, int H,
+    const int* __restrict__ rows_dev) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int row = (int)(t / ldh), j = (int)(t - (long long)row * ldh);
+    if (rows_dev) rows = min(rows, *rows_dev);
     if (row >= rows) return;
     const float hp = hx_prev[(long long)row * ldh + j];
     float hn_out = hp;                                  // feature tail / padding: plain copy
@@ -323,10 +328,12 @@ __device__ __forceinline__ v4f v4_tanh(v4f a) {
 
 __global__ __launch_bounds__(256) void gru_gates_fwd_v4_kernel(
     float* gi, const float* __restrict__ gh, int ldg, const float* __restrict__ hx_prev,
-    float* __restrict__ hx_new, int ldh, const int* __restrict__ seg_off, int rows, int H) {
+    float* __restrict__ hx_new, int ldh, const int* __restrict__ seg_off, int rows, int H,
+    const int* __restrict__ rows_dev) {
     const int q4 = ldh >> 2;                             // ldh is a multiple of 4
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int row = (int)(t / q4), j = 4 * (int)(t - (long long)row * q4);
+    if (rows_dev) rows = min(rows, *rows_dev);
     if (row >= rows) return;
     const v4f hp = *(const v4f*)(hx_prev + (long long)row * ldh + j);
     v4f hn_out = hp;                                    // feature tail / padding: plain copy
@@ -847,6 +854,11 @@ extern "C" int gi_prof_collect(double* ms, double* busy_ms, double* work, int* l
 // ================================ C ABI ==========================================================
 extern "C" int gi_seg_sum(const float* vals, int ldv, const int* perm, const int* off, int rows,
                           int cols, float* out, int ldo, int accumulate, void* stream) {
+    return gi_seg_sum_n(vals, ldv, perm, off, rows, cols, out, ldo, accumulate, nullptr, stream);
+}
+// rows_dev != NULL: bounded launch — `rows` sizes the grid, min(rows, *rows_dev) rows are processed
+int gi_seg_sum_n(const float* vals, int ldv, const int* perm, const int* off, int rows, int cols, float* out,
+                 int ldo, int accumulate, const int* rows_dev, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (rows <= 0) return 0;
     if (!vals || !off || !out || cols <= 0 || (ldv & 3) || (ldo & 3) || ldv < cols || ldo < cols)
@@ -857,7 +869,7 @@ extern "C" int gi_seg_sum(const float* vals, int ldv, const int* perm, const int
     // (algorithmic bytes depend on the device-side segment lengths; the caller knows them)
     GiProfScope prof((hipStream_t)stream, GI_PROF_SEGSUM, 0.0);
     hipLaunchKernelGGL(seg_sum_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, vals, ldv, perm, off, rows, c4n, out, ldo, accumulate);
+                       (hipStream_t)stream, vals, ldv, perm, off, rows, c4n, out, ldo, accumulate, rows_dev);
     return gi_launch_status();
 }
 
@@ -870,6 +882,10 @@ static int seg_softmax_args_ok(const void* en, const void* emb, int ld, const in
 extern "C" int gi_seg_softmax_fwd(const float* en, const float* emb, int ld, const int* perm,
                                   const int* off, int rows, int cols, float* out, int ldo,
                                   void* stream) {
+    return gi_seg_softmax_fwd_n(en, emb, ld, perm, off, rows, cols, out, ldo, nullptr, stream);
+}
+int gi_seg_softmax_fwd_n(const float* en, const float* emb, int ld, const int* perm, const int* off, int rows,
+                         int cols, float* out, int ldo, const int* rows_dev, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (rows <= 0) return 0;
     if (!seg_softmax_args_ok(en, emb, ld, perm, off, cols) || !out || (ldo & 3) || ldo < cols ||
@@ -879,7 +895,7 @@ extern "C" int gi_seg_softmax_fwd(const float* en, const float* emb, int ld, con
     const long long threads = (long long)rows * c4n;
     GiProfScope prof((hipStream_t)stream, GI_PROF_SEGSUM, 0.0);
     hipLaunchKernelGGL(seg_softmax_fwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256),
-                       0, (hipStream_t)stream, en, emb, ld, perm, off, rows, c4n, out, ldo);
+                       0, (hipStream_t)stream, en, emb, ld, perm, off, rows, c4n, out, ldo, rows_dev);
     return gi_launch_status();
 }
 
@@ -1055,6 +1071,10 @@ static bool gates_v4_ok(int H, int ldg, int ldh, int lddh, const void* a, const 
 extern "C" int gi_gru_gates_fwd(float* gi, float* gh, int ldg, const float* hx_prev, float* hx_new,
                                 int ldh, const int* seg_off, int rows, int H, int Fn,
                                 void* stream) {
+    return gi_gru_gates_fwd_n(gi, gh, ldg, hx_prev, hx_new, ldh, seg_off, rows, H, Fn, nullptr, stream);
+}
+int gi_gru_gates_fwd_n(float* gi, float* gh, int ldg, const float* hx_prev, float* hx_new, int ldh,
+                       const int* seg_off, int rows, int H, int Fn, const int* rows_dev, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (rows <= 0) return 0;
     if (!gi || !gh || !hx_prev || !hx_new || !seg_off || ldg < 3 * H || ldh < H + Fn)
@@ -1062,12 +1082,12 @@ extern "C" int gi_gru_gates_fwd(float* gi, float* gh, int ldg, const float* hx_p
     if ((gi_fuse_flags() & GI_FUSE_GATES_V4) && gates_v4_ok(H, ldg, ldh, ldh, gi, gh, hx_prev, hx_new)) {
         const long long threads = (long long)rows * (ldh / 4);
         hipLaunchKernelGGL(gru_gates_fwd_v4_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
-                           (hipStream_t)stream, gi, gh, ldg, hx_prev, hx_new, ldh, seg_off, rows, H);
+                           (hipStream_t)stream, gi, gh, ldg, hx_prev, hx_new, ldh, seg_off, rows, H, rows_dev);
         return gi_launch_status();
     }
     const long long threads = (long long)rows * ldh;
     hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, gi, gh, ldg, hx_prev, hx_new, ldh, seg_off, rows, H);
+                       (hipStream_t)stream, gi, gh, ldg, hx_prev, hx_new, ldh, seg_off, rows, H, rows_dev);
     return gi_launch_status();
 }
 

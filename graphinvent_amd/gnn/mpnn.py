@@ -69,15 +69,24 @@ def _set_dropout(dims, c, kind: int, seed: int) -> None:
     dims.drop_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
 
 
-def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dropout_seed=None):
+def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dropout_seed=None,
+                     bounds=None):
     """graph_compact + the fused forward.  Returns (logits, tape); the tape
     (dims, CompactGraph, workspace, per-type edge counts) is what backward consumes.
 
     ``dropout_seed`` (an int): training mode with AlphaDropout p > 0 — the graph is compacted without
     row sharing (every edge and every padded slot draws its own mask, as in the reference), every
     activation gets a stored backward factor (workspace x2), and the logits tensor carries B extra
-    rows for the factors of the logits (the returned tensor is the view of the first B)."""
+    rows for the factors of the logits (the returned tensor is the view of the first B).
+
+    ``bounds = (e_bound, d0_bound)``: the HOST-SYNC-FREE forward (inference only) — nothing is read back from the
+    device; buffers and launch grids are sized for the bounds (``ops.default_bounds``), the real graph sizes stay
+    on the device where every kernel reads them (``gi_compact_bound``, ``gi_graph.bounded``).  For callers that
+    cannot prefetch the compaction because they mutate ``nodes`` / ``edges`` in place between forwards
+    (``GraphGenerator.build_graphs``, GraphGenerator.py:118-157).  The tape cannot feed a backward."""
     lib = _L.load()
+    if bounds is not None:
+        return _forward_bounded(lib, consts, nodes, edges, params, kind, bounds)
     drop = dropout_seed is not None
     nodes, lay, gfix, S, E, U, D0, Ut = _ops.compact_count(nodes, edges, nodedup=drop)
     attn = kind != _L.KIND_GGNN
@@ -106,6 +115,36 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dro
                                  out.data_ptr(), apd, torch.cuda.current_stream(dev).cuda_stream),
              "gi_ggnn_forward")
     return (out[:B] if drop else out), (dims, graph, ws)
+
+
+def _forward_bounded(lib, consts, nodes, edges, params, kind, bounds):
+    if nodes.dim() != 3:
+        raise ValueError("nodes must be [B, N, Fn]")
+    B, N = nodes.shape[0], nodes.shape[1]
+    attn = kind != _L.KIND_GGNN
+    dims = _dims_from_constants(consts, B, kind)
+    if lib.gi_ggnn_num_params(C.byref(dims)) != len(params):
+        raise RuntimeError("parameter table does not match the model dimensions")
+    e_bound, d0_bound = bounds
+    dev = nodes.device
+    box = {}
+
+    def lay_ws(S_b, E_b, U_b, D0_b):
+        n_ws = lib.gi_ggnn_workspace_floats(C.byref(dims), S_b, E_b, U_b, D0_b)
+        if n_ws < 0:
+            _L.check(int(n_ws), "gi_ggnn_workspace_floats")
+        ws = box["ws"] = torch.empty(n_ws, dtype=torch.float32, device=dev)
+        return ws[lib.gi_ggnn_hx0_offset(C.byref(dims), S_b, E_b, U_b, D0_b):], \
+            lib.gi_ggnn_ldhx(C.byref(dims)), dims.H
+
+    graph, _ = _ops.compact_bounded(nodes, edges, lay_ws, e_bound, d0_bound, class_csr=attn)
+    apd = dims.N * dims.A + dims.N * dims.C + 1
+    out = torch.empty((B, apd), dtype=torch.float32, device=dev)
+    gs = graph.c_struct()
+    _L.check(lib.gi_ggnn_forward(C.byref(dims), _ptr_table(params), C.byref(gs), box["ws"].data_ptr(),
+                                 out.data_ptr(), apd, torch.cuda.current_stream(dev).cuda_stream),
+             "gi_ggnn_forward (bounded)")
+    return out, (dims, graph, box["ws"])
 
 
 _SIDE_STREAMS = {}
@@ -258,8 +297,30 @@ class _FusedMPNN(torch.nn.Module):
     #: input of the autograd node, for ``torch.autograd.grad(.., model.parameters())``, parameter
     #: hooks and autograd's in-place-modification checks (slower host side).
     autograd_params = False
+    #: True: forwards that need no gradient (``no_grad()`` / ``eval()`` inference, generation) run HOST-SYNC-FREE —
+    #: no read-back of the graph sizes, buffers sized for ``sync_free_bounds`` (None: ``ops.default_bounds``:
+    #: 4 B N directed edges, 64 feature classes per bond type), real sizes on the device.  For loops that mutate
+    #: ``nodes`` / ``edges`` in place between forwards (GraphGenerator.build_graphs) and so cannot use
+    #: ``ops.prefetch_compact``.  ``last_bounded_error()`` reports a violated bound / invalid input of the latest
+    #: such forward (one read-back; call it where you synchronise anyway).
+    sync_free = False
+    sync_free_bounds = None
+    _last_bounded_graph = None
     _grad_ready_hook = None
     _early_exchange_pending = False     # set by dp.DataParallel while its early all-reduce runs
+    def last_bounded_error(self) -> int:
+        """Error bits of the latest sync-free forward (``ops.bounded_error``), 0 = valid; raises on a violation."""
+        g = self.__dict__.get("_last_bounded_graph")
+        if g is None:
+            return 0
+        err = _ops.bounded_error(g)
+        if err:
+            raise ValueError("sync-free forward: " + ", ".join(
+                m for bit, m in ((1, "an edge's feature vector is not one-hot"),
+                                 (2, "more edges / feature classes than sync_free_bounds"),
+                                 (4, "node features are not 0/1")) if err & bit))
+        return 0
+
     def _dropout_active(self) -> bool:
         flag = self.__dict__.get("_has_dropout")
         if flag is None:                         # dropout probabilities are fixed at construction
@@ -301,7 +362,7 @@ class _FusedMPNN(torch.nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         skip = ("_param_cache", "_bucket", "_anchor", "_grad_bucket", "_grad_ready_hook",
-                "_early_exchange_pending")
+                "_early_exchange_pending", "_last_bounded_graph")
         import copy as _copy
         for k, v in self.__dict__.items():
             new.__dict__[k] = None if k in skip else _copy.deepcopy(v, memo)
@@ -315,6 +376,12 @@ class _FusedMPNN(torch.nn.Module):
             # every launch goes to the current stream of the CURRENT device: make that the inputs'
             with torch.cuda.device(nodes.device):
                 return self.forward(nodes, edges)
+        if self.sync_free and nodes.is_cuda and not self._dropout_active() and \
+                not (torch.is_grad_enabled() and any(p.requires_grad for p in params)):
+            bounds = self.sync_free_bounds or _ops.default_bounds(nodes.shape[0], nodes.shape[1], edges.shape[3])
+            out, tape = ggnn_forward_raw(self.constants, nodes, edges, params, self._KIND, None, bounds)
+            self.__dict__["_last_bounded_graph"] = tape[1]
+            return out
         if self.autograd_params:
             self._grad_bucket = None
             return _GGNNFunction.apply(self, nodes, edges, *params)

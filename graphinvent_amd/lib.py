@@ -38,7 +38,7 @@ cll = C.c_longlong
 
 class CompactLayout(C.Structure):
     _fields_ = [(n, ci) for n in ("total_ints", "counts", "type_off", "cidx", "node_mask",
-                                  "slot_of", "seg_off", "src_off", "type_off0", "scratch")]
+                                  "slot_of", "seg_off", "src_off", "type_off0", "scratch", "dims")]
 
 
 class GemmParams(C.Structure):
@@ -50,7 +50,8 @@ class GemmParams(C.Structure):
                 ("ngroups", ci), ("nsplit", ci), ("max_group_rows", ci), ("ones_col", ci),
                 ("c_split_stride", cll),
                 ("Bg", vp * GI_MAX_GROUPS), ("biasg", vp * GI_MAX_GROUPS),
-                ("Cg", vp * GI_MAX_GROUPS), ("gsplit", ci * GI_MAX_GROUPS)]
+                ("Cg", vp * GI_MAX_GROUPS), ("gsplit", ci * GI_MAX_GROUPS),
+                ("m_dev", vp), ("k_dev", vp)]
 
 
 CHAIN_MAXL, CHAIN_MAXW = 8, 256       # GI_CHAIN_MAXL, GI_CHAIN_MAXW
@@ -64,7 +65,7 @@ class ChainLayer(C.Structure):
 class ChainParams(C.Structure):
     _fields_ = [("layer", ChainLayer * CHAIN_MAXL), ("nlayers", ci), ("X", vp), ("ldx", ci),
                 ("x_idx", vp), ("grp_off", vp), ("ngroups", ci), ("group_rows", ci * GI_MAX_GROUPS),
-                ("rows", ci), ("backward", ci), ("image", vp), ("image_stride", cll)]
+                ("rows", ci), ("backward", ci), ("image", vp), ("image_stride", cll), ("tile_rows_dev", vp)]
 
 
 class ReduceDesc(C.Structure):
@@ -77,7 +78,7 @@ class Graph(C.Structure):
     _fields_ = [("S", ci), ("E", ci), ("U", ci), ("gfix", vp), ("u_src", vp), ("in_perm", vp),
                 ("mu_off", vp), ("mu_dst", vp), ("mu_slot", vp), ("out_perm", vp),
                 ("Ut", C.POINTER(ci)), ("D0", ci), ("ldc0", ci), ("d_src", vp), ("cmat", vp),
-                ("e2d", vp), ("cls_off", vp), ("cls_edges", vp)]
+                ("e2d", vp), ("cls_off", vp), ("cls_edges", vp), ("bounded", ci)]
 
 
 class GgnnDims(C.Structure):
@@ -110,6 +111,7 @@ SIGNATURES = {
     "gi_compact_fill": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci,
                              ci, ci, vp, vp, ci, vp, vp]),
     "gi_compact_class_csr": (ci, [vp, ci, ci, vp, vp, vp]),
+    "gi_compact_bound": (ci, [vp, ci, ci, ci, ci, ci, vp]),
     "gi_class_sum_dselu": (ci, [vp, vp, ci, vp, vp, ci, ci, vp, vp, ci, vp]),
     "gi_gemm": (ci, [C.POINTER(GemmParams), vp]),
     "gi_gemm_batch": (ci, [C.POINTER(GemmParams), ci, vp]),

@@ -92,6 +92,7 @@ class CompactGraph:
     gvar: torch.Tensor          # int32, variable-size part: u_src | in_perm | mu_off | mu_dst | mu_slot | out_perm | d_src
     cmat: Optional[torch.Tensor] = None   # fp32 [S+1, ldc0] pass-0 edge-count matrix
     class_csr: bool = False               # e2d / cls_off / cls_edges are filled (AttentionGGNN pass 0)
+    bounded: bool = False                 # S, E, U, D0, Ut are BOUNDS; the real sizes stay in gfix (compact_bounded)
 
     def view(self, name: str, n: int) -> torch.Tensor:
         o = getattr(self.layout, name)
@@ -154,6 +155,7 @@ class CompactGraph:
         g.cmat = self.cmat.data_ptr() if self.D0 > 0 else None
         g._ut = (C.c_int * self.Fe)(*self.Ut)
         g.Ut = g._ut
+        g.bounded = 1 if self.bounded else 0
         return g
 
 
@@ -208,7 +210,7 @@ def _unpack_counts(counts, Fe: int):
 # puts the three counting kernels on its critical path.  Entries are consumed once.
 #: how forward passes got their sizes so far: from a finished prefetch (no wait on the step's stream) or by a
 #: blocking read-back behind everything queued on it (bench.py reports the split over its timed region)
-READBACKS = {"prefetched": 0, "blocking": 0}
+READBACKS = {"prefetched": 0, "blocking": 0, "bounded": 0}     # "bounded": no read-back at all (compact_bounded)
 _PREFETCHED: "dict" = {}
 _PINNED: "list" = []
 _PINNED_NEXT = 0
@@ -304,6 +306,52 @@ def compact_fill(nodes, lay, gfix, S, E, U, D0, Ut, hx0: torch.Tensor, ldhx: int
         L.check(lib.gi_compact_class_csr(ptrs[7], E, D0, ptrs[8], ptrs[9], _stream()),
                 "gi_compact_class_csr")
     return CompactGraph(B, N, Fn, Fe, S, E, U, D0, list(Ut), lay, gfix, gvar, cmat, class_csr)
+
+
+def default_bounds(B: int, N: int, Fe: int):
+    """(e_bound, d0_bound) of a bounded forward when the caller declares none: 4 directed edges per node slot
+    on average (valence-bounded molecular graphs: sum of degrees <= 4 atoms) and 64 feature classes per bond
+    type (GDB-13: 15, ZINC-shaped: 27, ChEMBL-shaped: 36)."""
+    e = 4 * B * N
+    return e, min(64 * Fe, e)
+
+
+def compact_bounded(nodes: torch.Tensor, edges: torch.Tensor, lay_ws, e_bound: int, d0_bound: int,
+                    class_csr: bool = False):
+    """graph_compact WITHOUT the host read-back: counting phase, gi_compact_bound, fill — all enqueued; every
+    buffer is sized for the bounds (S <= B N, E, U <= e_bound, D0 <= d0_bound) and the real sizes never leave the
+    device.  `lay_ws(S_b, E_b, U_b, D0_b)` -> (hx0 view, ldhx, H) provides the workspace slice hx0 is written to.
+    Returns (CompactGraph with bounded=True, nodes as the kernels read them).  A batch that exceeds a bound or
+    has non-0/1 node features is flagged in gfix counts[2] (bits 1 / 2; `bounded_error`) and produces
+    meaningless logits instead of touching memory beyond the buffers."""
+    lib = L.load()
+    nodes_c, lay, gfix, Fe = _count_launch(nodes, edges)
+    B, N, Fn = nodes_c.shape
+    S_b, E_b, U_b = B * N, max(int(e_bound), 1), max(int(e_bound), 1)
+    D0_b = max(min(int(d0_bound), U_b), 1)             # (pass-0 rows are message rows of a kind: D0 <= U)
+    with torch.cuda.device(nodes_c.device):
+        L.check(lib.gi_compact_bound(gfix.data_ptr(), B, N, Fe, E_b, D0_b, _stream(nodes_c)), "gi_compact_bound")
+        hx0, ldhx, H = lay_ws(S_b, E_b, U_b, D0_b)
+        offs, total = _gvar_offsets(E_b, U_b, D0_b)
+        gvar = torch.empty(total, dtype=torch.int32, device=nodes_c.device)
+        ldc0 = r4(D0_b)
+        cmat = torch.empty((S_b + 1, ldc0), dtype=torch.float32, device=nodes_c.device)
+        dt = L.DTYPE_I8 if nodes_c.dtype == torch.int8 else L.DTYPE_F32
+        ptrs = [gvar.data_ptr() + 4 * o for o in offs]
+        L.check(lib.gi_compact_fill(nodes_c.data_ptr(), dt, B, N, Fn, Fe, gfix.data_ptr(), -1, E_b, U_b,
+                                    *ptrs[:6], hx0.data_ptr(), ldhx, H, D0_b, ptrs[6], cmat.data_ptr(), ldc0,
+                                    ptrs[7] if class_csr else None, _stream(nodes_c)), "gi_compact_fill")
+    READBACKS["bounded"] += 1
+    g = CompactGraph(B, N, Fn, Fe, S_b, E_b, U_b, D0_b, [U_b] * Fe, lay, gfix, gvar, cmat, bool(class_csr), True)
+    return g, nodes_c
+
+
+def bounded_error(graph: "CompactGraph") -> int:
+    """counts[2] of a bounded compaction (one host read-back — call it when you synchronise anyway): bit 0 = an
+    edge's feature vector is not one-hot, bit 1 = more edges / pass-0 rows than the bounds, bit 2 = node features
+    not 0/1 (the bounded forward needs the pass-0 shortcut).  0 = the logits of that forward are valid."""
+    c = graph.layout.counts
+    return int(graph.gfix[c + 2].item())
 
 
 def compact(nodes: torch.Tensor, edges: torch.Tensor, H: int, class_csr: bool = False,

@@ -76,9 +76,11 @@ int gi_abi_version(void);
  * pass-0 row, so that the pass-0 aggregation is cmat . m0 and its backward cmat^T . d agg.
  * ------------------------------------------------------------------------------------------ */
 #define GI_COUNTS 24
+#define GI_DIMS 8             /* device-side launch dimensions of a bounded forward (gi_compact_bound) */
 typedef struct gi_compact_layout_t {
     int total_ints;
     int counts, type_off, cidx, node_mask, slot_of, seg_off, src_off, type_off0, scratch;
+    int dims;
 } gi_compact_layout_t;
 
 int gi_compact_layout(int B, int N, int Fe, gi_compact_layout_t* out);
@@ -93,9 +95,20 @@ int gi_compact_count(const void* nodes, const void* edges, int in_dtype, int B, 
  * mode for gi_compact_fill.  nodedup == 0 is gi_compact_count. */
 int gi_compact_count_ex(const void* nodes, const void* edges, int in_dtype, int B, int N, int Fn,
                         int Fe, int* gfix, int nodedup, void* stream);
+/* BOUNDED (host-sync-free) forward, between phase 1 and phase 2: instead of reading S, E, U, D0 back the
+ * caller sizes every buffer for bounds (S <= B*N; E, U <= e_bound; D0 <= d0_bound) and this one-thread launch
+ * checks the counted sizes against them and derives the launch dimensions the forward's kernels read on the
+ * device: gfix[layout.dims + 0] = R = S + 1, + 1 = row-block height of the message chains, + 2 = 32.  On a
+ * violation — more edges / pass-0 rows than the bound (counts[2] |= 2), or a batch with edges whose pass-0
+ * shortcut is unavailable (node features not 0/1, counts[2] |= 4) — every size is set to 0: the forward then
+ * stays inside its buffers and returns meaningless logits; read counts[2] at the next synchronisation.
+ * This is what a caller that mutates `nodes` / `edges` in place between forwards
+ * (GraphGenerator.build_graphs, GraphGenerator.py:118-157) needs: no device -> host wait per forward. */
+int gi_compact_bound(int* gfix, int B, int N, int Fe, int e_bound, int d0_bound, void* stream);
 /* phase 2 (after the host has read S, E, U from counts): the variable-size index arrays and the
  * initial node rows hx0[S+1, ldhx] = [x | 0.. | x] with the input features in columns [0,Fn) and
- * again in [H, H+Fn) (row S = 0). */
+ * again in [H, H+Fn) (row S = 0).  S < 0: bounded mode — E, U, D0 (and the buffers) are the bounds handed to
+ * gi_compact_bound, the real sizes are read from gfix on the device. */
 int gi_compact_fill(const void* nodes, int in_dtype, int B, int N, int Fn, int Fe, const int* gfix,
                     int S, int E, int U, int* u_src, int* in_perm, int* mu_off, int* mu_dst,
                     int* mu_slot, int* out_perm, float* hx0, int ldhx, int H, int D0, int* d_src,
@@ -119,6 +132,10 @@ typedef struct gi_graph {
     const int* e2d;           /* [E]    AttentionGGNN pass 0 (NULL: that pass runs on message rows) */
     const int* cls_off;       /* [D0+1] */
     const int* cls_edges;     /* [E] */
+    int bounded;              /* != 0: host-sync-free forward — S, E, U, D0, Ut[] above are upper BOUNDS (the
+                                 sizes every buffer was allocated for); the real sizes stay on the device in
+                                 gfix (gi_compact_bound) and every kernel of gi_ggnn_forward reads them there.
+                                 Forward only (gi_ggnn_backward needs host sizes), no dropout mode. */
 } gi_graph;
 
 /* ------------------------------------------------------------------------------------------
@@ -153,6 +170,10 @@ typedef struct gi_gemm_params {
     long long c_split_stride;             /* floats between split slabs */
     const float* Bg[GI_MAX_GROUPS]; const float* biasg[GI_MAX_GROUPS]; float* Cg[GI_MAX_GROUPS];
     int gsplit[GI_MAX_GROUPS];            /* grouped split-K: slabs of group g (>= 1 each); nsplit ignored */
+    /* Bounded (host-sync-free) launches: M (and K) are then UPPER BOUNDS that size the grid, the real
+     * extents are read on the device — rows = min(M, *m_dev), reduction length = min(K, *k_dev); output
+     * tiles beyond the real rows exit at once.  NULL: M / K as given.  Not with groups or split-K. */
+    const int* m_dev; const int* k_dev;
 } gi_gemm_params;
 
 int gi_gemm(const gi_gemm_params* p, void* stream);
@@ -206,6 +227,10 @@ typedef struct {
     long long image_stride;               /* floats per group in the image; 0 = that of THESE layers.
                                              A chain that runs only the first layers of a packed
                                              stack passes the stride of the full pack. */
+    const int* tile_rows_dev;             /* bounded (host-sync-free) launch, else NULL: device int holding the
+                                             row-block height (32..36).  `rows` is then an upper BOUND of the
+                                             rows of all groups together (sizes the grid), the real row ranges
+                                             come from grp_off on the device (required), group_rows is unused */
 } gi_chain_params;
 
 /* The kernel streams the weights as a pre-packed image (one linear stream of 32 KB LDS tile images per

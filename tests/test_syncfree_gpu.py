@@ -1,0 +1,132 @@
+"""-m gpu: the host-sync-free ("bounded") forward — what a caller needs that mutates `nodes` / `edges` in place
+between forwards (GraphGenerator.build_graphs, GraphGenerator.py:118-157; one full-batch forward per generation
+round, Workflow.py:781-796 calls it under no_grad) and so cannot prefetch graph_compact's sizes: no device -> host
+read-back, buffers sized for declared bounds, real sizes read on the device by every kernel."""
+import numpy as np
+import pytest
+import torch
+
+from graphinvent_amd import ops, synthetic
+from graphinvent_amd.gnn import mpnn
+from graphinvent_amd.sampler import sample_actions_raw
+from oracle import ggnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _model(kind, shape, **over):
+    sh = synthetic.SHAPES[shape]
+    cfg = O.shaped_config(sh["n_atom_types"], sh["n_formal_charge"], sh["max_n_nodes"], **over)
+    P = O.init_params(cfg, seed=3, model=kind)
+    cls = mpnn.AttentionGGNN if kind == "AttGGNN" else mpnn.GGNN
+    m = cls(O.as_constants(dict(cfg, device="cuda")))
+    m.load_state_dict(P)
+    return m.to(DEV).eval(), cfg, sh
+
+
+def _dev(*a):
+    return [torch.from_numpy(np.ascontiguousarray(x)).float().to(DEV) for x in a]
+
+
+@pytest.mark.parametrize("kind,shape,B", [("GGNN", "gdb13", 1000), ("GGNN", "zinc", 200), ("AttGGNN", "gdb13", 300),
+                                          ("GGNN", "gdb13", 3)])
+def test_bounded_forward_equals_the_ordinary_forward(kind, shape, B):
+    model, cfg, sh = _model(kind, shape)
+    n8, e8, _ = synthetic.make_batch(B, **sh, seed=5)          # incl. empty / single-atom graphs
+    nodes, edges = _dev(n8, e8)
+    with torch.no_grad():
+        ref = model(nodes, edges)
+        before = dict(ops.READBACKS)
+        model.sync_free = True
+        out = model(nodes, edges)
+        assert ops.READBACKS["blocking"] == before["blocking"] and ops.READBACKS["bounded"] == before["bounded"] + 1
+        assert model.last_bounded_error() == 0
+        # same kernels, same per-row arithmetic (only grids and row-block partitions differ)
+        assert float((out - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+        # int8 inputs (the HDF dtype) take the same path
+        out8 = model(torch.from_numpy(n8).to(DEV), torch.from_numpy(e8).to(DEV))
+        assert torch.equal(out8, out)
+    # a forward that needs gradients ignores the switch (the backward needs host-side sizes)
+    model.train()
+    nb = ops.READBACKS["bounded"]
+    model(nodes, edges).sum().backward()
+    assert ops.READBACKS["bounded"] == nb and all(p.grad is not None for p in model.parameters())
+
+
+def test_generation_style_loop_never_reads_back():
+    """GraphGenerator.build_graphs pattern: ONE pair of tensors, mutated in place between forwards; forward +
+    sampling step per round.  No blocking read-back, logits equal to the ordinary forward's on a copy."""
+    model, cfg, sh = _model("GGNN", "gdb13", hidden_node_features=128, message_size=128)
+    B, N = 500, sh["max_n_nodes"]
+    rounds = [synthetic.make_batch(B, **sh, seed=100 + k) for k in range(5)]
+    nodes, edges = _dev(rounds[0][0], rounds[0][1])
+    A = cfg["len_f_add_per_node"]
+    model.sync_free = True
+    start = dict(ops.READBACKS)
+    outs = []
+    with torch.no_grad():
+        for k in range(5):
+            nk, ek = _dev(rounds[k][0], rounds[k][1])
+            nodes.copy_(nk); edges.copy_(ek)                     # in place: same storage, new graphs
+            logits = model(nodes, edges)
+            n_nodes = (nodes.sum(2) != 0).sum(1).int()
+            action, like, flags = sample_actions_raw(logits, n_nodes, edges, A)
+            outs.append((logits.clone(), action.clone()))
+    assert ops.READBACKS["blocking"] == start["blocking"] and ops.READBACKS["prefetched"] == start["prefetched"]
+    assert ops.READBACKS["bounded"] == start["bounded"] + 5
+    assert model.last_bounded_error() == 0
+    model.sync_free = False
+    with torch.no_grad():
+        for k in range(5):
+            ref = model(*_dev(rounds[k][0], rounds[k][1]))
+            assert float((outs[k][0] - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+            assert bool(torch.isfinite(outs[k][0]).all()) and int(outs[k][1][:, 0].max()) <= 2
+
+
+def test_bounded_forward_is_capturable_as_one_hip_graph():
+    """No host synchronisation inside: the whole forward (graph_compact included) records into ONE hipGraph and
+    replays on new graphs written into the captured input tensors."""
+    model, cfg, sh = _model("GGNN", "gdb13")
+    B = 256
+    b0 = synthetic.make_batch(B, **sh, seed=1)
+    nodes, edges = _dev(b0[0], b0[1])
+    model.sync_free = True
+    with torch.no_grad():
+        model(nodes, edges)                                      # warm-up: library one-time initialisation
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = model(nodes, edges)
+        for seed in (2, 3):
+            nb = synthetic.make_batch(B, **sh, seed=seed)
+            nk, ek = _dev(nb[0], nb[1])
+            nodes.copy_(nk); edges.copy_(ek)
+            graph.replay()
+            torch.cuda.synchronize()
+            got = out.clone()
+            model.sync_free = False
+            ref = model(nk, ek)
+            model.sync_free = True
+            assert float((got - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+
+
+def test_bound_violations_are_flagged_not_fatal():
+    model, cfg, sh = _model("GGNN", "gdb13")
+    n8, e8, _ = synthetic.make_batch(64, **sh, seed=9)
+    nodes, edges = _dev(n8, e8)
+    model.sync_free = True
+    with torch.no_grad():
+        model.sync_free_bounds = (10, 192)                       # far fewer edges than the batch has
+        out = model(nodes, edges)
+        torch.cuda.synchronize()
+        assert out.shape == (64, 13 * 45 + 13 * 3 + 1)
+        with pytest.raises(ValueError, match="more edges"):
+            model.last_bounded_error()
+        model.sync_free_bounds = None
+        bad = nodes.clone(); bad[0, 0, 0] = 0.5                 # not a 0/1 feature: no pass-0 shortcut
+        model(bad, edges)
+        with pytest.raises(ValueError, match="not 0/1"):
+            model.last_bounded_error()
+        ok = model(nodes, edges)                                 # and the model keeps working
+        assert model.last_bounded_error() == 0 and bool(torch.isfinite(ok).all())
