@@ -268,6 +268,25 @@ def generation_loop(model, cfg, batches, device, rounds: int):
     return out
 
 
+def committed_traffic():
+    """roofline.traffic: HBM-side bytes per launch of the GEMM family from the committed PMC passes of THIS
+    command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 correction applied;
+    tools/collect_profiles.sh -> profiles/<round>/traffic.json) — counters cannot be read from inside the
+    process, so the figure is the committed one, null when the file is not there."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PROFILE_DIR, "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return {"traffic": int(t["hbm_side_bytes_per_launch"]),
+                "traffic_note": f"bytes per launch, profiles/{PROFILE_DIR}/traffic.json: {t['source']}; "
+                                f"{t['fetch_correction']}"}
+    except (OSError, KeyError, ValueError):
+        return {"traffic": None,
+                "traffic_note": f"not measurable inside bench.py; the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                f"passes of this command go to profiles/{PROFILE_DIR}/traffic.json "
+                                "(tools/collect_profiles.sh)"}
+
+
 def cpu_baseline(cfg, threads: int = 0, n_timed: int = 3):
     """The oracle (reference algorithm on torch-CPU ops) timed on the host cores.  threads = 0: the
     thread count is chosen by a one-step probe of 8 / 16 / 32 threads — more threads make this
@@ -490,9 +509,7 @@ def main():
         result["roofline"] = {
             "bound": "mfma", "kernel": "gi_gemm*/gi_chain* (fp32 MFMA GEMM family, v_mfma_f32_32x32x2_f32)",
             "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-            "traffic_note": f"not measurable inside bench.py; the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                            f"passes of this command are under profiles/{PROFILE_DIR}/ (traffic.json)",
+            "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), **committed_traffic(),
             "launches_per_step": n[0] // prof_steps,
             "avg_launch_us": round(ms[0] * 1e3 / max(n[0], 1), 2),
             "flop_per_launch": round(work[0] / max(n[0], 1)),
@@ -517,10 +534,10 @@ def main():
         }
     # The same per-launch figure with every launch ALONE on the device: the product path overlaps the
     # weight-gradient GEMMs (second stream) with the dZ chain, so its launch durations above include
-    # the time two kernels share the CUs.  GI_WGRAD_SIDE_STREAM=0 serialises the step (slower step,
+    # the time two kernels share the CUs.  mpnn.WGRAD_SIDE_STREAM=False serialises the step (slower step,
     # shorter launches) — reported next to the headline, never instead of it.
     if not args.no_one_stream:
-        os.environ["GI_WGRAD_SIDE_STREAM"] = "0"
+        mpnn.WGRAD_SIDE_STREAM = False
         try:
             k1 = 8
             d1, _ = timed_steps(wl, k1, 2, world, device)
@@ -539,10 +556,10 @@ def main():
                     "achieved": round(tf1, 2), "frac": round(tf1 / PEAK_FP32_MFMA_TFLOPS, 4),
                     "avg_launch_us": round(ms1[0] * 1e3 / max(n1[0], 1), 2),
                     "ms_per_step": round(d1 / k1 * 1e3, 3),
-                    "note": "GI_WGRAD_SIDE_STREAM=0: no two GEMM launches share the device; the step is "
+                    "note": "mpnn.WGRAD_SIDE_STREAM=False: no two GEMM launches share the device; the step is "
                             "slower than the product path (ms_per_step above), the launches are shorter"}
         finally:
-            del os.environ["GI_WGRAD_SIDE_STREAM"]
+            mpnn.WGRAD_SIDE_STREAM = True
     if rank == 0 and not args.no_forward_only:
         # forward-only rate: inference on the same resident batches, no_grad
         model.eval()

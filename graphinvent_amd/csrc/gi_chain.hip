@@ -144,6 +144,7 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
     // the number of row blocks); in a bounded launch the grid is capped at the number of CUs and the bound's
     // surplus blocks cost an iteration of a few scalar loads instead of a 114 KB-LDS workgroup launch each
     // (measured: 1 364 surplus workgroups per chain launch made the bounded forward 0.3 ms slower).
+    if (args.c[0].skip_flag && *args.c[0].skip_flag != 0) return;   // rows served from gi_graph.p0_cache
     for (int id = blockIdx.x; id < args.chain_off[args.nchains]; id += gridDim.x) {
     // ---- which (chain, group, row block) -------------------------------------------------------
     const int ci = (args.nchains > 1 && id >= args.chain_off[1]) ? 1 : 0;

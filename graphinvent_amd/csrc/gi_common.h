@@ -45,6 +45,15 @@ int gi_seg_softmax_fwd_n(const float* en, const float* emb, int ld, const int* p
 int gi_gru_gates_fwd_n(float* gi, float* gh, int ldg, const float* hx_prev, float* hx_new, int ldh,
                        const int* seg_off, int rows, int H, int Fn, const int* rows_dev, void* stream);
 
+// ---- pass-0 row cache (gi_graph.p0_cache, gi_compact.hip): lookup before the pass-0 stack launch (words[0] =
+// hit flag, rows copied into m0 / e0 on a hit), insert after it (no-op on a hit).  nfam = 1 (message rows) or
+// 2 (message + energy rows); rows are ldm floats per family.
+long long gi_p0_cache_words_for(int row_floats);
+int gi_p0_cache_lookup(const int* gfix, int B, int N, int Fe, int* cache, int nfam, float* m0, float* e0, int ldm,
+                       void* stream);
+int gi_p0_cache_insert(const int* gfix, int B, int N, int Fe, int* cache, int nfam, const float* m0,
+                       const float* e0, int ldm, void* stream);
+
 // ---- optional per-launch timing (bench.py roofline leg) -----------------------------------------
 // When enabled, gi_gemm / gi_seg_sum bracket each kernel launch with hipEvents on the launch
 // stream; gi_prof_collect synchronises and sums the elapsed times.  Off by default (zero cost).

@@ -40,6 +40,7 @@ struct Lay {
         etype_off, etype;
     // pass-0 rows
     int type_off0, key_lo, key_hi, cls, qkeys, present, rep, dmap, d_slot;
+    int d_key;          // per pass-0 row: {bond type, pattern lo, pattern hi, 0} (the key of gi_graph.p0_cache)
 };
 constexpr int CNT_S = 0, CNT_E = 1, CNT_ERR = 2, CNT_U = 3, CNT_UT = 4, CNT_ET = 12, CNT_D0 = 20,
               CNT_P0BAD = 21, CNT_Q = 22, CNT_NODEDUP = 23, CNT_N = 24;
@@ -74,6 +75,7 @@ inline Lay make_layout(int B, int N, int Fe) {
     L.qkeys = take(2 * P0Q);
     L.present = take(Fe * P0Q); L.rep = take(Fe * P0Q); L.dmap = take(Fe * P0Q);
     L.d_slot = take(Fe * P0Q);
+    L.d_key = take(4 * Fe * P0Q);
     L.etype = take((int)(((long long)B * N * N + 3) / 4));
     L.total = o;
     return L;
@@ -180,9 +182,15 @@ __device__ void p0_classes(int ns, int Fe, int* __restrict__ gfix, const Lay& L)
         unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 40) & (CAP - 1);
         for (int probe = 0; probe < CAP; ++probe) {
             if (*(volatile int*)&bad_s) break;
-            const unsigned long long old = atomicCAS(&tab[h], EMPTY, key);
+            // plain read first: thousands of slots share a few dozen patterns, and same-address LDS
+            // atomics serialise — only the first arrivals of a pattern pay for one
+            unsigned long long old = *(volatile unsigned long long*)&tab[h];
             if (old == key) break;
-            if (old == EMPTY) { if (atomicAdd(&n_s, 1) >= P0Q) bad_s = 1; break; }
+            if (old == EMPTY) {
+                old = atomicCAS(&tab[h], EMPTY, key);
+                if (old == key) break;
+                if (old == EMPTY) { if (atomicAdd(&n_s, 1) >= P0Q) bad_s = 1; break; }
+            }
             h = (h + 1) & (CAP - 1);
         }
     }
@@ -287,7 +295,8 @@ __global__ __launch_bounds__(256) void compact_finish_kernel(int ns, int Fe, int
         for (int f = 0; f < Fe; ++f)
             if (gfix[L.mflag_t + f * ns + slot]) {
                 gfix[L.present + f * P0Q + lo] = 1;
-                atomicMin(&gfix[L.rep + f * P0Q + lo], slot);
+                // (the value only ever decreases: a stale read costs one redundant atomic, never a wrong minimum)
+                if (*(volatile int*)&gfix[L.rep + f * P0Q + lo] > slot) atomicMin(&gfix[L.rep + f * P0Q + lo], slot);
             }
     }
     if (slot == 0) {
@@ -303,34 +312,47 @@ __global__ __launch_bounds__(256) void compact_finish_kernel(int ns, int Fe, int
 }
 
 // pass-0 rows: exclusive scan of the present (bond type, class) table in row order -> row ids,
-// per-type offsets, D0.  One workgroup, table in LDS.
+// per-type offsets, D0.  One workgroup: wave-shuffle scan over chunks of 1024 table entries.
 __global__ __launch_bounds__(1024) void compact_p0_kernel(int Fe, int* __restrict__ gfix, Lay L) {
-    __shared__ int pres[GI_MAX_GROUPS * P0Q];
+    __shared__ int wsum[16];
     __shared__ int toff[GI_MAX_GROUPS + 1];
-    const int tid = threadIdx.x, n = Fe * P0Q;
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, n = Fe * P0Q;
     const bool bad = gfix[L.counts + CNT_P0BAD] != 0 || gfix[L.counts + CNT_E] == 0;
-    for (int i = tid; i < n; i += 1024) pres[i] = bad ? 0 : gfix[L.present + i];
+    if (tid == 0) carry_s = 0;
     __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int f = 0; f < Fe; ++f) {
-            toff[f] = run;
-            for (int q = 0; q < P0Q; ++q) {
-                const int v = pres[f * P0Q + q];
-                pres[f * P0Q + q] = v ? run : -1;
-                run += v;
-            }
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int v = (i < n && !bad) ? gfix[L.present + i] : 0;
+        int x = v;                                            // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o);
+            if (lane >= o) x += y;
         }
-        for (int f = Fe; f <= GI_MAX_GROUPS; ++f) toff[f] = run;
-        gfix[L.counts + CNT_D0] = run;
+        if (lane == 63) wsum[wid] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wsum[w];
+        const int carry = carry_s;
+        const int excl = carry + woff + x - v;
+        if (i < n) {
+            gfix[L.dmap + i] = v ? excl : -1;
+            if (v) {
+                gfix[L.d_slot + excl] = gfix[L.rep + i];
+                const int q = i % P0Q;
+                *reinterpret_cast<int4*>(gfix + L.d_key + 4 * excl) =
+                    make_int4(i / P0Q, gfix[L.qkeys + 2 * q], gfix[L.qkeys + 2 * q + 1], 0);
+            }
+            if (i % P0Q == 0) toff[i / P0Q] = excl;           // first row of bond type i / P0Q
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + x;
+        __syncthreads();
     }
-    __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        const int d = pres[i];
-        gfix[L.dmap + i] = d;
-        if (d >= 0) gfix[L.d_slot + d] = gfix[L.rep + i];
-    }
-    if (tid <= GI_MAX_GROUPS) gfix[L.type_off0 + tid] = toff[tid];
+    const int total = carry_s;
+    if (tid == 0) gfix[L.counts + CNT_D0] = total;
+    if (tid <= GI_MAX_GROUPS) gfix[L.type_off0 + tid] = tid < Fe ? toff[tid] : total;
 }
 
 // ---- fill -----------------------------------------------------------------------------------
@@ -525,7 +547,142 @@ __global__ __launch_bounds__(1024) void class_csr_kernel(const int* __restrict__
     }
 }
 
+
+// ---- pass-0 row cache (inference loops, gi_graph.p0_cache) --------------------------------------------
+// A pass-0 row is a function of (bond type, 0/1 feature pattern of the source node) and the weights; the
+// table below keeps every such row an inference loop has computed since the weights last changed (the
+// caller zero-fills the buffer then).  Layout (4-byte words): hdr[8] = {hit, rows, forwards, hits, ..},
+// idx[PC_DMAX] = table row of each pass-0 row of the CURRENT batch (-1: absent), hash[PC_HCAP] x
+// {pattern lo, pattern hi, bond type, row + 1} (open addressing, row + 1 == 0: free), rows[PC_CAP][row_floats].
+constexpr int PC_HDR = 8, PC_DMAX = GI_MAX_GROUPS * P0Q, PC_CAP = 2 * PC_DMAX, PC_HCAP = 4 * PC_CAP;
+struct P0Cache { int* hdr; int* idx; int* hash; float* rows; };
+__host__ __device__ inline P0Cache p0_cache_view(int* c) {
+    return {c, c + PC_HDR, c + PC_HDR + PC_DMAX, reinterpret_cast<float*>(c + PC_HDR + PC_DMAX + 4 * PC_HCAP)};
+}
+__device__ inline unsigned p0_hash(int klo, int khi, int t) {
+    const unsigned long long key = ((unsigned long long)(unsigned)khi << 32) | (unsigned)klo;
+    return (unsigned)(((key + (unsigned long long)t * 0x632BE59BD9B4E019ull) * 0x9E3779B97F4A7C15ull) >> 40) &
+           (PC_HCAP - 1);
+}
+// (bond type, pattern) of pass-0 row d (written next to the row ids by compact_p0_kernel)
+__device__ inline void p0_row_key(const int* __restrict__ gfix, const Lay& L, int Fe, int d, int& t, int& klo,
+                                  int& khi) {
+    const int4 k = *reinterpret_cast<const int4*>(gfix + L.d_key + 4 * d);
+    t = k.x; klo = k.y; khi = k.z;
+}
+__device__ inline int p0_rows_now(const int* __restrict__ gfix, const Lay& L) {
+    return (gfix[L.counts + CNT_ERR] & 6) ? 0 : gfix[L.counts + CNT_D0];   // (a bounded forward that overflowed: none)
+}
+
+__global__ __launch_bounds__(256) void p0_lookup_kernel(const int* __restrict__ gfix, Lay L, int Fe,
+                                                        int* __restrict__ cache, int nfam,
+                                                        float* __restrict__ m0, float* __restrict__ e0, int ldm) {
+    const P0Cache c = p0_cache_view(cache);
+    __shared__ int miss_s;
+    const int tid = threadIdx.x;
+    const int D0 = p0_rows_now(gfix, L);
+    if (tid == 0) miss_s = 0;
+    __syncthreads();
+    for (int d = tid; d < D0; d += 256) {
+        int t, klo, khi, row = -1;
+        p0_row_key(gfix, L, Fe, d, t, klo, khi);
+        unsigned h = p0_hash(klo, khi, t);
+        for (int probe = 0; probe < PC_HCAP; ++probe) {
+            const int4 e = reinterpret_cast<const int4*>(c.hash)[h];
+            if (e.w == 0) break;
+            if (e.x == klo && e.y == khi && e.z == t) { row = e.w - 1; break; }
+            h = (h + 1) & (PC_HCAP - 1);
+        }
+        c.idx[d] = row;
+        if (row < 0) miss_s = 1;
+    }
+    __syncthreads();
+    const int hit = (D0 > 0 && miss_s == 0) ? 1 : 0;
+    if (tid == 0) { c.hdr[0] = hit; c.hdr[2] += 1; c.hdr[3] += hit; }
+    if (!hit) return;
+    const int q = ldm >> 2, rowq = nfam * q;                      // float4 per family row / per table row
+    for (int i = tid; i < D0 * rowq; i += 256) {
+        const int d = i / rowq, j = i - d * rowq;
+        const float4 v = reinterpret_cast<const float4*>(c.rows)[(long long)c.idx[d] * rowq + j];
+        float* dst = (j < q ? m0 : e0) + (long long)d * ldm;
+        reinterpret_cast<float4*>(dst)[j < q ? j : j - q] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void p0_insert_kernel(const int* __restrict__ gfix, Lay L, int Fe,
+                                                        int* __restrict__ cache, int nfam,
+                                                        const float* __restrict__ m0,
+                                                        const float* __restrict__ e0, int ldm) {
+    const P0Cache c = p0_cache_view(cache);
+    const int tid = threadIdx.x;
+    const int D0 = p0_rows_now(gfix, L);
+    if (c.hdr[0] != 0 || D0 == 0) return;                        // served from the table / nothing computed
+    const bool clear = c.hdr[1] + D0 > PC_CAP;                    // would not fit: start over with this batch
+    __syncthreads();                                              // (everybody has read hdr[1])
+    if (clear) {
+        for (int i = tid; i < 4 * PC_HCAP; i += 256) c.hash[i] = 0;
+        if (tid == 0) c.hdr[1] = 0;
+        __threadfence();
+        __syncthreads();
+    }
+    for (int d = tid; d < D0; d += 256) {
+        if (!clear && c.idx[d] >= 0) continue;
+        int t, klo, khi;
+        p0_row_key(gfix, L, Fe, d, t, klo, khi);
+        const int row = atomicAdd(&c.hdr[1], 1);
+        unsigned h = p0_hash(klo, khi, t);
+        for (;;) {                                                // (bond type, pattern) pairs of a batch are distinct
+            if (atomicCAS(&c.hash[4 * h + 3], 0, row + 1) == 0) {
+                c.hash[4 * h] = klo; c.hash[4 * h + 1] = khi; c.hash[4 * h + 2] = t;
+                break;
+            }
+            h = (h + 1) & (PC_HCAP - 1);
+        }
+        c.idx[d] = row;
+    }
+    __syncthreads();
+    const int q = ldm >> 2, rowq = nfam * q;
+    for (int i = tid; i < D0 * rowq; i += 256) {                  // (rows already in the table: same values again)
+        const int d = i / rowq, j = i - d * rowq;
+        const float* src = (j < q ? m0 : e0) + (long long)d * ldm;
+        reinterpret_cast<float4*>(c.rows)[(long long)c.idx[d] * rowq + j] =
+            reinterpret_cast<const float4*>(src)[j < q ? j : j - q];
+    }
+}
+
 }  // namespace
+
+long long gi_p0_cache_words_for(int row_floats) {
+    if (row_floats <= 0 || (row_floats & 3)) return GI_EINVAL;
+    return (long long)PC_HDR + PC_DMAX + 4LL * PC_HCAP + (long long)PC_CAP * row_floats;
+}
+
+static int p0_cache_args(const int* gfix, int B, int N, int Fe, const int* cache, int nfam, const float* m0,
+                         const float* e0, int ldm, Lay& L) {
+    if (!gfix || !cache || !m0 || (nfam == 2 && !e0) || nfam < 1 || nfam > 2 || ldm <= 0 || (ldm & 3))
+        return GI_EINVAL;
+    if (B <= 0 || N <= 0 || Fe <= 0 || N > GI_MAX_NODES || Fe > GI_MAX_GROUPS) return GI_EINVAL;
+    L = make_layout(B, N, Fe);
+    return 0;
+}
+
+int gi_p0_cache_lookup(const int* gfix, int B, int N, int Fe, int* cache, int nfam, float* m0, float* e0, int ldm,
+                       void* stream) {
+    Lay L;
+    if (int rc = p0_cache_args(gfix, B, N, Fe, cache, nfam, m0, e0, ldm, L)) return rc;
+    hipLaunchKernelGGL(p0_lookup_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, gfix, L, Fe, cache, nfam, m0,
+                       e0, ldm);
+    return gi_launch_status();
+}
+
+int gi_p0_cache_insert(const int* gfix, int B, int N, int Fe, int* cache, int nfam, const float* m0,
+                       const float* e0, int ldm, void* stream) {
+    Lay L;
+    if (int rc = p0_cache_args(gfix, B, N, Fe, cache, nfam, m0, e0, ldm, L)) return rc;
+    hipLaunchKernelGGL(p0_insert_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, gfix, L, Fe, cache, nfam, m0,
+                       e0, ldm);
+    return gi_launch_status();
+}
 
 extern "C" int gi_compact_class_csr(const int* e2d, int E, int D0, int* cls_off, int* cls_edges,
                                     void* stream) {
@@ -604,6 +761,10 @@ __global__ void compact_bound_kernel(int Fe, int* __restrict__ gfix, Lay L, int 
         c[CNT_S] = c[CNT_E] = c[CNT_U] = c[CNT_D0] = 0;
         for (int t = 0; t < GI_MAX_GROUPS; ++t) { c[CNT_UT + t] = 0; c[CNT_ET + t] = 0; }
         for (int t = 0; t <= GI_MAX_GROUPS; ++t) { gfix[L.type_off + t] = 0; gfix[L.type_off0 + t] = 0; }
+        // the one compact row that is left (R = 1: the zero row) has no incoming edges and sends nothing —
+        // the edge index arrays are NOT filled after an overflow, nothing may be read through them
+        gfix[L.seg_off] = gfix[L.seg_off + 1] = 0;
+        gfix[L.src_off] = gfix[L.src_off + 1] = 0;
     }
     d[0] = c[CNT_S] + 1;
     auto blocks = [&](int h) { int n = 0; for (int t = 0; t < Fe; ++t) n += (c[CNT_UT + t] + h - 1) / h; return n; };

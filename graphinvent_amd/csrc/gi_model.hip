@@ -311,6 +311,7 @@ struct Run {
     const int* dims = nullptr;
     const int* d0_dev = nullptr;
     int R_bound = 0;
+    const int* skip = nullptr;              // set around the pass-0 stack launch: hit flag of gi_graph.p0_cache
     // AlphaDropout training mode (gnn/modules.py:130-142 with p > 0)
     bool drop = false;
     unsigned long long seed = 0;
@@ -838,6 +839,7 @@ void chain_fwd_params(gi_chain_params& c, const Run& r, float* ws, const Mlp* ml
     c.nlayers = L; c.X = X; c.ldx = ldx; c.x_idx = idx; c.backward = 0;
     chain_groups(c, g, rows);
     if (r.dims) c.tile_rows_dev = r.dims + g.dim_slot;
+    c.skip_flag = r.skip;
     for (int l = 0; l < L; ++l) {
         gi_chain_layer& y = c.layer[l];
         y.K = q.fan_in(l); y.N = q.fan_out(l);
@@ -1167,10 +1169,19 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
                 r.img_f[k] = ws + w.img_f[k];
                 chain_pack(r, k ? m.eatt : m.msg, d.Fe, false, r.img_f[k]);
             }
+    // pass-0 row cache (inference loops): only in front of the one-launch stack path, whose kernel can skip
+    int* const p0c = static_cast<int*>(gp->p0_cache);
+    const bool p0cache = p0c && w.D0 > 0 && E > 0 && !r.drop && r.img_f[0] && (!attn || r.img_f[1]) &&
+                         w.ldhx >= gi_r4(m.msg[0].in);
     // ---- message passes (gnn/summation_mpnn.py:128-144) ----------------------------------------
     for (int p = 0; p < d.passes; ++p) {
         const float* hx = ws + w.hx[p];
         r.pass = p;
+        if (p == 0 && p0cache) {
+            r.chk(gi_p0_cache_lookup(gfix, d.B, d.N, d.Fe, p0c, attn ? 2 : 1, ws + w.m[0],
+                                     attn ? ws + w.een[0] : nullptr, w.ldM, r.st));
+            r.skip = p0c;
+        }
         if (attn) {
             // AttentionGGNN.aggregate_message (gnn/mpnn.py:370-389): message and energy MLPs of the
             // edge's bond type on h_src(e), softmax over each node's incoming edges, weighted sum
@@ -1183,6 +1194,10 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
                     {m.eatt, w.aact[p], w.adz[p], w.ldEa, ws + w.een[p], w.ldM, nullptr}};
                 if (p0) edge_chains_forward(r, ws, ch, 2, bytype0, hx, w.ldhx, gp->d_src, w.D0);
                 else edge_chains_forward(r, ws, ch, 2, bytype, hx, w.ldhx, u_src, U);
+                if (p0 && p0cache) {
+                    r.skip = nullptr;
+                    r.chk(gi_p0_cache_insert(gfix, d.B, d.N, d.Fe, p0c, 2, ws + w.m[0], ws + w.een[0], w.ldM, r.st));
+                }
             }
             r.chk(gi_seg_softmax_fwd_n(ws + w.een[p], ws + w.m[p], w.ldM, p0 ? gp->e2d : in_perm, seg_off,
                                        R, d.M, ws + w.agg[p], w.ldM, r.dims, r.st));
@@ -1190,6 +1205,10 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
             // pass 0: h = [x | 0], one message row per (feature class, bond type); a_v = cmat . m0
             mlp_forward(r, ws, m.msg, bytype0, hx, w.ldhx, gp->d_src, w.D0, w.eact[0], w.ldEh,
                         ws + w.m[0], w.ldM);
+            if (p0cache) {
+                r.skip = nullptr;
+                r.chk(gi_p0_cache_insert(gfix, d.B, d.N, d.Fe, p0c, 1, ws + w.m[0], nullptr, w.ldM, r.st));
+            }
             if (r.ok()) {
                 gi_gemm_params q;
                 gemm_defaults(q);
@@ -1251,6 +1270,14 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
         mlp_jobs_forward(r, ws, jobs, 3);
     }
     return r.rc;
+}
+
+extern "C" long long gi_p0_cache_words(const gi_ggnn_dims* d) {
+    Model m;
+    if (int rc = build_model(d, m)) return rc;
+    Ws w;
+    make_ws(m, 0, 0, 0, 0, w);
+    return gi_p0_cache_words_for((m.d.kind == GI_KIND_ATTGGNN ? 2 : 1) * w.ldM);
 }
 
 extern "C" int gi_ggnn_first_readout_param(const gi_ggnn_dims* d) {

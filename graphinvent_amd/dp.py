@@ -32,6 +32,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import lib as _lib
 from .loss import apd_kl_loss, register_unit_gradient
 
 
@@ -80,7 +81,7 @@ class DataParallel:
         self._one = None               # cached root gradient (see step)
         self._comm_stream = None
         # overlap needs the HIP model (it exposes the flat bucket and the two-call backward)
-        self.overlap = (overlap and os.environ.get("GI_DP_OVERLAP", "1") != "0"
+        self.overlap = (overlap
                         and (self.world_size > 1 or always_reduce) and dist.is_initialized()
                         and hasattr(model, "_grad_bucket") and torch.cuda.is_available())
 
@@ -91,6 +92,7 @@ class DataParallel:
         with torch.no_grad():
             for p in self.params:
                 dist.broadcast(p.data, src=src, group=self.group)
+        _lib.WEIGHTS_EPOCH[0] += 1
 
     # -- the one exchange step ---------------------------------------------------------------
     def _model_bucket(self) -> Optional[torch.Tensor]:

@@ -70,7 +70,7 @@ def _set_dropout(dims, c, kind: int, seed: int) -> None:
 
 
 def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dropout_seed=None,
-                     bounds=None):
+                     bounds=None, p0_cache=None):
     """graph_compact + the fused forward.  Returns (logits, tape); the tape
     (dims, CompactGraph, workspace, per-type edge counts) is what backward consumes.
 
@@ -83,10 +83,13 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dro
     device; buffers and launch grids are sized for the bounds (``ops.default_bounds``), the real graph sizes stay
     on the device where every kernel reads them (``gi_compact_bound``, ``gi_graph.bounded``).  For callers that
     cannot prefetch the compaction because they mutate ``nodes`` / ``edges`` in place between forwards
-    (``GraphGenerator.build_graphs``, GraphGenerator.py:118-157).  The tape cannot feed a backward."""
+    (``GraphGenerator.build_graphs``, GraphGenerator.py:118-157).  The tape cannot feed a backward.
+
+    ``p0_cache`` (an int32 CUDA tensor of ``gi_p0_cache_words`` words, zero-filled whenever the weights change):
+    the pass-0 row cache of an inference loop (``gi_graph.p0_cache``); the tape cannot feed a backward."""
     lib = _L.load()
     if bounds is not None:
-        return _forward_bounded(lib, consts, nodes, edges, params, kind, bounds)
+        return _forward_bounded(lib, consts, nodes, edges, params, kind, bounds, p0_cache)
     drop = dropout_seed is not None
     nodes, lay, gfix, S, E, U, D0, Ut = _ops.compact_count(nodes, edges, nodedup=drop)
     attn = kind != _L.KIND_GGNN
@@ -111,13 +114,15 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dro
     apd = dims.N * dims.A + dims.N * dims.C + 1
     out = torch.empty((2 * B if drop else B, apd), dtype=torch.float32, device=dev)
     gs = graph.c_struct()
+    if p0_cache is not None and not drop:
+        gs.p0_cache = p0_cache.data_ptr()
     _L.check(lib.gi_ggnn_forward(C.byref(dims), _ptr_table(params), C.byref(gs), ws.data_ptr(),
                                  out.data_ptr(), apd, torch.cuda.current_stream(dev).cuda_stream),
              "gi_ggnn_forward")
     return (out[:B] if drop else out), (dims, graph, ws)
 
 
-def _forward_bounded(lib, consts, nodes, edges, params, kind, bounds):
+def _forward_bounded(lib, consts, nodes, edges, params, kind, bounds, p0_cache=None):
     if nodes.dim() != 3:
         raise ValueError("nodes must be [B, N, Fn]")
     B, N = nodes.shape[0], nodes.shape[1]
@@ -141,6 +146,8 @@ def _forward_bounded(lib, consts, nodes, edges, params, kind, bounds):
     apd = dims.N * dims.A + dims.N * dims.C + 1
     out = torch.empty((B, apd), dtype=torch.float32, device=dev)
     gs = graph.c_struct()
+    if p0_cache is not None:
+        gs.p0_cache = p0_cache.data_ptr()
     _L.check(lib.gi_ggnn_forward(C.byref(dims), _ptr_table(params), C.byref(gs), box["ws"].data_ptr(),
                                  out.data_ptr(), apd, torch.cuda.current_stream(dev).cuda_stream),
              "gi_ggnn_forward (bounded)")
@@ -148,12 +155,14 @@ def _forward_bounded(lib, consts, nodes, edges, params, kind, bounds):
 
 
 _SIDE_STREAMS = {}
+#: False keeps the whole backward on one stream (bench.py's one_stream measurement; no env knob)
+WGRAD_SIDE_STREAM = True
 
 
 def _side_stream(device: torch.device) -> int:
     """Second HIP stream (one per device) on which gi_ggnn_backward runs the weight-gradient GEMMs
-    concurrently with the dZ chain; GI_WGRAD_SIDE_STREAM=0 keeps everything on one stream."""
-    if _os_environ_flag("GI_WGRAD_SIDE_STREAM", "1") == "0":
+    concurrently with the dZ chain; ``mpnn.WGRAD_SIDE_STREAM = False`` keeps everything on one stream."""
+    if not WGRAD_SIDE_STREAM:
         return 0
     key = device.index if device.index is not None else torch.cuda.current_device()
     st = _SIDE_STREAMS.get(key)
@@ -163,11 +172,6 @@ def _side_stream(device: torch.device) -> int:
             _L.check(_L.load().gi_side_stream_create(C.byref(handle)), "gi_side_stream_create")
         st = _SIDE_STREAMS[key] = handle.value      # lives as long as the process
     return st
-
-
-def _os_environ_flag(name: str, default: str) -> str:
-    import os
-    return os.environ.get(name, default)
 
 
 def grad_bucket_layout(params):
@@ -263,8 +267,9 @@ class _GGNNDirect(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, nodes, edges, anchor):
         params = owner._params()
-        out, tape = ggnn_forward_raw(owner.constants, nodes, edges, params, owner._KIND,
-                                     owner._next_dropout_seed())
+        seed = owner._next_dropout_seed()
+        cache = owner._pass0_cache(params, nodes) if anchor is None and seed is None else None
+        out, tape = ggnn_forward_raw(owner.constants, nodes, edges, params, owner._KIND, seed, None, cache)
         ctx.owner = owner
         ctx.tape = tape
         # the parameters are not saved tensors here: remember their versions so that an in-place
@@ -306,6 +311,49 @@ class _FusedMPNN(torch.nn.Module):
     sync_free = False
     sync_free_bounds = None
     _last_bounded_graph = None
+    #: True (default): forwards that need no gradient keep the first message pass's rows — a function of (bond
+    #: type, 0/1 feature pattern of the source node) and the weights only — in a device-side table
+    #: (``gi_p0_cache_words``) and skip that pass's stack launch when every row of the batch is already there.
+    #: The table is emptied when a parameter's version, the parameter objects or ``lib.WEIGHTS_EPOCH`` (bumped by
+    #: ``optim.FusedAdam.step`` and ``dp.DataParallel.broadcast_parameters``, which write through raw pointers)
+    #: change; after any OTHER write that bypasses the version counter (``p.data.copy_``) call
+    #: ``reset_pass0_cache()``.
+    cache_pass0 = True
+
+    def reset_pass0_cache(self) -> None:
+        """Forget the cached pass-0 rows (next no-grad forward recomputes them)."""
+        st = self.__dict__.get("_p0_state")
+        if st is not None:
+            st["key"] = None
+
+    def pass0_cache_stats(self) -> dict:
+        """{"forwards", "hits", "rows"} of the pass-0 row cache since it was last emptied (one read-back)."""
+        st = self.__dict__.get("_p0_state")
+        if st is None or st.get("buf") is None:
+            return {"forwards": 0, "hits": 0, "rows": 0}
+        h = st["buf"][:4].tolist()
+        return {"forwards": h[2], "hits": h[3], "rows": h[1]}
+
+    def _pass0_cache(self, params, nodes):
+        if not self.cache_pass0 or not nodes.is_cuda:
+            return None
+        st = self.__dict__.get("_p0_state")
+        if st is None:
+            st = self.__dict__["_p0_state"] = {"buf": None, "key": None}
+        key = (_L.WEIGHTS_EPOCH[0], id(params), tuple((_ops._version(p), p.data_ptr()) for p in params))
+        buf = st["buf"]
+        if buf is None or buf.device != nodes.device:
+            dims = _dims_from_constants(self.constants, nodes.shape[0], self._KIND)
+            n = _L.load().gi_p0_cache_words(C.byref(dims))
+            if n < 0:
+                _L.check(int(n), "gi_p0_cache_words")
+            buf = st["buf"] = torch.zeros(n, dtype=torch.int32, device=nodes.device)
+            st["key"] = key
+        elif st["key"] != key:
+            buf.zero_()                              # weights changed: empty table (stream-ordered)
+            st["key"] = key
+        return buf
+
     _grad_ready_hook = None
     _early_exchange_pending = False     # set by dp.DataParallel while its early all-reduce runs
     def last_bounded_error(self) -> int:
@@ -362,7 +410,7 @@ class _FusedMPNN(torch.nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         skip = ("_param_cache", "_bucket", "_anchor", "_grad_bucket", "_grad_ready_hook",
-                "_early_exchange_pending", "_last_bounded_graph")
+                "_early_exchange_pending", "_last_bounded_graph", "_p0_state")
         import copy as _copy
         for k, v in self.__dict__.items():
             new.__dict__[k] = None if k in skip else _copy.deepcopy(v, memo)
@@ -379,7 +427,8 @@ class _FusedMPNN(torch.nn.Module):
         if self.sync_free and nodes.is_cuda and not self._dropout_active() and \
                 not (torch.is_grad_enabled() and any(p.requires_grad for p in params)):
             bounds = self.sync_free_bounds or _ops.default_bounds(nodes.shape[0], nodes.shape[1], edges.shape[3])
-            out, tape = ggnn_forward_raw(self.constants, nodes, edges, params, self._KIND, None, bounds)
+            out, tape = ggnn_forward_raw(self.constants, nodes, edges, params, self._KIND, None, bounds,
+                                         self._pass0_cache(params, nodes))
             self.__dict__["_last_bounded_graph"] = tape[1]
             return out
         if self.autograd_params:

@@ -28,7 +28,10 @@ EPI_MULACT = 64
 KIND_GGNN, KIND_ATTGGNN = 0, 1
 BWD_ALL, BWD_READOUT, BWD_PASSES = 0, 1, 2
 COUNTS = 24          # GI_COUNTS
-ABI_VERSION = 9      # GI_ABI_VERSION
+ABI_VERSION = 10
+#: bumped by code that rewrites model weights through raw pointers (optim.FusedAdam.step,
+#: dp.DataParallel.broadcast_parameters): invalidates gnn.mpnn's pass-0 row cache
+WEIGHTS_EPOCH = [0]     # GI_ABI_VERSION
 DTYPE_F32, DTYPE_I8 = 0, 1
 
 vp = C.c_void_p
@@ -65,7 +68,8 @@ class ChainLayer(C.Structure):
 class ChainParams(C.Structure):
     _fields_ = [("layer", ChainLayer * CHAIN_MAXL), ("nlayers", ci), ("X", vp), ("ldx", ci),
                 ("x_idx", vp), ("grp_off", vp), ("ngroups", ci), ("group_rows", ci * GI_MAX_GROUPS),
-                ("rows", ci), ("backward", ci), ("image", vp), ("image_stride", cll), ("tile_rows_dev", vp)]
+                ("rows", ci), ("backward", ci), ("image", vp), ("image_stride", cll), ("skip_flag", vp),
+                ("tile_rows_dev", vp)]
 
 
 class ReduceDesc(C.Structure):
@@ -78,7 +82,7 @@ class Graph(C.Structure):
     _fields_ = [("S", ci), ("E", ci), ("U", ci), ("gfix", vp), ("u_src", vp), ("in_perm", vp),
                 ("mu_off", vp), ("mu_dst", vp), ("mu_slot", vp), ("out_perm", vp),
                 ("Ut", C.POINTER(ci)), ("D0", ci), ("ldc0", ci), ("d_src", vp), ("cmat", vp),
-                ("e2d", vp), ("cls_off", vp), ("cls_edges", vp), ("bounded", ci)]
+                ("e2d", vp), ("cls_off", vp), ("cls_edges", vp), ("bounded", ci), ("p0_cache", vp)]
 
 
 class GgnnDims(C.Structure):
@@ -151,6 +155,7 @@ SIGNATURES = {
     "gi_side_stream_destroy": (ci, [vp]),
     "gi_ggnn_num_params": (ci, [C.POINTER(GgnnDims)]),
     "gi_ggnn_workspace_floats": (cll, [C.POINTER(GgnnDims), ci, ci, ci, ci]),
+    "gi_p0_cache_words": (cll, [C.POINTER(GgnnDims)]),
     "gi_ggnn_slab_floats": (cll, [C.POINTER(GgnnDims), ci, ci, C.POINTER(ci)]),
     "gi_ggnn_hx0_offset": (cll, [C.POINTER(GgnnDims), ci, ci, ci, ci]),
     "gi_ggnn_ldhx": (ci, [C.POINTER(GgnnDims)]),

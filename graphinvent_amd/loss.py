@@ -57,7 +57,7 @@ class _FusedKL(torch.autograd.Function):
         if d_out.numel() == 0:
             return d_out, None
         if grad.data_ptr() in _UNIT_GRADS:     # a registered constant 1.0: scaling would change nothing
-            if __debug__ and _CHECK_UNIT_GRADS and float(grad) != 1.0:
+            if __debug__ and CHECK_UNIT_GRADS and float(grad) != 1.0:
                 raise RuntimeError("fused KL loss: a tensor registered with register_unit_gradient no "
                                    "longer holds 1.0")
             return d_out, None
@@ -72,10 +72,9 @@ class _FusedKL(torch.autograd.Function):
 #: and never written by whoever registers them: ``dp.DataParallel``'s cached root gradient).  For these the
 #: in-place scaling of the loss gradient — one launch per step — is skipped; the result is bit-identical.
 _UNIT_GRADS = set()
-#: GI_CHECK_UNIT_GRADS=1: read every registered scalar back in backward and fail if it is not 1.0 (a host
-#: sync per step — for debugging a training loop that might write to its cached root gradient)
-import os as _os
-_CHECK_UNIT_GRADS = _os.environ.get("GI_CHECK_UNIT_GRADS", "0") == "1"
+#: set True to read every registered scalar back in backward and fail if it is not 1.0 (a host sync per
+#: step — for debugging a training loop that might write to its cached root gradient)
+CHECK_UNIT_GRADS = False
 
 
 def register_unit_gradient(t: torch.Tensor) -> torch.Tensor:

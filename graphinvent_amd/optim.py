@@ -159,4 +159,5 @@ class FusedAdam(torch.optim.Optimizer):
                                              st["m"].data_ptr() + 4 * lo, st["v"].data_ptr() + 4 * lo, hi - lo,
                                              float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
                                              st["step"], stream), "gi_adam_step")
+        L.WEIGHTS_EPOCH[0] += 1        # the kernel wrote through raw pointers: no version counter saw it
         return loss

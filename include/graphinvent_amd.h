@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GI_ABI_VERSION 9
+#define GI_ABI_VERSION 10
 #define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
 #define GI_MAX_NODES 128      /* max max_n_nodes */
 #define GI_P0_MAX_CLASSES 256 /* max distinct node feature rows for the pass-0 shortcut */
@@ -136,6 +136,10 @@ typedef struct gi_graph {
                                  sizes every buffer was allocated for); the real sizes stay on the device in
                                  gfix (gi_compact_bound) and every kernel of gi_ggnn_forward reads them there.
                                  Forward only (gi_ggnn_backward needs host sizes), no dropout mode. */
+    void* p0_cache;           /* NULL, or gi_p0_cache_words() 4-byte words of device memory (16-byte aligned,
+                                 zero-filled = empty) that OUTLIVE the call: the pass-0 row cache of an
+                                 inference loop, see gi_p0_cache_words.  Forward only (the hidden activations
+                                 of the pass-0 stacks are not produced on a hit). */
 } gi_graph;
 
 /* ------------------------------------------------------------------------------------------
@@ -227,6 +231,8 @@ typedef struct {
     long long image_stride;               /* floats per group in the image; 0 = that of THESE layers.
                                              A chain that runs only the first layers of a packed
                                              stack passes the stride of the full pack. */
+    const int* skip_flag;                 /* NULL, or a device int read at kernel start: != 0 -> the launch does
+                                             nothing (gi_ggnn_forward: pass-0 rows served from gi_graph.p0_cache) */
     const int* tile_rows_dev;             /* bounded (host-sync-free) launch, else NULL: device int holding the
                                              row-block height (32..36).  `rows` is then an upper BOUND of the
                                              rows of all groups together (sizes the grid), the real row ranges
@@ -521,6 +527,18 @@ int gi_ggnn_ws_query(const gi_ggnn_dims* d, int S, int E, int U, int D0, const c
                      int j, long long* off, int* ld);
 int gi_ggnn_forward(const gi_ggnn_dims* d, const float* const* params, const gi_graph* g,
                     float* ws, float* out, int ldout, void* stream);
+/* Pass-0 row cache for inference loops (generation: GraphGenerator.py:118-157 calls the model thousands of
+ * times with the same weights).  In the first message pass h = [x | 0], so a message row (and AttentionGGNN's
+ * energy row) depends only on (bond type, 0/1 feature pattern of the source node) and the weights: a few dozen
+ * distinct rows per batch, the same ones forward after forward.  With gi_graph.p0_cache set, gi_ggnn_forward
+ * looks every pass-0 row of the batch up in a device-side table keyed by (bond type, pattern); when all are
+ * there, the rows are copied from the table and the pass-0 stack launch exits at once (gi_chain_params.
+ * skip_flag), otherwise the stack runs as usual and its rows are added to the table (the table is emptied when
+ * they would not fit).  No host involvement: works inside a bounded (host-sync-free) forward and a captured
+ * hipGraph.  The CALLER zero-fills the buffer whenever a weight of the message / energy stacks changes
+ * (gnn/mpnn.py does, from the parameters' versions).  words[0] = hit flag of the latest forward, [1] = rows
+ * in the table, [2] / [3] = forwards / hits so far.  Returns the buffer size in 4-byte words, < 0 on error. */
+long long gi_p0_cache_words(const gi_ggnn_dims* d);
 /* consumes (overwrites) the activations in ws; y_out = the logits forward returned; grads[i]
  * receives the gradient of params[i]; slabs = gi_ggnn_slab_floats() floats of scratch.
  * side_stream (may be NULL): a second hipStream_t of the same device.  When given, the weight-

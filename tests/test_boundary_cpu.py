@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.gi_abi_version() == L.ABI_VERSION == 9
+    assert lib.gi_abi_version() == L.ABI_VERSION == 10
 
 
 def test_host_side_planning_functions():
@@ -38,6 +38,8 @@ def test_host_side_planning_functions():
     ws = lib.gi_ggnn_workspace_floats(C.byref(d), 6900, 12600, 8000, 45)
     ws0 = lib.gi_ggnn_workspace_floats(C.byref(d), 0, 0, 0, 0)
     assert ws > ws0 > 0 and ws % 4 == 0
+    words = lib.gi_p0_cache_words(C.byref(d))            # pass-0 row cache: header + hash + 4096 rows of ldM floats
+    assert words > 4096 * 100 and words % 4 == 0
     assert lib.gi_ggnn_workspace_floats(C.byref(d), 6900, 12600, 12601, 0) == -1   # U > E
     Ut = (C.c_int * 3)(6000, 1900, 100)
     assert lib.gi_ggnn_slab_floats(C.byref(d), 6900, 8000, Ut) > 0

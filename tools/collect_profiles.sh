@@ -2,7 +2,7 @@
 # Runs on the GPU box: rocprofv3 kernel stats of the default bench command + separate PMC passes
 # (HBM traffic and MFMA utilisation of the GEMM family / seg_sum) + the default bench JSON line.
 # Output -> gpurun_out/<tag>/ ; copy into profiles/<tag>/ afterwards.
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=/root/repo/gpurun_out/$TAG
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 BENCH="python /root/repo/bench.py --no-cpu-baseline --no-extra-configs --no-forward-only --no-probe --no-one-stream"
@@ -12,7 +12,7 @@ rm -f $OUT/stats/*kernel_trace.csv
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_MFMA" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
   name=$(echo $pass | cut -d' ' -f1)
   rm -rf /tmp/pmc_$name
-  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d /tmp/pmc_$name -o p -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-probe --no-extra-configs --no-one-stream > /tmp/pmc_$name.log 2>&1
+  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d /tmp/pmc_$name -o p -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-probe --no-extra-configs --no-one-stream --no-forward-only > /tmp/pmc_$name.log 2>&1
   python3 - "$name" <<'PY' > $OUT/pmc_$name.txt
 import csv, collections, glob, sys, re
 f = glob.glob("/tmp/pmc_%s/*counter_collection.csv" % sys.argv[1])
@@ -20,7 +20,7 @@ if not f: print("no counter file"); sys.exit(0)
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(lambda: collections.defaultdict(int))
 for r in csv.DictReader(open(f[0])):
     k = r["Kernel_Name"]
-    m = re.search(r"(gi_gemm_batch_kernel<[^>]*>|gi_gemm_kernel<[^>]*>|gi_chain_kernel<[^>]*>|\w+_kernel)", k)
+    m = re.search(r"(gi_gemm_tiles_kernel<[^>]*>|gi_chain_kernel<[^>]*>|\w+_kernel)", k)
     key = m.group(1) if m else k[:40]
     agg[key][r["Counter_Name"]] += float(r["Counter_Value"]); n[key][r["Counter_Name"]] += 1
 print("per-dispatch averages (rocprofv3 --pmc %s), kernel: {counter: avg} dispatches" % sys.argv[1])
@@ -47,7 +47,7 @@ json.dump({"kernel": "gi_gemm family (all dispatches of the profiled steps)", "d
            "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B for 16 B/lane reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE taken as is",
            "hbm_side_bytes_per_launch": int(f * 1024 * 2 + w * 1024),
            "note": "fabric-side counters: Infinity-Cache hits are included; TCC_EA0_RDREQ (pmc_TCC_HIT_sum.txt) shows the real DRAM reads",
-           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-probe`, tools/collect_profiles.sh"},
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-probe --no-extra-configs --no-one-stream --no-forward-only` (training steps only), tools/collect_profiles.sh"},
           open(out + "/traffic.json", "w"), indent=1)
 PY
 # the aggregation kernel beyond the Infinity Cache (567 MB of message rows): counter bytes behind the

@@ -8,6 +8,8 @@
 //   wgrad : a weight-gradient batch              (3 x 500x501 + 2 x 250x251 + 3x501 + 2 x 100x251 over 7258 rows, split-K slabs)
 //   fwd1  : one 7258x500x500 problem
 //   tier2 : the graph-level hidden-layer launch (3 x 1000x500x500)
+//   tier2s: the same as GI_LAB_NSPLIT (default 2) split-K slabs per problem, no epilogue (what a k-split of
+//           the launch would buy: more, shorter workgroups per CU)
 // persist_tenths: 0 = one workgroup per tile, 11 = library default (persistent grid for launches of more
 // than 1.1 rounds of resident workgroups), 1 = always persistent.  Every run checks 64 random outputs per
 // problem against a double-precision dot product.
@@ -48,7 +50,9 @@ int main(int argc, char** argv) {
     int M = 7258, n = 4, dims[8][3] = {{500, 500, 0}, {500, 500, 0}, {250, 250, 0}, {250, 250, 0}};
     const bool dgrad = !strcmp(cls, "dgrad"), wgrad = !strcmp(cls, "wgrad");
     if (!strcmp(cls, "fwd1")) n = 1;
-    if (!strcmp(cls, "tier2")) { M = 1000; n = 3; dims[2][0] = dims[2][1] = 500; }
+    const bool tier2s = !strcmp(cls, "tier2s");
+    const int lab_nsplit = getenv("GI_LAB_NSPLIT") ? atoi(getenv("GI_LAB_NSPLIT")) : 2;
+    if (!strcmp(cls, "tier2") || tier2s) { M = 1000; n = 3; dims[2][0] = dims[2][1] = 500; }
     if (wgrad) {
         n = 8;
         const int w[8][3] = {{500, 500, 3}, {500, 500, 3}, {500, 500, 3}, {250, 250, 12}, {250, 250, 12}, {3, 500, 24}, {100, 250, 24}, {100, 250, 24}};
@@ -64,9 +68,12 @@ int main(int argc, char** argv) {
         if (!wgrad) {
             const int N = dims[i][0], K = dims[i][1], ldk = r4(K), ldn = r4(N);
             A[i] = make((size_t)M * ldk, 11 + i, 1.f); p.A = A[i].d; p.lda = ldk;
-            Cm[i] = make((size_t)M * ldn, 21 + i, 1.f); p.C = Cm[i].d; p.ldc = ldn;
+            Cm[i] = make((size_t)M * ldn * (tier2s ? lab_nsplit : 1), 21 + i, 1.f); p.C = Cm[i].d; p.ldc = ldn;
             p.M = M; p.N = N; p.K = K;
-            if (!dgrad) {
+            if (tier2s) {
+                B[i] = make((size_t)N * K, 31 + i, 0.06f); p.B = B[i].d; p.ldb = K;
+                p.flags = GI_GEMM_SPLITK; p.nsplit = lab_nsplit; p.c_split_stride = (long long)M * ldn;
+            } else if (!dgrad) {
                 B[i] = make((size_t)N * K, 31 + i, 0.06f); p.B = B[i].d; p.ldb = K;
                 bias[i] = make(N, 41 + i, 0.1f); p.bias = bias[i].d;
                 p.flags = GI_EPI_BIAS | GI_EPI_SELU;
@@ -93,7 +100,7 @@ int main(int argc, char** argv) {
     double worst = 0;
     for (int i = 0; i < n; ++i) {
         const gi_gemm_params& p = probs[i];
-        const size_t csz = wgrad ? (size_t)p.nsplit * p.c_split_stride : (size_t)M * p.ldc;
+        const size_t csz = (wgrad || tier2s) ? (size_t)p.nsplit * p.c_split_stride : (size_t)M * p.ldc;
         std::vector<float> c(csz);
         (void)hipMemcpy(c.data(), p.C, csz * 4, hipMemcpyDeviceToHost);
         unsigned s = 777 + i;
@@ -101,7 +108,10 @@ int main(int argc, char** argv) {
             s = s * 1664525u + 1013904223u; const int r = (t < 2 ? (t ? p.M - 1 : 0) : (s >> 8) % p.M);
             s = s * 1664525u + 1013904223u; const int cidx = (t < 2 ? (t ? p.N - 1 : 0) : (s >> 8) % p.N);
             double ref = 0, got = 0, scale = 1;
-            if (!wgrad && !dgrad) {
+            if (tier2s) {
+                for (int k = 0; k < p.K; ++k) ref += (double)A[i].h[(size_t)r * p.lda + k] * B[i].h[(size_t)cidx * p.ldb + k];
+                for (int sp = 0; sp < p.nsplit; ++sp) got += c[(size_t)sp * p.c_split_stride + (size_t)r * p.ldc + cidx];
+            } else if (!wgrad && !dgrad) {
                 for (int k = 0; k < p.K; ++k) ref += (double)A[i].h[(size_t)r * p.lda + k] * B[i].h[(size_t)cidx * p.ldb + k];
                 ref = selu(ref + bias[i].h[cidx]); got = c[(size_t)r * p.ldc + cidx];
             } else if (dgrad) {

@@ -1,0 +1,84 @@
+"""debug: failing recipe (dbg_graph8 CACHE=0 HOLD=1) + buffer-by-buffer comparison with an eager bounded forward"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from graphinvent_amd import ops, synthetic
+from graphinvent_amd.gnn import mpnn
+from oracle import ggnn_oracle as O
+sh = synthetic.SHAPES["gdb13"]
+cfg = O.shaped_config(sh["n_atom_types"], sh["n_formal_charge"], sh["max_n_nodes"])
+P = O.init_params(cfg, seed=3, model="GGNN")
+def dev(*a): return [torch.from_numpy(np.ascontiguousarray(x)).float().cuda() for x in a]
+B = 256
+stash = []
+orig = mpnn.ggnn_forward_raw
+def keep(*a, **k):
+    r = orig(*a, **k); stash.append(r[1]); return r
+mpnn.ggnn_forward_raw = keep
+def views(tape, out):
+    dims, graph, ws = tape
+    lay = graph.layout
+    cnt = graph.gfix[lay.counts:lay.counts + 24].tolist()
+    S, E, U, D0 = cnt[0], cnt[1], cnt[3], cnt[20]
+    R = S + 1
+    v = {"counts": graph.gfix[lay.counts:lay.counts + 24], "type_off": graph.gfix[lay.type_off:lay.type_off + 4],
+         "type_off0": graph.gfix[lay.type_off0:lay.type_off0 + 4], "dims": graph.gfix[lay.dims:lay.dims + 3],
+         "cidx": graph.gfix[lay.cidx:lay.cidx + B * 13], "seg_off": graph.gfix[lay.seg_off:lay.seg_off + S + 2],
+         "cmat": graph.cmat[:R, :D0]}
+    offs = graph._offs
+    names = ["u_src", "in_perm", "mu_off", "mu_dst", "mu_slot", "out_perm", "d_src"]
+    lens = [U, E, U + 1, E, E, U, D0]
+    for nm, o, ln in zip(names, offs[:7], lens):
+        v[nm] = graph.gvar[o:o + ln]
+    for p in range(4):
+        v[f"hx{p}"] = ops.ws_view(ws, dims, graph, "hx", R, p)
+    for p in range(3):
+        v[f"m{p}"] = ops.ws_view(ws, dims, graph, "m", D0 if p == 0 else U, p)[:, :100]
+        v[f"agg{p}"] = ops.ws_view(ws, dims, graph, "agg", R, p)[:, :100]
+        v[f"gi{p}"] = ops.ws_view(ws, dims, graph, "gi", R, p)[:, :300]
+        v[f"gh{p}"] = ops.ws_view(ws, dims, graph, "gh", R, p)[:, :300]
+    for nm in ("en", "emb", "add1", "conn1"):
+        v[nm] = ops.ws_view(ws, dims, graph, nm, R)
+    for nm in ("cat_add", "cat_conn", "gemb"):
+        v[nm] = ops.ws_view(ws, dims, graph, nm, B)
+    v["out"] = out
+    return v, (S, E, U, D0)
+m = mpnn.GGNN(O.as_constants(dict(cfg, device="cuda"))); m.load_state_dict(P); m = m.cuda().eval()
+truth = {}
+with torch.no_grad():
+    m.cache_pass0 = False
+    for s in (1, 2, 3):
+        nb = synthetic.make_batch(B, **sh, seed=s)
+        truth[s] = m(*dev(nb[0], nb[1])).cpu()
+    b0 = synthetic.make_batch(B, **sh, seed=1)
+    nodes, edges = dev(b0[0], b0[1])
+    m.sync_free = True
+    m(nodes, edges); torch.cuda.synchronize()
+    del stash[:]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = m(nodes, edges)
+    ctape = stash[-1]
+    for seed in (2, 3, 1, 2):
+        nb = synthetic.make_batch(B, **sh, seed=seed)
+        nk, ek = dev(nb[0], nb[1])
+        nodes.copy_(nk); edges.copy_(ek)
+        graph.replay(); torch.cuda.synchronize()
+        gv, sizes = views(ctape, out)
+        gv = {k: t.clone() for k, t in gv.items()}
+        eout = m(nk, ek); torch.cuda.synchronize()
+        ev, esizes = views(stash[-1], eout)
+        t = truth[seed].cuda()
+        line = [f"seed {seed} got-truth {float((gv['out']-t).abs().max()):.3g} eager-truth {float((eout-t).abs().max()):.3g} sizes {sizes} {esizes}:"]
+        for k in gv:
+            a, b_ = gv[k], ev[k]
+            if a.shape != b_.shape:
+                line.append(f"{k}: SHAPE {tuple(a.shape)} vs {tuple(b_.shape)}"); continue
+            d = (a.float() - b_.float()).abs().max().item() if a.numel() else 0.0
+            if d != 0:
+                bad = ((a.float() - b_.float()).abs() > 0).nonzero()
+                line.append(f"{k}: {d:.3g} ({len(bad)} elems, first {bad[0].tolist()})")
+        print(" ".join(line), flush=True)
+        m.sync_free = False
+        ref = m(nk, ek)
+        m.sync_free = True

@@ -1,0 +1,23 @@
+"""forward-only probe (bench.py's forward_only leg): CACHE=0|1 python tools/runs/fwd_probe.py — pass-0 row cache off / on"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import bench
+from graphinvent_amd import ops
+from graphinvent_amd.gnn import mpnn
+cfg, constants = bench.workload_constants("cuda")
+torch.manual_seed(0)
+model = mpnn.GGNN(constants).cuda().eval()
+model.cache_pass0 = os.environ.get("CACHE", "1") == "1"
+batches = bench.make_batches(0, "cuda")
+steps = int(os.environ.get("STEPS", "40"))
+with torch.no_grad():
+    for rep in range(3):
+        for i in range(4):
+            model(*batches[i % 4][:2])
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(steps):
+            ops.prefetch_compact(*batches[(i + 1) % 4][:2])
+            model(*batches[i % 4][:2])
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print("CACHE", os.environ.get("CACHE", "1"), "forward-only ms", round(dt / steps * 1e3, 4), model.pass0_cache_stats())

@@ -12,6 +12,7 @@ model = mpnn.GGNN(constants).cuda().eval()
 batches = bench.make_batches(0, "cuda")
 nodes, edges = batches[0][0].clone(), batches[0][1].clone()
 model.sync_free = os.environ.get("MODE", "sync_free") == "sync_free"
+model.cache_pass0 = os.environ.get("CACHE", "1") == "1"
 A = cfg["len_f_add_per_node"]
 with torch.no_grad():
     for i in range(int(os.environ.get("ROUNDS", "23"))):
@@ -23,4 +24,4 @@ with torch.no_grad():
         n_nodes = (nodes.sum(2) != 0).sum(1).int()
         sample_actions_raw(logits, n_nodes, edges, A)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print(os.environ.get("MODE"), "ms/round", dt / (int(os.environ.get("ROUNDS", "23")) - 3) * 1e3, ops.READBACKS)
+print(os.environ.get("MODE"), "CACHE", os.environ.get("CACHE", "1"), "ms/round", dt / (int(os.environ.get("ROUNDS", "23")) - 3) * 1e3, ops.READBACKS)

@@ -1,0 +1,3 @@
+#!/bin/bash
+OUT=/root/repo/gpurun_out/r3_run13; mkdir -p $OUT; cd /root/repo; export TMPDIR=/tmp
+timeout 600 python tools/runs/dbg_graph.py 2>&1 | grep -v "^Extension\|amdgpu.ids" | tee $OUT/dbg.txt | cut -c1-250
