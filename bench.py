@@ -353,6 +353,9 @@ def main():
                     help="attggnn = gnn.mpnn.AttentionGGNN (configs[4]'s model class), for reference")
     ap.add_argument("--no-one-stream", action="store_true",
                     help="skip the extra roofline leg with the weight-gradient side stream off")
+    ap.add_argument("--one-stream", action="store_true",
+                    help="measurement: the WHOLE run with the weight gradients on the main stream (every launch "
+                         "alone on the device; tools/collect_traces.sh); not the product schedule")
     ap.add_argument("--no-prefetch-compact", action="store_true",
                     help="run graph_compact's counting phase inside the step instead of one batch ahead")
     ap.add_argument("--no-probe", action="store_true",
@@ -371,6 +374,9 @@ def main():
                          "numbers are not a measurement")
     args = ap.parse_args()
     SHAPE, MODEL, BATCH = args.shape, args.model, args.batch
+    if args.one_stream:
+        mpnn.WGRAD_SIDE_STREAM = False
+        args.no_one_stream = True
     headline = SHAPE == "gdb13" and MODEL == "ggnn" and BATCH == 1000
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

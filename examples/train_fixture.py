@@ -2,11 +2,12 @@
 (Workflow.train_epoch, Workflow.py:766-798) on the reference's shipped preprocessed data
 (data/pre-training/gdb13_1K-debug/train.h5; here the committed .npz conversion of it):
 
-    int8 block -> ShardedBlockLoader -> gnn.mpnn.GGNN(constants) -> apd_kl_loss -> FusedAdam
+    HDF / int8 rows -> BlockStreamLoader (block-wise, like BlockDatasetLoader.py:77-99) -> gnn.mpnn.GGNN(constants)
+    -> apd_kl_loss -> FusedAdam
 
     python examples/train_fixture.py [--epochs 30] [--batch 32] [--model GGNN|AttGGNN] [--h5 path.h5]
 
-With --h5 the three datasets are read from a GraphINVENT .h5 file through libhdf5 (ctypes)."""
+With --h5 the three datasets are STREAMED from a GraphINVENT .h5 file through libhdf5 (ctypes), a block at a time."""
 import argparse
 import os
 import sys
@@ -19,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from graphinvent_amd import dp                                    # noqa: E402
 from graphinvent_amd.gnn import mpnn                              # noqa: E402
-from graphinvent_amd.loader import ShardedBlockLoader, read_hdf_int8   # noqa: E402
+from graphinvent_amd.loader import ArraySource, BlockStreamLoader, HDFSource   # noqa: E402
 from graphinvent_amd.loss import apd_kl_loss                      # noqa: E402
 from graphinvent_amd.optim import FusedAdam                       # noqa: E402
 
@@ -43,15 +44,18 @@ def constants_for(nodes, edges, apds):
 
 def train(epochs=30, batch=32, model_name="GGNN", h5=None, seed=0, verbose=True):
     if h5:
-        nodes, edges, apds = read_hdf_int8(h5)
+        source = HDFSource(h5)
+        nodes, edges, apds = (np.empty((1,) + tuple(shp), dtype=np.int8) for shp in source.row_shapes)   # shapes only
     else:
         d = np.load(os.path.join(ROOT, "tests", "golden", "gdb13_1K-debug_train.npz"))
         nodes, edges, apds = d["nodes"], d["edges"], d["APDs"]
+        source = ArraySource(nodes, edges, apds)
     torch.manual_seed(seed)
     cls = mpnn.GGNN if model_name == "GGNN" else mpnn.AttentionGGNN
     model = cls(constants_for(nodes, edges, apds)).to("cuda").train()
     opt = FusedAdam(model.parameters(), lr=1e-4)                  # defaults.py:120 init_lr
-    loader = ShardedBlockLoader(nodes, edges, apds, batch, seed=seed)   # drops all-zero target rows
+    # trailing all-zero target rows (dataset-size padding) are trimmed; the ragged last minibatch is kept
+    loader = BlockStreamLoader(source, batch, block_size=max(batch, 10000), seed=seed)
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=epochs * len(loader) + 1)
     trainer = dp.DataParallel(model, opt, sched, loss_fn=apd_kl_loss)
     history = []

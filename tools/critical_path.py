@@ -1,7 +1,7 @@
 """Where one training step spends its time, from a (trimmed) rocprofv3 kernel trace as written by
-tools/ab/ab_run41.sh (columns Kernel_Name, Queue_Id, Start_Timestamp, End_Timestamp in ns):
+tools/collect_traces.sh (columns Kernel_Name, Queue_Id, Start_Timestamp, End_Timestamp in ns):
 
-    python tools/critical_path.py profiles/r02/trace_default.csv [step_index] [--list]
+    python tools/critical_path.py profiles/r03/trace_default.csv [step_index] [--list]
 
 The step between two consecutive `adam_kernel` launches is split into the phases of the fused forward /
 backward by structural markers (kernel names, not grid sizes): per phase the wall-clock span on the main
@@ -30,7 +30,7 @@ def main():
     st = rows[lo:hi]
     fill = next(r for r in st if "compact_fill" in r["Kernel_Name"] and r["Queue_Id"] == main_q)
     mq = [r for r in st if r["Queue_Id"] == main_q and r["s"] >= fill["s"]]
-    side_names = ("gi_gemm_batch_kernel<1, 1, true, true>", "reduce_slabs")
+    side_names = ("gi_gemm_batch_kernel<1, 1, true, true", "gi_gemm_tiles_kernel<1, 1, true, true", "reduce_slabs")
     side = [r for r in st if r["Queue_Id"] != main_q and any(n in r["Kernel_Name"] for n in side_names)]
     t0 = fill["s"]
 

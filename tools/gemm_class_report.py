@@ -1,10 +1,10 @@
 """Per-launch-class efficiency of the GEMM family with every launch ALONE on the device:
 
-    python tools/gemm_class_report.py profiles/r02/trace_onestream.csv profiles/r02/gemm_launch_log.txt
+    python tools/gemm_class_report.py profiles/r03/trace_onestream.csv profiles/r03/gemm_launch_log.txt
 
 Joins the `GI_GEMM_LOG` launch log (layout class, problems, useful FLOP, M x N x K per problem; one line per
 gi_gemm / gi_gemm_batch launch in launch order) with the kernel durations of a trace taken with
-GI_WGRAD_SIDE_STREAM=0 (tools/ab/ab_run41.sh).  Forward (class 00) and dgrad (class 01) launches are matched one
+`bench.py --one-stream` (tools/collect_traces.sh).  Forward (class 00) and dgrad (class 01) launches are matched one
 to one by their order inside a step — their sequence does not depend on the stream schedule; weight-gradient
 launches (class 11) are batched differently with and without the side stream, so they are reported as a total.
 TFLOP/s against the 157.3 TFLOP/s fp32 MFMA peak."""
