@@ -442,6 +442,11 @@ def main():
                                  if trainer.overlap else "flat fp32 bucket after the backward")},
     }
     result["config"]["fuse_flags"] = int(lib.load().gi_fuse_flags())     # GI_FUSE_* variants in use
+    result["config"]["gemm_arithmetic"] = (
+        "fp32 operands, fp32 accumulate everywhere; node-level readout layers >= 192 wide (6 of the 41 GEMM-family "
+        "launches per step) as three-way bf16 splits on the bf16 MFMA pipe (six bf16 products per fp32 product, "
+        "max error 4e-7 of sum|a||b|, the fp32 MFMA chain's own: 5e-7), everything else on v_mfma_f32_32x32x2_f32"
+        if lib.load().gi_bf3_enable(-1) else "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere")
     # graph_compact's sizes: found on the host (counting phase one batch ahead) / read back behind the stream
     result["config"]["compact_readbacks_timed_steps"] = first_readbacks
     if args.backend != "nccl":
@@ -566,6 +571,20 @@ def main():
                             "slower than the product path (ms_per_step above), the launches are shorter"}
         finally:
             mpnn.WGRAD_SIDE_STREAM = True
+    # The same step with every GEMM on the fp32 MFMA (gi_bf3_enable(0)): by default the six node-level
+    # hidden-layer launches of a step (forward + dgrad, K = N = 250 / 500) run as bf16x3 splits on the bf16 MFMA
+    # pipe — fp32 operands, fp32 accumulate, the same result to ~3e-7 (tests/test_kernels_gpu.py) — reported
+    # next to the headline so that the effect of that choice is visible, never instead of it.
+    if not args.no_one_stream:
+        was = handle.gi_bf3_enable(0)
+        try:
+            d0, _ = timed_steps(wl, 8, 2, world, device)
+        finally:
+            handle.gi_bf3_enable(was)
+        if rank == 0:
+            result["fp32_mfma_only"] = {"ms_per_step": round(d0 / 8 * 1e3, 3),
+                                        "value": round(BATCH * world * 8 / d0, 1), "unit": "graphs/s",
+                                        "note": "gi_bf3_enable(0) / GI_BF3=0: no bf16x3 launches"}
     if rank == 0 and not args.no_forward_only:
         # forward-only rate: inference on the same resident batches, no_grad
         model.eval()

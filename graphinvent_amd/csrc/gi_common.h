@@ -45,6 +45,12 @@ int gi_seg_softmax_fwd_n(const float* en, const float* emb, int ld, const int* p
 int gi_gru_gates_fwd_n(float* gi, float* gh, int ldg, const float* hx_prev, float* hx_new, int ldh,
                        const int* seg_off, int rows, int H, int Fn, const int* rows_dev, void* stream);
 
+// gi_gemm_batch hands launches whose problems all carry GI_GEMM_BF3 to gi_gemm_bf3.hip
+int gi_gemm_bf3_launch(const gi_gemm_params* probs, int n, void* stream);
+// GI_GEMM_LOG line of a launch (gi_gemm.hip); cls: two characters, "00" forward / "01" dgrad / "11" wgrad layouts,
+// "b0" / "b1" the bf16x3 launches of the forward / dgrad
+void gi_gemm_log_launch(const char* cls, const gi_gemm_params* probs, int n, int blocks, double flops);
+
 // ---- pass-0 row cache (gi_graph.p0_cache, gi_compact.hip): lookup before the pass-0 stack launch (words[0] =
 // hit flag, rows copied into m0 / e0 on a hit), insert after it (no-op on a hit).  nfam = 1 (message rows) or
 // 2 (message + energy rows); rows are ldm floats per family.

@@ -571,15 +571,19 @@ static FILE* launch_log() {
     return f;
 }
 
-static void log_launch(const gi_gemm_params* probs, int n, int blocks, double flops) {
+void gi_gemm_log_launch(const char* cls, const gi_gemm_params* probs, int n, int blocks, double flops) {
     FILE* f = launch_log();
     if (!f) return;
-    fprintf(f, "%d%d %d %d %.0f", probs[0].a_major, probs[0].b_major, n, blocks, flops);
+    fprintf(f, "%s %d %d %.0f", cls, n, blocks, flops);
     for (int i = 0; i < n; ++i)
         fprintf(f, " %dx%dx%d:g%d:s%d", probs[i].M, probs[i].N, probs[i].K, probs[i].ngroups,
                 probs[i].nsplit);
     fputc('\n', f);
     fflush(f);
+}
+static void log_launch(const gi_gemm_params* probs, int n, int blocks, double flops) {
+    const char cls[3] = {(char)('0' + (probs[0].a_major ? 1 : 0)), (char)('0' + (probs[0].b_major ? 1 : 0)), 0};
+    gi_gemm_log_launch(cls, probs, n, blocks, flops);
 }
 
 static int validate(const gi_gemm_params& p) {
@@ -665,15 +669,15 @@ static int own_epilogue(bool am, bool bm) {
 
 // Persistent grid: the number of workgroups of this kernel variant the device holds at once
 // (occupancy x CUs, from the runtime, cached per variant).  A launch with at least
-// GI_GEMM_PERSIST / 10 times that many tiles runs as that many workgroups walking the tile list
-// (stride = grid); smaller launches keep one workgroup per tile.  GI_GEMM_PERSIST=0 disables
+// persist_tenths / 10 times that many tiles runs as that many workgroups walking the tile list
+// (stride = grid); smaller launches keep one workgroup per tile.  0 disables
 // (default 0, see DESIGN.md: measured a tie on the device alone and a loss beside the weight-gradient stream).
 static int g_persist_tenths = -1, g_grid_cap = 0;
 static int persist_tenths() {
-    if (g_persist_tenths < 0) g_persist_tenths = getenv("GI_GEMM_PERSIST") ? atoi(getenv("GI_GEMM_PERSIST")) : 0;
+    if (g_persist_tenths < 0) g_persist_tenths = 0;
     return g_persist_tenths;
 }
-// Measurement / test hook: persist_tenths >= 0 replaces the GI_GEMM_PERSIST threshold; grid_cap > 0 runs
+// Measurement / test hook: persist_tenths >= 0 sets that threshold; grid_cap > 0 runs
 // every launch with more tiles than that as grid_cap workgroups walking the tile list (tests use a tiny
 // cap to push small problems through the tile loop), 0 removes the cap.
 extern "C" int gi_gemm_config(int persist_tenths_, int grid_cap) {
@@ -728,6 +732,9 @@ static int launch_tiles(GemmBatch& b, double flops, hipStream_t st) {
 extern "C" int gi_gemm_batch(const gi_gemm_params* probs, int n, void* stream) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (!probs || n < 1 || n > GI_GEMM_BATCH_MAX) return GI_EINVAL;
+    int nbf3 = 0;
+    for (int i = 0; i < n; ++i) nbf3 += (probs[i].flags & GI_GEMM_BF3) != 0;
+    if (nbf3) return nbf3 == n ? gi_gemm_bf3_launch(probs, n, stream) : GI_EINVAL;
     GemmBatch b;
     memset(&b, 0, sizeof(b));
     double flops = 0;

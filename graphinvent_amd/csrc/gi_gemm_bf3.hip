@@ -1,0 +1,330 @@
+// fp32 GEMM on the bf16 MFMA pipe by three-way operand splits (gfx950).
+//
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate and, on this path's big launches, at 0.60-0.64 of
+// its own peak with the chip power-limited.  Every fp32 value is the exact sum of
+// three bf16 values up to 2^-25 of its magnitude,
+//     x = x1 + x2 + x3,   x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)      (round to nearest even;
+//                                                                    both residuals are exact in fp32)
+// so   a b = a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1) + O(2^-24 |a b|):
+// six bf16 products per fp32 product, exact in the MFMA's fp32 accumulate, 12 v_mfma_f32_32x32x16_bf16 (32 cycles
+// each) per 32x32x32 block product against 16 v_mfma_f32_32x32x2_f32 (64 cycles each): 2.7x on the MFMA pipe
+// at an error of the size of fp32's own rounding (measured max |err| / sum |a||b| below 3e-7; the path's
+// parity bar is 1e-4).
+//
+//   C[M, N] = epilogue( A[M, K] . B[N, K]^T )      A fp32 row-major (activations, split while staging),
+//                                                  B a PRE-SPLIT image: three bf16 planes [N][Kp], Kp = K
+//                                                  rounded up to 32, zero padded (gi_bf3_pack: weights, once
+//                                                  per forward / backward; a transposed source gives dgrad's W^T)
+// Block = 256 threads = 4 waves (2 x 2), block tile 128 x 128 x 16, wave tile 64 x 64 = 2 x 2 accumulators of
+// 32 x 32.  LDS per k tile and operand: three planes of 128 rows x 16 bf16 (32 B per row, its two 16-byte
+// chunks swapped when (row >> 3) & 1: the 16 lanes of every ds_read_b128 lane group — rows {0-3, 12-15, 20-27} /
+// {4-11, 16-19, 28-31} of a fragment — then hit the 16 distinct 16-byte slots of the 256-byte bank row; with
+// (row >> 2) & 1 they were 2-way conflicted), double buffered: 48 KB and 156 VGPRs -> THREE workgroups per CU, whose staging / conversion
+// phases run under each other's MFMAs (one barrier per k tile of 24 MFMAs per wave).
+#include <string.h>
+#include <stdint.h>
+
+#include "gi_common.h"
+#include "gi_mfma.h"
+
+typedef __bf16 gi_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gi_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float gi_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned gi_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned gi_u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ float b3_sink[256];                    // where out-of-range lanes of edge tiles store
+
+constexpr int B3_BM = 128, B3_BN = 128, B3_BK = 16;
+constexpr int B3_ROWB = B3_BK * 2;                 // bytes of one row of one plane of a k tile (16 bf16)
+constexpr int B3_PLANE = 128 * B3_ROWB;            // 4 KB
+constexpr int B3_OPER = 3 * B3_PLANE;              // 12 KB
+constexpr int B3_BUF = 2 * B3_OPER;                // A + B of one k tile: 24 KB
+
+__host__ __device__ inline int b3_r32(int k) { return (k + 31) & ~31; }
+
+__device__ __forceinline__ unsigned b3_pk(float lo, float hi) {
+    gi_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, gi_bf16x2));     // v_cvt_pk_bf16_f32 (RNE)
+}
+__device__ __forceinline__ float b3_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float b3_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+// two fp32 values -> their three bf16 planes, packed pairwise (low half = x0)
+__device__ __forceinline__ void b3_split2(float x0, float x1, unsigned& p0, unsigned& p1, unsigned& p2) {
+    p0 = b3_pk(x0, x1);
+    const float r0 = x0 - b3_lo(p0), r1 = x1 - b3_hi(p0);
+    p1 = b3_pk(r0, r1);
+    const float s0 = r0 - b3_lo(p1), s1 = r1 - b3_hi(p1);
+    p2 = b3_pk(s0, s1);
+}
+
+// ---- operand image ------------------------------------------------------------------------------------
+struct B3PackArgs {
+    gi_bf3_pack_desc d[GI_BF3_PACK_MAX];
+    long long start[GI_BF3_PACK_MAX + 1];      // prefix of k PAIRS over the descriptors
+    int n;
+};
+
+__global__ __launch_bounds__(256) void gi_bf3_pack_kernel(const B3PackArgs a) {
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= a.start[a.n]) return;
+    int i = 0;
+    while (i < a.n - 1 && id >= a.start[i + 1]) ++i;
+    const gi_bf3_pack_desc& d = a.d[i];
+    const int Kp = b3_r32(d.cols), half = Kp >> 1;
+    const long long local = id - a.start[i];
+    const int n = (int)(local / half), k = 2 * (int)(local - (long long)n * half);
+    auto src = [&](int kk) -> float {
+        if (kk >= d.cols) return 0.f;
+        return d.transpose ? d.W[(long long)kk * d.ld + n] : d.W[(long long)n * d.ld + kk];
+    };
+    unsigned p0, p1, p2;
+    b3_split2(src(k), src(k + 1), p0, p1, p2);
+    unsigned* img = reinterpret_cast<unsigned*>(d.image);
+    const long long plane = (long long)d.rows * half, at = (long long)n * half + (k >> 1);
+    img[at] = p0; img[plane + at] = p1; img[2 * plane + at] = p2;
+}
+
+// ---- GEMM ---------------------------------------------------------------------------------------------
+struct B3Batch {
+    gi_gemm_params p[8];
+    int start[9];
+    int gx[8];
+    int n, total;
+};
+
+template <int EPI>       // 0: epilogue from the run-time flags, 1: bias + SELU (forward), 2: * selu'(act) (dgrad)
+__global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * B3_BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lhi = lane >> 5;
+
+    // ---- tile (block-uniform) ----------------------------------------------------------------------
+    int pi = 0;
+    while (pi < b.n - 1 && (int)blockIdx.x >= b.start[pi + 1]) ++pi;
+    const gi_gemm_params& p = b.p[pi];
+    const int local = blockIdx.x - b.start[pi];
+    const int by = local / b.gx[pi], bx = local - by * b.gx[pi];
+    const int m_end = p.m_dev ? min(p.M, *p.m_dev) : p.M;
+    const int m0 = by * B3_BM, n0 = bx * B3_BN;
+    if (m0 >= m_end) return;                                   // (bounded launch: beyond the rows on the device)
+    const int K = p.K, Kp = b3_r32(K), nk = Kp / B3_BK;
+    const unsigned char* const Bimg = reinterpret_cast<const unsigned char*>(p.B);
+    const long long bplane = (long long)p.N * Kp * 2;          // bytes per plane of the image
+
+    // ---- staging coordinates -----------------------------------------------------------------------
+    // A: 128 rows x 4 float4 per k tile -> 2 float4 per thread: k chunk c4 = tid & 3, rows (tid >> 2) + 64 i
+    const int c4 = tid & 3;
+    unsigned a_off[2], a_lds[2];
+    const int a_cmax = (p.lda >= ((K + 3) & ~3)) ? ((K + 3) & ~3) - 4 : K - 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rl = (tid >> 2) + 64 * i;
+        int row = min(m0 + rl, m_end - 1);
+        if (p.a_idx) row = p.a_idx[row];
+        a_off[i] = (unsigned)row * (unsigned)p.lda * 4u;
+        a_lds[i] = rl * B3_ROWB + 16 * ((c4 >> 1) ^ ((rl >> 3) & 1)) + 8 * (c4 & 1);
+    }
+    // B: per plane 128 rows x 2 chunks of 16 B -> one chunk per thread and plane
+    unsigned b_off, b_lds;
+    {
+        const int rl = tid >> 1, c = tid & 1;
+        const int row = min(n0 + rl, p.N - 1);
+        b_off = (unsigned)row * (unsigned)Kp * 2u + 16u * c;
+        b_lds = rl * B3_ROWB + 16 * (c ^ ((rl >> 3) & 1));
+    }
+
+    // two register stages: k tile kt + 2 travels global -> registers during the MFMAs of tiles kt and kt + 1
+    // (16-deep tiles are 24 MFMAs = 0.3 us of work per wave, far less than a trip to L2 / HBM)
+    v4f ra0[2], ra1[2];
+    gi_u32x4 rb0[3], rb1[3];
+    auto gload = [&](int kt, v4f (&ra)[2], gi_u32x4 (&rb)[3]) {
+        const int k0 = kt * B3_BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ra[i] = gi_load4_raw((const float*)((const char*)p.A + a_off[i]), k0 + 4 * c4, a_cmax);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            rb[pl] = *reinterpret_cast<const gi_u32x4*>(Bimg + pl * bplane + b_off + (unsigned)k0 * 2u);
+    };
+    auto sstore = [&](int kt, int buf, v4f (&ra)[2], gi_u32x4 (&rb)[3]) {
+        unsigned char* As = smem + buf * B3_BUF;
+        unsigned char* Bs = As + B3_OPER;
+        const int k0 = kt * B3_BK;
+        const bool full = k0 + B3_BK <= K;                       // block-uniform
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            v4f v = ra[i];
+            if (!full) v = gi_fix4(v, k0 + 4 * c4, a_cmax, K, true);
+            gi_u32x2 w0, w1, w2;
+            unsigned x0, x1, x2, y0, y1, y2;
+            b3_split2(v.x, v.y, x0, x1, x2);
+            b3_split2(v.z, v.w, y0, y1, y2);
+            w0.x = x0; w0.y = y0; w1.x = x1; w1.y = y1; w2.x = x2; w2.y = y2;
+            *reinterpret_cast<gi_u32x2*>(As + a_lds[i]) = w0;
+            *reinterpret_cast<gi_u32x2*>(As + B3_PLANE + a_lds[i]) = w1;
+            *reinterpret_cast<gi_u32x2*>(As + 2 * B3_PLANE + a_lds[i]) = w2;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<gi_u32x4*>(Bs + pl * B3_PLANE + b_lds) = rb[pl];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    auto compute = [&](int buf) {
+        const unsigned char* As = smem + buf * B3_BUF;
+        const unsigned char* Bs = As + B3_OPER;
+        gi_bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ra_ = wm * 64 + t * 32 + l31, rb_ = wn * 64 + t * 32 + l31;
+            const int oa = ra_ * B3_ROWB + 16 * (lhi ^ ((ra_ >> 3) & 1)), ob = rb_ * B3_ROWB + 16 * (lhi ^ ((rb_ >> 3) & 1));
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                af[t][pl] = *reinterpret_cast<const gi_bf16x8*>(As + pl * B3_PLANE + oa);
+                bf[t][pl] = *reinterpret_cast<const gi_bf16x8*>(Bs + pl * B3_PLANE + ob);
+            }
+        }
+        // smallest terms first; four independent accumulators between two MFMAs on the same one
+        constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][TA[term]], bf[u][TB[term]],
+                                                                        acc[t][u], 0, 0, 0);
+    };
+
+    // ---- k loop (nk is even: the image is padded to 32): loads two tiles ahead, one barrier per tile ------------
+    gload(0, ra0, rb0);
+    gload(1, ra1, rb1);
+    sstore(0, 0, ra0, rb0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        gload(min(kt + 2, nk - 1), ra0, rb0);                    // (past the end: re-load the last tile, unused)
+        compute(0);
+        sstore(kt + 1, 1, ra1, rb1);
+        __syncthreads();
+        gload(min(kt + 3, nk - 1), ra1, rb1);
+        compute(1);
+        sstore(min(kt + 2, nk - 1), 0, ra0, rb0);
+        __syncthreads();
+    }
+
+    // ---- epilogue (C/D layout of a 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) --
+    const int flags = EPI == 1 ? (GI_EPI_BIAS | GI_EPI_SELU) : (EPI == 2 ? GI_EPI_DSELU : p.flags);
+    const bool need_act = (flags & (GI_EPI_DSELU | GI_EPI_MULACT)) != 0;
+    const bool need_c = (flags & GI_EPI_ACCUM) != 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int col = n0 + wn * 64 + u * 32 + l31;
+            const bool col_ok = col < p.N;
+            const int colc = col_ok ? col : p.N - 1;
+            const int row0 = m0 + wm * 64 + t * 32 + 4 * lhi;
+            const float bv = (flags & GI_EPI_BIAS) ? p.bias[colc] : 0.f;
+            float av[16], cv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {                        // every load of the block before the first store
+                const int row = min(row0 + 8 * (r >> 2) + (r & 3), m_end - 1);
+                if (need_act) av[r] = p.act[(long long)row * p.ldact + colc];
+                if (need_c) cv[r] = p.C[(long long)row * p.ldc + colc];
+            }
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = acc[t][u][r] + bv;
+                if (flags & GI_EPI_SELU) x = gi_selu(x);
+                if (flags & GI_EPI_DSELU) x *= gi_selu_grad(av[r]);
+                if (flags & GI_EPI_MULACT) x *= av[r];
+                if (flags & GI_EPI_ACCUM) x += cv[r];
+                v[r] = x;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + 8 * (r >> 2) + (r & 3);
+                float* dst = (col_ok & (row < m_end)) ? p.C + (long long)row * p.ldc + col : b3_sink + tid;
+                *dst = v[r];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" long long gi_bf3_image_elems(int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return GI_EINVAL;
+    return 3LL * rows * b3_r32(cols);
+}
+
+extern "C" int gi_bf3_pack(const gi_bf3_pack_desc* descs, int n, void* stream) {
+    (void)hipGetLastError();
+    if (!descs || n < 1 || n > GI_BF3_PACK_MAX) return GI_EINVAL;
+    B3PackArgs a;
+    memset(&a, 0, sizeof(a));
+    long long total = 0;
+    for (int i = 0; i < n; ++i) {
+        const gi_bf3_pack_desc& d = descs[i];
+        if (!d.W || !d.image || d.rows <= 0 || d.cols <= 0 || d.ld < (d.transpose ? d.rows : d.cols))
+            return GI_EINVAL;
+        if (((uintptr_t)d.image & 15) != 0) return GI_EINVAL;
+        a.d[i] = d;
+        a.start[i] = total;
+        total += (long long)d.rows * (b3_r32(d.cols) / 2);
+    }
+    a.start[n] = total; a.n = n;
+    if (total > 0x7fffffffLL * 256) return GI_ELIMIT;
+    hipLaunchKernelGGL(gi_bf3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return gi_launch_status();
+}
+
+// gi_gemm_batch hands launches whose problems all carry GI_GEMM_BF3 to this launcher
+int gi_gemm_bf3_launch(const gi_gemm_params* probs, int n, void* stream) {
+    B3Batch b;
+    memset(&b, 0, sizeof(b));
+    double flops = 0;
+    int total = 0, k = 0;
+    int epi = -1;
+    for (int i = 0; i < n; ++i) {
+        const gi_gemm_params& p = probs[i];
+        if (p.a_major || p.b_major || p.ngroups || p.b_idx || p.nsplit != 1 || p.k_dev || !p.A || !p.B || !p.C)
+            return GI_EINVAL;
+        if (p.M < 0 || p.N <= 0 || p.K <= 0 || p.lda < p.K) return GI_EINVAL;
+        if (((uintptr_t)p.B & 15) != 0) return GI_EINVAL;
+        const int f = p.flags & ~GI_GEMM_BF3;
+        if (f & ~(GI_EPI_BIAS | GI_EPI_SELU | GI_EPI_DSELU | GI_EPI_ACCUM | GI_EPI_MULACT)) return GI_EINVAL;
+        if ((f & GI_EPI_BIAS) && !p.bias) return GI_EINVAL;
+        if ((f & (GI_EPI_DSELU | GI_EPI_MULACT)) && !p.act) return GI_EINVAL;
+        const long long lim = 0xffffffffLL / 4;
+        if (!p.a_idx && (long long)p.M * p.lda > lim) return GI_ELIMIT;
+        if ((long long)p.N * b3_r32(p.K) * 2 > 0xffffffffLL) return GI_ELIMIT;
+        const int e = f == (GI_EPI_BIAS | GI_EPI_SELU) ? 1 : (f == GI_EPI_DSELU ? 2 : 0);
+        epi = (epi < 0 || epi == e) ? e : 0;
+        if (p.M == 0) continue;
+        b.p[k] = p; b.p[k].flags = f;
+        b.gx[k] = gi_cdiv(p.N, B3_BN);
+        b.start[k] = total;
+        total += b.gx[k] * gi_cdiv(p.M, B3_BM);
+        flops += 2.0 * (double)p.M * (double)p.N * (double)p.K;
+        ++k;
+    }
+    if (k == 0) return 0;
+    b.start[k] = total; b.n = k; b.total = total;
+    hipStream_t st = (hipStream_t)stream;
+    GiProfScope prof(st, GI_PROF_GEMM, flops);
+    gi_gemm_log_launch((b.p[0].flags & GI_EPI_BIAS) ? "b0" : "b1", b.p, k, total, flops);
+    if (epi == 1) hipLaunchKernelGGL(gi_gemm_bf3_kernel<1>, dim3(total), dim3(256), 0, st, b);
+    else if (epi == 2) hipLaunchKernelGGL(gi_gemm_bf3_kernel<2>, dim3(total), dim3(256), 0, st, b);
+    else hipLaunchKernelGGL(gi_gemm_bf3_kernel<0>, dim3(total), dim3(256), 0, st, b);
+    return gi_launch_status();
+}

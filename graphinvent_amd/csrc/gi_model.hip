@@ -113,11 +113,24 @@ struct Ws {
     long long fshift;
     // split-K slabs of the skinny, long-reduction layers of the graph-level stacks (skinny_splits)
     long long skinny, skinny_floats;
+    long long bf3, bf3_floats;          // bf16x3 operand images of the node-level stacks' wide layers (gi_gemm_bf3.hip)
     long long total;
 };
 
 bool chain_fits(const Mlp& q, int dx_cols);
 long long chain_image_floats(const Mlp& q, int groups, bool backward, long long* stride);
+
+// Layers of the node-level readout stacks that run on the bf16 MFMA pipe (gi_gemm_bf3.hip: fp32 operands split
+// three ways, fp32 accumulate — the same result to ~3e-7): wide enough for 128 x 128 tiles in both directions.
+// GI_BF3=0 keeps every GEMM on v_mfma_f32_32x32x2_f32.
+constexpr int BF3_MIN_WIDTH = 192, BF3_MIN_ROWS = 2048;
+static int g_bf3 = -1;                  // -1: not read yet
+bool bf3_enabled() {
+    if (g_bf3 < 0) g_bf3 = getenv("GI_BF3") ? (atoi(getenv("GI_BF3")) != 0) : (GI_BF3_DEFAULT != 0);
+    return g_bf3 != 0;
+}
+bool bf3_wide(const Mlp& q, int l) { return q.fan_in(l) >= BF3_MIN_WIDTH && q.fan_out(l) >= BF3_MIN_WIDTH; }
+bool bf3_layer_ok(const Mlp& q, int l) { return bf3_enabled() && bf3_wide(q, l); }
 
 // A forward / dgrad problem with few output tiles and a long reduction (the first layer of fAddNet2 at
 // the ChEMBL shape: 250 x 500 outputs, K = N*A + G = 9 252 — 32 workgroups walking 290 k tiles each,
@@ -221,6 +234,17 @@ void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
         w.skinny_floats = need;
         w.skinny = take(std::max(need, 4LL), 1);
     }
+    {   // images of either direction share the region (the backward re-packs)
+        const Mlp* t1[4] = {&m.att, &m.emb, &m.add1, &m.conn1};
+        long long elems = 0;
+        for (const Mlp* q : t1)
+            for (int l = 0; l < q->layers(); ++l)
+                if (bf3_wide(*q, l))          // (sized whether or not the switch is on)
+                    elems += std::max(gi_bf3_image_elems(q->fan_out(l), q->fan_in(l)),
+                                      gi_bf3_image_elems(q->fan_in(l), q->fan_out(l)));
+        w.bf3_floats = elems / 2;
+        w.bf3 = take(std::max(w.bf3_floats, 4LL), 1);
+    }
     for (int k = 0; k < (attn ? 2 : 1); ++k) {
         const Mlp& q = k ? m.eatt[0] : m.msg[0];
         if (d.passes > 0 && !d.dropout && chain_fits(q, d.H)) {   // (dropout: layer by layer)
@@ -312,6 +336,15 @@ struct Run {
     const int* d0_dev = nullptr;
     int R_bound = 0;
     const int* skip = nullptr;              // set around the pass-0 stack launch: hit flag of gi_graph.p0_cache
+    // bf16x3 operand images packed for this call (bf3_prepare): weight -> image
+    struct { const float* W; const unsigned short* img; } bf3[GI_BF3_PACK_MAX];
+    int nbf3 = 0;
+    const unsigned short* bf3_image(const float* W, int rows) const {
+        if (rows < BF3_MIN_ROWS) return nullptr;
+        for (int i = 0; i < nbf3; ++i)
+            if (bf3[i].W == W) return bf3[i].img;
+        return nullptr;
+    }
     // AlphaDropout training mode (gnn/modules.py:130-142 with p > 0)
     bool drop = false;
     unsigned long long seed = 0;
@@ -487,6 +520,19 @@ struct Deferred {
 
 void flush_batch(Run& r, Batch& b, bool wgrad) {
     if (!r.ok() || b.n == 0) { b.n = 0; b.npost = 0; r.skinny_used = 0; return; }
+    int nb3 = 0;
+    for (int i = 0; i < b.n; ++i) nb3 += (b.p[i].flags & GI_GEMM_BF3) != 0;
+    if (nb3 && nb3 < b.n) {                       // a launch is all-bf16x3 or not at all: two launches
+        gi_gemm_params keep[8];
+        int nk = 0, n3 = 0;
+        for (int i = 0; i < b.n; ++i) {
+            if (b.p[i].flags & GI_GEMM_BF3) b.p[n3++] = b.p[i];        // (n3 <= i: in-place compaction is safe)
+            else keep[nk++] = b.p[i];
+        }
+        r.chk(gi_gemm_batch(b.p, n3, r.st));
+        for (int i = 0; i < nk; ++i) b.p[i] = keep[i];
+        b.n = nk;
+    }
     if (!wgrad) {                               // common tile for the whole launch
         long long b11 = 0;
         for (int i = 0; i < b.n; ++i) b11 += (long long)gi_cdiv(b.p[i].M, 64) * gi_cdiv(b.p[i].N, 64);
@@ -510,7 +556,9 @@ void add_fwd(Batch& b, Run& r, const float* W, const float* bias, int in, int ou
     p.A = X; p.lda = ldx; p.B = W; p.ldb = in; p.bias = bias; p.C = Y; p.ldc = ldy;
     p.M = rows; p.N = out; p.K = in;
     p.flags = GI_EPI_BIAS | (selu ? GI_EPI_SELU : 0);
+    if (const unsigned short* img = r.bf3_image(W, rows)) { p.B = reinterpret_cast<const float*>(img); p.flags |= GI_GEMM_BF3; }
     if (r.dims && rows == r.R_bound) { p.m_dev = r.dims; return; }     // node-level rows: counted on the device
+    if (p.flags & GI_GEMM_BF3) return;
     maybe_split_k(b, r, p);
 }
 
@@ -522,6 +570,11 @@ void add_dgrad(Batch& b, Run& r, int widx, int n_out, int n_in, int ncols, const
     p.A = dZ; p.lda = lddz; p.B = dgrad_operand(r, widx, n_out, n_in, p); p.C = dX; p.ldc = lddx;
     p.M = rows; p.N = ncols; p.K = n_out;
     dact(r, p, act, ldact, accumulate);
+    if (ncols == n_in)
+        if (const unsigned short* img = r.bf3_image(r.P[widx], rows)) {      // W^T image: rows n_in, reduction n_out
+            p.B = reinterpret_cast<const float*>(img); p.b_major = 0; p.ldb = 0; p.flags |= GI_GEMM_BF3;
+            return;
+        }
     maybe_split_k(b, r, p);
 }
 
@@ -1044,6 +1097,30 @@ extern "C" int gi_ggnn_num_params(const gi_ggnn_dims* d) {
     return rc ? rc : m.nparams;
 }
 
+// pack the bf16x3 images of this call's direction (forward: W [out][in] as is; backward: W^T for dgrad)
+void bf3_prepare(Run& r, const Model& m, float* ws, const Ws& w, bool backward, int rows) {
+    r.nbf3 = 0;
+    if (!bf3_enabled() || r.drop || rows < BF3_MIN_ROWS || w.bf3_floats <= 0) return;
+    const Mlp* t1[4] = {&m.att, &m.emb, &m.add1, &m.conn1};
+    gi_bf3_pack_desc d[GI_BF3_PACK_MAX];
+    unsigned short* img = reinterpret_cast<unsigned short*>(ws + w.bf3);
+    long long used = 0;
+    int n = 0;
+    for (const Mlp* q : t1)
+        for (int l = 0; l < q->layers() && n < GI_BF3_PACK_MAX; ++l) {
+            if (!bf3_layer_ok(*q, l)) continue;
+            const int fi = q->fan_in(l), fo = q->fan_out(l);
+            d[n].W = r.P[q->w(l)]; d[n].ld = fi; d[n].transpose = backward ? 1 : 0;
+            d[n].rows = backward ? fi : fo; d[n].cols = backward ? fo : fi;
+            d[n].image = img + used;
+            r.bf3[n].W = d[n].W; r.bf3[n].img = d[n].image;
+            used += std::max(gi_bf3_image_elems(fo, fi), gi_bf3_image_elems(fi, fo));
+            ++n;
+        }
+    if (n) r.chk(gi_bf3_pack(d, n, r.st));
+    r.nbf3 = n;
+}
+
 static bool sizes_ok(int S, int E, int U, int D0) {
     return S >= 0 && E >= 0 && U >= 0 && U <= E && D0 >= 0 && D0 <= U;
 }
@@ -1169,6 +1246,7 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
                 r.img_f[k] = ws + w.img_f[k];
                 chain_pack(r, k ? m.eatt : m.msg, d.Fe, false, r.img_f[k]);
             }
+    bf3_prepare(r, m, ws, w, false, R);
     // pass-0 row cache (inference loops): only in front of the one-launch stack path, whose kernel can skip
     int* const p0c = static_cast<int*>(gp->p0_cache);
     const bool p0cache = p0c && w.D0 > 0 && E > 0 && !r.drop && r.img_f[0] && (!attn || r.img_f[1]) &&
@@ -1272,6 +1350,12 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
     return r.rc;
 }
 
+extern "C" int gi_bf3_enable(int on) {
+    const int was = bf3_enabled() ? 1 : 0;
+    if (on >= 0) g_bf3 = on ? 1 : 0;
+    return was;
+}
+
 extern "C" long long gi_p0_cache_words(const gi_ggnn_dims* d) {
     Model m;
     if (int rc = build_model(d, m)) return rc;
@@ -1368,6 +1452,7 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
     if (phase == GI_BWD_PASSES)          // the readout half ran (and was reduced) in an earlier call
         readout_params([&](int widx) { sp.e[widx].reduced = 1; });
     if (phase != GI_BWD_PASSES) {
+    bf3_prepare(r, m, ws, w, true, S + 1);
     // ---- tier 2 (gnn/modules.py:265-279) ---------------------------------------------------------
     if (gi_fuse_flags() & GI_FUSE_TIER2_DSELU) {
         r.chk(gi_selu_bwd_cols3_f(d_out, lddout, y_out, ldout, out_fshift, d.B, NA, ws + w.dzA, w.ldNA, NC,

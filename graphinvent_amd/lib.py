@@ -25,10 +25,11 @@ GI_MAX_GROUPS = 8
 GI_MAX_NODES = 128
 EPI_BIAS, EPI_SELU, EPI_DSELU, EPI_ACCUM, GEMM_SPLITK = 1, 2, 4, 8, 16
 EPI_MULACT = 64
+GEMM_BF3 = 128        # GI_GEMM_BF3: B is a gi_bf3_pack image; the launch runs as bf16x3 splits on the bf16 MFMA pipe
 KIND_GGNN, KIND_ATTGGNN = 0, 1
 BWD_ALL, BWD_READOUT, BWD_PASSES = 0, 1, 2
 COUNTS = 24          # GI_COUNTS
-ABI_VERSION = 10
+ABI_VERSION = 11
 #: bumped by code that rewrites model weights through raw pointers (optim.FusedAdam.step,
 #: dp.DataParallel.broadcast_parameters): invalidates gnn.mpnn's pass-0 row cache
 WEIGHTS_EPOCH = [0]     # GI_ABI_VERSION
@@ -75,6 +76,11 @@ class ChainParams(C.Structure):
 class ReduceDesc(C.Structure):
     _fields_ = [("slabs", vp), ("dW", vp), ("db", vp), ("slab_stride", cll),
                 ("n_slabs", ci), ("N", ci), ("K", ci), ("ld", ci)]
+
+
+class Bf3PackDesc(C.Structure):
+    """gi_bf3_pack_desc"""
+    _fields_ = [("W", vp), ("rows", ci), ("cols", ci), ("ld", ci), ("transpose", ci), ("image", vp)]
 
 
 class Graph(C.Structure):
@@ -156,6 +162,9 @@ SIGNATURES = {
     "gi_ggnn_num_params": (ci, [C.POINTER(GgnnDims)]),
     "gi_ggnn_workspace_floats": (cll, [C.POINTER(GgnnDims), ci, ci, ci, ci]),
     "gi_p0_cache_words": (cll, [C.POINTER(GgnnDims)]),
+    "gi_bf3_enable": (ci, [ci]),
+    "gi_bf3_image_elems": (cll, [ci, ci]),
+    "gi_bf3_pack": (ci, [C.POINTER(Bf3PackDesc), ci, vp]),
     "gi_ggnn_slab_floats": (cll, [C.POINTER(GgnnDims), ci, ci, C.POINTER(ci)]),
     "gi_ggnn_hx0_offset": (cll, [C.POINTER(GgnnDims), ci, ci, ci, ci]),
     "gi_ggnn_ldhx": (ci, [C.POINTER(GgnnDims)]),

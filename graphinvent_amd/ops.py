@@ -367,6 +367,21 @@ def compact(nodes: torch.Tensor, edges: torch.Tensor, H: int, class_csr: bool = 
 # ------------------------------------------------------------------------------------------------
 # GEMM family
 # ------------------------------------------------------------------------------------------------
+@_on_device_of("W")
+def bf3_pack(W: torch.Tensor, transpose: bool = False) -> torch.Tensor:
+    """gi_bf3_pack: the three bf16 planes of a weight matrix for `gemm(..., flags=L.GEMM_BF3)`.  W [rows, cols]
+    row-major gives B[n][k] = W[n][k]; with `transpose` B[n][k] = W[k][n] (dgrad of a Linear weight)."""
+    lib = L.load()
+    rows, cols = (W.shape[1], W.shape[0]) if transpose else (W.shape[0], W.shape[1])
+    n = lib.gi_bf3_image_elems(rows, cols)
+    img = torch.empty(n, dtype=torch.int16, device=W.device)
+    d = L.Bf3PackDesc()
+    d.W, d.rows, d.cols, d.ld, d.transpose, d.image = W.data_ptr(), rows, cols, W.stride(0), int(transpose), img.data_ptr()
+    L.check(lib.gi_bf3_pack(C.byref(d), 1, _stream()), "gi_bf3_pack")
+    return img
+
+
+
 @_on_device_of("A")
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, flags=0, bias=None, act=None, ldact=0,
          a_idx=None, b_idx=None, a_major=False, b_major=False, tm=1, tn=1, grp_off=None,

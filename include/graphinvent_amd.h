@@ -22,7 +22,8 @@
  *     gi_gemm_config and gi_mlp_chain_config, and four switches read once from the environment:
  *       GI_FUSE=<mask>          launch-count reductions (gi_fuse_flags, default 15)
  *       GI_CHAIN=0              per-bond-type stacks layer by layer through gi_gemm instead of gi_mlp_chain
- *       GI_GEMM_PERSIST=<t>     persistent tile-stream grid for GEMM launches of >= t/10 rounds (default 0: off)
+ *       GI_BF3=0                every GEMM on the fp32 MFMA (default 1: the node-level readout layers >= 192 wide run
+ *                               as bf16x3 splits on the bf16 MFMA pipe, GI_GEMM_BF3 — same result to ~3e-7)
  *       GI_GEMM_LOG=<file>      one line per GEMM launch (tools/gemm_launch_report.py)
  */
 #ifndef GRAPHINVENT_AMD_H
@@ -32,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GI_ABI_VERSION 10
+#define GI_ABI_VERSION 11
 #define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
 #define GI_MAX_NODES 128      /* max max_n_nodes */
 #define GI_P0_MAX_CLASSES 256 /* max distinct node feature rows for the pass-0 shortcut */
@@ -157,6 +158,10 @@ typedef struct gi_graph {
 #define GI_EPI_ACCUM   8   /* v += C[row,col]                                */
 #define GI_GEMM_SPLITK 16  /* reduction range partitioned by groups/splits; C is a slab set */
 #define GI_EPI_MULACT  64  /* v *= act[row,col] (a stored factor: AlphaDropout training mode) */
+#define GI_GEMM_BF3    128 /* B is a pre-split bf16 image (gi_bf3_pack); the launch runs on the bf16 MFMA pipe with
+                              fp32 operands split three ways (six bf16 products per fp32 product, fp32 accumulate:
+                              the same result to ~3e-7 of sum |a||b|).  A contig fp32, no groups / split-K / b_idx;
+                              every problem of a batched launch or none */
 
 typedef struct gi_gemm_params {
     const float* A; const float* B; float* C;
@@ -165,7 +170,7 @@ typedef struct gi_gemm_params {
     const int* grp_off;                   /* device [ngroups+1] or NULL */
     int M, N, K;                          /* output M x N, reduction length K */
     int lda, ldb, ldc, ldact;
-    int flags;                            /* GI_EPI_* | GI_GEMM_SPLITK */
+    int flags;                            /* GI_EPI_* | GI_GEMM_SPLITK | GI_GEMM_BF3 */
     int a_major, b_major;                 /* operand stored [reduction][rows] instead of [rows][reduction] */
     int tm, tn;                           /* block tile = 64*tm x 64*tn, (tm,tn) in {(1,1),(1,2),(2,2)} */
     int ngroups, nsplit;                  /* ngroups 0 = ungrouped; nsplit >= 1 */
@@ -188,7 +193,8 @@ int gi_gemm(const gi_gemm_params* p, void* stream);
  * offsets from their base pointers: every matrix must span less than 4 GB (GI_ELIMIT otherwise). */
 int gi_gemm_batch(const gi_gemm_params* problems, int n, void* stream);
 /* Measurement / test hook (process-wide): persist_tenths >= 0 sets the persistent-grid threshold in tenths of
- * a full round of resident workgroups (default 11, environment GI_GEMM_PERSIST; 0 = one workgroup per tile);
+ * a full round of resident workgroups (default 0 = one workgroup per tile: the persistent grid measured a tie alone
+ * and a loss beside the weight-gradient stream);
  * grid_cap > 0 caps every launch at that many workgroups (0 = no cap). */
 int gi_gemm_config(int persist_tenths, int grid_cap);   /* returns 0 */
 
@@ -243,6 +249,26 @@ typedef struct {
  * group, zero padded, all layers back to back): gi_mlp_chain_pack writes it from layer[].W (needs
  * nlayers, ngroups, backward, K/N/W of every layer and `image`); it stays valid until the weights
  * change, for any rows / X / out of the same stack. */
+/* ------------------------------------------------------------------------------------------
+ * Operand image for GI_GEMM_BF3 launches: the three bf16 planes [rows][Kp] (Kp = cols rounded up to 32, zero
+ * padded) of a weight matrix, one plane after the other — B[n][k] = W[n * ld + k], or W[k * ld + n] with
+ * `transpose` (dgrad of a torch.nn.Linear weight [out, in]: rows = in, cols = out, ld = in).  Valid until the
+ * weights change.  `image`: gi_bf3_image_elems(rows, cols) 2-byte elements, 16-byte aligned.
+ * ------------------------------------------------------------------------------------------ */
+#define GI_BF3_PACK_MAX 16
+#define GI_BF3_DEFAULT 1    /* gi_ggnn_forward / backward: node-level readout layers >= 192 wide on GI_GEMM_BF3 launches
+                              (environment GI_BF3=0 / 1 overrides) */
+typedef struct {
+    const float* W; int rows, cols, ld; int transpose;
+    unsigned short* image;
+} gi_bf3_pack_desc;
+/* Process-wide switch of gi_ggnn_forward / backward's use of GI_GEMM_BF3 launches (initial value: environment
+ * GI_BF3, else GI_BF3_DEFAULT): on = 1 / 0 sets it, on < 0 only queries; returns the previous setting.  The
+ * workspace size does not depend on it. */
+int gi_bf3_enable(int on);
+long long gi_bf3_image_elems(int rows, int cols);
+int gi_bf3_pack(const gi_bf3_pack_desc* descs, int n, void* stream);
+
 long long gi_mlp_chain_image_floats(const gi_chain_params* p);
 int gi_mlp_chain_pack(const gi_chain_params* chains, int nchains, void* stream);
 /* nchains (1 or 2, same direction) independent chains in one launch; `image` must be packed. */

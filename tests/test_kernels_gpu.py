@@ -150,6 +150,53 @@ def test_gemm_forward_bias_selu(M, N, K, tm, tn, gemm_grid):
     assert bool((Y[:, N:] == 7.0).all())                # nothing written outside [M, N]
 
 
+@pytest.mark.parametrize("M,N,K", [(7258, 500, 500), (1000, 250, 250), (130, 200, 685), (257, 192, 36), (64, 129, 1000)])
+def test_gemm_bf16x3_split_matches_fp64_like_the_fp32_mfma_does(M, N, K):
+    """GI_GEMM_BF3: fp32 operands split into three bf16 each, six bf16 MFMA products per fp32 product, fp32
+    accumulate — `MLP.forward`'s Linear + SELU (gnn/modules.py:166-170) and its dgrad on the bf16 pipe.  The result
+    must be as close to the fp64 product as the fp32 MFMA chain's (both ~1e-7 of sum |a||b|), far inside the path's
+    1e-4 bar; rows / columns / reduction lengths off the 128 x 128 x 32 tile grid, row gather, accumulate."""
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    lda = ops.r4(K) + 4
+    X = torch.randn(M, lda, generator=g)
+    X[:, K:] = float("nan")                               # padding beyond K must never reach a product
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ldc = ops.r4(N) + 8
+    Xd, Wd = X.to(DEV), W.to(DEV)
+    img = ops.bf3_pack(Wd)
+    Y3 = torch.full((M, ldc), 7.0, device=DEV)
+    Y1 = torch.full((M, ldc), 7.0, device=DEV)
+    ops.gemm(Xd, img, Y3, M, N, K, lda, 0, ldc, flags=L.EPI_BIAS | L.EPI_SELU | L.GEMM_BF3, bias=b.to(DEV))
+    Xc = Xd.clone(); Xc[:, K:] = 0
+    ops.gemm(Xc, Wd, Y1, M, N, K, lda, K, ldc, flags=L.EPI_BIAS | L.EPI_SELU, bias=b.to(DEV))
+    ref = D.selu(X[:, :K].double() @ W.double().t() + b.double())
+    e3, e1 = rel(Y3[:, :N], ref), rel(Y1[:, :N], ref)
+    assert e3 < 2e-6 and e3 < 4 * e1 + 1e-7, (e3, e1)
+    assert bool((Y3[:, N:] == 7.0).all())                # nothing written outside [M, N]
+    # dgrad: dX = (dZ . W) * selu'(act), W [K_out = K, N_in = N2] through the transposed image; accumulate; gather
+    N2 = N
+    Wt = torch.randn(K, N2, generator=g) / K ** 0.5       # [out, in]
+    act = torch.randn(M, ops.r4(N2), generator=g)
+    dX0 = torch.randn(M, ops.r4(N2), generator=g)
+    idx = torch.randperm(M, generator=g).int()
+    imgT = ops.bf3_pack(Wt.to(DEV), transpose=True)
+    dX = dX0.clone().to(DEV)
+    ops.gemm(Xc, imgT, dX, M, N2, K, lda, 0, ops.r4(N2), flags=L.EPI_DSELU | L.EPI_ACCUM | L.GEMM_BF3,
+             act=act.to(DEV), ldact=ops.r4(N2), a_idx=idx.to(DEV))
+    y = act[:, :N2].double()
+    grad = D.selu_grad_from_out(y)
+    refd = (X[idx.long(), :K].double() @ Wt.double()) * grad + dX0[:, :N2].double()
+    assert rel(dX[:, :N2], refd) < 2e-6
+    # a launch mixes bf16x3 problems with fp32 ones: refused, not silently computed in one precision
+    p = (L.GemmParams * 2)()
+    for q in p:
+        q.A, q.B, q.C, q.M, q.N, q.K, q.lda, q.ldb, q.ldc = Xc.data_ptr(), Wd.data_ptr(), Y1.data_ptr(), M, N, K, lda, K, ldc
+        q.nsplit, q.ones_col, q.tm, q.tn = 1, -1, 1, 1
+    p[0].B, p[0].flags = img.data_ptr(), L.GEMM_BF3
+    assert L.load().gi_gemm_batch(p, 2, None) == -1         # GI_EINVAL
+
+
 @pytest.mark.parametrize("b_major", [False, True])
 def test_gemm_split_k_forward_and_dgrad_with_slab_epilogue(b_major, gemm_grid):
     """The skinny, long-reduction layers of the graph-level stacks (B x 500 outputs, K = N*A + G): split-K into

@@ -108,7 +108,9 @@ def test_bounded_forward_is_capturable_as_one_hip_graph():
             model.sync_free = False
             ref = model(nk, ek)
             model.sync_free = True
-            assert float((got - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+            # 1e-5, not 1e-6: at B = 256 the ordinary forward (1.8 k real node rows) keeps the readout's hidden layers
+            # on the fp32 MFMA while the bounded one (sized for 3.3 k rows) takes the bf16x3 launches (>= 2 048 rows)
+            assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
 
 
 def test_bound_violations_are_flagged_not_fatal():

@@ -3,7 +3,7 @@
 #   tools/ab.sh [-r REPS] [-o OUTDIR] [-a "extra bench args"] "label ENV=1 ENV2=x" "label2 ..." ...
 # Every argument is one variant: its first word is the label, the rest are environment assignments.  The
 # variants run round-robin REPS times (default 2) so that drift hits all of them alike; summary -> OUTDIR/summary.txt
-# e.g.  tools/ab.sh -r 2 "default" "persist GI_GEMM_PERSIST=11" -a "--shape zinc --batch 1000 --steps 10 --warmup 3"
+# e.g.  tools/ab.sh -r 2 "default" "fp32 GI_BF3=0" -a "--shape zinc --batch 1000 --steps 10 --warmup 3"
 REPS=2; OUT=/root/repo/gpurun_out/ab; ARGS=""
 while getopts "r:o:a:" o; do case $o in r) REPS=$OPTARG;; o) OUT=$OPTARG;; a) ARGS=$OPTARG;; esac; done
 shift $((OPTIND - 1))

@@ -22,6 +22,9 @@ def log_steps(path):
         if len(f) < 5:
             continue
         rec = dict(cls=f[0], nprob=int(f[1]), blocks=int(f[2]), flop=float(f[3]), probs=f[4:])
+        rec["bf3"] = rec["cls"][0] == "b"                      # bf16x3 launch (gi_gemm_bf3.hip): "b0" forward, "b1" dgrad
+        if rec["bf3"]:
+            rec["cls"] = "0" + rec["cls"][1]
         first = rec["cls"] == "01" and rec["nprob"] == 1 and rec["probs"][0].split(":")[0].endswith("x45") \
             and cur is not None and any(r["cls"] == "11" for r in cur)
         if cur is None or first:
@@ -47,6 +50,8 @@ def label(rec):
     k = max(d[2] for d in dims)
     n = max(d[1] for d in dims)
     what = {"00": "forward", "01": "dgrad  ", "11": "wgrad  "}[rec["cls"]]
+    if rec.get("bf3"):
+        what = what.rstrip() + " bf16x3"
     if rec["cls"] == "01" and k <= 64:
         what = "agg p0 "                               # pass-0 aggregation cmat . m0 (same operand layouts)
     return "%s  %d problem(s), rows %d, N <= %d, K <= %d" % (what, rec["nprob"], m, n, k)
@@ -57,7 +62,10 @@ def main():
     steps = [s for s in log_steps(log) if any(r["cls"] == "11" for r in s)]
     recs = steps[-1]                                   # a complete step of the log
     launches = trace_step(trace)
-    kind = lambda name: "11" if "true, true" in name else ("01" if "false, true" in name else "00")
+    def kind(name):
+        if "gi_gemm_bf3_kernel" in name:                        # <1>: bias + SELU epilogue = forward; <2> / <0>: dgrad
+            return "00" if "<1>" in name else "01"
+        return "11" if "true, true" in name else ("01" if "false, true" in name else "00")
     by_cls = {c: [r for r in launches if kind(r["Kernel_Name"]) == c] for c in ("00", "01", "11")}
     out = []
     for c in ("00", "01"):

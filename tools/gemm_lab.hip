@@ -7,6 +7,7 @@
 //   dgrad : its backward                         (the same, B operand reduction-major)
 //   wgrad : a weight-gradient batch              (3 x 500x501 + 2 x 250x251 + 3x501 + 2 x 100x251 over 7258 rows, split-K slabs)
 //   fwd1  : one 7258x500x500 problem
+//   fwd3 / dgrad3 / fwd13 / tier23: the same launches on the bf16 MFMA pipe (GI_GEMM_BF3: B pre-split by gi_bf3_pack)
 //   tier2 : the graph-level hidden-layer launch (3 x 1000x500x500)
 //   tier2s: the same as GI_LAB_NSPLIT (default 2) split-K slabs per problem, no epilogue (what a k-split of
 //           the launch would buy: more, shorter workgroups per CU)
@@ -18,6 +19,7 @@
 extern "C" int gi_gemm_config(int, int) { return 0; }
 #else
 #include "../graphinvent_amd/csrc/gi_gemm.hip"
+#include "../graphinvent_amd/csrc/gi_gemm_bf3.hip"
 #endif
 #include <stdio.h>
 #include <string.h>
@@ -41,7 +43,10 @@ static inline int r4(int x) { return (x + 3) & ~3; }
 static double selu(double x) { return 1.0507009873554804934193349852946 * (x > 0 ? x : 1.6732632423543772848170429916717 * (exp(x) - 1)); }
 
 int main(int argc, char** argv) {
-    const char* cls = argc > 1 ? argv[1] : "fwd";
+    char clsbuf[32]; strncpy(clsbuf, argc > 1 ? argv[1] : "fwd", 31); clsbuf[31] = 0;
+    bool bf3 = false;
+    if (strlen(clsbuf) > 1 && clsbuf[strlen(clsbuf) - 1] == '3') { bf3 = true; clsbuf[strlen(clsbuf) - 1] = 0; }
+    const char* cls = clsbuf;
     const int tm = argc > 2 ? atoi(argv[2]) : 1, tn = argc > 3 ? atoi(argv[3]) : 1;
     const int persist = argc > 4 ? atoi(argv[4]) : 11;
     const char* trace_path = argc > 5 ? argv[5] : nullptr;
@@ -93,6 +98,22 @@ int main(int argc, char** argv) {
             flops += 2.0 * M * no * (ni + 1);
         }
     }
+#ifndef LAB_OLD
+    if (bf3) {
+        if (wgrad || tier2s) { printf("no bf3 variant of this class\n"); return 1; }
+        for (int i = 0; i < n; ++i) {
+            gi_gemm_params& p = probs[i];
+            gi_bf3_pack_desc d;
+            d.W = p.B; d.rows = p.N; d.cols = p.K; d.ld = p.ldb; d.transpose = p.b_major;
+            const long long ne = gi_bf3_image_elems(p.N, p.K);
+            (void)hipMalloc(&d.image, ne * 2);
+            const int rc = gi_bf3_pack(&d, 1, 0);
+            if (rc) { printf("pack rc %d\n", rc); return 1; }
+            p.B = (const float*)d.image; p.b_major = 0; p.flags |= GI_GEMM_BF3;
+        }
+        (void)hipDeviceSynchronize();
+    }
+#endif
     auto launch = [&] { const int rc = gi_gemm_batch(probs, n, 0); if (rc) { printf("rc %d\n", rc); exit(1); } };
     for (int i = 0; i < 5; ++i) launch();
     (void)hipDeviceSynchronize();
@@ -139,8 +160,8 @@ int main(int argc, char** argv) {
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         best = ms < best ? ms : best; sum += ms;
     }
-    printf("%s tile=(%d,%d) persist=%d: %.2f us per launch (best %.2f), %.1f TF (best %.1f) = %.3f of 157.3   max rel err %.2e %s\n",
-           cls, tm, tn, persist, sum / rounds / reps * 1e3, best / reps * 1e3, flops * reps * rounds / (sum * 1e-3) / 1e12,
+    printf("%s%s tile=(%d,%d) persist=%d: %.2f us per launch (best %.2f), %.1f TF (best %.1f) = %.3f of 157.3   max rel err %.2e %s\n",
+           cls, bf3 ? "3 (bf16x3)" : "", tm, tn, persist, sum / rounds / reps * 1e3, best / reps * 1e3, flops * reps * rounds / (sum * 1e-3) / 1e12,
            flops * reps / (best * 1e-3) / 1e12, flops * reps * rounds / (sum * 1e-3) / 1e12 / 157.3, worst,
            worst < 2e-5 ? "OK" : "MISMATCH");
 #ifdef GI_GEMM_TRACE
