@@ -1515,7 +1515,8 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
         // No weight-gradient batches beside the node-level dgrad launches: those fill the device by
         // themselves (2 760 workgroups each at the headline batch), two streams only contend there;
         // everything queued goes out behind them, under the message passes' short launches (round 2: step
-        // 2.362 -> 2.344 ms, GEMM-family per-launch figure 0.349 -> 0.374 of peak).
+        // 2.362 -> 2.344 ms, GEMM-family per-launch figure 0.349 -> 0.374 of peak; re-measured in round 3 with the
+        // dgrad launches on the bf16 pipe: 2.20 ms held against 2.25-2.28 released).
         r.hold_kicks = true;
         mlp_jobs_backward(r, ws, sp, slabs, dq, jobs, 4);
         r.hold_kicks = false;
