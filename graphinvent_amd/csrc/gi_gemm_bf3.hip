@@ -23,6 +23,7 @@
 // phases run under each other's MFMAs (one barrier per k tile of 24 MFMAs per wave).
 #include <string.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "gi_common.h"
 #include "gi_mfma.h"
@@ -137,26 +138,39 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
     }
 
     // two register stages: k tile kt + 2 travels global -> registers during the MFMAs of tiles kt and kt + 1
-    // (16-deep tiles are 24 MFMAs = 0.3 us of work per wave, far less than a trip to L2 / HBM)
+    // (16-deep tiles are 24 MFMAs = 0.3 us of work per wave, far less than a trip to L2 / HBM).
+    // STEADY tiles are full in k: uniform base (advanced by the SALU) + a constant 32-bit lane offset per load, no
+    // clamping, no fix-up — the generic form (clamped column, zero fill beyond K) only runs a tile's last steps.
     v4f ra0[2], ra1[2];
     gi_u32x4 rb0[3], rb1[3];
-    auto gload = [&](int kt, v4f (&ra)[2], gi_u32x4 (&rb)[3]) {
+    unsigned a_voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a_voff[i] = a_off[i] + 16u * c4;
+    auto gload = [&](auto steady_c, int kt, v4f (&ra)[2], gi_u32x4 (&rb)[3]) __attribute__((always_inline)) {
+        constexpr bool STEADY = decltype(steady_c)::value;
         const int k0 = kt * B3_BK;
+        if (STEADY) {
+            const char* abase = (const char*)p.A + (size_t)k0 * 4;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) ra[i] = gi_load4_raw((const float*)((const char*)p.A + a_off[i]), k0 + 4 * c4, a_cmax);
+            for (int i = 0; i < 2; ++i) ra[i] = *(const v4f_u*)(abase + a_voff[i]);
+        } else {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-            rb[pl] = *reinterpret_cast<const gi_u32x4*>(Bimg + pl * bplane + b_off + (unsigned)k0 * 2u);
+            for (int i = 0; i < 2; ++i)
+                ra[i] = gi_load4_raw((const float*)((const char*)p.A + a_off[i]), k0 + 4 * c4, a_cmax);
+        }
+        const unsigned char* bbase = Bimg + (size_t)k0 * 2;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) rb[pl] = *reinterpret_cast<const gi_u32x4*>(bbase + pl * bplane + b_off);
     };
-    auto sstore = [&](int kt, int buf, v4f (&ra)[2], gi_u32x4 (&rb)[3]) {
+    auto sstore = [&](auto steady_c, int kt, int buf, v4f (&ra)[2], gi_u32x4 (&rb)[3]) __attribute__((always_inline)) {
+        constexpr bool STEADY = decltype(steady_c)::value;
         unsigned char* As = smem + buf * B3_BUF;
         unsigned char* Bs = As + B3_OPER;
         const int k0 = kt * B3_BK;
-        const bool full = k0 + B3_BK <= K;                       // block-uniform
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             v4f v = ra[i];
-            if (!full) v = gi_fix4(v, k0 + 4 * c4, a_cmax, K, true);
+            if (!STEADY) v = gi_fix4(v, k0 + 4 * c4, a_cmax, K, true);
             gi_u32x2 w0, w1, w2;
             unsigned x0, x1, x2, y0, y1, y2;
             b3_split2(v.x, v.y, x0, x1, x2);
@@ -205,18 +219,32 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
     };
 
     // ---- k loop (nk is even: the image is padded to 32): loads two tiles ahead, one barrier per tile ------------
-    gload(0, ra0, rb0);
-    gload(1, ra1, rb1);
-    sstore(0, 0, ra0, rb0);
+    const std::true_type ST{};
+    const std::false_type GEN{};
+    const int n_full = K / B3_BK;                                // k tiles that are full in k
+    gload(GEN, 0, ra0, rb0);
+    gload(GEN, min(1, nk - 1), ra1, rb1);
+    sstore(GEN, 0, 0, ra0, rb0);
     __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-        gload(min(kt + 2, nk - 1), ra0, rb0);                    // (past the end: re-load the last tile, unused)
+    int kt = 0;
+    for (; kt + 3 < n_full; kt += 2) {                           // every tile touched is full: kt + 1 .. kt + 3
+        gload(ST, kt + 2, ra0, rb0);
         compute(0);
-        sstore(kt + 1, 1, ra1, rb1);
+        sstore(ST, kt + 1, 1, ra1, rb1);
         __syncthreads();
-        gload(min(kt + 3, nk - 1), ra1, rb1);
+        gload(ST, kt + 3, ra1, rb1);
         compute(1);
-        sstore(min(kt + 2, nk - 1), 0, ra0, rb0);
+        sstore(ST, kt + 2, 0, ra0, rb0);
+        __syncthreads();
+    }
+    for (; kt < nk; kt += 2) {                                   // the last one or two pairs: generic
+        gload(GEN, min(kt + 2, nk - 1), ra0, rb0);               // (past the end: re-load the last tile, unused)
+        compute(0);
+        sstore(GEN, kt + 1, 1, ra1, rb1);
+        __syncthreads();
+        gload(GEN, min(kt + 3, nk - 1), ra1, rb1);
+        compute(1);
+        sstore(GEN, min(kt + 2, nk - 1), 0, ra0, rb0);
         __syncthreads();
     }
 

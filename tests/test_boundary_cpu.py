@@ -38,6 +38,12 @@ def test_host_side_planning_functions():
     ws = lib.gi_ggnn_workspace_floats(C.byref(d), 6900, 12600, 8000, 45)
     ws0 = lib.gi_ggnn_workspace_floats(C.byref(d), 0, 0, 0, 0)
     assert ws > ws0 > 0 and ws % 4 == 0
+    was = lib.gi_bf3_enable(-1)                            # bf16x3 switch: query, set, restore; the workspace does
+    assert was in (0, 1) and lib.gi_bf3_enable(0) == was   # not depend on it (a tape of either setting feeds either)
+    ws_off = lib.gi_ggnn_workspace_floats(C.byref(d), 6900, 12600, 8000, 45)
+    assert lib.gi_bf3_enable(1) == 0 and lib.gi_ggnn_workspace_floats(C.byref(d), 6900, 12600, 8000, 45) == ws_off == ws
+    lib.gi_bf3_enable(was)
+    assert lib.gi_bf3_image_elems(500, 500) == 3 * 500 * 512 and lib.gi_bf3_image_elems(0, 5) < 0
     words = lib.gi_p0_cache_words(C.byref(d))            # pass-0 row cache: header + hash + 4096 rows of ldM floats
     assert words > 4096 * 100 and words % 4 == 0
     assert lib.gi_ggnn_workspace_floats(C.byref(d), 6900, 12600, 12601, 0) == -1   # U > E
