@@ -336,13 +336,14 @@ struct Run {
     const int* d0_dev = nullptr;
     int R_bound = 0;
     const int* skip = nullptr;              // set around the pass-0 stack launch: hit flag of gi_graph.p0_cache
-    // bf16x3 operand images packed for this call (bf3_prepare): weight -> image
-    struct { const float* W; const unsigned short* img; } bf3[GI_BF3_PACK_MAX];
+    // layers that run as bf16x3 launches in this call (bf3_prepare): weight -> W^T image (backward; the forward
+    // reads the fp32 weight as stored, GI_GEMM_BF3B_F32, img = NULL)
+    struct Bf3 { const float* W; const unsigned short* img; } bf3[GI_BF3_PACK_MAX];
     int nbf3 = 0;
-    const unsigned short* bf3_image(const float* W, int rows) const {
+    const Bf3* bf3_layer(const float* W, int rows) const {
         if (rows < BF3_MIN_ROWS) return nullptr;
         for (int i = 0; i < nbf3; ++i)
-            if (bf3[i].W == W) return bf3[i].img;
+            if (bf3[i].W == W) return &bf3[i];
         return nullptr;
     }
     // AlphaDropout training mode (gnn/modules.py:130-142 with p > 0)
@@ -556,7 +557,7 @@ void add_fwd(Batch& b, Run& r, const float* W, const float* bias, int in, int ou
     p.A = X; p.lda = ldx; p.B = W; p.ldb = in; p.bias = bias; p.C = Y; p.ldc = ldy;
     p.M = rows; p.N = out; p.K = in;
     p.flags = GI_EPI_BIAS | (selu ? GI_EPI_SELU : 0);
-    if (const unsigned short* img = r.bf3_image(W, rows)) { p.B = reinterpret_cast<const float*>(img); p.flags |= GI_GEMM_BF3; }
+    if (r.bf3_layer(W, rows)) p.flags |= GI_GEMM_BF3 | GI_GEMM_BF3B_F32;       // (B = W [out][in] as stored)
     if (r.dims && rows == r.R_bound) { p.m_dev = r.dims; return; }     // node-level rows: counted on the device
     if (p.flags & GI_GEMM_BF3) return;
     maybe_split_k(b, r, p);
@@ -571,10 +572,11 @@ void add_dgrad(Batch& b, Run& r, int widx, int n_out, int n_in, int ncols, const
     p.M = rows; p.N = ncols; p.K = n_out;
     dact(r, p, act, ldact, accumulate);
     if (ncols == n_in)
-        if (const unsigned short* img = r.bf3_image(r.P[widx], rows)) {      // W^T image: rows n_in, reduction n_out
-            p.B = reinterpret_cast<const float*>(img); p.b_major = 0; p.ldb = 0; p.flags |= GI_GEMM_BF3;
-            return;
-        }
+        if (const Run::Bf3* e = r.bf3_layer(r.P[widx], rows))
+            if (e->img) {                                                     // W^T image: rows n_in, reduction n_out
+                p.B = reinterpret_cast<const float*>(e->img); p.b_major = 0; p.ldb = 0; p.flags |= GI_GEMM_BF3;
+                return;
+            }
     maybe_split_k(b, r, p);
 }
 
@@ -1097,7 +1099,8 @@ extern "C" int gi_ggnn_num_params(const gi_ggnn_dims* d) {
     return rc ? rc : m.nparams;
 }
 
-// pack the bf16x3 images of this call's direction (forward: W [out][in] as is; backward: W^T for dgrad)
+// the layers of this call that run as bf16x3 launches; the backward packs their W^T images (the forward stages the
+// fp32 weights as stored: 4 bytes per element through L2 instead of the image's 6 — 84 -> 76 us per launch)
 void bf3_prepare(Run& r, const Model& m, float* ws, const Ws& w, bool backward, int rows) {
     r.nbf3 = 0;
     if (!bf3_enabled() || r.drop || rows < BF3_MIN_ROWS || w.bf3_floats <= 0) return;
@@ -1113,11 +1116,11 @@ void bf3_prepare(Run& r, const Model& m, float* ws, const Ws& w, bool backward, 
             d[n].W = r.P[q->w(l)]; d[n].ld = fi; d[n].transpose = backward ? 1 : 0;
             d[n].rows = backward ? fi : fo; d[n].cols = backward ? fo : fi;
             d[n].image = img + used;
-            r.bf3[n].W = d[n].W; r.bf3[n].img = d[n].image;
+            r.bf3[n].W = d[n].W; r.bf3[n].img = backward ? d[n].image : nullptr;
             used += std::max(gi_bf3_image_elems(fo, fi), gi_bf3_image_elems(fi, fo));
             ++n;
         }
-    if (n) r.chk(gi_bf3_pack(d, n, r.st));
+    if (n && backward) r.chk(gi_bf3_pack(d, n, r.st));
     r.nbf3 = n;
 }
 

@@ -25,6 +25,7 @@ GI_MAX_GROUPS = 8
 GI_MAX_NODES = 128
 EPI_BIAS, EPI_SELU, EPI_DSELU, EPI_ACCUM, GEMM_SPLITK = 1, 2, 4, 8, 16
 EPI_MULACT = 64
+GEMM_BF3A, GEMM_BF3B_F32 = 256, 512       # with GEMM_BF3: A is an image too / B is the plain fp32 matrix
 GEMM_BF3 = 128        # GI_GEMM_BF3: B is a gi_bf3_pack image; the launch runs as bf16x3 splits on the bf16 MFMA pipe
 KIND_GGNN, KIND_ATTGGNN = 0, 1
 BWD_ALL, BWD_READOUT, BWD_PASSES = 0, 1, 2

@@ -162,6 +162,10 @@ typedef struct gi_graph {
                               fp32 operands split three ways (six bf16 products per fp32 product, fp32 accumulate:
                               the same result to ~3e-7 of sum |a||b|).  A contig fp32, no groups / split-K / b_idx;
                               every problem of a batched launch or none */
+#define GI_GEMM_BF3B_F32 512 /* with GI_GEMM_BF3: B is the plain fp32 matrix [N][ldb] (a forward weight as stored), split while
+                              it is staged like A: no image, 4 bytes per element through L2 instead of 6 */
+#define GI_GEMM_BF3A   256 /* with GI_GEMM_BF3: A is a pre-split bf16 image too ([3][M][Kp], gi_bf3_pack of an [M, K]
+                              matrix or the `planes` output of a producing launch); no a_idx */
 
 typedef struct gi_gemm_params {
     const float* A; const float* B; float* C;

@@ -174,6 +174,16 @@ def test_gemm_bf16x3_split_matches_fp64_like_the_fp32_mfma_does(M, N, K):
     e3, e1 = rel(Y3[:, :N], ref), rel(Y1[:, :N], ref)
     assert e3 < 2e-6 and e3 < 4 * e1 + 1e-7, (e3, e1)
     assert bool((Y3[:, N:] == 7.0).all())                # nothing written outside [M, N]
+    # the other operand forms compute the same planes, hence the same bits: B as the plain fp32 weight (split while
+    # staged: what the model's forward launches use) and A as a pre-split image
+    Yf = torch.full((M, ldc), 7.0, device=DEV)
+    ops.gemm(Xd, Wd, Yf, M, N, K, lda, K, ldc, flags=L.EPI_BIAS | L.EPI_SELU | L.GEMM_BF3 | L.GEMM_BF3B_F32,
+             bias=b.to(DEV))
+    assert torch.equal(Yf, Y3)
+    Ya = torch.full((M, ldc), 7.0, device=DEV)
+    ops.gemm(ops.bf3_pack(Xc[:, :K]), img, Ya, M, N, K, 0, 0, ldc,
+             flags=L.EPI_BIAS | L.EPI_SELU | L.GEMM_BF3 | L.GEMM_BF3A, bias=b.to(DEV))
+    assert torch.equal(Ya, Y3)
     # dgrad: dX = (dZ . W) * selu'(act), W [K_out = K, N_in = N2] through the transposed image; accumulate; gather
     N2 = N
     Wt = torch.randn(K, N2, generator=g) / K ** 0.5       # [out, in]

@@ -44,8 +44,11 @@ static double selu(double x) { return 1.0507009873554804934193349852946 * (x > 0
 
 int main(int argc, char** argv) {
     char clsbuf[32]; strncpy(clsbuf, argc > 1 ? argv[1] : "fwd", 31); clsbuf[31] = 0;
-    bool bf3 = false;
-    if (strlen(clsbuf) > 1 && clsbuf[strlen(clsbuf) - 1] == '3') { bf3 = true; clsbuf[strlen(clsbuf) - 1] = 0; }
+    bool bf3 = false, bf3a = false, bf3f = false;        // "...3": B pre-split; "...3a": A pre-split as well; "...3f": B as fp32
+    if (strlen(clsbuf) > 2 && !strcmp(clsbuf + strlen(clsbuf) - 2, "3f")) { bf3 = bf3f = true; clsbuf[strlen(clsbuf) - 2] = 0; }
+    else
+    if (strlen(clsbuf) > 2 && !strcmp(clsbuf + strlen(clsbuf) - 2, "3a")) { bf3 = bf3a = true; clsbuf[strlen(clsbuf) - 2] = 0; }
+    else if (strlen(clsbuf) > 1 && clsbuf[strlen(clsbuf) - 1] == '3') { bf3 = true; clsbuf[strlen(clsbuf) - 1] = 0; }
     const char* cls = clsbuf;
     const int tm = argc > 2 ? atoi(argv[2]) : 1, tn = argc > 3 ? atoi(argv[3]) : 1;
     const int persist = argc > 4 ? atoi(argv[4]) : 11;
@@ -103,6 +106,7 @@ int main(int argc, char** argv) {
         if (wgrad || tier2s) { printf("no bf3 variant of this class\n"); return 1; }
         for (int i = 0; i < n; ++i) {
             gi_gemm_params& p = probs[i];
+            if (bf3f) { if (p.b_major) { printf("3f: forward layout only\n"); return 1; } p.flags |= GI_GEMM_BF3 | GI_GEMM_BF3B_F32; continue; }
             gi_bf3_pack_desc d;
             d.W = p.B; d.rows = p.N; d.cols = p.K; d.ld = p.ldb; d.transpose = p.b_major;
             const long long ne = gi_bf3_image_elems(p.N, p.K);
@@ -110,6 +114,13 @@ int main(int argc, char** argv) {
             const int rc = gi_bf3_pack(&d, 1, 0);
             if (rc) { printf("pack rc %d\n", rc); return 1; }
             p.B = (const float*)d.image; p.b_major = 0; p.flags |= GI_GEMM_BF3;
+            if (bf3a) {
+                gi_bf3_pack_desc a;
+                a.W = p.A; a.rows = p.M; a.cols = p.K; a.ld = p.lda; a.transpose = 0;
+                (void)hipMalloc(&a.image, gi_bf3_image_elems(p.M, p.K) * 2);
+                if (gi_bf3_pack(&a, 1, 0)) { printf("pack A failed\n"); return 1; }
+                p.A = (const float*)a.image; p.flags |= GI_GEMM_BF3A;
+            }
         }
         (void)hipDeviceSynchronize();
     }
@@ -161,7 +172,7 @@ int main(int argc, char** argv) {
         best = ms < best ? ms : best; sum += ms;
     }
     printf("%s%s tile=(%d,%d) persist=%d: %.2f us per launch (best %.2f), %.1f TF (best %.1f) = %.3f of 157.3   max rel err %.2e %s\n",
-           cls, bf3 ? "3 (bf16x3)" : "", tm, tn, persist, sum / rounds / reps * 1e3, best / reps * 1e3, flops * reps * rounds / (sum * 1e-3) / 1e12,
+           cls, bf3f ? "3f (bf16x3, B fp32)" : bf3a ? "3a (bf16x3, A pre-split)" : (bf3 ? "3 (bf16x3)" : ""), tm, tn, persist, sum / rounds / reps * 1e3, best / reps * 1e3, flops * reps * rounds / (sum * 1e-3) / 1e12,
            flops * reps / (best * 1e-3) / 1e12, flops * reps * rounds / (sum * 1e-3) / 1e12 / 157.3, worst,
            worst < 2e-5 ? "OK" : "MISMATCH");
 #ifdef GI_GEMM_TRACE
