@@ -63,8 +63,8 @@ def main():
     recs = steps[-1]                                   # a complete step of the log
     launches = trace_step(trace)
     def kind(name):
-        if "gi_gemm_bf3_kernel" in name:                        # <1>: bias + SELU epilogue = forward; <2> / <0>: dgrad
-            return "00" if "<1>" in name else "01"
+        if "gi_gemm_bf3_kernel" in name:                        # <1, ..>: bias + SELU epilogue = forward; <2 / 0, ..>: dgrad
+            return "00" if "gi_gemm_bf3_kernel<1" in name else "01"
         return "11" if "true, true" in name else ("01" if "false, true" in name else "00")
     by_cls = {c: [r for r in launches if kind(r["Kernel_Name"]) == c] for c in ("00", "01", "11")}
     out = []
