@@ -82,6 +82,12 @@ __global__ __launch_bounds__(256) void gi_bf3_pack_kernel(const B3PackArgs a) {
         if (kk >= d.cols) return 0.f;
         return d.transpose ? d.W[(long long)kk * d.ld + n] : d.W[(long long)n * d.ld + kk];
     };
+    if (d.as_f32) {                                            // plain fp32 copy [rows][r4(cols)] (transposed or not)
+        const int ldo = (d.cols + 3) & ~3;
+        float* out = reinterpret_cast<float*>(d.image) + (long long)n * ldo;
+        if (k < ldo) { gi_f32x2 v = {src(k), src(k + 1)}; *reinterpret_cast<gi_f32x2*>(out + k) = v; }
+        return;
+    }
     unsigned p0, p1, p2;
     b3_split2(src(k), src(k + 1), p0, p1, p2);
     unsigned* img = reinterpret_cast<unsigned*>(d.image);

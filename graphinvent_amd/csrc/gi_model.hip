@@ -573,8 +573,9 @@ void add_dgrad(Batch& b, Run& r, int widx, int n_out, int n_in, int ncols, const
     dact(r, p, act, ldact, accumulate);
     if (ncols == n_in)
         if (const Run::Bf3* e = r.bf3_layer(r.P[widx], rows))
-            if (e->img) {                                                     // W^T image: rows n_in, reduction n_out
-                p.B = reinterpret_cast<const float*>(e->img); p.b_major = 0; p.ldb = 0; p.flags |= GI_GEMM_BF3;
+            if (e->img) {                                                     // W^T as fp32 [n_in][r4(n_out)]
+                p.B = reinterpret_cast<const float*>(e->img); p.b_major = 0; p.ldb = gi_r4(n_out);
+                p.flags |= GI_GEMM_BF3 | GI_GEMM_BF3B_F32;
                 return;
             }
     maybe_split_k(b, r, p);
@@ -1115,7 +1116,7 @@ void bf3_prepare(Run& r, const Model& m, float* ws, const Ws& w, bool backward, 
             const int fi = q->fan_in(l), fo = q->fan_out(l);
             d[n].W = r.P[q->w(l)]; d[n].ld = fi; d[n].transpose = backward ? 1 : 0;
             d[n].rows = backward ? fi : fo; d[n].cols = backward ? fo : fi;
-            d[n].image = img + used;
+            d[n].image = img + used; d[n].as_f32 = 1;     // (W^T as fp32: 4 bytes per element through L2, not 6)
             r.bf3[n].W = d[n].W; r.bf3[n].img = backward ? d[n].image : nullptr;
             used += std::max(gi_bf3_image_elems(fo, fi), gi_bf3_image_elems(fi, fo));
             ++n;

@@ -81,7 +81,7 @@ class ReduceDesc(C.Structure):
 
 class Bf3PackDesc(C.Structure):
     """gi_bf3_pack_desc"""
-    _fields_ = [("W", vp), ("rows", ci), ("cols", ci), ("ld", ci), ("transpose", ci), ("image", vp)]
+    _fields_ = [("W", vp), ("rows", ci), ("cols", ci), ("ld", ci), ("transpose", ci), ("image", vp), ("as_f32", ci)]
 
 
 class Graph(C.Structure):

@@ -368,15 +368,17 @@ def compact(nodes: torch.Tensor, edges: torch.Tensor, H: int, class_csr: bool = 
 # GEMM family
 # ------------------------------------------------------------------------------------------------
 @_on_device_of("W")
-def bf3_pack(W: torch.Tensor, transpose: bool = False) -> torch.Tensor:
+def bf3_pack(W: torch.Tensor, transpose: bool = False, as_f32: bool = False) -> torch.Tensor:
     """gi_bf3_pack: the three bf16 planes of a weight matrix for `gemm(..., flags=L.GEMM_BF3)`.  W [rows, cols]
-    row-major gives B[n][k] = W[n][k]; with `transpose` B[n][k] = W[k][n] (dgrad of a Linear weight)."""
+    row-major gives B[n][k] = W[n][k]; with `transpose` B[n][k] = W[k][n] (dgrad of a Linear weight).  `as_f32`: the
+    same matrix as plain fp32 [rows][r4(cols)] in the same buffer (for `L.GEMM_BF3 | L.GEMM_BF3B_F32`, ldb = r4(cols))."""
     lib = L.load()
     rows, cols = (W.shape[1], W.shape[0]) if transpose else (W.shape[0], W.shape[1])
     n = lib.gi_bf3_image_elems(rows, cols)
     img = torch.empty(n, dtype=torch.int16, device=W.device)
     d = L.Bf3PackDesc()
     d.W, d.rows, d.cols, d.ld, d.transpose, d.image = W.data_ptr(), rows, cols, W.stride(0), int(transpose), img.data_ptr()
+    d.as_f32 = int(as_f32)
     L.check(lib.gi_bf3_pack(C.byref(d), 1, _stream()), "gi_bf3_pack")
     return img
 

@@ -265,6 +265,9 @@ typedef struct {
 typedef struct {
     const float* W; int rows, cols, ld; int transpose;
     unsigned short* image;
+    int as_f32;               /* != 0: write B as plain fp32 [rows][(cols + 3) & ~3] instead of the three planes (for
+                                 GI_GEMM_BF3B_F32 launches: a transposed copy of a weight, 4 bytes per element through L2
+                                 instead of 6); fits the same buffer */
 } gi_bf3_pack_desc;
 /* Process-wide switch of gi_ggnn_forward / backward's use of GI_GEMM_BF3 launches (initial value: environment
  * GI_BF3, else GI_BF3_DEFAULT): on = 1 / 0 sets it, on < 0 only queries; returns the previous setting.  The

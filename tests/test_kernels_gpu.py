@@ -198,6 +198,12 @@ def test_gemm_bf16x3_split_matches_fp64_like_the_fp32_mfma_does(M, N, K):
     grad = D.selu_grad_from_out(y)
     refd = (X[idx.long(), :K].double() @ Wt.double()) * grad + dX0[:, :N2].double()
     assert rel(dX[:, :N2], refd) < 2e-6
+    # the model's dgrad launches: W^T as a plain fp32 copy, split while staged — the same bits
+    dXf = dX0.clone().to(DEV)
+    ops.gemm(Xc, ops.bf3_pack(Wt.to(DEV), transpose=True, as_f32=True), dXf, M, N2, K, lda, ops.r4(K), ops.r4(N2),
+             flags=L.EPI_DSELU | L.EPI_ACCUM | L.GEMM_BF3 | L.GEMM_BF3B_F32, act=act.to(DEV), ldact=ops.r4(N2),
+             a_idx=idx.to(DEV))
+    assert torch.equal(dXf, dX)
     # a launch mixes bf16x3 problems with fp32 ones: refused, not silently computed in one precision
     p = (L.GemmParams * 2)()
     for q in p:

@@ -68,6 +68,7 @@ int main(int argc, char** argv) {
     }
     gi_gemm_params probs[8];
     Mat A[8], B[8], Cm[8], bias[8], act[8];
+    int ldb_host[8] = {};                              // leading dimension of the host copy B[i].h (p.ldb may change with the operand form)
     double flops = 0;
     for (int i = 0; i < n; ++i) {
         gi_gemm_params& p = probs[i];
@@ -101,21 +102,24 @@ int main(int argc, char** argv) {
             flops += 2.0 * M * no * (ni + 1);
         }
     }
+    for (int i = 0; i < n; ++i) ldb_host[i] = probs[i].ldb;
 #ifndef LAB_OLD
     if (bf3) {
         if (wgrad || tier2s) { printf("no bf3 variant of this class\n"); return 1; }
         for (int i = 0; i < n; ++i) {
             gi_gemm_params& p = probs[i];
-            if (bf3f) { if (p.b_major) { printf("3f: forward layout only\n"); return 1; } p.flags |= GI_GEMM_BF3 | GI_GEMM_BF3B_F32; continue; }
-            gi_bf3_pack_desc d;
+            if (bf3f && !p.b_major) { p.flags |= GI_GEMM_BF3 | GI_GEMM_BF3B_F32; continue; }    // forward: W as stored
+            gi_bf3_pack_desc d = {};
+            d.as_f32 = bf3f ? 1 : 0;                              // dgrad "3f": W^T as a plain fp32 copy
             d.W = p.B; d.rows = p.N; d.cols = p.K; d.ld = p.ldb; d.transpose = p.b_major;
             const long long ne = gi_bf3_image_elems(p.N, p.K);
             (void)hipMalloc(&d.image, ne * 2);
             const int rc = gi_bf3_pack(&d, 1, 0);
             if (rc) { printf("pack rc %d\n", rc); return 1; }
             p.B = (const float*)d.image; p.b_major = 0; p.flags |= GI_GEMM_BF3;
+            if (bf3f) { p.flags |= GI_GEMM_BF3B_F32; p.ldb = r4(p.K); }
             if (bf3a) {
-                gi_bf3_pack_desc a;
+                gi_bf3_pack_desc a = {};
                 a.W = p.A; a.rows = p.M; a.cols = p.K; a.ld = p.lda; a.transpose = 0;
                 (void)hipMalloc(&a.image, gi_bf3_image_elems(p.M, p.K) * 2);
                 if (gi_bf3_pack(&a, 1, 0)) { printf("pack A failed\n"); return 1; }
@@ -141,13 +145,13 @@ int main(int argc, char** argv) {
             s = s * 1664525u + 1013904223u; const int cidx = (t < 2 ? (t ? p.N - 1 : 0) : (s >> 8) % p.N);
             double ref = 0, got = 0, scale = 1;
             if (tier2s) {
-                for (int k = 0; k < p.K; ++k) ref += (double)A[i].h[(size_t)r * p.lda + k] * B[i].h[(size_t)cidx * p.ldb + k];
+                for (int k = 0; k < p.K; ++k) ref += (double)A[i].h[(size_t)r * p.lda + k] * B[i].h[(size_t)cidx * ldb_host[i] + k];
                 for (int sp = 0; sp < p.nsplit; ++sp) got += c[(size_t)sp * p.c_split_stride + (size_t)r * p.ldc + cidx];
             } else if (!wgrad && !dgrad) {
-                for (int k = 0; k < p.K; ++k) ref += (double)A[i].h[(size_t)r * p.lda + k] * B[i].h[(size_t)cidx * p.ldb + k];
+                for (int k = 0; k < p.K; ++k) ref += (double)A[i].h[(size_t)r * p.lda + k] * B[i].h[(size_t)cidx * ldb_host[i] + k];
                 ref = selu(ref + bias[i].h[cidx]); got = c[(size_t)r * p.ldc + cidx];
             } else if (dgrad) {
-                for (int k = 0; k < p.K; ++k) ref += (double)A[i].h[(size_t)r * p.lda + k] * B[i].h[(size_t)k * p.ldb + cidx];
+                for (int k = 0; k < p.K; ++k) ref += (double)A[i].h[(size_t)r * p.lda + k] * B[i].h[(size_t)k * ldb_host[i] + cidx];
                 const double y = act[i].h[(size_t)r * p.ldact + cidx];
                 ref *= (y > 0 ? 1.0507009873554804934193349852946 : y + 1.0507009873554804934193349852946 * 1.6732632423543772848170429916717);
                 got = c[(size_t)r * p.ldc + cidx];
