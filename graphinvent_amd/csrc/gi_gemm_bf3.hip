@@ -11,16 +11,19 @@
 // at an error of the size of fp32's own rounding (measured max |err| / sum |a||b| below 3e-7; the path's
 // parity bar is 1e-4).
 //
-//   C[M, N] = epilogue( A[M, K] . B[N, K]^T )      A fp32 row-major (activations, split while staging),
-//                                                  B a PRE-SPLIT image: three bf16 planes [N][Kp], Kp = K
-//                                                  rounded up to 32, zero padded (gi_bf3_pack: weights, once
-//                                                  per forward / backward; a transposed source gives dgrad's W^T)
+//   C[M, N] = epilogue( A[M, K] . B[N, K]^T )
+// Operand forms: fp32 row-major, split while it is staged (A always in the model; B with GI_GEMM_BF3B_F32: the
+// forward's weights as stored, dgrad's W^T as a plain fp32 transposed copy from gi_bf3_pack(as_f32)), or a
+// PRE-SPLIT image of three bf16 planes [rows][Kp], Kp = K rounded up to 32, zero padded (gi_bf3_pack; B by
+// default, A with GI_GEMM_BF3A).  The launch tracks the bytes its workgroups pull from L2 (measured: 16 / 20 / 24 KB
+// per workgroup and k tile -> 75.6 / 82.7 / 95.7 us), so the model uses the fp32 form for both operands.
 // Block = 256 threads = 4 waves (2 x 2), block tile 128 x 128 x 16, wave tile 64 x 64 = 2 x 2 accumulators of
 // 32 x 32.  LDS per k tile and operand: three planes of 128 rows x 16 bf16 (32 B per row, its two 16-byte
 // chunks swapped when (row >> 3) & 1: the 16 lanes of every ds_read_b128 lane group — rows {0-3, 12-15, 20-27} /
-// {4-11, 16-19, 28-31} of a fragment — then hit the 16 distinct 16-byte slots of the 256-byte bank row; with
-// (row >> 2) & 1 they were 2-way conflicted), double buffered: 48 KB and 156 VGPRs -> THREE workgroups per CU, whose staging / conversion
-// phases run under each other's MFMAs (one barrier per k tile of 24 MFMAs per wave).
+// {4-11, 16-19, 28-31} of a fragment — then hit the 16 distinct 16-byte slots of the 256-byte bank row), double
+// buffered: 48 KB and <= 168 VGPRs -> THREE workgroups per CU, whose staging / conversion phases run under each
+// other's MFMAs (one barrier per k tile of 24 MFMAs per wave); k tiles travel global -> registers two tiles ahead;
+// launches of >= 512 tiles walk them in the XCD-aware order of gi_gemm.hip.
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
