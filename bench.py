@@ -445,7 +445,7 @@ def main():
     result["config"]["gemm_arithmetic"] = (
         "fp32 operands, fp32 accumulate everywhere; node-level readout layers >= 192 wide (6 of the 41 GEMM-family "
         "launches per step) as three-way bf16 splits on the bf16 MFMA pipe (six bf16 products per fp32 product, "
-        "max error 4e-7 of sum|a||b|, the fp32 MFMA chain's own: 5e-7), everything else on v_mfma_f32_32x32x2_f32"
+        "max error against the fp64 product 4e-7 relative, the fp32 MFMA chain's own: 5e-7), everything else on v_mfma_f32_32x32x2_f32"
         if lib.load().gi_bf3_enable(-1) else "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere")
     # graph_compact's sizes: found on the host (counting phase one batch ahead) / read back behind the stream
     result["config"]["compact_readbacks_timed_steps"] = first_readbacks

@@ -160,7 +160,7 @@ typedef struct gi_graph {
 #define GI_EPI_MULACT  64  /* v *= act[row,col] (a stored factor: AlphaDropout training mode) */
 #define GI_GEMM_BF3    128 /* B is a pre-split bf16 image (gi_bf3_pack); the launch runs on the bf16 MFMA pipe with
                               fp32 operands split three ways (six bf16 products per fp32 product, fp32 accumulate:
-                              the same result to ~3e-7 of sum |a||b|).  A contig fp32, no groups / split-K / b_idx;
+                              the same result to ~4e-7 relative, the fp32 MFMA chain's own distance from the fp64 product).  A contig fp32, no groups / split-K / b_idx;
                               every problem of a batched launch or none */
 #define GI_GEMM_BF3B_F32 512 /* with GI_GEMM_BF3: B is the plain fp32 matrix [N][ldb] (a forward weight as stored), split while
                               it is staged like A: no image, 4 bytes per element through L2 instead of 6 */
