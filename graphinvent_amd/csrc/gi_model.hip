@@ -123,7 +123,8 @@ long long chain_image_floats(const Mlp& q, int groups, bool backward, long long*
 // Layers of the node-level readout stacks that run on the bf16 MFMA pipe (gi_gemm_bf3.hip: fp32 operands split
 // three ways, fp32 accumulate — the same result to ~3e-7): wide enough for 128 x 128 tiles in both directions.
 // GI_BF3=0 keeps every GEMM on v_mfma_f32_32x32x2_f32.
-constexpr int BF3_MIN_WIDTH = 192, BF3_MIN_ROWS = 2048;
+// (rows: measured crossover against the fp32 kernel ~2 300 — 2 048 rows 35.0 vs 33.5 us, 3 000 rows 43.2 vs 53.5)
+constexpr int BF3_MIN_WIDTH = 192, BF3_MIN_ROWS = 2560;
 static int g_bf3 = -1;                  // -1: not read yet
 bool bf3_enabled() {
     if (g_bf3 < 0) g_bf3 = getenv("GI_BF3") ? (atoi(getenv("GI_BF3")) != 0) : (GI_BF3_DEFAULT != 0);

@@ -42,8 +42,11 @@ def test_bounded_forward_equals_the_ordinary_forward(kind, shape, B):
         out = model(nodes, edges)
         assert ops.READBACKS["blocking"] == before["blocking"] and ops.READBACKS["bounded"] == before["bounded"] + 1
         assert model.last_bounded_error() == 0
-        # same kernels, same per-row arithmetic (only grids and row-block partitions differ)
-        assert float((out - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+        # same kernels, same per-row arithmetic (only grids and row-block partitions differ) — except that the
+        # readout's hidden layers choose fp32-MFMA or bf16x3 launches by row count, the ordinary forward by the real
+        # rows, the bounded one by the bound (AttGGNN B = 300: 2.2 k real rows, sized for 3.9 k): both are fp32-
+        # accurate, a few 1e-6 apart
+        assert float((out - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
         # int8 inputs (the HDF dtype) take the same path
         out8 = model(torch.from_numpy(n8).to(DEV), torch.from_numpy(e8).to(DEV))
         assert torch.equal(out8, out)
@@ -109,7 +112,7 @@ def test_bounded_forward_is_capturable_as_one_hip_graph():
             ref = model(nk, ek)
             model.sync_free = True
             # 1e-5, not 1e-6: at B = 256 the ordinary forward (1.8 k real node rows) keeps the readout's hidden layers
-            # on the fp32 MFMA while the bounded one (sized for 3.3 k rows) takes the bf16x3 launches (>= 2 048 rows)
+            # on the fp32 MFMA while the bounded one (sized for 3.3 k rows) takes the bf16x3 launches (>= 2 560 rows)
             assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
 
 

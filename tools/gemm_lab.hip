@@ -55,7 +55,8 @@ int main(int argc, char** argv) {
     const char* trace_path = argc > 5 ? argv[5] : nullptr;
     if (getenv("GI_LAB_FILL")) g_fill = (float)atof(getenv("GI_LAB_FILL"));
     gi_gemm_config(persist, 0);
-    int M = 7258, n = 4, dims[8][3] = {{500, 500, 0}, {500, 500, 0}, {250, 250, 0}, {250, 250, 0}};
+    // GI_LAB_M: rows of the node-level classes (default: the headline batch)
+    int M = getenv("GI_LAB_M") ? atoi(getenv("GI_LAB_M")) : 7258, n = 4, dims[8][3] = {{500, 500, 0}, {500, 500, 0}, {250, 250, 0}, {250, 250, 0}};
     const bool dgrad = !strcmp(cls, "dgrad"), wgrad = !strcmp(cls, "wgrad");
     if (!strcmp(cls, "fwd1")) n = 1;
     const bool tier2s = !strcmp(cls, "tier2s");
