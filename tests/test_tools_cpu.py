@@ -3,13 +3,16 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_critical_path_on_the_committed_traces():
+@pytest.mark.parametrize("rnd", ["r02", "r03"])
+def test_critical_path_on_the_committed_traces(rnd):
     for tag in ("default", "onestream", "zinc", "chembl"):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "critical_path.py"),
-                              os.path.join(ROOT, "profiles", "r02", f"trace_{tag}.csv"), "0"],
+                              os.path.join(ROOT, "profiles", rnd, f"trace_{tag}.csv"), "0"],
                              capture_output=True, text=True)
         assert out.returncode == 0, out.stderr
         rows = {l[:28].strip(): l[28:].split() for l in out.stdout.splitlines()[1:]}
@@ -34,3 +37,20 @@ def test_gemm_class_report_on_the_committed_trace_and_launch_log():
     assert len(hidden) == 3 and all(0.5 < f < 0.75 for f in hidden)       # 0.60-0.62 of peak
     wgrad = float([l for l in lines if l.startswith("wgrad")][0].split()[-1])
     assert 0.4 < wgrad < 0.65
+
+
+def test_gemm_class_report_round_3_with_the_bf16x3_launches():
+    """The r03 launch log carries the bf16x3 launches as classes b0 / b1 (gi_gemm_bf3.hip); the report matches them
+    with the gi_gemm_bf3_kernel<...> rows of the trace and reproduces the figures of DESIGN.md section 5."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_class_report.py"),
+                          os.path.join(ROOT, "profiles", "r03", "trace_onestream.csv"),
+                          os.path.join(ROOT, "profiles", "r03", "gemm_launch_log.txt")],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    fwd = [float(l.split()[-1]) for l in lines if l.startswith("forward bf16x3")]
+    dgr = [float(l.split()[-1]) for l in lines if l.startswith("dgrad bf16x3")]
+    assert len(fwd) == 3 and len(dgr) == 3
+    assert all(0.75 < f < 1.0 for f in fwd) and all(0.65 < f < 0.95 for f in dgr)     # 0.87-0.88 / 0.78-0.80
+    committed = open(os.path.join(ROOT, "profiles", "r03", "gemm_class_report.txt")).read()
+    assert out.stdout.strip() == committed.strip()                                     # the committed report is this output
