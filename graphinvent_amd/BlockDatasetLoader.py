@@ -36,14 +36,14 @@ import numpy as np
 import torch
 
 try:                                        # imported as graphinvent_amd.BlockDatasetLoader
-    from .loader import ArraySource, BlockStreamLoader, HDFSource
+    from .loader import ArraySource, BlockStreamLoader, HDFSource, LazyRows
 except ImportError:                         # imported as top-level `BlockDatasetLoader` (drop-in layout)
     import os as _os
     import sys as _sys
     _root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
     if _root not in _sys.path:
         _sys.path.append(_root)
-    from graphinvent_amd.loader import ArraySource, BlockStreamLoader, HDFSource
+    from graphinvent_amd.loader import ArraySource, BlockStreamLoader, HDFSource, LazyRows
 
 
 class HDFDataset(torch.utils.data.Dataset):
@@ -71,15 +71,16 @@ class HDFDataset(torch.utils.data.Dataset):
         self.source.read_rows(lo, hi, outs)
         return outs
 
-    # the reference exposes the three h5py datasets as attributes; here they are read on demand, whole
+    # the reference exposes the three h5py datasets as attributes (BlockDatasetLoader.py:128-130): lazy here too —
+    # ``ds.nodes.shape`` / ``len(ds.nodes)`` read nothing, ``ds.nodes[lo:hi]`` reads those rows of that dataset only
     @property
-    def nodes(self): return self._rows(0, self.n_subgraphs)[0]
+    def nodes(self): return LazyRows(self.source, 0)
 
     @property
-    def edges(self): return self._rows(0, self.n_subgraphs)[1]
+    def edges(self): return LazyRows(self.source, 1)
 
     @property
-    def apds(self): return self._rows(0, self.n_subgraphs)[2]
+    def apds(self): return LazyRows(self.source, 2)
 
     def __getitem__(self, idx) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         if isinstance(idx, slice):

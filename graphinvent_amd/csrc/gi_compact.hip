@@ -750,7 +750,8 @@ extern "C" int gi_compact_count_ex(const void* nodes, const void* edges, int in_
 // although it has edges (non-0/1 node features or > GI_P0_MAX_CLASSES classes: counts[2] |= 4) cannot run
 // bounded: every size is set to 0, the forward then touches nothing beyond its buffers and returns garbage
 // logits; the caller reads counts[2] when it next synchronises.
-__global__ void compact_bound_kernel(int Fe, int* __restrict__ gfix, Lay L, int e_bound, int d0_bound, int ncu) {
+__global__ void compact_bound_kernel(int Fe, int* __restrict__ gfix, Lay L, int e_bound, int d0_bound, int ncu,
+                                     int* __restrict__ sticky_err) {
     if (threadIdx.x || blockIdx.x) return;
     int* c = gfix + L.counts;
     int* d = gfix + L.dims;
@@ -766,6 +767,9 @@ __global__ void compact_bound_kernel(int Fe, int* __restrict__ gfix, Lay L, int 
         gfix[L.seg_off] = gfix[L.seg_off + 1] = 0;
         gfix[L.src_off] = gfix[L.src_off + 1] = 0;
     }
+    // the error word of THIS forward's gfix dies with it; a caller that checks once after a whole generation loop
+    // (GraphGenerator.build_graphs: hundreds of forwards) needs every round's bits: OR them into its accumulator
+    if (sticky_err && c[CNT_ERR]) atomicOr(sticky_err, c[CNT_ERR]);
     d[0] = c[CNT_S] + 1;
     auto blocks = [&](int h) { int n = 0; for (int t = 0; t < Fe; ++t) n += (c[CNT_UT + t] + h - 1) / h; return n; };
     int h = 32, rounds = (blocks(32) + ncu - 1) / ncu;
@@ -777,7 +781,8 @@ __global__ void compact_bound_kernel(int Fe, int* __restrict__ gfix, Lay L, int 
     for (int i = 3; i < GI_DIMS; ++i) d[i] = 0;
 }
 
-extern "C" int gi_compact_bound(int* gfix, int B, int N, int Fe, int e_bound, int d0_bound, void* stream) {
+extern "C" int gi_compact_bound(int* gfix, int B, int N, int Fe, int e_bound, int d0_bound, int* sticky_err,
+                                void* stream) {
     (void)hipGetLastError();
     if (!gfix || B <= 0 || N <= 0 || Fe <= 0 || e_bound < 0 || d0_bound < 0) return GI_EINVAL;
     if (N > GI_MAX_NODES || Fe > GI_MAX_GROUPS) return GI_ELIMIT;
@@ -789,7 +794,7 @@ extern "C" int gi_compact_bound(int* gfix, int B, int N, int Fe, int e_bound, in
         return n;
     }();
     hipLaunchKernelGGL(compact_bound_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, Fe, gfix, L, e_bound,
-                       d0_bound, ncu);
+                       d0_bound, ncu, sticky_err);
     return gi_launch_status();
 }
 

@@ -418,6 +418,11 @@ int gi_gemm_bf3_launch(const gi_gemm_params* probs, int n, void* stream) {
             return GI_EINVAL;
         if (p.M < 0 || p.N <= 0 || p.K <= 0 || (!apl && p.lda < p.K)) return GI_EINVAL;
         if (apl && (p.a_idx || ((uintptr_t)p.A & 15) != 0)) return GI_EINVAL;
+        // operands are addressed by 32-bit byte offsets: a gathered row index is not bounded by M, so its offset
+        // cannot be checked here (round-3 advisor finding) — the bf16x3 path takes no row gather (the model's
+        // launches have none); and the 16-byte k chunks clamp into [0, 4): rows shorter than 4 floats need padding
+        if (p.a_idx) return GI_EINVAL;
+        if (p.K < 4 && ((!apl && p.lda < 4) || (bfp && p.ldb < 4))) return GI_EINVAL;
         if (!bfp && ((uintptr_t)p.B & 15) != 0) return GI_EINVAL;
         if (bfp && p.ldb < p.K) return GI_EINVAL;
         const int f = p.flags & ~(GI_GEMM_BF3 | GI_GEMM_BF3A | GI_GEMM_BF3B_F32);

@@ -70,7 +70,7 @@ def _set_dropout(dims, c, kind: int, seed: int) -> None:
 
 
 def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dropout_seed=None,
-                     bounds=None, p0_cache=None):
+                     bounds=None, p0_cache=None, sticky_err=None):
     """graph_compact + the fused forward.  Returns (logits, tape); the tape
     (dims, CompactGraph, workspace, per-type edge counts) is what backward consumes.
 
@@ -83,13 +83,14 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dro
     device; buffers and launch grids are sized for the bounds (``ops.default_bounds``), the real graph sizes stay
     on the device where every kernel reads them (``gi_compact_bound``, ``gi_graph.bounded``).  For callers that
     cannot prefetch the compaction because they mutate ``nodes`` / ``edges`` in place between forwards
-    (``GraphGenerator.build_graphs``, GraphGenerator.py:118-157).  The tape cannot feed a backward.
+    (``GraphGenerator.build_graphs``, GraphGenerator.py:118-157).  The tape cannot feed a backward.  ``sticky_err``:
+    a 1-element int32 CUDA tensor that accumulates the error bits of every bounded forward (``gi_compact_bound``).
 
     ``p0_cache`` (an int32 CUDA tensor of ``gi_p0_cache_words`` words, zero-filled whenever the weights change):
     the pass-0 row cache of an inference loop (``gi_graph.p0_cache``); the tape cannot feed a backward."""
     lib = _L.load()
     if bounds is not None:
-        return _forward_bounded(lib, consts, nodes, edges, params, kind, bounds, p0_cache)
+        return _forward_bounded(lib, consts, nodes, edges, params, kind, bounds, p0_cache, sticky_err)
     drop = dropout_seed is not None
     nodes, lay, gfix, S, E, U, D0, Ut = _ops.compact_count(nodes, edges, nodedup=drop)
     attn = kind != _L.KIND_GGNN
@@ -122,7 +123,7 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dro
     return (out[:B] if drop else out), (dims, graph, ws)
 
 
-def _forward_bounded(lib, consts, nodes, edges, params, kind, bounds, p0_cache=None):
+def _forward_bounded(lib, consts, nodes, edges, params, kind, bounds, p0_cache=None, sticky_err=None):
     if nodes.dim() != 3:
         raise ValueError("nodes must be [B, N, Fn]")
     B, N = nodes.shape[0], nodes.shape[1]
@@ -142,7 +143,7 @@ def _forward_bounded(lib, consts, nodes, edges, params, kind, bounds, p0_cache=N
         return ws[lib.gi_ggnn_hx0_offset(C.byref(dims), S_b, E_b, U_b, D0_b):], \
             lib.gi_ggnn_ldhx(C.byref(dims)), dims.H
 
-    graph, _ = _ops.compact_bounded(nodes, edges, lay_ws, e_bound, d0_bound, class_csr=attn)
+    graph, _ = _ops.compact_bounded(nodes, edges, lay_ws, e_bound, d0_bound, class_csr=attn, sticky_err=sticky_err)
     apd = dims.N * dims.A + dims.N * dims.C + 1
     out = torch.empty((B, apd), dtype=torch.float32, device=dev)
     gs = graph.c_struct()
@@ -306,8 +307,9 @@ class _FusedMPNN(torch.nn.Module):
     #: no read-back of the graph sizes, buffers sized for ``sync_free_bounds`` (None: ``ops.default_bounds``:
     #: 4 B N directed edges, 64 feature classes per bond type), real sizes on the device.  For loops that mutate
     #: ``nodes`` / ``edges`` in place between forwards (GraphGenerator.build_graphs) and so cannot use
-    #: ``ops.prefetch_compact``.  ``last_bounded_error()`` reports a violated bound / invalid input of the latest
-    #: such forward (one read-back; call it where you synchronise anyway).
+    #: ``ops.prefetch_compact``.  ``last_bounded_error()`` reports a violated bound / invalid input of ANY such
+    #: forward since it was last called (a device-side accumulator; one read-back — call it where you synchronise
+    #: anyway, e.g. once after a whole generation loop).
     sync_free = False
     sync_free_bounds = None
     _last_bounded_graph = None
@@ -356,12 +358,26 @@ class _FusedMPNN(torch.nn.Module):
 
     _grad_ready_hook = None
     _early_exchange_pending = False     # set by dp.DataParallel while its early all-reduce runs
+    def _bounded_err_word(self, device) -> torch.Tensor:
+        """The persistent device-side error accumulator of this model's sync-free forwards (one per device)."""
+        words = self.__dict__.get("_bounded_err")
+        if words is None:
+            words = self.__dict__["_bounded_err"] = {}
+        w = words.get(device)
+        if w is None:
+            w = words[device] = torch.zeros(1, dtype=torch.int32, device=device)
+        return w
+
     def last_bounded_error(self) -> int:
-        """Error bits of the latest sync-free forward (``ops.bounded_error``), 0 = valid; raises on a violation."""
-        g = self.__dict__.get("_last_bounded_graph")
-        if g is None:
-            return 0
-        err = _ops.bounded_error(g)
+        """Error bits (``ops.bounded_error``) of EVERY sync-free forward since the previous call, OR-ed on the device
+        (``gi_compact_bound``'s ``sticky_err``): 0 = all of them valid; raises on a violation.  Reads the
+        accumulator back (one synchronisation) and clears it."""
+        err = 0
+        for w in (self.__dict__.get("_bounded_err") or {}).values():
+            bits = int(w.item())
+            if bits:
+                w.zero_()
+                err |= bits
         if err:
             raise ValueError("sync-free forward: " + ", ".join(
                 m for bit, m in ((1, "an edge's feature vector is not one-hot"),
@@ -410,7 +426,7 @@ class _FusedMPNN(torch.nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         skip = ("_param_cache", "_bucket", "_anchor", "_grad_bucket", "_grad_ready_hook",
-                "_early_exchange_pending", "_last_bounded_graph", "_p0_state")
+                "_early_exchange_pending", "_last_bounded_graph", "_p0_state", "_bounded_err")
         import copy as _copy
         for k, v in self.__dict__.items():
             new.__dict__[k] = None if k in skip else _copy.deepcopy(v, memo)
@@ -426,9 +442,12 @@ class _FusedMPNN(torch.nn.Module):
                 return self.forward(nodes, edges)
         if self.sync_free and nodes.is_cuda and not self._dropout_active() and \
                 not (torch.is_grad_enabled() and any(p.requires_grad for p in params)):
+            if torch.cuda.is_current_stream_capturing():         # the only forward that can be recorded (no read-back)
+                import graphinvent_amd as _pkg                 # (works in the top-level `gnn.mpnn` layout too)
+                _pkg.assert_graph_safe()
             bounds = self.sync_free_bounds or _ops.default_bounds(nodes.shape[0], nodes.shape[1], edges.shape[3])
             out, tape = ggnn_forward_raw(self.constants, nodes, edges, params, self._KIND, None, bounds,
-                                         self._pass0_cache(params, nodes))
+                                         self._pass0_cache(params, nodes), self._bounded_err_word(nodes.device))
             self.__dict__["_last_bounded_graph"] = tape[1]
             return out
         if self.autograd_params:

@@ -30,7 +30,7 @@ GEMM_BF3 = 128        # GI_GEMM_BF3: B is a gi_bf3_pack image; the launch runs a
 KIND_GGNN, KIND_ATTGGNN = 0, 1
 BWD_ALL, BWD_READOUT, BWD_PASSES = 0, 1, 2
 COUNTS = 24          # GI_COUNTS
-ABI_VERSION = 11
+ABI_VERSION = 12
 #: bumped by code that rewrites model weights through raw pointers (optim.FusedAdam.step,
 #: dp.DataParallel.broadcast_parameters): invalidates gnn.mpnn's pass-0 row cache
 WEIGHTS_EPOCH = [0]     # GI_ABI_VERSION
@@ -122,7 +122,7 @@ SIGNATURES = {
     "gi_compact_fill": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci,
                              ci, ci, vp, vp, ci, vp, vp]),
     "gi_compact_class_csr": (ci, [vp, ci, ci, vp, vp, vp]),
-    "gi_compact_bound": (ci, [vp, ci, ci, ci, ci, ci, vp]),
+    "gi_compact_bound": (ci, [vp, ci, ci, ci, ci, ci, vp, vp]),
     "gi_class_sum_dselu": (ci, [vp, vp, ci, vp, vp, ci, ci, vp, vp, ci, vp]),
     "gi_gemm": (ci, [C.POINTER(GemmParams), vp]),
     "gi_gemm_batch": (ci, [C.POINTER(GemmParams), ci, vp]),

@@ -14,7 +14,7 @@ graphs) that is the first thing to cap throughput, so here:
   (double buffering), so the copy of batch k+1 overlaps the training step on batch k;
 * the int8 tensors go **straight into the model and the loss** — ``graph_compact`` and the fused KL
   kernel read int8 (``GI_DTYPE_I8``); no fp32 copy of the inputs is ever materialised;
-* every rank takes its own slice of each global minibatch (``dp.ShardedBatchSampler``).
+* every rank reads only its own slice of each block (``BlockStreamLoader``).
 
 Rows whose APD target is all zero (dataset-size padding, DataProcesser.py:268-269; reference loss
 = NaN on them) can be dropped up front with ``drop_zero_targets=True``.
@@ -23,18 +23,38 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from typing import Iterator, Optional, Tuple
 
 import numpy as np
 import torch
 
-from .dp import ShardedBatchSampler
 
 
 _HDF_NAMES = (b"nodes", b"edges", b"APDs")
 
+# libhdf5 keeps global library state and most builds are not thread-safe: EVERY H5* call of this process goes
+# through one lock per loaded library handle (two HDFSource objects — the training file read by the loader's
+# background thread, the validation file read by the main thread — must serialise against each other too).
+_HDF_LIBS = {}
+_HDF_LIBS_GUARD = threading.Lock()
+
 
 def _load_libhdf5(libhdf5: Optional[str] = None):
+    """(library handle, H5T_NATIVE_INT8 id, the process-wide lock of that handle)."""
+    with _HDF_LIBS_GUARD:
+        if libhdf5 in _HDF_LIBS:
+            return _HDF_LIBS[libhdf5]
+        entry = _open_libhdf5(libhdf5)
+        for known in _HDF_LIBS.values():                      # the same .so reached under two names: one lock
+            if known[0]._handle == entry[0]._handle:
+                entry = known
+                break
+        _HDF_LIBS[libhdf5] = entry
+        return entry
+
+
+def _open_libhdf5(libhdf5: Optional[str] = None):
     candidates = [libhdf5] if libhdf5 else ["libhdf5.so", "/opt/conda/lib/libhdf5.so",
                                             "libhdf5_serial.so"]
     for c in candidates:
@@ -59,7 +79,7 @@ def _load_libhdf5(libhdf5: Optional[str] = None):
     lib.H5Dread.argtypes = [i64] * 5 + [ctypes.c_void_p]
     for fn in ("H5Fclose", "H5Dclose", "H5Sclose"):
         getattr(lib, fn).argtypes = [i64]
-    return lib, i64.in_dll(lib, "H5T_NATIVE_INT8_g").value
+    return lib, i64.in_dll(lib, "H5T_NATIVE_INT8_g").value, threading.Lock()
 
 
 class HDFSource:
@@ -70,15 +90,18 @@ class HDFSource:
     reads it straight into the caller's (pinned) buffers.  One thread at a time may call into it (lock)."""
 
     def __init__(self, path: str, libhdf5: Optional[str] = None):
-        import threading
         self.path = path
-        self._lib, self._int8 = _load_libhdf5(libhdf5)
-        self._lock = threading.Lock()
+        self._lib, self._int8, self._lock = _load_libhdf5(libhdf5)
+        self._f, self._d, self.row_shapes = None, [], []
+        with self._lock:
+            self._open(path)
+
+    def _open(self, path: str) -> None:
         lib = self._lib
         self._f = lib.H5Fopen(path.encode(), 0, 0)                  # H5F_ACC_RDONLY
         if self._f < 0:
+            self._f = None
             raise OSError(f"cannot open {path}")
-        self._d, self.row_shapes = [], []
         n_rows = None
         for name in _HDF_NAMES:
             d = lib.H5Dopen2(self._f, name, 0)
@@ -97,15 +120,21 @@ class HDFSource:
             self.row_shapes.append(dims[1:])
         self.n_rows = n_rows
 
-    def read_rows(self, lo: int, hi: int, outs) -> None:
-        """rows [lo, hi) of (nodes, edges, APDs) into the first hi - lo rows of the int8 arrays `outs`."""
+    def read_rows(self, lo: int, hi: int, outs, which=(0, 1, 2)) -> None:
+        """rows [lo, hi) of (nodes, edges, APDs) into the first hi - lo rows of the int8 arrays `outs`;
+        `which` selects the datasets (indices into nodes / edges / APDs) `outs` corresponds to."""
         lib, n = self._lib, hi - lo
         if not 0 <= lo <= hi <= self.n_rows:
             raise IndexError((lo, hi, self.n_rows))
+        if len(outs) != len(which):
+            raise ValueError("one destination per selected dataset")
         if n == 0:
             return
         with self._lock:
-            for d, shp, out in zip(self._d, self.row_shapes, outs):
+            if self._f is None:
+                raise ValueError(f"{self.path} is closed")
+            for w, out in zip(which, outs):
+                d, shp = self._d[w], self.row_shapes[w]
                 arr = out.numpy() if torch.is_tensor(out) else out
                 if arr.dtype != np.int8 or arr.shape[1:] != shp or arr.shape[0] < n or not arr.flags.c_contiguous:
                     raise ValueError("destination must be a C-contiguous int8 array of >= hi - lo rows")
@@ -121,11 +150,12 @@ class HDFSource:
                     raise OSError(f"H5Dread failed for rows [{lo}, {hi}) of {self.path}")
 
     def close(self) -> None:
-        if self._f is not None:
-            for d in self._d:
-                self._lib.H5Dclose(d)
-            self._lib.H5Fclose(self._f)
-            self._f, self._d = None, []
+        with self._lock:
+            if self._f is not None:
+                for d in self._d:
+                    self._lib.H5Dclose(d)
+                self._lib.H5Fclose(self._f)
+                self._f, self._d = None, []
 
     def __del__(self):
         try:
@@ -146,10 +176,48 @@ class ArraySource:
         self.n_rows = self.arrays[0].shape[0]
         self.row_shapes = [a.shape[1:] for a in self.arrays]
 
-    def read_rows(self, lo: int, hi: int, outs) -> None:
-        for a, out in zip(self.arrays, outs):
+    def read_rows(self, lo: int, hi: int, outs, which=(0, 1, 2)) -> None:
+        if not 0 <= lo <= hi <= self.n_rows:
+            raise IndexError((lo, hi, self.n_rows))
+        for w, out in zip(which, outs):
             dst = out.numpy() if torch.is_tensor(out) else out
-            dst[:hi - lo] = a[lo:hi]
+            dst[:hi - lo] = self.arrays[w][lo:hi]
+
+
+class LazyRows:
+    """One dataset of a source as a read-on-index view: what the reference's ``HDFDataset.nodes`` / ``.edges`` /
+    ``.apds`` are (h5py datasets, BlockDatasetLoader.py:128-130) — ``shape``, ``len`` and ``view[i]`` /
+    ``view[lo:hi]`` (int8 numpy, only those rows of only this dataset are read)."""
+
+    def __init__(self, source, which: int):
+        self._src, self._which = source, which
+        self.shape = (source.n_rows,) + tuple(source.row_shapes[which])
+        self.dtype = np.dtype(np.int8)
+        self.ndim = len(self.shape)
+
+    def __len__(self) -> int:
+        return self.shape[0]
+
+    def __getitem__(self, idx):
+        n = self.shape[0]
+        if isinstance(idx, slice):
+            lo, hi, step = idx.indices(n)
+            if step != 1:
+                raise IndexError("row slices must be contiguous")
+            hi = max(hi, lo)
+            out = np.empty((hi - lo,) + self.shape[1:], dtype=np.int8)
+            self._src.read_rows(lo, hi, (out,), which=(self._which,))
+            return out
+        i = int(idx)
+        if i < 0:
+            i += n
+        out = np.empty((1,) + self.shape[1:], dtype=np.int8)
+        self._src.read_rows(i, i + 1, (out,), which=(self._which,))
+        return out[0]
+
+    def __array__(self, dtype=None, copy=None):                # np.asarray(view): the caller asked for it all
+        a = self[0:self.shape[0]]
+        return a if dtype is None else a.astype(dtype)
 
 
 def read_hdf_int8(path: str, libhdf5: Optional[str] = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
@@ -160,97 +228,6 @@ def read_hdf_int8(path: str, libhdf5: Optional[str] = None) -> Tuple[np.ndarray,
     src.read_rows(0, src.n_rows, outs)
     src.close()
     return outs
-
-
-class ShardedBlockLoader:
-    """Iterates (nodes, edges, apds) int8 minibatches of one rank, resident on ``device``."""
-
-    def __init__(self, nodes, edges, apds, batch_size: int, rank: int = 0, world_size: int = 1,
-                 seed: int = 0, shuffle: bool = True, device: Optional[str] = "cuda",
-                 drop_zero_targets: bool = True, prefetch: bool = True,
-                 prefetch_compact: bool = True):
-        as_t = lambda a: torch.as_tensor(np.ascontiguousarray(a)) if not torch.is_tensor(a) else a
-        nodes, edges, apds = as_t(nodes), as_t(edges), as_t(apds)
-        if not (nodes.dtype == edges.dtype == apds.dtype == torch.int8):
-            raise TypeError("ShardedBlockLoader expects the int8 arrays of the preprocessed HDF")
-        if not (nodes.shape[0] == edges.shape[0] == apds.shape[0]):
-            raise ValueError("nodes / edges / APDs disagree on the number of rows")
-        if drop_zero_targets:
-            keep = torch.nonzero(apds.ne(0).any(dim=1)).flatten()
-            if keep.numel() != apds.shape[0]:
-                nodes, edges, apds = nodes[keep], edges[keep], apds[keep]
-        self.device = torch.device(device) if device is not None else None
-        self.on_gpu = self.device is not None and self.device.type == "cuda"
-        pin = (lambda t: t.pin_memory()) if self.on_gpu else (lambda t: t)
-        self.block = tuple(pin(t.contiguous()) for t in (nodes, edges, apds))
-        self.batch_size = batch_size
-        self.sampler = ShardedBatchSampler(self.block[0].shape[0], batch_size, rank, world_size,
-                                           seed, shuffle)
-        self.prefetch = prefetch and self.on_gpu
-        # also run graph_compact's counting phase for the batch on the copy stream (ops.prefetch_compact)
-        self.prefetch_compact = prefetch_compact and self.on_gpu
-        self._stream = torch.cuda.Stream(self.device) if self.on_gpu else None
-        # two pinned staging slots per tensor (gather destination, H2D source)
-        self._stage = [tuple(pin(torch.empty((batch_size,) + t.shape[1:], dtype=torch.int8))
-                             for t in self.block) for _ in range(2)] if self.on_gpu else None
-        self._stage_done = [None, None]
-        # numpy views (same memory) for the row gather: np.take copies whole rows with memcpy, ~100x
-        # faster than torch.index_select on int8 rows of a few hundred bytes (4.6 ms -> 0.05 ms)
-        self._block_np = [t.numpy().reshape(t.shape[0], -1) for t in self.block]
-        self._stage_np = [[t.numpy().reshape(t.shape[0], -1) for t in st] for st in self._stage] \
-            if self.on_gpu else None
-
-    def set_epoch(self, epoch: int) -> None:
-        self.sampler.set_epoch(epoch)
-
-    def __len__(self) -> int:
-        return len(self.sampler)
-
-    def _gather(self, idx: np.ndarray, slot: int):
-        if not self.on_gpu:
-            index = torch.from_numpy(np.ascontiguousarray(idx)).long()
-            return tuple(t.index_select(0, index) for t in self.block)
-        if self._stage_done[slot] is not None:
-            self._stage_done[slot].synchronize()          # staging slot free again (its H2D finished)
-        stage = self._stage[slot]
-        for src, dst in zip(self._block_np, self._stage_np[slot]):
-            np.take(src, idx, axis=0, out=dst)            # vectorised row gather, pinned -> pinned
-        with torch.cuda.stream(self._stream):
-            dev = tuple(s.to(self.device, non_blocking=True) for s in stage)
-            if self.prefetch_compact:
-                from . import ops
-                ops.prefetch_compact(dev[0], dev[1], stream=self._stream)
-            ev = torch.cuda.Event()
-            ev.record(self._stream)
-        self._stage_done[slot] = ev
-        return dev, ev
-
-    def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
-        batches = iter(self.sampler)
-        if not self.on_gpu:
-            for idx in batches:
-                yield self._gather(idx, 0)
-            return
-        cur = torch.cuda.current_stream(self.device)
-        slot = 0
-        pending = None
-        nxt = next(batches, None)
-        if nxt is not None:
-            pending = self._gather(nxt, slot)
-        while pending is not None:
-            dev, ev = pending
-            nxt = next(batches, None)
-            pending = None
-            if nxt is not None and self.prefetch:
-                slot ^= 1
-                pending = self._gather(nxt, slot)         # copy of batch k+1 overlaps the step on k
-            cur.wait_event(ev)                            # consumer stream waits for ITS batch only
-            for t in dev:
-                t.record_stream(cur)
-            yield dev
-            if nxt is not None and not self.prefetch:
-                slot ^= 1
-                pending = self._gather(nxt, slot)
 
 
 class BlockStreamLoader:
@@ -269,14 +246,15 @@ class BlockStreamLoader:
     * Double buffering: block k + 1's slice is read by a background thread (libhdf5 through ctypes releases the
       GIL) into the second pinned buffer while block k's minibatches are consumed; peak pinned host memory is
       2 slices + 2 staging minibatches, independent of the file size (``pinned_bytes``).
-    * Minibatches go through the same staging as ``ShardedBlockLoader``: vectorised row gather into a pinned
-      staging buffer, asynchronous H2D on a side stream one batch ahead, graph_compact's counting phase for the
-      batch on that stream (``ops.prefetch_compact``); int8 all the way into the model and the loss.
+    * Staging of a minibatch: vectorised row gather (``np.take`` on whole rows: memcpy speed) into one of two
+      pinned staging buffers, asynchronous H2D on a side stream one batch ahead of the consumer, graph_compact's
+      counting phase for the batch on that stream (``ops.prefetch_compact``); int8 all the way into the model and
+      the loss.
     * ``drop_last=False`` keeps a block's ragged last minibatch like the reference (same size on every rank);
       ``drop_zero_targets`` trims the TRAILING all-zero-target rows of the file (dataset-size padding,
       DataProcesser.py:268-269; NaN loss in the reference) — found once at construction, identically on all ranks.
-    * With ``block_size >= rows``, one rank and ``drop_last=True`` the minibatches are bit-identical to
-      ``ShardedBlockLoader``'s (same permutation).
+    * With ``block_size >= rows`` and one rank the row order of an epoch is
+      ``np.random.default_rng([seed, epoch]).permutation(rows)`` (what ``dp.ShardedBatchSampler`` draws).
     """
 
     def __init__(self, source, batch_size: int, block_size: int = 10000, rank: int = 0, world_size: int = 1,
@@ -304,6 +282,7 @@ class BlockStreamLoader:
         self._stage = [mk(self.batch_size), mk(self.batch_size)] if self.on_gpu else None
         self._stage_done = [None, None]
         self._stream = torch.cuda.Stream(self.device) if self.on_gpu else None
+        self._reader = None                                   # background read of the next block's slice, if running
         self.pinned_bytes = sum(t.numel() for grp in self._slices + (self._stage or []) for t in grp)
 
     # ---- epoch plan (host arithmetic only; identical on every rank) -------------------------------------
@@ -355,7 +334,7 @@ class BlockStreamLoader:
             hi = lo
         return 0
 
-    # ---- staging (as ShardedBlockLoader._gather) --------------------------------------------------------
+    # ---- staging ----------------------------------------------------------------------------------------
     def _emit(self, slice_np, idx: np.ndarray, slot: int):
         if not self.on_gpu:
             return tuple(torch.from_numpy(np.take(a, idx, axis=0)) for a in slice_np), None
@@ -377,11 +356,13 @@ class BlockStreamLoader:
         return dev, ev
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
-        import threading
         order = [int(b) for b in self._block_order()]
         order = [b for b in order if self._batches_in(self._block_rows(b) // self.world) > 0]
         if not order:
             return
+        if self._reader is not None:                          # an abandoned iteration's reader still writes into a
+            self._reader.join()                               # slice buffer this one is about to reuse
+            self._reader = None
         err = []
 
         def read(b: int, which: int):
@@ -401,6 +382,7 @@ class BlockStreamLoader:
             reader = None
             if k + 1 < len(order):                            # next block's slice in the background
                 reader = threading.Thread(target=read, args=(order[k + 1], which ^ 1), daemon=True)
+                self._reader = reader
                 reader.start()
             _, L = self._slice_of(b)
             slice_np = [t.numpy()[:L] for t in self._slices[which]]
@@ -417,6 +399,7 @@ class BlockStreamLoader:
             # (np.take is synchronous), so the buffer may be overwritten by the read after next
             if reader is not None:
                 reader.join()
+                self._reader = None
             which ^= 1
         if pending is not None:
             yield self._hand_over(pending, cur)

@@ -317,20 +317,26 @@ def default_bounds(B: int, N: int, Fe: int):
 
 
 def compact_bounded(nodes: torch.Tensor, edges: torch.Tensor, lay_ws, e_bound: int, d0_bound: int,
-                    class_csr: bool = False):
+                    class_csr: bool = False, sticky_err: Optional[torch.Tensor] = None):
     """graph_compact WITHOUT the host read-back: counting phase, gi_compact_bound, fill — all enqueued; every
     buffer is sized for the bounds (S <= B N, E, U <= e_bound, D0 <= d0_bound) and the real sizes never leave the
     device.  `lay_ws(S_b, E_b, U_b, D0_b)` -> (hx0 view, ldhx, H) provides the workspace slice hx0 is written to.
     Returns (CompactGraph with bounded=True, nodes as the kernels read them).  A batch that exceeds a bound or
     has non-0/1 node features is flagged in gfix counts[2] (bits 1 / 2; `bounded_error`) and produces
-    meaningless logits instead of touching memory beyond the buffers."""
+    meaningless logits instead of touching memory beyond the buffers.  `sticky_err` (a 1-element int32 CUDA tensor
+    the caller keeps): the same bits OR-ed into it on the device, so one read-back after a loop covers every round."""
     lib = L.load()
     nodes_c, lay, gfix, Fe = _count_launch(nodes, edges)
     B, N, Fn = nodes_c.shape
     S_b, E_b, U_b = B * N, max(int(e_bound), 1), max(int(e_bound), 1)
     D0_b = max(min(int(d0_bound), U_b), 1)             # (pass-0 rows are message rows of a kind: D0 <= U)
     with torch.cuda.device(nodes_c.device):
-        L.check(lib.gi_compact_bound(gfix.data_ptr(), B, N, Fe, E_b, D0_b, _stream(nodes_c)), "gi_compact_bound")
+        if sticky_err is not None and not (sticky_err.is_cuda and sticky_err.dtype == torch.int32
+                                           and sticky_err.device == nodes_c.device and sticky_err.numel() >= 1):
+            raise ValueError("sticky_err must be an int32 tensor on the inputs' device")
+        L.check(lib.gi_compact_bound(gfix.data_ptr(), B, N, Fe, E_b, D0_b,
+                                     sticky_err.data_ptr() if sticky_err is not None else None,
+                                     _stream(nodes_c)), "gi_compact_bound")
         hx0, ldhx, H = lay_ws(S_b, E_b, U_b, D0_b)
         offs, total = _gvar_offsets(E_b, U_b, D0_b)
         gvar = torch.empty(total, dtype=torch.int32, device=nodes_c.device)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GI_ABI_VERSION 11
+#define GI_ABI_VERSION 12
 #define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
 #define GI_MAX_NODES 128      /* max max_n_nodes */
 #define GI_P0_MAX_CLASSES 256 /* max distinct node feature rows for the pass-0 shortcut */
@@ -103,9 +103,12 @@ int gi_compact_count_ex(const void* nodes, const void* edges, int in_dtype, int 
  * violation — more edges / pass-0 rows than the bound (counts[2] |= 2), or a batch with edges whose pass-0
  * shortcut is unavailable (node features not 0/1, counts[2] |= 4) — every size is set to 0: the forward then
  * stays inside its buffers and returns meaningless logits; read counts[2] at the next synchronisation.
+ * `sticky_err` (may be NULL): a caller-owned device int that accumulates (atomic OR) the error bits of every
+ * bounded forward — counts[2] lives in that forward's own gfix, so a loop that checks once at its end would
+ * otherwise see only the last round (bit 0 = an edge's feature vector is not one-hot, from phase 1).
  * This is what a caller that mutates `nodes` / `edges` in place between forwards
  * (GraphGenerator.build_graphs, GraphGenerator.py:118-157) needs: no device -> host wait per forward. */
-int gi_compact_bound(int* gfix, int B, int N, int Fe, int e_bound, int d0_bound, void* stream);
+int gi_compact_bound(int* gfix, int B, int N, int Fe, int e_bound, int d0_bound, int* sticky_err, void* stream);
 /* phase 2 (after the host has read S, E, U from counts): the variable-size index arrays and the
  * initial node rows hx0[S+1, ldhx] = [x | 0.. | x] with the input features in columns [0,Fn) and
  * again in [H, H+Fn) (row S = 0).  S < 0: bounded mode — E, U, D0 (and the buffers) are the bounds handed to
@@ -160,7 +163,8 @@ typedef struct gi_graph {
 #define GI_EPI_MULACT  64  /* v *= act[row,col] (a stored factor: AlphaDropout training mode) */
 #define GI_GEMM_BF3    128 /* B is a pre-split bf16 image (gi_bf3_pack); the launch runs on the bf16 MFMA pipe with
                               fp32 operands split three ways (six bf16 products per fp32 product, fp32 accumulate:
-                              the same result to ~4e-7 relative, the fp32 MFMA chain's own distance from the fp64 product).  A contig fp32, no groups / split-K / b_idx;
+                              the same result to ~4e-7 relative, the fp32 MFMA chain's own distance from the fp64 product).  A contig fp32, no groups / split-K / a_idx / b_idx
+                              (32-bit operand offsets: a gathered row is not bounded by M), K < 4 needs lda / ldb >= 4;
                               every problem of a batched launch or none */
 #define GI_GEMM_BF3B_F32 512 /* with GI_GEMM_BF3: B is the plain fp32 matrix [N][ldb] (a forward weight as stored), split while
                               it is staged like A: no image, 4 bytes per element through L2 instead of 6 */

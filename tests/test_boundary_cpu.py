@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.gi_abi_version() == L.ABI_VERSION == 11
+    assert lib.gi_abi_version() == L.ABI_VERSION == 12
 
 
 def test_host_side_planning_functions():
@@ -140,3 +140,21 @@ def test_graft_entry_build_runs_without_a_gpu():
     """The driver's "does it build" check: compiles every HIP source for gfx950 and binds the ABI."""
     import __graft_entry__ as entry
     entry.build()
+
+
+def test_graph_capture_flag_state_is_recorded_at_import():
+    """Round-3 advisor finding: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 only works when it is in the environment before
+    the HIP runtime initialises; the package records whether that can be relied on and refuses capture otherwise."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import graphinvent_amd as g, os; ok, why = g.graph_capture_safe(); "
+            "print(int(ok), os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE'));\n"
+            "try:\n    g.assert_graph_safe(); print('fine')\nexcept RuntimeError as e:\n    print('refused')")
+    def run(env_extra):
+        env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+        env.update(env_extra, PYTHONPATH=root)
+        return subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                              check=True).stdout.split()
+    assert run({}) == ["1", "0", "fine"]                                       # set by the package, in time
+    assert run({"DEBUG_CLR_GRAPH_PACKET_CAPTURE": "0"}) == ["1", "0", "fine"]  # the caller's own 0
+    assert run({"DEBUG_CLR_GRAPH_PACKET_CAPTURE": "1"}) == ["0", "1", "refused"]

@@ -5,8 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from graphinvent_amd.loader import (ArraySource, BlockStreamLoader, HDFSource, ShardedBlockLoader,
-                                    read_hdf_int8)
+from graphinvent_amd.loader import ArraySource, BlockStreamLoader, HDFSource, LazyRows, read_hdf_int8
 
 REF_H5 = "/root/reference/data/pre-training/gdb13_1K-debug/train.h5"
 
@@ -18,26 +17,26 @@ def _fixture(golden_dir, split="train"):
 
 def test_drops_padding_rows_and_shards_disjointly(golden_dir):
     n, e, a = _fixture(golden_dir)
-    loaders = [ShardedBlockLoader(n, e, a, 16, rank=r, world_size=2, seed=3, device=None)
-               for r in range(2)]
-    assert loaders[0].block[0].shape[0] == 129                 # 21 all-zero padding rows dropped
-    assert len(loaders[0]) == len(loaders[1]) == (129 // 16) // 2
+    loaders = [BlockStreamLoader(ArraySource(n, e, a), 16, block_size=10000, rank=r, world_size=2, seed=3,
+                                 device=None, drop_last=True) for r in range(2)]
+    assert loaders[0].n_rows == 129                            # 21 all-zero padding rows dropped
+    assert len(loaders[0]) == len(loaders[1]) == (129 // 2) // 16
     seen = []
     for ld in loaders:
         for nodes, edges, apds in ld:
             assert nodes.dtype == edges.dtype == apds.dtype == torch.int8
             assert nodes.shape == (16, 13, 8) and edges.shape == (16, 13, 13, 3) and apds.shape == (16, 625)
             assert int(apds.ne(0).any(1).sum()) == 16
-            seen.append(apds.numpy().tobytes())
-    assert len(seen) == 8
-    keep = ShardedBlockLoader(n, e, a, 16, device=None, drop_zero_targets=False)
-    assert keep.block[0].shape[0] == 150
+            seen.extend(r.numpy().tobytes() for r in apds)
+    assert len(seen) == 2 * 4 * 16
+    keep = BlockStreamLoader(ArraySource(n, e, a), 16, device=None, drop_zero_targets=False)
+    assert keep.n_rows == 150
 
 
 def test_epochs_reshuffle_but_ranks_agree_on_the_permutation(golden_dir):
     n, e, a = _fixture(golden_dir, "valid")
-    a0 = ShardedBlockLoader(n, e, a, 10, rank=0, world_size=2, seed=1, device=None)
-    b0 = ShardedBlockLoader(n, e, a, 10, rank=0, world_size=2, seed=1, device=None)
+    mk = lambda: BlockStreamLoader(ArraySource(n, e, a), 10, rank=0, world_size=2, seed=1, device=None)
+    a0, b0 = mk(), mk()
     first = [x[2].clone() for x in a0]
     assert all(torch.equal(p, q[2]) for p, q in zip(first, b0))       # deterministic
     a0.set_epoch(1)
@@ -46,8 +45,7 @@ def test_epochs_reshuffle_but_ranks_agree_on_the_permutation(golden_dir):
 
 def test_rejects_non_int8():
     with pytest.raises(TypeError):
-        ShardedBlockLoader(np.zeros((4, 2, 2), np.float32), np.zeros((4, 2, 2, 1), np.int8),
-                           np.zeros((4, 3), np.int8), 2, device=None)
+        ArraySource(np.zeros((4, 2, 2), np.float32), np.zeros((4, 2, 2, 1), np.int8), np.zeros((4, 3), np.int8))
 
 
 @pytest.mark.skipif(not (os.path.exists(REF_H5) and os.path.exists("/opt/conda/lib/libhdf5.so")),
@@ -107,16 +105,77 @@ def test_dropin_hdfdataset_reads_the_reference_file(golden_dir):
 
 
 # ---- block-wise streaming (BlockDatasetLoader.py:32-63, 77-99) ------------------------------------------------
-def test_block_stream_equals_the_in_memory_loader_when_one_block_holds_the_file(golden_dir):
+def test_block_stream_row_order_when_one_block_holds_the_file(golden_dir):
     n, e, a = _fixture(golden_dir)
-    new = BlockStreamLoader(ArraySource(n, e, a), 16, block_size=10000, device=None, drop_last=True, seed=3)
-    old = ShardedBlockLoader(n, e, a, 16, seed=3, device=None)
-    assert new.n_rows == 129 and len(new) == len(old) == 8          # trailing padding rows trimmed
+    ld = BlockStreamLoader(ArraySource(n, e, a), 16, block_size=10000, device=None, drop_last=True, seed=3)
+    assert ld.n_rows == 129 and len(ld) == 8                        # trailing padding rows trimmed
     for epoch in (0, 1):
-        new.set_epoch(epoch); old.set_epoch(epoch)
-        pairs = list(zip(new, old))
-        assert len(pairs) == 8
-        assert all(torch.equal(x[k], y[k]) for x, y in pairs for k in range(3))       # bit-identical batches
+        ld.set_epoch(epoch)
+        order = np.random.default_rng([3, epoch]).permutation(129)
+        got = list(ld)
+        assert len(got) == 8
+        for k, (bn, be, ba) in enumerate(got):                      # bit-identical rows in the seeded order
+            idx = order[16 * k:16 * (k + 1)]
+            assert np.array_equal(bn.numpy(), n[idx]) and np.array_equal(be.numpy(), e[idx]) \
+                and np.array_equal(ba.numpy(), a[idx])
+
+
+def test_lazy_dataset_views_read_only_what_is_asked():
+    """HDFDataset.nodes / .edges / .apds (BlockDatasetLoader.py:128-130 are lazy h5py datasets): shape and len cost
+    nothing, an index reads those rows of that dataset only (round-3 advisor finding)."""
+    from graphinvent_amd.BlockDatasetLoader import HDFDataset
+    rng = np.random.default_rng(0)
+    n = rng.integers(0, 2, (50, 3, 2)).astype(np.int8); e = rng.integers(0, 2, (50, 3, 3, 1)).astype(np.int8)
+    a = rng.integers(0, 5, (50, 7)).astype(np.int8)
+    base = ArraySource(n, e, a)
+    calls = []
+
+    class Spy:
+        n_rows, row_shapes = base.n_rows, base.row_shapes
+        def read_rows(self, lo, hi, outs, which=(0, 1, 2)):
+            calls.append((lo, hi, tuple(which)))
+            base.read_rows(lo, hi, outs, which=which)
+    ds = HDFDataset.from_arrays(n, e, a)
+    ds.source = Spy()
+    assert isinstance(ds.nodes, LazyRows) and ds.nodes.shape == (50, 3, 2) and len(ds.apds) == 50 and not calls
+    assert np.array_equal(ds.edges[7:19], e[7:19]) and calls == [(7, 19, (1,))]
+    assert np.array_equal(ds.apds[-1], a[49]) and calls[-1] == (49, 50, (2,))
+    assert np.array_equal(np.asarray(ds.nodes), n) and calls[-1] == (0, 50, (0,))
+    with pytest.raises(IndexError):
+        ds.nodes[0:10:2]
+
+
+def test_one_lock_per_libhdf5_handle_and_abandoned_reader_is_joined():
+    """Two sources of the same library share ONE lock (libhdf5 keeps global state); a new iteration joins the
+    background reader an abandoned one left running before it reuses the slice buffers."""
+    import threading, time
+    from graphinvent_amd import loader as L
+    if os.path.exists("/opt/conda/lib/libhdf5.so") and os.path.exists(REF_H5):
+        s1, s2 = HDFSource(REF_H5), HDFSource(REF_H5.replace("train.h5", "valid.h5"))
+        assert s1._lock is s2._lock
+        s1.close(); s2.close()
+        with pytest.raises(ValueError):
+            s1.read_rows(0, 1, tuple(np.empty((1,) + tuple(shp), np.int8) for shp in s1.row_shapes))
+    gate = threading.Event()
+
+    class Slow:
+        n_rows, row_shapes = 64, [(2,), (2,), (3,)]
+        active = 0
+        def read_rows(self, lo, hi, outs, which=(0, 1, 2)):
+            Slow.active += 1
+            assert Slow.active == 1, "two reads into the slice buffers at once"
+            if lo >= 16:
+                gate.wait(0.5)
+            for o in outs:
+                o[:hi - lo] = 1
+            Slow.active -= 1
+    ld = BlockStreamLoader(Slow(), 4, block_size=16, device=None, shuffle=False, drop_zero_targets=False)
+    it = iter(ld)
+    next(it)                                                            # block 0 consumed, reader of block 1 running
+    assert ld._reader is not None and ld._reader.is_alive()
+    t0 = time.time()
+    assert sum(1 for _ in ld) == 16                                     # new iteration: joins it first
+    gate.set()
 
 
 def test_block_stream_covers_every_row_once_blockwise_and_keeps_ragged_batches():
@@ -145,7 +204,7 @@ def test_block_stream_ranks_read_disjoint_slices_in_lock_step(golden_dir):
 
     class Counting:                                                     # which file rows does a rank touch?
         def __init__(self): self.n_rows, self.row_shapes, self.seen = src.n_rows, src.row_shapes, []
-        def read_rows(self, lo, hi, outs): self.seen.append((lo, hi)); src.read_rows(lo, hi, outs)
+        def read_rows(self, lo, hi, outs, which=(0, 1, 2)): self.seen.append((lo, hi)); src.read_rows(lo, hi, outs)
     srcs = [Counting(), Counting()]
     lds = [BlockStreamLoader(srcs[r], 16, block_size=50, rank=r, world_size=2, device=None, seed=1) for r in range(2)]
     for epoch in (0, 1):
@@ -170,7 +229,7 @@ def test_block_stream_pinned_memory_is_two_slices_whatever_the_file_size():
         n_rows = 10_000_000
         row_shapes = [(13, 8), (13, 13, 3), (625,)]
         reads = 0
-        def read_rows(self, lo, hi, outs):
+        def read_rows(self, lo, hi, outs, which=(0, 1, 2)):
             Virtual.reads += 1
             for o in outs:
                 o[:hi - lo].reshape(hi - lo, -1)[:] = (np.arange(lo, hi) % 127 + 1).astype(np.int8)[:, None]
@@ -201,3 +260,23 @@ def test_hdf_source_reads_row_ranges(golden_dir):
         src.read_rows(140, 151, outs)
     ld = BlockStreamLoader(src, 16, block_size=64, device=None, seed=2)
     assert ld.n_rows == 129 and sum(b[2].shape[0] for b in ld) == 129
+
+
+def test_hdf_roundtrip_through_libhdf5_without_the_reference_checkout(tmp_path):
+    """tests/h5util.write_h5 creates the three int8 datasets the way DataProcesser.py:157-161 does; HDFSource and the
+    drop-in HDFDataset read them back bit-exactly (runs wherever a libhdf5 is, e.g. on the GPU box)."""
+    from graphinvent_amd.BlockDatasetLoader import HDFDataset
+    from tests.h5util import have_libhdf5, write_h5
+    if not have_libhdf5():
+        pytest.skip("no libhdf5 on this box")
+    rng = np.random.default_rng(1)
+    n = rng.integers(0, 2, (77, 13, 8)).astype(np.int8); e = rng.integers(0, 2, (77, 13, 13, 3)).astype(np.int8)
+    a = rng.integers(0, 9, (77, 625)).astype(np.int8)
+    path = str(tmp_path / "x.h5")
+    write_h5(path, n, e, a)
+    rn, re_, ra = read_hdf_int8(path)
+    assert np.array_equal(rn, n) and np.array_equal(re_, e) and np.array_equal(ra, a)
+    ds = HDFDataset(path)
+    assert np.array_equal(ds.edges[70:77], e[70:77]) and torch.equal(ds[3][0], torch.from_numpy(n[3]).float())
+    got = np.concatenate([b[2].numpy() for b in BlockStreamLoader(ds.source, 10, block_size=30, device=None, seed=0)])
+    assert sorted(map(bytes, got)) == sorted(map(bytes, a))

@@ -490,17 +490,21 @@ def test_training_loop_pieces_on_device(tmp_path):
             dist.destroy_process_group()
 
 
-def test_int8_inputs_and_prefetching_loader(golden_dir):
-    """int8 batches (HDF dtype) through the loader -> model -> fused loss give bit-identical logits
-    and loss to the fp32 tensors the reference's loader would have produced."""
-    from graphinvent_amd.loader import ShardedBlockLoader
+def test_int8_inputs_through_the_block_stream_loader(golden_dir):
+    """int8 batches (HDF dtype) of the shipped fixture through BlockStreamLoader -> model -> fused loss: the rows are the
+    file's rows (bit-exact, tests/test_loader_gpu.py), and logits / loss equal those of the fp32 tensors the
+    reference's loader builds from the same rows (BlockDatasetLoader.py:139-141) — checked against the ORACLE on
+    those fp32 rows, not only against the HIP model itself."""
+    from graphinvent_amd.loader import ArraySource, BlockStreamLoader
     from graphinvent_amd.loss import apd_kl_loss
     d = np.load(os.path.join(golden_dir, "gdb13_1K-debug_train.npz"))
     cfg = O.make_config()
-    model = make_model(cfg, O.init_params(cfg, seed=2))
+    P = O.init_params(cfg, seed=2)
+    model = make_model(cfg, P)
     model.eval()
-    loader = ShardedBlockLoader(d["nodes"], d["edges"], d["APDs"], 32, seed=5)
-    assert len(loader) == 4
+    loader = BlockStreamLoader(ArraySource(d["nodes"], d["edges"], d["APDs"]), 32, block_size=64, seed=5,
+                               drop_last=True)
+    assert loader.n_rows == 129 and len(loader) == 4
     n_batches = 0
     with torch.no_grad():
         for nodes, edges, apds in loader:
@@ -510,6 +514,11 @@ def test_int8_inputs_and_prefetching_loader(golden_dir):
             assert torch.equal(out8, out32)
             l8, l32 = apd_kl_loss(out8, apds), apd_kl_loss(out32, apds.float())
             assert float(l8) == float(l32) and np.isfinite(float(l8))
+            o_ref = O.ggnn_forward(P, cfg, nodes.float().cpu(), edges.float().cpu())
+            l_ref = O.kl_loss(o_ref, apds.float().cpu())
+            live = torch.from_numpy(np.setdiff1d(np.arange(32), fully_masked_rows(edges.cpu().numpy())))
+            assert rel(out8.cpu()[live], o_ref[live]) < TOL
+            assert abs(float(l8) - float(l_ref)) < 1e-3 * abs(float(l_ref))
             n_batches += 1
     assert n_batches == 4
 

@@ -135,3 +135,30 @@ def test_bound_violations_are_flagged_not_fatal():
             model.last_bounded_error()
         ok = model(nodes, edges)                                 # and the model keeps working
         assert model.last_bounded_error() == 0 and bool(torch.isfinite(ok).all())
+
+
+def test_a_violation_in_an_early_round_is_still_reported_after_the_loop():
+    """Round-3 advisor finding: the error word lived in the forward's own gfix, so a loop that checks once at its end
+    (bench.py generation_loop, GraphGenerator.build_graphs) lost every round but the last.  Now the bits are OR-ed
+    into a per-model device word (gi_compact_bound's sticky_err); last_bounded_error() reads and clears it."""
+    model, cfg, sh = _model("GGNN", "gdb13")
+    n8, e8, _ = synthetic.make_batch(64, **sh, seed=9)
+    nodes, edges = _dev(n8, e8)
+    model.sync_free = True
+    with torch.no_grad():
+        bad = nodes.clone(); bad[3, 0, 1] = 0.25
+        model(nodes, edges)
+        model(bad, edges)                                       # round 2 of 5 is invalid
+        for _ in range(3):
+            ok = model(nodes, edges)
+        with pytest.raises(ValueError, match="not 0/1"):
+            model.last_bounded_error()
+        assert model.last_bounded_error() == 0                  # cleared by the read
+        assert bool(torch.isfinite(ok).all())
+        import copy
+        twin = copy.deepcopy(model)                             # a copy gets its own accumulator
+        twin.sync_free_bounds = (10, 192)
+        twin(nodes, edges)
+        assert model.last_bounded_error() == 0
+        with pytest.raises(ValueError, match="more edges"):
+            twin.last_bounded_error()
