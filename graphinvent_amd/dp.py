@@ -138,8 +138,8 @@ class DataParallel:
             pending[0].wait()
             raise RuntimeError("data-parallel overlap: an early all-reduce of the readout gradients "
                                "is pending, but param.grad are no longer views of the model's flat "
-                               "gradient bucket; construct DataParallel(overlap=False) (or set "
-                               "GI_DP_OVERLAP=0) for training loops that clone, accumulate or "
+                               "gradient bucket; construct DataParallel(overlap=False) "
+                               "for training loops that clone, accumulate or "
                                "replace gradients between backward and the optimizer step")
         if bucket is not None:                      # gradients already live in one flat buffer
             if pending is not None:

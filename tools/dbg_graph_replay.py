@@ -1,7 +1,7 @@
 """debug: the pytest flow (test_bounded_forward_is_capturable_as_one_hip_graph) with knobs.
 CACHE=0|1, HOLD=0|1 (keep the captured forward's tape alive), TWICE=0|1 (replay twice, report both)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from graphinvent_amd import ops, synthetic
 from graphinvent_amd.gnn import mpnn

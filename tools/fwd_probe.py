@@ -1,6 +1,6 @@
-"""forward-only probe (bench.py's forward_only leg): CACHE=0|1 python tools/runs/fwd_probe.py — pass-0 row cache off / on"""
+"""forward-only probe (bench.py's forward_only leg): CACHE=0|1 python tools/fwd_probe.py — pass-0 row cache off / on"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from graphinvent_amd import ops

@@ -1,6 +1,6 @@
-"""generation-loop probe: MODE=sync_free|blocking python tools/runs/gen_probe.py  (for rocprofv3 --kernel-trace --stats)"""
+"""generation-loop probe: MODE=sync_free|blocking python tools/gen_probe.py  (for rocprofv3 --kernel-trace --stats)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from graphinvent_amd import ops
