@@ -47,6 +47,16 @@ int gi_gru_gates_fwd_n(float* gi, float* gh, int ldg, const float* hx_prev, floa
 
 // gi_gemm_batch hands launches whose problems all carry GI_GEMM_BF3 to gi_gemm_bf3.hip
 int gi_gemm_bf3_launch(const gi_gemm_params* probs, int n, void* stream);
+// ... and gi_gemm_bf3_launch those with plain fp32 operands (no images, no gathers) to gi_gemm_b3v.hip: forward,
+// dgrad (W as stored, b_major) and weight-gradient (a_major + b_major, split-K slabs) layouts on 32-deep k tiles
+bool gi_b3v_eligible(const gi_gemm_params* probs, int n);
+int gi_b3v_launch(const gi_gemm_params* probs, int n, void* stream);
+extern "C" int gi_b3v_enable(int on);
+// ... and forward / dgrad launches (both operands fp32 with k contiguous) to the 512-thread ping-pong kernel of
+// gi_gemm_b3p.hip (128 x 256 tiles, two wave groups alternating between the MFMA pipe and the staging work)
+bool gi_b3p_eligible(const gi_gemm_params* probs, int n);
+int gi_b3p_launch(const gi_gemm_params* probs, int n, void* stream);
+extern "C" int gi_b3p_enable(int on);
 // GI_GEMM_LOG line of a launch (gi_gemm.hip); cls: two characters, "00" forward / "01" dgrad / "11" wgrad layouts,
 // "b0" / "b1" the bf16x3 launches of the forward / dgrad
 void gi_gemm_log_launch(const char* cls, const gi_gemm_params* probs, int n, int blocks, double flops);

@@ -8,19 +8,19 @@
 //   wgrad : a weight-gradient batch              (3 x 500x501 + 2 x 250x251 + 3x501 + 2 x 100x251 over 7258 rows, split-K slabs)
 //   fwd1  : one 7258x500x500 problem
 //   fwd3 / dgrad3 / fwd13 / tier23: the same launches on the bf16 MFMA pipe (GI_GEMM_BF3: B pre-split by gi_bf3_pack)
+//   fwd3f / dgrad3f with GI_B3V=1 (default) run on the 32-deep-tile kernels of gi_gemm_b3v.hip, GI_B3V=0 on the round-3
+//   kernel; dgrad3m: W as stored (b_major, no transposed copy; gi_gemm_b3v.hip only); wgrad3: the weight-gradient batch
+//   on the bf16 pipe (128x128 tiles, GI_LAB_WMUL (default 4) times the slabs of the 64x64-tile launch)
 //   tier2 : the graph-level hidden-layer launch (3 x 1000x500x500)
 //   tier2s: the same as GI_LAB_NSPLIT (default 2) split-K slabs per problem, no epilogue (what a k-split of
 //           the launch would buy: more, shorter workgroups per CU)
 // persist_tenths: 0 = one workgroup per tile, 11 = library default (persistent grid for launches of more
 // than 1.1 rounds of resident workgroups), 1 = always persistent.  Every run checks 64 random outputs per
 // problem against a double-precision dot product.
-#ifdef LAB_OLD       // round-2 kernel (one workgroup per tile), for A/B in the same call
-#include "experiments/gi_gemm_r2.hip.txt"
-extern "C" int gi_gemm_config(int, int) { return 0; }
-#else
 #include "../graphinvent_amd/csrc/gi_gemm.hip"
 #include "../graphinvent_amd/csrc/gi_gemm_bf3.hip"
-#endif
+#include "../graphinvent_amd/csrc/gi_gemm_b3v.hip"
+#include "../graphinvent_amd/csrc/gi_gemm_b3p.hip"
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
@@ -44,7 +44,9 @@ static double selu(double x) { return 1.0507009873554804934193349852946 * (x > 0
 
 int main(int argc, char** argv) {
     char clsbuf[32]; strncpy(clsbuf, argc > 1 ? argv[1] : "fwd", 31); clsbuf[31] = 0;
-    bool bf3 = false, bf3a = false, bf3f = false;        // "...3": B pre-split; "...3a": A pre-split as well; "...3f": B as fp32
+    bool bf3 = false, bf3a = false, bf3f = false, bf3m = false;        // "...3": B pre-split; "...3a": A pre-split as well; "...3f": B as fp32; "...3m": operands as stored
+    if (strlen(clsbuf) > 2 && !strcmp(clsbuf + strlen(clsbuf) - 2, "3m")) { bf3 = bf3m = true; clsbuf[strlen(clsbuf) - 2] = 0; }
+    else
     if (strlen(clsbuf) > 2 && !strcmp(clsbuf + strlen(clsbuf) - 2, "3f")) { bf3 = bf3f = true; clsbuf[strlen(clsbuf) - 2] = 0; }
     else
     if (strlen(clsbuf) > 2 && !strcmp(clsbuf + strlen(clsbuf) - 2, "3a")) { bf3 = bf3a = true; clsbuf[strlen(clsbuf) - 2] = 0; }
@@ -58,6 +60,8 @@ int main(int argc, char** argv) {
     // GI_LAB_M: rows of the node-level classes (default: the headline batch)
     int M = getenv("GI_LAB_M") ? atoi(getenv("GI_LAB_M")) : 7258, n = 4, dims[8][3] = {{500, 500, 0}, {500, 500, 0}, {250, 250, 0}, {250, 250, 0}};
     const bool dgrad = !strcmp(cls, "dgrad"), wgrad = !strcmp(cls, "wgrad");
+    const int wmul = (wgrad && bf3) ? (getenv("GI_LAB_WMUL") ? atoi(getenv("GI_LAB_WMUL")) : 4) : 1;
+    if (wgrad && bf3) bf3m = true;
     if (!strcmp(cls, "fwd1")) n = 1;
     const bool tier2s = !strcmp(cls, "tier2s");
     const int lab_nsplit = getenv("GI_LAB_NSPLIT") ? atoi(getenv("GI_LAB_NSPLIT")) : 2;
@@ -67,6 +71,7 @@ int main(int argc, char** argv) {
         const int w[8][3] = {{500, 500, 3}, {500, 500, 3}, {500, 500, 3}, {250, 250, 12}, {250, 250, 12}, {3, 500, 24}, {100, 250, 24}, {100, 250, 24}};
         memcpy(dims, w, sizeof(w));
     }
+    if (getenv("GI_LAB_N")) n = atoi(getenv("GI_LAB_N")) < n ? atoi(getenv("GI_LAB_N")) : n;   // only the first problems
     gi_gemm_params probs[8];
     Mat A[8], B[8], Cm[8], bias[8], act[8];
     int ldb_host[8] = {};                              // leading dimension of the host copy B[i].h (p.ldb may change with the operand form)
@@ -94,7 +99,7 @@ int main(int argc, char** argv) {
             }
             flops += 2.0 * M * N * K;
         } else {                                       // [dW | db] = dZ^T [X | 1], reduction over M rows
-            const int no = dims[i][0], ni = dims[i][1], ns = dims[i][2];
+            const int no = dims[i][0], ni = dims[i][1], ns = dims[i][2] * wmul;
             A[i] = make((size_t)M * r4(no), 11 + i, 1.f); p.A = A[i].d; p.lda = r4(no); p.a_major = 1;
             B[i] = make((size_t)M * r4(ni), 31 + i, 1.f); p.B = B[i].d; p.ldb = r4(ni); p.b_major = 1;
             p.M = no; p.N = ni + 1; p.K = M; p.ones_col = ni; p.ldc = r4(ni + 1);
@@ -104,11 +109,11 @@ int main(int argc, char** argv) {
         }
     }
     for (int i = 0; i < n; ++i) ldb_host[i] = probs[i].ldb;
-#ifndef LAB_OLD
     if (bf3) {
-        if (wgrad || tier2s) { printf("no bf3 variant of this class\n"); return 1; }
+        if (tier2s) { printf("no bf3 variant of this class\n"); return 1; }
         for (int i = 0; i < n; ++i) {
             gi_gemm_params& p = probs[i];
+            if (bf3m) { p.flags |= GI_GEMM_BF3 | (p.b_major ? 0 : GI_GEMM_BF3B_F32); continue; }    // operands as stored
             if (bf3f && !p.b_major) { p.flags |= GI_GEMM_BF3 | GI_GEMM_BF3B_F32; continue; }    // forward: W as stored
             gi_bf3_pack_desc d = {};
             d.as_f32 = bf3f ? 1 : 0;                              // dgrad "3f": W^T as a plain fp32 copy
@@ -129,7 +134,6 @@ int main(int argc, char** argv) {
         }
         (void)hipDeviceSynchronize();
     }
-#endif
     auto launch = [&] { const int rc = gi_gemm_batch(probs, n, 0); if (rc) { printf("rc %d\n", rc); exit(1); } };
     for (int i = 0; i < 5; ++i) launch();
     (void)hipDeviceSynchronize();
@@ -177,9 +181,32 @@ int main(int argc, char** argv) {
         best = ms < best ? ms : best; sum += ms;
     }
     printf("%s%s tile=(%d,%d) persist=%d: %.2f us per launch (best %.2f), %.1f TF (best %.1f) = %.3f of 157.3   max rel err %.2e %s\n",
-           cls, bf3f ? "3f (bf16x3, B fp32)" : bf3a ? "3a (bf16x3, A pre-split)" : (bf3 ? "3 (bf16x3)" : ""), tm, tn, persist, sum / rounds / reps * 1e3, best / reps * 1e3, flops * reps * rounds / (sum * 1e-3) / 1e12,
+           cls, bf3m ? "3m (bf16x3, operands as stored)" : bf3f ? "3f (bf16x3, B fp32)" : bf3a ? "3a (bf16x3, A pre-split)" : (bf3 ? "3 (bf16x3)" : ""), tm, tn, persist, sum / rounds / reps * 1e3, best / reps * 1e3, flops * reps * rounds / (sum * 1e-3) / 1e12,
            flops * reps / (best * 1e-3) / 1e12, flops * reps * rounds / (sum * 1e-3) / 1e12 / 157.3, worst,
            worst < 2e-5 ? "OK" : "MISMATCH");
+#ifdef GI_B3P_TRACE
+    if (trace_path) {
+        unsigned long long* buf; (void)hipMalloc(&buf, 2048 * 8); (void)hipMemset(buf, 0, 2048 * 8);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(gp_trace_buf), &buf, sizeof(buf));
+        launch(); (void)hipDeviceSynchronize();
+        std::vector<unsigned long long> h(2048);
+        (void)hipMemcpy(h.data(), buf, 2048 * 8, hipMemcpyDeviceToHost);
+        FILE* f = fopen(trace_path, "w");
+        // six stamps per iteration.  group 0: compute start, compute end | stage start, loads landed, LDS written, loads issued;
+        // group 1: stage start, loads landed, LDS written, loads issued | compute start, compute end
+        for (int g = 0; g < 2; ++g) {
+            fprintf(f, "group %d: durations (cycles) per iteration: %s\n", g, g == 0 ?
+                    "compute, barrier, wait-loads, split+write, issue-loads, barrier" : "wait-loads, split+write, issue-loads, barrier, compute, barrier");
+            for (int i = 0; i + 6 < 1024 && h[g * 1024 + i + 6]; i += 6) {
+                const unsigned long long* t = &h[g * 1024 + i];
+                if (g == 0) fprintf(f, "  %6llu: %5llu %5llu %5llu %5llu %5llu %5llu\n", t[0] - h[0], t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5]);
+                else fprintf(f, "  %6llu: %5llu %5llu %5llu %5llu %5llu %5llu\n", t[0] - h[0], t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5]);
+            }
+        }
+        fclose(f);
+        printf("phase trace -> %s\n", trace_path);
+    }
+#endif
 #ifdef GI_GEMM_TRACE
     if (trace_path) {
         int total = 0;
