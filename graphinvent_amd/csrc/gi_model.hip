@@ -260,7 +260,7 @@ void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
 }
 
 // ---- wgrad slab plan ----------------------------------------------------------------------------
-struct SlabEntry { long long off, stride; int nsplit, calls, done, n_out, n_in, ld, tn, bidx, launched, reduced; };
+struct SlabEntry { long long off, stride; int nsplit, calls, done, n_out, n_in, ld, tn, bidx, launched, reduced, bf3; };
 struct SlabPlan {
     SlabEntry e[160];
     long long total;
@@ -269,6 +269,17 @@ struct SlabPlan {
 // wgrad launch shape: 64x64 output tiles.  Weight-gradient GEMMs are deferred and launched in
 // batches of up to 8 problems, so ONE problem only needs ~256 workgroups (x its share of a
 // type-grouped launch); fewer splits = fewer slabs to write and reduce.
+// Weight gradients on the bf16 pipe (gi_gemm_b3p.hip, weight-gradient layout): hidden-layer problems of the node-level
+// readout stacks — both dimensions >= BF3_MIN_WIDTH, reduction over >= BF3_MIN_ROWS node rows.  Tiles are 128 x 256
+// and one workgroup owns a CU, so the slab count is chosen for equal tiles of ~29 k steps (920 rows): at the
+// headline batch 8 slabs -> a 500 x 501 problem is 64 workgroups, a 250 x 251 one 16, and four big problems (or two
+// big + six small) make one full round of the device (launch_wgrad_batches packs them that way).
+constexpr int BF3_WGRAD_SLAB_ROWS = 920;
+bool bf3_wgrad_ok(int n_out, int n_in, int red_rows) {
+    return bf3_enabled() && gi_b3p_enable(-1) && n_out >= BF3_MIN_WIDTH && n_in >= BF3_MIN_WIDTH &&
+           red_rows >= BF3_MIN_ROWS;
+}
+
 void wgrad_shape(int n_out, int n_in, int red_rows, double share, int& tn, int& nsplit) {
     // 64x64 output tiles; 128x128 tiles for the big square weight gradients (a quarter of the slabs)
     // measured slower: 2.73 against 2.64 ms per step (tools/experiments/README.md)
@@ -288,18 +299,20 @@ void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {   /
     long long o = 0;
     int maxEt = 0;
     for (int t = 0; t < d.Fe; ++t) maxEt = std::max(maxEt, Et ? Et[t] : E);
-    auto add = [&](int widx, int bidx, int n_out, int n_in, int red, int calls, double share) {
+    auto add = [&](int widx, int bidx, int n_out, int n_in, int red, int calls, double share, bool bf3 = false) {
         SlabEntry& e = sp.e[widx];
         e.bidx = bidx; e.launched = 0; e.reduced = 0;
         e.n_out = n_out; e.n_in = n_in; e.ld = gi_r4(n_in + 1); e.calls = calls; e.done = 0;
         wgrad_shape(n_out, n_in, red, share, e.tn, e.nsplit);
+        e.bf3 = bf3 && !d.dropout && bf3_wgrad_ok(n_out, n_in, red);
+        if (e.bf3) e.nsplit = std::max(1, (red + BF3_WGRAD_SLAB_ROWS / 2) / BF3_WGRAD_SLAB_ROWS);
         e.stride = gi_r4l((long long)n_out * e.ld);
         e.off = o;
         o += e.stride * e.nsplit * calls;
     };
-    auto add_mlp = [&](const Mlp& q, int red, int calls, double share = 1.0) {
+    auto add_mlp = [&](const Mlp& q, int red, int calls, double share = 1.0, bool bf3 = false) {
         for (int l = 0; l < q.layers(); ++l)
-            add(q.w(l), q.b(l), q.fan_out(l), q.fan_in(l), red, calls, share);
+            add(q.w(l), q.b(l), q.fan_out(l), q.fan_in(l), red, calls, share, bf3);
     };
     const int R = S + 1;
     for (int t = 0; t < d.Fe; ++t) {
@@ -310,7 +323,8 @@ void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {   /
     }
     add(m.gru_wih, m.gru_bih, 3 * d.H, d.M, R, d.passes, 1.0);
     add(m.gru_whh, m.gru_bhh, 3 * d.H, d.H, R, d.passes, 1.0);
-    add_mlp(m.att, R, 1); add_mlp(m.emb, R, 1); add_mlp(m.add1, R, 1); add_mlp(m.conn1, R, 1);
+    add_mlp(m.att, R, 1, 1.0, true); add_mlp(m.emb, R, 1, 1.0, true); add_mlp(m.add1, R, 1, 1.0, true);
+    add_mlp(m.conn1, R, 1, 1.0, true);
     add_mlp(m.add2, d.B, 1); add_mlp(m.conn2, d.B, 1); add_mlp(m.term2, d.B, 1);
     sp.total = o;
 }
@@ -607,6 +621,7 @@ void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* wid
     p.flags = GI_GEMM_SPLITK;
     p.nsplit = e0.nsplit; p.c_split_stride = e0.stride;
     p.tm = e0.tn; p.tn = e0.tn;                 // 1x1 (64x64 tiles) or 2x2 (128x128), see wgrad_shape
+    if (e0.bf3 && !g.n && !b_idx) p.flags |= GI_GEMM_BF3;      // bf16 pipe, 128 x 256 tiles (gi_gemm_b3p.hip)
     const int slot = q.n - 1;
     if (g.n) {
         p.ngroups = g.n; p.grp_off = g.off;
@@ -639,9 +654,30 @@ void launch_wgrad_batch(Run& r, const gi_gemm_params* p, int n, hipStream_t st) 
     if (nb && r.ok()) r.chk(gi_gemm_batch(b, nb, st));
 }
 
-// consecutive queued problems, up to 8 per launch
+// consecutive queued problems, up to 8 per launch; the bf16x3 ones (one workgroup per CU, equal tiles) are packed
+// separately, biggest first, into launches of about one round of the device
 void launch_wgrad_batches(Run& r, const gi_gemm_params* p, int n, hipStream_t st) {
-    for (int base = 0; base < n && r.ok(); base += 8) launch_wgrad_batch(r, p + base, std::min(8, n - base), st);
+    gi_gemm_params rest[96], b3[96];
+    int nr = 0, n3 = 0;
+    for (int i = 0; i < n; ++i) {
+        if (p[i].flags & GI_GEMM_BF3) b3[n3++] = p[i]; else rest[nr++] = p[i];
+    }
+    auto tiles = [](const gi_gemm_params& q) { return gi_cdiv(q.M, 128) * gi_cdiv(q.N, 256) * q.nsplit; };
+    for (int i = 1; i < n3; ++i)                                  // stable insertion sort, most tiles first
+        for (int j = i; j > 0 && tiles(b3[j]) > tiles(b3[j - 1]); --j) std::swap(b3[j], b3[j - 1]);
+    static const int cus = [] {
+        int dev = 0, c = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+        return c;
+    }();
+    for (int base = 0; base < n3 && r.ok();) {
+        int k = 0, t = 0;
+        while (base + k < n3 && k < 8 && (k == 0 || t + tiles(b3[base + k]) <= cus)) { t += tiles(b3[base + k]); ++k; }
+        r.chk(gi_gemm_batch(b3 + base, k, st));
+        base += k;
+    }
+    for (int base = 0; base < nr && r.ok(); base += 8) launch_wgrad_batch(r, rest + base, std::min(8, nr - base), st);
 }
 
 void flush_deferred(Run& r, Deferred& q) {

@@ -123,6 +123,8 @@ SIGNATURES = {
                              ci, ci, vp, vp, ci, vp, vp]),
     "gi_compact_class_csr": (ci, [vp, ci, ci, vp, vp, vp]),
     "gi_compact_bound": (ci, [vp, ci, ci, ci, ci, ci, vp, vp]),
+    "gi_b3p_enable": (ci, [ci]),
+    "gi_b3v_enable": (ci, [ci]),
     "gi_class_sum_dselu": (ci, [vp, vp, ci, vp, vp, ci, ci, vp, vp, ci, vp]),
     "gi_gemm": (ci, [C.POINTER(GemmParams), vp]),
     "gi_gemm_batch": (ci, [C.POINTER(GemmParams), ci, vp]),

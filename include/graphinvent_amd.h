@@ -273,6 +273,15 @@ typedef struct {
                                  GI_GEMM_BF3B_F32 launches: a transposed copy of a weight, 4 bytes per element through L2
                                  instead of 6); fits the same buffer */
 } gi_bf3_pack_desc;
+/* Which kernel runs a GI_GEMM_BF3 launch whose operands are plain fp32 (measurement aids; on = 1 / 0 sets, on < 0
+ * queries; both return the previous setting; environment GI_B3P / GI_B3V set the initial values, default 1):
+ *   gi_b3p_enable: the software-pipelined 128 x 256 kernel (gi_gemm_b3p.hip) — weight-gradient launches
+ *                  (a_major + b_major + split-K slabs; autograd of gnn/modules.py:166-170) always, forward / dgrad
+ *                  launches from 2.5 tiles per CU on;
+ *   gi_b3v_enable: the 32-deep-tile 128 x 128 kernel (gi_gemm_b3v.hip) for what is left (dgrad with W as stored);
+ * everything else — and everything when both are off — runs on the round-3 kernel (gi_gemm_bf3.hip). */
+int gi_b3p_enable(int on);
+int gi_b3v_enable(int on);
 /* Process-wide switch of gi_ggnn_forward / backward's use of GI_GEMM_BF3 launches (initial value: environment
  * GI_BF3, else GI_BF3_DEFAULT): on = 1 / 0 sets it, on < 0 only queries; returns the previous setting.  The
  * workspace size does not depend on it. */

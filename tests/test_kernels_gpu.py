@@ -184,26 +184,29 @@ def test_gemm_bf16x3_split_matches_fp64_like_the_fp32_mfma_does(M, N, K):
     ops.gemm(ops.bf3_pack(Xc[:, :K]), img, Ya, M, N, K, 0, 0, ldc,
              flags=L.EPI_BIAS | L.EPI_SELU | L.GEMM_BF3 | L.GEMM_BF3A, bias=b.to(DEV))
     assert torch.equal(Ya, Y3)
-    # dgrad: dX = (dZ . W) * selu'(act), W [K_out = K, N_in = N2] through the transposed image; accumulate; gather
+    # dgrad: dX = (dZ . W) * selu'(act), W [K_out = K, N_in = N2] through the transposed image; accumulate
     N2 = N
     Wt = torch.randn(K, N2, generator=g) / K ** 0.5       # [out, in]
     act = torch.randn(M, ops.r4(N2), generator=g)
     dX0 = torch.randn(M, ops.r4(N2), generator=g)
-    idx = torch.randperm(M, generator=g).int()
     imgT = ops.bf3_pack(Wt.to(DEV), transpose=True)
     dX = dX0.clone().to(DEV)
     ops.gemm(Xc, imgT, dX, M, N2, K, lda, 0, ops.r4(N2), flags=L.EPI_DSELU | L.EPI_ACCUM | L.GEMM_BF3,
-             act=act.to(DEV), ldact=ops.r4(N2), a_idx=idx.to(DEV))
+             act=act.to(DEV), ldact=ops.r4(N2))
     y = act[:, :N2].double()
     grad = D.selu_grad_from_out(y)
-    refd = (X[idx.long(), :K].double() @ Wt.double()) * grad + dX0[:, :N2].double()
+    refd = (X[:, :K].double() @ Wt.double()) * grad + dX0[:, :N2].double()
     assert rel(dX[:, :N2], refd) < 2e-6
     # the model's dgrad launches: W^T as a plain fp32 copy, split while staged — the same bits
     dXf = dX0.clone().to(DEV)
     ops.gemm(Xc, ops.bf3_pack(Wt.to(DEV), transpose=True, as_f32=True), dXf, M, N2, K, lda, ops.r4(K), ops.r4(N2),
-             flags=L.EPI_DSELU | L.EPI_ACCUM | L.GEMM_BF3 | L.GEMM_BF3B_F32, act=act.to(DEV), ldact=ops.r4(N2),
-             a_idx=idx.to(DEV))
+             flags=L.EPI_DSELU | L.EPI_ACCUM | L.GEMM_BF3 | L.GEMM_BF3B_F32, act=act.to(DEV), ldact=ops.r4(N2))
     assert torch.equal(dXf, dX)
+    # a row gather is refused on the bf16 pipe (32-bit operand offsets cannot be bounded for gathered rows)
+    idx = torch.randperm(M, generator=g).int()
+    with pytest.raises(RuntimeError, match="GI_EINVAL"):
+        ops.gemm(Xc, imgT, dX, M, N2, K, lda, 0, ops.r4(N2), flags=L.EPI_DSELU | L.GEMM_BF3, act=act.to(DEV),
+                 ldact=ops.r4(N2), a_idx=idx.to(DEV))
     # a launch mixes bf16x3 problems with fp32 ones: refused, not silently computed in one precision
     p = (L.GemmParams * 2)()
     for q in p:
@@ -211,6 +214,85 @@ def test_gemm_bf16x3_split_matches_fp64_like_the_fp32_mfma_does(M, N, K):
         q.nsplit, q.ones_col, q.tm, q.tn = 1, -1, 1, 1
     p[0].B, p[0].flags = img.data_ptr(), L.GEMM_BF3
     assert L.load().gi_gemm_batch(p, 2, None) == -1         # GI_EINVAL
+
+
+@pytest.fixture
+def bf3_kernel_switches():
+    lib = L.load()
+    prev = lib.gi_b3p_enable(-1), lib.gi_b3v_enable(-1)
+    yield lib
+    lib.gi_b3p_enable(prev[0]); lib.gi_b3v_enable(prev[1])
+    os.environ.pop("GI_B3P_ALL", None)
+
+
+@pytest.mark.parametrize("kernel", ["b3p", "b3v", "r3"])
+@pytest.mark.parametrize("M,N,K", [(7258, 500, 500), (1000, 250, 250), (300, 200, 685), (257, 192, 36), (129, 257, 1000)])
+def test_gemm_bf16x3_kernels_forward_and_dgrad_layouts_vs_fp64(M, N, K, kernel, bf3_kernel_switches):
+    """Every bf16x3 kernel — the software-pipelined 128 x 256 one (gi_gemm_b3p.hip), the 32-deep-tile 128 x 128 one
+    (gi_gemm_b3v.hip), the round-3 kernel — on the forward layout (bias + SELU) and on the dgrad layouts (W^T as a
+    contiguous copy; W AS STORED, reduction-major, transposed on the way into LDS) against the fp64 product:
+    max |d| / max |ref| < 2e-6, edges off every tile grid, nothing written outside [M, N]."""
+    lib = bf3_kernel_switches
+    lib.gi_b3p_enable(1 if kernel == "b3p" else 0)
+    lib.gi_b3v_enable(1 if kernel == "b3v" else 0)
+    os.environ["GI_B3P_ALL"] = "1"                      # (the pipelined kernel also for launches of few tiles)
+    g = torch.Generator().manual_seed(M + 7 * N + K)
+    lda, ldc = ops.r4(K) + 4, ops.r4(N) + 8
+    X = torch.randn(M, lda, generator=g); X[:, K:] = float("nan")
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    Xd, Wd = X.to(DEV), W.to(DEV)
+    Y = torch.full((M, ldc), 7.0, device=DEV)
+    ops.gemm(Xd, Wd, Y, M, N, K, lda, K, ldc, flags=L.EPI_BIAS | L.EPI_SELU | L.GEMM_BF3 | L.GEMM_BF3B_F32, bias=b.to(DEV))
+    ref = D.selu(X[:, :K].double() @ W.double().t() + b.double())
+    assert rel(Y[:, :N], ref) < 2e-6
+    assert bool((Y[:, N:] == 7.0).all())
+    # dgrad: dX[M, N] = (dZ[M, K] . Wt[K, N]) * selu'(act) (+ accumulate)
+    Wt = torch.randn(K, N, generator=g) / K ** 0.5
+    act = torch.randn(M, ops.r4(N), generator=g)
+    dX0 = torch.randn(M, ops.r4(N), generator=g)
+    refd = (X[:, :K].double() @ Wt.double()) * D.selu_grad_from_out(act[:, :N].double()) + dX0[:, :N].double()
+    dXc = dX0.clone().to(DEV)
+    ops.gemm(Xd, ops.bf3_pack(Wt.to(DEV), transpose=True, as_f32=True), dXc, M, N, K, lda, ops.r4(K), ops.r4(N),
+             flags=L.EPI_DSELU | L.EPI_ACCUM | L.GEMM_BF3 | L.GEMM_BF3B_F32, act=act.to(DEV), ldact=ops.r4(N))
+    assert rel(dXc[:, :N], refd) < 2e-6
+    if kernel != "r3":                                  # W as stored: only the round-4 kernels transpose while staging
+        dXm = dX0.clone().to(DEV)
+        ldw = N + (N & 1) if kernel == "b3v" else N     # (b3v reads column PAIRS of a major operand: even row pitch)
+        Wp = torch.zeros(K, ldw); Wp[:, :N] = Wt
+        ops.gemm(Xd, Wp.to(DEV), dXm, M, N, K, lda, ldw, ops.r4(N), flags=L.EPI_DSELU | L.EPI_ACCUM | L.GEMM_BF3,
+                 act=act.to(DEV), ldact=ops.r4(N), b_major=True)
+        assert rel(dXm[:, :N], refd) < 2e-6
+
+
+@pytest.mark.parametrize("kernel", ["b3p", "b3v"])
+@pytest.mark.parametrize("rows,n_out,n_in,nsplit", [(7258, 500, 500, 8), (2600, 250, 250, 3), (1000, 192, 301, 1),
+                                                    (517, 257, 129, 5), (40, 130, 200, 2)])
+def test_gemm_bf16x3_weight_gradient_layout_vs_fp64(rows, n_out, n_in, nsplit, kernel, bf3_kernel_switches):
+    """The A_MAJOR, B_MAJOR = true, true layout on the bf16 pipe: [dW | db] = dZ^T [X | 1] (autograd of
+    gnn/modules.py:166-170), both operands read along rows and transposed in registers on the way into LDS, the
+    ones column for the bias gradient, split-K slabs summed afterwards — against the fp64 product (< 2e-6 of
+    max |ref|, the slabs' sum; the fp32 MFMA kernel's own distance is printed beside it), slab tails beyond the
+    reduction range exactly zero, nothing written outside [n_out, n_in + 1]."""
+    lib = bf3_kernel_switches
+    lib.gi_b3p_enable(1 if kernel == "b3p" else 0)
+    lib.gi_b3v_enable(1 if kernel == "b3v" else 0)
+    g = torch.Generator().manual_seed(rows + n_out + n_in)
+    lddz, ldx, ldc = ops.r4(n_out) + 4, ops.r4(n_in), ops.r4(n_in + 1) + 4
+    dZ = torch.randn(rows, lddz, generator=g) * 1e-3; dZ[:, n_out:] = float("nan")
+    X = torch.randn(rows, ldx, generator=g)
+    stride = ops.r4(n_out * ldc)
+    ref = torch.cat([dZ[:, :n_out].double().t() @ X[:, :n_in].double(), dZ[:, :n_out].double().sum(0)[:, None]], 1)
+    outs = {}
+    for name, extra in (("bf16x3", L.GEMM_BF3), ("fp32", 0)):
+        C = torch.full((nsplit, stride), 7.0, device=DEV)
+        ops.gemm(dZ.to(DEV), X.to(DEV), C, n_out, n_in + 1, rows, lddz, ldx, ldc, flags=L.GEMM_SPLITK | extra,
+                 a_major=True, b_major=True, ones_col=n_in, nsplit=nsplit, c_split_stride=stride)
+        S = C[:, :n_out * ldc].view(nsplit, n_out, ldc)
+        assert bool((S[:, :, n_in + 1:] == 7.0).all())
+        outs[name] = S[:, :, :n_in + 1].double().sum(0).cpu()
+    e3, e1 = rel(outs["bf16x3"], ref), rel(outs["fp32"], ref)
+    assert e3 < 2e-6 and e3 < 4 * e1 + 2e-7, (e3, e1)
 
 
 @pytest.mark.parametrize("b_major", [False, True])

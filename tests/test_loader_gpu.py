@@ -123,8 +123,8 @@ def test_prefetched_compaction_on_the_loader_is_bit_identical_to_the_unprefetche
             for nodes, edges, apds in ld:
                 res.append((ids_of(apds), model(nodes, edges).clone()))
         delta = {k: ops.READBACKS[k] - before[k] for k in before}
-        assert delta == ({"prefetched": 5, "blocking": 0, "bounded": 0} if prefetch else
-                         {"prefetched": 0, "blocking": 5, "bounded": 0}), delta
+        assert delta == ({"prefetched": 6, "blocking": 0, "bounded": 0} if prefetch else
+                         {"prefetched": 0, "blocking": 6, "bounded": 0}), delta
         outs[prefetch] = res
     for (ia, a), (ib, b) in zip(outs[True], outs[False]):
         assert np.array_equal(ia, ib) and torch.equal(a, b)

@@ -69,21 +69,23 @@ int main(int argc, char** argv) {
            sum / 140 * 1e3, best / 20 * 1e3, flops * 140 / (sum * 1e-3) / 1e12, worst);
 #ifdef GI_B3P_TRACE
     if (trace_path) {
-        unsigned long long* buf; (void)hipMalloc(&buf, 2048 * 8); (void)hipMemset(buf, 0, 2048 * 8);
+        unsigned long long* buf; (void)hipMalloc(&buf, 8192 * 8); (void)hipMemset(buf, 0, 8192 * 8);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(gp_trace_buf), &buf, sizeof(buf));
         launch(); (void)hipDeviceSynchronize();
-        std::vector<unsigned long long> h(2048);
-        (void)hipMemcpy(h.data(), buf, 2048 * 8, hipMemcpyDeviceToHost);
+        std::vector<unsigned long long> h(8192);
+        (void)hipMemcpy(h.data(), buf, 8192 * 8, hipMemcpyDeviceToHost);
         FILE* f = fopen(trace_path, "w");
         if (!f) { printf("cannot write %s\n", trace_path); return 1; }
         for (int g = 0; g < 2; ++g) {
-            fprintf(f, "group %d: cycles per iteration: %s\n", g, g == 0 ?
-                    "compute, barrier, wait-loads, split+write, issue-loads, barrier" : "wait-loads, split+write, issue-loads, barrier, compute, barrier");
-            for (int i = 0; i + 6 < 1024 && h[g * 1024 + i + 6]; i += 6) {
-                const unsigned long long* t = &h[g * 1024 + i];
-                fprintf(f, "  %6lld: %5llu %5llu %5llu %5llu %5llu %5llu\n", (long long)(t[0] - h[0]), t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5]);
-            }
+            fprintf(f, "wave %d: cycles per k tile iteration (48 MFMAs per wave, 2 waves per SIMD):", 4 * g);
+            for (int i = 0; i + 1 < 1024 && h[g * 1024 + i + 1]; ++i) fprintf(f, " %llu", h[g * 1024 + i + 1] - h[g * 1024 + i]);
+            fprintf(f, "\n");
         }
+        unsigned long long t0 = ~0ull;
+        for (int bk = 0; bk < 1024 && h[2048 + 4 * bk]; ++bk) t0 = h[2048 + 4 * bk] < t0 ? h[2048 + 4 * bk] : t0;
+        fprintf(f, "workgroups (cycles from the first start): block start loop-start loop-end end\n");
+        for (int bk = 0; bk < 1024 && h[2048 + 4 * bk]; ++bk)
+            fprintf(f, "  %4d %7llu %7llu %7llu %7llu\n", bk, h[2048 + 4 * bk] - t0, h[2048 + 4 * bk + 1] - t0, h[2048 + 4 * bk + 2] - t0, h[2048 + 4 * bk + 3] - t0);
         fclose(f);
     }
 #endif

@@ -99,7 +99,8 @@ int main(int argc, char** argv) {
             }
             flops += 2.0 * M * N * K;
         } else {                                       // [dW | db] = dZ^T [X | 1], reduction over M rows
-            const int no = dims[i][0], ni = dims[i][1], ns = dims[i][2] * wmul;
+            const int no = dims[i][0], ni = dims[i][1];
+            const int ns = getenv("GI_LAB_NSPLIT_ALL") ? atoi(getenv("GI_LAB_NSPLIT_ALL")) : dims[i][2] * wmul;   // the same slab count for every problem
             A[i] = make((size_t)M * r4(no), 11 + i, 1.f); p.A = A[i].d; p.lda = r4(no); p.a_major = 1;
             B[i] = make((size_t)M * r4(ni), 31 + i, 1.f); p.B = B[i].d; p.ldb = r4(ni); p.b_major = 1;
             p.M = no; p.N = ni + 1; p.K = M; p.ones_col = ni; p.ldc = r4(ni + 1);
