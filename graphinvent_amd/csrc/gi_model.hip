@@ -274,10 +274,20 @@ struct SlabPlan {
 // and one workgroup owns a CU, so the slab count is chosen for equal tiles of ~29 k steps (920 rows): at the
 // headline batch 8 slabs -> a 500 x 501 problem is 64 workgroups, a 250 x 251 one 16, and four big problems (or two
 // big + six small) make one full round of the device (launch_wgrad_batches packs them that way).
-constexpr int BF3_WGRAD_SLAB_ROWS = 920;
+// The bond-type-grouped message stacks (reduction over a type's message rows; decided by the rows of all types
+// together) and the graph-level stacks (reduction over the B graphs) join from BF3_WGRAD_SMALL_MIN rows on: their
+// launches are a fraction of a round of whole-CU workgroups beside the message passes' dZ chains, which measured a
+// LOSS at the headline batch (8.4 k message rows, B = 1000: step 2.09 -> 2.16 ms) and a gain at 26 k message rows
+// (ZINC shape 4.38 -> 4.34 ms).
+constexpr int BF3_WGRAD_SLAB_ROWS = 920, BF3_WGRAD_MIN_ROWS = 768, BF3_WGRAD_SHORT_SLAB_ROWS = 336;
+constexpr int BF3_WGRAD_SMALL_MIN = 16000;
 bool bf3_wgrad_ok(int n_out, int n_in, int red_rows) {
     return bf3_enabled() && gi_b3p_enable(-1) && n_out >= BF3_MIN_WIDTH && n_in >= BF3_MIN_WIDTH &&
-           red_rows >= BF3_MIN_ROWS;
+           red_rows >= BF3_WGRAD_MIN_ROWS;
+}
+int bf3_wgrad_nsplit(int red_rows, int decide_rows) {
+    const int L = decide_rows >= BF3_MIN_ROWS ? BF3_WGRAD_SLAB_ROWS : BF3_WGRAD_SHORT_SLAB_ROWS;
+    return std::max(1, (red_rows + L / 2) / L);
 }
 
 void wgrad_shape(int n_out, int n_in, int red_rows, double share, int& tn, int& nsplit) {
@@ -299,33 +309,36 @@ void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {   /
     long long o = 0;
     int maxEt = 0;
     for (int t = 0; t < d.Fe; ++t) maxEt = std::max(maxEt, Et ? Et[t] : E);
-    auto add = [&](int widx, int bidx, int n_out, int n_in, int red, int calls, double share, bool bf3 = false) {
+    auto add = [&](int widx, int bidx, int n_out, int n_in, int red, int calls, double share, bool bf3 = false,
+                   int decide_rows = -1) {
         SlabEntry& e = sp.e[widx];
         e.bidx = bidx; e.launched = 0; e.reduced = 0;
         e.n_out = n_out; e.n_in = n_in; e.ld = gi_r4(n_in + 1); e.calls = calls; e.done = 0;
         wgrad_shape(n_out, n_in, red, share, e.tn, e.nsplit);
-        e.bf3 = bf3 && !d.dropout && bf3_wgrad_ok(n_out, n_in, red);
-        if (e.bf3) e.nsplit = std::max(1, (red + BF3_WGRAD_SLAB_ROWS / 2) / BF3_WGRAD_SLAB_ROWS);
+        if (decide_rows < 0) decide_rows = red;
+        e.bf3 = bf3 && !d.dropout && bf3_wgrad_ok(n_out, n_in, decide_rows);
+        if (e.bf3) e.nsplit = bf3_wgrad_nsplit(red, decide_rows);
         e.stride = gi_r4l((long long)n_out * e.ld);
         e.off = o;
         o += e.stride * e.nsplit * calls;
     };
-    auto add_mlp = [&](const Mlp& q, int red, int calls, double share = 1.0, bool bf3 = false) {
+    auto add_mlp = [&](const Mlp& q, int red, int calls, double share = 1.0, bool bf3 = false, int decide_rows = -1) {
         for (int l = 0; l < q.layers(); ++l)
-            add(q.w(l), q.b(l), q.fan_out(l), q.fan_in(l), red, calls, share, bf3);
+            add(q.w(l), q.b(l), q.fan_out(l), q.fan_in(l), red, calls, share, bf3, decide_rows);
     };
     const int R = S + 1;
     for (int t = 0; t < d.Fe; ++t) {
         const int et = Et ? Et[t] : E / d.Fe;
-        add_mlp(m.msg[t], et, d.passes, E > 0 ? 1.5 * (double)et / E : 1.0);
+        add_mlp(m.msg[t], et, d.passes, E > 0 ? 1.5 * (double)et / E : 1.0, E >= BF3_WGRAD_SMALL_MIN, E);
         if (d.kind == GI_KIND_ATTGGNN)
-            add_mlp(m.eatt[t], et, d.passes, E > 0 ? 1.5 * (double)et / E : 1.0);
+            add_mlp(m.eatt[t], et, d.passes, E > 0 ? 1.5 * (double)et / E : 1.0, E >= BF3_WGRAD_SMALL_MIN, E);
     }
     add(m.gru_wih, m.gru_bih, 3 * d.H, d.M, R, d.passes, 1.0);
     add(m.gru_whh, m.gru_bhh, 3 * d.H, d.H, R, d.passes, 1.0);
     add_mlp(m.att, R, 1, 1.0, true); add_mlp(m.emb, R, 1, 1.0, true); add_mlp(m.add1, R, 1, 1.0, true);
     add_mlp(m.conn1, R, 1, 1.0, true);
-    add_mlp(m.add2, d.B, 1); add_mlp(m.conn2, d.B, 1); add_mlp(m.term2, d.B, 1);
+    const bool g3 = d.B >= BF3_WGRAD_SMALL_MIN / 4;
+    add_mlp(m.add2, d.B, 1, 1.0, g3); add_mlp(m.conn2, d.B, 1, 1.0, g3); add_mlp(m.term2, d.B, 1, 1.0, g3);
     sp.total = o;
 }
 
@@ -621,7 +634,7 @@ void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* wid
     p.flags = GI_GEMM_SPLITK;
     p.nsplit = e0.nsplit; p.c_split_stride = e0.stride;
     p.tm = e0.tn; p.tn = e0.tn;                 // 1x1 (64x64 tiles) or 2x2 (128x128), see wgrad_shape
-    if (e0.bf3 && !g.n && !b_idx) p.flags |= GI_GEMM_BF3;      // bf16 pipe, 128 x 256 tiles (gi_gemm_b3p.hip)
+    if (e0.bf3 && !b_idx) p.flags |= GI_GEMM_BF3;              // bf16 pipe, 128 x 256 tiles (gi_gemm_b3p.hip)
     const int slot = q.n - 1;
     if (g.n) {
         p.ngroups = g.n; p.grp_off = g.off;
@@ -662,7 +675,11 @@ void launch_wgrad_batches(Run& r, const gi_gemm_params* p, int n, hipStream_t st
     for (int i = 0; i < n; ++i) {
         if (p[i].flags & GI_GEMM_BF3) b3[n3++] = p[i]; else rest[nr++] = p[i];
     }
-    auto tiles = [](const gi_gemm_params& q) { return gi_cdiv(q.M, 128) * gi_cdiv(q.N, 256) * q.nsplit; };
+    auto tiles = [](const gi_gemm_params& q) {
+        int zs = q.nsplit;
+        if (q.ngroups) { zs = 0; for (int g = 0; g < q.ngroups; ++g) zs += q.gsplit[g]; }
+        return gi_cdiv(q.M, 128) * gi_cdiv(q.N, 256) * zs;
+    };
     for (int i = 1; i < n3; ++i)                                  // stable insertion sort, most tiles first
         for (int j = i; j > 0 && tiles(b3[j]) > tiles(b3[j - 1]); --j) std::swap(b3[j], b3[j - 1]);
     static const int cus = [] {

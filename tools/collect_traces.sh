@@ -2,7 +2,7 @@
 # On the GPU box: raw rocprofv3 kernel traces (start / end of every launch, queue ids) of the training step for
 # tools/critical_path.py and tools/gemm_class_report.py — default schedule, every launch alone on the device
 # (bench.py --one-stream), ZINC shape, AttentionGGNN / ChEMBL shape; the last ~6 steps of each are kept.  Plus the
-# GI_GEMM_LOG launch log of the one-stream run.  Output -> gpurun_out/<tag>/ ; copy into profiles/<tag>/.
+# GI_GEMM_LOG launch log of the one-stream run (GI_TRACE_ALL=1: the ZINC / ChEMBL shapes too).  Output -> gpurun_out/<tag>/ ; copy into profiles/<tag>/.
 TAG=${1:-r03}
 OUT=/root/repo/gpurun_out/$TAG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 B="python /root/repo/bench.py --no-cpu-baseline --no-extra-configs --no-forward-only --no-probe --no-one-stream --steps 12 --warmup 4"
@@ -33,8 +33,8 @@ PY
 }
 tr default
 tr onestream --one-stream
-tr zinc --shape zinc --batch 1000 --model ggnn
-tr chembl --shape chembl --batch 250 --model attggnn
+[ -n "$GI_TRACE_ALL" ] && tr zinc --shape zinc --batch 1000 --model ggnn
+[ -n "$GI_TRACE_ALL" ] && tr chembl --shape chembl --batch 250 --model attggnn
 rm -f $OUT/gemm_launch_log.txt
 GI_GEMM_LOG=$OUT/gemm_launch_log.txt timeout 60 $B --one-stream --steps 2 --warmup 1 > /dev/null 2>&1
 cd /root/repo

@@ -30,7 +30,8 @@ def main():
     st = rows[lo:hi]
     fill = next(r for r in st if "compact_fill" in r["Kernel_Name"] and r["Queue_Id"] == main_q)
     mq = [r for r in st if r["Queue_Id"] == main_q and r["s"] >= fill["s"]]
-    side_names = ("gi_gemm_batch_kernel<1, 1, true, true", "gi_gemm_tiles_kernel<1, 1, true, true", "reduce_slabs")
+    side_names = ("gi_gemm_batch_kernel<1, 1, true, true", "gi_gemm_tiles_kernel<1, 1, true, true", "reduce_slabs",
+                  "gi_b3p_kernel<true, true", "gi_b3v_kernel<true, true")
     side = [r for r in st if r["Queue_Id"] != main_q and any(n in r["Kernel_Name"] for n in side_names)]
     t0 = fill["s"]
 

@@ -22,9 +22,11 @@ def log_steps(path):
         if len(f) < 5:
             continue
         rec = dict(cls=f[0], nprob=int(f[1]), blocks=int(f[2]), flop=float(f[3]), probs=f[4:])
-        rec["bf3"] = rec["cls"][0] == "b"                      # bf16x3 launch (gi_gemm_bf3.hip): "b0" forward, "b1" dgrad
+        # bf16x3 launches: "b0" / "b1" / "b2" (gi_gemm_bf3.hip, gi_gemm_b3v.hip), "p0" / "p1" / "p2" (gi_gemm_b3p.hip):
+        # forward / dgrad / weight-gradient layout
+        rec["bf3"] = rec["cls"][0] in "bp"
         if rec["bf3"]:
-            rec["cls"] = "0" + rec["cls"][1]
+            rec["cls"] = {"0": "00", "1": "01", "2": "11"}[rec["cls"][1]]
         first = rec["cls"] == "01" and rec["nprob"] == 1 and rec["probs"][0].split(":")[0].endswith("x45") \
             and cur is not None and any(r["cls"] == "11" for r in cur)
         if cur is None or first:
@@ -41,7 +43,7 @@ def trace_step(path, step=0):
     rows.sort(key=lambda r: r["s"])
     adam = [i for i, r in enumerate(rows) if "adam" in r["Kernel_Name"]]
     st = rows[adam[step] + 1:adam[step + 1]]
-    return [r for r in st if r["Kernel_Name"].startswith("gi_gemm")]
+    return [r for r in st if r["Kernel_Name"].startswith(("gi_gemm", "gi_b3p", "gi_b3v"))]
 
 
 def label(rec):
@@ -65,6 +67,10 @@ def main():
     def kind(name):
         if "gi_gemm_bf3_kernel" in name:                        # <1, ..>: bias + SELU epilogue = forward; <2 / 0, ..>: dgrad
             return "00" if "gi_gemm_bf3_kernel<1" in name else "01"
+        if "gi_b3p_kernel" in name or "gi_b3v_kernel" in name:  # <A_MAJOR, B_MAJOR, EPI>
+            if "<true, true" in name:
+                return "11"
+            return "00" if ", 1>" in name else "01"
         return "11" if "true, true" in name else ("01" if "false, true" in name else "00")
     by_cls = {c: [r for r in launches if kind(r["Kernel_Name"]) == c] for c in ("00", "01", "11")}
     out = []
@@ -83,6 +89,13 @@ def main():
     wus = sum(r["e"] - r["s"] for r in by_cls["11"])
     print("%-58s %9.3f %8.1f %8.1f %6.2f" % ("wgrad    all batches of the step", wf / 1e9, wus, wf / wus / 1e6,
                                            wf / wus / 1e6 / PEAK))
+    w3f = sum(r["flop"] for r in recs if r["cls"] == "11" and r.get("bf3"))
+    w3us = sum(r["e"] - r["s"] for r in by_cls["11"] if "gi_b3" in r["Kernel_Name"])
+    if w3us > 0:
+        print("%-58s %9.3f %8.1f %8.1f %6.2f" % ("  of which on the bf16 pipe (bf16x3)", w3f / 1e9, w3us, w3f / w3us / 1e6,
+                                               w3f / w3us / 1e6 / PEAK))
+        print("%-58s %9.3f %8.1f %8.1f %6.2f" % ("  of which on the fp32 MFMA", (wf - w3f) / 1e9, wus - w3us,
+                                               (wf - w3f) / (wus - w3us) / 1e6, (wf - w3f) / (wus - w3us) / 1e6 / PEAK))
     tot_f = sum(f for _, f, _ in out) + wf
     tot_us = sum(u for _, _, u in out) + wus
     print("%-58s %9.3f %8.1f %8.1f %6.2f" % ("gi_gemm / gi_gemm_batch launches (chains not logged)", tot_f / 1e9,
