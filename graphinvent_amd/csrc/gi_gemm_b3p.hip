@@ -315,6 +315,9 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
     // one term of the six-product sum for the wave's four accumulators (smallest terms first)
     auto mfma4 = [&](const gp_bf16x8 (&af)[2][3], const gp_bf16x8 (&bf)[2][3], int term) __attribute__((always_inline)) {
         constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
+#if defined(GP_DBG) && (GP_DBG & 16)      // lab, TIMING ONLY: what three products instead of six would cost
+        if (term < 3) return;
+#endif
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll

@@ -290,8 +290,13 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
         }
         // smallest terms first; four independent accumulators between two MFMAs on the same one
         constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
+#ifdef B3_X2_TIMING                       // lab, TIMING ONLY: three products instead of six
+        constexpr int T0 = 3;
+#else
+        constexpr int T0 = 0;
+#endif
 #pragma unroll
-        for (int term = 0; term < 6; ++term)
+        for (int term = T0; term < 6; ++term)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll

@@ -329,15 +329,18 @@ void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {   /
     const int R = S + 1;
     for (int t = 0; t < d.Fe; ++t) {
         const int et = Et ? Et[t] : E / d.Fe;
-        add_mlp(m.msg[t], et, d.passes, E > 0 ? 1.5 * (double)et / E : 1.0, E >= BF3_WGRAD_SMALL_MIN, E);
+        static const int force_msg = getenv("GI_B3W_MSG") ? atoi(getenv("GI_B3W_MSG")) : -1;   // (measurement aid)
+        const bool m3 = force_msg >= 0 ? force_msg != 0 : E >= BF3_WGRAD_SMALL_MIN;
+        add_mlp(m.msg[t], et, d.passes, E > 0 ? 1.5 * (double)et / E : 1.0, m3, E);
         if (d.kind == GI_KIND_ATTGGNN)
-            add_mlp(m.eatt[t], et, d.passes, E > 0 ? 1.5 * (double)et / E : 1.0, E >= BF3_WGRAD_SMALL_MIN, E);
+            add_mlp(m.eatt[t], et, d.passes, E > 0 ? 1.5 * (double)et / E : 1.0, m3, E);
     }
     add(m.gru_wih, m.gru_bih, 3 * d.H, d.M, R, d.passes, 1.0);
     add(m.gru_whh, m.gru_bhh, 3 * d.H, d.H, R, d.passes, 1.0);
     add_mlp(m.att, R, 1, 1.0, true); add_mlp(m.emb, R, 1, 1.0, true); add_mlp(m.add1, R, 1, 1.0, true);
     add_mlp(m.conn1, R, 1, 1.0, true);
-    const bool g3 = d.B >= BF3_WGRAD_SMALL_MIN / 4;
+    static const int force_g = getenv("GI_B3W_G") ? atoi(getenv("GI_B3W_G")) : -1;             // (measurement aid)
+    const bool g3 = force_g >= 0 ? force_g != 0 : d.B >= BF3_WGRAD_SMALL_MIN / 4;
     add_mlp(m.add2, d.B, 1, 1.0, g3); add_mlp(m.conn2, d.B, 1, 1.0, g3); add_mlp(m.term2, d.B, 1, 1.0, g3);
     sp.total = o;
 }
