@@ -96,22 +96,22 @@ __global__ __launch_bounds__(256) void compact_count_kernel(
     __syncthreads();
     const T* eg = edges + (long long)b * NN * Fe;
     signed char* etype_g = reinterpret_cast<signed char*>(gfix + L.etype) + (long long)b * NN;
+    // A cell (i, j) holds the SET of bond types between the pair as a bit mask.  The preprocessed data has at most
+    // one (a one-hot row), but the reference's generation loop applies actions to its dummy graph 0 for ever without
+    // resetting it (GraphGenerator.py:133, 424-427) and so builds cells with several types set; the reference then
+    // sums the per-type messages of such a cell (gnn/mpnn.py:286-294: every type's MLP masked by its 0/1 entry),
+    // i.e. it behaves like parallel edges.  Each set bit is an edge here; entries other than 0 / 1 are refused.
     for (int idx = tid; idx < NN; idx += 256) {
-        float sum = 0.f;
-        int t = -1, ones = 0, zeros = 0;
+        int mask = 0, bad = 0;
         for (int f = 0; f < Fe; ++f) {
             const float v = (float)eg[(long long)idx * Fe + f];
-            sum += v;
-            if (v == 1.f) { ++ones; if (t < 0) t = f; }
-            else if (v == 0.f) ++zeros;
+            if (v == 1.f) mask |= 1 << f;
+            else if (v != 0.f) bad = 1;
         }
-        signed char code = -1;
-        if (sum != 0.f) {                        // adjacency != 0  (gnn/summation_mpnn.py:100-105)
-            if (!(ones == 1 && zeros == Fe - 1)) err_s = 1;   // not one-hot: outside the data contract
-            code = (signed char)(t < 0 ? 0 : t);
-        }
-        typ[idx] = code;
-        etype_g[idx] = code;
+        if (bad) err_s |= 1;                     // an edge feature that is not 0 / 1: outside the data contract
+        if (mask & (mask - 1)) err_s |= 8;       // several bond types on one pair (legal for GGNN, see above)
+        typ[idx] = (signed char)mask;
+        etype_g[idx] = (signed char)mask;
     }
     __syncthreads();
     const int ns = gridDim.x * N;
@@ -122,13 +122,11 @@ __global__ __launch_bounds__(256) void compact_count_kernel(
 #pragma unroll
         for (int f = 0; f < GI_MAX_GROUPS; ++f) cct[f] = 0;
         for (int j = 0; j < N; ++j) {
-            rc += (typ[i * N + j] >= 0);
-            const int t = typ[j * N + i];
-            if (t >= 0) {
-                ++cc;
+            rc += __popc((unsigned)(unsigned char)typ[i * N + j]);
+            const int m = (unsigned char)typ[j * N + i];
+            cc += __popc((unsigned)m);
 #pragma unroll
-                for (int f = 0; f < GI_MAX_GROUPS; ++f) cct[f] += (t == f);
-            }
+            for (int f = 0; f < GI_MAX_GROUPS; ++f) cct[f] += (m >> f) & 1;
         }
         bool nz = false, binary = Fn <= 62;
         unsigned long long key = 0;                      // pattern of the 0/1 feature row
@@ -157,7 +155,7 @@ __global__ __launch_bounds__(256) void compact_count_kernel(
         gfix[L.nmsg + slot] = nm;
     }
     __syncthreads();
-    if (tid == 0 && err_s) atomicOr(&gfix[L.counts + CNT_ERR], 1);
+    if (tid == 0 && err_s) atomicOr(&gfix[L.counts + CNT_ERR], err_s);
     if (tid == 0 && b == 0) gfix[L.counts + CNT_NODEDUP] = nodedup;
 }
 
@@ -388,7 +386,7 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
     // Adjacency as bit masks (N <= 128 = two 64-bit words): rowmask[i] = sources j of edges into i,
     // colmask[t][j] = destinations i of j's type-t edges.  A rank inside a row / column is then one
     // popcount instead of a loop over up to N table entries (N = 88: 161 -> 40 us per launch).
-    __shared__ unsigned long long rowmask[NMAX][2];
+    __shared__ unsigned long long rowmask[GI_MAX_GROUPS][NMAX][2];   // [t][i]: sources j of i's incoming type-t edges
     __shared__ unsigned long long colmask[GI_MAX_GROUPS][NMAX][2];
     // per-slot scalars of this graph, read once (the cell loops below used to fetch them from global
     // memory per cell, one dependent load after another)
@@ -406,16 +404,20 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
         cstart_s[t][i] = gfix[L.cstart_t + t * ns + b * N + i];
     }
     if (tid < Fe) { toff_s[tid] = gfix[L.type_off + tid]; etoff_s[tid] = gfix[L.etype_off + tid]; }
-    for (int idx = tid; idx < NMAX * 2; idx += 256) (&rowmask[0][0])[idx] = 0ull;
-    for (int idx = tid; idx < GI_MAX_GROUPS * NMAX * 2; idx += 256) (&colmask[0][0][0])[idx] = 0ull;
+    for (int idx = tid; idx < GI_MAX_GROUPS * NMAX * 2; idx += 256) {
+        (&rowmask[0][0][0])[idx] = 0ull; (&colmask[0][0][0])[idx] = 0ull;
+    }
     for (int idx = tid; idx < NN; idx += 256) typ[idx] = etype_g[idx];
     __syncthreads();
-    for (int idx = tid; idx < NN; idx += 256) {
-        const int t = typ[idx];
-        if (t < 0) continue;
+    for (int idx = tid; idx < NN; idx += 256) {          // (a cell = the bit mask of its bond types, see compact_count)
+        const int m = (unsigned char)typ[idx];
+        if (!m) continue;
         const int i = idx / N, j = idx - i * N;
-        atomicOr(&rowmask[i][j >> 6], 1ull << (j & 63));
-        atomicOr(&colmask[t][j][i >> 6], 1ull << (i & 63));
+        for (int t = 0; t < Fe; ++t)
+            if ((m >> t) & 1) {
+                atomicOr(&rowmask[t][i][j >> 6], 1ull << (j & 63));
+                atomicOr(&colmask[t][j][i >> 6], 1ull << (i & 63));
+            }
     }
     __syncthreads();
     auto rank128 = [](const unsigned long long* m, int pos) {       // set bits below position pos
@@ -439,39 +441,50 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(
                 cmat[(long long)gfix[L.cidx + b * N + i] * ldc0 + (idx - i * zc)] = 0.f;
         }
     }
-    for (int idx = tid; idx < NN; idx += 256) {          // dst-CSR: edges into i, j ascending
-        const int t = typ[idx];
-        if (t < 0) continue;
+    for (int idx = tid; idx < NN; idx += 256) {          // dst-CSR: edges into i, (j, type) ascending
+        const int m = (unsigned char)typ[idx];
+        if (!m) continue;
         const int i = idx / N, j = idx - i * N;
-        const int rank = rank128(rowmask[i], j);
-        const int ed = seg_s[i] + rank;
-        // rank of this edge among j's type-t out-edges
-        const int urank = nd ? rank128(colmask[t][j], i) : 0;
-        in_perm[ed] = toff_s[t] + mstart_s[t][j] + urank;
-        kpos[idx] = ed;
+        int base = seg_s[i];                             // + edges into i from sources below j
+        for (int t = 0; t < Fe; ++t) base += rank128(rowmask[t][i], j);
+        kpos[idx] = base;                                // the cell's first edge slot; its types follow in order
+        int k = 0;
+        for (int t = 0; t < Fe; ++t)
+            if ((m >> t) & 1) {
+                // rank of this edge among j's type-t out-edges
+                const int urank = nd ? rank128(colmask[t][j], i) : 0;
+                in_perm[base + k] = toff_s[t] + mstart_s[t][j] + urank;
+                ++k;
+            }
     }
     __syncthreads();                                     // kpos complete, cmat rows zeroed
     for (int idx = tid; idx < NN; idx += 256) {          // message CSR: edges out of j of type t, i ascending
-        const int t = typ[idx];
-        if (t < 0) continue;
+        const int m = (unsigned char)typ[idx];
+        if (!m) continue;
         const int i = idx / N, j = idx - i * N;
         const int slot = b * N + j;
-        const int rank = rank128(colmask[t][j], i);
-        const int mo = etoff_s[t] + cstart_s[t][j] + rank;
-        mu_dst[mo] = cidx_s[i];
-        mu_slot[mo] = kpos[idx];
-        if (nd) {                                        // this edge's own message row
-            const int u = toff_s[t] + mstart_s[t][j] + rank;
-            int before = 0;                              // rows of lower bond types sent by the slot
-            for (int tt = 0; tt < t; ++tt) before += gfix[L.colcnt_t + tt * ns + slot];
-            u_src[u] = cidx_s[j];
-            out_perm[gfix[L.srcm_start + slot] + before + rank] = u;
-            mu_off[u] = mo;
-        }
-        if (D0 > 0) {  // counts are small integers: float atomics are exact and order-independent
-            const int d = gfix[L.dmap + t * P0Q + cls_s[j]];
-            atomicAdd(cmat + (long long)cidx_s[i] * ldc0 + d, 1.f);
-            if (e2d) e2d[kpos[idx]] = d;                 // dst-CSR edge slot -> pass-0 row
+        int k = 0;
+        for (int t = 0; t < Fe; ++t) {
+            if (!((m >> t) & 1)) continue;
+            const int ed = kpos[idx] + k;
+            ++k;
+            const int rank = rank128(colmask[t][j], i);
+            const int mo = etoff_s[t] + cstart_s[t][j] + rank;
+            mu_dst[mo] = cidx_s[i];
+            mu_slot[mo] = ed;
+            if (nd) {                                    // this edge's own message row
+                const int u = toff_s[t] + mstart_s[t][j] + rank;
+                int before = 0;                          // rows of lower bond types sent by the slot
+                for (int tt = 0; tt < t; ++tt) before += gfix[L.colcnt_t + tt * ns + slot];
+                u_src[u] = cidx_s[j];
+                out_perm[gfix[L.srcm_start + slot] + before + rank] = u;
+                mu_off[u] = mo;
+            }
+            if (D0 > 0) {  // counts are small integers: float atomics are exact and order-independent
+                const int d = gfix[L.dmap + t * P0Q + cls_s[j]];
+                atomicAdd(cmat + (long long)cidx_s[i] * ldc0 + d, 1.f);
+                if (e2d) e2d[ed] = d;                    // dst-CSR edge slot -> pass-0 row
+            }
         }
     }
     for (int idx = tid; idx < N * Fe; idx += 256) {      // message rows of source slot j, by type

@@ -92,7 +92,8 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dro
     if bounds is not None:
         return _forward_bounded(lib, consts, nodes, edges, params, kind, bounds, p0_cache, sticky_err)
     drop = dropout_seed is not None
-    nodes, lay, gfix, S, E, U, D0, Ut = _ops.compact_count(nodes, edges, nodedup=drop)
+    nodes, lay, gfix, S, E, U, D0, Ut = _ops.compact_count(nodes, edges, nodedup=drop,
+                                                           allow_multi_bond=kind == _L.KIND_GGNN)
     attn = kind != _L.KIND_GGNN
     B = nodes.shape[0]
     dims = _dims_from_constants(consts, B, kind)
@@ -378,11 +379,14 @@ class _FusedMPNN(torch.nn.Module):
             if bits:
                 w.zero_()
                 err |= bits
+        if self._KIND == _L.KIND_GGNN:
+            err &= ~_ops.ERR_MULTI_BOND              # several bond types on a pair = parallel edges, like the reference
         if err:
             raise ValueError("sync-free forward: " + ", ".join(
-                m for bit, m in ((1, "an edge's feature vector is not one-hot"),
+                m for bit, m in ((1, "a bond-type entry of an edge is not 0 / 1"),
                                  (2, "more edges / feature classes than sync_free_bounds"),
-                                 (4, "node features are not 0/1")) if err & bit))
+                                 (4, "node features are not 0/1"),
+                                 (8, "an atom pair carries several bond types (AttentionGGNN)")) if err & bit))
         return 0
 
     def _dropout_active(self) -> bool:

@@ -193,12 +193,18 @@ def _count_launch(nodes: torch.Tensor, edges: torch.Tensor, nodedup: bool = Fals
     return nodes, lay, gfix, Fe
 
 
-def _unpack_counts(counts, Fe: int):
+ERR_EDGE_VALUE, ERR_OVERFLOW, ERR_NODE_VALUE, ERR_MULTI_BOND = 1, 2, 4, 8     # bits of gfix counts[2]
+
+
+def _unpack_counts(counts, Fe: int, allow_multi_bond: bool = True):
     S, E, err, U, D0 = counts[0], counts[1], counts[2], counts[3], counts[20]
-    if err:
-        raise ValueError("edges tensor violates the preprocessed-HDF contract: every bonded pair "
-                         "must carry exactly one one-hot bond type (DataProcesser.py / "
-                         "MolecularGraph.py edge features)")
+    if err & ERR_EDGE_VALUE:
+        raise ValueError("edges tensor violates the preprocessed-HDF contract: bond-type entries must be 0 or 1 "
+                         "(DataProcesser.py / MolecularGraph.py edge features)")
+    if (err & ERR_MULTI_BOND) and not allow_multi_bond:
+        raise ValueError("an atom pair carries several bond types at once: GGNN treats them as parallel edges like the "
+                         "reference does (the generation loop's dummy graph, GraphGenerator.py:133, 424-427), but "
+                         "AttentionGGNN's softmax over neighbours (gnn/mpnn.py:370-389) is not defined per bond here")
     return S, E, U, D0, counts[4:4 + Fe]
 
 
@@ -261,7 +267,7 @@ def prefetch_compact(nodes: torch.Tensor, edges: torch.Tensor,
                                              weakref.ref(nodes), weakref.ref(edges))
 
 
-def compact_count(nodes: torch.Tensor, edges: torch.Tensor, nodedup: bool = False):
+def compact_count(nodes: torch.Tensor, edges: torch.Tensor, nodedup: bool = False, allow_multi_bond: bool = True):
     """Phase 1; returns (nodes, layout, gfix, S, E, U, D0, Ut).  One host read-back of 24 ints — the only
     synchronisation point of a forward pass, unless `prefetch_compact` already ran for this batch.
     nodedup: the layout without row sharing (a prefetched, de-duplicated result is discarded)."""
@@ -278,11 +284,11 @@ def compact_count(nodes: torch.Tensor, edges: torch.Tensor, nodedup: bool = Fals
         gfix.record_stream(cur)
         nodes_c.record_stream(cur)
         READBACKS["prefetched"] += 1
-        return (nodes_c, lay, gfix) + _unpack_counts(pinned.tolist(), Fe)
+        return (nodes_c, lay, gfix) + _unpack_counts(pinned.tolist(), Fe, allow_multi_bond)
     READBACKS["blocking"] += 1
     nodes, lay, gfix, Fe = _count_launch(nodes, edges, nodedup)
     counts = gfix[lay.counts:lay.counts + L.COUNTS].cpu().tolist()
-    return (nodes, lay, gfix) + _unpack_counts(counts, Fe)
+    return (nodes, lay, gfix) + _unpack_counts(counts, Fe, allow_multi_bond)
 
 
 @_on_device_of("nodes")

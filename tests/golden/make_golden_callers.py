@@ -1,0 +1,144 @@
+"""Golden vectors for the CALLERS of the hot path (BASELINE.json north_star: "Workflow.py and GraphGenerator.py call it
+unchanged"), produced in the build container by the UNMODIFIED reference methods with the reference's own ``gnn`` on
+CPU (tests/golden/ref_callers.py supplies the stub modules):
+
+  golden_workflow.npz   ``Workflow.get_dataloader`` + ``define_model_and_optimizer`` (-> ``create_model``) +
+                        EPOCHS x ``train_epoch`` + ``validation_epoch`` (Workflow.py:120-141, 225-292, 766-860) on the
+                        shipped fixture ``gdb13_1K-debug/valid.h5`` (used as training AND validation file: 100 rows,
+                        none of them padding).  ``batch_size`` = the whole file, so an epoch is ONE optimiser step on
+                        all rows and the reference loader's own shuffle (torch's global RNG) cannot change the batch:
+                        per-step training losses, the validation loss after every step, weight digests.
+  golden_generator.npz  ``GraphGenerator(model, batch_size).build_graphs()`` (GraphGenerator.py:27-43, 99-161 and what it
+                        calls) with the one random draw pinned (InverseCdfDraws): the finished graphs, their node counts,
+                        termination flags and per-action likelihoods.
+
+Before anything is written the restatement ``oracle/callers_oracle.py`` is run on the same inputs and must reproduce
+the unmodified methods BIT FOR BIT (that file is what the -m gpu tests can import on a box without the reference)."""
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import callers_oracle as CO            # noqa: E402
+from oracle import ggnn_oracle as O                # noqa: E402
+from tests.golden import ref_callers as RC         # noqa: E402
+from tests.golden.spec import digest               # noqa: E402
+
+FIXTURE = "/root/reference/data/pre-training/gdb13_1K-debug/valid.h5"
+SEED, EPOCHS = 1234, 4
+GEN_SEED, GEN_BATCH = 77, 48
+# the generation loop runs a SMALL GGNN trained for GEN_TRAIN_STEPS steps on the fixture (an untrained model samples
+# an invalid action in nine graphs out of ten and the loop ends after two rounds without ever growing a molecule);
+# its weights travel in the golden file
+GEN_CFG = dict(hidden_node_features=32, message_size=32, enn_hidden_dim=48, gather_width=32, gather_att_hidden_dim=48,
+               gather_emb_hidden_dim=48, mlp1_hidden_dim=64, mlp2_hidden_dim=64)
+GEN_TRAIN_STEPS = 300
+
+
+def data_dir():
+    d = tempfile.mkdtemp(prefix="gi_callers_")
+    for name in ("train", "valid", "test"):
+        shutil.copy(FIXTURE, os.path.join(d, name + ".h5"))
+    return d
+
+
+def run_workflow(make_workflow, constants):
+    """The training path as main.py / Workflow.training_phase drive it (Workflow.py:371-400), minus logging."""
+    torch.manual_seed(SEED)
+    wf = make_workflow(constants)
+    wf.train_dataloader = wf.get_dataloader(wf.train_h5_path, "training set")
+    wf.valid_dataloader = wf.get_dataloader(wf.valid_h5_path, "validation set")
+    start, end = wf.define_model_and_optimizer()
+    init = {k: v.detach().clone() for k, v in wf.model.state_dict().items()}
+    train, valid = [], []
+    for epoch in range(start, end):
+        wf.current_epoch = epoch
+        train.append(float(wf.train_epoch()))
+        valid.append(float(wf.validation_epoch()))
+    final = {k: v.detach().clone() for k, v in wf.model.state_dict().items()}
+    return dict(train=np.array(train), valid=np.array(valid), init=init, final=final, span=(start, end))
+
+
+def run_generator(make_generator, model, constants, draw_seed):
+    draw = CO.InverseCdfDraws(draw_seed, GEN_BATCH)
+    RC.pin_multinomial(draw)
+    gen = make_generator(model, GEN_BATCH, draw)
+    n = gen.build_graphs()
+    out = dict(n_generated=n, rounds=draw.round, margin=draw.margin,
+               nodes=gen.generated_nodes.cpu().numpy(), edges=gen.generated_edges.cpu().numpy(),
+               n_nodes=gen.generated_n_nodes.cpu().numpy(), terminated=gen.properly_terminated.cpu().numpy(),
+               likelihoods=gen.generated_likelihoods.cpu().numpy())
+    return out
+
+
+def main():
+    assert RC.have_reference()
+    d = data_dir()
+    cfg = O.make_config()
+    consts = RC.as_constants(RC.constants_dict("cpu", cfg, d, batch_size=100, epochs=EPOCHS))
+    WF, GG = RC.load("reference", consts)
+
+    ref = run_workflow(lambda c: WF.Workflow(constants=c), consts)
+    mine = run_workflow(lambda c: CO.WorkflowOracle(c), consts)
+    assert np.array_equal(ref["train"], mine["train"]) and np.array_equal(ref["valid"], mine["valid"]), (ref, mine)
+    assert all(torch.equal(ref["final"][k], mine["final"][k]) for k in ref["final"])
+    print("Workflow: restatement == unmodified, bit for bit;  train", ref["train"], " valid", ref["valid"])
+    blob = dict(seed=SEED, epochs=EPOCHS, train=ref["train"], valid=ref["valid"], batch_size=100,
+                init_digest=np.stack([digest(v) for v in ref["init"].values()]),
+                final_digest=np.stack([digest(v) for v in ref["final"].values()]),
+                keys=np.array(list(ref["final"].keys())))
+    for k in ("APDReadout.fTermNet2.seq.12.bias", "gru.bias_hh", "msg_nns.0.seq.0.weight"):
+        blob["final::" + k] = ref["final"][k].numpy()
+    np.savez_compressed(os.path.join(HERE, "golden_workflow.npz"), **blob)
+
+    # ---- generation loop -------------------------------------------------------------------------------------
+    gcfg = O.make_config(**GEN_CFG)
+    gconsts = RC.as_constants(dict(RC.constants_dict("cpu", gcfg, d, batch_size=100, epochs=GEN_TRAIN_STEPS),
+                                   init_lr=2e-3))
+    WF, GG = RC.load("reference", gconsts)
+    torch.manual_seed(GEN_SEED)
+    wf = WF.Workflow(constants=gconsts)                      # the unmodified training path once more, as the trainer
+    wf.train_dataloader = wf.get_dataloader(wf.train_h5_path, "training set")
+    start, end = wf.define_model_and_optimizer()
+    for epoch in range(start, end):
+        wf.current_epoch = epoch
+        last = float(wf.train_epoch())
+    print("small model trained to loss", last)
+    model = wf.model.eval()
+    weights = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    draw_seed = 0
+    while True:
+        with torch.no_grad():
+            ref_g = run_generator(lambda m, b, draw: GG.GraphGenerator(model=m, batch_size=b), model, gconsts, draw_seed)
+        if ref_g["margin"] > 2e-5:
+            break
+        draw_seed += 1                                       # (a draw within 2e-5 of a CDF boundary: another stream)
+    with torch.no_grad():
+        mine_g = run_generator(lambda m, b, draw: CO.GeneratorOracle(m, b, gconsts, draw), model, gconsts, draw_seed)
+    for k in ("n_generated", "rounds"):
+        assert ref_g[k] == mine_g[k], (k, ref_g[k], mine_g[k])
+    for k in ("nodes", "edges", "n_nodes", "terminated", "likelihoods"):
+        assert np.array_equal(ref_g[k], mine_g[k]), k
+    print("GraphGenerator.build_graphs: restatement == unmodified;  generated", ref_g["n_generated"], "graphs in",
+          ref_g["rounds"], "rounds, closest draw to a CDF boundary", ref_g["margin"], "(draw seed", draw_seed, ")",
+          " node counts", np.bincount(ref_g["n_nodes"][:ref_g["n_generated"]].astype(int)),
+          " properly terminated", int(ref_g["terminated"].sum()))
+    blob = dict(gen_seed=GEN_SEED, draw_seed=draw_seed, batch=GEN_BATCH, n_generated=ref_g["n_generated"],
+                rounds=ref_g["rounds"], margin=ref_g["margin"], nodes=ref_g["nodes"].astype(np.int8),
+                edges=ref_g["edges"].astype(np.int8), n_nodes=ref_g["n_nodes"], terminated=ref_g["terminated"],
+                likelihoods=ref_g["likelihoods"], cfg_keys=np.array(list(GEN_CFG)), cfg_vals=np.array(list(GEN_CFG.values())))
+    for k, v in weights.items():
+        blob["w::" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "golden_generator.npz"), **blob)
+    shutil.rmtree(d, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

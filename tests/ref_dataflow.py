@@ -55,13 +55,14 @@ def compact(nodes: np.ndarray, edges: np.ndarray, nodedup: bool = False) -> Dict
       out_perm [U], src_off [R+1]              source compact row -> its message rows (by type)"""
     B, N, Fn = nodes.shape
     Fe = edges.shape[3]
-    adj = edges.sum(3) != 0
-    ones = (edges == 1).sum(3)
-    zeros = (edges == 0).sum(3)
-    err = int(np.any(adj & ~((ones == 1) & (zeros == Fe - 1))))
-    etype = np.where(adj, edges.argmax(3), -1).astype(np.int8)          # [B,N,N]
-    rowcnt = adj.sum(2).reshape(-1)                                      # incoming per dst slot
-    colcnt = adj.sum(1).reshape(-1)                                      # outgoing per src slot
+    # an edge = a SET entry of the [B,N,N,Fe] tensor: a cell with several bond types set (the generation loop's dummy
+    # graph, GraphGenerator.py:133, 424-427) is that many parallel edges, which is what the reference's masked sum over
+    # the bond types computes (gnn/mpnn.py:286-294); entries other than 0 / 1 are outside the contract (err bit 0),
+    # several types on a pair are flagged (bit 3: fine for GGNN, refused by AttentionGGNN)
+    bonds = edges == 1
+    err = int(np.any((edges != 0) & ~bonds)) | (8 if np.any(bonds.sum(3) > 1) else 0)
+    rowcnt = bonds.sum((2, 3)).reshape(-1)                               # incoming per dst slot
+    colcnt = bonds.sum((1, 3)).reshape(-1)                               # outgoing per src slot
     active = (nodes != 0).any(2).reshape(-1) | (rowcnt > 0) | (colcnt > 0)
     if nodedup:
         active = np.ones(B * N, dtype=bool)
@@ -70,9 +71,9 @@ def compact(nodes: np.ndarray, edges: np.ndarray, nodedup: bool = False) -> Dict
     cidx = np.full(B * N, S, dtype=np.int32)
     cidx[active] = np.arange(S, dtype=np.int32)
     slot_of = np.nonzero(active)[0].astype(np.int32)
-    eb, ei, ej = np.nonzero(adj)                                         # dst-major order
+    eb, ei, ej, et = np.nonzero(bonds)                                   # dst-major order (row-major nonzero)
     E = eb.size
-    et = etype[eb, ei, ej].astype(np.int64)
+    et = et.astype(np.int64)
     dst_c = cidx[eb * N + ei]
     src_slot = eb * N + ej
     key = et * (B * N) + src_slot
@@ -301,7 +302,7 @@ def forward(P, cfg, nodes, edges, keep=False, model="GGNN"):
     H, M, G = cfg["hidden_node_features"], cfg["message_size"], cfg["gather_width"]
     Fe, A, C = cfg["n_edge_features"], cfg["len_f_add_per_node"], cfg["len_f_conn_per_node"]
     g = compact(nodes.numpy(), edges.numpy())
-    assert g["err"] == 0
+    assert g["err"] & ~(0 if attn else 8) == 0          # (several bond types on a pair: GGNN only)
     S, E, U = g["S"], g["E"], g["U"]
     T = {k: torch.from_numpy(v) for k, v in g.items() if isinstance(v, np.ndarray)}
     R = S + 1

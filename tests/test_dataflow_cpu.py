@@ -100,6 +100,30 @@ def test_compact_invariants(golden_dir):
     for c in range(S):
         rows = g["out_perm"][g["src_off"][c]:g["src_off"][c + 1]]
         assert np.all(g["u_src"][rows] == c) and np.all(np.diff(rows) > 0)
+    multi = edges[:4].copy()
+    multi[0, 0, 1, :] = [1, 1, 0]                       # two bond types on one pair: flagged (bit 3), parallel edges
+    assert D.compact(nodes[:4], multi)["err"] == 8
     bad = edges[:4].copy()
-    bad[0, 0, 1, :] = [1, 1, 0]
-    assert D.compact(nodes[:4], bad)["err"] == 1
+    bad[0, 0, 1, 0] = 2                                 # an entry that is not 0 / 1: outside the contract (bit 0)
+    assert D.compact(nodes[:4], bad)["err"] & 1
+
+
+def test_pairs_with_several_bond_types_are_parallel_edges_like_the_reference():
+    """The generation loop's dummy graph 0 accumulates bonds of several types on one atom pair
+    (GraphGenerator.py:133, 424-427: it samples and applies actions for ever and is never reset); the reference then sums
+    the per-type messages of the pair (gnn/mpnn.py:286-294).  The compact dataflow treats every set bond-type entry as
+    an edge of its own: forward and backward equal the oracle's in fp64, self-loops and all-ones feature rows included."""
+    cfg = O.make_config(**TINY)
+    n8, e8, a8 = tiny_inputs()
+    N = n8.shape[1]
+    n8[0] = 1                                                # the dummy graph: all-ones feature rows,
+    e8[0] = 0
+    e8[0, 0, 0, 0] = 1                                       # a self-loop,
+    e8[0, 0, 3, :] = [1, 0, 1]; e8[0, 3, 0, :] = [1, 0, 1]   # two bond types on one pair,
+    e8[0, 2, 0, :] = 1                                       # all three, one direction only
+    b = int(np.argmax(e8.reshape(e8.shape[0], -1).sum(1) * (np.arange(e8.shape[0]) > 0)))
+    i, j = [int(x[0]) for x in np.nonzero(e8[b].sum(2))]     # (and in another graph, on top of an existing bond)
+    e8[b, i, j, :] = 1; e8[b, j, i, :] = 1
+    g = D.compact(n8, e8)
+    assert g["err"] == 8 and g["E"] == int((e8 == 1).sum())
+    _check(cfg, n8, e8, a8, seed=7)

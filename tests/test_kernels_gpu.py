@@ -98,10 +98,40 @@ def test_compact_pass0_shortcut_is_switched_off_for_non_binary_features():
     assert g.D0 == 0 and g.cmat is None
 
 
-def test_compact_rejects_non_onehot_edges():
+def multi_bond_inputs(n8, e8):
+    """What GraphGenerator.build_graphs feeds the model in slot 0 (GraphGenerator.py:133, 424-427): all-ones feature
+    rows, a self-loop, atom pairs with several bond types set at once — plus one such pair in another graph."""
+    n8, e8 = n8.copy(), e8.copy()
+    n8[0] = 1
+    e8[0] = 0
+    e8[0, 0, 0, 0] = 1
+    e8[0, 0, 3, :] = [1, 0, 1]; e8[0, 3, 0, :] = [1, 0, 1]
+    e8[0, 2, 0, :] = 1
+    b = int(np.argmax(e8.reshape(e8.shape[0], -1).sum(1) * (np.arange(e8.shape[0]) > 0)))
+    i, j = [int(x[0]) for x in np.nonzero(e8[b].sum(2))]
+    e8[b, i, j, :] = 1; e8[b, j, i, :] = 1
+    return n8, e8
+
+
+def test_compact_pairs_with_several_bond_types_are_parallel_edges():
+    """Every set bond-type entry is an edge of its own (what the reference's masked sum over the bond types computes,
+    gnn/mpnn.py:286-294): the index arrays of such inputs, bit-exact against the numpy model; values other than 0 / 1
+    are still refused."""
     n8, e8, _ = tiny_inputs()
-    e8[5, 0, 1, :] = [1, 1, 0]
-    with pytest.raises(ValueError):
+    _compact_case(*multi_bond_inputs(n8, e8))
+    _compact_case(*multi_bond_inputs(n8, e8), nodedup=True)
+    for shape, B in (("gdb13", 100), ("chembl", 12)):
+        a, b, _ = synthetic.make_batch(B, **synthetic.SHAPES[shape], seed=9)
+        rng = np.random.default_rng(1)
+        for _ in range(3 * B):                               # random extra bond types on existing bonds
+            g = rng.integers(0, B)
+            ii, jj = np.nonzero(b[g].sum(2))
+            if len(ii):
+                k = rng.integers(0, len(ii))
+                b[g, ii[k], jj[k], rng.integers(0, b.shape[3])] = 1
+        _compact_case(a, b, H=100)
+    e8[5, 0, 1, 0] = 2
+    with pytest.raises(ValueError, match="0 or 1"):
         ops.compact(torch.from_numpy(n8).float().to(DEV), torch.from_numpy(e8).float().to(DEV), 16)
 
 

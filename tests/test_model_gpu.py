@@ -743,3 +743,34 @@ def test_four_bond_types_aromatic_preprocessing(model_name):
     num = sum(float((grads[k].double() - g32[k].double()).pow(2).sum()) for k in grads)
     den = sum(float(g32[k].double().pow(2).sum()) for k in grads)
     assert (num / den) ** 0.5 < 2e-3, (num / den) ** 0.5
+
+
+def test_multi_bond_pairs_match_the_reference_and_attggnn_refuses_them():
+    """The dummy graph of the reference's generation loop (GraphGenerator.py:133, 424-427) carries several bond types on
+    one atom pair; the reference's GGNN sums their messages (gnn/mpnn.py:286-294).  HIP GGNN: logits, loss and every
+    gradient against the oracle on such a batch; AttentionGGNN, whose neighbour softmax is not defined per bond type
+    here, raises instead of computing something else."""
+    from tests.test_kernels_gpu import multi_bond_inputs
+    n8, e8, a8 = tiny_inputs()
+    n8, e8 = multi_bond_inputs(n8, e8)
+    cfg = O.make_config(**TINY)
+    P = O.init_params(cfg, seed=5)
+    model = make_model(cfg, P)
+    out, loss, grads = hip_forward_backward(model, n8, e8, a8)
+    o_ref, l_ref, g_ref = O.forward_backward(P, cfg, *(torch.from_numpy(x).float() for x in (n8, e8, a8)))
+    live = np.setdiff1d(np.arange(n8.shape[0]), fully_masked_rows(e8))
+    assert rel(out[live], o_ref[live]) < TOL and abs(loss - float(l_ref)) < 1e-3 * abs(float(l_ref))
+    for k in g_ref:
+        assert rel(grads[k], g_ref[k]) < 2e-3, k
+    with torch.no_grad():                                       # the inference paths: blocking and host-sync-free
+        nodes, edges = to_dev(n8, e8)
+        model.eval()
+        ref = model(nodes, edges)
+        model.sync_free = True
+        assert torch.equal(model(nodes, edges), ref) and model.last_bounded_error() == 0
+    from tests.golden.spec import TINY_ATT
+    acfg = dict(O.make_config(**TINY_ATT), device="cuda")
+    att = mpnn.AttentionGGNN(O.as_constants(acfg))
+    att.load_state_dict(O.init_params(acfg, seed=5, model="AttGGNN"))
+    with pytest.raises(ValueError, match="several bond types"):
+        att.to("cuda")(nodes, edges)
