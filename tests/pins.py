@@ -91,6 +91,9 @@ def signs_from_hip(dims, graph, ws, out, attn: bool) -> Signs:
     return s
 
 
+TIE_TOL = 1e-5          # |pre-activation| below which two fp32 evaluations may legitimately disagree on x > 0
+
+
 class OraclePins:
     """The callable to install as `oracle.ggnn_oracle.SELU_BRANCH_HOOK` around ONE oracle forward.
 
@@ -142,10 +145,15 @@ class OraclePins:
         self.calls: Dict[tuple, int] = {}
         self.total = 0
         self.flipped = 0
+        self.max_flipped_abs = 0.0         # largest |pre-activation| (the ORACLE's own) the pin decided differently
 
     def _account(self, mask, x):
         self.total += mask.numel()
-        self.flipped += int((mask != (x > 0)).sum())
+        moved = mask != (x > 0)
+        n = int(moved.sum())
+        self.flipped += n
+        if n:
+            self.max_flipped_abs = max(self.max_flipped_abs, float(x.detach()[moved].abs().max()))
         return mask
 
     def __call__(self, prefix: str, layer: int, x: torch.Tensor):
@@ -240,6 +248,10 @@ def oracle_pinned(O, P, cfg, nodes, edges, target, signs: Signs, g: dict, model:
     finally:
         O.SELU_BRANCH_HOOK = None
         O.MASK_QUANTUM_HOOK = None
+    # a pin may only resolve TIES at the kink: every activation whose branch it changed must be a rounding-noise
+    # distance from 0 in the oracle's own evaluation (pre-activations are O(1), two correct fp32 evaluations differ
+    # by ~1e-6); a wrong index map, or an implementation error that moves a real activation across 0, fails here
+    assert pins.max_flipped_abs < TIE_TOL, (pins.max_flipped_abs, pins.flipped, pins.total)
     return out, loss, grads, pins.flipped, pins.total
 
 

@@ -50,6 +50,10 @@ def test_hip_models_match_reference_outputs(golden_dir, name):
         from tests import pins
         pins.assert_masked_rows_are_quantum_ties(O, model, cfg, P, g["nodes"], g["edges"], out, kind)
     assert abs(float(loss) - float(g["loss"])) < 1e-3 * abs(float(g["loss"]))
+    # ... and on the graphs that are not fully masked the reference's own logits give the same loss at 1e-4
+    tl = lambda x: torch.as_tensor(np.asarray(x)).float()[torch.from_numpy(live)]
+    ll = float(O.kl_loss(tl(g["logits"]), tl(g["apds"])))
+    assert abs(float(O.kl_loss(tl(out), tl(g["apds"]))) - ll) < TOL * abs(ll)
     num = den = 0.0
     worst = (0.0, "")
     for k, p in model.named_parameters():
@@ -58,5 +62,7 @@ def test_hip_models_match_reference_outputs(golden_dir, name):
         den += float(np.sum(ref[2:] ** 2))
         scale = max(np.max(np.abs(ref[2:])), 1e-12)
         worst = max(worst, (float(np.max(np.abs(d[2:] - ref[2:])) / scale), k))
+    print(f"\n[unpinned, {name}] gradient digests vs the reference's: global L2 {(num / den) ** 0.5:.2e}, worst tensor "
+          f"{worst[0]:.2e} ({worst[1]})")
     assert (num / den) ** 0.5 < 5e-3, (num / den) ** 0.5
-    assert worst[0] < 5e-2, worst
+    assert worst[0] < 2e-2, worst

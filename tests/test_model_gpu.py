@@ -49,6 +49,14 @@ def fully_masked_rows(e8):
     return np.nonzero(~e8.reshape(e8.shape[0], -1).any(1))[0]
 
 
+def live_loss(logits, apds, live):
+    """Workflow.loss (Workflow.py:850-858) over the graphs that are not fully masked: on those rows the reference's
+    golden logits and the HIP logits must give the same loss at 1e-4 (the all-rows loss also carries the masked
+    graphs' energy quanta, for which the reference's own fp32 and fp64 runs differ by 3e-3)."""
+    t = lambda x: torch.as_tensor(np.asarray(x)).float()
+    return float(O.kl_loss(t(logits)[live], t(apds)[live]))
+
+
 def hip_forward_backward(model, n8, e8, a8):
     nodes, edges, tgt = to_dev(n8, e8, a8)
     model.train()
@@ -116,6 +124,8 @@ def test_golden_tiny_logits_loss_grads(golden_dir):
     assert rel(out[masked], g["logits"][masked]) < 5e-3        # the reference's own fp32 run, un-pinned ...
     pins.assert_masked_rows_are_quantum_ties(O, model, cfg, P, g["nodes"], g["edges"], out)   # ... and pinned: 1e-4
     assert abs(loss - float(g["loss"])) < 1e-3 * abs(float(g["loss"]))
+    ll = live_loss(g["logits"], g["apds"], live)
+    assert abs(live_loss(out, g["apds"], live) - ll) < TOL * abs(ll)      # the reference's own logits, live rows: 1e-4
     # gradients: the masked graphs' quantisation noise feeds every weight, so compare against the
     # reference with the same 1e-4 bar where it holds and report the worst tensor
     worst = max((rel(grads[k], g["grad." + k]), k) for k in grads)
@@ -157,6 +167,8 @@ def test_golden_gdb13_default_dims(golden_dir):
     assert rel(out[masked], g["logits"][masked]) < 5e-3
     pins.assert_masked_rows_are_quantum_ties(O, model, cfg, P, g["nodes"], g["edges"], out)
     assert abs(loss - float(g["loss"])) < 1e-3 * abs(float(g["loss"]))
+    ll = live_loss(g["logits"], g["apds"], live)
+    assert abs(live_loss(out, g["apds"], live) - ll) < TOL * abs(ll)
     for k, v in grads.items():
         d, ref = digest(v), g["gdigest." + k]
         scale = max(np.max(np.abs(ref[2:])), 1e-12)
@@ -181,18 +193,28 @@ def test_fixture_batches_vs_oracle(golden_dir, split, rows):
     assert rel(out[masked], o32[masked]) < 5e-3
     pins.assert_masked_rows_are_quantum_ties(O, model, cfg, P, n8, e8, out)
     assert abs(loss - float(l32)) < 1e-3 * abs(float(l32))
+    ll = live_loss(o32, a8, live)
+    assert abs(live_loss(out, a8, live) - ll) < TOL * abs(ll)
     # batches with fully-masked graphs: a 1/16 energy-quantisation flip or a SELU sign flip moves
     # single tensors by ~1e-2 of their max in either implementation -> global L2 + gross-error cap
     num = sum(float((grads[k].double() - g32[k].double()).pow(2).sum()) for k in grads)
     den = sum(float(g32[k].double().pow(2).sum()) for k in grads)
-    assert (num / den) ** 0.5 < 5e-3, (num / den) ** 0.5
     worst = max((rel(grads[k], g32[k]), k) for k in grads)
-    assert worst[0] < 5e-2, worst
+    print(f"\n[unpinned, shipped {split} rows] gradients vs the fp32 oracle: global L2 {(num / den) ** 0.5:.2e}, worst "
+          f"tensor {worst[0]:.2e} ({worst[1]})")
+    assert (num / den) ** 0.5 < 5e-3, (num / den) ** 0.5
+    assert worst[0] < 3e-2, worst
 
 
 def _live_only(n8, e8, a8):
     keep = np.setdiff1d(np.arange(n8.shape[0]), fully_masked_rows(e8))
     return n8[keep], e8[keep], a8[keep]
+
+
+#: cap on the worst single gradient tensor (max |d| / max |ref| against fp64) WITHOUT the SELU-branch pin, per shape:
+#: a few times what the runs of round 4 printed (the fp32 oracle's own worst tensor is printed beside it and is of
+#: the same size: one activation on the other side of the kink moves a 3-output stack by ~1e-2)
+UNPINNED_WORST = {"gdb13": 2e-2, "zinc": 2e-2}
 
 
 def _oracle_both(cfg, P, n8, e8, a8):
@@ -212,8 +234,9 @@ def test_full_size_parity_vs_fp32_and_fp64_oracle(shape, B, over):
     gradients are NOT reproducible to 1e-4 at this size — SELU' is discontinuous at 0 and a few of
     the ~1e7 activations per step round to opposite sides of 0 in fp32 vs fp64 (measured: 4 sign
     flips at B=300 move the fp32 oracle's gradients by up to 5.6e-3 of max|g| from its fp64 run).
-    So the raw gradient check is: HIP is as close to the exact (fp64) gradient as the reference's
-    fp32 arithmetic is, within 3x; the branch-pinned test below is the strict one."""
+    So the raw gradient check is an absolute one — global relative L2 distance from the exact (fp64)
+    gradient below 5e-3 for HIP and for the reference's fp32 arithmetic alike, both printed — and a
+    per-shape cap on the worst single tensor; the branch-pinned tests below are the strict ones."""
     sh = synthetic.SHAPES[shape]
     cfg = O.shaped_config(sh["n_atom_types"], sh["n_formal_charge"], sh["max_n_nodes"], **over)
     P = O.init_params(cfg, seed=4)
@@ -234,9 +257,12 @@ def test_full_size_parity_vs_fp32_and_fp64_oracle(shape, B, over):
     # the kink — it changes with every change of summation order, in the reference as in here; the
     # bound is the absolute one, the strict statement is the branch-pinned test below)
     hip_l2, ref_l2 = l2(grads), l2(g32)
-    assert hip_l2 < 5e-3 and ref_l2 < 5e-3, (hip_l2, ref_l2)
     worst = max((rel(grads[k], g64[k]), k) for k in g64)
-    assert worst[0] < 5e-2, worst
+    worst_ref = max((rel(g32[k], g64[k]), k) for k in g64)
+    print(f"\n[unpinned, {shape} B={B}] global L2 vs fp64: HIP {hip_l2:.2e}, fp32 oracle {ref_l2:.2e}; worst tensor: "
+          f"HIP {worst[0]:.2e} ({worst[1]}), fp32 oracle {worst_ref[0]:.2e} ({worst_ref[1]})")
+    assert hip_l2 < 5e-3 and ref_l2 < 5e-3, (hip_l2, ref_l2)
+    assert worst[0] < UNPINNED_WORST[shape], worst
 
 
 @pytest.mark.parametrize("shape,B,over", [

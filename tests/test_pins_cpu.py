@@ -56,7 +56,8 @@ def test_pins_gdb13_shape(model):
 
 
 def test_a_wrong_mapping_is_detected():
-    """Sanity of the detector itself: shuffled message rows must flip many activations."""
+    """Sanity of the detectors themselves: shuffled message rows flip many activations (> 1e-3 of all), and — since
+    round 4 — oracle_pinned itself refuses a pin that moves anything but a tie at the kink (|pre-activation| < 1e-5)."""
     cfg = O.make_config(**TINY)
     n8, e8, a8 = _live(*tiny_inputs())
     P = O.init_params(cfg, seed=3)
@@ -65,7 +66,13 @@ def test_a_wrong_mapping_is_detected():
     signs = pins.signs_from_dataflow(tape)
     g = dict(tape["g"])
     g["in_perm"] = np.roll(g["in_perm"], 1)
-    _, _, _, flipped, total = pins.oracle_pinned(O, P, cfg, nodes, edges, tgt, signs, g)
+    with pytest.raises(AssertionError):                       # the pin would move real activations across 0
+        pins.oracle_pinned(O, P, cfg, nodes, edges, tgt, signs, g)
+    old, pins.TIE_TOL = pins.TIE_TOL, float("inf")
+    try:
+        _, _, _, flipped, total = pins.oracle_pinned(O, P, cfg, nodes, edges, tgt, signs, g)
+    finally:
+        pins.TIE_TOL = old
     assert flipped > 1e-3 * total
 
 
