@@ -477,8 +477,9 @@ def main():
             "ms_per_step_without_exchange": round(t_none, 3),
             "exposed_ms_overlapped": round(t_overlap - t_none, 3),
             "exposed_ms_after_backward": round(t_serial - t_none, 3),
-            "method": f"{k} timed steps each (max over ranks): product path; GI_DP_OVERLAP-off "
-                      "equivalent; exchange skipped"}
+            "method": f"{k} timed steps each (max over ranks): product path (early exchange of the readout "
+                      "tail overlapped with the message passes' backward); DataParallel(overlap=False): one "
+                      "all-reduce after the backward; exchange skipped"}
         trainer.broadcast_parameters()                         # re-align the ranks for what follows
 
     # ---- roofline leg: per-launch HIP-event timing of the GEMM family + seg_sum -----------------

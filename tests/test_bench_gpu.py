@@ -36,11 +36,11 @@ def _run_bench(world: int, backend: str, extra=()):
     return json.loads(lines[0])
 
 
-def _check(d, world: int, backend: str):
+def _check(d, world: int, backend: str, batch: int = 1000):
     assert d["n_gpus"] == world and d["steps"] == 3 and d["warmup"] == 1
     assert d["scaling"] == "weak" and d["unit"] == "graphs/s" and d["higher_is_better"] is True
-    assert d["config"]["global_batch"] == 1000 * world and d["config"]["parallelism"] == f"dp{world}"
-    assert d["value"] > 0 and abs(d["value"] - 1000 * world * 3 / (d["ms_per_step"] * 3e-3)) < 0.01 * d["value"]
+    assert d["config"]["global_batch"] == batch * world and d["config"]["parallelism"] == f"dp{world}"
+    assert d["value"] > 0 and abs(d["value"] - batch * world * 3 / (d["ms_per_step"] * 3e-3)) < 0.01 * d["value"]
     loss = d["config"]["loss"]
     assert loss == loss and 0 < loss < 100                   # finite (the run aborts on a diverged checksum)
     ar = d["allreduce"]
@@ -59,6 +59,22 @@ def test_bench_two_ranks_gloo_sharing_the_gpu():
     assert "smoke test" in d["config"]["backend"]
 
 
+def test_bench_eight_ranks_gloo_sharing_the_gpu():
+    """The world size the driver's scaling run ends at (`bench.py --gpus 8`), on ONE device over gloo with a small
+    per-rank batch: eight ranks through the rendezvous, the weight broadcast, the overlapped two-call backward with
+    the early exchange of the readout tail, FusedAdam on every rank and the cross-rank weight checksum (a diverged
+    checksum aborts the run) — so that the first real 8-GPU execution (backend nccl = RCCL, one rank per device) only
+    swaps the transport.  Not a measurement."""
+    d = _run_bench(8, "gloo", extra=("--batch", "96"))
+    _check(d, 8, "gloo", batch=96)
+    assert sorted(d["allreduce"]["ranks"]) == sorted(set(d["allreduce"]["ranks"])) or len(d["allreduce"]["ranks"]) == 8
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL, one rank per device)")
 def test_bench_two_ranks_rccl():
     _check(_run_bench(2, "nccl"), 2, "nccl")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 8, reason="needs 8 GPUs (RCCL over xGMI, one rank per device)")
+def test_bench_eight_ranks_rccl():
+    _check(_run_bench(8, "nccl"), 8, "nccl")

@@ -280,3 +280,25 @@ def test_hdf_roundtrip_through_libhdf5_without_the_reference_checkout(tmp_path):
     assert np.array_equal(ds.edges[70:77], e[70:77]) and torch.equal(ds[3][0], torch.from_numpy(n[3]).float())
     got = np.concatenate([b[2].numpy() for b in BlockStreamLoader(ds.source, 10, block_size=30, device=None, seed=0)])
     assert sorted(map(bytes, got)) == sorted(map(bytes, a))
+
+
+def test_eight_ranks_stay_in_lock_step_and_read_disjoint_eighths():
+    """The world size of the scaling run: every rank yields the same minibatch sizes per block without talking to
+    the others, the eight slices of a block are disjoint, and together they cover it up to the rows % 8 tail."""
+    rows = 5003
+    n = np.zeros((rows, 2, 2), np.int8); e = np.zeros((rows, 2, 2, 1), np.int8); a = np.ones((rows, 5), np.int8)
+    ids = np.arange(rows)
+    a[:, 0] = ids % 100 + 1; a[:, 1] = (ids // 100) % 100 + 1; a[:, 2] = ids // 10000 + 1
+    lds = [BlockStreamLoader(ArraySource(n, e, a), 50, block_size=2000, rank=r, world_size=8, device=None, seed=7)
+           for r in range(8)]
+    for epoch in (0, 1, 2):
+        per_rank = []
+        for ld in lds:
+            ld.set_epoch(epoch)
+            bs = list(ld)
+            got = np.concatenate([(b[2][:, 0].numpy().astype(np.int64) - 1) + 100 * (b[2][:, 1].numpy().astype(np.int64) - 1)
+                                  + 10000 * (b[2][:, 2].numpy().astype(np.int64) - 1) for b in bs])
+            per_rank.append(([b[2].shape[0] for b in bs], got))
+        assert all(p[0] == per_rank[0][0] for p in per_rank) and len(per_rank[0][0]) == len(lds[0])
+        allrows = np.concatenate([p[1] for p in per_rank])
+        assert len(allrows) == len(set(allrows.tolist())) == 8 * (2000 // 8) * 2 + 8 * (1003 // 8)
