@@ -36,6 +36,7 @@
 #include "gi_common.h"
 
 #include "gi_mfma.h"
+#include "gi_x2.h"
 #include <type_traits>
 
 
@@ -420,6 +421,7 @@ __global__ __launch_bounds__(256) void gi_gemm_tiles_kernel(const GemmBatch b) {
         float* const Cp = t.Cp;
         const bool need_act = (flags & (GI_EPI_DSELU | GI_EPI_MULACT)) != 0;
         const bool need_c = (flags & GI_EPI_ACCUM) != 0;
+        float amax = 0.f;                                // max |stored value| (gi_gemm_params.c_amax)
         auto load_rows = [&](int row0, int colc, int c, float (&av)[4], float (&cv)[4]) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -455,15 +457,18 @@ __global__ __launch_bounds__(256) void gi_gemm_tiles_kernel(const GemmBatch b) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = row0 + 8 * c + r;
-                        float* dst = (col_ok & (row < m_end))
-                            ? (float*)((char*)Cp + ((unsigned)row * (unsigned)p.ldc + (unsigned)col) * 4u)
-                            : gi_store_sink + tid;
+                        const bool ok = col_ok & (row < m_end);
+                        float* dst = ok ? (float*)((char*)Cp + ((unsigned)row * (unsigned)p.ldc + (unsigned)col) * 4u)
+                                        : gi_store_sink + tid;
                         *dst = v[r];
+                        amax = fmaxf(amax, ok ? fabsf(v[r]) : 0.f);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
+        // the fp16x2 launches that read this tensor next scale it by its largest magnitude (gi_x2.h)
+        if (p.c_amax) gx_amax_publish(amax, p.c_amax);
     };
     auto epi_of = [&](const Tile& t) __attribute__((always_inline)) {
         GemmEpi e;

@@ -39,6 +39,7 @@
 
 #include "gi_common.h"
 #include "gi_mfma.h"
+#include "gi_x2.h"
 
 typedef __bf16 gp_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 gp_bf16x2 __attribute__((ext_vector_type(2)));
@@ -64,8 +65,9 @@ __device__ unsigned long long* gp_trace_buf;
 constexpr int GP_BM = 128, GP_BN = 256, GP_BK = 32;
 constexpr int GP_CHA = GP_BM * 16, GP_CHB = GP_BN * 16;          // bytes of one k chunk (8 bf16) of all rows
 constexpr int GP_PLA = 4 * GP_CHA, GP_PLB = 4 * GP_CHB;          // one plane of a 32-deep tile: 8 KB / 16 KB
-constexpr int GP_A = 3 * GP_PLA, GP_B = 3 * GP_PLB;              // 24 KB / 48 KB
+constexpr int GP_A = 3 * GP_PLA, GP_B = 3 * GP_PLB;              // 24 KB / 48 KB (three bf16 planes)
 constexpr int GP_STAGE = GP_A + GP_B;                            // 72 KB
+constexpr int GP_STAGE_X2 = 2 * (GP_PLA + GP_PLB);               // 48 KB (two fp16 planes, GI_GEMM_X2)
 
 __device__ __forceinline__ unsigned gp_lds_a(int kc, int row) { return kc * GP_CHA + ((row * 16 + kc * 32) & (GP_CHA - 1)); }
 __device__ __forceinline__ unsigned gp_lds_b(int kc, int row) { return kc * GP_CHB + ((row * 16 + kc * 32) & (GP_CHB - 1)); }
@@ -102,8 +104,12 @@ struct GpBatch {
 
 // EPI: 0 = epilogue from the run-time flags, 1 = bias + SELU (forward), 2 = * selu'(act) (dgrad), 3 = plain store
 // (weight-gradient slabs).
-template <bool AM, bool BMJ, int EPI>
+// X2 (GI_GEMM_X2): operands as two scaled fp16 values each (gi_x2.h) — two LDS planes, three f16 MFMA products per
+// fp32 product (24 MFMAs per wave and k tile in 6 groups instead of 48 in 12), scales from a_amax / b_amax.
+template <bool AM, bool BMJ, int EPI, bool X2>
 __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, unsigned char* const smem) {
+    constexpr int NP = X2 ? 2 : 3;
+    constexpr int A_BYTES = NP * GP_PLA, STAGE = NP * (GP_PLA + GP_PLB);
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3, l31 = lane & 31, lhi = lane >> 5;
 #ifdef GI_B3P_TRACE
@@ -146,6 +152,8 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
     }
     const int nk = ke > kb ? (ke - kb + GP_BK - 1) / GP_BK : 0;
     const int n_full = ke > kb ? (ke - kb) / GP_BK : 0;
+    float sa = 1.f, ia = 1.f, sb = 1.f, ib = 1.f;               // fp16x2: per-tensor power-of-two scales
+    if (X2) { gx_scale(gx_amax_read(p.a_amax), sa, ia); gx_scale(gx_amax_read(p.b_amax), sb, ib); }
 
     // ---- staging coordinates -----------------------------------------------------------------------
     // contig operand: 8 float4 per 32-deep row -> c8 = tid & 7, rows (tid >> 3) + 64 i  (A: 2, B: 4 float4 per thread)
@@ -173,13 +181,13 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
         for (int i = 0; i < 4; ++i) {
             const int rl = crow + 64 * i;
             b_off[i] = (unsigned)min(n0 + rl, p.N - 1) * (unsigned)p.ldb * 4u;
-            b_w[i] = GP_A + gp_lds_b(c8 >> 1, rl) + 8 * (c8 & 1);
+            b_w[i] = A_BYTES + gp_lds_b(c8 >> 1, rl) + 8 * (c8 & 1);
         }
     } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             b_off[i] = 4u * (unsigned)min(n0 + 128 * halfw + lane + 64 * i, b_cols - 1);
-            b_w[i] = GP_A + gp_lds_b(kcw, 128 * halfw + lane + 64 * i);
+            b_w[i] = A_BYTES + gp_lds_b(kcw, 128 * halfw + lane + 64 * i);
         }
     }
     // the ones column of a major B (bias gradient): which of the lane's two columns, if any
@@ -243,7 +251,7 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
     unsigned q0[4], q1[4], q2[4];                  // planes of the 8-byte / 16-byte piece being assembled
     auto stage_chunk = [&](auto st, int kt, int c) __attribute__((always_inline)) {
         constexpr bool ST = decltype(st)::value;
-        unsigned char* S = smem + (kt & 1) * GP_STAGE;
+        unsigned char* S = smem + (kt & 1) * STAGE;
         const int k0 = kb + kt * GP_BK;
         const bool contig_chunk = (!AM && !BMJ) || (!AM && c < 4);
         if (contig_chunk) {
@@ -254,14 +262,15 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
                 v = gi_fix4(v, k0 + 4 * c8, isA ? a_cmax : b_cmax, p.K, true);
                 if (isA) ra[u] = v; else rb[u - 2] = v;
             }
-            gp_split2(h ? v.z : v.x, h ? v.w : v.y, q0[h], q1[h], q2[h]);
+            if (X2) gx_split2(h ? v.z : v.x, h ? v.w : v.y, isA ? sa : sb, q0[h], q1[h]);
+            else gp_split2(h ? v.z : v.x, h ? v.w : v.y, q0[h], q1[h], q2[h]);
             if (h == 1) {
                 const unsigned w = isA ? a_w[u] : b_w[u - 2];
                 const int pb = isA ? GP_PLA : GP_PLB;
-                gp_u32x2 w0 = {q0[0], q0[1]}, w1 = {q1[0], q1[1]}, w2 = {q2[0], q2[1]};
+                gp_u32x2 w0 = {q0[0], q0[1]}, w1 = {q1[0], q1[1]};
                 *reinterpret_cast<gp_u32x2*>(S + w) = w0;
                 *reinterpret_cast<gp_u32x2*>(S + pb + w) = w1;
-                *reinterpret_cast<gp_u32x2*>(S + 2 * pb + w) = w2;
+                if (!X2) { gp_u32x2 w2 = {q2[0], q2[1]}; *reinterpret_cast<gp_u32x2*>(S + 2 * pb + w) = w2; }
             }
         } else {
             const int col = c >> 2, h = c & 3;     // 0: the A column (major A only), 1, 2: the B columns
@@ -277,14 +286,15 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
                     x[j] = v;
                 }
             }
-            gp_split2(x[2 * h], x[2 * h + 1], q0[h], q1[h], q2[h]);
+            if (X2) gx_split2(x[2 * h], x[2 * h + 1], isA ? sa : sb, q0[h], q1[h]);
+            else gp_split2(x[2 * h], x[2 * h + 1], q0[h], q1[h], q2[h]);
             if (h == 3) {
                 const unsigned w = isA ? a_w[0] : b_w[col - 1];
                 const int pb = isA ? GP_PLA : GP_PLB;
-                gp_u32x4 w0 = {q0[0], q0[1], q0[2], q0[3]}, w1 = {q1[0], q1[1], q1[2], q1[3]}, w2 = {q2[0], q2[1], q2[2], q2[3]};
+                gp_u32x4 w0 = {q0[0], q0[1], q0[2], q0[3]}, w1 = {q1[0], q1[1], q1[2], q1[3]};
                 *reinterpret_cast<gp_u32x4*>(S + w) = w0;
                 *reinterpret_cast<gp_u32x4*>(S + pb + w) = w1;
-                *reinterpret_cast<gp_u32x4*>(S + 2 * pb + w) = w2;
+                if (!X2) { gp_u32x4 w2 = {q2[0], q2[1], q2[2], q2[3]}; *reinterpret_cast<gp_u32x4*>(S + 2 * pb + w) = w2; }
             }
         }
     };
@@ -299,14 +309,14 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
 
     gp_bf16x8 af0[2][3], bf0[2][3], af1[2][3], bf1[2][3];       // fragments of the two 16-deep halves
     auto read_frags = [&](int kt, int s, gp_bf16x8 (&af)[2][3], gp_bf16x8 (&bf)[2][3]) __attribute__((always_inline)) {
-        const unsigned char* As = smem + (kt & 1) * GP_STAGE;
-        const unsigned char* Bs = As + GP_A;
+        const unsigned char* As = smem + (kt & 1) * STAGE;
+        const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const unsigned oa = gp_lds_a(2 * s + lhi, wm * 64 + t * 32 + l31);
             const unsigned ob = gp_lds_b(2 * s + lhi, wn * 64 + t * 32 + l31);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NP; ++pl) {
                 af[t][pl] = *reinterpret_cast<const gp_bf16x8*>(As + pl * GP_PLA + oa);
                 bf[t][pl] = *reinterpret_cast<const gp_bf16x8*>(Bs + pl * GP_PLB + ob);
             }
@@ -315,14 +325,18 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
     // one term of the six-product sum for the wave's four accumulators (smallest terms first)
     auto mfma4 = [&](const gp_bf16x8 (&af)[2][3], const gp_bf16x8 (&bf)[2][3], int term) __attribute__((always_inline)) {
         constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
-#if defined(GP_DBG) && (GP_DBG & 16)      // lab, TIMING ONLY: what three products instead of six would cost
-        if (term < 3) return;
-#endif
+        constexpr int XA[3] = {1, 0, 0}, XB[3] = {0, 1, 0};      // fp16x2: a2 b1 + a1 b2 + a1 b1
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][TA[term]], bf[u][TB[term]], acc[t][u], 0, 0, 0);
+            for (int u = 0; u < 2; ++u) {
+                if (X2)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gx_f16x8, af[t][XA[term]]),
+                                                                       __builtin_bit_cast(gx_f16x8, bf[u][XB[term]]),
+                                                                       acc[t][u], 0, 0, 0);
+                else
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][TA[term]], bf[u][TB[term]], acc[t][u], 0, 0, 0);
+            }
     };
 
     // ---- one iteration: the 12 groups of k tile kt ------------------------------------------------------------
@@ -331,16 +345,22 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
     auto iteration = [&](auto first_c, auto stage_c, auto load_c, auto st, int kt) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_c)::value, STAGE = decltype(stage_c)::value, LOAD = decltype(load_c)::value;
         GP_STAMP();
+        constexpr int NT = X2 ? 3 : 6;                   // products per 16-deep half; one group of 4 MFMAs per product
+        constexpr int SKEW = X2 ? 1 : 2;                 // groups of the previous tile that run first (LDS latency cover)
+        constexpr int CPG = 12 / (2 * NT);               // staging chunks per group
 #pragma unroll
-        for (int g = 0; g < 12; ++g) {
+        for (int g = 0; g < 2 * NT; ++g) {
             if (g == 0) read_frags(kt, 0, af0, bf0);
-            if (g == 2) read_frags(kt, 1, af1, bf1);
-            if (g < 2) { if (!FIRST) mfma4(af1, bf1, 4 + g); }
-            else if (g < 8) mfma4(af0, bf0, g - 2);
-            else mfma4(af1, bf1, g - 8);
+            if (g == SKEW) read_frags(kt, 1, af1, bf1);
+            if (g < SKEW) { if (!FIRST) mfma4(af1, bf1, NT - SKEW + g); }
+            else if (g < SKEW + NT) mfma4(af0, bf0, g - SKEW);
+            else mfma4(af1, bf1, g - SKEW - NT);
             if (STAGE) {
-                stage_chunk(st, kt + 1, g);
-                if (LOAD) gload_after(st, kt + 2, g);
+#pragma unroll
+                for (int c = g * CPG; c < (g + 1) * CPG; ++c) {
+                    stage_chunk(st, kt + 1, c);
+                    if (LOAD) gload_after(st, kt + 2, c);
+                }
             }
             GP_GROUP_ORDER();
         }
@@ -368,8 +388,8 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
         for (; kt + 2 < nk; ++kt) iteration(F, T, T, F, kt);
         for (; kt + 1 < nk; ++kt) iteration(F, T, F, F, kt);
         for (; kt < nk; ++kt) iteration(F, F, F, F, kt);
-        mfma4(af1, bf1, 4);                                                    // the skewed tail of the last tile
-        mfma4(af1, bf1, 5);
+        if (X2) mfma4(af1, bf1, 2);                                            // the skewed tail of the last tile
+        else { mfma4(af1, bf1, 4); mfma4(af1, bf1, 5); }
     }
     GP_WG_STAMP(2);
 
@@ -384,6 +404,7 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
     const float* const actp = p.act;
     const float* const biasp = p.bias;
     float* const sink = gp_sink + tid;
+    float amax = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -408,7 +429,7 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dr = 8 * (r >> 2) + (r & 3);
-                float x = acc[t][u][r] + bv;
+                float x = X2 ? (acc[t][u][r] * ia) * ib + bv : acc[t][u][r] + bv;
                 if (flags & GI_EPI_SELU) {                        // scale * (max(x, 0) + alpha * (exp(min(x, 0)) - 1)): no branch
                     const float e = gi_exp_nonpos(fminf(x, 0.f));
                     x = GI_SELU_SCALE * (fmaxf(x, 0.f) + GI_SELU_ALPHA * (e - 1.f));
@@ -416,11 +437,14 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
                 if (flags & GI_EPI_DSELU) x *= gi_selu_grad(av[r]);
                 if (flags & GI_EPI_MULACT) x *= av[r];
                 if (flags & GI_EPI_ACCUM) x += cv[r];
-                float* dst = (col_ok & (dr < rows_left)) ? cbase + (long long)dr * ldc : sink;
+                const bool ok = col_ok & (dr < rows_left);
+                float* dst = ok ? cbase + (long long)dr * ldc : sink;
                 *dst = x;
+                amax = fmaxf(amax, ok ? fabsf(x) : 0.f);
             }
         }
     }
+    if (p.c_amax) gx_amax_publish(amax, p.c_amax);       // for the fp16x2 launches that read this tensor next
     GP_WG_STAMP(3);
 }
 
@@ -428,14 +452,14 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
 // TILE STREAM — as many workgroups as the device has CUs, each walking tiles id, id + grid, ... (longest reductions
 // first: gi_gemm_batch's order) — so no CU waits for a 512-thread / 144 KB workgroup to be torn down and set up
 // between two tiles.
-template <bool AM, bool BMJ, int EPI>
+template <bool AM, bool BMJ, int EPI, bool X2 = false>
 __global__ __launch_bounds__(512, 2) void gi_b3p_kernel(const GpBatch b) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];        // 2 * GP_STAGE
-    for (int tile = blockIdx.x; tile < b.total; tile += gridDim.x) gp_tile<AM, BMJ, EPI>(b, tile, smem);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];        // 2 stages
+    for (int tile = blockIdx.x; tile < b.total; tile += gridDim.x) gp_tile<AM, BMJ, EPI, X2>(b, tile, smem);
 }
 
 int g_b3p_enabled = -1, g_b3p_stream_cus = -1;
-bool g_b3p_attr_set[3][4] = {};
+bool g_b3p_attr_set[2][3][4] = {};
 
 }  // namespace
 
@@ -488,8 +512,10 @@ int gi_b3p_launch(const gi_gemm_params* probs, int n, void* stream) {
         if (!p.ngroups && !p.C) return GI_EINVAL;
         if (splitk && (!am || !bmj || p.m_dev)) return GI_EINVAL;            // slabs: weight-gradient layout only
         if (p.ones_col >= 0 && (!bmj || p.ones_col != p.N - 1)) return GI_EINVAL;
-        const int f = p.flags & ~(GI_GEMM_BF3 | GI_GEMM_BF3B_F32 | GI_GEMM_SPLITK);
+        const int f = p.flags & ~(GI_GEMM_BF3 | GI_GEMM_BF3B_F32 | GI_GEMM_SPLITK | GI_GEMM_X2);
         if (f & ~(GI_EPI_BIAS | GI_EPI_SELU | GI_EPI_DSELU | GI_EPI_ACCUM | GI_EPI_MULACT)) return GI_EINVAL;
+        if (((p.flags & GI_GEMM_X2) != 0) != ((probs[0].flags & GI_GEMM_X2) != 0)) return GI_EINVAL;
+        if ((p.flags & GI_GEMM_X2) && (!p.a_amax || !p.b_amax)) return GI_EINVAL;
         if ((f & GI_EPI_BIAS) && !p.bias) return GI_EINVAL;
         if ((f & (GI_EPI_DSELU | GI_EPI_MULACT)) && !p.act) return GI_EINVAL;
         const long long lim = 0xffffffffLL / 4;
@@ -528,20 +554,24 @@ int gi_b3p_launch(const gi_gemm_params* probs, int n, void* stream) {
     typedef void (*kern_t)(const GpBatch);
     kern_t fn;
     int li;
-    if (am) { li = 2; if (epi != 3) epi = 0; fn = epi == 3 ? (kern_t)gi_b3p_kernel<true, true, 3> : (kern_t)gi_b3p_kernel<true, true, 0>; }
-    else if (bmj) { li = 1; if (epi != 2) epi = 0; fn = epi == 2 ? (kern_t)gi_b3p_kernel<false, true, 2> : (kern_t)gi_b3p_kernel<false, true, 0>; }
+    const bool x2 = (probs[0].flags & GI_GEMM_X2) != 0;
+#define GP_PICK(A, B, E) (x2 ? (kern_t)gi_b3p_kernel<A, B, E, true> : (kern_t)gi_b3p_kernel<A, B, E, false>)
+    if (am) { li = 2; if (epi != 3) epi = 0; fn = epi == 3 ? GP_PICK(true, true, 3) : GP_PICK(true, true, 0); }
+    else if (bmj) { li = 1; if (epi != 2) epi = 0; fn = epi == 2 ? GP_PICK(false, true, 2) : GP_PICK(false, true, 0); }
     else {
         li = 0;
         if (epi != 1 && epi != 2) epi = 0;
-        fn = epi == 1 ? (kern_t)gi_b3p_kernel<false, false, 1> : (epi == 2 ? (kern_t)gi_b3p_kernel<false, false, 2> : (kern_t)gi_b3p_kernel<false, false, 0>);
+        fn = epi == 1 ? GP_PICK(false, false, 1) : (epi == 2 ? GP_PICK(false, false, 2) : GP_PICK(false, false, 0));
     }
-    if (!g_b3p_attr_set[li][epi]) {                 // 144 KB of dynamic LDS needs the opt-in
-        if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GP_STAGE) != hipSuccess)
+#undef GP_PICK
+    const int lds_bytes = 2 * (x2 ? GP_STAGE_X2 : GP_STAGE);
+    if (!g_b3p_attr_set[x2 ? 1 : 0][li][epi]) {     // 144 KB (96 KB) of dynamic LDS needs the opt-in
+        if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
             return (int)hipGetLastError();
-        g_b3p_attr_set[li][epi] = true;
+        g_b3p_attr_set[x2 ? 1 : 0][li][epi] = true;
     }
     GiProfScope prof(st, GI_PROF_GEMM, flops);
-    gi_gemm_log_launch(am ? "p2" : (bmj ? "p1" : "p0"), b.p, k, total, flops);
+    gi_gemm_log_launch(x2 ? (am ? "y2" : (bmj ? "y1" : "y0")) : (am ? "p2" : (bmj ? "p1" : "p0")), b.p, k, total, flops);
     int grid = total;
     if (g_b3p_stream_cus < 0) {
         int dev = 0, cus = 0;
@@ -551,6 +581,6 @@ int gi_b3p_launch(const gi_gemm_params* probs, int n, void* stream) {
         g_b3p_stream_cus = (e && atoi(e) == 0) ? 0 : cus;
     }
     if (g_b3p_stream_cus > 0 && grid > g_b3p_stream_cus && !bounded) grid = g_b3p_stream_cus;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), 2 * GP_STAGE, st, b);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds_bytes, st, b);
     return gi_launch_status();
 }

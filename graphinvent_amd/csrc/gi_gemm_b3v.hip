@@ -382,7 +382,7 @@ bool gi_b3v_eligible(const gi_gemm_params* probs, int n) {
     if (!gi_b3v_enable(-1)) return false;
     for (int i = 0; i < n; ++i) {
         const gi_gemm_params& p = probs[i];
-        if (!(p.flags & GI_GEMM_BF3) || (p.flags & GI_GEMM_BF3A)) return false;
+        if (!(p.flags & GI_GEMM_BF3) || (p.flags & (GI_GEMM_BF3A | GI_GEMM_X2))) return false;
         if (p.a_major != probs[0].a_major || p.b_major != probs[0].b_major) return false;
         if (p.a_major && !p.b_major) return false;
         if (!p.b_major && !(p.flags & GI_GEMM_BF3B_F32)) return false;      // contig B must be plain fp32, not an image

@@ -31,6 +31,7 @@
 
 #include "gi_common.h"
 #include "gi_mfma.h"
+#include "gi_x2.h"
 
 typedef __bf16 gi_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 gi_bf16x2 __attribute__((ext_vector_type(2)));
@@ -112,9 +113,14 @@ struct B3Batch {
 // gi_gemm_params.planes wrote): its staging is then a plain copy like B's.
 // BFP: B is plain fp32 [N][ldb] (GI_GEMM_BF3B_F32) and split while staging like A — 4 bytes per element through
 // L2 instead of the image's 6.
-template <int EPI, bool APL, bool BFP>
+// X2 (GI_GEMM_X2, with BFP and not APL): the operands as two scaled fp16 values each instead of three bf16 (gi_x2.h):
+// two LDS planes per operand, three f16 MFMA products per fp32 product, scales from a_amax / b_amax, 1 / (sa sb) in
+// the epilogue.
+template <int EPI, bool APL, bool BFP, bool X2 = false>
 __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * B3_BUF];
+    constexpr int NP = X2 ? 2 : 3;
+    constexpr int OPER = NP * B3_PLANE, BUF = 2 * OPER;           // (B3_OPER / B3_BUF with NP planes)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lhi = lane >> 5;
 
@@ -136,6 +142,8 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
     const int m0 = by * B3_BM, n0 = bx * B3_BN;
     if (m0 >= m_end) return;                                   // (bounded launch: beyond the rows on the device)
     const int K = p.K, Kp = b3_r32(K), nk = Kp / B3_BK;
+    float sa = 1.f, ia = 1.f, sb = 1.f, ib = 1.f;               // fp16x2: per-tensor power-of-two scales
+    if (X2) { gx_scale(gx_amax_read(p.a_amax), sa, ia); gx_scale(gx_amax_read(p.b_amax), sb, ib); }
     const unsigned char* const Bimg = reinterpret_cast<const unsigned char*>(p.B);
     const long long bplane = (long long)p.N * Kp * 2;          // bytes per plane of the image
 
@@ -226,8 +234,8 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
     };
     auto sstore = [&](auto steady_c, int kt, int buf, v4f (&ra)[2], gi_u32x4 (&rb)[3], gi_u32x4 (&rp)[3], v4f (&rf)[2]) __attribute__((always_inline)) {
         constexpr bool STEADY = decltype(steady_c)::value;
-        unsigned char* As = smem + buf * B3_BUF;
-        unsigned char* Bs = As + B3_OPER;
+        unsigned char* As = smem + buf * BUF;
+        unsigned char* Bs = As + OPER;
         const int k0 = kt * B3_BK;
         if (APL) {
 #pragma unroll
@@ -239,12 +247,18 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
             if (!STEADY) v = gi_fix4(v, k0 + 4 * c4, a_cmax, K, true);
             gi_u32x2 w0, w1, w2;
             unsigned x0, x1, x2, y0, y1, y2;
-            b3_split2(v.x, v.y, x0, x1, x2);
-            b3_split2(v.z, v.w, y0, y1, y2);
-            w0.x = x0; w0.y = y0; w1.x = x1; w1.y = y1; w2.x = x2; w2.y = y2;
+            if (X2) {
+                gx_split2(v.x, v.y, sa, x0, x1);
+                gx_split2(v.z, v.w, sa, y0, y1);
+            } else {
+                b3_split2(v.x, v.y, x0, x1, x2);
+                b3_split2(v.z, v.w, y0, y1, y2);
+                w2.x = x2; w2.y = y2;
+                *reinterpret_cast<gi_u32x2*>(As + 2 * B3_PLANE + a_lds[i]) = w2;
+            }
+            w0.x = x0; w0.y = y0; w1.x = x1; w1.y = y1;
             *reinterpret_cast<gi_u32x2*>(As + a_lds[i]) = w0;
             *reinterpret_cast<gi_u32x2*>(As + B3_PLANE + a_lds[i]) = w1;
-            *reinterpret_cast<gi_u32x2*>(As + 2 * B3_PLANE + a_lds[i]) = w2;
         }
         if (BFP) {
 #pragma unroll
@@ -253,12 +267,18 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
                 if (!STEADY) v = gi_fix4(v, k0 + 4 * c4, bf_cmax, K, true);
                 gi_u32x2 w0, w1, w2;
                 unsigned x0, x1, x2, y0, y1, y2;
-                b3_split2(v.x, v.y, x0, x1, x2);
-                b3_split2(v.z, v.w, y0, y1, y2);
-                w0.x = x0; w0.y = y0; w1.x = x1; w1.y = y1; w2.x = x2; w2.y = y2;
+                if (X2) {
+                    gx_split2(v.x, v.y, sb, x0, x1);
+                    gx_split2(v.z, v.w, sb, y0, y1);
+                } else {
+                    b3_split2(v.x, v.y, x0, x1, x2);
+                    b3_split2(v.z, v.w, y0, y1, y2);
+                    w2.x = x2; w2.y = y2;
+                    *reinterpret_cast<gi_u32x2*>(Bs + 2 * B3_PLANE + bf_lds[i]) = w2;
+                }
+                w0.x = x0; w0.y = y0; w1.x = x1; w1.y = y1;
                 *reinterpret_cast<gi_u32x2*>(Bs + bf_lds[i]) = w0;
                 *reinterpret_cast<gi_u32x2*>(Bs + B3_PLANE + bf_lds[i]) = w1;
-                *reinterpret_cast<gi_u32x2*>(Bs + 2 * B3_PLANE + bf_lds[i]) = w2;
             }
         } else {
 #pragma unroll
@@ -275,18 +295,31 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
 
     auto compute = [&](int buf) {
-        const unsigned char* As = smem + buf * B3_BUF;
-        const unsigned char* Bs = As + B3_OPER;
+        const unsigned char* As = smem + buf * BUF;
+        const unsigned char* Bs = As + OPER;
         gi_bf16x8 af[2][3], bf[2][3];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int ra_ = wm * 64 + t * 32 + l31, rb_ = wn * 64 + t * 32 + l31;
             const int oa = ra_ * B3_ROWB + 16 * (lhi ^ ((ra_ >> 3) & 1)), ob = rb_ * B3_ROWB + 16 * (lhi ^ ((rb_ >> 3) & 1));
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NP; ++pl) {
                 af[t][pl] = *reinterpret_cast<const gi_bf16x8*>(As + pl * B3_PLANE + oa);
                 bf[t][pl] = *reinterpret_cast<const gi_bf16x8*>(Bs + pl * B3_PLANE + ob);
             }
+        }
+        if (X2) {                                    // a2 b1 + a1 b2 + a1 b1 on the f16 MFMA (smallest terms first)
+            constexpr int XA[3] = {1, 0, 0}, XB[3] = {0, 1, 0};
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            __builtin_bit_cast(gx_f16x8, af[t][XA[term]]), __builtin_bit_cast(gx_f16x8, bf[u][XB[term]]),
+                            acc[t][u], 0, 0, 0);
+            return;
         }
         // smallest terms first; four independent accumulators between two MFMAs on the same one
         constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
@@ -339,6 +372,7 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
     const int flags = EPI == 1 ? (GI_EPI_BIAS | GI_EPI_SELU) : (EPI == 2 ? GI_EPI_DSELU : p.flags);
     const bool need_act = (flags & (GI_EPI_DSELU | GI_EPI_MULACT)) != 0;
     const bool need_c = (flags & GI_EPI_ACCUM) != 0;
+    float amax = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -358,7 +392,7 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float x = acc[t][u][r] + bv;
+                float x = X2 ? (acc[t][u][r] * ia) * ib + bv : acc[t][u][r] + bv;
                 if (flags & GI_EPI_SELU) x = gi_selu(x);
                 if (flags & GI_EPI_DSELU) x *= gi_selu_grad(av[r]);
                 if (flags & GI_EPI_MULACT) x *= av[r];
@@ -368,11 +402,14 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + 8 * (r >> 2) + (r & 3);
-                float* dst = (col_ok & (row < m_end)) ? p.C + (long long)row * p.ldc + col : b3_sink + tid;
+                const bool ok = col_ok & (row < m_end);
+                float* dst = ok ? p.C + (long long)row * p.ldc + col : b3_sink + tid;
                 *dst = v[r];
+                amax = fmaxf(amax, ok ? fabsf(v[r]) : 0.f);
             }
         }
     }
+    if (p.c_amax) gx_amax_publish(amax, p.c_amax);       // for the fp16x2 launches that read this tensor next
 }
 
 }  // namespace
@@ -419,6 +456,11 @@ int gi_gemm_bf3_launch(const gi_gemm_params* probs, int n, void* stream) {
     for (int i = 0; i < n; ++i) nbfp += (probs[i].flags & GI_GEMM_BF3B_F32) != 0;
     if (nbfp && nbfp != n) return GI_EINVAL;
     const bool bfp = nbfp != 0;
+    int nx2 = 0;
+    for (int i = 0; i < n; ++i) nx2 += (probs[i].flags & GI_GEMM_X2) != 0;
+    if (nx2 && (nx2 != n || !bfp || apl)) return GI_EINVAL;       // fp16x2: every problem, both operands plain fp32
+    const bool x2 = nx2 != 0;
+    for (int i = 0; i < n; ++i) if (x2 && (!probs[i].a_amax || !probs[i].b_amax)) return GI_EINVAL;
     for (int i = 0; i < n; ++i) {
         const gi_gemm_params& p = probs[i];
         if (p.a_major || p.b_major || p.ngroups || p.b_idx || p.nsplit != 1 || p.k_dev || !p.A || !p.B || !p.C)
@@ -432,7 +474,7 @@ int gi_gemm_bf3_launch(const gi_gemm_params* probs, int n, void* stream) {
         if (p.K < 4 && ((!apl && p.lda < 4) || (bfp && p.ldb < 4))) return GI_EINVAL;
         if (!bfp && ((uintptr_t)p.B & 15) != 0) return GI_EINVAL;
         if (bfp && p.ldb < p.K) return GI_EINVAL;
-        const int f = p.flags & ~(GI_GEMM_BF3 | GI_GEMM_BF3A | GI_GEMM_BF3B_F32);
+        const int f = p.flags & ~(GI_GEMM_BF3 | GI_GEMM_BF3A | GI_GEMM_BF3B_F32 | GI_GEMM_X2);
         if (f & ~(GI_EPI_BIAS | GI_EPI_SELU | GI_EPI_DSELU | GI_EPI_ACCUM | GI_EPI_MULACT)) return GI_EINVAL;
         if ((f & GI_EPI_BIAS) && !p.bias) return GI_EINVAL;
         if ((f & (GI_EPI_DSELU | GI_EPI_MULACT)) && !p.act) return GI_EINVAL;
@@ -459,9 +501,13 @@ int gi_gemm_bf3_launch(const gi_gemm_params* probs, int n, void* stream) {
     }
     hipStream_t st = (hipStream_t)stream;
     GiProfScope prof(st, GI_PROF_GEMM, flops);
-    gi_gemm_log_launch((b.p[0].flags & GI_EPI_BIAS) ? "b0" : "b1", b.p, k, total, flops);
+    gi_gemm_log_launch(x2 ? ((b.p[0].flags & GI_EPI_BIAS) ? "x0" : "x1") : ((b.p[0].flags & GI_EPI_BIAS) ? "b0" : "b1"), b.p, k,
+                       total, flops);
 #define GI_B3_LAUNCH(E, A, F) hipLaunchKernelGGL((gi_gemm_bf3_kernel<E, A, F>), dim3(total), dim3(256), 0, st, b)
-    if (bfp) {                                            // (forward weights as stored: own epilogue or run-time flags)
+#define GI_X2_LAUNCH(E) hipLaunchKernelGGL((gi_gemm_bf3_kernel<E, false, true, true>), dim3(total), dim3(256), 0, st, b)
+    if (x2) {
+        if (epi == 1) GI_X2_LAUNCH(1); else if (epi == 2) GI_X2_LAUNCH(2); else GI_X2_LAUNCH(0);
+    } else if (bfp) {                                     // (forward weights as stored: own epilogue or run-time flags)
         if (apl) return GI_EINVAL;
         if (epi == 1) GI_B3_LAUNCH(1, false, true); else GI_B3_LAUNCH(0, false, true);
     } else if (apl) {
@@ -470,5 +516,6 @@ int gi_gemm_bf3_launch(const gi_gemm_params* probs, int n, void* stream) {
         if (epi == 1) GI_B3_LAUNCH(1, false, false); else if (epi == 2) GI_B3_LAUNCH(2, false, false); else GI_B3_LAUNCH(0, false, false);
     }
 #undef GI_B3_LAUNCH
+#undef GI_X2_LAUNCH
     return gi_launch_status();
 }

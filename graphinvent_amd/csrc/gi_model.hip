@@ -114,6 +114,7 @@ struct Ws {
     // split-K slabs of the skinny, long-reduction layers of the graph-level stacks (skinny_splits)
     long long skinny, skinny_floats;
     long long bf3, bf3_floats;          // bf16x3 operand images of the node-level stacks' wide layers (gi_gemm_bf3.hip)
+    long long amax;                     // fp16x2 launches: max |.| of their operand tensors, 3 (of 4) amax cells per layer (gi_x2.h)
     long long total;
 };
 
@@ -126,6 +127,11 @@ long long chain_image_floats(const Mlp& q, int groups, bool backward, long long*
 // (rows: measured crossover against the fp32 kernel ~2 300 — 2 048 rows 35.0 vs 33.5 us, 3 000 rows 43.2 vs 53.5)
 constexpr int BF3_MIN_WIDTH = 192, BF3_MIN_ROWS = 2560;
 static int g_bf3 = -1;                  // -1: not read yet
+static int g_x2 = -1;                   // fp16x2 instead of bf16x3 on those launches (environment GI_X2, default 1)
+static bool x2_enabled() {
+    if (g_x2 < 0) g_x2 = getenv("GI_X2") ? (atoi(getenv("GI_X2")) != 0) : 1;
+    return g_x2 != 0;
+}
 bool bf3_enabled() {
     if (g_bf3 < 0) g_bf3 = getenv("GI_BF3") ? (atoi(getenv("GI_BF3")) != 0) : (GI_BF3_DEFAULT != 0);
     return g_bf3 != 0;
@@ -245,6 +251,7 @@ void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
                                       gi_bf3_image_elems(q->fan_in(l), q->fan_out(l)));
         w.bf3_floats = elems / 2;
         w.bf3 = take(std::max(w.bf3_floats, 4LL), 1);
+        w.amax = take(4LL * GI_AMAX_WORDS * GI_BF3_PACK_MAX, 1);
     }
     for (int k = 0; k < (attn ? 2 : 1); ++k) {
         const Mlp& q = k ? m.eatt[0] : m.msg[0];
@@ -369,7 +376,9 @@ struct Run {
     const int* skip = nullptr;              // set around the pass-0 stack launch: hit flag of gi_graph.p0_cache
     // layers that run as bf16x3 launches in this call (bf3_prepare): weight -> W^T image (backward; the forward
     // reads the fp32 weight as stored, GI_GEMM_BF3B_F32, img = NULL)
-    struct Bf3 { const float* W; const unsigned short* img; } bf3[GI_BF3_PACK_MAX];
+    // amax (fp16x2, gi_x2.h; NULL: the launch stays bf16x3): [0] max |W|, [1] max |layer input|, [2] max |dZ of the
+    // layer's output| — written by gi_absmax / by the c_amax of the launch that produces the tensor
+    struct Bf3 { const float* W; const unsigned short* img; float* amax; } bf3[GI_BF3_PACK_MAX];
     int nbf3 = 0;
     const Bf3* bf3_layer(const float* W, int rows) const {
         if (rows < BF3_MIN_ROWS) return nullptr;
@@ -582,13 +591,19 @@ void flush_batch(Run& r, Batch& b, bool wgrad) {
 }
 
 void add_fwd(Batch& b, Run& r, const float* W, const float* bias, int in, int out, const float* X,
-             int ldx, int rows, float* Y, int ldy, bool selu) {
+             int ldx, int rows, float* Y, int ldy, bool selu, const float* Wnext = nullptr) {
     if (rows <= 0) return;
     gi_gemm_params& p = b.next();
     p.A = X; p.lda = ldx; p.B = W; p.ldb = in; p.bias = bias; p.C = Y; p.ldc = ldy;
     p.M = rows; p.N = out; p.K = in;
     p.flags = GI_EPI_BIAS | (selu ? GI_EPI_SELU : 0);
-    if (r.bf3_layer(W, rows)) p.flags |= GI_GEMM_BF3 | GI_GEMM_BF3B_F32;       // (B = W [out][in] as stored)
+    if (const Run::Bf3* e = r.bf3_layer(W, rows)) {
+        p.flags |= GI_GEMM_BF3 | GI_GEMM_BF3B_F32;                             // (B = W [out][in] as stored)
+        if (e->amax) { p.flags |= GI_GEMM_X2; p.a_amax = e->amax + GI_AMAX_WORDS; p.b_amax = e->amax; }
+    }
+    if (Wnext)                                    // Y is the next layer's input: it needs max |Y| if it runs fp16x2
+        if (const Run::Bf3* nx = r.bf3_layer(Wnext, rows))
+            if (nx->amax) p.c_amax = nx->amax + GI_AMAX_WORDS;
     if (r.dims && rows == r.R_bound) { p.m_dev = r.dims; return; }     // node-level rows: counted on the device
     if (p.flags & GI_GEMM_BF3) return;
     maybe_split_k(b, r, p);
@@ -596,17 +611,21 @@ void add_fwd(Batch& b, Run& r, const float* W, const float* bias, int in, int ou
 
 void add_dgrad(Batch& b, Run& r, int widx, int n_out, int n_in, int ncols, const float* dZ,
                int lddz, int rows, float* dX, int lddx, const float* act, int ldact,
-               bool accumulate) {
+               bool accumulate, int widx_prev = -1) {
     if (rows <= 0) return;
     gi_gemm_params& p = b.next();
     p.A = dZ; p.lda = lddz; p.B = dgrad_operand(r, widx, n_out, n_in, p); p.C = dX; p.ldc = lddx;
     p.M = rows; p.N = ncols; p.K = n_out;
     dact(r, p, act, ldact, accumulate);
+    if (widx_prev >= 0)                           // dX is the dZ of the previous layer's output: its fp16x2 launches
+        if (const Run::Bf3* pv = r.bf3_layer(r.P[widx_prev], rows))          // (dgrad, weight gradient) need max |dX|
+            if (pv->amax) p.c_amax = pv->amax + 2 * GI_AMAX_WORDS;
     if (ncols == n_in)
         if (const Run::Bf3* e = r.bf3_layer(r.P[widx], rows))
             if (e->img) {                                                     // W^T as fp32 [n_in][r4(n_out)]
                 p.B = reinterpret_cast<const float*>(e->img); p.b_major = 0; p.ldb = gi_r4(n_out);
                 p.flags |= GI_GEMM_BF3 | GI_GEMM_BF3B_F32;
+                if (e->amax) { p.flags |= GI_GEMM_X2; p.a_amax = e->amax + 2 * GI_AMAX_WORDS; p.b_amax = e->amax; }
                 return;
             }
     maybe_split_k(b, r, p);
@@ -637,7 +656,12 @@ void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* wid
     p.flags = GI_GEMM_SPLITK;
     p.nsplit = e0.nsplit; p.c_split_stride = e0.stride;
     p.tm = e0.tn; p.tn = e0.tn;                 // 1x1 (64x64 tiles) or 2x2 (128x128), see wgrad_shape
-    if (e0.bf3 && !b_idx) p.flags |= GI_GEMM_BF3;              // bf16 pipe, 128 x 256 tiles (gi_gemm_b3p.hip)
+    if (e0.bf3 && !b_idx) {                                    // bf16 pipe, 128 x 256 tiles (gi_gemm_b3p.hip)
+        p.flags |= GI_GEMM_BF3;
+        if (!g.n)
+            if (const Run::Bf3* e = r.bf3_layer(r.P[widx[0]], rows))
+                if (e->amax) { p.flags |= GI_GEMM_X2; p.a_amax = e->amax + 2 * GI_AMAX_WORDS; p.b_amax = e->amax + GI_AMAX_WORDS; }
+    }
     const int slot = q.n - 1;
     if (g.n) {
         p.ngroups = g.n; p.grp_off = g.off;
@@ -783,7 +807,8 @@ void mlp_jobs_forward(Run& r, float* ws, const MlpJob* jobs, int n) {
             const float* src = (l == 0) ? q.X : ws + q.acts[l - 1];
             float* dst = (l == L - 1) ? q.out : ws + q.acts[l];
             add_fwd(b, r, r.P[q.mlp->w(l)], r.P[q.mlp->b(l)], q.mlp->fan_in(l), q.mlp->fan_out(l), src,
-                    l == 0 ? q.ldx : q.ldh, q.rows, dst, l == L - 1 ? q.ldout : q.ldh, true);
+                    l == 0 ? q.ldx : q.ldh, q.rows, dst, l == L - 1 ? q.ldout : q.ldh, true,
+                    l + 1 < L ? r.P[q.mlp->w(l + 1)] : nullptr);
         }
         flush_batch(r, b, false);
         for (int j = 0; j < n && r.drop; ++j) {
@@ -819,7 +844,7 @@ void mlp_jobs_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred& 
                         q.rows);
             if (l > 0) {
                 add_dgrad(bd, r, widx, q.mlp->fan_out(l), q.mlp->fan_in(l), q.mlp->fan_in(l), dZ, lddz,
-                          q.rows, ws + q.dzs[l - 1], q.ldh, ws + q.acts[l - 1], q.ldh, false);
+                          q.rows, ws + q.dzs[l - 1], q.ldh, ws + q.acts[l - 1], q.ldh, false, q.mlp->w(l - 1));
             } else if (q.dX) {
                 add_dgrad(bd, r, widx, q.mlp->fan_out(0), q.mlp->fan_in(0), q.dx_cols, dZ, lddz, q.rows,
                           q.dX, q.lddx, nullptr, 0, q.accumulate);
@@ -1179,6 +1204,30 @@ void bf3_prepare(Run& r, const Model& m, float* ws, const Ws& w, bool backward, 
             ++n;
         }
     if (n && backward) r.chk(gi_bf3_pack(d, n, r.st));
+    // fp16x2 (gi_x2.h): three amax cells per layer — max |W| (gi_absmax, here, in the forward), max |layer input| and max
+    // |dZ of its output| (the c_amax of the launches that produce them; zeroed here, once per forward: the backward
+    // runs on the same workspace)
+    if (n && x2_enabled() && gi_b3p_enable(-1)) {
+        float* am = ws + w.amax;
+        gi_absmax_desc ad[GI_BF3_PACK_MAX];
+        for (int i = 0; i < n; ++i) {
+            r.bf3[i].amax = am + 4LL * GI_AMAX_WORDS * i;
+            ad[i].x = r.bf3[i].W; ad[i].rows = 1; ad[i].out = r.bf3[i].amax;
+        }
+        int k = 0;
+        for (const Mlp* q : t1)
+            for (int l = 0; l < q->layers() && k < n; ++l) {
+                if (!bf3_layer_ok(*q, l)) continue;
+                ad[k].cols = q->fan_in(l) * q->fan_out(l); ad[k].ld = ad[k].cols;
+                ++k;
+            }
+        if (!backward) {
+            r.chk((int)hipMemsetAsync(am, 0, sizeof(float) * 4 * GI_AMAX_WORDS * n, r.st));
+            r.chk(gi_absmax(ad, n, r.st));
+        }
+    } else {
+        for (int i = 0; i < n; ++i) r.bf3[i].amax = nullptr;
+    }
     r.nbf3 = n;
 }
 
@@ -1409,6 +1458,14 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
         mlp_jobs_forward(r, ws, jobs, 3);
     }
     return r.rc;
+}
+
+// fp16x2 instead of bf16x3 on the GI_GEMM_BF3 launches of gi_ggnn_forward / backward (environment GI_X2, default 1):
+// on = 1 / 0 sets, on < 0 queries; returns the previous setting.
+extern "C" int gi_x2_enable(int on) {
+    const int prev = x2_enabled() ? 1 : 0;
+    if (on >= 0) g_x2 = on ? 1 : 0;
+    return prev;
 }
 
 extern "C" int gi_bf3_enable(int on) {

@@ -1361,3 +1361,68 @@ extern "C" int gi_kl_loss(const float* out, int ldo, const void* target, int tgt
                            loss_mean);
     return gi_launch_status();
 }
+
+
+// ---- largest magnitude of several tensors (the weights of the fp16x2 GEMM launches, gi_x2.h) -----------------------
+#include "gi_x2.h"
+namespace {
+struct AbsmaxArgs { gi_absmax_desc d[GI_ABSMAX_MAX]; int start[GI_ABSMAX_MAX + 1]; int n; };
+// a workgroup = 256 threads x 8 float4 of one tensor (contiguous tensors: rows folded into one run by the host)
+__global__ __launch_bounds__(256) void absmax_kernel(const AbsmaxArgs a) {
+    int i = 0;
+    while (i < a.n - 1 && (int)blockIdx.x >= a.start[i + 1]) ++i;
+    const gi_absmax_desc& d = a.d[i];
+    const long long n = (long long)d.rows * d.cols;                     // (ld == cols here)
+    const long long base = (long long)(blockIdx.x - a.start[i]) * 8192;
+    float m = 0.f;
+    if (((uintptr_t)d.x & 15) == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const long long e = base + ((long long)k * 256 + threadIdx.x) * 4;
+            if (e + 3 < n) {
+                const v4f v = *reinterpret_cast<const v4f*>(d.x + e);
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            } else {
+                for (long long q = e; q < n && q < e + 4; ++q) m = fmaxf(m, fabsf(d.x[q]));
+            }
+        }
+    } else {
+        for (long long e = base + threadIdx.x; e < n && e < base + 8192; e += 256) m = fmaxf(m, fabsf(d.x[e]));
+    }
+    gx_amax_publish(m, d.out);
+}
+// rows with a pitch (ld > cols): one row per workgroup pass
+__global__ __launch_bounds__(256) void absmax_rows_kernel(const gi_absmax_desc d) {
+    float m = 0.f;
+    for (int r = blockIdx.x; r < d.rows; r += gridDim.x)
+        for (int c = threadIdx.x; c < d.cols; c += 256) m = fmaxf(m, fabsf(d.x[(long long)r * d.ld + c]));
+    gx_amax_publish(m, d.out);
+}
+}  // namespace
+
+extern "C" int gi_absmax(const gi_absmax_desc* descs, int n, void* stream) {
+    (void)hipGetLastError();
+    if (!descs || n < 1 || n > GI_ABSMAX_MAX) return GI_EINVAL;
+    AbsmaxArgs a;
+    memset(&a, 0, sizeof(a));
+    int total = 0, k = 0;
+    for (int i = 0; i < n; ++i) {
+        const gi_absmax_desc& d = descs[i];
+        if (!d.x || !d.out || d.rows < 0 || d.cols < 0 || d.ld < d.cols) return GI_EINVAL;
+        const long long elems = (long long)d.rows * d.cols;
+        if (elems == 0) continue;
+        if (d.ld != d.cols && d.rows > 1) {                  // pitched rows: their own small launch
+            hipLaunchKernelGGL(absmax_rows_kernel, dim3(std::min(d.rows, 1024)), dim3(256), 0, (hipStream_t)stream, d);
+            continue;
+        }
+        if (elems > 0x7fffffffLL * 64) return GI_ELIMIT;
+        a.d[k] = d; a.d[k].rows = 1; a.d[k].cols = (int)std::min<long long>(elems, 0x7fffffff); a.d[k].ld = a.d[k].cols;
+        if (elems > 0x7fffffffLL) return GI_ELIMIT;
+        a.start[k] = total;
+        total += (int)((elems + 8191) / 8192);
+        ++k;
+    }
+    a.start[k] = total; a.n = k;
+    if (total > 0) hipLaunchKernelGGL(absmax_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, a);
+    return gi_launch_status();
+}

@@ -26,11 +26,13 @@ GI_MAX_NODES = 128
 EPI_BIAS, EPI_SELU, EPI_DSELU, EPI_ACCUM, GEMM_SPLITK = 1, 2, 4, 8, 16
 EPI_MULACT = 64
 GEMM_BF3A, GEMM_BF3B_F32 = 256, 512       # with GEMM_BF3: A is an image too / B is the plain fp32 matrix
+AMAX_WORDS = 2048     # floats of an amax cell (include/graphinvent_amd.h GI_AMAX_WORDS)
+GEMM_X2 = 1024        # with GEMM_BF3 and fp32 operands: two scaled fp16 planes per operand, three products (needs a_amax / b_amax)
 GEMM_BF3 = 128        # GI_GEMM_BF3: B is a gi_bf3_pack image; the launch runs as bf16x3 splits on the bf16 MFMA pipe
 KIND_GGNN, KIND_ATTGGNN = 0, 1
 BWD_ALL, BWD_READOUT, BWD_PASSES = 0, 1, 2
 COUNTS = 24          # GI_COUNTS
-ABI_VERSION = 12
+ABI_VERSION = 13
 #: bumped by code that rewrites model weights through raw pointers (optim.FusedAdam.step,
 #: dp.DataParallel.broadcast_parameters): invalidates gnn.mpnn's pass-0 row cache
 WEIGHTS_EPOCH = [0]     # GI_ABI_VERSION
@@ -56,7 +58,7 @@ class GemmParams(C.Structure):
                 ("c_split_stride", cll),
                 ("Bg", vp * GI_MAX_GROUPS), ("biasg", vp * GI_MAX_GROUPS),
                 ("Cg", vp * GI_MAX_GROUPS), ("gsplit", ci * GI_MAX_GROUPS),
-                ("m_dev", vp), ("k_dev", vp)]
+                ("m_dev", vp), ("k_dev", vp), ("a_amax", vp), ("b_amax", vp), ("c_amax", vp)]
 
 
 CHAIN_MAXL, CHAIN_MAXW = 8, 256       # GI_CHAIN_MAXL, GI_CHAIN_MAXW
@@ -77,6 +79,10 @@ class ChainParams(C.Structure):
 class ReduceDesc(C.Structure):
     _fields_ = [("slabs", vp), ("dW", vp), ("db", vp), ("slab_stride", cll),
                 ("n_slabs", ci), ("N", ci), ("K", ci), ("ld", ci)]
+
+
+class AbsmaxDesc(C.Structure):            # gi_absmax_desc
+    _fields_ = [("x", vp), ("rows", ci), ("cols", ci), ("ld", ci), ("out", vp)]
 
 
 class Bf3PackDesc(C.Structure):
@@ -123,7 +129,9 @@ SIGNATURES = {
                              ci, ci, vp, vp, ci, vp, vp]),
     "gi_compact_class_csr": (ci, [vp, ci, ci, vp, vp, vp]),
     "gi_compact_bound": (ci, [vp, ci, ci, ci, ci, ci, vp, vp]),
+    "gi_absmax": (ci, [vp, ci, vp]),
     "gi_b3p_enable": (ci, [ci]),
+    "gi_x2_enable": (ci, [ci]),
     "gi_b3v_enable": (ci, [ci]),
     "gi_class_sum_dselu": (ci, [vp, vp, ci, vp, vp, ci, ci, vp, vp, ci, vp]),
     "gi_gemm": (ci, [C.POINTER(GemmParams), vp]),

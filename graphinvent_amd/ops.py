@@ -400,7 +400,7 @@ def bf3_pack(W: torch.Tensor, transpose: bool = False, as_f32: bool = False) -> 
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, flags=0, bias=None, act=None, ldact=0,
          a_idx=None, b_idx=None, a_major=False, b_major=False, tm=1, tn=1, grp_off=None,
          ngroups=0, max_group_rows=0, Bg=(), biasg=(), Cg=(), nsplit=1, c_split_stride=0,
-         ones_col=-1, gsplit=()):
+         ones_col=-1, gsplit=(), a_amax=None, b_amax=None, c_amax=None):
     lib = L.load()
     p = L.GemmParams()
     p.A, p.B, p.C = _ptr(A), _ptr(B), _ptr(C_out)
@@ -410,6 +410,7 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, flags=0, bias=None, act=None, l
     p.flags, p.a_major, p.b_major, p.tm, p.tn = flags, int(a_major), int(b_major), tm, tn
     p.ngroups, p.nsplit, p.max_group_rows, p.ones_col = ngroups, nsplit, max_group_rows, ones_col
     p.c_split_stride = c_split_stride
+    p.a_amax, p.b_amax, p.c_amax = _ptr(a_amax), _ptr(b_amax), _ptr(c_amax)
     for i, t in enumerate(Bg):
         p.Bg[i] = _ptr(t)
     for i, t in enumerate(biasg):
@@ -433,6 +434,22 @@ def selu_bwd_rows(dY, idx, Y, out, rows, cols):
     L.check(L.load().gi_selu_bwd_rows(dY.data_ptr(), dY.stride(0), _ptr(idx), Y.data_ptr(),
                                       Y.stride(0), out.data_ptr(), out.stride(0), rows, cols,
                                       _stream()), "gi_selu_bwd_rows")
+
+
+def absmax(tensors, out: torch.Tensor) -> torch.Tensor:
+    """max |x| of each 2-D tensor (row pitch = its stride) into the amax cell out[i] (fp32 [n, AMAX_WORDS], zeroed here;
+    the value is ``out[i].max()``): what a GI_GEMM_X2 launch needs for operands no GEMM epilogue produced (the weights)."""
+    lib = L.load()
+    tensors = list(tensors)
+    assert out.dim() == 2 and out.shape[1] == L.AMAX_WORDS and out.is_contiguous() and out.shape[0] >= len(tensors)
+    out[:len(tensors)].zero_()
+    d = (L.AbsmaxDesc * len(tensors))()
+    for i, t in enumerate(tensors):
+        d[i].x, d[i].rows, d[i].cols, d[i].ld = t.data_ptr(), t.shape[0], t.shape[1], t.stride(0)
+        d[i].out = out[i].data_ptr()
+    with torch.cuda.device(out.device):
+        L.check(lib.gi_absmax(d, len(tensors), _stream(out)), "gi_absmax")
+    return out
 
 
 def reduce_slabs(items):

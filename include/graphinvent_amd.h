@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GI_ABI_VERSION 12
+#define GI_ABI_VERSION 13
 #define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
 #define GI_MAX_NODES 128      /* max max_n_nodes */
 #define GI_P0_MAX_CLASSES 256 /* max distinct node feature rows for the pass-0 shortcut */
@@ -170,6 +170,11 @@ typedef struct gi_graph {
                               it is staged like A: no image, 4 bytes per element through L2 instead of 6 */
 #define GI_GEMM_BF3A   256 /* with GI_GEMM_BF3: A is a pre-split bf16 image too ([3][M][Kp], gi_bf3_pack of an [M, K]
                               matrix or the `planes` output of a producing launch); no a_idx */
+#define GI_GEMM_X2    1024 /* with GI_GEMM_BF3 and plain fp32 operands: split every operand into TWO scaled fp16 values
+                              instead of three bf16 (csrc/gi_x2.h): three f16 MFMA products per fp32 product instead of
+                              six, the same ~3e-7 distance from the fp64 product.  Needs the largest magnitude of both
+                              operand tensors on the device (`a_amax`, `b_amax`: written by the `c_amax` of the launch
+                              that produced the tensor, or by gi_absmax) */
 
 typedef struct gi_gemm_params {
     const float* A; const float* B; float* C;
@@ -191,9 +196,22 @@ typedef struct gi_gemm_params {
      * extents are read on the device — rows = min(M, *m_dev), reduction length = min(K, *k_dev); output
      * tiles beyond the real rows exit at once.  NULL: M / K as given.  Not with groups or split-K. */
     const int* m_dev; const int* k_dev;
+    /* GI_GEMM_X2: the "amax cells" (GI_AMAX_WORDS floats each, see below) holding max |A|, max |B|, read when the kernel
+     * starts.  c_amax (any launch, may be NULL): the cell that receives max |C| over everything this launch stores —
+     * the caller zeroes the cell before the producer runs. */
+    const float* a_amax; const float* b_amax;
+    float* c_amax;
 } gi_gemm_params;
 
 int gi_gemm(const gi_gemm_params* p, void* stream);
+/* An amax cell: GI_AMAX_WORDS floats, the tensor's largest magnitude = the maximum over the cell (writers spread their
+ * atomic max over 64 slots one 128-byte line apart, csrc/gi_x2.h; all values >= 0, a zeroed cell = "nothing yet"). */
+#define GI_AMAX_WORDS 2048
+/* max |x| of up to GI_ABSMAX_MAX matrices [rows][cols] (pitch ld) in one launch, maxed into the amax cell `out` (zero it
+ * first) — the weights' side of GI_GEMM_X2 (their other operands get theirs from the producing launch's c_amax). */
+#define GI_ABSMAX_MAX 16
+typedef struct { const float* x; int rows, cols, ld; float* out; } gi_absmax_desc;
+int gi_absmax(const gi_absmax_desc* descs, int n, void* stream);
 /* n (<= 8) independent problems of the same tile shape and operand layouts in ONE launch.
  * Every launch is a tile loop: launches with more output tiles than the device holds workgroups at once
  * run as a persistent grid (each workgroup walks tiles id, id + grid, ...; the next tile's first operand
@@ -282,6 +300,9 @@ typedef struct {
  * everything else — and everything when both are off — runs on the round-3 kernel (gi_gemm_bf3.hip). */
 int gi_b3p_enable(int on);
 int gi_b3v_enable(int on);
+/* gi_ggnn_forward / backward: their GI_GEMM_BF3 launches as fp16x2 (GI_GEMM_X2: two scaled fp16 planes per operand,
+ * three products; environment GI_X2, default 1) or as bf16x3 (0).  on < 0 queries; returns the previous setting. */
+int gi_x2_enable(int on);
 /* Process-wide switch of gi_ggnn_forward / backward's use of GI_GEMM_BF3 launches (initial value: environment
  * GI_BF3, else GI_BF3_DEFAULT): on = 1 / 0 sets it, on < 0 only queries; returns the previous setting.  The
  * workspace size does not depend on it. */

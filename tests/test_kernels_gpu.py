@@ -325,6 +325,77 @@ def test_gemm_bf16x3_weight_gradient_layout_vs_fp64(rows, n_out, n_in, nsplit, k
     assert e3 < 2e-6 and e3 < 4 * e1 + 2e-7, (e3, e1)
 
 
+@pytest.mark.parametrize("kernel", ["b3p", "r3"])
+@pytest.mark.parametrize("M,N,K,big", [(7258, 500, 500, 1.0), (1000, 250, 250, 3e4), (257, 192, 36, 1e-6), (129, 257, 1000, 1.0)])
+def test_gemm_fp16x2_split_vs_fp64_with_amax_cells_from_the_producers(M, N, K, big, kernel, bf3_kernel_switches):
+    """GI_GEMM_X2 (csrc/gi_x2.h): two scaled fp16 planes per operand, three f16 MFMA products.  The scales come from the
+    operands' amax cells — max |W| from gi_absmax, max |X| from the c_amax of the launch that PRODUCED X (an fp32 GEMM
+    here) — and the result is as close to the fp64 product as the bf16x3 split (< 2e-6 of max |ref|) at every
+    magnitude of the tensors (`big` scales X: the per-tensor power-of-two scale keeps fp16's 5-bit exponent in range).
+    Forward layout, dgrad layout (W^T copy, and W as stored for the pipelined kernel), and the weight-gradient
+    layout of the pipelined kernel; the launch's own c_amax cell == max |stored|."""
+    lib = bf3_kernel_switches
+    lib.gi_b3p_enable(1 if kernel == "b3p" else 0); lib.gi_b3v_enable(0)
+    os.environ["GI_B3P_ALL"] = "1"
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    lda, ldc = ops.r4(K), ops.r4(N) + 8
+    X0 = torch.randn(M, 64, generator=g) * big
+    P = torch.randn(K, 64, generator=g) / 8
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * big
+    cells = torch.zeros(4, L.AMAX_WORDS, device=DEV)
+    Xd = torch.zeros(M, lda, device=DEV)
+    ops.gemm(X0.to(DEV), P.to(DEV), Xd, M, K, 64, 64, 64, lda, flags=0, c_amax=cells[0])     # the producer of X
+    X = Xd.cpu()
+    assert float(cells[0].max()) == float(X[:, :K].abs().max())
+    Wd = W.to(DEV)
+    ops.absmax([Wd], cells[1:2])
+    assert float(cells[1].max()) == float(W.abs().max())
+    Y = torch.full((M, ldc), 7.0, device=DEV)
+    F = L.GEMM_BF3 | L.GEMM_BF3B_F32 | L.GEMM_X2
+    # (tiny magnitudes without the SELU: its fp32 exp(x) - 1 — ATen's form, gi_common.h — cancels at |x| ~ 1e-6)
+    selu = big >= 1.0
+    ops.gemm(Xd, Wd, Y, M, N, K, lda, K, ldc, flags=L.EPI_BIAS | (L.EPI_SELU if selu else 0) | F, bias=b.to(DEV),
+             a_amax=cells[0], b_amax=cells[1], c_amax=cells[2])
+    ref = X[:, :K].double() @ W.double().t() + b.double()
+    ref = D.selu(ref) if selu else ref
+    assert rel(Y[:, :N], ref) < 2e-6
+    assert bool((Y[:, N:] == 7.0).all())
+    assert float(cells[2].max()) == float(Y[:, :N].abs().max())
+    # dgrad layouts
+    Wt = torch.randn(K, N, generator=g) / K ** 0.5
+    act = torch.randn(M, ops.r4(N), generator=g)
+    refd = (X[:, :K].double() @ Wt.double()) * D.selu_grad_from_out(act[:, :N].double())
+    ops.absmax([Wt.to(DEV)], cells[3:4])
+    dXc = torch.zeros(M, ops.r4(N), device=DEV)
+    ops.gemm(Xd, ops.bf3_pack(Wt.to(DEV), transpose=True, as_f32=True), dXc, M, N, K, lda, ops.r4(K), ops.r4(N),
+             flags=L.EPI_DSELU | F, act=act.to(DEV), ldact=ops.r4(N), a_amax=cells[0], b_amax=cells[3])
+    assert rel(dXc[:, :N], refd) < 2e-6
+    if kernel == "b3p":
+        dXm = torch.zeros(M, ops.r4(N), device=DEV)
+        ops.gemm(Xd, Wt.to(DEV), dXm, M, N, K, lda, N, ops.r4(N), flags=L.EPI_DSELU | L.GEMM_BF3 | L.GEMM_X2,
+                 act=act.to(DEV), ldact=ops.r4(N), b_major=True, a_amax=cells[0], b_amax=cells[3])
+        assert rel(dXm[:, :N], refd) < 2e-6
+        # weight-gradient layout: [dW | db] = dZ^T [X | 1], dZ = act here (its amax by gi_absmax)
+        ops.absmax([act.to(DEV)], cells[3:4])
+        nsplit, ldw = 3, ops.r4(K + 1) + 4
+        stride = ops.r4(N * ldw)
+        C = torch.full((nsplit, stride), 7.0, device=DEV)
+        ops.gemm(act.to(DEV), Xd, C, N, K + 1, M, ops.r4(N), lda, ldw, flags=L.GEMM_SPLITK | L.GEMM_BF3 | L.GEMM_X2,
+                 a_major=True, b_major=True, ones_col=K, nsplit=nsplit, c_split_stride=stride,
+                 a_amax=cells[3], b_amax=cells[0])
+        S = C[:, :N * ldw].view(nsplit, N, ldw)
+        refw = torch.cat([act[:, :N].double().t() @ X[:, :K].double(), act[:, :N].double().sum(0)[:, None]], 1)
+        assert bool((S[:, :, K + 1:] == 7.0).all())
+        assert rel(S[:, :, :K + 1].double().sum(0).cpu(), refw) < 2e-6
+
+
+def test_gemm_fp16x2_needs_both_amax_cells():
+    X = torch.randn(256, 64, device=DEV); W = torch.randn(128, 64, device=DEV); Y = torch.zeros(256, 128, device=DEV)
+    with pytest.raises(RuntimeError, match="GI_EINVAL"):
+        ops.gemm(X, W, Y, 256, 128, 64, 64, 64, 128, flags=L.GEMM_BF3 | L.GEMM_BF3B_F32 | L.GEMM_X2)
+
+
 @pytest.mark.parametrize("b_major", [False, True])
 def test_gemm_split_k_forward_and_dgrad_with_slab_epilogue(b_major, gemm_grid):
     """The skinny, long-reduction layers of the graph-level stacks (B x 500 outputs, K = N*A + G): split-K into

@@ -135,6 +135,18 @@ int main(int argc, char** argv) {
         }
         (void)hipDeviceSynchronize();
     }
+    if (bf3 && getenv("GI_LAB_X2") && atoi(getenv("GI_LAB_X2"))) {     // fp16x2: two scaled fp16 planes, three products
+        float* am; (void)hipMalloc(&am, 64 * 4 * GI_AMAX_WORDS);
+        std::vector<float> hm(64 * GI_AMAX_WORDS, 0.f);
+        for (int i = 0; i < n; ++i) {
+            gi_gemm_params& p = probs[i];
+            for (float v : A[i].h) hm[2 * i * GI_AMAX_WORDS] = fmaxf(hm[2 * i * GI_AMAX_WORDS], fabsf(v));
+            for (float v : B[i].h) hm[(2 * i + 1) * GI_AMAX_WORDS] = fmaxf(hm[(2 * i + 1) * GI_AMAX_WORDS], fabsf(v));
+            p.a_amax = am + 2 * i * GI_AMAX_WORDS; p.b_amax = am + (2 * i + 1) * GI_AMAX_WORDS; p.flags |= GI_GEMM_X2;
+        }
+        (void)hipMemcpy(am, hm.data(), hm.size() * 4, hipMemcpyHostToDevice);
+        printf("[fp16x2] ");
+    }
     auto launch = [&] { const int rc = gi_gemm_batch(probs, n, 0); if (rc) { printf("rc %d\n", rc); exit(1); } };
     for (int i = 0; i < 5; ++i) launch();
     (void)hipDeviceSynchronize();

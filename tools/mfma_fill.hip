@@ -44,8 +44,13 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
                     else asm volatile("v_sub_f32 %0, %1, %2" : "=v"(x[q]) : "v"(x[q]), "v"(u[(q + 2) & 7]));
                 } else if (KIND == 1) {
                     asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(x[q]) : "v"(x[q]), "v"(x[(q + 1) & 7]), "v"(x[(q + 2) & 7]));
-                } else {                               // v_pk_add_f32 on register pairs
+                } else if (KIND == 2) {                // v_pk_add_f32 on register pairs
                     asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(xp[q & 3]) : "v"(xp[q & 3]), "v"(xp[(q + 1) & 3]));
+                } else {                               // the fp16x2 split's mix: v_mul, v_cvt_pk_f16_f32, v_fma_mix_f32
+                    const int m = (j * NF + f) % 3;
+                    if (m == 0) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(x[q]) : "v"(x[(q + 3) & 7]), "v"(x[(q + 5) & 7]));
+                    else if (m == 1) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u[q]) : "v"(x[q]), "v"(x[(q + 1) & 7]));
+                    else asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(x[q]) : "v"(x[(q + 2) & 7]), "v"(x[(q + 4) & 7]), "v"(u[(q + 6) & 7]));
                 }
             }
         }
@@ -70,7 +75,7 @@ static void run(int threads, float* out, unsigned long long* cyc) {
     unsigned long long lo = ~0ull, hi = 0; double own = 0;
     for (int w = 0; w < nw; ++w) { lo = c[2 * w] < lo ? c[2 * w] : lo; hi = c[2 * w + 1] > hi ? c[2 * w + 1] : hi; own += (double)(c[2 * w + 1] - c[2 * w]) / nw; }
     printf("  waves/SIMD %d  fillers/MFMA %2d (%s): %.1f matrix-pipe cycles per MFMA (workgroup span / MFMAs per SIMD), a wave's own loop %.1f cycles per MFMA\n",
-           threads / 256, NF, KIND == 0 ? "split mix" : (KIND == 1 ? "v_fma" : "v_pk_add_f32"),
+           threads / 256, NF, KIND == 0 ? "split mix" : (KIND == 1 ? "v_fma" : (KIND == 2 ? "v_pk_add_f32" : "fp16x2 split mix")),
            (double)(hi - lo) / (iters * 4.0 * (threads / 256)), own / (iters * 4.0));
 }
 
@@ -83,6 +88,7 @@ int main() {
         run<8, 0>(threads, out, cyc); run<12, 0>(threads, out, cyc);
         run<4, 1>(threads, out, cyc); run<6, 1>(threads, out, cyc); run<8, 1>(threads, out, cyc);
         run<2, 2>(threads, out, cyc); run<4, 2>(threads, out, cyc);
+        run<3, 3>(threads, out, cyc); run<5, 3>(threads, out, cyc); run<6, 3>(threads, out, cyc); run<8, 3>(threads, out, cyc);
     }
     return 0;
 }
