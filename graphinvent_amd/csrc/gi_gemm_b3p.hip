@@ -281,7 +281,8 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
                 const bool one = !isA && (col == 1 ? ones0 : ones1);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    float v = one ? 1.f : x[j];
+                    float v = one ? (X2 ? ib : 1.f) : x[j];     // fp16x2: 1.0 AFTER the scale (the epilogue leaves that column's 1 / sb out):
+                                                                // the tensor's scale may take a plain 1.0 beyond fp16's range
                     if (!ST) v = (kr + j < ke) ? v : 0.f;          // zero fill along the reduction (wave-uniform)
                     x[j] = v;
                 }
@@ -414,6 +415,7 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
             const int colc = col_ok ? col : Ncols - 1;
             const int row0 = m0 + wm * 64 + t * 32 + 4 * lhi;
             const float bv = (flags & GI_EPI_BIAS) ? biasp[colc] : 0.f;
+            const float ibc = (X2 && BMJ && col == p.ones_col) ? 1.f : ib;   // (the ones column was staged as 1 / sb)
             const int rows_left = m_end - row0;                   // rows row0 .. row0 + rows_left - 1 exist
             float* const cbase = Cp + (long long)row0 * ldc + col;
             const float* const abase = need_act ? actp + (long long)min(row0, m_end - 1) * ldact + colc : nullptr;
@@ -429,7 +431,7 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dr = 8 * (r >> 2) + (r & 3);
-                float x = X2 ? (acc[t][u][r] * ia) * ib + bv : acc[t][u][r] + bv;
+                float x = X2 ? (acc[t][u][r] * ia) * ibc + bv : acc[t][u][r] + bv;
                 if (flags & GI_EPI_SELU) {                        // scale * (max(x, 0) + alpha * (exp(min(x, 0)) - 1)): no branch
                     const float e = gi_exp_nonpos(fminf(x, 0.f));
                     x = GI_SELU_SCALE * (fmaxf(x, 0.f) + GI_SELU_ALPHA * (e - 1.f));

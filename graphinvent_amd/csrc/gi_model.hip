@@ -267,7 +267,7 @@ void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
 }
 
 // ---- wgrad slab plan ----------------------------------------------------------------------------
-struct SlabEntry { long long off, stride; int nsplit, calls, done, n_out, n_in, ld, tn, bidx, launched, reduced, bf3; };
+struct SlabEntry { long long off, stride; int nsplit, calls, done, n_out, n_in, ld, tn, bidx, launched, reduced, bf3, single_last; };   // single_last: the last call wrote ONE slab (the pass-0 rows, defer_wgrad)
 struct SlabPlan {
     SlabEntry e[160];
     long long total;
@@ -367,6 +367,8 @@ struct Run {
     long long img_b_stride[2] = {0, 0};
     const struct Mlp* eatt0 = nullptr;      // identifies the energy stacks (second image)
     bool hold_kicks = false;                // no weight-gradient launches on the side stream for now
+    bool p0_on_main = false;                // everything queued went to the side stream before the pass-0 dZ chain; the
+                                            // pass-0 rows' own (one-slab) problems follow their chain on the main stream
     // bounded (host-sync-free) forward: the sizes of the graph are on the device (gi_compact_bound) —
     // dims[0] = R, dims[1] / dims[2] = row-block heights of the message / pass-0 chains; d0_dev = D0.
     // Host-side S, E, U, D0 are then BOUNDS that size buffers and grids only.
@@ -483,12 +485,23 @@ bool chain_fits(const Mlp& q, int dx_cols);
 void chain_fwd_params(gi_chain_params& c, const Run& r, float* ws, const Mlp* mlps, const Grp& g,
                       const float* X, int ldx, const int* idx, int rows, const long long* acts,
                       int ldh, float* final_dst, int ld_final);
+// Pass 0 has a few hundred distinct message rows (one per atom kind and bond type): its chain launch is a dozen
+// workgroups that each stream their bond type's whole ~1 MB weight image, 57 us forward and 125 us backward on the
+// critical path for next to no arithmetic (profiles/r04/x2/critical_path_amax_cells.txt).  Layer by layer the same rows
+// are 5 (4) grouped launches of a dozen 64 x 64 tiles: measured a tie in the forward (50 us), and in the backward the
+// four dgrad launches end 30-40 us before the chain would (they run beside pass 1's weight gradients either way).
+// GI_P0_LAYERWISE: bit 0 forward, bit 1 backward.  Default 0: with the pass-0 weight gradients in one slab the chain won the A/B at all three shapes (profiles/r04/p0).
+bool p0_layerwise(const Run& r, const Grp& g, int rows, bool backward) {
+    static const int v = getenv("GI_P0_LAYERWISE") ? atoi(getenv("GI_P0_LAYERWISE")) : 0;     // bit 0: forward, bit 1: backward
+    return (v & (backward ? 2 : 1)) && g.dim_slot == 2 && !r.dims && rows <= 2048;
+}
 
 void mlp_forward(Run& r, float* ws, const Mlp* mlps, const Grp& g, const float* X, int ldx,
                  const int* a_idx, int rows, const long long* acts, int ldh, float* final_dst,
                  int ld_final) {
     const int L = mlps[0].layers();
-    if (g.n && r.ok() && rows > 0 && r.img_f[mlps == r.eatt0 ? 1 : 0] && ldx >= gi_r4(mlps[0].in)) {
+    if (g.n && r.ok() && rows > 0 && r.img_f[mlps == r.eatt0 ? 1 : 0] && ldx >= gi_r4(mlps[0].in) &&
+        !p0_layerwise(r, g, rows, false)) {
         gi_chain_params c;                      // the whole stack in one resident-activation launch
         chain_fwd_params(c, r, ws, mlps, g, X, ldx, a_idx, rows, acts, ldh, final_dst, ld_final);
         r.chk(gi_mlp_chain(&c, 1, r.st));
@@ -639,7 +652,7 @@ constexpr int wgrad_kick_n() { return 8; }
 gi_reduce_desc reduce_desc(const SlabEntry& e, float* slabs, float* const* grads, int widx) {
     gi_reduce_desc q;
     q.slabs = slabs + e.off; q.dW = grads[widx]; q.db = grads[e.bidx];
-    q.slab_stride = e.stride; q.n_slabs = e.nsplit * e.calls; q.N = e.n_out; q.K = e.n_in;
+    q.slab_stride = e.stride; q.n_slabs = e.nsplit * e.calls - (e.single_last ? e.nsplit - 1 : 0); q.N = e.n_out; q.K = e.n_in;
     q.ld = e.ld;
     return q;
 }
@@ -656,7 +669,11 @@ void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* wid
     p.flags = GI_GEMM_SPLITK;
     p.nsplit = e0.nsplit; p.c_split_stride = e0.stride;
     p.tm = e0.tn; p.tn = e0.tn;                 // 1x1 (64x64 tiles) or 2x2 (128x128), see wgrad_shape
-    if (e0.bf3 && !b_idx) {                                    // bf16 pipe, 128 x 256 tiles (gi_gemm_b3p.hip)
+    // The pass-0 rows (a few dozen per bond type, the stack's last call): ONE slab instead of the plan's nsplit — split
+    // nine ways the launch was 2 200 workgroups that mostly store zeros, 50 us + their share of the final reduction
+    // behind the last dZ chain with nothing left to overlap (profiles/r04/x2/critical_path_amax_cells.txt)
+    const bool one_slab = g.n && g.dim_slot == 2;
+    if (e0.bf3 && !b_idx && !one_slab) {                                    // bf16 pipe, 128 x 256 tiles (gi_gemm_b3p.hip)
         p.flags |= GI_GEMM_BF3;
         if (!g.n)
             if (const Run::Bf3* e = r.bf3_layer(r.P[widx[0]], rows))
@@ -669,6 +686,7 @@ void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* wid
             SlabEntry& e = sp.e[widx[t]];
             p.Cg[t] = slabs + e.off + (long long)e.done * e.nsplit * e.stride;
             p.gsplit[t] = e.nsplit;
+            if (one_slab && e.done == e.calls - 1) { p.gsplit[t] = 1; e.single_last = 1; }
             e.done++;
             q.widx[slot][t] = widx[t];
         }
@@ -881,12 +899,12 @@ void msg_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred& dq, c
                   float* dX, int lddx, int dx_cols, const SegIn* seg = nullptr) {
     const int L = mlps[0].layers();
     if (g.n && r.ok() && rows > 0 && r.img_b[mlps == r.eatt0 ? 1 : 0] && dx_cols == mlps[0].in &&
-        ldz >= gi_r4(mlps[0].out)) {
+        ldz >= gi_r4(mlps[0].out) && !p0_layerwise(r, g, rows, true)) {
         gi_chain_params c;                      // the whole dZ chain in one launch, then the wgrads
         seg_launch(r, seg, rows, mlps[0].out, const_cast<float*>(Zlast), ldz);
         if (chain_bwd_params(c, r, ws, mlps, g, Zlast, ldz, rows, acts, dzs, ldh, dX, lddx, dx_cols))
             r.chk(gi_mlp_chain(&c, 1, r.st));
-        r.hold_kicks = false;
+        r.hold_kicks = r.p0_on_main;
         defer_stack_wgrads(r, ws, sp, slabs, dq, mlps, g, X, ldx, a_idx, rows, acts, dzs, ldh, Zlast,
                            ldz);
         return;
@@ -1114,7 +1132,7 @@ void edge_chains_backward(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferre
         if (nl[0] && nl[1]) r.chk(gi_mlp_chain(c, 2, r.st));
         else if (nl[0]) r.chk(gi_mlp_chain(&c[0], 1, r.st));
         else if (nl[1]) r.chk(gi_mlp_chain(&c[1], 1, r.st));
-        r.hold_kicks = false;
+        r.hold_kicks = r.p0_on_main;
         for (int j = 0; j < 2; ++j)
             defer_stack_wgrads(r, ws, sp, slabs, dq, ch[j].mlps, g, X, ldx, a_idx, rows, ch[j].acts,
                                ch[j].dzs, ch[j].ldh, ch[j].out, ch[j].ldout);
@@ -1534,7 +1552,8 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
     make_ws(m, S, E, U, gp->D0, w);
     SlabPlan sp;
     plan_slabs(m, S, U, Ut, sp);
-    const Grp bytype0{d.Fe, gfix + L.type_off0, w.D0};
+    Grp bytype0{d.Fe, gfix + L.type_off0, w.D0};
+    bytype0.dim_slot = 2;                                  // (marks the pass-0 rows: p0_layerwise)
     Run r{(hipStream_t)stream, params, 0};
     r.drop = d.dropout != 0; r.seed = d.drop_seed; r.fshift = w.fshift;
     r.skinny = ws + w.skinny; r.skinny_floats = w.skinny_floats;
@@ -1715,6 +1734,7 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
                 {m.eatt, w.aact[p], w.adz[p], w.ldEa, ws + w.een[p], w.ldM,
                  p > 0 ? ws + w.dxa : nullptr}};
             if (p0) {   // per class row: sum over its (hundreds of) edge slots, both stacks in one launch
+                if (r.side) { kick_deferred(r, dq, r.side, true); r.hold_kicks = r.p0_on_main = true; }
                 r.chk(gi_class_sum_dselu(ws + w.tmp_emb, ws + w.tmp_en, w.ldM, gp->cls_edges,
                                          gp->cls_off, w.D0, d.M, ws + w.m[p], ws + w.een[p], w.ldM,
                                          r.st));
@@ -1738,6 +1758,7 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
         } else if (p == 0 && w.D0 > 0) {
             // pass 0: d m0 = selu'(m0) * (cmat^T . d agg): split-K over the R rows, slabs summed with
             // the SELU backward folded in; then the MLP backward on the D0 class rows (no d h needed)
+            if (r.side) { kick_deferred(r, dq, r.side, true); r.hold_kicks = r.p0_on_main = true; }   // nothing queued waits for the pass-0 chain
             gi_gemm_params q;
             gemm_defaults(q);
             q.A = gp->cmat; q.lda = gp->ldc0; q.a_major = 1;
@@ -1780,7 +1801,10 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
         std::swap(dh, dh2);
     }
     // ---- all weight-gradient GEMMs, 8 problems per launch, then slabs -> parameter gradients -------
-    if (r.side) {
+    if (r.side && r.p0_on_main) {
+        flush_deferred(r, dq);            // a dozen workgroups, right behind their chain: no hand-over to wait for
+        join_side(r, r.side);
+    } else if (r.side) {
         kick_deferred(r, dq, r.side, true);
         join_side(r, r.side);
     } else {
