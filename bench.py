@@ -13,12 +13,16 @@ passes, GDB-13-shaped graphs (max_n_nodes 13, 5 atom types x 3 charges, 3 bond t
 PER GPU (weak scaling).  fp32 throughout (the reference's dtype and the parity bar).
 
 Rank 0 prints one JSON line.  Besides the contract fields it carries
-  roofline      dominant kernel family (fp32-MFMA GEMM): useful FLOP/s measured with HIP events
+  roofline      dominant kernel family (fp32-accurate GEMM): useful FLOP/s measured with HIP events
                 around every launch on the stream it runs on (gi_prof_*), over extra profiled steps
                 of the same workload, against the 157.3 TFLOP/s fp32 matrix peak; achieved = FLOP /
                 SUM of the launch durations = flop_per_launch / avg_launch_us, the per-launch figure
                 the rocprofv3 kernel stats under profiles/ reproduce (the backward runs GEMMs on two
-                streams at once: the FLOP / union-of-intervals figure is reported next to it)
+                streams at once: the FLOP / union-of-intervals figure is reported next to it).
+                `frac` divides ALL useful flops by the fp32 MFMA peak, which flatters the launches that run as
+                bf16x3 / fp16x2 splits on the 16-bit pipe; `frac_own_pipe` prices every launch against the pipe it
+                ran on (157.3; 2382 / 6 = 397; 2382 / 3 = 794 fp32-equivalent TFLOP/s) = sum of the ideal launch
+                times / sum of the measured ones, and `pipes` lists the three groups
   extra_configs the non-headline BASELINE configurations on this GPU (configs[2]: GGNN on
                 ZINC-shaped graphs B=1000; configs[4] per-GPU work: AttentionGGNN on ChEMBL-shaped
                 graphs B=250), a few timed steps each
@@ -57,7 +61,11 @@ from graphinvent_amd.loss import apd_kl_loss                 # noqa: E402
 BATCH = 1000
 N_BATCHES = 4                  # distinct resident minibatches cycled through
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PROFILE_DIR = "r03"            # profiles/<dir>/: rocprofv3 kernel stats + PMC passes of this command
+# fp32-EQUIVALENT peaks of the split launches: the 16-bit MFMA's dense peak (MI355X_MICROARCH.md: 2 382 TFLOP/s for
+# v_mfma_f32_32x32x16_bf16 / _f16) over the products one fp32 product costs (6 bf16, 3 f16)
+PEAK_16BIT_MFMA_TFLOPS = 2382.0
+PIPES = (("fp32_mfma", PEAK_FP32_MFMA_TFLOPS), ("bf16x3", PEAK_16BIT_MFMA_TFLOPS / 6), ("fp16x2", PEAK_16BIT_MFMA_TFLOPS / 3))
+PROFILE_DIR = "r04"            # profiles/<dir>/: rocprofv3 kernel stats + PMC passes of this command
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
 
 
@@ -163,6 +171,8 @@ def workload_text(shape, model_name, cfg):
 EXTRA_CONFIGS = (  # (BASELINE.json entry, shape, model, graphs per GPU per step)
     ("configs[2]: GGNN on ZINC-250k-shaped graphs, batch=1000", "zinc", "ggnn", 1000),
     ("configs[4] per-GPU work: AttGGNN on ChEMBL-shaped graphs max_n_nodes=88", "chembl", "attggnn", 250),
+    ("NOT a BASELINE config: the headline model and graphs at batch=4000 (where the launches fill the device)",
+     "gdb13", "ggnn", 4000),
 )
 
 
@@ -266,6 +276,20 @@ def generation_loop(model, cfg, batches, device, rounds: int):
                    "rounds; this rank only.  sync_free: no read-back, buffers sized for 4 B N directed edges "
                    "(1.8x / 4x the real node / edge rows of these batches)" % nodes.shape[0])
     return out
+
+
+def own_pipe(handle):
+    """(frac_own_pipe, per-pipe table) of the last gi_prof_collect: every GEMM launch against the matrix pipe it ran on."""
+    ms = (C.c_double * 3)(); work = (C.c_double * 3)(); n = (C.c_int * 3)()
+    lib.check(handle.gi_prof_pipes(ms, work, n), "gi_prof_pipes")
+    ideal = sum(work[i] / (peak * 1e12) for i, (_, peak) in enumerate(PIPES))          # seconds at peak
+    total = sum(ms) * 1e-3
+    table = {}
+    for i, (name, peak) in enumerate(PIPES):
+        tf = work[i] / (ms[i] * 1e-3) / 1e12 if ms[i] > 0 else 0.0
+        table[name] = {"launches": n[i], "gflop": round(work[i] / 1e9, 2), "sum_of_launch_ms": round(ms[i], 3),
+                       "achieved": round(tf, 2), "peak_fp32_equivalent": round(peak, 1), "frac": round(tf / peak, 4)}
+    return (round(ideal / total, 4) if total > 0 else 0.0), table
 
 
 def committed_traffic():
@@ -443,9 +467,13 @@ def main():
     }
     result["config"]["fuse_flags"] = int(lib.load().gi_fuse_flags())     # GI_FUSE_* variants in use
     result["config"]["gemm_arithmetic"] = (
-        "fp32 operands, fp32 accumulate everywhere; node-level readout layers >= 192 wide (6 of the 41 GEMM-family "
-        "launches per step) as three-way bf16 splits on the bf16 MFMA pipe (six bf16 products per fp32 product, "
-        "max error against the fp64 product 4e-7 relative, the fp32 MFMA chain's own: 5e-7), everything else on v_mfma_f32_32x32x2_f32"
+        "fp32 operands, fp32 accumulate everywhere; the node-level readout layers >= 192 wide (forward, dgrad and weight "
+        "gradients: 8 of the GEMM-family launches per step, roofline.pipes) split every fp32 operand into "
+        + ("two scaled fp16 values (three f16 MFMA products per fp32 product, per-tensor power-of-two scale from the "
+           "tensor's largest magnitude)" if lib.load().gi_x2_enable(-1) else
+           "three bf16 values (six bf16 MFMA products per fp32 product)")
+        + ": max error against the fp64 product 3e-7 relative, the fp32 MFMA chain's own: 5e-7 "
+          "(tests/test_kernels_gpu.py); everything else on v_mfma_f32_32x32x2_f32"
         if lib.load().gi_bf3_enable(-1) else "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere")
     # graph_compact's sizes: found on the host (counting phase one batch ahead) / read back behind the stream
     result["config"]["compact_readbacks_timed_steps"] = first_readbacks
@@ -518,10 +546,11 @@ def main():
         # concurrently with the dZ chain, so FLOP / union-of-intervals is higher; reported next to it.
         tf_union = work[0] / (busy[0] * 1e-3) / 1e12 if busy[0] > 0 else 0.0
         tf = work[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
+        own, pipes = own_pipe(handle)
         result["roofline"] = {
-            "bound": "mfma", "kernel": "gi_gemm*/gi_chain* (fp32 MFMA GEMM family, v_mfma_f32_32x32x2_f32)",
+            "bound": "mfma", "kernel": "gi_gemm*/gi_chain*/gi_b3p* (fp32-accurate GEMM family: fp32 MFMA, bf16x3 and fp16x2 splits)",
             "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), **committed_traffic(),
+            "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "frac_own_pipe": own, "pipes": pipes, **committed_traffic(),
             "launches_per_step": n[0] // prof_steps,
             "avg_launch_us": round(ms[0] * 1e3 / max(n[0], 1), 2),
             "flop_per_launch": round(work[0] / max(n[0], 1)),
@@ -564,18 +593,21 @@ def main():
                 lib.check(handle.gi_prof_collect(ms1, busy1, work1, n1), "gi_prof_collect")
                 handle.gi_prof_enable(0)
                 tf1 = work1[0] / (ms1[0] * 1e-3) / 1e12 if ms1[0] > 0 else 0.0
+                own1, pipes1 = own_pipe(handle)
                 result["roofline"]["one_stream"] = {
                     "achieved": round(tf1, 2), "frac": round(tf1 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "frac_own_pipe": own1, "pipes": pipes1,
                     "avg_launch_us": round(ms1[0] * 1e3 / max(n1[0], 1), 2),
                     "ms_per_step": round(d1 / k1 * 1e3, 3),
                     "note": "mpnn.WGRAD_SIDE_STREAM=False: no two GEMM launches share the device; the step is "
                             "slower than the product path (ms_per_step above), the launches are shorter"}
         finally:
             mpnn.WGRAD_SIDE_STREAM = True
-    # The same step with every GEMM on the fp32 MFMA (gi_bf3_enable(0)): by default the six node-level
-    # hidden-layer launches of a step (forward + dgrad, K = N = 250 / 500) run as bf16x3 splits on the bf16 MFMA
-    # pipe — fp32 operands, fp32 accumulate, the same result to ~3e-7 (tests/test_kernels_gpu.py) — reported
-    # next to the headline so that the effect of that choice is visible, never instead of it.
+    # The same step with every GEMM on the fp32 MFMA (gi_bf3_enable(0)), and with the split launches as bf16x3 instead
+    # of fp16x2 (gi_x2_enable(0)): by default the node-level hidden-layer launches of a step (forward, dgrad, weight
+    # gradients, K = N = 250 / 500) run as fp16x2 splits on the 16-bit MFMA pipe — fp32 operands, fp32 accumulate, the
+    # same result to ~3e-7 (tests/test_kernels_gpu.py) — reported next to the headline so that the effect of that
+    # choice is visible, never instead of it.
     if not args.no_one_stream:
         was = handle.gi_bf3_enable(0)
         try:
@@ -585,7 +617,17 @@ def main():
         if rank == 0:
             result["fp32_mfma_only"] = {"ms_per_step": round(d0 / 8 * 1e3, 3),
                                         "value": round(BATCH * world * 8 / d0, 1), "unit": "graphs/s",
-                                        "note": "gi_bf3_enable(0) / GI_BF3=0: no bf16x3 launches"}
+                                        "note": "gi_bf3_enable(0) / GI_BF3=0: no launches on the 16-bit pipe"}
+        if handle.gi_x2_enable(-1):
+            handle.gi_x2_enable(0)
+            try:
+                d3, _ = timed_steps(wl, 8, 2, world, device)
+            finally:
+                handle.gi_x2_enable(1)
+            if rank == 0:
+                result["bf16x3_only"] = {"ms_per_step": round(d3 / 8 * 1e3, 3),
+                                         "value": round(BATCH * world * 8 / d3, 1), "unit": "graphs/s",
+                                         "note": "gi_x2_enable(0) / GI_X2=0: the split launches as three bf16 planes"}
     if rank == 0 and not args.no_forward_only:
         # forward-only rate: inference on the same resident batches, no_grad
         model.eval()

@@ -74,6 +74,8 @@ int gi_p0_cache_insert(const int* gfix, int B, int N, int Fe, int* cache, int nf
 // When enabled, gi_gemm / gi_seg_sum bracket each kernel launch with hipEvents on the launch
 // stream; gi_prof_collect synchronises and sums the elapsed times.  Off by default (zero cost).
 enum { GI_PROF_GEMM = 0, GI_PROF_SEGSUM = 1, GI_PROF_KINDS = 2 };
+// matrix pipe of a GEMM launch, in bits 8.. of the kind: 0 fp32 MFMA, 1 bf16 MFMA (bf16x3 split), 2 f16 MFMA (fp16x2 split)
+enum { GI_PROF_PIPE_BF3 = 1 << 8, GI_PROF_PIPE_X2 = 2 << 8, GI_PROF_PIPES = 3 };
 bool gi_prof_on();
 void gi_prof_push(int kind, double work, hipEvent_t start, hipEvent_t stop);
 struct GiProfScope {

@@ -572,7 +572,7 @@ int gi_b3p_launch(const gi_gemm_params* probs, int n, void* stream) {
             return (int)hipGetLastError();
         g_b3p_attr_set[x2 ? 1 : 0][li][epi] = true;
     }
-    GiProfScope prof(st, GI_PROF_GEMM, flops);
+    GiProfScope prof(st, GI_PROF_GEMM | (x2 ? GI_PROF_PIPE_X2 : GI_PROF_PIPE_BF3), flops);
     gi_gemm_log_launch(x2 ? (am ? "y2" : (bmj ? "y1" : "y0")) : (am ? "p2" : (bmj ? "p1" : "p0")), b.p, k, total, flops);
     int grid = total;
     if (g_b3p_stream_cus < 0) {

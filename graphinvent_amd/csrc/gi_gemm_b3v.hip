@@ -443,7 +443,7 @@ int gi_b3v_launch(const gi_gemm_params* probs, int n, void* stream) {
     for (int i = 0; i < k; ++i) bounded |= b.p[i].m_dev != nullptr;
     b.remap = (total >= 512 && !bounded && !am) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    GiProfScope prof(st, GI_PROF_GEMM, flops);
+    GiProfScope prof(st, GI_PROF_GEMM | GI_PROF_PIPE_BF3, flops);
     gi_gemm_log_launch(am ? "b2" : (bmj ? "b1" : "b0"), b.p, k, total, flops);
 #define GV_LAUNCH(A, B, E) hipLaunchKernelGGL((gi_b3v_kernel<A, B, E>), dim3(total), dim3(256), 0, st, b)
     if (am) { if (epi == 3) GV_LAUNCH(true, true, 3); else GV_LAUNCH(true, true, 0); }

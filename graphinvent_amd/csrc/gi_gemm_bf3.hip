@@ -500,7 +500,7 @@ int gi_gemm_bf3_launch(const gi_gemm_params* probs, int n, void* stream) {
         b.remap = (total >= 512 && !bounded) ? 1 : 0;       // (bounded: the order would be over the bound's tiles)
     }
     hipStream_t st = (hipStream_t)stream;
-    GiProfScope prof(st, GI_PROF_GEMM, flops);
+    GiProfScope prof(st, GI_PROF_GEMM | (x2 ? GI_PROF_PIPE_X2 : GI_PROF_PIPE_BF3), flops);
     gi_gemm_log_launch(x2 ? ((b.p[0].flags & GI_EPI_BIAS) ? "x0" : "x1") : ((b.p[0].flags & GI_EPI_BIAS) ? "b0" : "b1"), b.p, k,
                        total, flops);
 #define GI_B3_LAUNCH(E, A, F) hipLaunchKernelGGL((gi_gemm_bf3_kernel<E, A, F>), dim3(total), dim3(256), 0, st, b)

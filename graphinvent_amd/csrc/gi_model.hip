@@ -715,29 +715,33 @@ void launch_wgrad_batch(Run& r, const gi_gemm_params* p, int n, hipStream_t st) 
 // consecutive queued problems, up to 8 per launch; the bf16x3 ones (one workgroup per CU, equal tiles) are packed
 // separately, biggest first, into launches of about one round of the device
 void launch_wgrad_batches(Run& r, const gi_gemm_params* p, int n, hipStream_t st) {
-    gi_gemm_params rest[96], b3[96];
-    int nr = 0, n3 = 0;
+    gi_gemm_params rest[96], b3[2][96];                           // b3[0]: bf16x3, b3[1]: fp16x2 (a launch is one or the other)
+    int nr = 0, n3[2] = {0, 0};
     for (int i = 0; i < n; ++i) {
-        if (p[i].flags & GI_GEMM_BF3) b3[n3++] = p[i]; else rest[nr++] = p[i];
+        if (p[i].flags & GI_GEMM_BF3) { const int x = (p[i].flags & GI_GEMM_X2) ? 1 : 0; b3[x][n3[x]++] = p[i]; }
+        else rest[nr++] = p[i];
     }
     auto tiles = [](const gi_gemm_params& q) {
         int zs = q.nsplit;
         if (q.ngroups) { zs = 0; for (int g = 0; g < q.ngroups; ++g) zs += q.gsplit[g]; }
         return gi_cdiv(q.M, 128) * gi_cdiv(q.N, 256) * zs;
     };
-    for (int i = 1; i < n3; ++i)                                  // stable insertion sort, most tiles first
-        for (int j = i; j > 0 && tiles(b3[j]) > tiles(b3[j - 1]); --j) std::swap(b3[j], b3[j - 1]);
     static const int cus = [] {
         int dev = 0, c = 0;
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
         return c;
     }();
-    for (int base = 0; base < n3 && r.ok();) {
-        int k = 0, t = 0;
-        while (base + k < n3 && k < 8 && (k == 0 || t + tiles(b3[base + k]) <= cus)) { t += tiles(b3[base + k]); ++k; }
-        r.chk(gi_gemm_batch(b3 + base, k, st));
-        base += k;
+    for (int x = 1; x >= 0; --x) {
+        gi_gemm_params* q = b3[x];
+        for (int i = 1; i < n3[x]; ++i)                           // stable insertion sort, most tiles first
+            for (int j = i; j > 0 && tiles(q[j]) > tiles(q[j - 1]); --j) std::swap(q[j], q[j - 1]);
+        for (int base = 0; base < n3[x] && r.ok();) {
+            int k = 0, t = 0;
+            while (base + k < n3[x] && k < 8 && (k == 0 || t + tiles(q[base + k]) <= cus)) { t += tiles(q[base + k]); ++k; }
+            r.chk(gi_gemm_batch(q + base, k, st));
+            base += k;
+        }
     }
     for (int base = 0; base < nr && r.ok(); base += 8) launch_wgrad_batch(r, rest + base, std::min(8, nr - base), st);
 }

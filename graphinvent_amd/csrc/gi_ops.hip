@@ -812,6 +812,8 @@ namespace {
 struct ProfRec { int kind; double work; hipEvent_t a, b; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
+double g_pipe_ms[GI_PROF_PIPES], g_pipe_work[GI_PROF_PIPES];
+int g_pipe_n[GI_PROF_PIPES];
 }  // namespace
 bool gi_prof_on() { return g_prof_on; }
 void gi_prof_push(int kind, double work, hipEvent_t a, hipEvent_t b) { g_prof.push_back({kind, work, a, b}); }
@@ -824,6 +826,7 @@ extern "C" int gi_prof_enable(int on) {
 extern "C" int gi_prof_collect(double* ms, double* busy_ms, double* work, int* launches) {
     if (!ms || !busy_ms || !work || !launches) return GI_EINVAL;
     for (int k = 0; k < GI_PROF_KINDS; ++k) { ms[k] = 0; busy_ms[k] = 0; work[k] = 0; launches[k] = 0; }
+    for (int k = 0; k < GI_PROF_PIPES; ++k) { g_pipe_ms[k] = 0; g_pipe_work[k] = 0; g_pipe_n[k] = 0; }
     int rc = 0;
     if (g_prof.empty()) return 0;
     for (ProfRec& r : g_prof) (void)hipEventSynchronize(r.b);
@@ -835,8 +838,10 @@ extern "C" int gi_prof_collect(double* ms, double* busy_ms, double* work, int* l
         float t = 0.f, t0 = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) rc = GI_EINVAL;
         if (hipEventElapsedTime(&t0, base, r.a) != hipSuccess) rc = GI_EINVAL;
-        ms[r.kind] += t; work[r.kind] += r.work; launches[r.kind] += 1;
-        iv[r.kind].push_back({(double)t0, (double)t0 + t});
+        const int kind = r.kind & 0xff, pipe = std::min(r.kind >> 8, GI_PROF_PIPES - 1);
+        ms[kind] += t; work[kind] += r.work; launches[kind] += 1;
+        iv[kind].push_back({(double)t0, (double)t0 + t});
+        if (kind == GI_PROF_GEMM) { g_pipe_ms[pipe] += t; g_pipe_work[pipe] += r.work; g_pipe_n[pipe] += 1; }
     }
     for (int k = 0; k < GI_PROF_KINDS; ++k) {
         std::sort(iv[k].begin(), iv[k].end());
@@ -849,6 +854,13 @@ extern "C" int gi_prof_collect(double* ms, double* busy_ms, double* work, int* l
     for (ProfRec& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();
     return rc;
+}
+
+// the GEMM family of the LAST gi_prof_collect by matrix pipe: [0] fp32 MFMA, [1] bf16 MFMA (bf16x3), [2] f16 MFMA (fp16x2)
+extern "C" int gi_prof_pipes(double* ms, double* work, int* launches) {
+    if (!ms || !work || !launches) return GI_EINVAL;
+    for (int k = 0; k < GI_PROF_PIPES; ++k) { ms[k] = g_pipe_ms[k]; work[k] = g_pipe_work[k]; launches[k] = g_pipe_n[k]; }
+    return 0;
 }
 
 // ================================ C ABI ==========================================================

@@ -167,6 +167,7 @@ SIGNATURES = {
     "gi_scale_by_scalar": (ci, [vp, cll, vp, vp]),
     "gi_prof_enable": (ci, [ci]),
     "gi_prof_collect": (ci, [vp, vp, vp, vp]),
+    "gi_prof_pipes": (ci, [vp, vp, vp]),
     "gi_sample_actions": (ci, [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]),
     "gi_side_stream_create": (ci, [C.POINTER(vp)]),
     "gi_side_stream_destroy": (ci, [vp]),

@@ -543,6 +543,10 @@ int gi_sample_actions(const float* logits, int ldl, const float* uniform, const 
  * 2*M*N*K; seg_sum: 0, the caller knows the bytes) and the number of launches; it clears the log. */
 int gi_prof_enable(int on);
 int gi_prof_collect(double* ms, double* busy_ms, double* work, int* launches);
+/* The GEMM family of the LAST gi_prof_collect split by the matrix pipe the launch ran on — [0] fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32), [1] bf16 MFMA (GI_GEMM_BF3: six bf16 products per fp32 product), [2] f16 MFMA (GI_GEMM_X2:
+ * three f16 products): summed elapsed ms, useful flops 2*M*N*K and launches, three entries each. */
+int gi_prof_pipes(double* ms, double* work, int* launches);
 
 /* ------------------------------------------------------------------------------------------
  * Whole-model entry points: one call enqueues the complete GGNN forward (or backward) —

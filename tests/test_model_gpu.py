@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from graphinvent_amd import ops, synthetic
+from graphinvent_amd import lib as L, ops, synthetic
 from graphinvent_amd.gnn import mpnn
 from oracle import ggnn_oracle as O
 from tests import pins
@@ -397,6 +397,34 @@ def test_bench_batch_gradients_1e4_vs_fp32_oracle_autograd(shape, B, over, cpu_t
     grads, _ = mpnn.ggnn_backward_raw(tape_hip, out, o_leaf.grad, params)
     names = [k for k, _ in model.named_parameters()]
     assert_parity_with_both_pins(O, P, cfg, "GGNN", n8, e8, a8, out, loss, names, grads, signs, g, mask_pin)
+
+
+def test_batch_4000_every_16bit_pipe_launch_class_against_the_fp32_mfma_step():
+    """bench.py's B = 4000 extra configuration: from 4 000 graphs on the GRAPH-LEVEL stacks' weight gradients run on the
+    16-bit pipe too (bf16x3: their operands have no amax cells) beside the node-level ones (fp16x2) — two launch
+    classes that must not share a launch (round 4: they did, GI_EINVAL).  Every gradient tensor of the step agrees with
+    the same step on the fp32 MFMA alone (gi_bf3_enable(0)) far inside the parity bar, logits and loss likewise."""
+    sh = synthetic.SHAPES["gdb13"]
+    cfg = O.shaped_config(sh["n_atom_types"], sh["n_formal_charge"], sh["max_n_nodes"], hidden_node_features=128,
+                          message_size=128)
+    model = make_model(cfg, O.init_params(cfg, seed=4))
+    n8, e8, a8 = synthetic.make_batch(4000, **sh, seed=0)
+    lib = L.load()
+    was = lib.gi_bf3_enable(1)
+    try:
+        out1, loss1, g1 = hip_forward_backward(model, n8, e8, a8)
+        lib.gi_bf3_enable(0)
+        out0, loss0, g0 = hip_forward_backward(model, n8, e8, a8)
+    finally:
+        lib.gi_bf3_enable(was)
+    assert rel(out1, out0) < 2e-5 and abs(loss1 - loss0) < 2e-5 * abs(loss0)
+    worst = max((rel(g1[k], g0[k]), k) for k in g0)
+    print("\nB = 4000: worst gradient tensor against the fp32-MFMA-only step", worst)
+    # (SELU ties at the kink flip between two correct fp32 evaluations and move single tensors by up to 5.6e-3 of
+    #  max |g| in the reference's own fp32 / fp64 runs, DESIGN.md section 2; a mis-scaled or missing launch is O(1))
+    num = sum(float((g1[k].double() - g0[k].double()).pow(2).sum()) for k in g0)
+    den = sum(float(g0[k].double().pow(2).sum()) for k in g0)
+    assert worst[0] < 1e-2 and (num / den) ** 0.5 < 1e-3, (worst, (num / den) ** 0.5)
 
 
 def test_full_batch_properties():
