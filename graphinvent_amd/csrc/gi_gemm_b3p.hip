@@ -486,6 +486,8 @@ bool gi_b3p_eligible(const gi_gemm_params* probs, int n) {
     // quantises badly below ~2.5 tiles per CU (measured at the headline batch, 348 tiles: 75 us against 70 us for the
     // three-workgroups-per-CU kernel of round 3; at 26 000 rows, 1 224 tiles: 225 against 244 us)
     if (!probs[0].a_major && tiles < 640 && !getenv("GI_B3P_ALL")) return false;
+    static const bool grouped_to_b3v = getenv("GI_B3V_GROUPED") && atoi(getenv("GI_B3V_GROUPED"));   // (measurement aid)
+    if (probs[0].a_major && probs[0].ngroups && grouped_to_b3v) return false;
     for (int i = 0; i < n; ++i) {
         const gi_gemm_params& p = probs[i];
         if (!(p.flags & GI_GEMM_BF3) || (p.flags & GI_GEMM_BF3A)) return false;

@@ -49,7 +49,15 @@ def _check(d, world: int, backend: str, batch: int = 1000):
               "exposed_ms_overlapped", "exposed_ms_after_backward"):
         assert isinstance(ar[k], float) and ar[k] == ar[k], k
     assert ar["bucket_MB"] > 20
-    assert d["roofline"]["frac"] > 0 and d["roofline"]["bound"] == "mfma"
+    rf = d["roofline"]
+    assert rf["frac"] > 0 and rf["bound"] == "mfma"
+    # every launch priced against the pipe it ran on: the three groups add up to the family, and the own-pipe
+    # fraction can only be below the all-against-fp32 one when launches ran on the faster 16-bit pipe
+    pipes = rf["pipes"]
+    assert set(pipes) == {"fp32_mfma", "bf16x3", "fp16x2"}
+    assert sum(p["launches"] for p in pipes.values()) == rf["launches_per_step"] * 3
+    assert abs(sum(p["gflop"] for p in pipes.values()) - rf["useful_gflop_per_step"] * 3) < 0.02 * rf["useful_gflop_per_step"] * 3
+    assert 0 < rf["frac_own_pipe"] <= rf["frac"] + 1e-4
     assert "overlapped" in d["config"]["allreduce"]
 
 

@@ -72,6 +72,10 @@ int main(int argc, char** argv) {
         memcpy(dims, w, sizeof(w));
     }
     if (getenv("GI_LAB_N")) n = atoi(getenv("GI_LAB_N")) < n ? atoi(getenv("GI_LAB_N")) : n;   // only the first problems
+    if (getenv("GI_LAB_SQ") && !wgrad) {               // GI_LAB_SQ=250: three square problems (one message layer, one per bond type)
+        n = 3;
+        for (int i = 0; i < n; ++i) dims[i][0] = dims[i][1] = atoi(getenv("GI_LAB_SQ"));
+    }
     gi_gemm_params probs[8];
     Mat A[8], B[8], Cm[8], bias[8], act[8];
     int ldb_host[8] = {};                              // leading dimension of the host copy B[i].h (p.ldb may change with the operand form)
