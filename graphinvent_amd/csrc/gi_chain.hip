@@ -553,6 +553,11 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
             image_bytes += (long long)chains[c].ngroups * chain_tiles(chains[c]) * CH_TILE * 4;
         big = image_bytes > (4LL << 20) && 1.15 * gi_cdiv(blocks(2 * CH_ROWS), ncu) < 0.9 * rounds;
     }
+    {   // (measurement aid) GI_CHAIN_BWD64=1: 64-row blocks for the dZ chains of the message passes only — half the
+        // workgroups, so half the CUs stay free for the weight-gradient queue that runs beside every backward chain
+        static const bool bwd64 = getenv("GI_CHAIN_BWD64") && atoi(getenv("GI_CHAIN_BWD64"));
+        if (bwd64 && rows64 < 0 && chains[0].backward && blocks(CH_ROWS) >= ncu / 2) big = true;
+    }
     if (g_chain_cfg.tile_rows > 0) {                        // tests / measurements: force a height
         h = std::min(std::max(g_chain_cfg.tile_rows, CH_ROWS), CH_ROWS + CH_XMAX);
         big = false;
