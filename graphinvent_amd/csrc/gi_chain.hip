@@ -36,6 +36,7 @@
 #include <algorithm>
 
 #include "gi_mfma.h"
+#include "gi_x2.h"
 
 namespace {
 
@@ -437,6 +438,310 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
     }
 }
 
+// ======================================================================================================
+// fp16x2 variant (gi_chain_params.x2_wamax != NULL; csrc/gi_x2.h): the same chain with every fp32 operand as two scaled
+// fp16 values and three v_mfma_f32_32x32x16_f16 products per fp32 product — 12 MFMAs of 32 cycles per wave and 32-deep
+// weight tile for 64 rows where the fp32 kernel spends 16 of 64 cycles for 32.  With the matrix work out of the way a
+// workgroup can carry 64 rows without becoming MFMA-bound: HALF the weight stream per row (the stream is what bounds the
+// fp32 kernel at one 32-row block per CU) on half the CUs, the other half free for the weight-gradient queue that runs
+// beside every backward chain.
+//   * weight image: the same 32 KB per 32-deep tile, now [plane 2][k chunk of 8: 4][column 256][8 halves] — the B
+//     fragment of column n and k chunk c is one ds_read_b128 — scaled per (layer, bond type) by a power of two from
+//     max |W| (gi_mlp_chain_pack computes it into x2_wamax first); streamed by the same LDS-DMA two-slot ring;
+//   * activation tile: [plane 2][k chunk of 8: 32][row 64][8 halves] = 64 KB, scaled PER ROW BLOCK AND LAYER by a power
+//     of two from the largest magnitude of the 64 x 256 tile (a maximum per wave -> LDS -> the epilogue's own barrier):
+//     no global atomics; the epilogue splits the new activations and rewrites the tile in place.  The last bits of a
+//     row therefore depend on which rows share its block — which is why gi_ggnn_backward uses this variant for its dZ
+//     chains and gi_ggnn_forward keeps the fp32 chain, whose rows are bit-independent (blocking against host-sync-free
+//     forward, forwards with and without a tape, the pass-0 row cache).  A per-ROW scale was built and measured: exact row independence,
+//     and 160 cross-lane maxima per layer and thread that cost more than the variant gains (profiles/r04/chain_x2/);
+//   * C = acc / (sa sb) + bias in the epilogue; everything behind it (SELU, SELU', HBM stores) as in the fp32 kernel.
+// 64 rows per workgroup, no extra VALU rows; bounded launches walk 64-row blocks (the device-side height is not used).
+constexpr int CX_ROWS = 64;
+constexpr int CX_PLANE = 32 * CX_ROWS * 16;                 // bytes of one activation plane (32 KB)
+__device__ __forceinline__ unsigned cx_a_off(int plane, int chunk, int row) {
+    return (unsigned)(plane * CX_PLANE + (chunk * CX_ROWS + row) * 16);
+}
+__device__ __forceinline__ unsigned cx_b_off(int plane, int chunk, int col) {
+    return (unsigned)(((plane * 4 + chunk) * CH_W + col) * 16);
+}
+
+__global__ __launch_bounds__(256) void gi_chain_pack_x2_kernel(const PackArgs a) {
+    const gi_chain_params& P = a.c;
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;      // one 16-byte piece (8 halves of a plane) each
+    const long long per_group = (long long)a.tiles * (CH_TILE / 4);      // (whole waves only: 2 048 pieces per tile)
+    const int g = (int)(id / per_group);
+    const int rem = (int)(id - (long long)g * per_group);
+    int tile = rem / (CH_TILE / 4);
+    const int q = rem - tile * (CH_TILE / 4);
+    int l = 0;
+    for (;;) {
+        const int nk = (P.layer[l].K + CH_KT - 1) / CH_KT;
+        if (tile < nk) break;
+        tile -= nk; ++l;
+    }
+    const gi_chain_layer& Ly = P.layer[l];
+    const float* __restrict__ W = Ly.W[g];
+    const int K = Ly.K, N = Ly.N;
+    const int plane = q >> 10, chunk = (q >> 8) & 3, n = q & (CH_W - 1);
+    const int k0 = tile * CH_KT + chunk * 8;
+    float s, inv;
+    gx_scale(gx_amax_read(P.x2_wamax + ((long long)l * P.ngroups + g) * GI_AMAX_WORDS), s, inv);
+    float w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        const bool ok = n < N && k < K;
+        const long long at = !P.backward ? (long long)n * K + k : (long long)k * N + n;   // B[n][k] = W[n][k] / W[k][n]
+        w[j] = ok ? W[ok ? at : 0] : 0.f;
+    }
+    unsigned o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned p0, p1;
+        gx_split2(w[2 * j], w[2 * j + 1], s, p0, p1);
+        o[j] = plane ? p1 : p0;
+    }
+    typedef unsigned cx_u32x4 __attribute__((ext_vector_type(4)));
+    cx_u32x4 v = {o[0], o[1], o[2], o[3]};
+    reinterpret_cast<cx_u32x4*>(P.image)[id] = v;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) {
+    __shared__ __attribute__((aligned(16))) unsigned char Ah[2 * CX_PLANE];
+    __shared__ __attribute__((aligned(1024))) float Bs[2 * CH_TILE];
+    __shared__ float red[8];                                // per wave: max |new activation|
+    typedef unsigned cx_u32x2 __attribute__((ext_vector_type(2)));
+    if (args.c[0].skip_flag && *args.c[0].skip_flag != 0) return;
+    for (int id = blockIdx.x; id < args.chain_off[args.nchains]; id += gridDim.x) {
+    const int ci = (args.nchains > 1 && id >= args.chain_off[1]) ? 1 : 0;
+    const gi_chain_params& P = args.c[ci];
+    const int local = id - args.chain_off[ci];
+    int g = 0, first = 0;
+    if (args.dev_tiles) {                                    // row blocks of the groups, counted on the device
+        for (; g < P.ngroups; ++g) {
+            const int rows = __builtin_amdgcn_readfirstlane(P.grp_off[g + 1] - P.grp_off[g]);
+            const int nb = (rows + CX_ROWS - 1) / CX_ROWS;
+            if (local < first + nb) break;
+            first += nb;
+        }
+        if (g == P.ngroups) continue;                        // beyond the real row blocks
+    } else {
+        while (g < P.ngroups - 1 && local >= args.tile_off[ci][g + 1]) ++g;
+        first = args.tile_off[ci][g];
+    }
+    const int lo = P.grp_off ? __builtin_amdgcn_readfirstlane(P.grp_off[g]) : 0;
+    const int hi = P.grp_off ? __builtin_amdgcn_readfirstlane(P.grp_off[g + 1]) : P.rows;
+    const int r0 = lo + CX_ROWS * (local - first);
+    if (r0 >= hi) continue;                                 // block-uniform, before any barrier
+    const int nvalid = min(hi - r0, CX_ROWS);
+    const int L = P.nlayers;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int swid = __builtin_amdgcn_readfirstlane(wid);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int T = chain_tiles(P);
+
+    const float* const img = P.image + (long long)g * (P.image_stride ? P.image_stride : (long long)T * CH_TILE) +
+                             (swid * 4) * 256 + lane * 4;
+    const unsigned bs_lds = (unsigned)(uintptr_t)Bs + (unsigned)(swid * 4) * 1024u;
+    auto dma_tile = [&](int t) {
+        t = min(t, T - 1);
+        const float* src = img + (long long)t * CH_TILE;
+        const unsigned dst = bs_lds + (unsigned)(t & 1) * (unsigned)(CH_TILE * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lds_dma_1k(src + q * 256, dst + q * 1024u);
+    };
+    // 1 / scale of a layer's weights (this bond type): layer 0 here, layer l + 1 at the end of epilogue l
+    auto w_inv_scale = [&](int l) {
+        float s_, inv_;
+        gx_scale(gx_amax_read(P.x2_wamax + ((long long)l * P.ngroups + g) * GI_AMAX_WORDS), s_, inv_);
+        return inv_;
+    };
+    float ib = w_inv_scale(0);
+    // largest magnitude over the workgroup: wave maximum -> LDS; the caller's barrier; then every thread reads all 8
+    auto wave_max_to_lds = [&](float m) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) red[wid] = m;
+    };
+    auto wg_max_from_lds = [&]() {
+        float m = red[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
+        return m;
+    };
+    f32x16 acc[2];
+    float sa = 1.f, ia = 1.f;                               // scale of the activation tile in LDS and its inverse
+    gx_f16x8 af[2][2][2], bf[2][2];                          // [stage][row block][plane], [stage][plane]
+    auto read_frags = [&](int slot, int kt, int step, gx_f16x8 (&a)[2][2], gx_f16x8 (&b)[2]) {
+        const unsigned char* bt = reinterpret_cast<const unsigned char*>(Bs) + slot * (CH_TILE * 4);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+                a[rb][pl] = *reinterpret_cast<const gx_f16x8*>(Ah + cx_a_off(pl, kt * 4 + 2 * step + lhi, rb * 32 + l31));
+            b[pl] = *reinterpret_cast<const gx_f16x8*>(bt + cx_b_off(pl, 2 * step + lhi, wid * 32 + l31));
+        }
+    };
+    auto mma = [&](const gx_f16x8 (&a)[2][2], const gx_f16x8 (&b)[2]) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {                     // a2 b1 + a1 b2 + a1 b1 (smallest terms first)
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][1], b[0], acc[rb], 0, 0, 0);
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][0], b[1], acc[rb], 0, 0, 0);
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rb][0], b[0], acc[rb], 0, 0, 0);
+        }
+    };
+
+    auto epilogue = [&](int l) {
+        const gi_chain_layer& Ly = P.layer[l];
+        const int N = Ly.N, ldo = Ly.ldo;
+        const int col = wid * 32 + l31;
+        const bool col_ok = col < N;
+        const int coff = col_ok ? 4 * col : 0x40000000;
+        float av[2][16];
+        const bool dselu = BWD && Ly.act != nullptr;
+        if (dselu) {
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(Ly.act + (long long)r0 * Ly.ldact), 0, nvalid * Ly.ldact * 4, 0x00020000);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    av[rb][r] = __builtin_bit_cast(
+                        float, __builtin_amdgcn_raw_buffer_load_b32(ra, row * Ly.ldact * 4 + coff, 0, 0));
+                }
+        }
+        const float bv = BWD ? 0.f : Ly.bias[g][col_ok ? col : N - 1];
+        float v[2][16];
+        float m = 0.f;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = (acc[rb][r] * ia) * ib + bv;
+                if (!BWD) x = gi_selu(x);
+                if (dselu) x *= gi_selu_grad(av[rb][r]);
+                x = col_ok ? x : 0.f;                        // zero = the next layer's k padding
+                v[rb][r] = x;
+                m = fmaxf(m, fabsf(x));
+            }
+        wave_max_to_lds(m);
+        // Drain this wave's DMA queue, then: every wave is past its last read of the activation tile, and the eight
+        // wave maxima are in LDS.
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (l + 1 < L) {                                     // next layer's A operand: split, in place
+            gx_scale(wg_max_from_lds(), sa, ia);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const float y = v[rb][r] * sa;
+                    const _Float16 h1 = (_Float16)y;
+                    const _Float16 h2 = (_Float16)(y - (float)h1);
+                    *reinterpret_cast<_Float16*>(Ah + cx_a_off(0, col >> 3, row) + (col & 7) * 2) = h1;
+                    *reinterpret_cast<_Float16*>(Ah + cx_a_off(1, col >> 3, row) + (col & 7) * 2) = h2;
+                }
+        }
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(Ly.out + (long long)r0 * ldo), 0, nvalid * ldo * 4, 0x00020000);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[rb][r]), ro,
+                                                      row * ldo * 4 + coff, 0, 0);
+            }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+        if (l + 1 < L) ib = w_inv_scale(l + 1);             // (lands under the next layer's k loop)
+    };
+
+    // ---- prologue: the 64 input rows -> scale -> two fp16 planes in LDS (zero beyond K0) ---------------
+    {
+        const int mc4 = tid & 63, mrow = tid >> 6;
+        const int K0 = P.layer[0].K, cmax = ((K0 + 3) & ~3) - 4;
+        const int c = 4 * mc4;
+        long long src[8];
+        v4f v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) src[i] = min(r0 + mrow + 8 * i, hi - 1);
+        if (P.x_idx) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) src[i] = P.x_idx[src[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = gi_load4_raw(P.X + src[i] * P.ldx, c, cmax);
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v4f w = v[i];
+            w.x = (c < K0) ? w.x : 0.f; w.y = (c + 1 < K0) ? w.y : 0.f;
+            w.z = (c + 2 < K0) ? w.z : 0.f; w.w = (c + 3 < K0) ? w.w : 0.f;
+            v[i] = w;
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(w.x), fabsf(w.y))), fmaxf(fabsf(w.z), fabsf(w.w)));
+        }
+        wave_max_to_lds(m);
+        __syncthreads();
+        gx_scale(wg_max_from_lds(), sa, ia);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            unsigned p0a, p1a, p0b, p1b;
+            gx_split2(v[i].x, v[i].y, sa, p0a, p1a);
+            gx_split2(v[i].z, v[i].w, sa, p0b, p1b);
+            const unsigned at = cx_a_off(0, c >> 3, mrow + 8 * i) + (c & 7) * 2;
+            cx_u32x2 w0 = {p0a, p0b}, w1 = {p1a, p1b};
+            *reinterpret_cast<cx_u32x2*>(Ah + at) = w0;
+            *reinterpret_cast<cx_u32x2*>(Ah + CX_PLANE + at) = w1;
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+    __syncthreads();                        // the A planes are in LDS (and every plain load has landed)
+    dma_tile(0);
+
+    // ---- main loop over the weight tiles (two-slot ring: see the fp32 kernel) ------------------------------
+#define GI_CHAIN_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    int l = 0, kt = 0, nk = (P.layer[0].K + CH_KT - 1) / CH_KT, lN = P.layer[0].N;
+    int since_epi = 2;
+    for (int s = 0; s < T; ++s) {
+        if (__builtin_amdgcn_readfirstlane(since_epi) < 1) { GI_CHAIN_WAIT(40); } else { GI_CHAIN_WAIT(0); }
+        since_epi = __builtin_amdgcn_readfirstlane(since_epi + 1);
+        dma_tile(s + 1);
+        const int slot = s & 1;
+        if (swid * 32 < __builtin_amdgcn_readfirstlane(lN)) {
+            read_frags(slot, kt, 0, af[0], bf[0]);
+            read_frags(slot, kt, 1, af[1], bf[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(af[0], bf[0]);
+            mma(af[1], bf[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        kt = __builtin_amdgcn_readfirstlane(kt + 1);
+        if (kt == __builtin_amdgcn_readfirstlane(nk)) {       // layer done
+            epilogue(l);
+            since_epi = 0;
+            l = __builtin_amdgcn_readfirstlane(l + 1);
+            if (l < L) {
+                kt = 0;
+                nk = __builtin_amdgcn_readfirstlane((P.layer[l].K + CH_KT - 1) / CH_KT);
+                lN = __builtin_amdgcn_readfirstlane(P.layer[l].N);
+            }
+        }
+    }
+#undef GI_CHAIN_WAIT
+    __syncthreads();
+    }
+}
+
 int validate_chain(const gi_chain_params& p) {
     if (p.nlayers < 1 || p.nlayers > GI_CHAIN_MAXL || !p.X || p.rows < 0) return GI_EINVAL;
     if (p.ngroups < 1 || p.ngroups > GI_MAX_GROUPS) return GI_EINVAL;
@@ -453,6 +758,7 @@ int validate_chain(const gi_chain_params& p) {
             if (!p.backward && !q.bias[t]) return GI_EINVAL;
         }
     }
+    if (p.x2_wamax && ((uintptr_t)p.x2_wamax & 3)) return GI_EINVAL;
     return 0;
 }
 
@@ -484,6 +790,21 @@ extern "C" int gi_mlp_chain_pack(const gi_chain_params* chains, int nchains, voi
         a.c = p;
         a.tiles = chain_tiles(p);
         const long long n4 = (long long)p.ngroups * a.tiles * (CH_TILE / 4);
+        if (p.x2_wamax) {                   // fp16x2 image: max |W| per (layer, bond type) first, then the two planes
+            const size_t cells = (size_t)p.nlayers * p.ngroups;
+            if (hipMemsetAsync(p.x2_wamax, 0, cells * GI_AMAX_WORDS * sizeof(float), (hipStream_t)stream) != hipSuccess)
+                return (int)hipGetLastError();
+            gi_absmax_desc d[GI_ABSMAX_MAX];
+            int nd = 0;
+            for (int l = 0; l < p.nlayers; ++l)
+                for (int t = 0; t < p.ngroups; ++t) {
+                    d[nd].x = p.layer[l].W[t]; d[nd].rows = 1; d[nd].cols = p.layer[l].K * p.layer[l].N;
+                    d[nd].ld = d[nd].cols; d[nd].out = p.x2_wamax + ((size_t)l * p.ngroups + t) * GI_AMAX_WORDS;
+                    if (++nd == GI_ABSMAX_MAX) { const int e = gi_absmax(d, nd, stream); if (e) return e; nd = 0; }
+                }
+            if (nd) { const int e = gi_absmax(d, nd, stream); if (e) return e; }
+            hipLaunchKernelGGL(gi_chain_pack_x2_kernel, dim3((unsigned)(n4 / 256)), dim3(256), 0, (hipStream_t)stream, a);
+        } else
         hipLaunchKernelGGL(gi_chain_pack_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
                            (hipStream_t)stream, a);
         const int e = gi_launch_status();
@@ -515,6 +836,7 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
         const int rc = validate_chain(p);
         if (rc) return rc;
         if (p.backward != chains[0].backward) return GI_EINVAL;
+        if ((p.x2_wamax != nullptr) != (chains[0].x2_wamax != nullptr)) return GI_EINVAL;   // one arithmetic per launch
         if (!p.image || ((uintptr_t)p.image & 15)) return GI_EINVAL;   // gi_mlp_chain_pack'ed weights
         if (p.image_stride && p.image_stride < (long long)chain_tiles(p) * CH_TILE) return GI_EINVAL;
         for (int g = 0; g < p.ngroups; ++g)
@@ -571,6 +893,8 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
         big = false; h = CH_ROWS;
         a.dev_tiles = 1; a.tile_rows_dev = chains[0].tile_rows_dev;
     }
+    const bool x2 = chains[0].x2_wamax != nullptr;
+    if (x2) { big = false; h = CX_ROWS; }                  // (bounded too: 64-row blocks, the device-side height is not used)
     if (big) h = 2 * CH_ROWS;
     a.tile_rows = h;
     for (int c = 0; c < nchains; ++c) {
@@ -582,7 +906,7 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
             a.tile_off[c][g] = t;
             if (!bounded) t += gi_cdiv(p.ngroups > 1 ? p.group_rows[g] : p.rows, h);
         }
-        if (bounded) t = gi_cdiv(p.rows, CH_ROWS) + p.ngroups;
+        if (bounded) t = gi_cdiv(p.rows, x2 ? CX_ROWS : CH_ROWS) + p.ngroups;
         a.tile_off[c][p.ngroups] = t;
         total += t;
         for (int l = 0; l < p.nlayers; ++l)
@@ -603,7 +927,10 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
     // the step gains 1.6 % (headline 2.312 / 2.332 -> 2.277 / 2.295 ms, ZINC shape 5.044 -> 4.957, ChEMBL shape
     // 3.854 -> 3.813; profiles/r03/chain_ring_ab.txt).  gi_mlp_chain_config(ring = 3): the three-slot ring.
     const bool ring2 = !big && g_chain_cfg.ring != 3;
-    if (big) {
+    if (x2) {
+        if (chains[0].backward) hipLaunchKernelGGL((gi_chain_x2_kernel<true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((gi_chain_x2_kernel<false>), grid, block, 0, st, a);
+    } else if (big) {
         if (chains[0].backward) hipLaunchKernelGGL((gi_chain_kernel<true, 2, 2>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((gi_chain_kernel<false, 2, 2>), grid, block, 0, st, a);
     } else if (ring2) {

@@ -108,6 +108,7 @@ struct Ws {
     // packed weight images of the resident-activation chains (gi_chain.hip): [msg, energy] stacks,
     // forward and backward layouts; 0 floats when the stack does not fit the chain kernel
     long long img_f[2], img_b[2], img_f_n[2], img_b_n[2], img_b_stride[2];
+    long long chain_amax[2];            // fp16x2 chains: amax cells of the stack's weights, [layer][bond type] (gi_chain_params.x2_wamax)
     // AlphaDropout training mode: the workspace is allocated twice; float i of the second half holds
     // the backward factor d y / d z of activation i of the first (0: mode off)
     long long fshift;
@@ -135,6 +136,15 @@ static bool x2_enabled() {
 bool bf3_enabled() {
     if (g_bf3 < 0) g_bf3 = getenv("GI_BF3") ? (atoi(getenv("GI_BF3")) != 0) : (GI_BF3_DEFAULT != 0);
     return g_bf3 != 0;
+}
+// The message / energy stacks' chain launches as fp16x2 (64-row blocks on the f16 pipe, gi_chain.hip): with the other
+// 16-bit-pipe launches (GI_BF3, GI_X2) — the dZ chains of the BACKWARD only.  The forward keeps the fp32 chain: its
+// rows are bit-independent of one another, which the pass-0 row cache, the equality of blocking and host-sync-free
+// forwards and of forwards with and without a tape rely on (the fp16x2 chain scales activations per 64-row block, so a
+// row's last bits depend on its block).  GI_CHAIN_X2=0: the fp32-MFMA chain in the backward too.
+static bool chain_x2_enabled() {
+    static const int v = getenv("GI_CHAIN_X2") ? atoi(getenv("GI_CHAIN_X2")) : 1;
+    return v != 0 && x2_enabled() && bf3_enabled();
 }
 bool bf3_wide(const Mlp& q, int l) { return q.fan_in(l) >= BF3_MIN_WIDTH && q.fan_out(l) >= BF3_MIN_WIDTH; }
 bool bf3_layer_ok(const Mlp& q, int l) { return bf3_enabled() && bf3_wide(q, l); }
@@ -260,6 +270,7 @@ void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
             w.img_b_n[k] = chain_image_floats(q, d.Fe, true, &w.img_b_stride[k]);
             w.img_f[k] = take(w.img_f_n[k], 1);
             w.img_b[k] = take(w.img_b_n[k], 1);
+            w.chain_amax[k] = take((long long)GI_AMAX_WORDS * GI_CHAIN_MAXL * GI_MAX_GROUPS, 1);
         }
     }
     w.fshift = d.dropout ? gi_r4l(o) : 0;
@@ -364,6 +375,7 @@ struct Run {
     SideStream* side = nullptr;    // optional second stream for the weight-gradient GEMMs
     float* img_f[2] = {nullptr, nullptr};   // packed chain weight images [msg, energy stack]; null: the
     float* img_b[2] = {nullptr, nullptr};   // stack runs layer by layer
+    float* chain_amax[2] = {nullptr, nullptr};   // != null: the stack's chains run as fp16x2 (gi_chain.hip), images packed that way
     long long img_b_stride[2] = {0, 0};
     const struct Mlp* eatt0 = nullptr;      // identifies the energy stacks (second image)
     bool hold_kicks = false;                // no weight-gradient launches on the side stream for now
@@ -980,6 +992,7 @@ void chain_pack(Run& r, const Mlp* mlps, int groups, bool backward, float* image
     for (int i = 0; i < L; ++i)
         for (int t = 0; t < groups; ++t) c.layer[i].W[t] = r.P[mlps[t].w(backward ? L - 1 - i : i)];
     c.image = image;
+    c.x2_wamax = r.chain_amax[mlps == r.eatt0 ? 1 : 0];
     r.chk(gi_mlp_chain_pack(&c, 1, r.st));
 }
 
@@ -999,6 +1012,7 @@ void chain_fwd_params(gi_chain_params& c, const Run& r, float* ws, const Mlp* ml
     c.nlayers = L; c.X = X; c.ldx = ldx; c.x_idx = idx; c.backward = 0;
     chain_groups(c, g, rows);
     if (r.dims) c.tile_rows_dev = r.dims + g.dim_slot;
+    c.x2_wamax = r.chain_amax[mlps == r.eatt0 ? 1 : 0];
     c.skip_flag = r.skip;
     for (int l = 0; l < L; ++l) {
         gi_chain_layer& y = c.layer[l];
@@ -1021,6 +1035,7 @@ int chain_bwd_params(gi_chain_params& c, const Run& r, float* ws, const Mlp* mlp
     c.image = r.img_b[mlps == r.eatt0 ? 1 : 0];
     c.image_stride = r.img_b_stride[mlps == r.eatt0 ? 1 : 0];
     c.X = Zlast; c.ldx = ldz; c.x_idx = nullptr; c.backward = 1;
+    c.x2_wamax = r.chain_amax[mlps == r.eatt0 ? 1 : 0];
     chain_groups(c, g, rows);
     int n = 0;
     for (int l = L - 1; l >= 0; --l) {
@@ -1686,6 +1701,7 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
     if (d.passes > 0 && E > 0)          // packed weight images of the dZ chains, once per backward
         for (int k = 0; k < (attn ? 2 : 1); ++k)
             if (w.img_b_n[k] > 0) {
+                if (chain_x2_enabled()) r.chain_amax[k] = ws + w.chain_amax[k];
                 r.img_b[k] = ws + w.img_b[k];
                 r.img_b_stride[k] = w.img_b_stride[k];
                 chain_pack(r, k ? m.eatt : m.msg, d.Fe, true, r.img_b[k]);

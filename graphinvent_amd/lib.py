@@ -32,7 +32,7 @@ GEMM_BF3 = 128        # GI_GEMM_BF3: B is a gi_bf3_pack image; the launch runs a
 KIND_GGNN, KIND_ATTGGNN = 0, 1
 BWD_ALL, BWD_READOUT, BWD_PASSES = 0, 1, 2
 COUNTS = 24          # GI_COUNTS
-ABI_VERSION = 13
+ABI_VERSION = 14
 #: bumped by code that rewrites model weights through raw pointers (optim.FusedAdam.step,
 #: dp.DataParallel.broadcast_parameters): invalidates gnn.mpnn's pass-0 row cache
 WEIGHTS_EPOCH = [0]     # GI_ABI_VERSION
@@ -73,7 +73,7 @@ class ChainParams(C.Structure):
     _fields_ = [("layer", ChainLayer * CHAIN_MAXL), ("nlayers", ci), ("X", vp), ("ldx", ci),
                 ("x_idx", vp), ("grp_off", vp), ("ngroups", ci), ("group_rows", ci * GI_MAX_GROUPS),
                 ("rows", ci), ("backward", ci), ("image", vp), ("image_stride", cll), ("skip_flag", vp),
-                ("tile_rows_dev", vp)]
+                ("tile_rows_dev", vp), ("x2_wamax", vp)]
 
 
 class ReduceDesc(C.Structure):

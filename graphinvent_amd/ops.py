@@ -473,8 +473,9 @@ def ws_view(ws: torch.Tensor, dims, graph: "CompactGraph", name: str, rows: int,
     return ws[off.value:off.value + rows * ld.value].view(rows, ld.value)
 
 
-def mlp_chain(chains, backward=False):
-    """gi_mlp_chain.  chains: list (1 or 2) of dicts with keys
+def mlp_chain(chains, backward=False, x2=False):
+    """gi_mlp_chain (x2: the fp16x2 variant — amax cells for the weights are allocated here, gi_mlp_chain_pack fills
+    them and writes the two-plane image).  chains: list (1 or 2) of dicts with keys
     X, x_idx (or None), grp_off (int32 tensor [G+1] or None), group_rows (host ints), rows,
     seg (backward, optional: dict(vals, idx, off) — gi_chain_params.seg_vals: X is formed in place) and
     layers = list of dicts(W=[per-group tensors], bias=[per-group tensors] (forward), out, act (backward
@@ -503,6 +504,10 @@ def mlp_chain(chains, backward=False):
             for t, b in enumerate(ly.get("bias") or ()):
                 y.bias[t] = b.data_ptr()
     images = []
+    if x2:
+        for c, spec in zip(arr, chains):
+            images.append(torch.empty(c.nlayers * c.ngroups, L.AMAX_WORDS, dtype=torch.float32, device=spec["X"].device))
+            c.x2_wamax = images[-1].data_ptr()
     for c, spec in zip(arr, chains):       # packed weight images (kept alive until the launch is queued)
         n = lib.gi_mlp_chain_image_floats(C.byref(c))
         if n < 0:

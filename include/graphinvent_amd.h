@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GI_ABI_VERSION 13
+#define GI_ABI_VERSION 14
 #define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
 #define GI_MAX_NODES 128      /* max max_n_nodes */
 #define GI_P0_MAX_CLASSES 256 /* max distinct node feature rows for the pass-0 shortcut */
@@ -269,6 +269,13 @@ typedef struct {
                                              row-block height (32..36).  `rows` is then an upper BOUND of the
                                              rows of all groups together (sizes the grid), the real row ranges
                                              come from grp_off on the device (required), group_rows is unused */
+    float* x2_wamax;                      /* NULL, or nlayers x ngroups amax cells (GI_AMAX_WORDS floats each, [layer][group]):
+                                             the fp16x2 chain (csrc/gi_x2.h) — gi_mlp_chain_pack computes max |W| of
+                                             every layer and group into them and writes the image as two scaled fp16
+                                             planes; gi_mlp_chain then runs 64-row blocks on the f16 MFMA pipe (three
+                                             products per fp32 product, activations scaled per row and layer: a row's
+                                             result depends on nothing but the row).  Pack and launch must agree; a
+                                             bounded launch walks 64-row blocks (the value behind tile_rows_dev is unused) */
 } gi_chain_params;
 
 /* The kernel streams the weights as a pre-packed image (one linear stream of 32 KB LDS tile images per

@@ -444,7 +444,7 @@ def test_gemm_forward_gather_and_groups(gemm_grid):
     assert rel(Y[:, :N], ref) < 2e-5
 
 
-def _chain_case(sizes, off, seed, two=False):
+def _chain_case(sizes, off, seed, two=False, x2=False, in_scale=1.0):
     """Resident-activation MLP chain (gi_mlp_chain) against fp64 torch, forward and dZ chain: grouped
     rows (ragged, an empty group, a 1-row group), gathered input, widths that are not multiples of 4
     or 32, every hidden activation / dZ buffer checked, nothing written outside [rows, N]."""
@@ -453,7 +453,7 @@ def _chain_case(sizes, off, seed, two=False):
     E, R = off[-1], 300
     K0 = sizes[0]
     ldx = ops.r4(K0) + 4
-    h = torch.randn(R, ldx, generator=g)
+    h = torch.randn(R, ldx, generator=g) * in_scale
     idx = torch.randint(0, R, (E,), generator=g, dtype=torch.int32)
     offt = torch.tensor(off, dtype=torch.int32)
     rows_g = [off[t + 1] - off[t] for t in range(G)]
@@ -471,7 +471,7 @@ def _chain_case(sizes, off, seed, two=False):
                           layers=[dict(W=[dev(w) for w in Ws[c][l]], bias=[dev(b) for b in bs[c][l]],
                                        out=bufs[l], K=sizes[l], N=sizes[l + 1])
                                   for l in range(len(sizes) - 1)]))
-    ops.mlp_chain(specs, backward=False)
+    ops.mlp_chain(specs, backward=False, x2=x2)
     refs = []
     for c in range(nchains):
         acts = []
@@ -490,7 +490,7 @@ def _chain_case(sizes, off, seed, two=False):
     L_ = len(sizes) - 1
     bspecs, bouts = [], []
     for c in range(nchains):
-        dZ = torch.randn(E, ops.r4(sizes[-1]), generator=g)
+        dZ = torch.randn(E, ops.r4(sizes[-1]), generator=g) * in_scale
         douts = [torch.full((E, ops.r4(sizes[l]) + 4), 7.0, device=DEV) for l in range(L_)]
         layers = []
         for l in range(L_ - 1, -1, -1):
@@ -504,7 +504,7 @@ def _chain_case(sizes, off, seed, two=False):
         bspecs.append(dict(X=dev(dZ), x_idx=None, grp_off=dev(offt), group_rows=rows_g, rows=E,
                            layers=layers))
         bouts.append((dZ, douts))
-    ops.mlp_chain(bspecs, backward=True)
+    ops.mlp_chain(bspecs, backward=True, x2=x2)
     for c in range(nchains):
         dZ, douts = bouts[c]
         z = dZ[:, :sizes[-1]].double()
@@ -533,6 +533,25 @@ def test_mlp_chain_forward_and_dz_chain(sizes, off):
 
 def test_mlp_chain_two_chains_one_launch():
     _chain_case((100, 250, 250, 100), [0, 90, 130, 131], seed=5, two=True)
+
+
+@pytest.mark.parametrize("in_scale", [1.0, 1e-4, 3e3])
+@pytest.mark.parametrize("sizes,off", [
+    ((128, 250, 250, 250, 250, 128), [0, 600, 600, 777]),       # bench config, middle group empty
+    ((100, 250, 250, 250, 250, 100), [0, 33, 34, 131]),         # reference default dims
+    ((100, 250, 250, 250, 250, 100), [0, 1000, 1001, 2500]),    # several 64-row blocks per group, ragged tails
+    ((16, 24, 24, 12), [0, 5, 7, 8]),                           # tiny config
+    ((37, 256, 7, 130), [0, 64]),                               # one group, awkward widths, exactly one block
+    ((128, 100), [0, 31, 95]),                                  # single layer
+])
+def test_mlp_chain_fp16x2_forward_and_dz_chain(sizes, off, in_scale):
+    """The fp16x2 chain (gi_chain_params.x2_wamax; csrc/gi_x2.h): 64-row blocks, weights as two scaled fp16 planes
+    (scale per layer and group from gi_mlp_chain_pack's own amax pass), activations split per row block and layer in
+    the epilogue — against the same fp64 reference and at the same 3e-5 as the fp32-MFMA chain, for inputs (and
+    upstream gradients) of magnitude 1, 1e-4 and 3e3, single and two chains per launch."""
+    _chain_case(sizes, off, seed=sum(sizes), x2=True, in_scale=in_scale)
+    if in_scale == 1.0:
+        _chain_case(sizes, off, seed=sum(sizes) + 1, two=True, x2=True)
 
 
 @pytest.mark.parametrize("tile_rows", [33, 34, 36])
