@@ -468,7 +468,7 @@ def main():
     result["config"]["fuse_flags"] = int(lib.load().gi_fuse_flags())     # GI_FUSE_* variants in use
     result["config"]["gemm_arithmetic"] = (
         "fp32 operands, fp32 accumulate everywhere; the node-level readout layers >= 192 wide (forward, dgrad and weight "
-        "gradients: 8 of the GEMM-family launches per step, roofline.pipes) split every fp32 operand into "
+        "gradients) and the backward's message-stack dZ chains (roofline.pipes counts the launches) split every fp32 operand into "
         + ("two scaled fp16 values (three f16 MFMA products per fp32 product, per-tensor power-of-two scale from the "
            "tensor's largest magnitude)" if lib.load().gi_x2_enable(-1) else
            "three bf16 values (six bf16 MFMA products per fp32 product)")

@@ -76,6 +76,7 @@ __host__ __device__ inline int chain_tiles(const gi_chain_params& p) {
 struct PackArgs {
     gi_chain_params c;
     int tiles;
+    long long stride16;                     // fp16x2 image: 16-byte units per group
 };
 
 __global__ __launch_bounds__(256) void gi_chain_pack_kernel(const PackArgs a) {
@@ -445,9 +446,12 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
 // workgroup can carry 64 rows without becoming MFMA-bound: HALF the weight stream per row (the stream is what bounds the
 // fp32 kernel at one 32-row block per CU) on half the CUs, the other half free for the weight-gradient queue that runs
 // beside every backward chain.
-//   * weight image: the same 32 KB per 32-deep tile, now [plane 2][k chunk of 8: 4][column 256][8 halves] — the B
+//   * weight image: 16 KB per 16-deep tile (one MFMA k step), [plane 2][k chunk of 8: 2][column 256][8 halves] — the B
 //     fragment of column n and k chunk c is one ds_read_b128 — scaled per (layer, bond type) by a power of two from
-//     max |W| (gi_mlp_chain_pack computes it into x2_wamax first); streamed by the same LDS-DMA two-slot ring;
+//     max |W| (gi_mlp_chain_pack computes it into x2_wamax first); streamed by LDS-DMA into a FOUR-slot ring of those
+//     tiles (the same 64 KB as two 32-deep slots): with the matrix work down to 6 MFMAs per tile a step is one DMA
+//     round trip, so what counts is how many tiles are in flight — three instead of one (measured with two 32-deep
+//     slots: 60 us per launch alone, 5.6 % MFMA busy);
 //   * activation tile: [plane 2][k chunk of 8: 32][row 64][8 halves] = 64 KB, scaled PER ROW BLOCK AND LAYER by a power
 //     of two from the largest magnitude of the 64 x 256 tile (a maximum per wave -> LDS -> the epilogue's own barrier):
 //     no global atomics; the epilogue splits the new activations and rewrites the tile in place.  The last bits of a
@@ -459,32 +463,41 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
 // 64 rows per workgroup, no extra VALU rows; bounded launches walk 64-row blocks (the device-side height is not used).
 constexpr int CX_ROWS = 64;
 constexpr int CX_PLANE = 32 * CX_ROWS * 16;                 // bytes of one activation plane (32 KB)
+constexpr int CX_KT = 16;                                   // reduction depth of one weight tile
+constexpr int CX_TILE = CH_W * CX_KT;                       // floats (= 4-byte units) per weight tile image: 16 KB
+constexpr int CX_RING = 4;
+__host__ __device__ inline int cx_tiles(const gi_chain_params& p) {
+    int t = 0;
+    for (int l = 0; l < p.nlayers; ++l) t += (p.layer[l].K + CX_KT - 1) / CX_KT;
+    return t;
+}
 __device__ __forceinline__ unsigned cx_a_off(int plane, int chunk, int row) {
     return (unsigned)(plane * CX_PLANE + (chunk * CX_ROWS + row) * 16);
 }
 __device__ __forceinline__ unsigned cx_b_off(int plane, int chunk, int col) {
-    return (unsigned)(((plane * 4 + chunk) * CH_W + col) * 16);
+    return (unsigned)(((plane * 2 + chunk) * CH_W + col) * 16);
 }
 
 __global__ __launch_bounds__(256) void gi_chain_pack_x2_kernel(const PackArgs a) {
     const gi_chain_params& P = a.c;
     const long long id = (long long)blockIdx.x * 256 + threadIdx.x;      // one 16-byte piece (8 halves of a plane) each
-    const long long per_group = (long long)a.tiles * (CH_TILE / 4);      // (whole waves only: 2 048 pieces per tile)
+    const long long per_group = (long long)a.tiles * (CX_TILE / 4);      // (whole waves only: 1 024 pieces per tile)
     const int g = (int)(id / per_group);
     const int rem = (int)(id - (long long)g * per_group);
-    int tile = rem / (CH_TILE / 4);
-    const int q = rem - tile * (CH_TILE / 4);
+    int tile = rem / (CX_TILE / 4);
+    const int q = rem - tile * (CX_TILE / 4);
+    const int tile_in_group = tile;
     int l = 0;
     for (;;) {
-        const int nk = (P.layer[l].K + CH_KT - 1) / CH_KT;
+        const int nk = (P.layer[l].K + CX_KT - 1) / CX_KT;
         if (tile < nk) break;
         tile -= nk; ++l;
     }
     const gi_chain_layer& Ly = P.layer[l];
     const float* __restrict__ W = Ly.W[g];
     const int K = Ly.K, N = Ly.N;
-    const int plane = q >> 10, chunk = (q >> 8) & 3, n = q & (CH_W - 1);
-    const int k0 = tile * CH_KT + chunk * 8;
+    const int plane = q >> 9, chunk = (q >> 8) & 1, n = q & (CH_W - 1);
+    const int k0 = tile * CX_KT + chunk * 8;
     float s, inv;
     gx_scale(gx_amax_read(P.x2_wamax + ((long long)l * P.ngroups + g) * GI_AMAX_WORDS), s, inv);
     float w[8];
@@ -504,13 +517,14 @@ __global__ __launch_bounds__(256) void gi_chain_pack_x2_kernel(const PackArgs a)
     }
     typedef unsigned cx_u32x4 __attribute__((ext_vector_type(4)));
     cx_u32x4 v = {o[0], o[1], o[2], o[3]};
-    reinterpret_cast<cx_u32x4*>(P.image)[id] = v;
+    // a group's tiles start at the group stride of the fp32 layout (what image_stride means to every caller)
+    reinterpret_cast<cx_u32x4*>(P.image)[(long long)g * a.stride16 + (long long)tile_in_group * (CX_TILE / 4) + q] = v;
 }
 
 template <bool BWD>
 __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) {
     __shared__ __attribute__((aligned(16))) unsigned char Ah[2 * CX_PLANE];
-    __shared__ __attribute__((aligned(1024))) float Bs[2 * CH_TILE];
+    __shared__ __attribute__((aligned(1024))) float Bs[CX_RING * CX_TILE];
     __shared__ float red[8];                                // per wave: max |new activation|
     typedef unsigned cx_u32x2 __attribute__((ext_vector_type(2)));
     if (args.c[0].skip_flag && *args.c[0].skip_flag != 0) return;
@@ -540,17 +554,19 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int swid = __builtin_amdgcn_readfirstlane(wid);
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int T = chain_tiles(P);
+    const int T = cx_tiles(P);                               // steps = 16-deep weight tiles of the whole chain
 
-    const float* const img = P.image + (long long)g * (P.image_stride ? P.image_stride : (long long)T * CH_TILE) +
-                             (swid * 4) * 256 + lane * 4;
-    const unsigned bs_lds = (unsigned)(uintptr_t)Bs + (unsigned)(swid * 4) * 1024u;
+    // weight stream: tile t of this group -> ring slot t % 4; a wave moves 2 of a tile's 16 one-KB pieces
+    const float* const img = P.image + (long long)g * (P.image_stride ? P.image_stride
+                                                                      : (long long)chain_tiles(P) * CH_TILE) +
+                             (swid * 2) * 256 + lane * 4;
+    const unsigned bs_lds = (unsigned)(uintptr_t)Bs + (unsigned)(swid * 2) * 1024u;
     auto dma_tile = [&](int t) {
-        t = min(t, T - 1);
-        const float* src = img + (long long)t * CH_TILE;
-        const unsigned dst = bs_lds + (unsigned)(t & 1) * (unsigned)(CH_TILE * 4);
+        t = min(t, T - 1);                                   // past the end: re-fetch the last tile (fixed load count)
+        const float* src = img + (long long)t * CX_TILE;
+        const unsigned dst = bs_lds + (unsigned)(t & (CX_RING - 1)) * (unsigned)(CX_TILE * 4);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) lds_dma_1k(src + q * 256, dst + q * 1024u);
+        for (int q = 0; q < 2; ++q) lds_dma_1k(src + q * 256, dst + q * 1024u);
     };
     // 1 / scale of a layer's weights (this bond type): layer 0 here, layer l + 1 at the end of epilogue l
     auto w_inv_scale = [&](int l) {
@@ -573,15 +589,15 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
     };
     f32x16 acc[2];
     float sa = 1.f, ia = 1.f;                               // scale of the activation tile in LDS and its inverse
-    gx_f16x8 af[2][2][2], bf[2][2];                          // [stage][row block][plane], [stage][plane]
-    auto read_frags = [&](int slot, int kt, int step, gx_f16x8 (&a)[2][2], gx_f16x8 (&b)[2]) {
-        const unsigned char* bt = reinterpret_cast<const unsigned char*>(Bs) + slot * (CH_TILE * 4);
+    gx_f16x8 af[2][2], bf[2];                                // [row block][plane], [plane]
+    auto read_frags = [&](int slot, int kt, gx_f16x8 (&a)[2][2], gx_f16x8 (&b)[2]) {
+        const unsigned char* bt = reinterpret_cast<const unsigned char*>(Bs) + slot * (CX_TILE * 4);
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
-                a[rb][pl] = *reinterpret_cast<const gx_f16x8*>(Ah + cx_a_off(pl, kt * 4 + 2 * step + lhi, rb * 32 + l31));
-            b[pl] = *reinterpret_cast<const gx_f16x8*>(bt + cx_b_off(pl, 2 * step + lhi, wid * 32 + l31));
+                a[rb][pl] = *reinterpret_cast<const gx_f16x8*>(Ah + cx_a_off(pl, kt * 2 + lhi, rb * 32 + l31));
+            b[pl] = *reinterpret_cast<const gx_f16x8*>(bt + cx_b_off(pl, lhi, wid * 32 + l31));
         }
     };
     auto mma = [&](const gx_f16x8 (&a)[2][2], const gx_f16x8 (&b)[2]) {
@@ -706,23 +722,27 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
     __syncthreads();                        // the A planes are in LDS (and every plain load has landed)
-    dma_tile(0);
+    dma_tile(0); dma_tile(1); dma_tile(2);
 
-    // ---- main loop over the weight tiles (two-slot ring: see the fp32 kernel) ------------------------------
+    // ---- main loop over the weight tiles: four-slot ring, three tiles in flight -----------------------------
+    // Step s: wait for THIS wave's two pieces of tile s, barrier (=> the whole tile is there and every wave is done with
+    // tile s - 1, whose slot tile s + 3 goes to), start the DMA of tile s + 3, multiply tile s.  Loads complete in issue
+    // order: right before the wait of step s the youngest four are tiles s + 1 and s + 2, so "at most 4 outstanding"
+    // means tile s is complete.  An epilogue drains everything (vmcnt(0) in every wave + barrier: tiles up to s + 3 are
+    // in LDS) and leaves <= 36 stores in flight; the three steps after it need no load to complete, and waiting for the
+    // stores (older than the 2 + 2 loads issued since) would only stall: "at most 44".
 #define GI_CHAIN_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
-    int l = 0, kt = 0, nk = (P.layer[0].K + CH_KT - 1) / CH_KT, lN = P.layer[0].N;
-    int since_epi = 2;
+    int l = 0, kt = 0, nk = (P.layer[0].K + CX_KT - 1) / CX_KT, lN = P.layer[0].N;
+    int since_epi = 3;
     for (int s = 0; s < T; ++s) {
-        if (__builtin_amdgcn_readfirstlane(since_epi) < 1) { GI_CHAIN_WAIT(40); } else { GI_CHAIN_WAIT(0); }
+        if (__builtin_amdgcn_readfirstlane(since_epi) < 3) { GI_CHAIN_WAIT(44); } else { GI_CHAIN_WAIT(4); }
         since_epi = __builtin_amdgcn_readfirstlane(since_epi + 1);
-        dma_tile(s + 1);
-        const int slot = s & 1;
+        dma_tile(s + 3);
+        const int slot = s & (CX_RING - 1);
         if (swid * 32 < __builtin_amdgcn_readfirstlane(lN)) {
-            read_frags(slot, kt, 0, af[0], bf[0]);
-            read_frags(slot, kt, 1, af[1], bf[1]);
+            read_frags(slot, kt, af, bf);
             __builtin_amdgcn_sched_barrier(0);
-            mma(af[0], bf[0]);
-            mma(af[1], bf[1]);
+            mma(af, bf);
             __builtin_amdgcn_sched_barrier(0);
         }
         kt = __builtin_amdgcn_readfirstlane(kt + 1);
@@ -732,7 +752,7 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
             l = __builtin_amdgcn_readfirstlane(l + 1);
             if (l < L) {
                 kt = 0;
-                nk = __builtin_amdgcn_readfirstlane((P.layer[l].K + CH_KT - 1) / CH_KT);
+                nk = __builtin_amdgcn_readfirstlane((P.layer[l].K + CX_KT - 1) / CX_KT);
                 lN = __builtin_amdgcn_readfirstlane(P.layer[l].N);
             }
         }
@@ -803,7 +823,10 @@ extern "C" int gi_mlp_chain_pack(const gi_chain_params* chains, int nchains, voi
                     if (++nd == GI_ABSMAX_MAX) { const int e = gi_absmax(d, nd, stream); if (e) return e; nd = 0; }
                 }
             if (nd) { const int e = gi_absmax(d, nd, stream); if (e) return e; }
-            hipLaunchKernelGGL(gi_chain_pack_x2_kernel, dim3((unsigned)(n4 / 256)), dim3(256), 0, (hipStream_t)stream, a);
+            a.tiles = cx_tiles(p);
+            a.stride16 = (p.image_stride ? p.image_stride : (long long)chain_tiles(p) * CH_TILE) / 4;
+            const long long n16 = (long long)p.ngroups * a.tiles * (CX_TILE / 4);
+            hipLaunchKernelGGL(gi_chain_pack_x2_kernel, dim3((unsigned)(n16 / 256)), dim3(256), 0, (hipStream_t)stream, a);
         } else
         hipLaunchKernelGGL(gi_chain_pack_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
                            (hipStream_t)stream, a);
@@ -918,7 +941,7 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
     if (total == 0) return 0;
     a.trace = g_chain_cfg.trace;                            // per-workgroup timestamps (tools/trace_chain.py)
     hipStream_t st = (hipStream_t)stream;
-    GiProfScope prof(st, GI_PROF_GEMM, flops);
+    GiProfScope prof(st, GI_PROF_GEMM | (x2 ? GI_PROF_PIPE_X2 : 0), flops);
     const dim3 grid(bounded ? std::min(total, ncu) : total), block(512);
     // 32-row blocks stream their weights through a TWO-slot ring (114 KB of LDS instead of 146 KB with three):
     // one workgroup of the GEMM family (37 KB) fits on the CU beside a chain workgroup, which is what the
