@@ -8,7 +8,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("rnd", ["r02", "r03"])
+@pytest.mark.parametrize("rnd", ["r02", "r03", "r04"])
 def test_critical_path_on_the_committed_traces(rnd):
     for tag in ("default", "onestream", "zinc", "chembl"):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "critical_path.py"),
@@ -23,6 +23,12 @@ def test_critical_path_on_the_committed_traces(rnd):
             assert side == 0.0                      # weight gradients on the main queue
         else:
             assert side > 0.2 * span                # a second queue overlaps the backward
+        if rnd == "r04" and tag == "default":       # round 4: nothing left behind the last dZ chain (155 us in r03)
+            assert float(rows["tail (side queue only)"][0]) < 20.0
+            committed = open(os.path.join(ROOT, "profiles", rnd, "critical_path_default.txt")).read()
+            full = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "critical_path.py"),
+                                   os.path.join(ROOT, "profiles", rnd, "trace_default.csv")], capture_output=True, text=True)
+            assert full.stdout.strip() == committed.strip()           # the committed table is this tool's output
 
 
 def test_gemm_class_report_on_the_committed_trace_and_launch_log():
@@ -56,3 +62,24 @@ def test_gemm_class_report_round_3_with_the_bf16x3_launches():
     assert all(0.25 < f < 0.40 for f in own)                                          # against 397: 0.31-0.35
     committed = open(os.path.join(ROOT, "profiles", "r03", "gemm_class_report.txt")).read()
     assert out.stdout.strip() == committed.strip()                                     # the committed report is this output
+
+
+def test_gemm_class_report_round_4_with_the_fp16x2_launches():
+    """The r04 launch log carries the fp16x2 launches as classes x0 / x1 (gi_gemm_bf3.hip) and y2 (gi_gemm_b3p.hip, weight
+    gradients); the report prices them against the fp32 MFMA peak AND against their own pipe (2382 / 3 TFLOP/s)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_class_report.py"),
+                          os.path.join(ROOT, "profiles", "r04", "trace_onestream.csv"),
+                          os.path.join(ROOT, "profiles", "r04", "gemm_launch_log.txt")],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    fwd = [l.split() for l in lines if l.startswith("forward fp16x2")]
+    dgr = [l.split() for l in lines if l.startswith("dgrad fp16x2")]
+    assert len(fwd) == 3 and len(dgr) == 3
+    for row in fwd + dgr:
+        frac, own = float(row[-2]), float(row[-1])
+        assert 0.85 < frac < 1.3 and 0.15 < own < 0.30 and abs(own - frac * 157.3 / 794.0) < 0.011
+    w16 = [l.split() for l in lines if "16-bit pipe (fp16x2)" in l]
+    assert len(w16) == 1 and float(w16[0][-2]) > 1.2 and 0.2 < float(w16[0][-1]) < 0.4
+    committed = open(os.path.join(ROOT, "profiles", "r04", "gemm_class_report.txt")).read()
+    assert out.stdout.strip() == committed.strip()
