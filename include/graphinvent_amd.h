@@ -19,12 +19,21 @@
  *   - no exceptions cross the ABI; one process per GPU, calls come from one host thread at a time.
  *     Process-wide state is limited to: the optional per-launch timing log (gi_prof_*), a pool of
  *     timing-disabled hipEvents used to order the backward's two streams, the test / measurement hooks
- *     gi_gemm_config and gi_mlp_chain_config, and four switches read once from the environment:
+ *     gi_gemm_config and gi_mlp_chain_config, and switches read once from the environment:
  *       GI_FUSE=<mask>          launch-count reductions (gi_fuse_flags, default 15)
  *       GI_CHAIN=0              per-bond-type stacks layer by layer through gi_gemm instead of gi_mlp_chain
- *       GI_BF3=0                every GEMM on the fp32 MFMA (default 1: the node-level readout layers >= 192 wide run
- *                               as bf16x3 splits on the bf16 MFMA pipe, GI_GEMM_BF3 — same result to ~3e-7)
+ *       GI_BF3=0                every GEMM and chain on the fp32 MFMA (default 1: the node-level readout layers >= 192
+ *                               wide and the backward's dZ chains run as splits on the 16-bit MFMA pipe, GI_GEMM_BF3 —
+ *                               same result to ~3e-7; gi_bf3_enable)
+ *       GI_X2=0                 those launches as three bf16 planes (six products) instead of two scaled fp16 planes
+ *                               (three products, GI_GEMM_X2; gi_x2_enable); also puts the dZ chains back on fp32
+ *       GI_CHAIN_X2=0           only the dZ chains back on the fp32 chain kernel (gi_chain_params.x2_wamax unused)
  *       GI_GEMM_LOG=<file>      one line per GEMM launch (tools/gemm_launch_report.py)
+ *     and measurement aids that pick between kernels / schedules that compute the same thing (the A/B files under
+ *     profiles/r04 name them): GI_B3P, GI_B3V, GI_B3P_ALL, GI_B3P_STREAM, GI_B3V_GROUPED (which 16-bit-pipe kernel),
+ *     GI_B3W_MSG, GI_B3W_G (message-stack / graph-level weight gradients on the 16-bit pipe below their size
+ *     thresholds), GI_P0_LAYERWISE (pass 0 without the chain kernel), GI_CHAIN_BWD64 (64-row fp32 chain blocks in
+ *     the backward).
  */
 #ifndef GRAPHINVENT_AMD_H
 #define GRAPHINVENT_AMD_H
