@@ -158,3 +158,40 @@ def test_graph_capture_flag_state_is_recorded_at_import():
     assert run({}) == ["1", "0", "fine"]                                       # set by the package, in time
     assert run({"DEBUG_CLR_GRAPH_PACKET_CAPTURE": "0"}) == ["1", "0", "fine"]  # the caller's own 0
     assert run({"DEBUG_CLR_GRAPH_PACKET_CAPTURE": "1"}) == ["0", "1", "refused"]
+
+
+def test_ctypes_structs_have_the_sizes_and_offsets_of_the_header(tmp_path):
+    """graphinvent_amd/lib.py mirrors the header's structs by hand (ctypes): a field added on one side only shifts
+    everything behind it silently.  A C program compiled from include/graphinvent_amd.h with gcc prints sizeof of every
+    mirrored struct and the offsets of the fields added last; they must equal ctypes' view."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    pairs = [("gi_compact_layout_t", L.CompactLayout), ("gi_gemm_params", L.GemmParams), ("gi_chain_layer", L.ChainLayer),
+             ("gi_chain_params", L.ChainParams), ("gi_reduce_desc", L.ReduceDesc), ("gi_absmax_desc", L.AbsmaxDesc),
+             ("gi_bf3_pack_desc", L.Bf3PackDesc), ("gi_graph", L.Graph), ("gi_ggnn_dims", L.GgnnDims),
+             ("gi_dropout_params", L.DropoutParams)]
+    offs = [("gi_gemm_params", "c_amax", L.GemmParams.c_amax.offset),
+            ("gi_gemm_params", "m_dev", L.GemmParams.m_dev.offset),
+            ("gi_chain_params", "x2_wamax", L.ChainParams.x2_wamax.offset),
+            ("gi_chain_params", "image_stride", L.ChainParams.image_stride.offset),
+            ("gi_graph", "p0_cache", L.Graph.p0_cache.offset),
+            ("gi_ggnn_dims", "drop_seed", L.GgnnDims.drop_seed.offset)]
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "graphinvent_amd.h"', 'int main(void) {']
+    src += [f'  printf("%zu\\n", sizeof({c}));' for c, _ in pairs]
+    src += [f'  printf("%zu\\n", offsetof({c}, {f}));' for c, f, _ in offs]
+    src += ['  printf("%d %d %d %d\\n", GI_ABI_VERSION, GI_MAX_GROUPS, GI_CHAIN_MAXL, GI_AMAX_WORDS);', '  return 0;', '}']
+    cfile, exe = tmp_path / "sizes.c", tmp_path / "sizes"
+    cfile.write_text("\n".join(src))
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run(["gcc", "-I", inc, str(cfile), "-o", str(exe)], check=True)          # (the header is plain C)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    got = [int(x) for x in out[:len(pairs) + len(offs)]]
+    for (c, t), n in zip(pairs, got):
+        assert C.sizeof(t) == n, (c, C.sizeof(t), n)
+    for (c, f, o), n in zip(offs, got[len(pairs):]):
+        assert o == n, (c, f, o, n)
+    abi, groups, maxl, words = (int(x) for x in out[len(pairs) + len(offs)].split())
+    assert (abi, groups, maxl, words) == (L.ABI_VERSION, L.GI_MAX_GROUPS, L.CHAIN_MAXL, L.AMAX_WORDS)
