@@ -195,3 +195,18 @@ def test_ctypes_structs_have_the_sizes_and_offsets_of_the_header(tmp_path):
         assert o == n, (c, f, o, n)
     abi, groups, maxl, words = (int(x) for x in out[len(pairs) + len(offs)].split())
     assert (abi, groups, maxl, words) == (L.ABI_VERSION, L.GI_MAX_GROUPS, L.CHAIN_MAXL, L.AMAX_WORDS)
+
+
+def test_every_environment_switch_the_library_reads_is_documented_in_the_header():
+    """`getenv("GI_…")` in csrc/ against the conventions block of include/graphinvent_amd.h (lab-only macros of the
+    tools/ programs — GI_LAB_* — are not the library's)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    read = set()
+    csrc = os.path.join(root, "graphinvent_amd", "csrc")
+    for name in os.listdir(csrc):
+        if name.endswith((".hip", ".h")):
+            read |= set(re.findall(r'getenv\("(GI_[A-Z0-9_]+)"\)', open(os.path.join(csrc, name)).read()))
+    header = open(os.path.join(root, "include", "graphinvent_amd.h")).read()
+    block = header[:header.index("#ifndef GRAPHINVENT_AMD_H")]
+    documented = set(re.findall(r"\b(GI_[A-Z0-9_]+)\b", block))
+    assert read and read <= documented, sorted(read - documented)
