@@ -475,6 +475,13 @@ def main():
         + ": max error against the fp64 product 3e-7 relative, the fp32 MFMA chain's own: 5e-7 "
           "(tests/test_kernels_gpu.py); everything else on v_mfma_f32_32x32x2_f32"
         if lib.load().gi_bf3_enable(-1) else "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere")
+    # fp16x2 dynamic-range guard (gi_graph.x2_guard): counted on the device during every warm-up and timed step
+    gs = model.x2_guard_stats()
+    result["x2_guard"] = dict(gs, steps_observed=args.steps + args.warmup,
+                              note="rows of a forward fp16x2 launch's activations / rows+columns of its weights more "
+                                   "than 2^24 below the tensor's largest magnitude (fewer than ~14 bits left): any "
+                                   "such line trips the model into bf16x3 splits from the next forward on; "
+                                   "dgrad_rows is informational (the backward's outputs are sums over rows)")
     # graph_compact's sizes: found on the host (counting phase one batch ahead) / read back behind the stream
     result["config"]["compact_readbacks_timed_steps"] = first_readbacks
     if args.backend != "nccl":

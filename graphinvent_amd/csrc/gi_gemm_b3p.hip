@@ -249,6 +249,7 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
 
     // ---- staging chunk c (0..11) of k tile kt: one pair-split, and the LDS writes it completes ----------------
     unsigned q0[4], q1[4], q2[4];                  // planes of the 8-byte / 16-byte piece being assembled
+    float rowmax[2] = {0.f, 0.f};                  // fp16x2 guard (gi_gemm_params.x2_guard): max |a| staged of the thread's two contig A rows
     auto stage_chunk = [&](auto st, int kt, int c) __attribute__((always_inline)) {
         constexpr bool ST = decltype(st)::value;
         unsigned char* S = smem + (kt & 1) * STAGE;
@@ -262,6 +263,8 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
                 v = gi_fix4(v, k0 + 4 * c8, isA ? a_cmax : b_cmax, p.K, true);
                 if (isA) ra[u] = v; else rb[u - 2] = v;
             }
+            if (X2 && !AM && isA && h == 0)
+                rowmax[u & 1] = fmaxf(fmaxf(rowmax[u & 1], fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             if (X2) gx_split2(h ? v.z : v.x, h ? v.w : v.y, isA ? sa : sb, q0[h], q1[h]);
             else gp_split2(h ? v.z : v.x, h ? v.w : v.y, q0[h], q1[h], q2[h]);
             if (h == 1) {
@@ -393,6 +396,25 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
         else { mfma4(af1, bf1, 4); mfma4(af1, bf1, 5); }
     }
     GP_WG_STAMP(2);
+
+    // ---- fp16x2 dynamic-range guard (forward / dgrad layouts; see gi_gemm_bf3.hip): rows of A whose largest scaled
+    // magnitude is below 2^-11 keep fewer than ~14 bits.  Once per launch: the workgroups of the first column tile.
+    if (X2 && !AM && p.x2_guard && bx == 0 && !(p.flags & GI_GEMM_SPLITK)) {
+        int n_low = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float m = rowmax[i];
+            m = fmaxf(m, __shfl_xor(m, 1));
+            m = fmaxf(m, __shfl_xor(m, 2));
+            m = fmaxf(m, __shfl_xor(m, 4));                     // the eight lanes (k chunks) of a row
+            const bool real_row = m0 + crow + 64 * i < m_end;
+            n_low += (c8 == 0 && real_row && m > 0.f && m * sa < 0x1p-11f) ? 1 : 0;
+        }
+        if (n_low) {
+            atomicAdd(p.x2_guard, n_low);
+            if (p.x2_guard_host) *reinterpret_cast<volatile int*>(p.x2_guard_host) = 1;
+        }
+    }
 
     // ---- epilogue (C/D layout of a 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) --
     // One workgroup per CU: nothing else runs while a tile's 64 outputs per thread are finished, so this part is

@@ -183,6 +183,8 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
     // (16-deep tiles are 24 MFMAs = 0.3 us of work per wave, far less than a trip to L2 / HBM).
     // STEADY tiles are full in k: uniform base (advanced by the SALU) + a constant 32-bit lane offset per load, no
     // clamping, no fix-up — the generic form (clamped column, zero fill beyond K) only runs a tile's last steps.
+    // fp16x2 dynamic-range guard (gi_gemm_params.x2_guard): the largest magnitude this thread staged of its two A rows
+    float rowmax[2] = {0.f, 0.f};
     v4f ra0[2], ra1[2], rf0[2], rf1[2];            // (rf*: B as fp32 when BFP, else unused)
     gi_u32x4 rb0[3], rb1[3], rp0[3], rp1[3];       // (rp*: A planes when APL, else unused)
     unsigned bf_voff[2];
@@ -248,6 +250,7 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
             gi_u32x2 w0, w1, w2;
             unsigned x0, x1, x2, y0, y1, y2;
             if (X2) {
+                rowmax[i] = fmaxf(fmaxf(rowmax[i], fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                 gx_split2(v.x, v.y, sa, x0, x1);
                 gx_split2(v.z, v.w, sa, y0, y1);
             } else {
@@ -366,6 +369,27 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
         compute(1);
         sstore(GEN, min(kt + 2, nk - 1), 0, ra0, rb0, rp0, rf0);
         __syncthreads();
+    }
+
+    // ---- fp16x2 dynamic-range guard: rows of A that the per-tensor scale leaves with too few bits -----------------
+    // A row whose largest SCALED magnitude is below 2^-11 (more than 2^24 below the tensor's maximum, which scales into
+    // [2^13, 2^14)) keeps fewer than ~14 significant bits: h1 is still a normal fp16, the residual h2 already rounds to
+    // fp16's subnormal quantum 2^-24.  Counted once per launch (by the workgroups of the first column tile); zero rows
+    // are exact and not counted.
+    if (X2 && p.x2_guard && bx == 0) {
+        int n_low = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float m = rowmax[i];
+            m = fmaxf(m, __shfl_xor(m, 1));
+            m = fmaxf(m, __shfl_xor(m, 2));                     // the four lanes (k chunks) of a row
+            const bool real_row = m0 + (tid >> 2) + 64 * i < m_end;
+            n_low += (c4 == 0 && real_row && m > 0.f && m * sa < 0x1p-11f) ? 1 : 0;
+        }
+        if (n_low) {
+            atomicAdd(p.x2_guard, n_low);
+            if (p.x2_guard_host) *reinterpret_cast<volatile int*>(p.x2_guard_host) = 1;
+        }
     }
 
     // ---- epilogue (C/D layout of a 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) --

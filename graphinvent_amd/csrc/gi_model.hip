@@ -142,9 +142,9 @@ bool bf3_enabled() {
 // rows are bit-independent of one another, which the pass-0 row cache, the equality of blocking and host-sync-free
 // forwards and of forwards with and without a tape rely on (the fp16x2 chain scales activations per 64-row block, so a
 // row's last bits depend on its block).  GI_CHAIN_X2=0: the fp32-MFMA chain in the backward too.
-static bool chain_x2_enabled() {
+static bool chain_x2_enabled(bool call_x2) {
     static const int v = getenv("GI_CHAIN_X2") ? atoi(getenv("GI_CHAIN_X2")) : 1;
-    return v != 0 && x2_enabled() && bf3_enabled();
+    return v != 0 && call_x2 && x2_enabled() && bf3_enabled();
 }
 bool bf3_wide(const Mlp& q, int l) { return q.fan_in(l) >= BF3_MIN_WIDTH && q.fan_out(l) >= BF3_MIN_WIDTH; }
 bool bf3_layer_ok(const Mlp& q, int l) { return bf3_enabled() && bf3_wide(q, l); }
@@ -392,7 +392,11 @@ struct Run {
     // reads the fp32 weight as stored, GI_GEMM_BF3B_F32, img = NULL)
     // amax (fp16x2, gi_x2.h; NULL: the launch stays bf16x3): [0] max |W|, [1] max |layer input|, [2] max |dZ of the
     // layer's output| — written by gi_absmax / by the c_amax of the launch that produces the tensor
-    struct Bf3 { const float* W; const unsigned short* img; float* amax; } bf3[GI_BF3_PACK_MAX];
+    // in_ok / dz_ok: the cell has a PRODUCER in this model — the forward launch of the layer below (c_amax of add_fwd)
+    // and the dgrad launch of the layer above (c_amax of add_dgrad).  A stack's first layer reads h (GRU gate kernel)
+    // and its last layer's dZ comes from the loss / gather backward: nobody measures those, so fp16x2 launches that
+    // would need them stay bf16x3 (round-4 advisor finding: a zeroed cell reads as scale 1).
+    struct Bf3 { const float* W; const unsigned short* img; float* amax; bool in_ok, dz_ok; } bf3[GI_BF3_PACK_MAX];
     int nbf3 = 0;
     const Bf3* bf3_layer(const float* W, int rows) const {
         if (rows < BF3_MIN_ROWS) return nullptr;
@@ -408,6 +412,9 @@ struct Run {
     // scratch for split-K slabs of skinny problems inside one batched launch (reset by flush_batch)
     float* skinny = nullptr;
     long long skinny_floats = 0, skinny_used = 0;
+    bool x2 = true;                         // fp16x2 on this call's 16-bit-pipe launches (GI_X2 and not GI_RUN_NO_X2 / GI_BWD_NO_X2)
+    int* guard = nullptr;                   // gi_graph.x2_guard / x2_guard_host: the fp16x2 dynamic-range guard
+    int* guard_host = nullptr;
     struct SlabPlan* sp = nullptr; // backward only: where the wgrad slabs go and what they reduce to
     float* slabs = nullptr;
     float* const* grads = nullptr;
@@ -562,6 +569,7 @@ struct Batch {
 void maybe_split_k(Batch& b, Run& r, gi_gemm_params& p) {
     const int ns = skinny_splits(p.M, p.N, p.K);
     if (ns <= 1 || p.ngroups || p.a_idx || b.npost >= 8) return;
+    if (p.c_amax) return;       // (the slabs' epilogue publishes no amax, and the GEMM's own would be that of partial sums)
     const int ld = gi_r4(p.N);
     const long long stride = gi_r4l((long long)p.M * ld), need = stride * ns;
     if (!r.skinny || r.skinny_used + need > r.skinny_floats) return;
@@ -586,17 +594,16 @@ struct Deferred {
 
 void flush_batch(Run& r, Batch& b, bool wgrad) {
     if (!r.ok() || b.n == 0) { b.n = 0; b.npost = 0; r.skinny_used = 0; return; }
-    int nb3 = 0;
-    for (int i = 0; i < b.n; ++i) nb3 += (b.p[i].flags & GI_GEMM_BF3) != 0;
-    if (nb3 && nb3 < b.n) {                       // a launch is all-bf16x3 or not at all: two launches
-        gi_gemm_params keep[8];
-        int nk = 0, n3 = 0;
+    // a launch is ONE arithmetic: fp16x2 problems, bf16x3 problems and fp32-MFMA problems each get their own
+    {
+        gi_gemm_params cls[2][8];
+        int nc[2] = {0, 0}, nk = 0;
         for (int i = 0; i < b.n; ++i) {
-            if (b.p[i].flags & GI_GEMM_BF3) b.p[n3++] = b.p[i];        // (n3 <= i: in-place compaction is safe)
-            else keep[nk++] = b.p[i];
+            if (b.p[i].flags & GI_GEMM_BF3) { const int x = (b.p[i].flags & GI_GEMM_X2) ? 1 : 0; cls[x][nc[x]++] = b.p[i]; }
+            else b.p[nk++] = b.p[i];                                    // (nk <= i: in-place compaction is safe)
         }
-        r.chk(gi_gemm_batch(b.p, n3, r.st));
-        for (int i = 0; i < nk; ++i) b.p[i] = keep[i];
+        for (int x = 1; x >= 0; --x)
+            if (nc[x] && r.ok()) r.chk(gi_gemm_batch(cls[x], nc[x], r.st));
         b.n = nk;
     }
     if (!wgrad) {                               // common tile for the whole launch
@@ -605,7 +612,7 @@ void flush_batch(Run& r, Batch& b, bool wgrad) {
         const int tn = b11 > 8192 ? 2 : 1;
         for (int i = 0; i < b.n; ++i) { b.p[i].tm = 1; b.p[i].tn = tn; }
     }
-    r.chk(gi_gemm_batch(b.p, b.n, r.st));
+    if (b.n && r.ok()) r.chk(gi_gemm_batch(b.p, b.n, r.st));
     for (int i = 0; i < b.npost && r.ok(); ++i) {
         const SlabEpilogue& e = b.post[i];
         r.chk(gi_slab_epilogue(e.slabs, e.nsplit, e.stride, e.rows, e.cols, e.ld, e.flags, e.bias, e.act,
@@ -624,7 +631,10 @@ void add_fwd(Batch& b, Run& r, const float* W, const float* bias, int in, int ou
     p.flags = GI_EPI_BIAS | (selu ? GI_EPI_SELU : 0);
     if (const Run::Bf3* e = r.bf3_layer(W, rows)) {
         p.flags |= GI_GEMM_BF3 | GI_GEMM_BF3B_F32;                             // (B = W [out][in] as stored)
-        if (e->amax) { p.flags |= GI_GEMM_X2; p.a_amax = e->amax + GI_AMAX_WORDS; p.b_amax = e->amax; }
+        if (e->amax && e->in_ok) {
+            p.flags |= GI_GEMM_X2; p.a_amax = e->amax + GI_AMAX_WORDS; p.b_amax = e->amax;
+            p.x2_guard = r.guard; p.x2_guard_host = r.guard_host;           // activation rows outside the per-tensor range
+        }
     }
     if (Wnext)                                    // Y is the next layer's input: it needs max |Y| if it runs fp16x2
         if (const Run::Bf3* nx = r.bf3_layer(Wnext, rows))
@@ -650,7 +660,10 @@ void add_dgrad(Batch& b, Run& r, int widx, int n_out, int n_in, int ncols, const
             if (e->img) {                                                     // W^T as fp32 [n_in][r4(n_out)]
                 p.B = reinterpret_cast<const float*>(e->img); p.b_major = 0; p.ldb = gi_r4(n_out);
                 p.flags |= GI_GEMM_BF3 | GI_GEMM_BF3B_F32;
-                if (e->amax) { p.flags |= GI_GEMM_X2; p.a_amax = e->amax + 2 * GI_AMAX_WORDS; p.b_amax = e->amax; }
+                if (e->amax && e->dz_ok) {
+                    p.flags |= GI_GEMM_X2; p.a_amax = e->amax + 2 * GI_AMAX_WORDS; p.b_amax = e->amax;
+                    p.x2_guard = r.guard ? r.guard + 2 : nullptr;            // dZ rows: counted, never a trip (sums over rows)
+                }
                 return;
             }
     maybe_split_k(b, r, p);
@@ -689,7 +702,7 @@ void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* wid
         p.flags |= GI_GEMM_BF3;
         if (!g.n)
             if (const Run::Bf3* e = r.bf3_layer(r.P[widx[0]], rows))
-                if (e->amax) { p.flags |= GI_GEMM_X2; p.a_amax = e->amax + 2 * GI_AMAX_WORDS; p.b_amax = e->amax + GI_AMAX_WORDS; }
+                if (e->amax && e->in_ok && e->dz_ok) { p.flags |= GI_GEMM_X2; p.a_amax = e->amax + 2 * GI_AMAX_WORDS; p.b_amax = e->amax + GI_AMAX_WORDS; }
     }
     const int slot = q.n - 1;
     if (g.n) {
@@ -1219,14 +1232,22 @@ extern "C" int gi_ggnn_num_params(const gi_ggnn_dims* d) {
     return rc ? rc : m.nparams;
 }
 
-// the layers of this call that run as bf16x3 launches; the backward packs their W^T images (the forward stages the
-// fp32 weights as stored: 4 bytes per element through L2 instead of the image's 6 — 84 -> 76 us per launch)
-void bf3_prepare(Run& r, const Model& m, float* ws, const Ws& w, bool backward, int rows) {
+// the layers of this call that run as bf16x3 / fp16x2 launches.  Builds the table the launches look their layer up in
+// (r.bf3: W^T image for the backward — the forward stages the fp32 weights as stored: 4 bytes per element through L2
+// instead of the image's 6, 84 -> 76 us per launch — and the amax cells) and, per `what`, enqueues on `st`:
+//   BF3_DO_AMAX  zero the cells, max |W| of every layer (gi_absmax), the weights' dynamic-range check (the forward),
+//   BF3_DO_PACK  the W^T images (the backward, or the forward on its side stream: GI_RUN_PREPACK_BWD).
+// `backward` selects which table is left in r (a forward that prepacks calls this twice: images first, then its own).
+enum { BF3_DO_AMAX = 1, BF3_DO_PACK = 2 };
+void bf3_prepare(Run& r, const Model& m, float* ws, const Ws& w, bool backward, int rows, int what, hipStream_t st) {
     r.nbf3 = 0;
     if (!bf3_enabled() || r.drop || rows < BF3_MIN_ROWS || w.bf3_floats <= 0) return;
     const Mlp* t1[4] = {&m.att, &m.emb, &m.add1, &m.conn1};
     gi_bf3_pack_desc d[GI_BF3_PACK_MAX];
+    gi_absmax_desc ad[GI_BF3_PACK_MAX], wd[GI_BF3_PACK_MAX];       // (flattened for gi_absmax; [out][in] for the guard)
     unsigned short* img = reinterpret_cast<unsigned short*>(ws + w.bf3);
+    float* am = ws + w.amax;
+    const bool x2 = r.x2 && gi_b3p_enable(-1);
     long long used = 0;
     int n = 0;
     for (const Mlp* q : t1)
@@ -1237,35 +1258,37 @@ void bf3_prepare(Run& r, const Model& m, float* ws, const Ws& w, bool backward, 
             d[n].rows = backward ? fi : fo; d[n].cols = backward ? fo : fi;
             d[n].image = img + used; d[n].as_f32 = 1;     // (W^T as fp32: 4 bytes per element through L2, not 6)
             r.bf3[n].W = d[n].W; r.bf3[n].img = backward ? d[n].image : nullptr;
+            r.bf3[n].in_ok = l > 0; r.bf3[n].dz_ok = l + 1 < q->layers();
+            // fp16x2 (gi_x2.h): three amax cells per layer — max |W| (gi_absmax, in the forward), max |layer input| and
+            // max |dZ of its output| (the c_amax of the launches that produce them; zeroed once per forward: the
+            // backward runs on the same workspace)
+            r.bf3[n].amax = x2 ? am + 4LL * GI_AMAX_WORDS * n : nullptr;
+            ad[n].x = d[n].W; ad[n].rows = 1; ad[n].cols = fi * fo; ad[n].ld = fi * fo; ad[n].out = r.bf3[n].amax;
+            wd[n].x = d[n].W; wd[n].rows = fo; wd[n].cols = fi; wd[n].ld = fi; wd[n].out = r.bf3[n].amax;
             used += std::max(gi_bf3_image_elems(fo, fi), gi_bf3_image_elems(fi, fo));
             ++n;
         }
-    if (n && backward) r.chk(gi_bf3_pack(d, n, r.st));
-    // fp16x2 (gi_x2.h): three amax cells per layer — max |W| (gi_absmax, here, in the forward), max |layer input| and max
-    // |dZ of its output| (the c_amax of the launches that produce them; zeroed here, once per forward: the backward
-    // runs on the same workspace)
-    if (n && x2_enabled() && gi_b3p_enable(-1)) {
-        float* am = ws + w.amax;
-        gi_absmax_desc ad[GI_BF3_PACK_MAX];
-        for (int i = 0; i < n; ++i) {
-            r.bf3[i].amax = am + 4LL * GI_AMAX_WORDS * i;
-            ad[i].x = r.bf3[i].W; ad[i].rows = 1; ad[i].out = r.bf3[i].amax;
-        }
-        int k = 0;
-        for (const Mlp* q : t1)
-            for (int l = 0; l < q->layers() && k < n; ++l) {
-                if (!bf3_layer_ok(*q, l)) continue;
-                ad[k].cols = q->fan_in(l) * q->fan_out(l); ad[k].ld = ad[k].cols;
-                ++k;
-            }
-        if (!backward) {
-            r.chk((int)hipMemsetAsync(am, 0, sizeof(float) * 4 * GI_AMAX_WORDS * n, r.st));
-            r.chk(gi_absmax(ad, n, r.st));
-        }
-    } else {
-        for (int i = 0; i < n; ++i) r.bf3[i].amax = nullptr;
+    if (n && backward && (what & BF3_DO_PACK)) r.chk(gi_bf3_pack(d, n, st));
+    if (n && x2 && (what & BF3_DO_AMAX)) {
+        r.chk((int)hipMemsetAsync(am, 0, sizeof(float) * 4 * GI_AMAX_WORDS * n, st));
+        r.chk(gi_absmax(ad, n, st));
+        if (r.guard && r.ok()) r.chk(gi_x2_weight_guard(wd, n, r.guard + 1, r.guard_host, st));
     }
     r.nbf3 = n;
+}
+
+// per device: "the weight images a forward prepacked for its backward are written" (GI_RUN_PREPACK_BWD -> GI_BWD_PREPACKED).
+// Every forward records it on the side stream behind its packs; that stream is in order, so the latest record covers
+// every earlier forward's images too (several forwards, then their backwards: GraphGeneratorRL.py:131-132).
+hipEvent_t prepack_event() {
+    constexpr int MAXDEV = 16;
+    static hipEvent_t ev[MAXDEV];
+    static bool made[MAXDEV] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = (dev >= 0 && dev < MAXDEV) ? dev : 0;
+    if (!made[dev]) { (void)hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming); made[dev] = true; }
+    return ev[dev];
 }
 
 static bool sizes_ok(int S, int E, int U, int D0) {
@@ -1345,7 +1368,14 @@ static int dropout_graph_ok(const gi_ggnn_dims& d, int S, int E, int U, int D0) 
 
 extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* params,
                                const gi_graph* gp, float* ws, float* out, int ldout, void* stream) {
+    return gi_ggnn_forward_ex(dp, params, gp, ws, out, ldout, stream, nullptr, 0);
+}
+
+extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* params,
+                                  const gi_graph* gp, float* ws, float* out, int ldout, void* stream,
+                                  void* side_stream, int run_flags) {
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
+    if (run_flags & ~(GI_RUN_PREPACK_BWD | GI_RUN_NO_X2)) return GI_EINVAL;
     Model m;
     int rc = build_model(dp, m);
     if (rc) return rc;
@@ -1374,6 +1404,8 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
     Run r{(hipStream_t)stream, params, 0};
     r.drop = d.dropout != 0; r.seed = d.drop_seed; r.fshift = w.fshift;
     r.skinny = ws + w.skinny; r.skinny_floats = w.skinny_floats;
+    r.x2 = x2_enabled() && !(run_flags & GI_RUN_NO_X2);
+    r.guard = gp->x2_guard; r.guard_host = gp->x2_guard_host;
     const int R = w.R;
     if (gp->bounded) { r.dims = gfix + L.dims; r.d0_dev = gfix + L.counts + 20; r.R_bound = R; }
     int maxUt = 0;
@@ -1393,7 +1425,38 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
                 r.img_f[k] = ws + w.img_f[k];
                 chain_pack(r, k ? m.eatt : m.msg, d.Fe, false, r.img_f[k]);
             }
-    bf3_prepare(r, m, ws, w, false, R);
+    // Everything else that depends on the weights only goes to the side stream when there is one: the amax cells of
+    // the fp16x2 layers (needed by the readout, hundreds of microseconds from here) and — GI_RUN_PREPACK_BWD — the
+    // images the backward would otherwise pack at its start, in front of its first launches.
+    SideStream fside{(hipStream_t)side_stream, 0};
+    hipStream_t prep = r.st;
+    hipEvent_t cells_ready = nullptr;
+    if (side_stream) {
+        hipEvent_t start = fside.next();
+        r.chk((int)hipEventRecord(start, r.st));            // (the weights were last written on the caller's stream)
+        r.chk((int)hipStreamWaitEvent(fside.st, start, 0));
+        prep = fside.st;
+    }
+    if ((run_flags & GI_RUN_PREPACK_BWD) && !r.drop) {
+        bf3_prepare(r, m, ws, w, true, R, BF3_DO_PACK, prep);
+        if (d.passes > 0 && E > 0)
+            for (int k = 0; k < (attn ? 2 : 1); ++k)
+                if (w.img_b_n[k] > 0) {
+                    Run rp = r;                                   // (chain_pack reads the stream and the flavour from its Run)
+                    rp.st = prep;
+                    rp.chain_amax[k] = chain_x2_enabled(r.x2) ? ws + w.chain_amax[k] : nullptr;
+                    chain_pack(rp, k ? m.eatt : m.msg, d.Fe, true, ws + w.img_b[k]);
+                    r.chk(rp.rc);
+                }
+    }
+    bf3_prepare(r, m, ws, w, false, R, BF3_DO_AMAX, prep);
+    if (side_stream) {
+        cells_ready = fside.next();
+        r.chk((int)hipEventRecord(cells_ready, fside.st));
+        if (run_flags & GI_RUN_PREPACK_BWD) r.chk((int)hipEventRecord(prepack_event(), fside.st));
+    } else if (run_flags & GI_RUN_PREPACK_BWD) {
+        r.chk((int)hipEventRecord(prepack_event(), r.st));
+    }
     // pass-0 row cache (inference loops): only in front of the one-launch stack path, whose kernel can skip
     int* const p0c = static_cast<int*>(gp->p0_cache);
     const bool p0cache = p0c && w.D0 > 0 && E > 0 && !r.drop && r.img_f[0] && (!attn || r.img_f[1]) &&
@@ -1464,6 +1527,7 @@ extern "C" int gi_ggnn_forward(const gi_ggnn_dims* dp, const float* const* param
                                  seg_off, R, d.H, d.Fn, r.dims, r.st));
     }
     // ---- readout (gnn/mpnn.py:299-303) -----------------------------------------------------------
+    if (cells_ready) r.chk((int)hipStreamWaitEvent(r.st, cells_ready, 0));     // amax cells zeroed, max |W| in them
     const float* hx = ws + w.hx[d.passes];
     {   // the four node-level stacks, layer by layer in shared launches
         MlpJob jobs[4] = {};
@@ -1537,6 +1601,8 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
                                       const gi_graph* gp, float* ws, float* slabs,
                                       const float* y_out, int ldout, const float* d_out, int lddout,
                                       float* const* grads, void* stream, void* side_stream, int phase) {
+    const bool prepacked = (phase & GI_BWD_PREPACKED) != 0, no_x2 = (phase & GI_BWD_NO_X2) != 0;
+    phase &= ~(GI_BWD_PREPACKED | GI_BWD_NO_X2);
     if (phase != GI_BWD_ALL && phase != GI_BWD_READOUT && phase != GI_BWD_PASSES) return GI_EINVAL;
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     Model m;
@@ -1576,6 +1642,9 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
     Run r{(hipStream_t)stream, params, 0};
     r.drop = d.dropout != 0; r.seed = d.drop_seed; r.fshift = w.fshift;
     r.skinny = ws + w.skinny; r.skinny_floats = w.skinny_floats;
+    r.x2 = x2_enabled() && !no_x2;
+    r.guard = gp->x2_guard; r.guard_host = nullptr;       // (the backward only counts: dZ rows never trip)
+    if (prepacked) r.chk((int)hipStreamWaitEvent(r.st, prepack_event(), 0));   // images written by the forward's side stream
     const long long out_fshift = r.drop ? (long long)d.B * ldout : 0;   // logits -> their factors
     const int R = w.R;
     int maxUt = 0;
@@ -1608,7 +1677,7 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
     if (phase == GI_BWD_PASSES)          // the readout half ran (and was reduced) in an earlier call
         readout_params([&](int widx) { sp.e[widx].reduced = 1; });
     if (phase != GI_BWD_PASSES) {
-    bf3_prepare(r, m, ws, w, true, S + 1);
+    bf3_prepare(r, m, ws, w, true, S + 1, prepacked ? 0 : BF3_DO_PACK, r.st);
     // ---- tier 2 (gnn/modules.py:265-279) ---------------------------------------------------------
     if (gi_fuse_flags() & GI_FUSE_TIER2_DSELU) {
         r.chk(gi_selu_bwd_cols3_f(d_out, lddout, y_out, ldout, out_fshift, d.B, NA, ws + w.dzA, w.ldNA, NC,
@@ -1701,10 +1770,10 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
     if (d.passes > 0 && E > 0)          // packed weight images of the dZ chains, once per backward
         for (int k = 0; k < (attn ? 2 : 1); ++k)
             if (w.img_b_n[k] > 0) {
-                if (chain_x2_enabled()) r.chain_amax[k] = ws + w.chain_amax[k];
+                if (chain_x2_enabled(r.x2)) r.chain_amax[k] = ws + w.chain_amax[k];
                 r.img_b[k] = ws + w.img_b[k];
                 r.img_b_stride[k] = w.img_b_stride[k];
-                chain_pack(r, k ? m.eatt : m.msg, d.Fe, true, r.img_b[k]);
+                if (!prepacked) chain_pack(r, k ? m.eatt : m.msg, d.Fe, true, r.img_b[k]);
             }
     // ---- message passes, reversed -------------------------------------------------------------------
     // d h scatter (segmented sum of the message stacks' input gradients over the source CSR): its own

@@ -1410,7 +1410,94 @@ __global__ __launch_bounds__(256) void absmax_rows_kernel(const gi_absmax_desc d
         for (int c = threadIdx.x; c < d.cols; c += 256) m = fmaxf(m, fabsf(d.x[(long long)r * d.ld + c]));
     gx_amax_publish(m, d.out);
 }
+// fp16x2 dynamic-range guard of the WEIGHTS (gi_x2_weight_guard): rows and columns of a matrix whose largest scaled
+// magnitude is below 2^-11 (see gi_gemm_bf3.hip) — an output channel of the forward launch (row of W) or of the dgrad
+// launch (column of W) that the per-tensor scale leaves with fewer than ~14 significant bits.  One workgroup per
+// (matrix, direction, 32 lines): rows — a wave per row at a time, lanes along the row; columns — 32 adjacent columns
+// x 8 row lanes, reduced through LDS.
+struct WGuardArgs { gi_absmax_desc d[GI_ABSMAX_MAX]; int start[GI_ABSMAX_MAX + 1]; int n; int* counter; int* host_flag; };
+__global__ __launch_bounds__(256) void x2_weight_guard_kernel(const WGuardArgs a) {
+    __shared__ float part[8][32];
+    int i = 0;
+    while (i < a.n - 1 && (int)blockIdx.x >= a.start[i + 1]) ++i;
+    const gi_absmax_desc& d = a.d[i];
+    int local = blockIdx.x - a.start[i];
+    const int row_chunks = (d.rows + 31) / 32;
+    float s, inv;
+    gx_scale(gx_amax_read(d.out), s, inv);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int n_low = 0;
+    if (local < row_chunks) {
+        for (int r = local * 32 + wid; r < min(local * 32 + 32, d.rows); r += 4) {
+            float m = 0.f;
+            for (int c = lane; c < d.cols; c += 64) m = fmaxf(m, fabsf(d.x[(long long)r * d.ld + c]));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            n_low += (lane == 0 && m > 0.f && m * s < 0x1p-11f) ? 1 : 0;
+        }
+    } else {
+        local -= row_chunks;
+        const int c = local * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+        float m = 0.f;
+        if (c < d.cols)
+            for (int r = rl; r < d.rows; r += 8) m = fmaxf(m, fabsf(d.x[(long long)r * d.ld + c]));
+        part[rl][threadIdx.x & 31] = m;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+#pragma unroll
+            for (int k = 1; k < 8; ++k) m = fmaxf(m, part[k][threadIdx.x]);
+            n_low += (c < d.cols && m > 0.f && m * s < 0x1p-11f) ? 1 : 0;
+        }
+    }
+    if (n_low) {
+        atomicAdd(a.counter, n_low);
+        if (a.host_flag) *reinterpret_cast<volatile int*>(a.host_flag) = 1;
+    }
+}
 }  // namespace
+
+// rows / columns of up to GI_ABSMAX_MAX weight matrices outside fp16x2's per-tensor range (the cells d.out must hold
+// the matrices' amax already: gi_absmax on the same stream first)
+extern "C" int gi_x2_weight_guard(const gi_absmax_desc* descs, int n, int* counter, int* host_flag, void* stream) {
+    (void)hipGetLastError();
+    if (!descs || n < 1 || n > GI_ABSMAX_MAX || !counter) return GI_EINVAL;
+    WGuardArgs a;
+    memset(&a, 0, sizeof(a));
+    int total = 0, k = 0;
+    for (int i = 0; i < n; ++i) {
+        const gi_absmax_desc& d = descs[i];
+        if (!d.x || !d.out || d.rows < 0 || d.cols < 0 || d.ld < d.cols) return GI_EINVAL;
+        if (d.rows == 0 || d.cols == 0) continue;
+        a.d[k] = d;
+        a.start[k] = total;
+        total += (d.rows + 31) / 32 + (d.cols + 31) / 32;
+        ++k;
+    }
+    if (k == 0) return 0;
+    a.start[k] = total; a.n = k; a.counter = counter; a.host_flag = host_flag;
+    hipLaunchKernelGGL(x2_weight_guard_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, a);
+    return gi_launch_status();
+}
+
+// One int of host memory that kernels can write: the trip flag of the fp16x2 dynamic-range guard (gi_graph.x2_guard_host)
+extern "C" int gi_host_flag_create(int** host, int** dev) {
+    if (!host || !dev) return GI_EINVAL;
+    (void)hipGetLastError();
+    void* h = nullptr;
+    void* d = nullptr;
+    hipError_t e = hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) return (int)e;
+    *reinterpret_cast<volatile int*>(h) = 0;
+    e = hipHostGetDevicePointer(&d, h, 0);
+    if (e != hipSuccess) { (void)hipHostFree(h); return (int)e; }
+    *host = static_cast<int*>(h);
+    *dev = static_cast<int*>(d);
+    return 0;
+}
+extern "C" int gi_host_flag_destroy(int* host) {
+    if (!host) return 0;
+    return (int)hipHostFree(host);
+}
 
 extern "C" int gi_absmax(const gi_absmax_desc* descs, int n, void* stream) {
     (void)hipGetLastError();

@@ -70,7 +70,7 @@ def _set_dropout(dims, c, kind: int, seed: int) -> None:
 
 
 def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dropout_seed=None,
-                     bounds=None, p0_cache=None, sticky_err=None):
+                     bounds=None, p0_cache=None, sticky_err=None, want_backward=False, guard=None, no_x2=False):
     """graph_compact + the fused forward.  Returns (logits, tape); the tape
     (dims, CompactGraph, workspace, per-type edge counts) is what backward consumes.
 
@@ -87,7 +87,13 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dro
     a 1-element int32 CUDA tensor that accumulates the error bits of every bounded forward (``gi_compact_bound``).
 
     ``p0_cache`` (an int32 CUDA tensor of ``gi_p0_cache_words`` words, zero-filled whenever the weights change):
-    the pass-0 row cache of an inference loop (``gi_graph.p0_cache``); the tape cannot feed a backward."""
+    the pass-0 row cache of an inference loop (``gi_graph.p0_cache``); the tape cannot feed a backward.
+
+    ``want_backward``: a backward will follow — the weight images it needs (W^T of the 16-bit-pipe layers, the dZ
+    chains' image) are packed NOW on the side stream, which idles during a forward (``GI_RUN_PREPACK_BWD``); the tape
+    remembers, and ``ggnn_backward_raw`` waits for them instead of packing in front of its first launches.
+    ``guard = (counters, host_flag_dev_ptr)``: the fp16x2 dynamic-range guard (``gi_graph.x2_guard``);
+    ``no_x2``: this forward (and its backward) as bf16x3 splits (``GI_RUN_NO_X2``)."""
     lib = _L.load()
     if bounds is not None:
         return _forward_bounded(lib, consts, nodes, edges, params, kind, bounds, p0_cache, sticky_err)
@@ -118,9 +124,21 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dro
     gs = graph.c_struct()
     if p0_cache is not None and not drop:
         gs.p0_cache = p0_cache.data_ptr()
-    _L.check(lib.gi_ggnn_forward(C.byref(dims), _ptr_table(params), C.byref(gs), ws.data_ptr(),
-                                 out.data_ptr(), apd, torch.cuda.current_stream(dev).cuda_stream),
+    if guard is not None:
+        gs.x2_guard, gs.x2_guard_host = guard[0].data_ptr(), guard[1]
+        graph.x2_guard = guard[0]                           # (the backward counts its dZ rows there too)
+    flags = _L.RUN_NO_X2 if no_x2 else 0
+    side = _side_stream(dev) if (PREPACK_SIDE and not drop) else 0
+    if want_backward and not drop:
+        flags |= _L.RUN_PREPACK_BWD
+    _L.check(lib.gi_ggnn_forward_ex(C.byref(dims), _ptr_table(params), C.byref(gs), ws.data_ptr(),
+                                    out.data_ptr(), apd, torch.cuda.current_stream(dev).cuda_stream, side, flags),
              "gi_ggnn_forward")
+    if side:
+        ws.record_stream(_side_stream_obj(dev, side))       # (a tape dropped without a backward frees ws early)
+    # what the backward of THIS tape must repeat: the run flags and the process-wide arithmetic switches of the forward
+    graph.run_flags = flags
+    graph.modes = (lib.gi_bf3_enable(-1), lib.gi_x2_enable(-1), lib.gi_b3p_enable(-1))
     return (out[:B] if drop else out), (dims, graph, ws)
 
 
@@ -157,8 +175,22 @@ def _forward_bounded(lib, consts, nodes, edges, params, kind, bounds, p0_cache=N
 
 
 _SIDE_STREAMS = {}
+_SIDE_STREAM_OBJS = {}
 #: False keeps the whole backward on one stream (bench.py's one_stream measurement; no env knob)
 WGRAD_SIDE_STREAM = True
+#: False (environment GI_PREPACK=0): the forward packs nothing ahead and enqueues the weights' amax pass on its own
+#: stream — the round-4 schedule (A/B aid)
+import os as _os_env
+PREPACK_SIDE = _os_env.environ.get("GI_PREPACK", "1") != "0"
+
+
+def _side_stream_obj(device: torch.device, handle: int):
+    """torch's view of the side stream (for ``Tensor.record_stream``)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), handle)
+    st = _SIDE_STREAM_OBJS.get(key)
+    if st is None:
+        st = _SIDE_STREAM_OBJS[key] = torch.cuda.ExternalStream(handle, device=device)
+    return st
 
 
 def _side_stream(device: torch.device) -> int:
@@ -222,15 +254,31 @@ def ggnn_backward_raw(tape, out, d_out, params, early_hook=None, bucket=None):
     args = (C.byref(dims), _ptr_table(params), C.byref(gs), ws.data_ptr(), slabs.data_ptr(),
             out.data_ptr(), out.stride(0), d_out.data_ptr(), d_out.stride(0), _ptr_table(grads),
             main.cuda_stream, side)
-    if early_hook is None:
-        _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_ALL), "gi_ggnn_backward")
+    # the forward's arithmetic: its run flags, and the process-wide switches as they stood then (toggling one between
+    # a forward and its backward would make the backward read amax cells / images nobody wrote)
+    fl = getattr(graph, "run_flags", 0)
+    bits = (_L.BWD_PREPACKED if fl & _L.RUN_PREPACK_BWD else 0) | (_L.BWD_NO_X2 if fl & _L.RUN_NO_X2 else 0)
+    guard = getattr(graph, "x2_guard", None)
+    if guard is not None:
+        gs.x2_guard = guard.data_ptr()
+    modes = getattr(graph, "modes", None)
+    now = (lib.gi_bf3_enable(-1), lib.gi_x2_enable(-1), lib.gi_b3p_enable(-1))
+    restore = modes is not None and tuple(modes) != now
+    if restore:
+        lib.gi_bf3_enable(modes[0]); lib.gi_x2_enable(modes[1]); lib.gi_b3p_enable(modes[2])
+    try:
+        if early_hook is None:
+            _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_ALL | bits), "gi_ggnn_backward")
+            return grads, gflat
+        _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_READOUT | bits), "gi_ggnn_backward(readout)")
+        ready = torch.cuda.Event()
+        ready.record(_side_stream_obj(dev, side) if side else main)
+        early_hook(gflat, offs[lib.gi_ggnn_first_readout_param(C.byref(dims))], ready)
+        _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_PASSES | bits), "gi_ggnn_backward(passes)")
         return grads, gflat
-    _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_READOUT), "gi_ggnn_backward(readout)")
-    ready = torch.cuda.Event()
-    ready.record(torch.cuda.ExternalStream(side, device=dev) if side else main)
-    early_hook(gflat, offs[lib.gi_ggnn_first_readout_param(C.byref(dims))], ready)
-    _L.check(lib.gi_ggnn_backward_phase(*args, _L.BWD_PASSES), "gi_ggnn_backward(passes)")
-    return grads, gflat
+    finally:
+        if restore:
+            lib.gi_bf3_enable(now[0]); lib.gi_x2_enable(now[1]); lib.gi_b3p_enable(now[2])
 
 
 class _GGNNFunction(torch.autograd.Function):
@@ -239,7 +287,8 @@ class _GGNNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, nodes, edges, *params):
         out, tape = ggnn_forward_raw(owner.constants, nodes, edges, params, owner._KIND,
-                                     owner._next_dropout_seed())
+                                     owner._next_dropout_seed(), want_backward=True,
+                                     guard=owner._x2_guard_state(nodes.device), no_x2=owner._x2_off())
         ctx.owner = owner
         ctx.tape = tape
         ctx.save_for_backward(out, *params)
@@ -271,7 +320,9 @@ class _GGNNDirect(torch.autograd.Function):
         params = owner._params()
         seed = owner._next_dropout_seed()
         cache = owner._pass0_cache(params, nodes) if anchor is None and seed is None else None
-        out, tape = ggnn_forward_raw(owner.constants, nodes, edges, params, owner._KIND, seed, None, cache)
+        out, tape = ggnn_forward_raw(owner.constants, nodes, edges, params, owner._KIND, seed, None, cache,
+                                     want_backward=anchor is not None, guard=owner._x2_guard_state(nodes.device),
+                                     no_x2=owner._x2_off())
         ctx.owner = owner
         ctx.tape = tape
         # the parameters are not saved tensors here: remember their versions so that an in-place
@@ -322,6 +373,55 @@ class _FusedMPNN(torch.nn.Module):
     #: change; after any OTHER write that bypasses the version counter (``p.data.copy_``) call
     #: ``reset_pass0_cache()``.
     cache_pass0 = True
+
+    #: True (default): the fp16x2 launches of this model run under the dynamic-range guard (``gi_graph.x2_guard``): every
+    #: forward counts, on the device, the activation rows and weight rows / columns that the per-TENSOR fp16x2 scale
+    #: would leave with fewer than ~14 significant bits (largest magnitude more than 2^24 below the tensor's).  The
+    #: first such row sets a host-visible flag; from the NEXT forward on the model runs those launches as bf16x3 splits
+    #: (fp32's exponent range, 9 % slower) until ``x2_guard_reset()``.  ``x2_guard_stats()`` reports the counters.
+    x2_guard = True
+
+    def _x2_guard_state(self, device):
+        if not self.x2_guard or device.type != "cuda":
+            return None
+        st = self.__dict__.get("_x2_guard")
+        if st is None:
+            st = self.__dict__["_x2_guard"] = {}
+        g = st.get(device)
+        if g is None:
+            host, dev = C.c_void_p(), C.c_void_p()
+            with torch.cuda.device(device):
+                _L.check(_L.load().gi_host_flag_create(C.byref(host), C.byref(dev)), "gi_host_flag_create")
+            g = st[device] = (torch.zeros(_L.X2_GUARD_WORDS, dtype=torch.int32, device=device), dev.value,
+                              C.cast(host, C.POINTER(C.c_int)))
+        return g
+
+    def _x2_off(self) -> bool:
+        """True once the guard has tripped on any device (no synchronisation: reads the mapped host flags)."""
+        if self.__dict__.get("_x2_forced_off"):
+            return True
+        for g in (self.__dict__.get("_x2_guard") or {}).values():
+            if g[2][0] != 0:
+                self.__dict__["_x2_forced_off"] = True
+                return True
+        return False
+
+    def x2_guard_stats(self) -> dict:
+        """Counters of the fp16x2 dynamic-range guard since the last reset (one read-back per device):
+        ``forward_rows`` / ``weight_lines`` trip the guard, ``dgrad_rows`` is informational, ``tripped`` = the
+        model now runs bf16x3 splits."""
+        tot = [0, 0, 0, 0]
+        for g in (self.__dict__.get("_x2_guard") or {}).values():
+            tot = [a + b for a, b in zip(tot, g[0].tolist())]
+        return {"forward_rows": tot[0], "weight_lines": tot[1], "dgrad_rows": tot[2], "tripped": self._x2_off()}
+
+    def x2_guard_reset(self) -> None:
+        """Clear the counters and the trip flag: fp16x2 again from the next forward on."""
+        for g in (self.__dict__.get("_x2_guard") or {}).values():
+            g[0].zero_()
+            torch.cuda.synchronize(g[0].device)             # (no launch may set the flag after it was cleared)
+            g[2][0] = 0
+        self.__dict__["_x2_forced_off"] = False
 
     def reset_pass0_cache(self) -> None:
         """Forget the cached pass-0 rows (next no-grad forward recomputes them)."""
@@ -430,7 +530,8 @@ class _FusedMPNN(torch.nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         skip = ("_param_cache", "_bucket", "_anchor", "_grad_bucket", "_grad_ready_hook",
-                "_early_exchange_pending", "_last_bounded_graph", "_p0_state", "_bounded_err")
+                "_early_exchange_pending", "_last_bounded_graph", "_p0_state", "_bounded_err", "_x2_guard",
+                "_x2_forced_off")
         import copy as _copy
         for k, v in self.__dict__.items():
             new.__dict__[k] = None if k in skip else _copy.deepcopy(v, memo)
@@ -449,6 +550,12 @@ class _FusedMPNN(torch.nn.Module):
             if torch.cuda.is_current_stream_capturing():         # the only forward that can be recorded (no read-back)
                 import graphinvent_amd as _pkg                 # (works in the top-level `gnn.mpnn` layout too)
                 _pkg.assert_graph_safe()
+                # persistent device state must exist BEFORE the capture: allocated inside it, its zero-fill would be
+                # recorded and every replay would clear what the previous ones accumulated (round-4 advisor finding)
+                if nodes.device not in (self.__dict__.get("_bounded_err") or {}) or \
+                        (self.cache_pass0 and (self.__dict__.get("_p0_state") or {}).get("buf") is None):
+                    raise RuntimeError("run one sync-free forward of this model outside the capture first: its sticky "
+                                       "error word and pass-0 row cache are allocated (and zero-filled) on first use")
             bounds = self.sync_free_bounds or _ops.default_bounds(nodes.shape[0], nodes.shape[1], edges.shape[3])
             out, tape = ggnn_forward_raw(self.constants, nodes, edges, params, self._KIND, None, bounds,
                                          self._pass0_cache(params, nodes), self._bounded_err_word(nodes.device))

@@ -31,8 +31,11 @@ GEMM_X2 = 1024        # with GEMM_BF3 and fp32 operands: two scaled fp16 planes 
 GEMM_BF3 = 128        # GI_GEMM_BF3: B is a gi_bf3_pack image; the launch runs as bf16x3 splits on the bf16 MFMA pipe
 KIND_GGNN, KIND_ATTGGNN = 0, 1
 BWD_ALL, BWD_READOUT, BWD_PASSES = 0, 1, 2
+BWD_PREPACKED, BWD_NO_X2 = 0x100, 0x200        # OR-ed into the phase (GI_BWD_PREPACKED, GI_BWD_NO_X2)
+RUN_PREPACK_BWD, RUN_NO_X2 = 1, 2              # gi_ggnn_forward_ex flags (GI_RUN_*)
+X2_GUARD_WORDS = 4                             # GI_X2_GUARD_WORDS
 COUNTS = 24          # GI_COUNTS
-ABI_VERSION = 14
+ABI_VERSION = 15
 #: bumped by code that rewrites model weights through raw pointers (optim.FusedAdam.step,
 #: dp.DataParallel.broadcast_parameters): invalidates gnn.mpnn's pass-0 row cache
 WEIGHTS_EPOCH = [0]     # GI_ABI_VERSION
@@ -58,7 +61,8 @@ class GemmParams(C.Structure):
                 ("c_split_stride", cll),
                 ("Bg", vp * GI_MAX_GROUPS), ("biasg", vp * GI_MAX_GROUPS),
                 ("Cg", vp * GI_MAX_GROUPS), ("gsplit", ci * GI_MAX_GROUPS),
-                ("m_dev", vp), ("k_dev", vp), ("a_amax", vp), ("b_amax", vp), ("c_amax", vp)]
+                ("m_dev", vp), ("k_dev", vp), ("a_amax", vp), ("b_amax", vp), ("c_amax", vp),
+                ("x2_guard", vp), ("x2_guard_host", vp)]
 
 
 CHAIN_MAXL, CHAIN_MAXW = 8, 256       # GI_CHAIN_MAXL, GI_CHAIN_MAXW
@@ -95,7 +99,8 @@ class Graph(C.Structure):
     _fields_ = [("S", ci), ("E", ci), ("U", ci), ("gfix", vp), ("u_src", vp), ("in_perm", vp),
                 ("mu_off", vp), ("mu_dst", vp), ("mu_slot", vp), ("out_perm", vp),
                 ("Ut", C.POINTER(ci)), ("D0", ci), ("ldc0", ci), ("d_src", vp), ("cmat", vp),
-                ("e2d", vp), ("cls_off", vp), ("cls_edges", vp), ("bounded", ci), ("p0_cache", vp)]
+                ("e2d", vp), ("cls_off", vp), ("cls_edges", vp), ("bounded", ci), ("p0_cache", vp),
+                ("x2_guard", vp), ("x2_guard_host", vp)]
 
 
 class GgnnDims(C.Structure):
@@ -130,6 +135,9 @@ SIGNATURES = {
     "gi_compact_class_csr": (ci, [vp, ci, ci, vp, vp, vp]),
     "gi_compact_bound": (ci, [vp, ci, ci, ci, ci, ci, vp, vp]),
     "gi_absmax": (ci, [vp, ci, vp]),
+    "gi_x2_weight_guard": (ci, [vp, ci, vp, vp, vp]),
+    "gi_host_flag_create": (ci, [C.POINTER(vp), C.POINTER(vp)]),
+    "gi_host_flag_destroy": (ci, [vp]),
     "gi_b3p_enable": (ci, [ci]),
     "gi_x2_enable": (ci, [ci]),
     "gi_b3v_enable": (ci, [ci]),
@@ -183,6 +191,7 @@ SIGNATURES = {
     "gi_ggnn_ws_query": (ci, [C.POINTER(GgnnDims), ci, ci, ci, ci, C.c_char_p, ci, ci,
                               C.POINTER(cll), C.POINTER(ci)]),
     "gi_ggnn_forward": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), C.POINTER(Graph), vp, vp, ci, vp]),
+    "gi_ggnn_forward_ex": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), C.POINTER(Graph), vp, vp, ci, vp, vp, ci]),
     "gi_ggnn_backward": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), C.POINTER(Graph), vp, vp, vp, ci,
                               vp, ci, C.POINTER(vp), vp, vp]),
     "gi_ggnn_backward_phase": (ci, [C.POINTER(GgnnDims), C.POINTER(vp), C.POINTER(Graph), vp, vp, vp,

@@ -400,7 +400,7 @@ def bf3_pack(W: torch.Tensor, transpose: bool = False, as_f32: bool = False) -> 
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, flags=0, bias=None, act=None, ldact=0,
          a_idx=None, b_idx=None, a_major=False, b_major=False, tm=1, tn=1, grp_off=None,
          ngroups=0, max_group_rows=0, Bg=(), biasg=(), Cg=(), nsplit=1, c_split_stride=0,
-         ones_col=-1, gsplit=(), a_amax=None, b_amax=None, c_amax=None):
+         ones_col=-1, gsplit=(), a_amax=None, b_amax=None, c_amax=None, x2_guard=None, x2_guard_host=0):
     lib = L.load()
     p = L.GemmParams()
     p.A, p.B, p.C = _ptr(A), _ptr(B), _ptr(C_out)
@@ -411,6 +411,7 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, *, flags=0, bias=None, act=None, l
     p.ngroups, p.nsplit, p.max_group_rows, p.ones_col = ngroups, nsplit, max_group_rows, ones_col
     p.c_split_stride = c_split_stride
     p.a_amax, p.b_amax, p.c_amax = _ptr(a_amax), _ptr(b_amax), _ptr(c_amax)
+    p.x2_guard, p.x2_guard_host = _ptr(x2_guard), (x2_guard_host or None)
     for i, t in enumerate(Bg):
         p.Bg[i] = _ptr(t)
     for i, t in enumerate(biasg):
@@ -450,6 +451,44 @@ def absmax(tensors, out: torch.Tensor) -> torch.Tensor:
     with torch.cuda.device(out.device):
         L.check(lib.gi_absmax(d, len(tensors), _stream(out)), "gi_absmax")
     return out
+
+
+class HostFlag:
+    """One int of pinned host memory that kernels can write (``gi_host_flag_create``): ``.dev`` is the pointer to hand
+    to kernels (``gi_graph.x2_guard_host``), ``.value`` reads / writes it from the host without a synchronisation."""
+
+    def __init__(self, device=None):
+        host, dev = C.c_void_p(), C.c_void_p()
+        with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+            L.check(L.load().gi_host_flag_create(C.byref(host), C.byref(dev)), "gi_host_flag_create")
+        self._host, self.dev = host, dev.value
+        self._view = C.cast(host, C.POINTER(C.c_int))
+
+    @property
+    def value(self) -> int:
+        return int(self._view[0])
+
+    @value.setter
+    def value(self, v: int) -> None:
+        self._view[0] = int(v)
+
+    def close(self) -> None:
+        if self._host is not None:
+            L.load().gi_host_flag_destroy(self._host)
+            self._host = None
+
+
+def x2_weight_guard(tensors, cells: torch.Tensor, counter: torch.Tensor, host_flag: int = 0) -> None:
+    """gi_x2_weight_guard: count in ``counter[0]`` the rows and columns of each matrix whose largest magnitude lies more
+    than 2^24 below the matrix's (``cells[i]`` = its amax cell, filled by ``absmax`` on this stream before)."""
+    tensors = list(tensors)
+    d = (L.AbsmaxDesc * len(tensors))()
+    for i, t in enumerate(tensors):
+        d[i].x, d[i].rows, d[i].cols, d[i].ld = t.data_ptr(), t.shape[0], t.shape[1], t.stride(0)
+        d[i].out = cells[i].data_ptr()
+    with torch.cuda.device(counter.device):
+        L.check(L.load().gi_x2_weight_guard(d, len(tensors), counter.data_ptr(), host_flag or None, _stream(counter)),
+                "gi_x2_weight_guard")
 
 
 def reduce_slabs(items):

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GI_ABI_VERSION 14
+#define GI_ABI_VERSION 15
 #define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
 #define GI_MAX_NODES 128      /* max max_n_nodes */
 #define GI_P0_MAX_CLASSES 256 /* max distinct node feature rows for the pass-0 shortcut */
@@ -153,7 +153,24 @@ typedef struct gi_graph {
                                  zero-filled = empty) that OUTLIVE the call: the pass-0 row cache of an
                                  inference loop, see gi_p0_cache_words.  Forward only (the hidden activations
                                  of the pass-0 stacks are not produced on a hit). */
+    int* x2_guard;            /* NULL, or GI_X2_GUARD_WORDS device ints that OUTLIVE the call: sticky counters of the
+                                 fp16x2 dynamic-range guard (see GI_GEMM_X2 / gi_gemm_params.x2_guard):
+                                 [0] rows of a FORWARD launch's activation operand whose largest magnitude lies more
+                                     than 2^24 below the tensor's (such a row keeps fewer than ~14 bits in fp16x2),
+                                 [1] rows / columns of a weight matrix of those layers in the same position,
+                                 [2] the same for the dZ operands of the dgrad launches (informational: everything the
+                                     backward outputs is a sum over rows, which an absolute error floor of 2^-38 of the
+                                     tensor's maximum does not move),
+                                 [3] reserved (stays 0). */
+    int* x2_guard_host;       /* NULL, or ONE int of host memory mapped into the device (gi_host_flag_create): set to 1
+                                 by the launch that increments counter [0] or [1], so that the host learns of a trip
+                                 without a read-back and can run the following calls with GI_RUN_NO_X2 */
 } gi_graph;
+#define GI_X2_GUARD_WORDS 4
+/* One int of pinned host memory that kernels can write (hipHostMalloc mapped): *host = the caller's view,
+ * *dev = the pointer to hand to kernels (gi_graph.x2_guard_host).  Zeroed on creation. */
+int gi_host_flag_create(int** host, int** dev);
+int gi_host_flag_destroy(int* host);
 
 /* ------------------------------------------------------------------------------------------
  * Dense GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32) with fused prologue/epilogue.  One kernel
@@ -210,6 +227,11 @@ typedef struct gi_gemm_params {
      * the caller zeroes the cell before the producer runs. */
     const float* a_amax; const float* b_amax;
     float* c_amax;
+    /* GI_GEMM_X2 launches with a row-major A (forward / dgrad layouts), optional: dynamic-range guard.  The launch counts
+     * in x2_guard[0] the rows of A whose largest magnitude is non-zero and more than 2^24 below max |A| (a row the
+     * per-TENSOR scale leaves with fewer than ~14 significant bits; an exactly-zero row is exact; every row is counted
+     * once per launch) and, when it counted a row and x2_guard_host != NULL, stores 1 there. */
+    int* x2_guard; int* x2_guard_host;
 } gi_gemm_params;
 
 int gi_gemm(const gi_gemm_params* p, void* stream);
@@ -221,6 +243,11 @@ int gi_gemm(const gi_gemm_params* p, void* stream);
 #define GI_ABSMAX_MAX 16
 typedef struct { const float* x; int rows, cols, ld; float* out; } gi_absmax_desc;
 int gi_absmax(const gi_absmax_desc* descs, int n, void* stream);
+/* fp16x2 dynamic-range guard of weight matrices (descs[i].out = the matrix's amax cell, already filled by gi_absmax on
+ * this stream): counts in *counter the ROWS and COLUMNS whose largest magnitude is non-zero and more than 2^24 below
+ * the matrix's — an output channel of the forward (row of W) or of the dgrad (column of W) launch that the per-tensor
+ * scale leaves with fewer than ~14 significant bits — and stores 1 to *host_flag (may be NULL) when it counted one. */
+int gi_x2_weight_guard(const gi_absmax_desc* descs, int n, int* counter, int* host_flag, void* stream);
 /* n (<= 8) independent problems of the same tile shape and operand layouts in ONE launch.
  * Every launch is a tile loop: launches with more output tiles than the device holds workgroups at once
  * run as a persistent grid (each workgroup walks tiles id, id + grid, ...; the next tile's first operand
@@ -282,8 +309,11 @@ typedef struct {
                                              the fp16x2 chain (csrc/gi_x2.h) — gi_mlp_chain_pack computes max |W| of
                                              every layer and group into them and writes the image as two scaled fp16
                                              planes; gi_mlp_chain then runs 64-row blocks on the f16 MFMA pipe (three
-                                             products per fp32 product, activations scaled per row and layer: a row's
-                                             result depends on nothing but the row).  Pack and launch must agree; a
+                                             products per fp32 product, activations scaled per 64-ROW BLOCK and layer by
+                                             a power of two from the block's largest magnitude: a row's last bits
+                                             depend on which rows share its block — NOT bitwise row-independent like
+                                             the fp32 chain, which is why gi_ggnn_forward keeps that one and only the
+                                             backward's dZ chains run this way).  Pack and launch must agree; a
                                              bounded launch walks 64-row blocks (the value behind tile_rows_dev is unused) */
 } gi_chain_params;
 
@@ -614,6 +644,20 @@ int gi_ggnn_ws_query(const gi_ggnn_dims* d, int S, int E, int U, int D0, const c
                      int j, long long* off, int* ld);
 int gi_ggnn_forward(const gi_ggnn_dims* d, const float* const* params, const gi_graph* g,
                     float* ws, float* out, int ldout, void* stream);
+/* The same with a second stream and run flags.  side_stream (may be NULL; gi_side_stream_create): everything that
+ * depends on the WEIGHTS only is enqueued there instead of in front of the kernels that wait for it — the amax cells
+ * of the fp16x2 layers' weights and their dynamic-range check (needed by the readout, ~0.4 ms into the forward), and,
+ * with GI_RUN_PREPACK_BWD, what gi_ggnn_backward would otherwise pack at its start: the W^T images of the 16-bit-pipe
+ * layers and the dZ chains' weight image (then call the backward with GI_BWD_PREPACKED: it waits for that work
+ * instead of redoing it).  `stream` waits for the side stream where it needs the results; the caller keeps `ws`
+ * alive until the side stream's work is done (it is ordered before the backward; without a backward: until the side
+ * stream drains).
+ * GI_RUN_NO_X2: this call's 16-bit-pipe launches as bf16x3 instead of fp16x2 (what GI_X2=0 does process-wide) — what a
+ * caller switches to after gi_graph.x2_guard_host tripped.  Forward and backward of one tape must agree. */
+#define GI_RUN_PREPACK_BWD 1
+#define GI_RUN_NO_X2 2
+int gi_ggnn_forward_ex(const gi_ggnn_dims* d, const float* const* params, const gi_graph* g,
+                       float* ws, float* out, int ldout, void* stream, void* side_stream, int flags);
 /* Pass-0 row cache for inference loops (generation: GraphGenerator.py:118-157 calls the model thousands of
  * times with the same weights).  In the first message pass h = [x | 0], so a message row (and AttentionGGNN's
  * energy row) depends only on (bond type, 0/1 feature pattern of the source node) and the weights: a few dozen
@@ -643,6 +687,11 @@ int gi_ggnn_backward(const gi_ggnn_dims* d, const float* const* params, const gi
 #define GI_BWD_ALL 0
 #define GI_BWD_READOUT 1
 #define GI_BWD_PASSES 2
+/* OR-ed into `phase`: GI_BWD_PREPACKED — the forward ran as gi_ggnn_forward_ex(.., GI_RUN_PREPACK_BWD) with the same
+ * side stream: the weight images of this backward are (being) written there, the call waits for them instead of packing;
+ * GI_BWD_NO_X2 — bf16x3 instead of fp16x2, like GI_RUN_NO_X2 (the forward of the same tape must have run that way). */
+#define GI_BWD_PREPACKED 0x100
+#define GI_BWD_NO_X2 0x200
 int gi_ggnn_backward_phase(const gi_ggnn_dims* d, const float* const* params, const gi_graph* g,
                            float* ws, float* slabs, const float* y_out, int ldout,
                            const float* d_out, int lddout, float* const* grads, void* stream,

@@ -103,6 +103,37 @@ def load(which: str, constants):
     return Workflow, GraphGenerator
 
 
+_TOUCHED = ("Workflow", "GraphGenerator", "BlockDatasetLoader", "gnn", "rdkit", "h5py", "Analyzer", "DataProcesser",
+            "GraphGeneratorRL", "ScoringFunction", "MolecularGraph", "util", "parameters", "parameters.constants",
+            "torch.utils.tensorboard")
+
+
+class isolated:
+    """Context manager / pytest-fixture body: whatever ``load`` and ``pin_multinomial`` change process-wide — the stub
+    and caller modules in ``sys.modules`` (``gnn.*`` included), ``sys.path``, ``torch.distributions.Multinomial`` — is put
+    back on exit, so that tests run in any order (a later ``import gnn.mpnn`` must not find the drop-in registered
+    under the reference's name; round-4 advisor finding)."""
+
+    def __enter__(self):
+        import torch
+        self._mods = {k: v for k, v in sys.modules.items() if k in _TOUCHED or k.startswith("gnn.")}
+        self._path = list(sys.path)
+        self._multinomial = torch.distributions.Multinomial
+        self._tb = getattr(torch.utils, "tensorboard", None)
+        return self
+
+    def __exit__(self, *exc):
+        import torch
+        for k in [k for k in sys.modules if k in _TOUCHED or k.startswith("gnn.")]:
+            del sys.modules[k]
+        sys.modules.update(self._mods)
+        sys.path[:] = self._path
+        torch.distributions.Multinomial = self._multinomial
+        if self._tb is None and hasattr(torch.utils, "tensorboard") and "torch.utils.tensorboard" not in sys.modules:
+            del torch.utils.tensorboard
+        return False
+
+
 def pin_multinomial(draw):
     """Replace ``torch.distributions.Multinomial`` (GraphGenerator.py:533-537) by the seeded inverse-CDF draw."""
     import torch

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.gi_abi_version() == L.ABI_VERSION == 14
+    assert lib.gi_abi_version() == L.ABI_VERSION == 15
 
 
 def test_host_side_planning_functions():
@@ -78,6 +78,8 @@ def test_state_dict_is_the_reference_wire_format():
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present on this box")
 def test_constructor_is_seed_for_seed_identical_to_the_reference():
+    for m in [k for k in sys.modules if k == "gnn" or k.startswith("gnn.")]:
+        del sys.modules[m]                      # (whatever an earlier test registered under the reference's name)
     sys.path.insert(0, REF)
     try:
         import gnn.mpnn as ref_mpnn
@@ -174,6 +176,8 @@ def test_ctypes_structs_have_the_sizes_and_offsets_of_the_header(tmp_path):
              ("gi_bf3_pack_desc", L.Bf3PackDesc), ("gi_graph", L.Graph), ("gi_ggnn_dims", L.GgnnDims),
              ("gi_dropout_params", L.DropoutParams)]
     offs = [("gi_gemm_params", "c_amax", L.GemmParams.c_amax.offset),
+            ("gi_gemm_params", "x2_guard_host", L.GemmParams.x2_guard_host.offset),
+            ("gi_graph", "x2_guard_host", L.Graph.x2_guard_host.offset),
             ("gi_gemm_params", "m_dev", L.GemmParams.m_dev.offset),
             ("gi_chain_params", "x2_wamax", L.ChainParams.x2_wamax.offset),
             ("gi_chain_params", "image_stride", L.ChainParams.image_stride.offset),

@@ -17,6 +17,14 @@ from oracle import callers_oracle as CO
 from oracle import ggnn_oracle as O
 from tests.golden import ref_callers as RC
 
+
+@pytest.fixture(autouse=True)
+def _restore_process_state():
+    """ref_callers.load / pin_multinomial replace modules and torch.distributions.Multinomial process-wide."""
+    with RC.isolated():
+        yield
+
+
 FIXTURE = "/root/reference/data/pre-training/gdb13_1K-debug/valid.h5"
 needs_ref = pytest.mark.skipif(not (RC.have_reference() and os.path.exists(FIXTURE)
                                     and os.path.exists("/opt/conda/lib/libhdf5.so")),

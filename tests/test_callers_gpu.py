@@ -26,6 +26,14 @@ import torch
 from oracle import callers_oracle as CO
 from oracle import ggnn_oracle as O
 from tests.golden import ref_callers as RC
+
+
+@pytest.fixture(autouse=True)
+def _restore_process_state():
+    """ref_callers.load / pin_multinomial replace modules and torch.distributions.Multinomial process-wide."""
+    with RC.isolated():
+        yield
+
 from tests.h5util import have_libhdf5, write_h5
 
 pytestmark = pytest.mark.gpu
