@@ -59,7 +59,19 @@ struct ChainArgs {
     // is computed here from grp_off, and the row-block height comes from the device (gfix dims[1], 0: tile_rows)
     int dev_tiles;
     const int* tile_rows_dev;
+    // XCD-aware row-block order (ordinary launches): the dispatcher deals consecutive workgroup ids round-robin to the 8
+    // XCDs (private 4 MB L2 each).  Row blocks are sorted by bond type, and a block streams its TYPE's whole ~1 MB
+    // weight image: in dispatch order every XCD's L2 sees all three images (3.5 MB + the activations: 17 % / 32 % of
+    // the L2 requests of the fp32 / fp16x2 chain missed, profiles/r04/pmc_chain_kernels.txt); with the bijective remap
+    // of gi_gemm.hip one XCD walks CONSECUTIVE blocks, i.e. one or two types.  GI_CHAIN_XCD=0: dispatch order.
+    int remap;
 };
+__device__ __forceinline__ int chain_block_id(const ChainArgs& a, int bid) {
+    const int total = a.chain_off[a.nchains];
+    if (!a.remap || (int)gridDim.x != total) return bid;
+    const int q = total >> 3, r = total & 7, xcd = bid & 7, j = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
 
 __host__ __device__ inline int chain_tiles(const gi_chain_params& p) {
     int t = 0;
@@ -147,7 +159,8 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
     // surplus blocks cost an iteration of a few scalar loads instead of a 114 KB-LDS workgroup launch each
     // (measured: 1 364 surplus workgroups per chain launch made the bounded forward 0.3 ms slower).
     if (args.c[0].skip_flag && *args.c[0].skip_flag != 0) return;   // rows served from gi_graph.p0_cache
-    for (int id = blockIdx.x; id < args.chain_off[args.nchains]; id += gridDim.x) {
+    for (int bid = blockIdx.x; bid < args.chain_off[args.nchains]; bid += gridDim.x) {
+    const int id = chain_block_id(args, bid);
     // ---- which (chain, group, row block) -------------------------------------------------------
     const int ci = (args.nchains > 1 && id >= args.chain_off[1]) ? 1 : 0;
     const gi_chain_params& P = args.c[ci];
@@ -471,8 +484,10 @@ __host__ __device__ inline int cx_tiles(const gi_chain_params& p) {
     for (int l = 0; l < p.nlayers; ++l) t += (p.layer[l].K + CX_KT - 1) / CX_KT;
     return t;
 }
+// rows rotate by two (32 B = 8 banks) per k chunk: the epilogue's lanes write four adjacent chunks (1 KB apart: the same
+// banks without the rotation) at once; the fragment reads stay 32 consecutive rows (mod 64) of one chunk
 __device__ __forceinline__ unsigned cx_a_off(int plane, int chunk, int row) {
-    return (unsigned)(plane * CX_PLANE + (chunk * CX_ROWS + row) * 16);
+    return (unsigned)(plane * CX_PLANE + (chunk * CX_ROWS + ((row + 2 * chunk) & (CX_ROWS - 1))) * 16);
 }
 __device__ __forceinline__ unsigned cx_b_off(int plane, int chunk, int col) {
     return (unsigned)(((plane * 2 + chunk) * CH_W + col) * 16);
@@ -528,7 +543,8 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
     __shared__ float red[8];                                // per wave: max |new activation|
     typedef unsigned cx_u32x2 __attribute__((ext_vector_type(2)));
     if (args.c[0].skip_flag && *args.c[0].skip_flag != 0) return;
-    for (int id = blockIdx.x; id < args.chain_off[args.nchains]; id += gridDim.x) {
+    for (int bid = blockIdx.x; bid < args.chain_off[args.nchains]; bid += gridDim.x) {
+    const int id = chain_block_id(args, bid);
     const int ci = (args.nchains > 1 && id >= args.chain_off[1]) ? 1 : 0;
     const gi_chain_params& P = args.c[ci];
     const int local = id - args.chain_off[ci];
@@ -650,16 +666,26 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
         __syncthreads();
         if (l + 1 < L) {                                     // next layer's A operand: split, in place
             gx_scale(wg_max_from_lds(), sa, ia);
+            // A lane holds ONE column of 16 rows per row block: written one by one that is 64 two-byte stores per
+            // thread into 8 of the 32 banks (round 4: 45 % of the kernel's LDS cycles were bank conflicts).  Neighbouring
+            // lanes (columns c, c + 1) exchange one value per ROW PAIR instead — the even lane takes both columns of the
+            // pair's first row, the odd lane both of its second — and store packed dwords: half the stores, and with the
+            // per-chunk row rotation of cx_a_off the 64 lanes of a wave cover all 32 banks twice (the minimum for 256 B).
+            const int odd = lane & 1;
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int t = 0; t < 8; ++t) {
+                    const float mine0 = v[rb][2 * t], mine1 = v[rb][2 * t + 1];
+                    const float got = __shfl_xor(odd ? mine0 : mine1, 1);        // the neighbour's value of MY row
+                    const float lo = odd ? got : mine0, hi = odd ? mine1 : got;   // columns c & ~1, c | 1 of that row
+                    const int r = 2 * t + odd;
                     const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    const float y = v[rb][r] * sa;
-                    const _Float16 h1 = (_Float16)y;
-                    const _Float16 h2 = (_Float16)(y - (float)h1);
-                    *reinterpret_cast<_Float16*>(Ah + cx_a_off(0, col >> 3, row) + (col & 7) * 2) = h1;
-                    *reinterpret_cast<_Float16*>(Ah + cx_a_off(1, col >> 3, row) + (col & 7) * 2) = h2;
+                    unsigned p0, p1;
+                    gx_split2(lo, hi, sa, p0, p1);
+                    const unsigned at = cx_a_off(0, col >> 3, row) + ((col & 7) >> 1) * 4;
+                    *reinterpret_cast<unsigned*>(Ah + at) = p0;
+                    *reinterpret_cast<unsigned*>(Ah + CX_PLANE + at) = p1;
                 }
         }
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
@@ -940,6 +966,10 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
     a.nchains = nchains;
     if (total == 0) return 0;
     a.trace = g_chain_cfg.trace;                            // per-workgroup timestamps (tools/trace_chain.py)
+    {
+        static const bool xcd = !(getenv("GI_CHAIN_XCD") && atoi(getenv("GI_CHAIN_XCD")) == 0);
+        a.remap = (xcd && !bounded && total >= 16) ? 1 : 0;
+    }
     hipStream_t st = (hipStream_t)stream;
     GiProfScope prof(st, GI_PROF_GEMM | (x2 ? GI_PROF_PIPE_X2 : 0), flops);
     const dim3 grid(bounded ? std::min(total, ncu) : total), block(512);

@@ -61,6 +61,21 @@ extern "C" int gi_b3p_enable(int on);
 // "b0" / "b1" the bf16x3 launches of the forward / dgrad
 void gi_gemm_log_launch(const char* cls, const gi_gemm_params* probs, int n, int blocks, double flops);
 
+// ---- bias-gradient column of weight-gradient slabs, computed on its own (gi_ops.hip) ---------------------------------
+// A weight-gradient GEMM [dW | db] = dZ^T [X | 1] carries the bias gradient as an extra "ones" column: n_in + 1 output
+// columns.  When n_in is a multiple of the 64-wide tile that one column costs a whole extra column of tiles (129 -> 3
+// tiles instead of 2: the GRU projections, every stack's first layer at H = 128).  Such problems run as plain
+// n_out x n_in GEMMs and this launch writes column `col` of their slabs: slab s of a problem gets the column sums of dZ
+// over the s-th of `nsplit` equal row chunks (fixed order: deterministic), so the slab reduction finds db as before.
+struct GiBiasSlab {
+    const float* dZ; int lddz;           // [rows, n_out] row-major
+    const int* grp_off; int g;           // rows [grp_off[g], grp_off[g + 1]) on the device, or NULL: rows [0, rows)
+    int rows, n_out;
+    float* slab; long long stride;       // slab s at slab + s * stride, [n_out, ld]
+    int ld, col, nsplit;
+};
+int gi_bias_slabs(const GiBiasSlab* descs, int n, hipStream_t st);
+
 // ---- pass-0 row cache (gi_graph.p0_cache, gi_compact.hip): lookup before the pass-0 stack launch (words[0] =
 // hit flag, rows copied into m0 / e0 on a hit), insert after it (no-op on a hit).  nfam = 1 (message rows) or
 // 2 (message + energy rows); rows are ldm floats per family.

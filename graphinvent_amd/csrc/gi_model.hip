@@ -308,11 +308,20 @@ int bf3_wgrad_nsplit(int red_rows, int decide_rows) {
     return std::max(1, (red_rows + L / 2) / L);
 }
 
+// The bias gradient as its own launch (GiBiasSlab, gi_common.h) when the "ones" column would start a new column of
+// 64-wide tiles: n_in % 64 == 0 (GRU projections and first layers at H = 128: 129 columns = 3 tiles for 2 tiles' worth
+// of work).  fp32-MFMA weight gradients only (the 16-bit-pipe kernel's 256-wide tiles hold 501 columns either way).
+// GI_WGRAD_BIAS=0: the ones column everywhere (round-4 schedule).
+bool wgrad_sep_bias(int n_in) {
+    static const bool on = getenv("GI_WGRAD_BIAS") && atoi(getenv("GI_WGRAD_BIAS")) != 0;    // default OFF: measured a loss, see below
+    return on && n_in >= 64 && (n_in & 63) == 0;
+}
+
 void wgrad_shape(int n_out, int n_in, int red_rows, double share, int& tn, int& nsplit) {
     // 64x64 output tiles; 128x128 tiles for the big square weight gradients (a quarter of the slabs)
     // measured slower: 2.73 against 2.64 ms per step (tools/experiments/README.md)
     tn = 1;
-    const int tiles = gi_cdiv(n_out, 64) * gi_cdiv(n_in + 1, 64);
+    const int tiles = gi_cdiv(n_out, 64) * gi_cdiv(wgrad_sep_bias(n_in) ? n_in : n_in + 1, 64);
     const int kt = gi_cdiv(std::max(red_rows, 1), 32);
     // workgroups per problem, measured in round 2: 96 -> 2.44-2.51 ms per step, 128 -> 2.39-2.40,
     // 192 -> 2.34-2.35, 256 -> 2.37, 384 -> 2.40-2.41
@@ -588,8 +597,9 @@ struct Deferred {
     gi_gemm_params p[96];
     int widx[96][GI_MAX_GROUPS];     // weight indices each problem's slabs belong to
     int nw[96];
+    unsigned char sep_bias[96];      // the problem's bias-gradient column is written by gi_bias_slabs, not by a ones column
     int n = 0;
-    gi_gemm_params& next() { gemm_defaults(p[n]); nw[n] = 0; return p[n++]; }
+    gi_gemm_params& next() { gemm_defaults(p[n]); nw[n] = 0; sep_bias[n] = 0; return p[n++]; }
 };
 
 void flush_batch(Run& r, Batch& b, bool wgrad) {
@@ -705,6 +715,10 @@ void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* wid
                 if (e->amax && e->in_ok && e->dz_ok) { p.flags |= GI_GEMM_X2; p.a_amax = e->amax + 2 * GI_AMAX_WORDS; p.b_amax = e->amax + GI_AMAX_WORDS; }
     }
     const int slot = q.n - 1;
+    if (!(p.flags & GI_GEMM_BF3) && wgrad_sep_bias(e0.n_in)) {          // plain n_out x n_in problem; db by gi_bias_slabs
+        p.N = e0.n_in; p.ones_col = -1;
+        q.sep_bias[slot] = 1;
+    }
     if (g.n) {
         p.ngroups = g.n; p.grp_off = g.off;
         for (int t = 0; t < g.n; ++t) {
@@ -739,12 +753,25 @@ void launch_wgrad_batch(Run& r, const gi_gemm_params* p, int n, hipStream_t st) 
 
 // consecutive queued problems, up to 8 per launch; the bf16x3 ones (one workgroup per CU, equal tiles) are packed
 // separately, biggest first, into launches of about one round of the device
-void launch_wgrad_batches(Run& r, const gi_gemm_params* p, int n, hipStream_t st) {
+void launch_wgrad_batches(Run& r, const gi_gemm_params* p, const unsigned char* sep, int n, hipStream_t st) {
     gi_gemm_params rest[96], b3[2][96];                           // b3[0]: bf16x3, b3[1]: fp16x2 (a launch is one or the other)
     int nr = 0, n3[2] = {0, 0};
+    GiBiasSlab bias[96 * GI_MAX_GROUPS > 256 ? 256 : 96 * GI_MAX_GROUPS];
+    int nbias = 0;
     for (int i = 0; i < n; ++i) {
         if (p[i].flags & GI_GEMM_BF3) { const int x = (p[i].flags & GI_GEMM_X2) ? 1 : 0; b3[x][n3[x]++] = p[i]; }
         else rest[nr++] = p[i];
+        if (sep && sep[i]) {                                      // bias-gradient column of this problem's slabs
+            const gi_gemm_params& q = p[i];
+            const int ng = q.ngroups ? q.ngroups : 1;
+            for (int g = 0; g < ng && nbias < 256; ++g) {
+                GiBiasSlab& b = bias[nbias++];
+                b.dZ = q.A; b.lddz = q.lda; b.grp_off = q.ngroups ? q.grp_off : nullptr; b.g = g;
+                b.rows = q.K; b.n_out = q.M;
+                b.slab = q.ngroups ? q.Cg[g] : q.C; b.stride = q.c_split_stride;
+                b.ld = q.ldc; b.col = q.N; b.nsplit = q.ngroups ? q.gsplit[g] : q.nsplit;
+            }
+        }
     }
     auto tiles = [](const gi_gemm_params& q) {
         int zs = q.nsplit;
@@ -769,10 +796,11 @@ void launch_wgrad_batches(Run& r, const gi_gemm_params* p, int n, hipStream_t st
         }
     }
     for (int base = 0; base < nr && r.ok(); base += 8) launch_wgrad_batch(r, rest + base, std::min(8, nr - base), st);
+    if (nbias && r.ok()) r.chk(gi_bias_slabs(bias, nbias, st));
 }
 
 void flush_deferred(Run& r, Deferred& q) {
-    launch_wgrad_batches(r, q.p, q.n, r.st);
+    launch_wgrad_batches(r, q.p, q.sep_bias, q.n, r.st);
     q.n = 0;
 }
 
@@ -813,7 +841,7 @@ void kick_deferred(Run& r, Deferred& q, SideStream* side, bool all) {
     hipEvent_t ready = side->next();
     r.chk((int)hipEventRecord(ready, r.st));
     r.chk((int)hipStreamWaitEvent(side->st, ready, 0));
-    launch_wgrad_batches(r, q.p, n, side->st);
+    launch_wgrad_batches(r, q.p, q.sep_bias, n, side->st);
     // parameters whose last slab has just been queued: reduce them right behind, on the side stream
     // too, so that only the final pass's gradients are left for the end of the backward
     gi_reduce_desc descs[96 * GI_MAX_GROUPS > 160 ? 160 : 96 * GI_MAX_GROUPS];
@@ -830,6 +858,7 @@ void kick_deferred(Run& r, Deferred& q, SideStream* side, bool all) {
     for (int i = n; i < q.n; ++i) {
         q.p[i - n] = q.p[i];
         q.nw[i - n] = q.nw[i];
+        q.sep_bias[i - n] = q.sep_bias[i];
         for (int k = 0; k < q.nw[i]; ++k) q.widx[i - n][k] = q.widx[i][k];
     }
     q.n -= n;

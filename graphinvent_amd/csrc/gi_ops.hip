@@ -1410,6 +1410,57 @@ __global__ __launch_bounds__(256) void absmax_rows_kernel(const gi_absmax_desc d
         for (int c = threadIdx.x; c < d.cols; c += 256) m = fmaxf(m, fabsf(d.x[(long long)r * d.ld + c]));
     gx_amax_publish(m, d.out);
 }
+// ---- bias-gradient column of weight-gradient slabs (GiBiasSlab, gi_common.h) ----------------------------------------
+// One workgroup per (problem, 16 output channels, slab): 4 column threads (one float4 each) x 64 row lanes, four rows in
+// flight per lane — a column sum is a pure latency problem (11 MB per GRU problem, no reuse), so what counts is bytes in
+// flight: ~270 workgroups x 16 KB.  The first version (64 columns x 4 row lanes, two scalar loads in flight: 66
+// workgroups x 2 KB) cost the weight-gradient queue MORE than the column of tiles it removed.  Partial sums are
+// combined in a fixed order (xor shuffles over the row lanes of a wave, then the four waves through LDS): deterministic.
+typedef v4f v4f_unaligned __attribute__((aligned(4)));
+constexpr int GI_BIAS_SLAB_MAX = 40;
+struct BiasSlabArgs { GiBiasSlab d[GI_BIAS_SLAB_MAX]; int start[GI_BIAS_SLAB_MAX + 1]; int n; };
+__global__ __launch_bounds__(256) void bias_slabs_kernel(const BiasSlabArgs a) {
+    __shared__ v4f part[4][4];
+    int i = 0;
+    while (i < a.n - 1 && (int)blockIdx.x >= a.start[i + 1]) ++i;
+    const GiBiasSlab& d = a.d[i];
+    const int local = blockIdx.x - a.start[i];
+    const int s = local % d.nsplit, cb = local / d.nsplit;
+    const int lo = d.grp_off ? d.grp_off[d.g] : 0, hi = d.grp_off ? d.grp_off[d.g + 1] : d.rows;
+    const int chunk = (hi - lo + d.nsplit - 1) / d.nsplit;
+    const int r0 = lo + s * chunk, r1 = min(r0 + chunk, hi);
+    const int ct = threadIdx.x & 3, rl = threadIdx.x >> 2;
+    const int c = cb * 16 + 4 * ct;
+    const int cc = min(c, ((d.n_out + 3) & ~3) - 4);             // (a readable float4 of the row: lddz >= r4(n_out))
+    const float* src = d.dZ + cc;
+    v4f acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    int r = r0 + rl;
+    for (; r + 192 < r1; r += 256) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] += *reinterpret_cast<const v4f_unaligned*>(src + (long long)(r + 64 * u) * d.lddz);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (r + 64 * u < r1) acc[u] += *reinterpret_cast<const v4f_unaligned*>(src + (long long)(r + 64 * u) * d.lddz);
+    v4f sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) {
+        sum.x += __shfl_xor(sum.x, o); sum.y += __shfl_xor(sum.y, o);
+        sum.z += __shfl_xor(sum.z, o); sum.w += __shfl_xor(sum.w, o);
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane < 4) part[wid][lane] = sum;
+    __syncthreads();
+    if (threadIdx.x < 4 && c == cc) {
+        const v4f t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        float* dst = d.slab + (long long)s * d.stride + d.col;
+        const float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c + j < d.n_out) dst[(long long)(c + j) * d.ld] = v[j];
+    }
+}
+
 // fp16x2 dynamic-range guard of the WEIGHTS (gi_x2_weight_guard): rows and columns of a matrix whose largest scaled
 // magnitude is below 2^-11 (see gi_gemm_bf3.hip) — an output channel of the forward launch (row of W) or of the dgrad
 // launch (column of W) that the per-tensor scale leaves with fewer than ~14 significant bits.  One workgroup per
@@ -1455,6 +1506,29 @@ __global__ __launch_bounds__(256) void x2_weight_guard_kernel(const WGuardArgs a
     }
 }
 }  // namespace
+
+int gi_bias_slabs(const GiBiasSlab* descs, int n, hipStream_t st) {
+    for (int base = 0; base < n; base += GI_BIAS_SLAB_MAX) {
+        BiasSlabArgs a;
+        memset(&a, 0, sizeof(a));
+        int total = 0, k = 0;
+        for (int i = base; i < n && i < base + GI_BIAS_SLAB_MAX; ++i) {
+            const GiBiasSlab& d = descs[i];
+            if (!d.dZ || !d.slab || d.n_out < 4 || d.nsplit < 1 || d.rows < 0 || d.lddz < ((d.n_out + 3) & ~3) ||
+                d.col < 0 || d.col >= d.ld)
+                return GI_EINVAL;
+            a.d[k] = d;
+            a.start[k] = total;
+            total += ((d.n_out + 15) / 16) * d.nsplit;
+            ++k;
+        }
+        a.start[k] = total; a.n = k;
+        if (total > 0) hipLaunchKernelGGL(bias_slabs_kernel, dim3(total), dim3(256), 0, st, a);
+        const int e = gi_launch_status();
+        if (e) return e;
+    }
+    return 0;
+}
 
 // rows / columns of up to GI_ABSMAX_MAX weight matrices outside fp16x2's per-tensor range (the cells d.out must hold
 // the matrices' amax already: gi_absmax on the same stream first)

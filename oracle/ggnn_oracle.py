@@ -201,7 +201,9 @@ def _selu(x: torch.Tensor, prefix: str, layer: int) -> torch.Tensor:
     mask = SELU_BRANCH_HOOK(prefix, layer, x) if SELU_BRANCH_HOOK is not None else None
     if mask is None:
         return torch.selu(x)
-    return SELU_SCALE * torch.where(mask, x, SELU_ALPHA * (torch.exp(x) - 1.0))
+    # (the exponential of the branch NOT taken must stay finite: exp(x) = inf for x > 88.7 — activations a trained model
+    # does reach — turns autograd's 0 * inf into NaN; a pin only ever moves ties |x| < 1e-5 onto this branch)
+    return SELU_SCALE * torch.where(mask, x, SELU_ALPHA * (torch.exp(torch.clamp(x, max=1.0)) - 1.0))
 
 
 #: Test-only: ``torch.nn.AlphaDropout(dropout_p)`` in TRAINING mode (gnn/modules.py:142; identity in

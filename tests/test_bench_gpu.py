@@ -78,6 +78,28 @@ def test_bench_eight_ranks_gloo_sharing_the_gpu():
     assert sorted(d["allreduce"]["ranks"]) == sorted(set(d["allreduce"]["ranks"])) or len(d["allreduce"]["ranks"]) == 8
 
 
+def test_scale_script_dry_run_over_gloo(tmp_path):
+    """tools/scale.sh — what produces the N = 1, 2, 4, 8 lines on the first multi-GPU box — run end to end on ONE device
+    with the ranks sharing it over gloo (SCALE_BACKEND=gloo, small batch, 3 steps): four JSON lines that parse, the
+    rank counts right, `allreduce.exposed_ms_*` present for N > 1, and the summary lines the script prints.  A dry run
+    of the script's control flow, not a measurement: scaling on RCCL / xGMI is UNMEASURED (README)."""
+    out = tmp_path / "scale"
+    env = dict(os.environ, SCALE_BACKEND="gloo", SCALE_PORT=str(_free_port() - 8), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale.sh"), str(out), "--batch", "96", "--steps", "3",
+                        "--warmup", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    summary = [ln for ln in r.stdout.splitlines() if ln.startswith("N=")]
+    assert len(summary) == 4 and all("graphs/s" in ln for ln in summary), r.stdout[-2000:]
+    for n in (1, 2, 4, 8):
+        d = json.loads(open(out / f"scale_{n}.json").read())
+        assert d["n_gpus"] == n and d["config"]["global_batch"] == 96 * n and d["value"] > 0
+        if n > 1:
+            ar = d["allreduce"]
+            assert ar["ranks_seen"] == n and ar["backend"] == "gloo"
+            assert all(isinstance(ar[k], float) for k in ("exposed_ms_overlapped", "exposed_ms_after_backward"))
+            assert "exchange exposed" in summary[(1, 2, 4, 8).index(n)]
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL, one rank per device)")
 def test_bench_two_ranks_rccl():
     _check(_run_bench(2, "nccl"), 2, "nccl")

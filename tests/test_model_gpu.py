@@ -679,6 +679,82 @@ def test_direct_gradient_writeback_has_autograd_accumulate_semantics():
     assert all(torch.equal(a, b) for a, b in zip(gs, g1))
 
 
+def test_reinforcement_learning_call_pattern_several_forwards_one_backward():
+    """How GraphGeneratorRL drives the model (GraphGeneratorRL.py:131-132, Workflow.py:569-598): in every generation
+    round the AGENT runs forward WITH grad and the PRIOR (a deepcopy, Workflow.py:187-188) under no_grad on the same
+    graphs; the per-round likelihood terms are combined into one loss and ONE backward runs through all the agent's
+    forwards, then the optimizer steps.  Here: three rounds at the default dimensions on batches big enough for the
+    16-bit-pipe layers (>= 2 560 node rows), so that three tapes are alive at once — each with its own workspace,
+    weight images prepacked on the side stream (GI_RUN_PREPACK_BWD) and amax cells — and are consumed in reverse
+    order.  The accumulated gradient must be (a) the sum of the three rounds differentiated one at a time by the same
+    kernels, to summation-order noise, (b) the oracle's gradient of the same loss within the unpinned bounds of this
+    file; the prior gets no gradient and its forward equals the agent's bit for bit."""
+    sh = synthetic.SHAPES["gdb13"]
+    cfg = O.shaped_config(sh["n_atom_types"], sh["n_formal_charge"], sh["max_n_nodes"])
+    P = O.init_params(cfg, seed=21)
+    agent = make_model(cfg, P).train()
+    prior = copy.deepcopy(agent).eval()
+    rounds = [_live_only(*synthetic.make_batch(420, **sh, seed=70 + k)) for k in range(3)]
+    coef = (1.0, 0.5, 2.0)
+
+    def round_term(model, k, with_prior):
+        n8, e8, a8 = rounds[k]
+        nodes, edges, tgt = to_dev(n8, e8, a8)
+        logp = torch.log_softmax(model(nodes, edges), dim=1)
+        w = tgt / tgt.sum(1, keepdim=True)
+        term = -(w * logp).sum(1)                                   # a likelihood-style per-graph quantity
+        if with_prior:
+            with torch.no_grad():
+                lp_prior = torch.log_softmax(prior(nodes, edges), dim=1)
+            term = term + 0.1 * (w * (logp - lp_prior)).sum(1) ** 2
+        return coef[k] * term.mean()
+
+    with torch.no_grad():                                           # the copy computes what the original does
+        nd, ed = to_dev(rounds[0][0], rounds[0][1])
+        assert torch.equal(prior(nd, ed), agent(nd, ed))
+    # (a) one backward through three live tapes (a fourth forward's tape is dropped without a backward)
+    agent.zero_grad(set_to_none=True)
+    loss = sum(round_term(agent, k, True) for k in range(3))
+    assert agent(*to_dev(rounds[0][0], rounds[0][1])).requires_grad
+    loss.backward()
+    torch.cuda.synchronize()
+    joint = {k: p.grad.detach().double().cpu() for k, p in agent.named_parameters()}
+    assert all(p.grad is None for p in prior.parameters())
+    # ... against the rounds differentiated one at a time
+    single = {k: torch.zeros_like(v) for k, v in joint.items()}
+    for k in range(3):
+        agent.zero_grad(set_to_none=True)
+        round_term(agent, k, True).backward()
+        for name, p in agent.named_parameters():
+            single[name] += p.grad.detach().double().cpu()
+    for name in joint:
+        assert rel(joint[name], single[name]) < 2e-6, name
+    # (b) the oracle on the same loss (plain torch autograd on CPU)
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    total = 0.0
+    for k in range(3):
+        n8, e8, a8 = rounds[k]
+        t = lambda x: torch.from_numpy(x).float()
+        logp = torch.log_softmax(O.FORWARDS["GGNN"](Pr, cfg, t(n8), t(e8)), dim=1)
+        with torch.no_grad():
+            lp_prior = torch.log_softmax(O.FORWARDS["GGNN"](P, cfg, t(n8), t(e8)), dim=1)
+        w = t(a8) / t(a8).sum(1, keepdim=True)
+        term = -(w * logp).sum(1) + 0.1 * (w * (logp - lp_prior)).sum(1) ** 2
+        total = total + coef[k] * term.mean()
+    total.backward()
+    assert abs(float(loss) - float(total)) < TOL * abs(float(total))
+    num = sum(float((joint[k] - Pr[k].grad.double()).pow(2).sum()) for k in joint)
+    den = sum(float(Pr[k].grad.double().pow(2).sum()) for k in joint)
+    worst = max((rel(joint[k], Pr[k].grad), k) for k in joint)
+    print(f"\n[RL pattern] gradients vs the fp32 oracle: global L2 {(num / den) ** 0.5:.2e}, worst tensor {worst[0]:.2e} ({worst[1]})")
+    assert (num / den) ** 0.5 < 5e-3 and worst[0] < 3e-2, ((num / den) ** 0.5, worst)
+    # the optimizer step the learning step ends with (Workflow.py:598) sees those gradients
+    opt = torch.optim.Adam(agent.parameters(), lr=1e-4)
+    before = [p.detach().clone() for p in agent.parameters()]
+    opt.step()
+    assert any(not torch.equal(a, b) for a, b in zip(before, agent.parameters()))
+
+
 @pytest.mark.parametrize("shape", ["gdb13", "chembl"])
 def test_batch_size_extremes_and_row_independence(shape):
     """B = 1 and B = 3 against the oracle; a B = 3000 batch gives every graph the logits it gets in a

@@ -76,6 +76,13 @@ int main(int argc, char** argv) {
         n = 3;
         for (int i = 0; i < n; ++i) dims[i][0] = dims[i][1] = atoi(getenv("GI_LAB_SQ"));
     }
+    if (getenv("GI_LAB_DIMS") && !wgrad) {             // GI_LAB_DIMS="500x128,500x128,250x136": N x K of every problem (up to 8)
+        n = 0;
+        for (const char* q = getenv("GI_LAB_DIMS"); *q && n < 8; ++n) {
+            dims[n][0] = atoi(q); while (*q && *q != 'x') ++q; if (*q) ++q;
+            dims[n][1] = atoi(q); while (*q && *q != ',') ++q; if (*q) ++q;
+        }
+    }
     gi_gemm_params probs[8];
     Mat A[8], B[8], Cm[8], bias[8], act[8];
     int ldb_host[8] = {};                              // leading dimension of the host copy B[i].h (p.ldb may change with the operand form)

@@ -5,16 +5,19 @@
 # path, readout tail exchanged under the message passes' backward; exposed_ms_after_backward: one all-reduce behind
 # the backward).  Prediction to judge the first real curve against: DESIGN.md section 7.
 #   tools/scale.sh [OUT_DIR] [extra bench.py args...]        (needs the GPUs; N is capped at the visible device count)
+# SCALE_BACKEND=gloo: the same four launches with the ranks SHARING the visible device(s) over gloo — a dry run of this
+# script's control flow on a 1-GPU box (tests/test_bench_gpu.py), not a measurement; N is then not capped.
 OUT=${1:-gpurun_out/scale}; shift
+BACKEND=${SCALE_BACKEND:-nccl}
 mkdir -p $OUT
 cd "$(dirname "$0")/.."
 export HSA_ENABLE_IPC_MODE_LEGACY=0 MASTER_ADDR=127.0.0.1
 NDEV=$(python -c 'import torch; print(torch.cuda.device_count())')
 for N in 1 2 4 8; do
-  [ "$N" -gt "$NDEV" ] && { echo "N=$N skipped: $NDEV device(s) visible"; continue; }
+  [ "$BACKEND" = nccl ] && [ "$N" -gt "$NDEV" ] && { echo "N=$N skipped: $NDEV device(s) visible"; continue; }
   ARGS="--gpus $N --steps 20 --warmup 5 --no-cpu-baseline --no-probe --no-extra-configs --no-forward-only --no-one-stream $*"
   if [ "$N" = 1 ]; then python bench.py $ARGS > $OUT/scale_$N.log 2>&1
-  else python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29500 + N)) bench.py --backend nccl $ARGS > $OUT/scale_$N.log 2>&1
+  else python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((${SCALE_PORT:-29500} + N)) bench.py --backend $BACKEND $ARGS > $OUT/scale_$N.log 2>&1
   fi
   grep '^{"metric"' $OUT/scale_$N.log > $OUT/scale_$N.json || { echo "N=$N FAILED"; tail -5 $OUT/scale_$N.log; continue; }
   python - $OUT/scale_$N.json <<'PY'
