@@ -1587,6 +1587,12 @@ extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* pa
         for (MlpJob& j : jobs) j.out_fshift = r.drop ? (long long)d.B * ldout : 0;
         mlp_jobs_forward(r, ws, jobs, 3);
     }
+    // Whatever the caller enqueues on `stream` after this call — the backward, or a kernel that reuses the workspace's
+    // memory because the tape was dropped without one — is ordered behind the side stream's packs into `ws` (they
+    // finished hundreds of microseconds ago: a wait that never stalls).  The caller therefore needs no cross-stream
+    // bookkeeping of its own for `ws` (torch: no Tensor.record_stream, which would keep the caching allocator from
+    // reusing the block until the low-priority side stream has drained).
+    if (side_stream && (run_flags & GI_RUN_PREPACK_BWD)) r.chk((int)hipStreamWaitEvent(r.st, prepack_event(), 0));
     return r.rc;
 }
 

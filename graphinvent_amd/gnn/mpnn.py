@@ -134,8 +134,8 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dro
     _L.check(lib.gi_ggnn_forward_ex(C.byref(dims), _ptr_table(params), C.byref(gs), ws.data_ptr(),
                                     out.data_ptr(), apd, torch.cuda.current_stream(dev).cuda_stream, side, flags),
              "gi_ggnn_forward")
-    if side:
-        ws.record_stream(_side_stream_obj(dev, side))       # (a tape dropped without a backward frees ws early)
+    # (no ws.record_stream(side stream): gi_ggnn_forward_ex orders the side stream's packs into ws before everything
+    # enqueued on the current stream after it, so a tape dropped without a backward may free ws at once)
     # what the backward of THIS tape must repeat: the run flags and the process-wide arithmetic switches of the forward
     graph.run_flags = flags
     graph.modes = (lib.gi_bf3_enable(-1), lib.gi_x2_enable(-1), lib.gi_b3p_enable(-1))

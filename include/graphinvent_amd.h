@@ -652,9 +652,9 @@ int gi_ggnn_forward(const gi_ggnn_dims* d, const float* const* params, const gi_
  * of the fp16x2 layers' weights and their dynamic-range check (needed by the readout, ~0.4 ms into the forward), and,
  * with GI_RUN_PREPACK_BWD, what gi_ggnn_backward would otherwise pack at its start: the W^T images of the 16-bit-pipe
  * layers and the dZ chains' weight image (then call the backward with GI_BWD_PREPACKED: it waits for that work
- * instead of redoing it).  `stream` waits for the side stream where it needs the results; the caller keeps `ws`
- * alive until the side stream's work is done (it is ordered before the backward; without a backward: until the side
- * stream drains).
+ * instead of redoing it).  `stream` waits for the side stream where it needs the results, and at the end of the call
+ * for the packs into `ws`: everything the caller enqueues on `stream` afterwards (the backward, a reuse of the
+ * workspace's memory) is ordered behind the side stream's work on `ws`.
  * GI_RUN_NO_X2: this call's 16-bit-pipe launches as bf16x3 instead of fp16x2 (what GI_X2=0 does process-wide) — what a
  * caller switches to after gi_graph.x2_guard_host tripped.  Forward and backward of one tape must agree. */
 #define GI_RUN_PREPACK_BWD 1
