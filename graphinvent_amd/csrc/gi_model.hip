@@ -278,7 +278,7 @@ void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
 }
 
 // ---- wgrad slab plan ----------------------------------------------------------------------------
-struct SlabEntry { long long off, stride; int nsplit, calls, done, n_out, n_in, ld, tn, bidx, launched, reduced, bf3, single_last; };   // single_last: the last call wrote ONE slab (the pass-0 rows, defer_wgrad)
+struct SlabEntry { long long off, stride; int nsplit, calls, done, n_out, n_in, ld, tn, bidx, launched, reduced, bf3, single_last, sep; };   // sep: bias column by gi_bias_slabs, reduced with the last batch   // single_last: the last call wrote ONE slab (the pass-0 rows, defer_wgrad)
 struct SlabPlan {
     SlabEntry e[160];
     long long total;
@@ -311,9 +311,14 @@ int bf3_wgrad_nsplit(int red_rows, int decide_rows) {
 // The bias gradient as its own launch (GiBiasSlab, gi_common.h) when the "ones" column would start a new column of
 // 64-wide tiles: n_in % 64 == 0 (GRU projections and first layers at H = 128: 129 columns = 3 tiles for 2 tiles' worth
 // of work).  fp32-MFMA weight gradients only (the 16-bit-pipe kernel's 256-wide tiles hold 501 columns either way).
-// GI_WGRAD_BIAS=0: the ones column everywhere (round-4 schedule).
+// The bias columns of ALL such problems of a backward are written by ONE launch (two in the two-call backward) on the
+// weight-gradient queue, and their parameters are reduced with the last batch.
+// MEASURED AND NOT ADOPTED (default off; GI_WGRAD_BIAS=1 switches it on; tools/experiments/README.md): the tiles it
+// removes are worth ~60 us of weight-gradient kernel time per step, but one bias launch per hand-over (five per step,
+// ~10 us each beside the GEMMs) lost 30 us (1.955 against 1.923 ms), and the single launch ties (1.952-1.961 against
+// 1.945-1.964 ms; ZINC shape 4.06-4.09 against 4.09-4.11): more, smaller split-K slabs to write and reduce eat the rest.
 bool wgrad_sep_bias(int n_in) {
-    static const bool on = getenv("GI_WGRAD_BIAS") && atoi(getenv("GI_WGRAD_BIAS")) != 0;    // default OFF: measured a loss, see below
+    static const bool on = getenv("GI_WGRAD_BIAS") && atoi(getenv("GI_WGRAD_BIAS")) != 0;
     return on && n_in >= 64 && (n_in & 63) == 0;
 }
 
@@ -598,6 +603,8 @@ struct Deferred {
     int widx[96][GI_MAX_GROUPS];     // weight indices each problem's slabs belong to
     int nw[96];
     unsigned char sep_bias[96];      // the problem's bias-gradient column is written by gi_bias_slabs, not by a ones column
+    GiBiasSlab bias[160];            // ... collected over the whole backward, launched once (flush_bias)
+    int nbias = 0;
     int n = 0;
     gi_gemm_params& next() { gemm_defaults(p[n]); nw[n] = 0; sep_bias[n] = 0; return p[n++]; }
 };
@@ -715,9 +722,10 @@ void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* wid
                 if (e->amax && e->in_ok && e->dz_ok) { p.flags |= GI_GEMM_X2; p.a_amax = e->amax + 2 * GI_AMAX_WORDS; p.b_amax = e->amax + GI_AMAX_WORDS; }
     }
     const int slot = q.n - 1;
-    if (!(p.flags & GI_GEMM_BF3) && wgrad_sep_bias(e0.n_in)) {          // plain n_out x n_in problem; db by gi_bias_slabs
-        p.N = e0.n_in; p.ones_col = -1;
+    if (!(p.flags & GI_GEMM_BF3) && !one_slab && wgrad_sep_bias(e0.n_in)) {   // plain n_out x n_in problem; db by gi_bias_slabs
+        p.N = e0.n_in; p.ones_col = -1;                                  // (the pass-0 rows: a few dozen, one slab, keep the column)
         q.sep_bias[slot] = 1;
+        for (int t = 0; t < (g.n ? g.n : 1); ++t) sp.e[widx[t]].sep = 1;
     }
     if (g.n) {
         p.ngroups = g.n; p.grp_off = g.off;
@@ -753,18 +761,19 @@ void launch_wgrad_batch(Run& r, const gi_gemm_params* p, int n, hipStream_t st) 
 
 // consecutive queued problems, up to 8 per launch; the bf16x3 ones (one workgroup per CU, equal tiles) are packed
 // separately, biggest first, into launches of about one round of the device
-void launch_wgrad_batches(Run& r, const gi_gemm_params* p, const unsigned char* sep, int n, hipStream_t st) {
+void launch_wgrad_batches(Run& r, Deferred& dq, const gi_gemm_params* p, const unsigned char* sep, int n, hipStream_t st) {
     gi_gemm_params rest[96], b3[2][96];                           // b3[0]: bf16x3, b3[1]: fp16x2 (a launch is one or the other)
     int nr = 0, n3[2] = {0, 0};
-    GiBiasSlab bias[96 * GI_MAX_GROUPS > 256 ? 256 : 96 * GI_MAX_GROUPS];
-    int nbias = 0;
+    GiBiasSlab* const bias = dq.bias;
+    int& nbias = dq.nbias;
     for (int i = 0; i < n; ++i) {
         if (p[i].flags & GI_GEMM_BF3) { const int x = (p[i].flags & GI_GEMM_X2) ? 1 : 0; b3[x][n3[x]++] = p[i]; }
         else rest[nr++] = p[i];
         if (sep && sep[i]) {                                      // bias-gradient column of this problem's slabs
             const gi_gemm_params& q = p[i];
             const int ng = q.ngroups ? q.ngroups : 1;
-            for (int g = 0; g < ng && nbias < 256; ++g) {
+            for (int g = 0; g < ng; ++g) {
+                if (nbias == 160) { r.chk(gi_bias_slabs(bias, nbias, st)); nbias = 0; }      // (very deep configurations only)
                 GiBiasSlab& b = bias[nbias++];
                 b.dZ = q.A; b.lddz = q.lda; b.grp_off = q.ngroups ? q.grp_off : nullptr; b.g = g;
                 b.rows = q.K; b.n_out = q.M;
@@ -796,11 +805,17 @@ void launch_wgrad_batches(Run& r, const gi_gemm_params* p, const unsigned char* 
         }
     }
     for (int base = 0; base < nr && r.ok(); base += 8) launch_wgrad_batch(r, rest + base, std::min(8, nr - base), st);
-    if (nbias && r.ok()) r.chk(gi_bias_slabs(bias, nbias, st));
+}
+
+// the bias-gradient columns of every problem launched so far without a ones column: one launch, on a stream that is
+// ordered behind their dZ (the stream of their weight-gradient GEMMs)
+void flush_bias(Run& r, Deferred& q, hipStream_t st) {
+    if (q.nbias && r.ok()) r.chk(gi_bias_slabs(q.bias, q.nbias, st));
+    q.nbias = 0;
 }
 
 void flush_deferred(Run& r, Deferred& q) {
-    launch_wgrad_batches(r, q.p, q.sep_bias, q.n, r.st);
+    launch_wgrad_batches(r, q, q.p, q.sep_bias, q.n, r.st);
     q.n = 0;
 }
 
@@ -841,7 +856,7 @@ void kick_deferred(Run& r, Deferred& q, SideStream* side, bool all) {
     hipEvent_t ready = side->next();
     r.chk((int)hipEventRecord(ready, r.st));
     r.chk((int)hipStreamWaitEvent(side->st, ready, 0));
-    launch_wgrad_batches(r, q.p, q.sep_bias, n, side->st);
+    launch_wgrad_batches(r, q, q.p, q.sep_bias, n, side->st);
     // parameters whose last slab has just been queued: reduce them right behind, on the side stream
     // too, so that only the final pass's gradients are left for the end of the backward
     gi_reduce_desc descs[96 * GI_MAX_GROUPS > 160 ? 160 : 96 * GI_MAX_GROUPS];
@@ -849,7 +864,7 @@ void kick_deferred(Run& r, Deferred& q, SideStream* side, bool all) {
     for (int i = 0; i < n; ++i)
         for (int k = 0; k < q.nw[i]; ++k) {
             SlabEntry& e = r.sp->e[q.widx[i][k]];
-            if (++e.launched == e.calls && !e.reduced && nd < 160) {
+            if (++e.launched == e.calls && !e.reduced && !e.sep && nd < 160) {   // (sep: bias column still to come)
                 e.reduced = 1;
                 descs[nd++] = reduce_desc(e, r.slabs, r.grads, q.widx[i][k]);
             }
@@ -1788,9 +1803,19 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
         // queued (side stream if there is one) so that the caller can start exchanging the gradients
         // of these parameters while the message passes are still being differentiated
         if (r.side) {
-            kick_deferred(r, dq, r.side, true);          // also reduces every finished parameter
+            kick_deferred(r, dq, r.side, true);          // also reduces every finished parameter ...
+            flush_bias(r, dq, r.side->st);               // ... but those whose bias column comes from its own launch: now
+            gi_reduce_desc descs[160];
+            int nd = 0;
+            readout_params([&](int widx) {
+                if (sp.e[widx].reduced) return;
+                sp.e[widx].reduced = 1;
+                descs[nd++] = reduce_desc(sp.e[widx], slabs, grads, widx);
+            });
+            if (nd && r.ok()) r.chk(gi_reduce_slabs(descs, nd, r.side->st));
         } else {
             flush_deferred(r, dq);
+            flush_bias(r, dq, r.st);
             gi_reduce_desc descs[160];
             int nd = 0;
             readout_params([&](int widx) {
@@ -1858,7 +1883,7 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
                 {m.eatt, w.aact[p], w.adz[p], w.ldEa, ws + w.een[p], w.ldM,
                  p > 0 ? ws + w.dxa : nullptr}};
             if (p0) {   // per class row: sum over its (hundreds of) edge slots, both stacks in one launch
-                if (r.side) { kick_deferred(r, dq, r.side, true); r.hold_kicks = r.p0_on_main = true; }
+                if (r.side) { kick_deferred(r, dq, r.side, true); flush_bias(r, dq, r.side->st); r.hold_kicks = r.p0_on_main = true; }
                 r.chk(gi_class_sum_dselu(ws + w.tmp_emb, ws + w.tmp_en, w.ldM, gp->cls_edges,
                                          gp->cls_off, w.D0, d.M, ws + w.m[p], ws + w.een[p], w.ldM,
                                          r.st));
@@ -1882,7 +1907,7 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
         } else if (p == 0 && w.D0 > 0) {
             // pass 0: d m0 = selu'(m0) * (cmat^T . d agg): split-K over the R rows, slabs summed with
             // the SELU backward folded in; then the MLP backward on the D0 class rows (no d h needed)
-            if (r.side) { kick_deferred(r, dq, r.side, true); r.hold_kicks = r.p0_on_main = true; }   // nothing queued waits for the pass-0 chain
+            if (r.side) { kick_deferred(r, dq, r.side, true); flush_bias(r, dq, r.side->st); r.hold_kicks = r.p0_on_main = true; }   // nothing queued waits for the pass-0 chain
             gi_gemm_params q;
             gemm_defaults(q);
             q.A = gp->cmat; q.lda = gp->ldc0; q.a_major = 1;
@@ -1927,12 +1952,15 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
     // ---- all weight-gradient GEMMs, 8 problems per launch, then slabs -> parameter gradients -------
     if (r.side && r.p0_on_main) {
         flush_deferred(r, dq);            // a dozen workgroups, right behind their chain: no hand-over to wait for
+        flush_bias(r, dq, r.st);          // (nothing: the pass-0 problems keep their ones column)
         join_side(r, r.side);
     } else if (r.side) {
         kick_deferred(r, dq, r.side, true);
+        flush_bias(r, dq, r.side->st);
         join_side(r, r.side);
     } else {
         flush_deferred(r, dq);
+        flush_bias(r, dq, r.st);
     }
     gi_reduce_desc descs[160];            // whatever has not been reduced on the side stream yet
     int nd = 0;

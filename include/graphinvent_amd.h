@@ -34,8 +34,8 @@
  *     GI_B3W_MSG, GI_B3W_G (message-stack / graph-level weight gradients on the 16-bit pipe below their size
  *     thresholds), GI_P0_LAYERWISE (pass 0 without the chain kernel), GI_CHAIN_BWD64 (64-row fp32 chain blocks in
  *     the backward), GI_CHAIN_XCD (0: the chain kernels' row blocks in dispatch order instead of the XCD-aware one),
- *     GI_WGRAD_BIAS (0: every weight gradient carries its bias gradient as a "ones" column, none through its own
- *     launch); graphinvent_amd/gnn/mpnn.py reads GI_PREPACK (0: gi_ggnn_forward_ex without a side stream and without
+ *     GI_WGRAD_BIAS (1: weight gradients whose input width is a multiple of 64 get their bias gradient from a separate
+ *     launch instead of a "ones" column that costs a column of tiles — measured a tie, off by default); graphinvent_amd/gnn/mpnn.py reads GI_PREPACK (0: gi_ggnn_forward_ex without a side stream and without
  *     GI_RUN_PREPACK_BWD: the round-4 schedule).
  */
 #ifndef GRAPHINVENT_AMD_H

@@ -214,7 +214,13 @@ def _live_only(n8, e8, a8):
 #: cap on the worst single gradient tensor (max |d| / max |ref| against fp64) WITHOUT the SELU-branch pin, per shape:
 #: a few times what the runs of round 4 printed (the fp32 oracle's own worst tensor is printed beside it and is of
 #: the same size: one activation on the other side of the kink moves a 3-output stack by ~1e-2)
-UNPINNED_WORST = {"gdb13": 2e-2, "zinc": 5e-2}     # (zinc: 2.06e-2 with the fp16x2 chains — a different tie at the kink, on a 3-output stack)
+UNPINNED_WORST = {"gdb13": 2e-2, "zinc": 2e-2}
+#: ... beyond which (up to this) the test must PROVE that the tensor moved because of ties at the SELU kink and nothing
+#: else: the same batch differentiated by the fp32 oracle on the branches the HIP forward took (tests/pins.py — which
+#: itself asserts that every activation whose branch the pin changes has |pre-activation| < 1e-5 in the oracle's own
+#: run) must then agree with the HIP gradients at 1e-4 on EVERY tensor.  (Round 4 had raised the zinc cap to 5e-2 with
+#: the fp16x2 chains — 2.06e-2, "a different tie at the kink" — without asserting that; round-4 verdict, weak #2.)
+UNPINNED_HARD_CAP = 5e-2
 
 
 def _oracle_both(cfg, P, n8, e8, a8):
@@ -262,7 +268,25 @@ def test_full_size_parity_vs_fp32_and_fp64_oracle(shape, B, over):
     print(f"\n[unpinned, {shape} B={B}] global L2 vs fp64: HIP {hip_l2:.2e}, fp32 oracle {ref_l2:.2e}; worst tensor: "
           f"HIP {worst[0]:.2e} ({worst[1]}), fp32 oracle {worst_ref[0]:.2e} ({worst_ref[1]})")
     assert hip_l2 < 5e-3 and ref_l2 < 5e-3, (hip_l2, ref_l2)
-    assert worst[0] < UNPINNED_WORST[shape], worst
+    assert worst[0] < UNPINNED_HARD_CAP, worst
+    if worst[0] >= UNPINNED_WORST[shape]:
+        params = list(model.parameters())
+        nodes, edges, tgt = to_dev(n8, e8, a8)
+        out2, tape = mpnn.ggnn_forward_raw(model.constants, nodes, edges, params)
+        dims, graph, ws = tape
+        signs = pins.signs_from_hip(dims, graph, ws, out2, attn=False)
+        garr = pins.graph_arrays(graph)
+        o_leaf = out2.detach().clone().requires_grad_(True)
+        O.kl_loss(o_leaf, tgt).backward()
+        g_hip, _ = mpnn.ggnn_backward_raw(tape, out2, o_leaf.grad, params)
+        t = lambda x: torch.from_numpy(x).float()
+        _, _, g_pin, flipped, total = pins.oracle_pinned(O, P, cfg, t(n8), t(e8), t(a8), signs, garr, "GGNN")
+        names = [k for k, _ in model.named_parameters()]
+        worst_pinned = max((rel(gr, g_pin[k]), k) for k, gr in zip(names, g_hip))
+        print(f"[unpinned, {shape}] worst tensor {worst[0]:.2e} >= {UNPINNED_WORST[shape]:.0e}: with the {flipped} of {total} "
+              f"tie activations pinned the worst tensor is {worst_pinned[0]:.2e} ({worst_pinned[1]})")
+        assert flipped > 0 and flipped < 1e-6 * total, (flipped, total)
+        assert worst_pinned[0] < TOL, worst_pinned
 
 
 @pytest.mark.parametrize("shape,B,over", [
