@@ -325,12 +325,16 @@ bool wgrad_sep_bias(int n_in) {
 void wgrad_shape(int n_out, int n_in, int red_rows, double share, int& tn, int& nsplit) {
     // 64x64 output tiles; 128x128 tiles for the big square weight gradients (a quarter of the slabs)
     // measured slower: 2.73 against 2.64 ms per step (tools/experiments/README.md)
-    tn = 1;
-    const int tiles = gi_cdiv(n_out, 64) * gi_cdiv(wgrad_sep_bias(n_in) ? n_in : n_in + 1, 64);
+    // (measurement aids, re-run in round 5: GI_WGRAD_TN=2 -> 128 x 128 tiles for problems of at least 192 x 192,
+    // GI_WGRAD_WGS=<n> -> workgroups per problem)
+    static const int env_tn = getenv("GI_WGRAD_TN") ? atoi(getenv("GI_WGRAD_TN")) : 1;
+    static const int env_wgs = getenv("GI_WGRAD_WGS") ? atoi(getenv("GI_WGRAD_WGS")) : 0;
+    tn = (env_tn == 2 && n_out >= 192 && n_in >= 192) ? 2 : 1;
+    const int tiles = gi_cdiv(n_out, 64 * tn) * gi_cdiv(wgrad_sep_bias(n_in) ? n_in : n_in + 1, 64 * tn);
     const int kt = gi_cdiv(std::max(red_rows, 1), 32);
     // workgroups per problem, measured in round 2: 96 -> 2.44-2.51 ms per step, 128 -> 2.39-2.40,
     // 192 -> 2.34-2.35, 256 -> 2.37, 384 -> 2.40-2.41
-    const double wgs = 192.0;
+    const double wgs = env_wgs > 0 ? (double)env_wgs : 192.0;
     const int want = (int)(wgs * share / tiles + 0.5);
     nsplit = std::min(std::max(want, 1), std::max(1, kt / 2));
 }

@@ -17,28 +17,66 @@ namespace {
 // ---- K4 seg_sum -----------------------------------------------------------------------------
 // one thread per (compact row, 16-byte column group); lanes of a row group share perm[k] (broadcast
 // load) and read one contiguous row of `vals` -> fully coalesced row gathers.
+// A molecular graph's node has ~1.8 incoming edges: a thread's work is a chain of three DEPENDENT loads (offsets ->
+// edge index -> message row) and one store, so the rate is bytes in flight over latency.  With one output per thread
+// 2 048 resident threads x 16 B = 32 KB per CU were in flight: 4.0 TB/s = 0.50 of the HBM peak beyond the Infinity
+// Cache (round 2-4).  Each thread now carries U independent outputs (rows c, c + stride, ...) through the three load
+// stages together: U x the bytes in flight — 3.85 (U = 1), 4.43 (2), 4.58 (4), 3.3 TB/s (8: registers cost occupancy)
+// on the 567 MB probe of bench.py (profiles/r05/segsum_probe.txt): U = 4, 0.57 of 8 TB/s.  The order in which ONE
+// output's rows are added is unchanged (first pair, further pairs, tail), so results are bit-identical for every U
+// (GI_SEGSUM_U = 1 / 2 / 4: measurement aid).
+template <int U>
 __global__ __launch_bounds__(256) void seg_sum_kernel(
     const float* __restrict__ vals, int ldv, const int* __restrict__ perm,
     const int* __restrict__ off, int rows, int c4n, float* out, int ldo, int accumulate,
     const int* __restrict__ rows_dev) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int c = (int)(t / c4n), q = (int)(t - (long long)c * c4n);
     if (rows_dev) rows = min(rows, *rows_dev);          // bounded launch: the real row count is on the device
-    if (c >= rows) return;
-    const int lo = off[c], hi = off[c + 1];
-    v4f acc = {0.f, 0.f, 0.f, 0.f};
-    int k = lo;
-    for (; k + 1 < hi; k += 2) {                      // two independent row loads in flight
-        const int p0 = perm[k], p1 = perm[k + 1];
-        const v4f a = *(const v4f*)(vals + (long long)p0 * ldv + 4 * q);
-        const v4f b = *(const v4f*)(vals + (long long)p1 * ldv + 4 * q);
-        acc += a;
-        acc += b;
+    const long long stride = (long long)gridDim.x * 256;
+    const long long t0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    int c[U], q[U], lo[U], hi[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const long long t = t0 + u * stride;
+        c[u] = (int)(t / c4n); q[u] = (int)(t - (long long)c[u] * c4n);
+        ok[u] = c[u] < rows;
+        lo[u] = ok[u] ? off[c[u]] : 0;
+        hi[u] = ok[u] ? off[c[u] + 1] : 0;
     }
-    if (k < hi) acc += *(const v4f*)(vals + (long long)perm[k] * ldv + 4 * q);
-    v4f* dst = (v4f*)(out + (long long)c * ldo + 4 * q);
-    if (accumulate) acc += *dst;
-    *dst = acc;
+    int p0[U], p1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                        // the first pair of every output: all loads in flight together
+        p0[u] = lo[u] < hi[u] ? perm[lo[u]] : -1;
+        p1[u] = lo[u] + 1 < hi[u] ? perm[lo[u] + 1] : -1;
+    }
+    v4f a[U], b[U], acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        a[u] = p0[u] >= 0 ? __builtin_nontemporal_load((const v4f*)(vals + (long long)p0[u] * ldv + 4 * q[u])) : v4f{0.f, 0.f, 0.f, 0.f};
+        b[u] = p1[u] >= 0 ? __builtin_nontemporal_load((const v4f*)(vals + (long long)p1[u] * ldv + 4 * q[u])) : v4f{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        acc[u] = v4f{0.f, 0.f, 0.f, 0.f};
+        if (p0[u] >= 0) acc[u] += a[u];
+        if (p1[u] >= 0) acc[u] += b[u];
+        int k = lo[u] + 2;
+        for (; k + 1 < hi[u]; k += 2) {                  // longer segments: two independent row loads in flight
+            const int r0 = perm[k], r1 = perm[k + 1];
+            const v4f x = *(const v4f*)(vals + (long long)r0 * ldv + 4 * q[u]);
+            const v4f y = *(const v4f*)(vals + (long long)r1 * ldv + 4 * q[u]);
+            acc[u] += x;
+            acc[u] += y;
+        }
+        if (k < hi[u]) acc[u] += *(const v4f*)(vals + (long long)perm[k] * ldv + 4 * q[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+        v4f* dst = (v4f*)(out + (long long)c[u] * ldo + 4 * q[u]);
+        if (accumulate) acc[u] += *dst;
+        *dst = acc[u];           // (a non-temporal store measured no gain: 4.44 against 4.49 TB/s)
+    }
 }
 
 __device__ __forceinline__ v4f v4_selu_grad(v4f y) {
@@ -880,8 +918,12 @@ int gi_seg_sum_n(const float* vals, int ldv, const int* perm, const int* off, in
     const long long threads = (long long)rows * c4n;
     // (algorithmic bytes depend on the device-side segment lengths; the caller knows them)
     GiProfScope prof((hipStream_t)stream, GI_PROF_SEGSUM, 0.0);
-    hipLaunchKernelGGL(seg_sum_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, vals, ldv, perm, off, rows, c4n, out, ldo, accumulate, rows_dev);
+    static const int U = [] { const char* e = getenv("GI_SEGSUM_U"); const int v = e ? atoi(e) : 4; return (v == 1 || v == 2) ? v : 4; }();
+    const unsigned blocks = (unsigned)((threads + 256LL * U - 1) / (256LL * U));
+#define GI_SEGSUM_LAUNCH(UU) hipLaunchKernelGGL(seg_sum_kernel<UU>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, vals, \
+                                                ldv, perm, off, rows, c4n, out, ldo, accumulate, rows_dev)
+    if (U == 1) GI_SEGSUM_LAUNCH(1); else if (U == 2) GI_SEGSUM_LAUNCH(2); else GI_SEGSUM_LAUNCH(4);
+#undef GI_SEGSUM_LAUNCH
     return gi_launch_status();
 }
 

@@ -35,7 +35,9 @@
  *     thresholds), GI_P0_LAYERWISE (pass 0 without the chain kernel), GI_CHAIN_BWD64 (64-row fp32 chain blocks in
  *     the backward), GI_CHAIN_XCD (0: the chain kernels' row blocks in dispatch order instead of the XCD-aware one),
  *     GI_WGRAD_BIAS (1: weight gradients whose input width is a multiple of 64 get their bias gradient from a separate
- *     launch instead of a "ones" column that costs a column of tiles — measured a tie, off by default); graphinvent_amd/gnn/mpnn.py reads GI_PREPACK (0: gi_ggnn_forward_ex without a side stream and without
+ *     launch instead of a "ones" column that costs a column of tiles — measured a tie, off by default), GI_WGRAD_TN /
+ *     GI_WGRAD_WGS (tile class / workgroups per problem of the fp32-MFMA weight gradients), GI_SEGSUM_U (outputs per
+ *     thread of the aggregation kernel: 1, 2 or 4); graphinvent_amd/gnn/mpnn.py reads GI_PREPACK (0: gi_ggnn_forward_ex without a side stream and without
  *     GI_RUN_PREPACK_BWD: the round-4 schedule).
  */
 #ifndef GRAPHINVENT_AMD_H
