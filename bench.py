@@ -65,7 +65,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 # v_mfma_f32_32x32x16_bf16 / _f16) over the products one fp32 product costs (6 bf16, 3 f16)
 PEAK_16BIT_MFMA_TFLOPS = 2382.0
 PIPES = (("fp32_mfma", PEAK_FP32_MFMA_TFLOPS), ("bf16x3", PEAK_16BIT_MFMA_TFLOPS / 6), ("fp16x2", PEAK_16BIT_MFMA_TFLOPS / 3))
-PROFILE_DIR = "r04"            # profiles/<dir>/: rocprofv3 kernel stats + PMC passes of this command
+PROFILE_DIR = "r05"            # profiles/<dir>/: rocprofv3 kernel stats + PMC passes of this command
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
 
 

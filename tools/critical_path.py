@@ -30,9 +30,12 @@ def main():
     st = rows[lo:hi]
     fill = next(r for r in st if "compact_fill" in r["Kernel_Name"] and r["Queue_Id"] == main_q)
     mq = [r for r in st if r["Queue_Id"] == main_q and r["s"] >= fill["s"]]
-    side_names = ("gi_gemm_batch_kernel<1, 1, true, true", "gi_gemm_tiles_kernel<1, 1, true, true", "reduce_slabs",
-                  "gi_b3p_kernel<true, true", "gi_b3v_kernel<true, true")
-    side = [r for r in st if r["Queue_Id"] != main_q and any(n in r["Kernel_Name"] for n in side_names)]
+    # the second queue: weight-gradient GEMMs, slab reductions and (round 5) what the forward packs ahead for the backward
+    # plus the fp16x2 layers' amax / dynamic-range passes — everything but the next batch's compaction prefetch
+    prefetch = ("compact_", "copyBuffer", "fillBufferAligned", "FillFunctor")
+    side = [r for r in st if r["Queue_Id"] != main_q and
+            (not any(n in r["Kernel_Name"] for n in prefetch) or
+             ("fillBufferAligned" in r["Kernel_Name"] and r["s"] >= fill["s"] and int(r["Grid_Size_X"]) > 1024))]
     t0 = fill["s"]
 
     def first(pred, after=0.0):
@@ -44,7 +47,11 @@ def main():
     mean = first(lambda n: "mean_rows" in n)
     gather_b = first(lambda n: "gather_bwd" in n)
     colsum = first(lambda n: "colsum" in n)
-    pack_b = [r for r in mq if "chain_pack" in r["Kernel_Name"]][-1]
+    # the message passes' backward starts with the GRU gate backward of the last pass (round 4: with the dZ chains'
+    # weight pack, which the forward now does ahead on the second queue)
+    gates_b = [r for r in mq if "gru_gates_bwd" in r["Kernel_Name"]]
+    packs = [r for r in mq if "chain_pack" in r["Kernel_Name"] and r["s"] > colsum["e"]]
+    pack_b = packs[-1] if packs else (gates_b[0] if gates_b else colsum)
     adam_k = mq[-1]
     last_bwd = mq[-2]
     bounds = [
