@@ -280,16 +280,17 @@ def _rel(a, b):
 
 #: What the measurement found (profiles/r05/x2_trial.txt, gpu_trained_checkpoint.log), on models fitted to a loss of
 #: 0.1-0.17 (from 6.0 / 7.4), gradient tensors' maxima between 1e-10 and 2e-2, i.e. heavy cancellation inside the sums:
-#: NO fp32 evaluation reproduces the fp64 gradient to 1e-4 on EVERY tensor any more.  GDB-13 shape: worst tensor 0.4e-4
-#: to 2.0e-4 from fp64 depending on the checkpoint (the 1-output termination stack, a sum over ~950 graphs), the same in
-#: all three modes (fp16x2 1.8e-4, bf16x3 2.0e-4, fp32 MFMA 2.0e-4), the fp32 oracle 0.1-0.5e-4.  ZINC shape: fp16x2
-#: 3.3e-4, fp32 MFMA 4.3e-4, the reference's own arithmetic (fp32 oracle) 2.2e-4.  The k-ordered MFMA accumulation
-#: chain + split-K slabs are a factor 2-10 behind ATen's blocked CPU summation on the most cancelling tensors, and
-#: fp16x2 is NOT behind the fp32 MFMA anywhere.  The bar on a fitted model is therefore: logits and loss 1e-4 as
-#: everywhere; the gradient as a whole (global relative L2 over all tensors) within 1e-4 of fp64; every single tensor
-#: within 5e-4; and fp16x2's worst tensor no further from fp64 than 1.5 x the fp32-MFMA-only mode's
-#: (test_fp16x2_is_no_further_from_fp64_than_the_fp32_mfma below).
-TRAINED_TENSOR_CAP, TRAINED_GLOBAL_L2 = 5e-4, 1e-4
+#:   GDB-13 shape  gradient as a whole (relative L2 over all tensors) 1.5e-5 from fp64 in all three modes (the fp32
+#:                 oracle: 0.8e-5); worst single tensor 3.2-3.9e-5 (oracle 1.5e-5) — with another checkpoint of the same
+#:                 recipe 1.8-2.0e-4, again the same in all three modes (the 1-output termination stack);
+#:   ZINC shape    gradient as a whole 2.5e-4 (fp16x2) / 2.5e-4 (fp32 MFMA only), the reference's own arithmetic (fp32
+#:                 oracle) 1.1e-4; worst tensor 3.3e-4 / 4.3e-4, oracle 2.2e-4.
+#: On a fitted model NO fp32 evaluation reproduces the fp64 gradient to 1e-4 any more, the reference's own included; the
+#: k-ordered MFMA accumulation chain + split-K slabs are a factor ~2 behind ATen's blocked CPU summation, and fp16x2 is
+#: NOT behind the fp32 MFMA anywhere.  The bar on a fitted model is therefore relative to the reference's own
+#: arithmetic: logits and loss 1e-4 as everywhere; the gradient as a whole within max(1e-4, 3 x the fp32 oracle's
+#: distance from fp64); the worst single tensor within 1e-4 + 3 x the fp32 oracle's worst; and fp16x2's worst tensor no
+#: further from fp64 than 1.5 x the fp32-MFMA-only mode's (test_fp16x2_is_no_further_from_fp64_than_the_fp32_mfma).
 _WORST = {}
 
 
@@ -354,8 +355,8 @@ def test_trained_checkpoint_parity_in_every_arithmetic_mode(shape, B, over, mode
         l2_ref = (sum(float((g32[k].double() - g64[k]).pow(2).sum()) for k in names) / den) ** 0.5
         print(f"[trained checkpoint, {shape}, {mode}] the gradient as a whole, relative L2 distance from fp64: HIP {l2_hip:.2e}, "
               f"fp32 oracle {l2_ref:.2e}")
-        assert l2_hip < TRAINED_GLOBAL_L2, l2_hip
-        assert worst[1] < TRAINED_TENSOR_CAP, worst
+        assert l2_hip < max(1e-4, 3 * l2_ref), (l2_hip, l2_ref)
+        assert worst[1] < 1e-4 + 3 * worst_ref[2], (worst, worst_ref)
         assert stats["forward_rows"] == 0 and stats["weight_lines"] == 0 and not stats["tripped"], stats
     finally:
         lib.gi_bf3_enable(was[0]); lib.gi_x2_enable(was[1])
