@@ -330,7 +330,9 @@ void wgrad_shape(int n_out, int n_in, int red_rows, double share, int& tn, int& 
     static const int env_tn = getenv("GI_WGRAD_TN") ? atoi(getenv("GI_WGRAD_TN")) : 1;
     static const int env_wgs = getenv("GI_WGRAD_WGS") ? atoi(getenv("GI_WGRAD_WGS")) : 0;
     tn = (env_tn == 2 && n_out >= 192 && n_in >= 192) ? 2 : 1;
-    const int tiles = gi_cdiv(n_out, 64 * tn) * gi_cdiv(wgrad_sep_bias(n_in) ? n_in : n_in + 1, 64 * tn);
+    if (env_tn == 12) tn = 12;                          // 64 x 128 tiles (tm = 1, tn = 2) for every problem
+    const int tiles = tn == 12 ? gi_cdiv(n_out, 64) * gi_cdiv(wgrad_sep_bias(n_in) ? n_in : n_in + 1, 128)
+                               : gi_cdiv(n_out, 64 * tn) * gi_cdiv(wgrad_sep_bias(n_in) ? n_in : n_in + 1, 64 * tn);
     const int kt = gi_cdiv(std::max(red_rows, 1), 32);
     // workgroups per problem, measured in round 2: 96 -> 2.44-2.51 ms per step, 128 -> 2.39-2.40,
     // 192 -> 2.34-2.35, 256 -> 2.37, 384 -> 2.40-2.41
@@ -714,7 +716,7 @@ void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* wid
     p.ones_col = e0.n_in;
     p.flags = GI_GEMM_SPLITK;
     p.nsplit = e0.nsplit; p.c_split_stride = e0.stride;
-    p.tm = e0.tn; p.tn = e0.tn;                 // 1x1 (64x64 tiles) or 2x2 (128x128), see wgrad_shape
+    p.tm = e0.tn == 12 ? 1 : e0.tn; p.tn = e0.tn == 12 ? 2 : e0.tn;     // 1x1 (64x64 tiles) or 2x2 (128x128), see wgrad_shape
     // The pass-0 rows (a few dozen per bond type, the stack's last call): ONE slab instead of the plan's nsplit — split
     // nine ways the launch was 2 200 workgroups that mostly store zeros, 50 us + their share of the final reduction
     // behind the last dZ chain with nothing left to overlap (profiles/r04/x2/critical_path_amax_cells.txt)
@@ -1796,7 +1798,12 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
         // everything queued goes out behind them, under the message passes' short launches (round 2: step
         // 2.362 -> 2.344 ms, GEMM-family per-launch figure 0.349 -> 0.374 of peak; re-measured in round 3 with the
         // dgrad launches on the bf16 pipe: 2.20 ms held against 2.25-2.28 released).
-        r.hold_kicks = true;
+        // Round 5, with the backward bound by the weight-gradient queue: holding still wins at the headline batch
+        // (7.3 k node rows: 1.935 against 1.944 ms) and loses from ~10 k rows on (B = 2000: 3.35 -> 3.24 ms, ZINC shape
+        // 4.05 -> 4.00, ChEMBL shape 3.24 -> 3.21, B = 4000 a tie; profiles/r05/ab/ab_hold_kicks.txt).
+        // GI_HOLD_KICKS = 0 / 1 forces either.
+        static const int hold_env = getenv("GI_HOLD_KICKS") ? atoi(getenv("GI_HOLD_KICKS")) : -1;
+        r.hold_kicks = hold_env >= 0 ? hold_env != 0 : R <= 9000;
         mlp_jobs_backward(r, ws, sp, slabs, dq, jobs, 4);
         r.hold_kicks = false;
         if (r.side) kick_deferred(r, dq, r.side, false);
