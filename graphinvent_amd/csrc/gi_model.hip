@@ -695,7 +695,10 @@ void add_dgrad(Batch& b, Run& r, int widx, int n_out, int n_in, int ncols, const
 void flush_deferred(Run& r, Deferred& q);
 void kick_deferred(Run& r, Deferred& q, SideStream* side, bool all);
 // queued weight-gradient problems that make up one hand-over to the side stream (one launch)
-constexpr int wgrad_kick_n() { return 8; }
+inline int wgrad_kick_n() {
+    static const int n = [] { const char* e = getenv("GI_KICK_N"); const int v = e ? atoi(e) : 8; return (v >= 1 && v <= 8) ? v : 8; }();   // (measurement aid)
+    return n;
+}
 
 gi_reduce_desc reduce_desc(const SlabEntry& e, float* slabs, float* const* grads, int widx) {
     gi_reduce_desc q;
@@ -1265,6 +1268,7 @@ extern "C" int gi_side_stream_create(void** out) {
     hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
     if (e != hipSuccess) return (int)e;
     hipStream_t st = nullptr;
+    if (getenv("GI_SIDE_PRIO") && atoi(getenv("GI_SIDE_PRIO")) == 0) least = (least + greatest) / 2;   // (measurement aid: not the lowest)
     e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least);
     if (e != hipSuccess) return (int)e;
     *out = (void*)st;

@@ -918,7 +918,11 @@ int gi_seg_sum_n(const float* vals, int ldv, const int* perm, const int* off, in
     const long long threads = (long long)rows * c4n;
     // (algorithmic bytes depend on the device-side segment lengths; the caller knows them)
     GiProfScope prof((hipStream_t)stream, GI_PROF_SEGSUM, 0.0);
-    static const int U = [] { const char* e = getenv("GI_SEGSUM_U"); const int v = e ? atoi(e) : 4; return (v == 1 || v == 2) ? v : 4; }();
+    // U outputs per thread pay when the launch has far more threads than the device holds at once (HBM-resident
+    // operands: the 30 M-thread probe); the step's own launches (230 k threads on 10 MB that sit in L2) are faster with
+    // every output on its own thread: 5.0 against 9.6 us (profiles/r05)
+    static const int U_env = [] { const char* e = getenv("GI_SEGSUM_U"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
+    const int U = U_env ? U_env : (threads >= (4LL << 20) ? 4 : 1);
     const unsigned blocks = (unsigned)((threads + 256LL * U - 1) / (256LL * U));
 #define GI_SEGSUM_LAUNCH(UU) hipLaunchKernelGGL(seg_sum_kernel<UU>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, vals, \
                                                 ldv, perm, off, rows, c4n, out, ldo, accumulate, rows_dev)
