@@ -65,3 +65,41 @@ def test_the_ones_column_of_the_weight_gradient_layout_is_exact_for_any_scale():
         assert float(h1[0]) == 1.0 and float(h2[0]) == 0.0
         plain = np.float32(1.0) * s
         assert (float(plain) > 65504.0) == (amax < 0.25)
+
+
+def guard_counts(a: np.ndarray) -> int:
+    """numpy model of gi_gemm_params.x2_guard (gi_gemm_bf3.hip / gi_gemm_b3p.hip): rows of A whose largest SCALED
+    magnitude is non-zero and below 2^-11."""
+    s, _ = X.scale(np.abs(a).max())
+    rowmax = np.abs(a).max(axis=1).astype(np.float32) * s
+    return int(((rowmax > 0) & (rowmax < np.float32(2.0 ** -11))).sum())
+
+
+def test_guard_threshold_marks_the_rows_that_lose_their_bits():
+    """The threshold of the dynamic-range guard in the terms of this arithmetic model: a row whose largest element scales
+    below 2^-11 (= lies more than 2^24 below the tensor's maximum, which scales into [2^13, 2^14)) is represented with a
+    per-row product error above the path's 1e-4 bar (here 6e-4 at 2^-25.5 below the maximum); a row just above the
+    threshold (2^-20.5 below) stays at 1e-5; exactly-zero rows are exact and not counted: the guard counts the rows
+    that can miss the bar and no others."""
+    rng = np.random.default_rng(7)
+    a = rng.standard_normal((64, 256)).astype(np.float32)
+    b = rng.standard_normal((32, 256)).astype(np.float32)
+    a[0, 0] = 8.0                                                   # the tensor's maximum: scale 2^10
+    a[5] *= np.float32(2.0 ** -22)                                 # largest element ~2^-20.5 below the maximum: not counted
+    a[6] *= np.float32(2.0 ** -27)                                 # ~2^-25.5 below: counted
+    a[7] = 0.0                                                     # exact
+    assert guard_counts(a) == 1
+    s, inv = X.scale(np.abs(a).max())
+    h1, h2 = X.split(a, s)
+    back = (h1.astype(np.float64) + h2.astype(np.float64)) * float(inv)
+    rel_row = np.abs(back - a).max(axis=1) / np.maximum(np.abs(a).astype(np.float64).max(axis=1), 1e-300)
+    assert rel_row[7] == 0.0
+    assert rel_row[5] < 2.0 ** -13 < rel_row[6]                       # what is left of the row's elements: ~14 bits / ~9 bits
+    ref = a.astype(np.float64) @ b.astype(np.float64).T
+    got = X.matmul(a, b)
+    S = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64).T
+    err_row = np.abs(got - ref).max(axis=1) / S.max(axis=1).clip(1e-300)
+    assert np.delete(err_row, [5, 6, 7]).max() < 1e-6                # rows near the maximum
+    assert err_row[5] < 2e-5 and err_row[6] > 1e-4                    # the uncounted row meets the 1e-4 bar, the counted one may not
+    # ... and per TENSOR nothing of it shows (the bar of the parity suite)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 3e-7
