@@ -979,7 +979,10 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
     // chain workgroups owning their CU).  One weight tile of look-ahead less costs nothing measurable alone;
     // the step gains 1.6 % (headline 2.312 / 2.332 -> 2.277 / 2.295 ms, ZINC shape 5.044 -> 4.957, ChEMBL shape
     // 3.854 -> 3.813; profiles/r03/chain_ring_ab.txt).  gi_mlp_chain_config(ring = 3): the three-slot ring.
-    const bool ring2 = !big && g_chain_cfg.ring != 3;
+    // (measurement aid GI_CHAIN_RING3_SMALL=<n>: launches of at most n row blocks — the pass-0 rows: a dozen workgroups,
+    // pure weight-stream latency, nothing else wants the CUs' LDS — take the three-slot ring: one more tile in flight)
+    static const int ring3_small = getenv("GI_CHAIN_RING3_SMALL") ? atoi(getenv("GI_CHAIN_RING3_SMALL")) : 0;
+    const bool ring2 = !big && g_chain_cfg.ring != 3 && !(total <= ring3_small);
     if (x2) {
         if (chains[0].backward) hipLaunchKernelGGL((gi_chain_x2_kernel<true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((gi_chain_x2_kernel<false>), grid, block, 0, st, a);
