@@ -136,7 +136,16 @@ __global__ __launch_bounds__(256) void gi_gemm_tiles_kernel(const GemmBatch b) {
         const gi_gemm_params& p = b.p[i];
         t.pi = i;
         const int gx = b.gx[i], gy = b.gy[i], gxy = gx * gy;
-        const int local = id - b.start[i];
+        int local = id - b.start[i];
+        // split-K launches (weight gradients), flag bit 11: the XCD-aware order over the problem's WHOLE tile list, so
+        // that one XCD walks consecutive slabs — the tiles of a slab read the SAME rows of both operands and share
+        // them in one L2 (round 5; the order inside a slab, below, spreads a slab over all eight L2s)
+        const bool slab_order = (p.flags & 2048) != 0;
+        if (slab_order) {
+            const int T = b.start[i + 1] - b.start[i];
+            const int q = T >> 3, r = T & 7, xcd = local & 7, j = local >> 3;
+            local = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        }
         const int bz = local / gxy;
         int rem = local - bz * gxy;
         // XCD-aware tile order (flag bit 5, set by the host for launches of many workgroups, see
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(256) void gi_gemm_tiles_kernel(const GemmBatch b) {
         int gxy_real = gxy;
         if (p.m_dev) gxy_real = gx * ((min(p.M, *p.m_dev) + BM - 1) / BM);
         const bool surplus = rem >= gxy_real;
-        if ((p.flags & 32) && !surplus) {
+        if ((p.flags & 32) && !surplus && !slab_order) {
             const int q = gxy_real >> 3, r = gxy_real & 7, xcd = rem & 7, j = rem >> 3;
             rem = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
         }
@@ -714,6 +723,12 @@ static int launch_tiles(GemmBatch& b, double flops, hipStream_t st) {
         if ((b.p[i].flags & ~GI_GEMM_SPLITK) != own_epilogue(am, bm)) epi = 0;
     if (want_remap(b.total))
         for (int i = 0; i < b.n; ++i) b.p[i].flags |= 32;
+    {   // GI_WGRAD_SLAB_ORDER=0: split-K launches keep the per-slab order (measurement aid)
+        static const bool slab = !(getenv("GI_WGRAD_SLAB_ORDER") && atoi(getenv("GI_WGRAD_SLAB_ORDER")) == 0);
+        if (slab && b.total >= 64)
+            for (int i = 0; i < b.n; ++i)
+                if ((b.p[i].flags & GI_GEMM_SPLITK) && !b.p[i].m_dev) b.p[i].flags |= 2048;
+    }
     int grid = b.total;
     // Bounded launches (rows counted on the device, m_dev): the grid would be sized for the BOUND and its surplus
     // workgroups, though they exit at once, are dispatched at the tail of the launch at the dispatcher's rate

@@ -576,6 +576,14 @@ int gi_b3p_launch(const gi_gemm_params* probs, int n, void* stream) {
     bool bounded = false;
     for (int i = 0; i < k; ++i) bounded |= b.p[i].m_dev != nullptr;
     b.remap = (total >= 512 && !bounded && !am) ? 1 : 0;
+    {   // Weight-gradient launches (split-K slabs): consecutive tile ids are the column / row tiles of ONE slab, i.e. the
+        // workgroups that read the SAME rows of both operands — dealt round-robin to the 8 XCDs each of them pulls its
+        // 128 + 256 columns of those rows through a different L2 (2.5-3.1 x the operand bytes per launch through the
+        // fabric, profiles/r04).  With the bijective remap one XCD walks consecutive ids: a slab's tiles share an L2.
+        // GI_B3P_WGRAD_REMAP=0: dispatch order.
+        static const bool wremap = !(getenv("GI_B3P_WGRAD_REMAP") && atoi(getenv("GI_B3P_WGRAD_REMAP")) == 0);
+        if (am && wremap && !bounded && total >= 16) b.remap = 1;
+    }
     hipStream_t st = (hipStream_t)stream;
     typedef void (*kern_t)(const GpBatch);
     kern_t fn;
