@@ -65,6 +65,7 @@ struct ChainArgs {
     // the L2 requests of the fp32 / fp16x2 chain missed, profiles/r04/pmc_chain_kernels.txt); with the bijective remap
     // of gi_gemm.hip one XCD walks CONSECUTIVE blocks, i.e. one or two types.  GI_CHAIN_XCD=0: dispatch order.
     int remap;
+    int dbg;                                // TIMING-ONLY lab switches of the fp16x2 kernel (GI_DBG_X2 bit mask; results wrong)
 };
 __device__ __forceinline__ int chain_block_id(const ChainArgs& a, int bid) {
     const int total = a.chain_off[a.nchains];
@@ -248,6 +249,12 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
         const int coff = col_ok ? 4 * col : 0x40000000;     // beyond any tile: dropped / reads 0
         float av[RB][16];
         const bool dselu = BWD && Ly.act != nullptr;
+        if (dselu && (args.dbg & 1)) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) av[rb][r] = 1.f;
+        } else
         if (dselu) {
             const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(Ly.act + (long long)r0 * Ly.ldact), 0, nrows * Ly.ldact * 4, 0x00020000);
@@ -633,6 +640,12 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
         const int coff = col_ok ? 4 * col : 0x40000000;
         float av[2][16];
         const bool dselu = BWD && Ly.act != nullptr;
+        if (dselu && (args.dbg & 1)) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) av[rb][r] = 1.f;
+        } else
         if (dselu) {
             const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(Ly.act + (long long)r0 * Ly.ldact), 0, nvalid * Ly.ldact * 4, 0x00020000);
@@ -664,7 +677,7 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
         // wave maxima are in LDS.
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
-        if (l + 1 < L) {                                     // next layer's A operand: split, in place
+        if (l + 1 < L && !(args.dbg & 4)) {                  // next layer's A operand: split, in place
             gx_scale(wg_max_from_lds(), sa, ia);
             // A lane holds ONE column of 16 rows per row block: written one by one that is 64 two-byte stores per
             // thread into 8 of the 32 banks (round 4: 45 % of the kernel's LDS cycles were bank conflicts).  Neighbouring
@@ -690,6 +703,7 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
         }
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(Ly.out + (long long)r0 * ldo), 0, nvalid * ldo * 4, 0x00020000);
+        if (!(args.dbg & 2))
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -765,7 +779,7 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
         since_epi = __builtin_amdgcn_readfirstlane(since_epi + 1);
         dma_tile(s + 3);
         const int slot = s & (CX_RING - 1);
-        if (swid * 32 < __builtin_amdgcn_readfirstlane(lN)) {
+        if (swid * 32 < __builtin_amdgcn_readfirstlane(lN) && !(args.dbg & 8)) {
             read_frags(slot, kt, af, bf);
             __builtin_amdgcn_sched_barrier(0);
             mma(af, bf);
@@ -773,6 +787,10 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
         }
         kt = __builtin_amdgcn_readfirstlane(kt + 1);
         if (kt == __builtin_amdgcn_readfirstlane(nk)) {       // layer done
+            if (args.dbg & 16) {                              // (lab: no epilogue at all)
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __syncthreads();
+            } else
             epilogue(l);
             since_epi = 0;
             l = __builtin_amdgcn_readfirstlane(l + 1);
@@ -969,6 +987,9 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
     {
         static const bool xcd = !(getenv("GI_CHAIN_XCD") && atoi(getenv("GI_CHAIN_XCD")) == 0);
         a.remap = (xcd && !bounded && total >= 16) ? 1 : 0;
+#ifdef GI_CHAIN_X2_LAB      // (make FLAGS+=-DGI_CHAIN_X2_LAB: the breakdown of profiles/r05/x2_chain_breakdown.txt; results WRONG with a mask)
+        a.dbg = getenv("GI_DBG_X2") ? atoi(getenv("GI_DBG_X2")) : 0;
+#endif
     }
     hipStream_t st = (hipStream_t)stream;
     GiProfScope prof(st, GI_PROF_GEMM | (x2 ? GI_PROF_PIPE_X2 : 0), flops);
