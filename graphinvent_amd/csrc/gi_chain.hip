@@ -806,6 +806,269 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
     }
 }
 
+// ======================================================================================================
+// fp16x2 chain, ROW-INDEPENDENT variant (gi_chain_params.x2_rows32; round 5): 32 rows per workgroup, every ROW of the
+// activation tile scaled by its own power of two.  tools/stream_lab + the phase breakdown of the 64-row kernel
+// (profiles/r05/x2_chain_breakdown.txt) showed that the chain kernels are NOT bound by their weight stream (the bare
+// stream of a 1.15 MB image per workgroup: 12.5 us on half the CUs, 19 us on all) but by phases that do not overlap —
+// in the fp32 kernel 31 us of v_mfma_f32_32x32x2_f32 per launch, in the 64-row fp16x2 kernel five 4-us epilogues and
+// the fragment-read -> MFMA chain of every step.  This variant
+//   * transposes the product: C^T = W . A^T — the MFMA's A operand is the WEIGHT fragment (32 output channels x 16 k),
+//     its B operand the ACTIVATION fragment (16 k x 32 rows); same fragments, same LDS reads, operands swapped.  A lane
+//     then holds ONE row (lane & 31) and 16 output channels of it: the row's largest magnitude is 16 in-register maxima,
+//     one cross-half exchange and the other waves' 7 values through LDS — the per-row scale that cost "160 cross-lane
+//     maxima per thread" in the row-major layout (round 4) is nearly free, and 1 / scale of the row is a per-lane
+//     constant in the epilogue;
+//   * so every row's result depends on nothing but the row and the weights: bit-independent of which rows share its
+//     block — usable by gi_ggnn_forward (pass-0 row cache, blocking == host-sync-free, tape == no tape);
+//   * writes the next layer's planes as 8-byte pieces, 32 lanes = 32 adjacent rows of one k chunk: conflict-free by
+//     construction; stages the fp32 outputs through LDS and stores whole rows (16 bytes per lane, coalesced);
+//   * 3 MFMAs (v_mfma_f32_32x32x16_f16) per wave and 16-deep step: 3.2 us of matrix-pipe time per launch.
+constexpr int CR_ROWS = 32;
+constexpr int CR_PLANE = 32 * CR_ROWS * 16;                 // bytes of one activation plane (16 KB)
+constexpr int CR_OLD = CH_W + 4;                            // floats per row of the output staging tile
+__device__ __forceinline__ unsigned cr_a_off(int plane, int chunk, int row) {
+    return (unsigned)(plane * CR_PLANE + (chunk * CR_ROWS + row) * 16);
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(512) void gi_chain_x2r_kernel(const ChainArgs args) {
+    __shared__ __attribute__((aligned(16))) unsigned char Ah[2 * CR_PLANE];
+    __shared__ __attribute__((aligned(1024))) float Bs[CX_RING * CX_TILE];
+    __shared__ __attribute__((aligned(16))) float Os[CR_ROWS * CR_OLD];
+    __shared__ float red[8][CR_ROWS];                       // per wave: max |new activation| of every row
+    typedef unsigned cx_u32x2 __attribute__((ext_vector_type(2)));
+    if (args.c[0].skip_flag && *args.c[0].skip_flag != 0) return;
+    for (int bid = blockIdx.x; bid < args.chain_off[args.nchains]; bid += gridDim.x) {
+    const int id = chain_block_id(args, bid);
+    const int ci = (args.nchains > 1 && id >= args.chain_off[1]) ? 1 : 0;
+    const gi_chain_params& P = args.c[ci];
+    const int local = id - args.chain_off[ci];
+    int g = 0, first = 0;
+    if (args.dev_tiles) {                                    // row blocks of the groups, counted on the device
+        for (; g < P.ngroups; ++g) {
+            const int rows = __builtin_amdgcn_readfirstlane(P.grp_off[g + 1] - P.grp_off[g]);
+            const int nb = (rows + CR_ROWS - 1) / CR_ROWS;
+            if (local < first + nb) break;
+            first += nb;
+        }
+        if (g == P.ngroups) continue;                        // beyond the real row blocks
+    } else {
+        while (g < P.ngroups - 1 && local >= args.tile_off[ci][g + 1]) ++g;
+        first = args.tile_off[ci][g];
+    }
+    const int lo = P.grp_off ? __builtin_amdgcn_readfirstlane(P.grp_off[g]) : 0;
+    const int hi = P.grp_off ? __builtin_amdgcn_readfirstlane(P.grp_off[g + 1]) : P.rows;
+    const int r0 = lo + CR_ROWS * (local - first);
+    if (r0 >= hi) continue;                                 // block-uniform, before any barrier
+    const int nvalid = min(hi - r0, CR_ROWS);
+    const int L = P.nlayers;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int swid = __builtin_amdgcn_readfirstlane(wid);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int T = cx_tiles(P);
+
+    const float* const img = P.image + (long long)g * (P.image_stride ? P.image_stride
+                                                                      : (long long)chain_tiles(P) * CH_TILE) +
+                             (swid * 2) * 256 + lane * 4;
+    const unsigned bs_lds = (unsigned)(uintptr_t)Bs + (unsigned)(swid * 2) * 1024u;
+    auto dma_tile = [&](int t) {
+        t = min(t, T - 1);                                   // past the end: re-fetch the last tile (fixed load count)
+        const float* src = img + (long long)t * CX_TILE;
+        const unsigned dst = bs_lds + (unsigned)(t & (CX_RING - 1)) * (unsigned)(CX_TILE * 4);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) lds_dma_1k(src + q * 256, dst + q * 1024u);
+    };
+    auto w_inv_scale = [&](int l) {
+        float s_, inv_;
+        gx_scale(gx_amax_read(P.x2_wamax + ((long long)l * P.ngroups + g) * GI_AMAX_WORDS), s_, inv_);
+        return inv_;
+    };
+    float ib = w_inv_scale(0);
+    f32x16 acc;
+    float sa = 1.f, ia = 1.f;                               // scale of THIS LANE's row (l31) in the LDS planes, and its inverse
+    gx_f16x8 af[2], wf[2];                                   // activation / weight fragment, [plane]
+    auto read_frags = [&](int slot, int kt) {
+        const unsigned char* bt = reinterpret_cast<const unsigned char*>(Bs) + slot * (CX_TILE * 4);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            af[pl] = *reinterpret_cast<const gx_f16x8*>(Ah + cr_a_off(pl, kt * 2 + lhi, l31));
+            wf[pl] = *reinterpret_cast<const gx_f16x8*>(bt + cx_b_off(pl, lhi, wid * 32 + l31));
+        }
+    };
+    auto mma = [&]() {                                       // C^T: w2 a1 + w1 a2 + w1 a1 (smallest terms first)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1], af[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0], af[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0], af[0], acc, 0, 0, 0);
+    };
+    // the row scale of this lane from the 8 waves' row maxima (after a barrier behind their red[] writes)
+    auto row_scale_from_lds = [&]() {
+        float m = red[0][l31];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w][l31]);
+        gx_scale(m, sa, ia);
+    };
+
+    auto epilogue = [&](int l) {
+        const gi_chain_layer& Ly = P.layer[l];
+        const int N = Ly.N, ldo = Ly.ldo;
+        // this lane: row l31 of the block, output channels nb + 8 j + {0..3}, j = 0..3
+        const int nb = wid * 32 + 4 * lhi;
+        const bool row_ok = l31 < nvalid;
+        const bool dselu = BWD && Ly.act != nullptr;
+        v4f fac[4], bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { fac[j] = v4f{1.f, 1.f, 1.f, 1.f}; bv[j] = v4f{0.f, 0.f, 0.f, 0.f}; }
+        if (dselu) {                                        // selu'(through the stored activation) of this row's channels
+            const float* arow = Ly.act + (long long)(r0 + (row_ok ? l31 : 0)) * Ly.ldact;
+            const int cmax = ((N + 3) & ~3) - 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v4f y = gi_load4_raw(arow, nb + 8 * j, cmax);
+                fac[j] = v4f{gi_selu_grad(y.x), gi_selu_grad(y.y), gi_selu_grad(y.z), gi_selu_grad(y.w)};
+            }
+        }
+        if (!BWD) {
+            const float* brow = Ly.bias[g];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const int n = nb + 8 * j + e; bv[j][e] = brow[n < N ? n : N - 1]; }
+        }
+        const float iab = ia * ib;
+        v4f x[4];
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[4 * j + e] * iab + bv[j][e];
+                if (!BWD) v = gi_selu(v);
+                if (dselu) v *= fac[j][e];
+                v = (nb + 8 * j + e < N && row_ok) ? v : 0.f;        // zero = the next layer's k padding / rows beyond the block
+                x[j][e] = v;
+                m = fmaxf(m, fabsf(v));
+            }
+        m = fmaxf(m, __shfl_xor(m, 32));                     // both channel halves of the row
+        if (lhi == 0) red[wid][l31] = m;
+        // Drain this wave's DMA queue, then: every wave is past its last read of the activation planes, and the eight
+        // row-maximum vectors are in LDS.
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (l + 1 < L) {                                     // next layer's A^T operand: this row's own scale, split, in place
+            row_scale_from_lds();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned p0a, p1a, p0b, p1b;
+                gx_split2(x[j].x, x[j].y, sa, p0a, p1a);
+                gx_split2(x[j].z, x[j].w, sa, p0b, p1b);
+                const unsigned at = cr_a_off(0, (wid * 32 + 8 * j) >> 3, l31) + 8 * lhi;
+                cx_u32x2 w0 = {p0a, p0b}, w1 = {p1a, p1b};
+                *reinterpret_cast<cx_u32x2*>(Ah + at) = w0;
+                *reinterpret_cast<cx_u32x2*>(Ah + CR_PLANE + at) = w1;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<v4f*>(&Os[l31 * CR_OLD + nb + 8 * j]) = x[j];
+        __syncthreads();                                     // the output tile is staged (and the new planes are written)
+        {   // whole rows to HBM: 16 lanes x 16 bytes per row and pass, 4 passes over the 256 columns
+            const int row = tid >> 4, c0 = 4 * (tid & 15);
+            float* orow = Ly.out + (long long)(r0 + row) * ldo;
+            if (row < nvalid) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = c0 + 64 * q;
+                    const v4f v = *reinterpret_cast<const v4f*>(&Os[row * CR_OLD + c]);
+                    if (c + 3 < N) *reinterpret_cast<v4f_u*>(orow + c) = v;
+                    else {
+                        if (c < N) orow[c] = v.x;
+                        if (c + 1 < N) orow[c + 1] = v.y;
+                        if (c + 2 < N) orow[c + 2] = v.z;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (l + 1 < L) ib = w_inv_scale(l + 1);             // (lands under the next layer's k loop)
+    };
+
+    // ---- prologue: the 32 input rows -> per-row scale -> two fp16 planes in LDS (zero beyond K0) --------
+    {
+        const int mc4 = tid & 63, mrow = tid >> 6;           // a wave = one row per pass, its lanes the row's 64 float4
+        const int K0 = P.layer[0].K, cmax = ((K0 + 3) & ~3) - 4;
+        const int c = 4 * mc4;
+        long long src[4];
+        v4f v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) src[i] = min(r0 + mrow + 8 * i, hi - 1);
+        if (P.x_idx) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) src[i] = P.x_idx[src[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = gi_load4_raw(P.X + src[i] * P.ldx, c, cmax);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v4f w = v[i];
+            const bool rv = mrow + 8 * i < nvalid;
+            w.x = (rv && c < K0) ? w.x : 0.f; w.y = (rv && c + 1 < K0) ? w.y : 0.f;
+            w.z = (rv && c + 2 < K0) ? w.z : 0.f; w.w = (rv && c + 3 < K0) ? w.w : 0.f;
+            v[i] = w;
+            float m = fmaxf(fmaxf(fabsf(w.x), fabsf(w.y)), fmaxf(fabsf(w.z), fabsf(w.w)));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));      // the row's largest magnitude
+            float s_, i_;
+            gx_scale(m, s_, i_);
+            unsigned p0a, p1a, p0b, p1b;
+            gx_split2(w.x, w.y, s_, p0a, p1a);
+            gx_split2(w.z, w.w, s_, p0b, p1b);
+            const unsigned at = cr_a_off(0, c >> 3, mrow + 8 * i) + (c & 7) * 2;
+            cx_u32x2 w0 = {p0a, p0b}, w1 = {p1a, p1b};
+            *reinterpret_cast<cx_u32x2*>(Ah + at) = w0;
+            *reinterpret_cast<cx_u32x2*>(Ah + CR_PLANE + at) = w1;
+            if (lane == 0) red[0][mrow + 8 * i] = m;         // (red[1..7] = 0: row_scale_from_lds takes the maximum)
+        }
+        if (wid > 0 && lane < CR_ROWS) red[wid][lane] = 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    __syncthreads();                        // the A planes and the row maxima are in LDS (and every plain load has landed)
+    row_scale_from_lds();
+    dma_tile(0); dma_tile(1); dma_tile(2);
+
+    // ---- main loop over the weight tiles: the four-slot ring of gi_chain_x2_kernel, three tiles in flight ------
+#define GI_CHAIN_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    int l = 0, kt = 0, nk = (P.layer[0].K + CX_KT - 1) / CX_KT, lN = P.layer[0].N;
+    int since_epi = 3;
+    for (int s = 0; s < T; ++s) {
+        if (__builtin_amdgcn_readfirstlane(since_epi) < 3) { GI_CHAIN_WAIT(44); } else { GI_CHAIN_WAIT(4); }
+        since_epi = __builtin_amdgcn_readfirstlane(since_epi + 1);
+        dma_tile(s + 3);
+        const int slot = s & (CX_RING - 1);
+        if (swid * 32 < __builtin_amdgcn_readfirstlane(lN)) {
+            read_frags(slot, kt);
+            __builtin_amdgcn_sched_barrier(0);
+            mma();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        kt = __builtin_amdgcn_readfirstlane(kt + 1);
+        if (kt == __builtin_amdgcn_readfirstlane(nk)) {       // layer done
+            epilogue(l);
+            since_epi = 0;
+            l = __builtin_amdgcn_readfirstlane(l + 1);
+            if (l < L) {
+                kt = 0;
+                nk = __builtin_amdgcn_readfirstlane((P.layer[l].K + CX_KT - 1) / CX_KT);
+                lN = __builtin_amdgcn_readfirstlane(P.layer[l].N);
+            }
+        }
+    }
+#undef GI_CHAIN_WAIT
+    __syncthreads();
+    }
+}
+
 int validate_chain(const gi_chain_params& p) {
     if (p.nlayers < 1 || p.nlayers > GI_CHAIN_MAXL || !p.X || p.rows < 0) return GI_EINVAL;
     if (p.ngroups < 1 || p.ngroups > GI_MAX_GROUPS) return GI_EINVAL;
@@ -961,7 +1224,10 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
         a.dev_tiles = 1; a.tile_rows_dev = chains[0].tile_rows_dev;
     }
     const bool x2 = chains[0].x2_wamax != nullptr;
-    if (x2) { big = false; h = CX_ROWS; }                  // (bounded too: 64-row blocks, the device-side height is not used)
+    const bool x2r = x2 && chains[0].x2_rows32 != 0;       // the row-independent 32-row variant
+    for (int c = 0; c < nchains; ++c)
+        if ((chains[c].x2_rows32 != 0) != (chains[0].x2_rows32 != 0)) return GI_EINVAL;
+    if (x2) { big = false; h = x2r ? CR_ROWS : CX_ROWS; }  // (bounded too: fixed block height, the device-side height is not used)
     if (big) h = 2 * CH_ROWS;
     a.tile_rows = h;
     for (int c = 0; c < nchains; ++c) {
@@ -973,7 +1239,7 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
             a.tile_off[c][g] = t;
             if (!bounded) t += gi_cdiv(p.ngroups > 1 ? p.group_rows[g] : p.rows, h);
         }
-        if (bounded) t = gi_cdiv(p.rows, x2 ? CX_ROWS : CH_ROWS) + p.ngroups;
+        if (bounded) t = gi_cdiv(p.rows, x2 ? (x2r ? CR_ROWS : CX_ROWS) : CH_ROWS) + p.ngroups;
         a.tile_off[c][p.ngroups] = t;
         total += t;
         for (int l = 0; l < p.nlayers; ++l)
@@ -1004,7 +1270,10 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
     // pure weight-stream latency, nothing else wants the CUs' LDS — take the three-slot ring: one more tile in flight)
     static const int ring3_small = getenv("GI_CHAIN_RING3_SMALL") ? atoi(getenv("GI_CHAIN_RING3_SMALL")) : 0;
     const bool ring2 = !big && g_chain_cfg.ring != 3 && !(total <= ring3_small);
-    if (x2) {
+    if (x2r) {
+        if (chains[0].backward) hipLaunchKernelGGL((gi_chain_x2r_kernel<true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((gi_chain_x2r_kernel<false>), grid, block, 0, st, a);
+    } else if (x2) {
         if (chains[0].backward) hipLaunchKernelGGL((gi_chain_x2_kernel<true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((gi_chain_x2_kernel<false>), grid, block, 0, st, a);
     } else if (big) {

@@ -77,7 +77,7 @@ class ChainParams(C.Structure):
     _fields_ = [("layer", ChainLayer * CHAIN_MAXL), ("nlayers", ci), ("X", vp), ("ldx", ci),
                 ("x_idx", vp), ("grp_off", vp), ("ngroups", ci), ("group_rows", ci * GI_MAX_GROUPS),
                 ("rows", ci), ("backward", ci), ("image", vp), ("image_stride", cll), ("skip_flag", vp),
-                ("tile_rows_dev", vp), ("x2_wamax", vp)]
+                ("tile_rows_dev", vp), ("x2_wamax", vp), ("x2_rows32", ci)]
 
 
 class ReduceDesc(C.Structure):

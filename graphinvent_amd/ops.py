@@ -512,7 +512,7 @@ def ws_view(ws: torch.Tensor, dims, graph: "CompactGraph", name: str, rows: int,
     return ws[off.value:off.value + rows * ld.value].view(rows, ld.value)
 
 
-def mlp_chain(chains, backward=False, x2=False):
+def mlp_chain(chains, backward=False, x2=False, rows32=False):
     """gi_mlp_chain (x2: the fp16x2 variant — amax cells for the weights are allocated here, gi_mlp_chain_pack fills
     them and writes the two-plane image).  chains: list (1 or 2) of dicts with keys
     X, x_idx (or None), grp_off (int32 tensor [G+1] or None), group_rows (host ints), rows,
@@ -547,6 +547,7 @@ def mlp_chain(chains, backward=False, x2=False):
         for c, spec in zip(arr, chains):
             images.append(torch.empty(c.nlayers * c.ngroups, L.AMAX_WORDS, dtype=torch.float32, device=spec["X"].device))
             c.x2_wamax = images[-1].data_ptr()
+            c.x2_rows32 = 1 if rows32 else 0                # the row-independent 32-row variant (gi_chain_params.x2_rows32)
     for c, spec in zip(arr, chains):       # packed weight images (kept alive until the launch is queued)
         n = lib.gi_mlp_chain_image_floats(C.byref(c))
         if n < 0:

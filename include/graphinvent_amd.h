@@ -326,6 +326,12 @@ typedef struct {
                                              the fp32 chain, which is why gi_ggnn_forward keeps that one and only the
                                              backward's dZ chains run this way).  Pack and launch must agree; a
                                              bounded launch walks 64-row blocks (the value behind tile_rows_dev is unused) */
+    int x2_rows32;                        /* with x2_wamax: != 0 = the ROW-INDEPENDENT fp16x2 chain — 32-row blocks, every row
+                                             of the activation tile scaled by its OWN power of two (the product is formed
+                                             transposed, so that a lane holds one row: its maximum is an in-register
+                                             reduction), outputs staged through LDS and stored as whole rows.  A row's
+                                             result depends on the row and the weights only, bit for bit, like the fp32
+                                             chain's: what gi_ggnn_forward uses.  Same packed image as the 64-row variant. */
 } gi_chain_params;
 
 /* The kernel streams the weights as a pre-packed image (one linear stream of 32 KB LDS tile images per

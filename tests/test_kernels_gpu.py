@@ -444,7 +444,7 @@ def test_gemm_forward_gather_and_groups(gemm_grid):
     assert rel(Y[:, :N], ref) < 2e-5
 
 
-def _chain_case(sizes, off, seed, two=False, x2=False, in_scale=1.0):
+def _chain_case(sizes, off, seed, two=False, x2=False, in_scale=1.0, rows32=False):
     """Resident-activation MLP chain (gi_mlp_chain) against fp64 torch, forward and dZ chain: grouped
     rows (ragged, an empty group, a 1-row group), gathered input, widths that are not multiples of 4
     or 32, every hidden activation / dZ buffer checked, nothing written outside [rows, N]."""
@@ -471,7 +471,7 @@ def _chain_case(sizes, off, seed, two=False, x2=False, in_scale=1.0):
                           layers=[dict(W=[dev(w) for w in Ws[c][l]], bias=[dev(b) for b in bs[c][l]],
                                        out=bufs[l], K=sizes[l], N=sizes[l + 1])
                                   for l in range(len(sizes) - 1)]))
-    ops.mlp_chain(specs, backward=False, x2=x2)
+    ops.mlp_chain(specs, backward=False, x2=x2, rows32=rows32)
     refs = []
     for c in range(nchains):
         acts = []
@@ -504,7 +504,7 @@ def _chain_case(sizes, off, seed, two=False, x2=False, in_scale=1.0):
         bspecs.append(dict(X=dev(dZ), x_idx=None, grp_off=dev(offt), group_rows=rows_g, rows=E,
                            layers=layers))
         bouts.append((dZ, douts))
-    ops.mlp_chain(bspecs, backward=True, x2=x2)
+    ops.mlp_chain(bspecs, backward=True, x2=x2, rows32=rows32)
     for c in range(nchains):
         dZ, douts = bouts[c]
         z = dZ[:, :sizes[-1]].double()
@@ -552,6 +552,55 @@ def test_mlp_chain_fp16x2_forward_and_dz_chain(sizes, off, in_scale):
     _chain_case(sizes, off, seed=sum(sizes), x2=True, in_scale=in_scale)
     if in_scale == 1.0:
         _chain_case(sizes, off, seed=sum(sizes) + 1, two=True, x2=True)
+
+
+@pytest.mark.parametrize("in_scale", [1.0, 1e-4, 3e3])
+@pytest.mark.parametrize("sizes,off", [
+    ((128, 250, 250, 250, 250, 128), [0, 600, 600, 777]),       # bench config, middle group empty
+    ((100, 250, 250, 250, 250, 100), [0, 33, 34, 131]),         # reference default dims
+    ((100, 250, 250, 250, 250, 100), [0, 1000, 1001, 2500]),    # many 32-row blocks per group, ragged tails
+    ((16, 24, 24, 12), [0, 5, 7, 8]),                           # tiny config
+    ((37, 256, 7, 130), [0, 64]),                               # one group, awkward widths
+    ((128, 100), [0, 31, 95]),                                  # single layer
+])
+def test_mlp_chain_fp16x2_row_independent_variant(sizes, off, in_scale):
+    """gi_chain_params.x2_rows32 (round 5): 32-row blocks, every ROW scaled by its own power of two, the product formed
+    transposed so that a lane holds one row — the same fp64 reference and the same 3e-5 as the other two chain
+    kernels, forward and dZ chain, magnitudes 1 / 1e-4 / 3e3, one and two chains per launch."""
+    _chain_case(sizes, off, seed=sum(sizes), x2=True, in_scale=in_scale, rows32=True)
+    if in_scale == 1.0:
+        _chain_case(sizes, off, seed=sum(sizes) + 1, two=True, x2=True, rows32=True)
+
+
+def test_mlp_chain_fp16x2_rows32_is_bitwise_row_independent():
+    """What the FORWARD needs of its chain (pass-0 row cache, blocking == host-sync-free, tape == no tape): a row's
+    outputs depend on the row and the weights only, bit for bit — whichever rows share its block, whatever their
+    magnitudes.  The same rows run (a) in their original order, (b) permuted, with every other row multiplied by 1e4
+    so that each block's companions change completely; the 64-row per-block variant is NOT invariant (asserted, so that
+    the test would notice if it were handed the wrong kernel)."""
+    g = torch.Generator().manual_seed(3)
+    sizes, E = (128, 250, 250, 128), 500
+    X = torch.randn(E, 128, generator=g)
+    Ws = [(torch.randn(o, i, generator=g) / i ** 0.5).to(DEV) for i, o in zip(sizes, sizes[1:])]
+    bs = [(torch.randn(o, generator=g) * 0.3).to(DEV) for o in sizes[1:]]
+
+    def run(Xin, rows32):
+        n = Xin.shape[0]
+        outs = [torch.zeros(n, ops.r4(o), device=DEV) for o in sizes[1:]]
+        spec = dict(X=Xin.to(DEV), x_idx=None, grp_off=None, group_rows=[n], rows=n,
+                    layers=[dict(W=[Ws[l]], bias=[bs[l]], out=outs[l], K=sizes[l], N=sizes[l + 1]) for l in range(3)])
+        ops.mlp_chain([spec], backward=False, x2=True, rows32=rows32)
+        torch.cuda.synchronize()
+        return [o.cpu() for o in outs]
+
+    perm = torch.randperm(E, generator=g)
+    big = torch.zeros(2 * E, 128)
+    big[0::2] = X[perm]
+    big[1::2] = X * 1e4                                         # loud neighbours in every block
+    for rows32, expect_equal in ((True, True), (False, False)):
+        a, b = run(X, rows32), run(big, rows32)
+        same = all(torch.equal(b[l][0::2], a[l][perm]) for l in range(3))
+        assert same == expect_equal, (rows32, same)
 
 
 @pytest.mark.parametrize("tile_rows", [33, 34, 36])

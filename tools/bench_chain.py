@@ -62,7 +62,8 @@ def main(U=8400, sizes=(128, 250, 250, 250, 250, 128), reps=30, backward=False):
 
     flops = 2.0 * U * sum(a * b for a, b in zip(sizes, sizes[1:]))
     x2 = bool(int(os.environ.get("BENCH_CHAIN_X2", "0")))          # the fp16x2 kernel (its pack launches are timed along:
-    t_chain = timed(lambda: ops.mlp_chain([spec], backward=backward, x2=x2))   # use rocprofv3 --stats for the kernel alone)
+    r32 = bool(int(os.environ.get("BENCH_CHAIN_ROWS32", "0")))     # ... its row-independent 32-row variant
+    t_chain = timed(lambda: ops.mlp_chain([spec], backward=backward, x2=x2 or r32, rows32=r32))   # use rocprofv3 --stats for the kernel alone)
     t_layer = timed(layered)
     print(f"{'backward' if backward else 'forward '} U={U}: chain {t_chain:7.1f} us ({flops / t_chain / 1e6:5.1f} TF/s)"
           f"   layer-by-layer {t_layer:7.1f} us ({flops / t_layer / 1e6:5.1f} TF/s)", flush=True)
