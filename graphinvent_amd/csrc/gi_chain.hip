@@ -579,17 +579,20 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
     const int l31 = lane & 31, lhi = lane >> 5;
     const int T = cx_tiles(P);                               // steps = 16-deep weight tiles of the whole chain
 
-    // weight stream: tile t of this group -> ring slot t % 4; a wave moves 2 of a tile's 16 one-KB pieces
+    // weight stream: tile t of this group -> ring slot t % 4.  WAVE-PRIVATE (round 5, see gi_chain_x2r_kernel): a wave
+    // multiplies output columns 32 wid .. 32 wid + 31, i.e. it needs 2 KB of every tile — [plane][k half][its 32
+    // columns][8 halves] — and fetches exactly those (lanes 0-31: k half 0, lanes 32-63: k half 1; one instruction per
+    // plane) into its own 2 KB of the slot, in fragment order: no barrier in the k loop.
     const float* const img = P.image + (long long)g * (P.image_stride ? P.image_stride
                                                                       : (long long)chain_tiles(P) * CH_TILE) +
-                             (swid * 2) * 256 + lane * 4;
-    const unsigned bs_lds = (unsigned)(uintptr_t)Bs + (unsigned)(swid * 2) * 1024u;
+                             (lhi * CH_W + swid * 32 + l31) * 4;
+    const unsigned bs_lds = (unsigned)(uintptr_t)Bs + (unsigned)swid * 2048u;
     auto dma_tile = [&](int t) {
         t = min(t, T - 1);                                   // past the end: re-fetch the last tile (fixed load count)
         const float* src = img + (long long)t * CX_TILE;
         const unsigned dst = bs_lds + (unsigned)(t & (CX_RING - 1)) * (unsigned)(CX_TILE * 4);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) lds_dma_1k(src + q * 256, dst + q * 1024u);
+        for (int q = 0; q < 2; ++q) lds_dma_1k(src + q * (2 * CH_W * 4), dst + q * 1024u);      // plane q
     };
     // 1 / scale of a layer's weights (this bond type): layer 0 here, layer l + 1 at the end of epilogue l
     auto w_inv_scale = [&](int l) {
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
                 a[rb][pl] = *reinterpret_cast<const gx_f16x8*>(Ah + cx_a_off(pl, kt * 2 + lhi, rb * 32 + l31));
-            b[pl] = *reinterpret_cast<const gx_f16x8*>(bt + cx_b_off(pl, lhi, wid * 32 + l31));
+            b[pl] = *reinterpret_cast<const gx_f16x8*>(bt + wid * 2048 + pl * 1024 + lane * 16);
         }
     };
     auto mma = [&](const gx_f16x8 (&a)[2][2], const gx_f16x8 (&b)[2]) {
@@ -632,32 +635,40 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
         }
     };
 
+    // (backward) the stored activations a layer's epilogue needs are requested a whole k loop ahead — behind the
+    // previous epilogue / the prologue — instead of at its start (an HBM round trip in front of every epilogue)
+    float av[2][16];
+    auto prefetch_acts = [&](int l) {
+        if (!BWD || l >= L || !P.layer[l].act) return;
+        const gi_chain_layer& Ly = P.layer[l];
+        const int col = wid * 32 + l31;
+        const int coff = col < Ly.N ? 4 * col : 0x40000000;
+        if (args.dbg & 1) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) av[rb][r] = 1.f;
+            return;
+        }
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(Ly.act + (long long)r0 * Ly.ldact), 0, nvalid * Ly.ldact * 4, 0x00020000);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                av[rb][r] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(ra, row * Ly.ldact * 4 + coff, 0, 0));
+            }
+    };
+
     auto epilogue = [&](int l) {
         const gi_chain_layer& Ly = P.layer[l];
         const int N = Ly.N, ldo = Ly.ldo;
         const int col = wid * 32 + l31;
         const bool col_ok = col < N;
         const int coff = col_ok ? 4 * col : 0x40000000;
-        float av[2][16];
         const bool dselu = BWD && Ly.act != nullptr;
-        if (dselu && (args.dbg & 1)) {
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) av[rb][r] = 1.f;
-        } else
-        if (dselu) {
-            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(Ly.act + (long long)r0 * Ly.ldact), 0, nvalid * Ly.ldact * 4, 0x00020000);
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    av[rb][r] = __builtin_bit_cast(
-                        float, __builtin_amdgcn_raw_buffer_load_b32(ra, row * Ly.ldact * 4 + coff, 0, 0));
-                }
-        }
         const float bv = BWD ? 0.f : Ly.bias[g][col_ok ? col : N - 1];
         float v[2][16];
         float m = 0.f;
@@ -701,6 +712,7 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
                     *reinterpret_cast<unsigned*>(Ah + CX_PLANE + at) = p1;
                 }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the new planes are written (no barrier in the k loop)
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(Ly.out + (long long)r0 * ldo), 0, nvalid * ldo * 4, 0x00020000);
         if (!(args.dbg & 2))
@@ -717,6 +729,7 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
         if (l + 1 < L) ib = w_inv_scale(l + 1);             // (lands under the next layer's k loop)
+        prefetch_acts(l + 1);
     };
 
     // ---- prologue: the 64 input rows -> scale -> two fp16 planes in LDS (zero beyond K0) ---------------
@@ -756,6 +769,7 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
             *reinterpret_cast<cx_u32x2*>(Ah + at) = w0;
             *reinterpret_cast<cx_u32x2*>(Ah + CX_PLANE + at) = w1;
         }
+        prefetch_acts(0);
     }
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -765,17 +779,17 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
     dma_tile(0); dma_tile(1); dma_tile(2);
 
     // ---- main loop over the weight tiles: four-slot ring, three tiles in flight -----------------------------
-    // Step s: wait for THIS wave's two pieces of tile s, barrier (=> the whole tile is there and every wave is done with
-    // tile s - 1, whose slot tile s + 3 goes to), start the DMA of tile s + 3, multiply tile s.  Loads complete in issue
-    // order: right before the wait of step s the youngest four are tiles s + 1 and s + 2, so "at most 4 outstanding"
-    // means tile s is complete.  An epilogue drains everything (vmcnt(0) in every wave + barrier: tiles up to s + 3 are
-    // in LDS) and leaves <= 36 stores in flight; the three steps after it need no load to complete, and waiting for the
-    // stores (older than the 2 + 2 loads issued since) would only stall: "at most 44".
-#define GI_CHAIN_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    // Step s: wait for THIS wave's share of tile s (nobody else reads it) and for its own fragment reads of tile s - 1,
+    // whose slot tile s + 3 goes to; start the DMA of tile s + 3; multiply tile s.  Loads complete in issue order: right
+    // before the wait of step s the youngest four are tiles s + 1 and s + 2, so "at most 4 outstanding" means tile s is
+    // complete.  An epilogue drains everything (vmcnt(0): tiles up to s + 3 are in LDS) and leaves <= 36 stores and (dZ
+    // chain) the next layer's 32 activation loads in flight; the three steps after it need no load to complete, and
+    // waiting for those (older than the 2 + 2 loads issued since) would only stall: "at most 60" (the counter's range).
+#define GI_CHAIN_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory")
     int l = 0, kt = 0, nk = (P.layer[0].K + CX_KT - 1) / CX_KT, lN = P.layer[0].N;
     int since_epi = 3;
     for (int s = 0; s < T; ++s) {
-        if (__builtin_amdgcn_readfirstlane(since_epi) < 3) { GI_CHAIN_WAIT(44); } else { GI_CHAIN_WAIT(4); }
+        if (__builtin_amdgcn_readfirstlane(since_epi) < 3) { GI_CHAIN_WAIT(60); } else { GI_CHAIN_WAIT(4); }
         since_epi = __builtin_amdgcn_readfirstlane(since_epi + 1);
         dma_tile(s + 3);
         const int slot = s & (CX_RING - 1);
@@ -808,11 +822,14 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
 
 // ======================================================================================================
 // fp16x2 chain, ROW-INDEPENDENT variant (gi_chain_params.x2_rows32; round 5): 32 rows per workgroup, every ROW of the
-// activation tile scaled by its own power of two.  tools/stream_lab + the phase breakdown of the 64-row kernel
-// (profiles/r05/x2_chain_breakdown.txt) showed that the chain kernels are NOT bound by their weight stream (the bare
-// stream of a 1.15 MB image per workgroup: 12.5 us on half the CUs, 19 us on all) but by phases that do not overlap —
-// in the fp32 kernel 31 us of v_mfma_f32_32x32x2_f32 per launch, in the 64-row fp16x2 kernel five 4-us epilogues and
-// the fragment-read -> MFMA chain of every step.  This variant
+// activation tile scaled by its own power of two.  What the measurements of this round say about the chain kernels
+// (profiles/r05: stream_lab.txt, x2_chain_breakdown.txt, chain_scaling.txt, x2r_chain_breakdown.txt):
+//   * one launch takes the same time with 8 workgroups as with 256 (fp32 49 -> 58 us, fp16x2 64-row 51 -> 64 us): a
+//     workgroup is a DEPENDENT CHAIN of phases — 72 k steps of (wait for the tile, fragment reads, MFMAs), five
+//     epilogues of ~1000 instructions per wave — and nothing on the chip is saturated: not the L2 (the bare stream of a
+//     1.15 MB image per workgroup is 12.5 us), not the matrix pipe (3 - 6 us), not HBM;
+//   * so the levers are instructions and waits per workgroup, and a SECOND workgroup per CU to fill the gaps.
+// This variant
 //   * transposes the product: C^T = W . A^T — the MFMA's A operand is the WEIGHT fragment (32 output channels x 16 k),
 //     its B operand the ACTIVATION fragment (16 k x 32 rows); same fragments, same LDS reads, operands swapped.  A lane
 //     then holds ONE row (lane & 31) and 16 output channels of it: the row's largest magnitude is 16 in-register maxima,
@@ -821,23 +838,32 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
 //     constant in the epilogue;
 //   * so every row's result depends on nothing but the row and the weights: bit-independent of which rows share its
 //     block — usable by gi_ggnn_forward (pass-0 row cache, blocking == host-sync-free, tape == no tape);
+//   * WAVE-PRIVATE weight rings: a wave multiplies output channels 32 wid .. 32 wid + 31, i.e. it needs 2 KB of every
+//     16 KB tile, and fetches exactly those bytes itself, in fragment order, into its own part of the ring slot.  No
+//     wave reads what another loaded: the k loop has NO barrier (the 64-row kernel has 72), only the wave's own vmcnt;
+//   * biases of all layers sit in LDS from the prologue on (16 dependent global loads per lane and layer before);
+//     the backward's stored activations are requested a whole k loop ahead of the epilogue that needs them;
 //   * writes the next layer's planes as 8-byte pieces, 32 lanes = 32 adjacent rows of one k chunk: conflict-free by
-//     construction; stages the fp32 outputs through LDS and stores whole rows (16 bytes per lane, coalesced);
-//   * 3 MFMAs (v_mfma_f32_32x32x16_f16) per wave and 16-deep step: 3.2 us of matrix-pipe time per launch.
-constexpr int CR_ROWS = 32;
-constexpr int CR_PLANE = 32 * CR_ROWS * 16;                 // bytes of one activation plane (16 KB)
+//     construction;
+//   * DUAL = false (launches of at most one workgroup per CU): four-slot ring, three tiles in flight; fp32 outputs
+//     staged through LDS and stored as whole rows — 138 KB of LDS, one workgroup per CU, 43 us at 256 workgroups;
+//   * DUAL = true (more row blocks than CUs): TWO workgroups per CU — two-slot ring, one tile in flight per workgroup,
+//     no staging tile (a lane stores its row's 4 x 16 bytes per layer itself, the L2 merges them into lines), 73 KB of
+//     LDS and <= 128 VGPRs.  264 blocks: 56 us against 76 (two rounds); 512: 64 against 82; 1024: 121 against 159.
+constexpr int CR_ROWS = 32;                                 // rows of the (transposed) MFMA tile
 constexpr int CR_OLD = CH_W + 4;                            // floats per row of the output staging tile
-__device__ __forceinline__ unsigned cr_a_off(int plane, int chunk, int row) {
-    return (unsigned)(plane * CR_PLANE + (chunk * CR_ROWS + row) * 16);
-}
 
-template <bool BWD>
-__global__ __launch_bounds__(512) void gi_chain_x2r_kernel(const ChainArgs args) {
-    __shared__ __attribute__((aligned(16))) unsigned char Ah[2 * CR_PLANE];
-    __shared__ __attribute__((aligned(1024))) float Bs[CX_RING * CX_TILE];
-    __shared__ __attribute__((aligned(16))) float Os[CR_ROWS * CR_OLD];
+template <bool BWD, bool DUAL>
+__global__ __launch_bounds__(512, DUAL ? 4 : 1) void gi_chain_x2r_kernel(const ChainArgs args) {
+    constexpr int PLANE = 32 * CR_ROWS * 16;                // bytes of one activation plane: [k chunk 32][row][8 halves]
+    constexpr int RING = DUAL ? 2 : CX_RING;
+    __shared__ __attribute__((aligned(16))) unsigned char Ah[2 * PLANE];
+    __shared__ __attribute__((aligned(1024))) float Bs[RING * CX_TILE];
+    __shared__ __attribute__((aligned(16))) float Os[DUAL ? 4 : CR_ROWS * CR_OLD];
     __shared__ float red[8][CR_ROWS];                       // per wave: max |new activation| of every row
+    __shared__ __attribute__((aligned(16))) float bias_s[BWD ? 4 : GI_CHAIN_MAXL * CH_W];   // every layer's bias (0 beyond N)
     typedef unsigned cx_u32x2 __attribute__((ext_vector_type(2)));
+    auto a_off = [](int plane, int chunk, int row) { return (unsigned)(plane * PLANE + (chunk * CR_ROWS + row) * 16); };
     if (args.c[0].skip_flag && *args.c[0].skip_flag != 0) return;
     for (int bid = blockIdx.x; bid < args.chain_off[args.nchains]; bid += gridDim.x) {
     const int id = chain_block_id(args, bid);
@@ -866,18 +892,21 @@ __global__ __launch_bounds__(512) void gi_chain_x2r_kernel(const ChainArgs args)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int swid = __builtin_amdgcn_readfirstlane(wid);
     const int l31 = lane & 31, lhi = lane >> 5;
+    const int nb = wid * 32 + 4 * lhi;                       // this lane's output channels: nb + 8 j + {0..3}, j < 4
     const int T = cx_tiles(P);
 
+    // this wave's 2 KB of a tile: [plane][k half][its 32 channels][8 halves]; lanes 0-31 fetch k half 0, lanes 32-63
+    // k half 1 (512 contiguous bytes each), one instruction per plane, into the wave's own 2 KB of the ring slot
     const float* const img = P.image + (long long)g * (P.image_stride ? P.image_stride
                                                                       : (long long)chain_tiles(P) * CH_TILE) +
-                             (swid * 2) * 256 + lane * 4;
-    const unsigned bs_lds = (unsigned)(uintptr_t)Bs + (unsigned)(swid * 2) * 1024u;
+                             (lhi * CH_W + swid * 32 + l31) * 4;
+    const unsigned bs_lds = (unsigned)(uintptr_t)Bs + (unsigned)swid * 2048u;
     auto dma_tile = [&](int t) {
         t = min(t, T - 1);                                   // past the end: re-fetch the last tile (fixed load count)
         const float* src = img + (long long)t * CX_TILE;
-        const unsigned dst = bs_lds + (unsigned)(t & (CX_RING - 1)) * (unsigned)(CX_TILE * 4);
+        const unsigned dst = bs_lds + (unsigned)(t & (RING - 1)) * (unsigned)(CX_TILE * 4);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) lds_dma_1k(src + q * 256, dst + q * 1024u);
+        for (int q = 0; q < 2; ++q) lds_dma_1k(src + q * (2 * CH_W * 4), dst + q * 1024u);      // plane q
     };
     auto w_inv_scale = [&](int l) {
         float s_, inv_;
@@ -886,14 +915,14 @@ __global__ __launch_bounds__(512) void gi_chain_x2r_kernel(const ChainArgs args)
     };
     float ib = w_inv_scale(0);
     f32x16 acc;
-    float sa = 1.f, ia = 1.f;                               // scale of THIS LANE's row (l31) in the LDS planes, and its inverse
+    float sa = 1.f, ia = 1.f;                                // scale of THIS LANE's row (l31) in the LDS planes, its inverse
     gx_f16x8 af[2], wf[2];                                   // activation / weight fragment, [plane]
     auto read_frags = [&](int slot, int kt) {
         const unsigned char* bt = reinterpret_cast<const unsigned char*>(Bs) + slot * (CX_TILE * 4);
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
-            af[pl] = *reinterpret_cast<const gx_f16x8*>(Ah + cr_a_off(pl, kt * 2 + lhi, l31));
-            wf[pl] = *reinterpret_cast<const gx_f16x8*>(bt + cx_b_off(pl, lhi, wid * 32 + l31));
+            af[pl] = *reinterpret_cast<const gx_f16x8*>(Ah + a_off(pl, kt * 2 + lhi, l31));
+            wf[pl] = *reinterpret_cast<const gx_f16x8*>(bt + wid * 2048 + pl * 1024 + lane * 16);
         }
     };
     auto mma = [&]() {                                       // C^T: w2 a1 + w1 a2 + w1 a1 (smallest terms first)
@@ -901,120 +930,137 @@ __global__ __launch_bounds__(512) void gi_chain_x2r_kernel(const ChainArgs args)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0], af[1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0], af[0], acc, 0, 0, 0);
     };
-    // the row scale of this lane from the 8 waves' row maxima (after a barrier behind their red[] writes)
-    auto row_scale_from_lds = [&]() {
-        float m = red[0][l31];
+    // the scale of one row from the 8 waves' row maxima (after a barrier behind their red[] writes)
+    auto row_scale_from_lds = [&](int row, float& s_, float& i_) {
+        float m = red[0][row];
 #pragma unroll
-        for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w][l31]);
-        gx_scale(m, sa, ia);
+        for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w][row]);
+        gx_scale(m, s_, i_);
+    };
+    // (backward) the stored activations a layer's epilogue needs — this lane's row, its channels — are requested a
+    // whole k loop ahead, behind the previous epilogue / the prologue: an HBM round trip is most of a 3-us epilogue
+    v4f ypre[4];
+    auto prefetch_acts = [&](int l) {
+        if (!BWD || l >= L || !P.layer[l].act) return;
+        const gi_chain_layer& Ly = P.layer[l];
+        const float* arow = Ly.act + (long long)(r0 + (l31 < nvalid ? l31 : 0)) * Ly.ldact;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ypre[j] = gi_load4_raw(arow, nb + 8 * j, ((Ly.N + 3) & ~3) - 4);
     };
 
+    // a layer's epilogue.  Part one: x <- the new activations of this lane's row, their largest magnitude to red[]
     auto epilogue = [&](int l) {
         const gi_chain_layer& Ly = P.layer[l];
         const int N = Ly.N, ldo = Ly.ldo;
-        // this lane: row l31 of the block, output channels nb + 8 j + {0..3}, j = 0..3
-        const int nb = wid * 32 + 4 * lhi;
-        const bool row_ok = l31 < nvalid;
+        const bool live = l31 < nvalid;
         const bool dselu = BWD && Ly.act != nullptr;
-        v4f fac[4], bv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { fac[j] = v4f{1.f, 1.f, 1.f, 1.f}; bv[j] = v4f{0.f, 0.f, 0.f, 0.f}; }
-        if (dselu) {                                        // selu'(through the stored activation) of this row's channels
-            const float* arow = Ly.act + (long long)(r0 + (row_ok ? l31 : 0)) * Ly.ldact;
-            const int cmax = ((N + 3) & ~3) - 4;
+        v4f x[4];
+        {
+            const float iab = ia * ib;
+            float m = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const v4f y = gi_load4_raw(arow, nb + 8 * j, cmax);
-                fac[j] = v4f{gi_selu_grad(y.x), gi_selu_grad(y.y), gi_selu_grad(y.z), gi_selu_grad(y.w)};
+                v4f fac = {1.f, 1.f, 1.f, 1.f}, bv = {0.f, 0.f, 0.f, 0.f};
+                if (dselu) fac = v4f{gi_selu_grad(ypre[j].x), gi_selu_grad(ypre[j].y), gi_selu_grad(ypre[j].z), gi_selu_grad(ypre[j].w)};
+                if (!BWD) bv = *reinterpret_cast<const v4f*>(&bias_s[l * CH_W + nb + 8 * j]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[4 * j + e] * iab + bv[e];
+                    if (!BWD) v = gi_selu(v);
+                    if (dselu) v *= fac[e];
+                    v = (nb + 8 * j + e < N && live) ? v : 0.f;      // zero = the next layer's k padding / rows beyond the block
+                    x[j][e] = v;
+                    m = fmaxf(m, fabsf(v));
+                }
             }
+            m = fmaxf(m, __shfl_xor(m, 32));                 // both channel halves of the row
+            if (lhi == 0) red[wid][l31] = m;
         }
-        if (!BWD) {
-            const float* brow = Ly.bias[g];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const int n = nb + 8 * j + e; bv[j][e] = brow[n < N ? n : N - 1]; }
-        }
-        const float iab = ia * ib;
-        v4f x[4];
-        float m = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = acc[4 * j + e] * iab + bv[j][e];
-                if (!BWD) v = gi_selu(v);
-                if (dselu) v *= fac[j][e];
-                v = (nb + 8 * j + e < N && row_ok) ? v : 0.f;        // zero = the next layer's k padding / rows beyond the block
-                x[j][e] = v;
-                m = fmaxf(m, fabsf(v));
-            }
-        m = fmaxf(m, __shfl_xor(m, 32));                     // both channel halves of the row
-        if (lhi == 0) red[wid][l31] = m;
-        // Drain this wave's DMA queue, then: every wave is past its last read of the activation planes, and the eight
-        // row-maximum vectors are in LDS.
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (l + 1 < L) {                                     // next layer's A^T operand: this row's own scale, split, in place
-            row_scale_from_lds();
+        // Every wave is past its last read of the activation planes, and the eight row-maximum vectors are in LDS.
+        // (!DUAL: this wave's DMA queue drains here, which is what the vmcnt arithmetic of the k loop assumes.)
+        if (DUAL) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // Part two: the row's planes for the next layer (its own scale), its outputs
+        const bool more = l + 1 < L && !(args.dbg & 8);      // (lab bit 8: no rewrite of the activation planes)
+        if (more) {
+            row_scale_from_lds(l31, sa, ia);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 unsigned p0a, p1a, p0b, p1b;
                 gx_split2(x[j].x, x[j].y, sa, p0a, p1a);
                 gx_split2(x[j].z, x[j].w, sa, p0b, p1b);
-                const unsigned at = cr_a_off(0, (wid * 32 + 8 * j) >> 3, l31) + 8 * lhi;
+                const unsigned at = a_off(0, wid * 4 + j, l31) + 8 * lhi;
                 cx_u32x2 w0 = {p0a, p0b}, w1 = {p1a, p1b};
                 *reinterpret_cast<cx_u32x2*>(Ah + at) = w0;
-                *reinterpret_cast<cx_u32x2*>(Ah + CR_PLANE + at) = w1;
+                *reinterpret_cast<cx_u32x2*>(Ah + PLANE + at) = w1;
             }
         }
+        if (!DUAL) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<v4f*>(&Os[l31 * CR_OLD + nb + 8 * j]) = x[j];
-        __syncthreads();                                     // the output tile is staged (and the new planes are written)
-        {   // whole rows to HBM: 16 lanes x 16 bytes per row and pass, 4 passes over the 256 columns
-            const int row = tid >> 4, c0 = 4 * (tid & 15);
-            float* orow = Ly.out + (long long)(r0 + row) * ldo;
-            if (row < nvalid) {
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<v4f*>(&Os[l31 * CR_OLD + nb + 8 * j]) = x[j];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the new planes are written (the output tile is staged)
+        if (!(args.dbg & 16)) {
+            if (DUAL) {                                      // the lane's 4 x 4 channels of its row straight to HBM
+                if (live) {
+                    float* orow = Ly.out + (long long)(r0 + l31) * ldo;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = c0 + 64 * q;
-                    const v4f v = *reinterpret_cast<const v4f*>(&Os[row * CR_OLD + c]);
-                    if (c + 3 < N) *reinterpret_cast<v4f_u*>(orow + c) = v;
-                    else {
-                        if (c < N) orow[c] = v.x;
-                        if (c + 1 < N) orow[c + 1] = v.y;
-                        if (c + 2 < N) orow[c + 2] = v.z;
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = nb + 8 * j;
+                        if (c + 3 < N) *reinterpret_cast<v4f_u*>(orow + c) = x[j];
+                        else {
+                            if (c < N) orow[c] = x[j].x;
+                            if (c + 1 < N) orow[c + 1] = x[j].y;
+                            if (c + 2 < N) orow[c + 2] = x[j].z;
+                        }
+                    }
+                }
+            } else {                                         // whole rows: 16 lanes x 16 bytes per row, 4 passes over the 256 columns
+                const int row = tid >> 4, c0 = 4 * (tid & 15);
+                if (row < nvalid) {
+                    float* orow = Ly.out + (long long)(r0 + row) * ldo;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = c0 + 64 * q;
+                        const v4f v = *reinterpret_cast<const v4f*>(&Os[row * CR_OLD + c]);
+                        if (c + 3 < N) *reinterpret_cast<v4f_u*>(orow + c) = v;
+                        else {
+                            if (c < N) orow[c] = v.x;
+                            if (c + 1 < N) orow[c + 1] = v.y;
+                            if (c + 2 < N) orow[c + 2] = v.z;
+                        }
                     }
                 }
             }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        if (l + 1 < L) ib = w_inv_scale(l + 1);             // (lands under the next layer's k loop)
+        if (more) ib = w_inv_scale(l + 1);                  // (lands under the next layer's k loop)
+        prefetch_acts(l + 1);
     };
 
-    // ---- prologue: the 32 input rows -> per-row scale -> two fp16 planes in LDS (zero beyond K0) --------
+    // ---- prologue: the input rows -> per-row scale -> two fp16 planes in LDS (zero beyond K0); the biases ------------
     {
         const int mc4 = tid & 63, mrow = tid >> 6;           // a wave = one row per pass, its lanes the row's 64 float4
         const int K0 = P.layer[0].K, cmax = ((K0 + 3) & ~3) - 4;
         const int c = 4 * mc4;
-        long long src[4];
-        v4f v[4];
+        constexpr int NP = CR_ROWS / 8;
+        long long src[NP];
+        v4f v[NP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) src[i] = min(r0 + mrow + 8 * i, hi - 1);
+        for (int i = 0; i < NP; ++i) src[i] = min(r0 + mrow + 8 * i, hi - 1);
         if (P.x_idx) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) src[i] = P.x_idx[src[i]];
+            for (int i = 0; i < NP; ++i) src[i] = P.x_idx[src[i]];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = gi_load4_raw(P.X + src[i] * P.ldx, c, cmax);
+        for (int i = 0; i < NP; ++i) v[i] = gi_load4_raw(P.X + src[i] * P.ldx, c, cmax);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NP; ++i) {
             v4f w = v[i];
             const bool rv = mrow + 8 * i < nvalid;
             w.x = (rv && c < K0) ? w.x : 0.f; w.y = (rv && c + 1 < K0) ? w.y : 0.f;
             w.z = (rv && c + 2 < K0) ? w.z : 0.f; w.w = (rv && c + 3 < K0) ? w.w : 0.f;
-            v[i] = w;
             float m = fmaxf(fmaxf(fabsf(w.x), fabsf(w.y)), fmaxf(fabsf(w.z), fabsf(w.w)));
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));      // the row's largest magnitude
@@ -1023,37 +1069,55 @@ __global__ __launch_bounds__(512) void gi_chain_x2r_kernel(const ChainArgs args)
             unsigned p0a, p1a, p0b, p1b;
             gx_split2(w.x, w.y, s_, p0a, p1a);
             gx_split2(w.z, w.w, s_, p0b, p1b);
-            const unsigned at = cr_a_off(0, c >> 3, mrow + 8 * i) + (c & 7) * 2;
+            const unsigned at = a_off(0, c >> 3, mrow + 8 * i) + (c & 7) * 2;
             cx_u32x2 w0 = {p0a, p0b}, w1 = {p1a, p1b};
             *reinterpret_cast<cx_u32x2*>(Ah + at) = w0;
-            *reinterpret_cast<cx_u32x2*>(Ah + CR_PLANE + at) = w1;
+            *reinterpret_cast<cx_u32x2*>(Ah + PLANE + at) = w1;
             if (lane == 0) red[0][mrow + 8 * i] = m;         // (red[1..7] = 0: row_scale_from_lds takes the maximum)
         }
         if (wid > 0 && lane < CR_ROWS) red[wid][lane] = 0.f;
+        if (!BWD)
+            for (int i = tid; i < L * CH_W; i += 512) {
+                const int li = i / CH_W, n = i % CH_W;
+                bias_s[i] = n < P.layer[li].N ? P.layer[li].bias[g][n] : 0.f;
+            }
+        prefetch_acts(0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    __syncthreads();                        // the A planes and the row maxima are in LDS (and every plain load has landed)
-    row_scale_from_lds();
-    dma_tile(0); dma_tile(1); dma_tile(2);
+    __syncthreads();                        // the A planes, the row maxima and the biases are in LDS (and every plain load has landed)
+    row_scale_from_lds(l31, sa, ia);
+    dma_tile(0);
+    if (!DUAL) { dma_tile(1); dma_tile(2); }
 
-    // ---- main loop over the weight tiles: the four-slot ring of gi_chain_x2_kernel, three tiles in flight ------
-#define GI_CHAIN_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    // ---- main loop over the weight tiles.  !DUAL: four slots, three tiles in flight; DUAL: two slots, one in flight —
+    // tile s + 1 is requested when the wave's fragment reads of tile s - 1 have returned, and lands while tile s is
+    // multiplied; the CU's other workgroup covers what that leaves open.  No barrier in here: the rings are
+    // wave-private, the activation planes are read-only until the epilogue.
+    // vmcnt arithmetic (!DUAL): the epilogue drained the queue, so the three steps behind it find their tiles landed
+    // and must not wait for the epilogue's stores (vmcnt counts them too): vmcnt(44) = no wait; from then on at most the
+    // two youngest tiles (4 loads) may be outstanding.
+#define GI_CHAIN_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory")
     int l = 0, kt = 0, nk = (P.layer[0].K + CX_KT - 1) / CX_KT, lN = P.layer[0].N;
     int since_epi = 3;
     for (int s = 0; s < T; ++s) {
-        if (__builtin_amdgcn_readfirstlane(since_epi) < 3) { GI_CHAIN_WAIT(44); } else { GI_CHAIN_WAIT(4); }
+        if (DUAL) { GI_CHAIN_WAIT(0); }
+        else if (__builtin_amdgcn_readfirstlane(since_epi) < 3) { GI_CHAIN_WAIT(44); } else { GI_CHAIN_WAIT(4); }
         since_epi = __builtin_amdgcn_readfirstlane(since_epi + 1);
-        dma_tile(s + 3);
-        const int slot = s & (CX_RING - 1);
+        if (!(args.dbg & 1)) dma_tile(s + (DUAL ? 1 : 3));
+        const int slot = s & (RING - 1);
         if (swid * 32 < __builtin_amdgcn_readfirstlane(lN)) {
-            read_frags(slot, kt);
+            if (!(args.dbg & 2)) read_frags(slot, kt);
             __builtin_amdgcn_sched_barrier(0);
-            mma();
+            if (!(args.dbg & 4)) mma();
             __builtin_amdgcn_sched_barrier(0);
         }
         kt = __builtin_amdgcn_readfirstlane(kt + 1);
         if (kt == __builtin_amdgcn_readfirstlane(nk)) {       // layer done
+            if (args.dbg & 32) {                              // (lab: no epilogue at all)
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __syncthreads();
+            } else
             epilogue(l);
             since_epi = 0;
             l = __builtin_amdgcn_readfirstlane(l + 1);
@@ -1253,7 +1317,7 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
     {
         static const bool xcd = !(getenv("GI_CHAIN_XCD") && atoi(getenv("GI_CHAIN_XCD")) == 0);
         a.remap = (xcd && !bounded && total >= 16) ? 1 : 0;
-#ifdef GI_CHAIN_X2_LAB      // (make FLAGS+=-DGI_CHAIN_X2_LAB: the breakdown of profiles/r05/x2_chain_breakdown.txt; results WRONG with a mask)
+#ifdef GI_CHAIN_X2_LAB      // (make EXTRA=-DGI_CHAIN_X2_LAB: the breakdowns of profiles/r05/x2_chain_breakdown.txt, x2r_chain_breakdown.txt; results WRONG with a mask)
         a.dbg = getenv("GI_DBG_X2") ? atoi(getenv("GI_DBG_X2")) : 0;
 #endif
     }
@@ -1271,8 +1335,17 @@ extern "C" int gi_mlp_chain(const gi_chain_params* chains, int nchains, void* st
     static const int ring3_small = getenv("GI_CHAIN_RING3_SMALL") ? atoi(getenv("GI_CHAIN_RING3_SMALL")) : 0;
     const bool ring2 = !big && g_chain_cfg.ring != 3 && !(total <= ring3_small);
     if (x2r) {
-        if (chains[0].backward) hipLaunchKernelGGL((gi_chain_x2r_kernel<true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((gi_chain_x2r_kernel<false>), grid, block, 0, st, a);
+        // more row blocks than CUs: two workgroups per CU (GI_CHAIN_X2R_DUAL=0 / 1: never / always — measurements)
+        static const int dual_env = getenv("GI_CHAIN_X2R_DUAL") ? atoi(getenv("GI_CHAIN_X2R_DUAL")) : -1;
+        const bool dual = dual_env >= 0 ? dual_env != 0 : total > ncu;
+        const dim3 gridx(bounded ? std::min(total, dual ? 2 * ncu : ncu) : total);
+        if (chains[0].backward) {
+            if (dual) hipLaunchKernelGGL((gi_chain_x2r_kernel<true, true>), gridx, block, 0, st, a);
+            else hipLaunchKernelGGL((gi_chain_x2r_kernel<true, false>), gridx, block, 0, st, a);
+        } else {
+            if (dual) hipLaunchKernelGGL((gi_chain_x2r_kernel<false, true>), gridx, block, 0, st, a);
+            else hipLaunchKernelGGL((gi_chain_x2r_kernel<false, false>), gridx, block, 0, st, a);
+        }
     } else if (x2) {
         if (chains[0].backward) hipLaunchKernelGGL((gi_chain_x2_kernel<true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((gi_chain_x2_kernel<false>), grid, block, 0, st, a);

@@ -46,8 +46,6 @@ __device__ float b3_sink[256];                    // where out-of-range lanes of
 constexpr int B3_BM = 128, B3_BN = 128, B3_BK = 16;
 constexpr int B3_ROWB = B3_BK * 2;                 // bytes of one row of one plane of a k tile (16 bf16)
 constexpr int B3_PLANE = 128 * B3_ROWB;            // 4 KB
-constexpr int B3_OPER = 3 * B3_PLANE;              // 12 KB
-constexpr int B3_BUF = 2 * B3_OPER;                // A + B of one k tile: 24 KB
 
 __host__ __device__ inline int b3_r32(int k) { return (k + 31) & ~31; }
 
@@ -119,7 +117,7 @@ struct B3Batch {
 template <int EPI, bool APL, bool BFP, bool X2 = false>
 __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
     constexpr int NP = X2 ? 2 : 3;
-    constexpr int OPER = NP * B3_PLANE, BUF = 2 * OPER;           // (B3_OPER / B3_BUF with NP planes)
+    constexpr int OPER = NP * B3_PLANE, BUF = 2 * OPER;           // one operand of a k tile (NP planes), A + B
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lhi = lane >> 5;

@@ -109,6 +109,7 @@ struct Ws {
     // forward and backward layouts; 0 floats when the stack does not fit the chain kernel
     long long img_f[2], img_b[2], img_f_n[2], img_b_n[2], img_b_stride[2];
     long long chain_amax[2];            // fp16x2 chains: amax cells of the stack's weights, [layer][bond type] (gi_chain_params.x2_wamax)
+    long long img_fx[2], chain_amax_f[2];   // the same for the FORWARD chain of the message rows (gi_chain_params.x2_rows32)
     // AlphaDropout training mode: the workspace is allocated twice; float i of the second half holds
     // the backward factor d y / d z of activation i of the first (0: mode off)
     long long fshift;
@@ -145,6 +146,13 @@ bool bf3_enabled() {
 static bool chain_x2_enabled(bool call_x2) {
     static const int v = getenv("GI_CHAIN_X2") ? atoi(getenv("GI_CHAIN_X2")) : 1;
     return v != 0 && call_x2 && x2_enabled() && bf3_enabled();
+}
+// ... and, round 5, the FORWARD chains of the message rows through the row-independent kernel (gi_chain_x2r_kernel:
+// every row scaled by itself, so the properties listed above hold bit for bit — tests/test_kernels_gpu.py).  The
+// pass-0 rows keep the fp32 chain (a dozen workgroups; and what the row cache stores).  GI_CHAIN_FWD_X2=0: fp32.
+static bool chain_fwd_x2_enabled(bool call_x2) {
+    static const int v = getenv("GI_CHAIN_FWD_X2") ? atoi(getenv("GI_CHAIN_FWD_X2")) : 1;
+    return v != 0 && chain_x2_enabled(call_x2);
 }
 bool bf3_wide(const Mlp& q, int l) { return q.fan_in(l) >= BF3_MIN_WIDTH && q.fan_out(l) >= BF3_MIN_WIDTH; }
 bool bf3_layer_ok(const Mlp& q, int l) { return bf3_enabled() && bf3_wide(q, l); }
@@ -271,6 +279,8 @@ void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
             w.img_f[k] = take(w.img_f_n[k], 1);
             w.img_b[k] = take(w.img_b_n[k], 1);
             w.chain_amax[k] = take((long long)GI_AMAX_WORDS * GI_CHAIN_MAXL * GI_MAX_GROUPS, 1);
+            w.img_fx[k] = take(w.img_f_n[k], 1);               // fp16x2 forward image (message rows; pass 0 stays fp32)
+            w.chain_amax_f[k] = take((long long)GI_AMAX_WORDS * GI_CHAIN_MAXL * GI_MAX_GROUPS, 1);
         }
     }
     w.fshift = d.dropout ? gi_r4l(o) : 0;
@@ -396,6 +406,8 @@ struct Run {
     float* img_f[2] = {nullptr, nullptr};   // packed chain weight images [msg, energy stack]; null: the
     float* img_b[2] = {nullptr, nullptr};   // stack runs layer by layer
     float* chain_amax[2] = {nullptr, nullptr};   // != null: the stack's chains run as fp16x2 (gi_chain.hip), images packed that way
+    float* img_fx[2] = {nullptr, nullptr};       // != null: the forward chain of the MESSAGE rows runs as row-independent fp16x2
+    float* chain_amax_f[2] = {nullptr, nullptr}; // (gi_chain_params.x2_rows32) from this image / these cells; pass-0 rows: img_f
     long long img_b_stride[2] = {0, 0};
     const struct Mlp* eatt0 = nullptr;      // identifies the energy stacks (second image)
     bool hold_kicks = false;                // no weight-gradient launches on the side stream for now
@@ -1079,6 +1091,11 @@ void chain_fwd_params(gi_chain_params& c, const Run& r, float* ws, const Mlp* ml
     chain_groups(c, g, rows);
     if (r.dims) c.tile_rows_dev = r.dims + g.dim_slot;
     c.x2_wamax = r.chain_amax[mlps == r.eatt0 ? 1 : 0];
+    if (r.img_fx[mlps == r.eatt0 ? 1 : 0] && g.dim_slot == 1) {   // message rows: one row's result depends on that row only,
+        c.image = r.img_fx[mlps == r.eatt0 ? 1 : 0];              // so blocking and bounded launches agree bit for bit
+        c.x2_wamax = r.chain_amax_f[mlps == r.eatt0 ? 1 : 0];
+        c.x2_rows32 = 1;
+    }
     c.skip_flag = r.skip;
     for (int l = 0; l < L; ++l) {
         gi_chain_layer& y = c.layer[l];
@@ -1102,6 +1119,10 @@ int chain_bwd_params(gi_chain_params& c, const Run& r, float* ws, const Mlp* mlp
     c.image_stride = r.img_b_stride[mlps == r.eatt0 ? 1 : 0];
     c.X = Zlast; c.ldx = ldz; c.x_idx = nullptr; c.backward = 1;
     c.x2_wamax = r.chain_amax[mlps == r.eatt0 ? 1 : 0];
+    {   // (measurement aid) GI_CHAIN_BWD_X2R=1: the dZ chains through the row-independent kernel too
+        static const bool bwd_x2r = getenv("GI_CHAIN_BWD_X2R") && atoi(getenv("GI_CHAIN_BWD_X2R"));
+        if (bwd_x2r && c.x2_wamax) c.x2_rows32 = 1;
+    }
     chain_groups(c, g, rows);
     int n = 0;
     for (int l = L - 1; l >= 0; --l) {
@@ -1503,6 +1524,41 @@ extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* pa
                     r.chk(rp.rc);
                 }
     }
+    // fp16x2 image of the message rows' forward chain (+ its weights through the guard): first on the side stream,
+    // the main stream needs it after the pass-0 stage
+    hipEvent_t fx_ready = nullptr;
+    if ((d.passes > 1 || w.D0 <= 0) && d.passes > 0 && E > 0 && !r.drop && chain_fwd_x2_enabled(r.x2)) {
+        for (int k = 0; k < (attn ? 2 : 1); ++k)
+            if (w.img_f_n[k] > 0) {
+                const Mlp* mlps = k ? m.eatt : m.msg;
+                Run rp = r;
+                rp.st = prep;
+                rp.chain_amax[k] = ws + w.chain_amax_f[k];
+                chain_pack(rp, mlps, d.Fe, false, ws + w.img_fx[k]);
+                r.chk(rp.rc);
+                r.img_fx[k] = ws + w.img_fx[k];
+                r.chain_amax_f[k] = ws + w.chain_amax_f[k];
+                if (r.guard && r.ok()) {                      // output channels / input columns below the per-tensor range
+                    gi_absmax_desc wd[GI_ABSMAX_MAX];
+                    int n = 0;
+                    const int L = mlps[0].layers();
+                    for (int l = 0; l < L; ++l)
+                        for (int t = 0; t < d.Fe; ++t) {
+                            wd[n].x = r.P[mlps[t].w(l)]; wd[n].rows = mlps[0].fan_out(l); wd[n].cols = mlps[0].fan_in(l);
+                            wd[n].ld = wd[n].cols;
+                            wd[n].out = r.chain_amax_f[k] + ((long long)l * d.Fe + t) * GI_AMAX_WORDS;
+                            if (++n == GI_ABSMAX_MAX || (l == L - 1 && t == d.Fe - 1)) {
+                                r.chk(gi_x2_weight_guard(wd, n, r.guard + 1, r.guard_host, prep));
+                                n = 0;
+                            }
+                        }
+                }
+            }
+        if (side_stream && r.img_fx[0]) {
+            fx_ready = fside.next();
+            r.chk((int)hipEventRecord(fx_ready, fside.st));
+        }
+    }
     bf3_prepare(r, m, ws, w, false, R, BF3_DO_AMAX, prep);
     if (side_stream) {
         cells_ready = fside.next();
@@ -1519,6 +1575,7 @@ extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* pa
     for (int p = 0; p < d.passes; ++p) {
         const float* hx = ws + w.hx[p];
         r.pass = p;
+        if (fx_ready && p == (w.D0 > 0 ? 1 : 0)) r.chk((int)hipStreamWaitEvent(r.st, fx_ready, 0));
         if (p == 0 && p0cache) {
             r.chk(gi_p0_cache_lookup(gfix, d.B, d.N, d.Fe, p0c, attn ? 2 : 1, ws + w.m[0],
                                      attn ? ws + w.een[0] : nullptr, w.ldM, r.st));

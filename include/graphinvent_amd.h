@@ -28,12 +28,16 @@
  *       GI_X2=0                 those launches as three bf16 planes (six products) instead of two scaled fp16 planes
  *                               (three products, GI_GEMM_X2; gi_x2_enable); also puts the dZ chains back on fp32
  *       GI_CHAIN_X2=0           only the dZ chains back on the fp32 chain kernel (gi_chain_params.x2_wamax unused)
+ *       GI_CHAIN_FWD_X2=0       only the FORWARD chains of the message rows back on the fp32 chain kernel (default: the
+ *                               row-independent fp16x2 kernel, gi_chain_params.x2_rows32; the pass-0 rows are fp32 always)
  *       GI_GEMM_LOG=<file>      one line per GEMM launch (tools/gemm_launch_report.py)
  *     and measurement aids that pick between kernels / schedules that compute the same thing (the A/B files under
  *     profiles/r04 name them): GI_B3P, GI_B3V, GI_B3P_ALL, GI_B3P_STREAM, GI_B3V_GROUPED (which 16-bit-pipe kernel),
  *     GI_B3W_MSG, GI_B3W_G (message-stack / graph-level weight gradients on the 16-bit pipe below their size
  *     thresholds), GI_P0_LAYERWISE (pass 0 without the chain kernel), GI_CHAIN_BWD64 (64-row fp32 chain blocks in
  *     the backward), GI_CHAIN_XCD (0: the chain kernels' row blocks in dispatch order instead of the XCD-aware one),
+ *     GI_CHAIN_X2R_DUAL (0 / 1: the row-independent fp16x2 chain never / always as two workgroups per CU; default: when a
+ *     launch has more row blocks than CUs), GI_CHAIN_BWD_X2R (1: the dZ chains through that kernel too),
  *     GI_WGRAD_BIAS (1: weight gradients whose input width is a multiple of 64 get their bias gradient from a separate
  *     launch instead of a "ones" column that costs a column of tiles — measured a tie, off by default), GI_WGRAD_TN /
  *     GI_WGRAD_WGS (tile class / workgroups per problem of the fp32-MFMA weight gradients), GI_SEGSUM_U (outputs per
@@ -331,7 +335,9 @@ typedef struct {
                                              transposed, so that a lane holds one row: its maximum is an in-register
                                              reduction), outputs staged through LDS and stored as whole rows.  A row's
                                              result depends on the row and the weights only, bit for bit, like the fp32
-                                             chain's: what gi_ggnn_forward uses.  Same packed image as the 64-row variant. */
+                                             chain's: what gi_ggnn_forward uses for the message rows.  Same packed image as
+                                             the 64-row variant.  Launches of more row blocks than the chip has CUs run
+                                             two workgroups per CU (a build of the kernel with half the LDS). */
 } gi_chain_params;
 
 /* The kernel streams the weights as a pre-packed image (one linear stream of 32 KB LDS tile images per

@@ -572,6 +572,14 @@ def test_mlp_chain_fp16x2_row_independent_variant(sizes, off, in_scale):
         _chain_case(sizes, off, seed=sum(sizes) + 1, two=True, x2=True, rows32=True)
 
 
+def test_mlp_chain_fp16x2_rows32_two_workgroups_per_cu():
+    """More row blocks than CUs -> the launcher takes the two-workgroups-per-CU build of the kernel (two-slot weight ring,
+    outputs stored from registers): 264 and 700 blocks in three ragged groups, forward and dZ chain, one and two chains."""
+    _chain_case((128, 250, 250, 128), [0, 2816, 5632, 8448], seed=8448, x2=True, rows32=True)
+    _chain_case((100, 250, 250, 250, 250, 100), [0, 15000, 15001, 22400], seed=22400, x2=True, rows32=True)
+    _chain_case((128, 250, 128), [0, 7000, 7000, 8600], seed=8600, two=True, x2=True, rows32=True)
+
+
 def test_mlp_chain_fp16x2_rows32_is_bitwise_row_independent():
     """What the FORWARD needs of its chain (pass-0 row cache, blocking == host-sync-free, tape == no tape): a row's
     outputs depend on the row and the weights only, bit for bit — whichever rows share its block, whatever their
@@ -601,6 +609,13 @@ def test_mlp_chain_fp16x2_rows32_is_bitwise_row_independent():
         a, b = run(X, rows32), run(big, rows32)
         same = all(torch.equal(b[l][0::2], a[l][perm]) for l in range(3))
         assert same == expect_equal, (rows32, same)
+    # ... and of the build of the kernel: the same rows inside a 9 000-row input (282 blocks: two workgroups per CU)
+    a = run(X, True)
+    huge = torch.randn(9000, 128, generator=g) * 30
+    at = torch.randperm(9000, generator=g)[:E]
+    huge[at] = X
+    b = run(huge, True)
+    assert all(torch.equal(b[l][at], a[l]) for l in range(3))
 
 
 @pytest.mark.parametrize("tile_rows", [33, 34, 36])

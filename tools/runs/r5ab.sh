@@ -1,0 +1,6 @@
+cd /root/repo; export TMPDIR=/tmp; O=/root/repo/gpurun_out/r5ab; mkdir -p $O
+tools/ab.sh -r 3 -o $O/ab_default "dual" "ext GI_CHAIN_X2R_DUAL=0" "fwd_fp32 GI_CHAIN_FWD_X2=0" > /dev/null 2>&1; cat $O/ab_default/summary.txt
+tools/ab.sh -r 2 -o $O/ab_zinc -a "--shape zinc --batch 1000 --steps 10 --warmup 3" "dual" "ext GI_CHAIN_X2R_DUAL=0" "fwd_fp32 GI_CHAIN_FWD_X2=0" > /dev/null 2>&1; cat $O/ab_zinc/summary.txt
+tools/ab.sh -r 2 -o $O/ab_chembl -a "--model attggnn --shape chembl --batch 250 --steps 10 --warmup 3" "dual_forced GI_CHAIN_FWD_X2=2" "fwd_fp32" > /dev/null 2>&1; cat $O/ab_chembl/summary.txt
+cd /tmp
+for v in "1 1"; do set -- $v; rm -rf /tmp/cb; BENCH_CHAIN_X2=$1 BENCH_CHAIN_ROWS32=$2 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/cb -o b -- python /root/repo/tools/bench_chain.py both > /dev/null 2>&1; echo "x2=$1 rows32=$2:"; grep 'gi_chain' /tmp/cb/*kernel_stats.csv | grep -v pack | sed 's/(anonymous namespace):://g' | cut -d, -f1-4; done > $O/chain_variants.txt 2>&1; cat $O/chain_variants.txt

@@ -1,0 +1,8 @@
+cd /root/repo; export TMPDIR=/tmp; O=/root/repo/gpurun_out/r5ac; mkdir -p $O
+timeout 900 python -m pytest tests/test_kernels_gpu.py -q -x -k "chain" > $O/k.log 2>&1; tail -5 $O/k.log
+cd /tmp
+for v in "1 0" "1 1"; do set -- $v; rm -rf /tmp/cb; BENCH_CHAIN_X2=$1 BENCH_CHAIN_ROWS32=$2 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/cb -o b -- python /root/repo/tools/bench_chain.py both > /dev/null 2>&1; echo "x2=$1 rows32=$2:"; grep 'gi_chain' /tmp/cb/*kernel_stats.csv | grep -v pack | sed 's/(anonymous namespace):://g;s/"void //' | awk -F'"' '{print $1 $2 $3}' | cut -c1-90; done > $O/chain_variants.txt 2>&1; cat $O/chain_variants.txt
+cd /root/repo
+tools/ab.sh -r 3 -o $O/ab_default "default" "bwd_x2r GI_CHAIN_BWD_X2R=1" > /dev/null 2>&1; cat $O/ab_default/summary.txt
+tools/ab.sh -r 2 -o $O/ab_zinc -a "--shape zinc --batch 1000 --steps 10 --warmup 3" "default" "bwd_x2r GI_CHAIN_BWD_X2R=1" > /dev/null 2>&1; cat $O/ab_zinc/summary.txt
+tools/ab.sh -r 2 -o $O/ab_chembl -a "--model attggnn --shape chembl --batch 250 --steps 10 --warmup 3" "default" "bwd_x2r GI_CHAIN_BWD_X2R=1" > /dev/null 2>&1; cat $O/ab_chembl/summary.txt
