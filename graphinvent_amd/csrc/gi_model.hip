@@ -147,9 +147,8 @@ static bool chain_x2_enabled(bool call_x2) {
     static const int v = getenv("GI_CHAIN_X2") ? atoi(getenv("GI_CHAIN_X2")) : 1;
     return v != 0 && call_x2 && x2_enabled() && bf3_enabled();
 }
-// ... and, round 5, the FORWARD chains of the message rows through the row-independent kernel (gi_chain_x2r_kernel:
-// every row scaled by itself, so the properties listed above hold bit for bit — tests/test_kernels_gpu.py).  The
-// pass-0 rows keep the fp32 chain (a dozen workgroups; and what the row cache stores).  GI_CHAIN_FWD_X2=0: fp32.
+// ... and, round 5, the FORWARD chains through the row-independent kernel (gi_chain_x2r_kernel: every row scaled by
+// itself, so the properties listed above hold bit for bit — tests/test_kernels_gpu.py).  GI_CHAIN_FWD_X2=0: fp32.
 static bool chain_fwd_x2_enabled(bool call_x2) {
     static const int v = getenv("GI_CHAIN_FWD_X2") ? atoi(getenv("GI_CHAIN_FWD_X2")) : 1;
     return v != 0 && chain_x2_enabled(call_x2);
@@ -1091,8 +1090,8 @@ void chain_fwd_params(gi_chain_params& c, const Run& r, float* ws, const Mlp* ml
     chain_groups(c, g, rows);
     if (r.dims) c.tile_rows_dev = r.dims + g.dim_slot;
     c.x2_wamax = r.chain_amax[mlps == r.eatt0 ? 1 : 0];
-    if (r.img_fx[mlps == r.eatt0 ? 1 : 0] && g.dim_slot == 1) {   // message rows: one row's result depends on that row only,
-        c.image = r.img_fx[mlps == r.eatt0 ? 1 : 0];              // so blocking and bounded launches agree bit for bit
+    if (r.img_fx[mlps == r.eatt0 ? 1 : 0]) {                      // one row's result depends on that row only: blocking and
+        c.image = r.img_fx[mlps == r.eatt0 ? 1 : 0];              // bounded launches, cached and recomputed pass-0 rows agree bit for bit
         c.x2_wamax = r.chain_amax_f[mlps == r.eatt0 ? 1 : 0];
         c.x2_rows32 = 1;
     }
@@ -1119,7 +1118,8 @@ int chain_bwd_params(gi_chain_params& c, const Run& r, float* ws, const Mlp* mlp
     c.image_stride = r.img_b_stride[mlps == r.eatt0 ? 1 : 0];
     c.X = Zlast; c.ldx = ldz; c.x_idx = nullptr; c.backward = 1;
     c.x2_wamax = r.chain_amax[mlps == r.eatt0 ? 1 : 0];
-    {   // (measurement aid) GI_CHAIN_BWD_X2R=1: the dZ chains through the row-independent kernel too
+    {   // (measurement aid) GI_CHAIN_BWD_X2R=1: the dZ chains through the row-independent kernel too (measured: +0.6 % at
+        // the headline batch, -0.7 % ZINC shape, +1.4 % ChEMBL shape; for the pass-0 rows only: ties — profiles/r05/ab)
         static const bool bwd_x2r = getenv("GI_CHAIN_BWD_X2R") && atoi(getenv("GI_CHAIN_BWD_X2R"));
         if (bwd_x2r && c.x2_wamax) c.x2_rows32 = 1;
     }
@@ -1498,7 +1498,16 @@ extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* pa
         for (int k = 0; k < (attn ? 2 : 1); ++k)
             if (w.img_f_n[k] > 0) {
                 r.img_f[k] = ws + w.img_f[k];
-                chain_pack(r, k ? m.eatt : m.msg, d.Fe, false, r.img_f[k]);
+                if (!r.drop && chain_fwd_x2_enabled(r.x2)) {   // the row-independent fp16x2 chain: its image instead of the fp32 one
+                    Run rp = r;
+                    rp.chain_amax[k] = ws + w.chain_amax_f[k];
+                    chain_pack(rp, k ? m.eatt : m.msg, d.Fe, false, ws + w.img_fx[k]);
+                    r.chk(rp.rc);
+                    r.img_fx[k] = ws + w.img_fx[k];
+                    r.chain_amax_f[k] = ws + w.chain_amax_f[k];
+                } else {
+                    chain_pack(r, k ? m.eatt : m.msg, d.Fe, false, r.img_f[k]);
+                }
             }
     // Everything else that depends on the weights only goes to the side stream when there is one: the amax cells of
     // the fp16x2 layers (needed by the readout, hundreds of microseconds from here) and — GI_RUN_PREPACK_BWD — the
@@ -1524,41 +1533,25 @@ extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* pa
                     r.chk(rp.rc);
                 }
     }
-    // fp16x2 image of the message rows' forward chain (+ its weights through the guard): first on the side stream,
-    // the main stream needs it after the pass-0 stage
-    hipEvent_t fx_ready = nullptr;
-    if ((d.passes > 1 || w.D0 <= 0) && d.passes > 0 && E > 0 && !r.drop && chain_fwd_x2_enabled(r.x2)) {
+    // the forward chains' weights through the fp16x2 guard (output channels / input columns below the per-tensor range)
+    if (r.guard && r.ok())
         for (int k = 0; k < (attn ? 2 : 1); ++k)
-            if (w.img_f_n[k] > 0) {
+            if (r.img_fx[k]) {
                 const Mlp* mlps = k ? m.eatt : m.msg;
-                Run rp = r;
-                rp.st = prep;
-                rp.chain_amax[k] = ws + w.chain_amax_f[k];
-                chain_pack(rp, mlps, d.Fe, false, ws + w.img_fx[k]);
-                r.chk(rp.rc);
-                r.img_fx[k] = ws + w.img_fx[k];
-                r.chain_amax_f[k] = ws + w.chain_amax_f[k];
-                if (r.guard && r.ok()) {                      // output channels / input columns below the per-tensor range
-                    gi_absmax_desc wd[GI_ABSMAX_MAX];
-                    int n = 0;
-                    const int L = mlps[0].layers();
-                    for (int l = 0; l < L; ++l)
-                        for (int t = 0; t < d.Fe; ++t) {
-                            wd[n].x = r.P[mlps[t].w(l)]; wd[n].rows = mlps[0].fan_out(l); wd[n].cols = mlps[0].fan_in(l);
-                            wd[n].ld = wd[n].cols;
-                            wd[n].out = r.chain_amax_f[k] + ((long long)l * d.Fe + t) * GI_AMAX_WORDS;
-                            if (++n == GI_ABSMAX_MAX || (l == L - 1 && t == d.Fe - 1)) {
-                                r.chk(gi_x2_weight_guard(wd, n, r.guard + 1, r.guard_host, prep));
-                                n = 0;
-                            }
+                gi_absmax_desc wd[GI_ABSMAX_MAX];
+                int n = 0;
+                const int L = mlps[0].layers();
+                for (int l = 0; l < L; ++l)
+                    for (int t = 0; t < d.Fe; ++t) {
+                        wd[n].x = r.P[mlps[t].w(l)]; wd[n].rows = mlps[0].fan_out(l); wd[n].cols = mlps[0].fan_in(l);
+                        wd[n].ld = wd[n].cols;
+                        wd[n].out = r.chain_amax_f[k] + ((long long)l * d.Fe + t) * GI_AMAX_WORDS;
+                        if (++n == GI_ABSMAX_MAX || (l == L - 1 && t == d.Fe - 1)) {
+                            r.chk(gi_x2_weight_guard(wd, n, r.guard + 1, r.guard_host, prep));
+                            n = 0;
                         }
-                }
+                    }
             }
-        if (side_stream && r.img_fx[0]) {
-            fx_ready = fside.next();
-            r.chk((int)hipEventRecord(fx_ready, fside.st));
-        }
-    }
     bf3_prepare(r, m, ws, w, false, R, BF3_DO_AMAX, prep);
     if (side_stream) {
         cells_ready = fside.next();
@@ -1575,7 +1568,6 @@ extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* pa
     for (int p = 0; p < d.passes; ++p) {
         const float* hx = ws + w.hx[p];
         r.pass = p;
-        if (fx_ready && p == (w.D0 > 0 ? 1 : 0)) r.chk((int)hipStreamWaitEvent(r.st, fx_ready, 0));
         if (p == 0 && p0cache) {
             r.chk(gi_p0_cache_lookup(gfix, d.B, d.N, d.Fe, p0c, attn ? 2 : 1, ws + w.m[0],
                                      attn ? ws + w.een[0] : nullptr, w.ldM, r.st));

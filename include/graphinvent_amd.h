@@ -28,8 +28,8 @@
  *       GI_X2=0                 those launches as three bf16 planes (six products) instead of two scaled fp16 planes
  *                               (three products, GI_GEMM_X2; gi_x2_enable); also puts the dZ chains back on fp32
  *       GI_CHAIN_X2=0           only the dZ chains back on the fp32 chain kernel (gi_chain_params.x2_wamax unused)
- *       GI_CHAIN_FWD_X2=0       only the FORWARD chains of the message rows back on the fp32 chain kernel (default: the
- *                               row-independent fp16x2 kernel, gi_chain_params.x2_rows32; the pass-0 rows are fp32 always)
+ *       GI_CHAIN_FWD_X2=0       only the FORWARD chains back on the fp32 chain kernel (default: the row-independent
+ *                               fp16x2 kernel, gi_chain_params.x2_rows32)
  *       GI_GEMM_LOG=<file>      one line per GEMM launch (tools/gemm_launch_report.py)
  *     and measurement aids that pick between kernels / schedules that compute the same thing (the A/B files under
  *     profiles/r04 name them): GI_B3P, GI_B3V, GI_B3P_ALL, GI_B3P_STREAM, GI_B3V_GROUPED (which 16-bit-pipe kernel),

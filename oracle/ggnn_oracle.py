@@ -403,13 +403,18 @@ def kl_loss(output: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
 FORWARDS["AttGGNN"] = attggnn_forward
 
 
-def forward_backward(P, cfg, nodes, edges, target, model: str = "GGNN"):
+def forward_backward(P, cfg, nodes, edges, target, model: str = "GGNN", upstream=None):
     """One forward + loss + backward; returns (logits, loss, grads-by-key).  Train-step order of
-    Workflow.py:785-796 up to (not including) the optimizer."""
+    Workflow.py:785-796 up to (not including) the optimizer.  upstream != None: the gradients are J^T . upstream — the
+    backward operator applied to a GIVEN d loss / d logits instead of this evaluation's own (tests: the backward's
+    arithmetic apart from the conditioning of softmax - target on a fitted model)."""
     leaves = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in P.items())
     out = FORWARDS[model](leaves, cfg, nodes, edges)
     loss = kl_loss(out, target)
-    grads = torch.autograd.grad(loss, list(leaves.values()))
+    if upstream is not None:
+        grads = torch.autograd.grad(out, list(leaves.values()), grad_outputs=upstream.to(out.dtype))
+    else:
+        grads = torch.autograd.grad(loss, list(leaves.values()))
     return out.detach(), loss.detach(), OrderedDict(zip(leaves.keys(), grads))
 
 

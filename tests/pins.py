@@ -237,14 +237,15 @@ class MaskQuantumPin:
 
 
 def oracle_pinned(O, P, cfg, nodes, edges, target, signs: Signs, g: dict, model: str = "GGNN",
-                  mask_pin: Optional[MaskQuantumPin] = None):
+                  mask_pin: Optional[MaskQuantumPin] = None, upstream=None):
     """`O.forward_backward` in fp32 with the SELU branches of `signs` (and, with `mask_pin`, the energy
-    quanta of fully-masked graphs); returns (logits, loss, grads, flipped activations, all activations)."""
+    quanta of fully-masked graphs); returns (logits, loss, grads, flipped activations, all activations).
+    upstream: see O.forward_backward (grads = J^T . upstream)."""
     pins = OraclePins(signs, g, nodes.numpy(), edges.numpy(), model)
     O.SELU_BRANCH_HOOK = pins
     O.MASK_QUANTUM_HOOK = mask_pin
     try:
-        out, loss, grads = O.forward_backward(P, cfg, nodes, edges, target, model)
+        out, loss, grads = O.forward_backward(P, cfg, nodes, edges, target, model, upstream=upstream)
     finally:
         O.SELU_BRANCH_HOOK = None
         O.MASK_QUANTUM_HOOK = None

@@ -279,18 +279,27 @@ def _rel(a, b):
 
 
 #: What the measurement found (profiles/r05/x2_trial.txt, gpu_trained_checkpoint.log), on models fitted to a loss of
-#: 0.1-0.17 (from 6.0 / 7.4), gradient tensors' maxima between 1e-10 and 2e-2, i.e. heavy cancellation inside the sums:
-#:   GDB-13 shape  gradient as a whole (relative L2 over all tensors) 1.5e-5 from fp64 in all three modes (the fp32
-#:                 oracle: 0.8e-5); worst single tensor 3.2-3.9e-5 (oracle 1.5e-5) — with another checkpoint of the same
-#:                 recipe 1.8-2.0e-4, again the same in all three modes (the 1-output termination stack);
-#:   ZINC shape    gradient as a whole 2.5e-4 (fp16x2) / 2.5e-4 (fp32 MFMA only), the reference's own arithmetic (fp32
-#:                 oracle) 1.1e-4; worst tensor 3.3e-4 / 4.3e-4, oracle 2.2e-4.
-#: On a fitted model NO fp32 evaluation reproduces the fp64 gradient to 1e-4 any more, the reference's own included; the
-#: k-ordered MFMA accumulation chain + split-K slabs are a factor ~2 behind ATen's blocked CPU summation, and fp16x2 is
-#: NOT behind the fp32 MFMA anywhere.  The bar on a fitted model is therefore relative to the reference's own
-#: arithmetic: logits and loss 1e-4 as everywhere; the gradient as a whole within max(1e-4, 3 x the fp32 oracle's
-#: distance from fp64); the worst single tensor within 1e-4 + 3 x the fp32 oracle's worst; and fp16x2's worst tensor no
-#: further from fp64 than 1.5 x the fp32-MFMA-only mode's (test_fp16x2_is_no_further_from_fp64_than_the_fp32_mfma).
+#: 0.17-0.23 (from 6.0 / 7.4), gradient tensors' maxima between 1e-10 and 1e-1:
+#:   * On a fitted model d loss / d logits = softmax - target is a difference of nearly equal numbers: an error of 1e-6
+#:     in a logit (every fp32 evaluation has one: HIP 1-2e-6 of the largest logit in all three modes, ATen's blocked CPU
+#:     sums 1e-7) comes back multiplied by p / |p - t|.  Tensors fed by few, well-fitted outputs (the 1-output
+#:     termination stack) showed 2e-4 with one checkpoint of this recipe and 1.7e-3 with another — the same in all three
+#:     arithmetic modes, and a property of the loss, not of the backward: it depends on which weights 300 noisy steps
+#:     happened to reach.  The test therefore separates the two things:
+#:       (a) logits and loss against the fp32 and the fp64 oracle at 1e-4 as everywhere;
+#:       (b) the BACKWARD OPERATOR: HIP's gradients against J^T v of the fp64 oracle for the SAME v (the d loss / d logits
+#:           of the HIP logits), tensor by tensor, next to the fp32 oracle's own distance from fp64 for that v;
+#:       (c) end to end (each evaluation's own logits -> own gradient): the gradient as a whole, reported per tensor.
+#:   * (b), GDB-13 shape: gradient as a whole 1.0-1.1e-6 from fp64 in all three modes (the fp32 oracle: 0.7e-6); worst
+#:     single tensor 5.0e-6 fp16x2 / 6.8e-6 bf16x3 / 1.1e-5 fp32 MFMA only (oracle 4-5e-6).  ZINC shape: as a whole
+#:     1.6e-6 in both modes (oracle 1.0e-6); worst tensor 5.3e-6 fp16x2 / 6.6e-6 fp32 MFMA only (oracle 3.3e-6).  The
+#:     backward operator is at the reference's own fp32 arithmetic on a fitted model, and fp16x2 is NOT behind the fp32
+#:     MFMA anywhere.  Bars: the gradient as a whole within max(2e-5, 3 x the fp32 oracle's distance from fp64), every
+#:     single tensor within 1e-4, and fp16x2's worst tensor no further from fp64 than 1.5 x the fp32-MFMA-only mode's
+#:     (test_fp16x2_is_no_further_from_fp64_than_the_fp32_mfma).
+#:   * (c): gradient as a whole 8e-6 (GDB-13) / 6e-5 (ZINC) from the fp64 oracle's own, worst tensor 3e-5 / 8e-5 with
+#:     these checkpoints (the same in all modes; the fp32 oracle's own end-to-end distance is ~10x smaller because
+#:     ATen's logits are).  Bar: the gradient as a whole within 1e-3.
 _WORST = {}
 
 
@@ -305,8 +314,9 @@ def test_trained_checkpoint_parity_in_every_arithmetic_mode(shape, B, over, mode
     """Weights, activations and gradients of a FITTED model (300 Adam steps at lr 1e-3 on the bench batch: the loss
     halves, every weight tensor has moved) instead of an initialisation.  On the batch's live graphs: logits and loss
     1e-4 against the fp32 AND the fp64 oracle fed the same weights; every gradient tensor against the fp64 oracle's
-    autograd on the SELU branches of the HIP forward (tests/pins.py), next to the fp32 oracle's own distance from it —
-    in the fp16x2 / bf16x3-only / fp32-MFMA-only modes; the dynamic-range guard stays silent on the trained model."""
+    J^T v for the v the HIP backward was fed, on the SELU branches of the HIP forward (tests/pins.py), next to the fp32
+    oracle's own distance from it; the gradient as a whole end to end — in the fp16x2 / bf16x3-only / fp32-MFMA-only
+    modes; the dynamic-range guard stays silent on the trained model.  (Why two comparisons: the note above _WORST.)"""
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
     model, cfg, host, _, P, losses, moved = _checkpoint(shape, B, over)
     assert np.isfinite(losses).all() and losses[-1] < 0.6 * losses[0] and moved > 0.05, (losses, moved)
@@ -330,10 +340,13 @@ def test_trained_checkpoint_parity_in_every_arithmetic_mode(shape, B, over, mode
         grads, _ = mpnn.ggnn_backward_raw(tape, out, o_leaf.grad, params)
         names = [k for k, _ in model.named_parameters()]
         t = lambda x, dt: torch.from_numpy(x).to(dt)
+        v = o_leaf.grad.detach().cpu()                    # d loss / d logits at the HIP logits: what the HIP backward was fed
         o32, l32, g32, flipped, total = pins.oracle_pinned(O, P, cfg, t(n8, torch.float32), t(e8, torch.float32),
-                                                           t(a8, torch.float32), signs, g, "GGNN")
-        P64 = {k: v.double() for k, v in P.items()}
+                                                           t(a8, torch.float32), signs, g, "GGNN", upstream=v)
+        P64 = {k: v_.double() for k, v_ in P.items()}
         o64, l64, g64, _, _ = pins.oracle_pinned(O, P64, cfg, t(n8, torch.float64), t(e8, torch.float64),
+                                                 t(a8, torch.float64), signs, g, "GGNN", upstream=v.double())
+        _, _, g64_own, _, _ = pins.oracle_pinned(O, P64, cfg, t(n8, torch.float64), t(e8, torch.float64),
                                                  t(a8, torch.float64), signs, g, "GGNN")
         assert flipped < 1e-5 * total, (flipped, total)
         assert _rel(out, o32) < 1e-4 and _rel(out, o64) < 1e-4, (_rel(out, o32), _rel(out, o64))
@@ -353,10 +366,15 @@ def test_trained_checkpoint_parity_in_every_arithmetic_mode(shape, B, over, mode
         den = sum(float(g64[k].pow(2).sum()) for k in names)
         l2_hip = (sum(float((gr.double().cpu() - g64[k]).pow(2).sum()) for k, gr in zip(names, grads)) / den) ** 0.5
         l2_ref = (sum(float((g32[k].double() - g64[k]).pow(2).sum()) for k in names) / den) ** 0.5
-        print(f"[trained checkpoint, {shape}, {mode}] the gradient as a whole, relative L2 distance from fp64: HIP {l2_hip:.2e}, "
-              f"fp32 oracle {l2_ref:.2e}")
-        assert l2_hip < max(1e-4, 3 * l2_ref), (l2_hip, l2_ref)
-        assert worst[1] < 1e-4 + 3 * worst_ref[2], (worst, worst_ref)
+        den_own = sum(float(g64_own[k].pow(2).sum()) for k in names)
+        l2_e2e = (sum(float((gr.double().cpu() - g64_own[k]).pow(2).sum()) for k, gr in zip(names, grads)) / den_own) ** 0.5
+        e2e = max(((k, _rel(gr, g64_own[k])) for k, gr in zip(names, grads)), key=lambda r: r[1])
+        print(f"[trained checkpoint, {shape}, {mode}] the gradient as a whole, relative L2 distance from fp64: backward operator "
+              f"(same d loss / d logits) HIP {l2_hip:.2e}, fp32 oracle {l2_ref:.2e}; end to end (the fp64 oracle's own logits "
+              f"and gradient) HIP {l2_e2e:.2e}, its worst tensor {e2e[1]:.2e} ({e2e[0]})")
+        assert l2_hip < max(2e-5, 3 * l2_ref), (l2_hip, l2_ref)
+        assert l2_e2e < 1e-3, l2_e2e
+        assert worst[1] < 1e-4, (worst, worst_ref)
         assert stats["forward_rows"] == 0 and stats["weight_lines"] == 0 and not stats["tripped"], stats
     finally:
         lib.gi_bf3_enable(was[0]); lib.gi_x2_enable(was[1])
