@@ -134,14 +134,18 @@ __global__ __launch_bounds__(256) void gi_chain_pack_kernel(const PackArgs a) {
 // LDS-DMA of one 1 KB piece: every lane's 16 bytes land at LDS (m0 base) + 16 * lane.  Invisible to
 // the compiler's s_waitcnt bookkeeping on purpose (its own LDS-DMA handling drains vmcnt(0) at every
 // barrier): the kernel counts these loads itself, see GI_CHAIN_WAIT below.
+// m0 is on the clobber list instead of being saved and restored around every piece (4 scalar instructions of a k step's
+// ~50): clang warns that it is a reserved register it "may not preserve" — nothing else in this file uses m0 (gfx9+ LDS
+// instructions do not), which the disassembly shows (the only writes of m0 are these).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void lds_dma_1k(const float* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :
                  : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
+                 : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 // RB = 32-row MFMA blocks per workgroup, RING = weight tiles in LDS.  <1, 3>: the kernel described above.
 // <2, 2>: 64 rows per workgroup for batches of several rounds of row blocks (ZINC / ChEMBL shapes): every

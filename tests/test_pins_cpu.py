@@ -139,3 +139,23 @@ def test_mask_quantum_pin_is_a_no_op_on_consistent_energies_and_on_fp64():
     pin64 = pins.MaskQuantumPin(tape["att_acts"][-1], tape["g"]["cidx"], B, N, cfg["big_positive"])
     a = pins.oracle_quantum_pinned_logits(O, P64, cfg, nodes.double(), edges.double(), pin64)
     assert pin64.quanta == 0 and torch.equal(a, O.ggnn_forward(P64, cfg, nodes.double(), edges.double()))
+
+
+def test_oracle_backward_operator_with_a_given_upstream_gradient():
+    """`forward_backward(..., upstream=v)` returns J^T v: with v = d loss / d logits of its own evaluation it is the
+    ordinary gradient, it is linear in v, and it is what tests/test_x2_trial_gpu.py compares the HIP backward with
+    (the backward operator apart from the conditioning of softmax - target on a fitted model)."""
+    cfg = O.make_config(**TINY)
+    n8, e8, a8 = _live(*tiny_inputs())
+    P = O.init_params(cfg, seed=5)
+    nodes, edges, tgt = (torch.from_numpy(x).double() for x in (n8, e8, a8))
+    P = {k: v.double() for k, v in P.items()}
+    out, loss, g = O.forward_backward(P, cfg, nodes, edges, tgt)
+    o = out.clone().requires_grad_(True)
+    O.kl_loss(o, tgt).backward()
+    _, _, gv = O.forward_backward(P, cfg, nodes, edges, tgt, upstream=o.grad)
+    _, _, g2 = O.forward_backward(P, cfg, nodes, edges, tgt, upstream=-2.0 * o.grad)
+    for k in g:
+        scale = max(float(g[k].abs().max()), 1e-300)
+        assert float((gv[k] - g[k]).abs().max()) < 1e-12 * scale, k
+        assert float((g2[k] + 2.0 * g[k]).abs().max()) < 1e-12 * scale, k
