@@ -468,8 +468,8 @@ def main():
     result["config"]["fuse_flags"] = int(lib.load().gi_fuse_flags())     # GI_FUSE_* variants in use
     result["config"]["gemm_arithmetic"] = (
         "fp32 operands, fp32 accumulate everywhere; the node-level readout layers >= 192 wide (forward, dgrad and weight "
-        "gradients) and the backward's message-stack dZ chains (roofline.pipes counts the launches) split every fp32 operand into "
-        + ("two scaled fp16 values (three f16 MFMA products per fp32 product, per-tensor power-of-two scale from the "
+        "gradients) and the message stacks' chain launches, forward and dZ (roofline.pipes counts the launches) split every fp32 operand into "
+        + ("two scaled fp16 values (three f16 MFMA products per fp32 product, power-of-two scale per tensor — per ROW for the forward chains' activations — from the "
            "tensor's largest magnitude)" if lib.load().gi_x2_enable(-1) else
            "three bf16 values (six bf16 MFMA products per fp32 product)")
         + ": max error against the fp64 product 3e-7 relative, the fp32 MFMA chain's own: 5e-7 "

@@ -23,10 +23,10 @@
  *       GI_FUSE=<mask>          launch-count reductions (gi_fuse_flags, default 15)
  *       GI_CHAIN=0              per-bond-type stacks layer by layer through gi_gemm instead of gi_mlp_chain
  *       GI_BF3=0                every GEMM and chain on the fp32 MFMA (default 1: the node-level readout layers >= 192
- *                               wide and the backward's dZ chains run as splits on the 16-bit MFMA pipe, GI_GEMM_BF3 —
- *                               same result to ~3e-7; gi_bf3_enable)
+ *                               wide and the message stacks' chains, forward and dZ, run as splits on the 16-bit MFMA
+ *                               pipe, GI_GEMM_BF3 — same result to ~3e-7; gi_bf3_enable)
  *       GI_X2=0                 those launches as three bf16 planes (six products) instead of two scaled fp16 planes
- *                               (three products, GI_GEMM_X2; gi_x2_enable); also puts the dZ chains back on fp32
+ *                               (three products, GI_GEMM_X2; gi_x2_enable); also puts the chains back on fp32
  *       GI_CHAIN_X2=0           only the dZ chains back on the fp32 chain kernel (gi_chain_params.x2_wamax unused)
  *       GI_CHAIN_FWD_X2=0       only the FORWARD chains back on the fp32 chain kernel (default: the row-independent
  *                               fp16x2 kernel, gi_chain_params.x2_rows32)
