@@ -327,8 +327,8 @@ typedef struct {
                                              products per fp32 product, activations scaled per 64-ROW BLOCK and layer by
                                              a power of two from the block's largest magnitude: a row's last bits
                                              depend on which rows share its block — NOT bitwise row-independent like
-                                             the fp32 chain, which is why gi_ggnn_forward keeps that one and only the
-                                             backward's dZ chains run this way).  Pack and launch must agree; a
+                                             the fp32 chain: gi_ggnn_backward's dZ chains run this way, gi_ggnn_forward
+                                             uses x2_rows32 below).  Pack and launch must agree; a
                                              bounded launch walks 64-row blocks (the value behind tile_rows_dev is unused) */
     int x2_rows32;                        /* with x2_wamax: != 0 = the ROW-INDEPENDENT fp16x2 chain — 32-row blocks, every row
                                              of the activation tile scaled by its OWN power of two (the product is formed
