@@ -981,9 +981,9 @@ __global__ __launch_bounds__(512, DUAL ? 4 : 1) void gi_chain_x2r_kernel(const C
             if (lhi == 0) red[wid][l31] = m;
         }
         // Every wave is past its last read of the activation planes, and the eight row-maximum vectors are in LDS.
-        // (!DUAL: this wave's DMA queue drains here, which is what the vmcnt arithmetic of the k loop assumes.)
-        if (DUAL) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // This wave's DMA queue drains here (the tiles in flight had the VALU work above to land), which is what the
+        // vmcnt arithmetic of the k loop assumes.
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         // Part two: the row's planes for the next layer (its own scale), its outputs
         const bool more = l + 1 < L && !(args.dbg & 8);      // (lab bit 8: no rewrite of the activation planes)
         if (more) {
@@ -1091,31 +1091,35 @@ __global__ __launch_bounds__(512, DUAL ? 4 : 1) void gi_chain_x2r_kernel(const C
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     __syncthreads();                        // the A planes, the row maxima and the biases are in LDS (and every plain load has landed)
     row_scale_from_lds(l31, sa, ia);
-    dma_tile(0);
-    if (!DUAL) { dma_tile(1); dma_tile(2); }
+    dma_tile(0); dma_tile(1);
+    if (!DUAL) dma_tile(2);
 
-    // ---- main loop over the weight tiles.  !DUAL: four slots, three tiles in flight; DUAL: two slots, one in flight —
-    // tile s + 1 is requested when the wave's fragment reads of tile s - 1 have returned, and lands while tile s is
-    // multiplied; the CU's other workgroup covers what that leaves open.  No barrier in here: the rings are
-    // wave-private, the activation planes are read-only until the epilogue.
-    // vmcnt arithmetic (!DUAL): the epilogue drained the queue, so the three steps behind it find their tiles landed
-    // and must not wait for the epilogue's stores (vmcnt counts them too): vmcnt(44) = no wait; from then on at most the
-    // two youngest tiles (4 loads) may be outstanding.
+    // ---- main loop over the weight tiles.  !DUAL: four slots, three tiles in flight.  DUAL: two slots and TWO tiles in
+    // flight — a slot is free as soon as the wave's fragment reads of it have returned (the MFMAs need that wait
+    // anyway), so tile s + 2 is requested into the slot of tile s in front of the MFMAs of tile s.  (One tile in flight
+    // left 20 us of the launch waiting for the stream, profiles/r05/x2_chain_breakdown_final.txt.)
+    // No barrier in here: the rings are wave-private, the activation planes are read-only until the epilogue.
+    // vmcnt arithmetic: the epilogue drained the queue, so the steps right behind it (three; DUAL: two) find their tiles
+    // landed and must not wait for the epilogue's stores / the next layer's activation loads (vmcnt counts them too):
+    // vmcnt(60) = no wait; from then on at most the youngest two tiles (DUAL: one) may be outstanding.
 #define GI_CHAIN_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory")
     int l = 0, kt = 0, nk = (P.layer[0].K + CX_KT - 1) / CX_KT, lN = P.layer[0].N;
     int since_epi = 3;
     for (int s = 0; s < T; ++s) {
-        if (DUAL) { GI_CHAIN_WAIT(0); }
-        else if (__builtin_amdgcn_readfirstlane(since_epi) < 3) { GI_CHAIN_WAIT(44); } else { GI_CHAIN_WAIT(4); }
+        if (__builtin_amdgcn_readfirstlane(since_epi) < (DUAL ? 2 : 3)) { GI_CHAIN_WAIT(60); }
+        else if (DUAL) { GI_CHAIN_WAIT(2); } else { GI_CHAIN_WAIT(4); }
         since_epi = __builtin_amdgcn_readfirstlane(since_epi + 1);
-        if (!(args.dbg & 1)) dma_tile(s + (DUAL ? 1 : 3));
+        if (!DUAL && !(args.dbg & 1)) dma_tile(s + 3);
         const int slot = s & (RING - 1);
-        if (swid * 32 < __builtin_amdgcn_readfirstlane(lN)) {
-            if (!(args.dbg & 2)) read_frags(slot, kt);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(args.dbg & 4)) mma();
-            __builtin_amdgcn_sched_barrier(0);
+        const bool active = swid * 32 < __builtin_amdgcn_readfirstlane(lN);
+        if (active && !(args.dbg & 2)) read_frags(slot, kt);
+        if (DUAL) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers: the slot is free
+            if (!(args.dbg & 1)) dma_tile(s + 2);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (active && !(args.dbg & 4)) mma();
+        __builtin_amdgcn_sched_barrier(0);
         kt = __builtin_amdgcn_readfirstlane(kt + 1);
         if (kt == __builtin_amdgcn_readfirstlane(nk)) {       // layer done
             if (args.dbg & 32) {                              // (lab: no epilogue at all)
