@@ -851,7 +851,8 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
 //     construction;
 //   * DUAL = false (launches of at most one workgroup per CU): four-slot ring, three tiles in flight; fp32 outputs
 //     staged through LDS and stored as whole rows — 138 KB of LDS, one workgroup per CU, 43 us at 256 workgroups;
-//   * DUAL = true (more row blocks than CUs): TWO workgroups per CU — two-slot ring, one tile in flight per workgroup,
+//   * DUAL = true (more row blocks than CUs): TWO workgroups per CU — two-slot ring with two tiles in flight (a slot is
+//     re-requested as soon as its fragments are in registers),
 //     no staging tile (a lane stores its row's 4 x 16 bytes per layer itself, the L2 merges them into lines), 73 KB of
 //     LDS and <= 128 VGPRs.  264 blocks: 56 us against 76 (two rounds); 512: 64 against 82; 1024: 121 against 159.
 constexpr int CR_ROWS = 32;                                 // rows of the (transposed) MFMA tile
