@@ -393,10 +393,13 @@ def test_fp16x2_is_no_further_from_fp64_than_the_fp32_mfma():
         assert x2[0] < 1.5 * f32[0] + 1e-5, (shape, x2, f32)
 
 
-def test_guard_trips_the_model_into_bf16x3_and_reports_it():
+@pytest.mark.parametrize("wname", ["APDReadout.fAddNet1.seq.3.weight",      # a 500 x 500 hidden layer of a node-level stack (GEMM launches)
+                                   "msg_nns.0.seq.3.weight"])               # a 250 x 250 hidden layer of a message stack (chain launches)
+def test_guard_trips_the_model_into_bf16x3_and_reports_it(wname):
     """End to end: a weight matrix of a fp16x2 layer with three rows 2^-30 below its maximum -> gi_x2_weight_guard counts
     them during the forward and sets the host flag; the NEXT forward runs with GI_RUN_NO_X2 and agrees with the
-    process-wide bf16x3 mode bit for bit; x2_guard_reset() re-arms."""
+    process-wide bf16x3 mode bit for bit; x2_guard_reset() re-arms.  Both kinds of fp16x2 forward launches: the GEMMs of
+    the node-level stacks and (since the forward chains run as fp16x2) the message stacks' chain launches."""
     sh = synthetic.SHAPES["gdb13"]
     cfg = O.shaped_config(sh["n_atom_types"], sh["n_formal_charge"], sh["max_n_nodes"], hidden_node_features=128,
                           message_size=128)
@@ -410,7 +413,7 @@ def test_guard_trips_the_model_into_bf16x3_and_reports_it():
         model.cache_pass0 = False
         ref_x2 = model(nodes, edges).clone()
         assert model.x2_guard_stats() == {"forward_rows": 0, "weight_lines": 0, "dgrad_rows": 0, "tripped": False}
-        w = dict(model.named_parameters())["APDReadout.fAddNet1.seq.3.weight"]          # a 500 x 500 hidden layer
+        w = dict(model.named_parameters())[wname]
         w[[1, 2, 3]] *= 2.0 ** -30
         first = model(nodes, edges).clone()                     # still fp16x2; the guard notices
         torch.cuda.synchronize()
