@@ -8,7 +8,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("rnd", ["r02", "r03", "r04"])
+@pytest.mark.parametrize("rnd", ["r02", "r03", "r04", "r05"])
 def test_critical_path_on_the_committed_traces(rnd):
     for tag in ("default", "onestream", "zinc", "chembl"):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "critical_path.py"),
@@ -23,7 +23,7 @@ def test_critical_path_on_the_committed_traces(rnd):
             assert side == 0.0                      # weight gradients on the main queue
         else:
             assert side > 0.2 * span                # a second queue overlaps the backward
-        if rnd == "r04" and tag == "default":       # round 4: nothing left behind the last dZ chain (155 us in r03)
+        if rnd in ("r04", "r05") and tag == "default":   # since round 4: nothing left behind the last dZ chain (155 us in r03)
             assert float(rows["tail (side queue only)"][0]) < 20.0
             committed = open(os.path.join(ROOT, "profiles", rnd, "critical_path_default.txt")).read()
             full = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "critical_path.py"),
@@ -83,3 +83,27 @@ def test_gemm_class_report_round_4_with_the_fp16x2_launches():
     assert len(w16) == 1 and float(w16[0][-2]) > 1.2 and 0.2 < float(w16[0][-1]) < 0.4
     committed = open(os.path.join(ROOT, "profiles", "r04", "gemm_class_report.txt")).read()
     assert out.stdout.strip() == committed.strip()
+
+
+def test_chain_scaling_report_reads_a_kernel_trace(tmp_path):
+    """tools/chain_scaling.py report: launches grouped by kernel and number of workgroups, median of the last four."""
+    cols = ["Kind", "Agent_Id", "Queue_Id", "Stream_Id", "Thread_Id", "Dispatch_Id", "Kernel_Id", "Kernel_Name", "Correlation_Id",
+            "Start_Timestamp", "End_Timestamp", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count",
+            "Workgroup_Size_X", "Workgroup_Size_Y", "Workgroup_Size_Z", "Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"]
+    lines = [",".join('"%s"' % c for c in cols)]
+    t = 1000
+    for name, us in (("void (anonymous namespace)::gi_chain_x2r_kernel<false, true>((anonymous namespace)::ChainArgs)", 55),
+                     ("void (anonymous namespace)::gi_chain_kernel<false, 1, 2>((anonymous namespace)::ChainArgs)", 103),
+                     ("(anonymous namespace)::gi_chain_pack_x2_kernel((anonymous namespace)::PackArgs)", 5)):
+        for rep in range(6):
+            dur = us * 1000 + (500000 if rep < 2 else rep)          # two slow warm-up launches, ignored by the median
+            row = ["KERNEL_DISPATCH", 1, 1, 1, 1, 1, 1, name, 1, t, t + dur, 0, 0, 0, 0, 0, 512, 1, 1, 264 * 512, 1, 1]
+            lines.append(",".join('"%s"' % v for v in row))
+            t += dur + 1000
+    path = tmp_path / "trace.csv"
+    path.write_text("\n".join(lines) + "\n")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "chain_scaling.py"), "report", str(path)],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    row = out.stdout.splitlines()[-1].split()
+    assert row[0] == "264" and abs(float(row[1]) - 103.0) < 0.1 and row[2] == "-" and abs(float(row[3]) - 55.0) < 0.1, out.stdout
