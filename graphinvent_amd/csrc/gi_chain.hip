@@ -490,6 +490,12 @@ constexpr int CX_PLANE = 32 * CX_ROWS * 16;                 // bytes of one acti
 constexpr int CX_KT = 16;                                   // reduction depth of one weight tile
 constexpr int CX_TILE = CH_W * CX_KT;                       // floats (= 4-byte units) per weight tile image: 16 KB
 constexpr int CX_RING = 4;
+// one workgroup's largest magnitude -> its slot of an amax cell (ONE thread calls; gi_x2.h: 64 slots, a line apart)
+__device__ __forceinline__ void cx_amax_publish_wg(float m, float* cell) {
+    float* slot = cell + (blockIdx.x & (GX_AMAX_SLOTS - 1)) * GX_AMAX_STRIDE;
+    if (m > *reinterpret_cast<volatile float*>(slot))
+        atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, m));
+}
 __host__ __device__ inline int cx_tiles(const gi_chain_params& p) {
     int t = 0;
     for (int l = 0; l < p.nlayers; ++l) t += (p.layer[l].K + CX_KT - 1) / CX_KT;
@@ -683,7 +689,9 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
                 float x = (acc[rb][r] * ia) * ib + bv;
                 if (!BWD) x = gi_selu(x);
                 if (dselu) x *= gi_selu_grad(av[rb][r]);
-                x = col_ok ? x : 0.f;                        // zero = the next layer's k padding
+                // zero = the next layer's k padding; rows beyond the block's (copies of its last row, with selu'(0) for a
+                // factor in the dZ chain) stay out of the block's scale and of the published maximum
+                x = (col_ok && rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi < nvalid) ? x : 0.f;
                 v[rb][r] = x;
                 m = fmaxf(m, fabsf(x));
             }
@@ -692,6 +700,7 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
         // wave maxima are in LDS.
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
+        if (Ly.out_amax && tid == 0) cx_amax_publish_wg(wg_max_from_lds(), Ly.out_amax);   // for the stack's fp16x2 weight gradients
         if (l + 1 < L && !(args.dbg & 4)) {                  // next layer's A operand: split, in place
             gx_scale(wg_max_from_lds(), sa, ia);
             // A lane holds ONE column of 16 rows per row block: written one by one that is 64 two-byte stores per
@@ -763,6 +772,7 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
         wave_max_to_lds(m);
         __syncthreads();
         gx_scale(wg_max_from_lds(), sa, ia);
+        if (P.x_amax && tid == 0) cx_amax_publish_wg(wg_max_from_lds(), P.x_amax);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             unsigned p0a, p1a, p0b, p1b;
@@ -1004,7 +1014,15 @@ __global__ __launch_bounds__(512, DUAL ? 4 : 1) void gi_chain_x2r_kernel(const C
 #pragma unroll
             for (int j = 0; j < 4; ++j) *reinterpret_cast<v4f*>(&Os[l31 * CR_OLD + nb + 8 * j]) = x[j];
         }
+        float blk_max = 0.f;                                 // the block's largest new activation, for the stack's fp16x2 weight
+        if (Ly.out_amax && swid == 0) {                      // gradients (read between the barriers: red[] is stable there)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) blk_max = fmaxf(blk_max, red[4 * lhi + w][l31]);   // lane: one row, four of the eight waves
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) blk_max = fmaxf(blk_max, __shfl_xor(blk_max, o));
+        }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the new planes are written (the output tile is staged)
+        if (Ly.out_amax && swid == 0 && lane == 0) cx_amax_publish_wg(blk_max, Ly.out_amax);
         if (!(args.dbg & 16)) {
             if (DUAL) {                                      // the lane's 4 x 4 channels of its row straight to HBM
                 if (live) {
@@ -1092,6 +1110,12 @@ __global__ __launch_bounds__(512, DUAL ? 4 : 1) void gi_chain_x2r_kernel(const C
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     __syncthreads();                        // the A planes, the row maxima and the biases are in LDS (and every plain load has landed)
     row_scale_from_lds(l31, sa, ia);
+    if (P.x_amax && swid == 0) {            // largest |input| of the block (rows beyond the block were zeroed)
+        float m = red[0][l31];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) cx_amax_publish_wg(m, P.x_amax);
+    }
     dma_tile(0); dma_tile(1);
     if (!DUAL) dma_tile(2);
 

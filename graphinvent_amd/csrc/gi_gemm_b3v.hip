@@ -29,6 +29,7 @@
 
 #include "gi_common.h"
 #include "gi_mfma.h"
+#include "gi_x2.h"
 
 typedef __bf16 gv_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 gv_bf16x2 __attribute__((ext_vector_type(2)));
@@ -324,6 +325,7 @@ __global__ __launch_bounds__(256, 3) void gi_b3v_kernel(const GvBatch b) {
     const int flags = EPI == 1 ? (GI_EPI_BIAS | GI_EPI_SELU) : (EPI == 2 ? GI_EPI_DSELU : (EPI == 3 ? 0 : p.flags));
     const bool need_act = (flags & (GI_EPI_DSELU | GI_EPI_MULACT)) != 0;
     const bool need_c = (flags & GI_EPI_ACCUM) != 0;
+    float amax = 0.f;                                             // largest |value| stored (gi_gemm_params.c_amax)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -353,11 +355,18 @@ __global__ __launch_bounds__(256, 3) void gi_b3v_kernel(const GvBatch b) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + 8 * (r >> 2) + (r & 3);
-                float* dst = (col_ok & (row < m_end)) ? Cp + (long long)row * p.ldc + col : gv_sink + tid;
+                const bool ok = col_ok & (row < m_end);
+                float* dst = ok ? Cp + (long long)row * p.ldc + col : gv_sink + tid;
                 *dst = v[r];
+                amax = fmaxf(amax, ok ? fabsf(v[r]) : 0.f);
             }
         }
     }
+    // A bf16x3 launch can be the PRODUCER of a tensor an fp16x2 launch reads next (a stack's last layer 192+ wide has no
+    // amax cell for its own dZ and stays bf16x3, while the dZ it hands to the layer below is scaled from this cell).
+    // Round 6: this kernel left the cell at zero — scale 1, fp16 planes of raw 1e-4-sized dZ values, every gradient
+    // upstream of such a layer ~5e-4 off (tests/test_dims_gpu.py, A = 432).
+    if (p.c_amax && !(p.flags & GI_GEMM_SPLITK)) gx_amax_publish(amax, p.c_amax);
 }
 
 int g_b3v_enabled = -1;

@@ -35,7 +35,7 @@ BWD_PREPACKED, BWD_NO_X2 = 0x100, 0x200        # OR-ed into the phase (GI_BWD_PR
 RUN_PREPACK_BWD, RUN_NO_X2 = 1, 2              # gi_ggnn_forward_ex flags (GI_RUN_*)
 X2_GUARD_WORDS = 4                             # GI_X2_GUARD_WORDS
 COUNTS = 24          # GI_COUNTS
-ABI_VERSION = 15
+ABI_VERSION = 16
 #: bumped by code that rewrites model weights through raw pointers (optim.FusedAdam.step,
 #: dp.DataParallel.broadcast_parameters): invalidates gnn.mpnn's pass-0 row cache
 WEIGHTS_EPOCH = [0]     # GI_ABI_VERSION
@@ -70,14 +70,14 @@ CHAIN_MAXL, CHAIN_MAXW = 8, 256       # GI_CHAIN_MAXL, GI_CHAIN_MAXW
 
 class ChainLayer(C.Structure):
     _fields_ = [("W", vp * GI_MAX_GROUPS), ("bias", vp * GI_MAX_GROUPS), ("out", vp), ("ldo", ci),
-                ("act", vp), ("ldact", ci), ("K", ci), ("N", ci)]
+                ("act", vp), ("ldact", ci), ("K", ci), ("N", ci), ("out_amax", vp)]
 
 
 class ChainParams(C.Structure):
     _fields_ = [("layer", ChainLayer * CHAIN_MAXL), ("nlayers", ci), ("X", vp), ("ldx", ci),
                 ("x_idx", vp), ("grp_off", vp), ("ngroups", ci), ("group_rows", ci * GI_MAX_GROUPS),
                 ("rows", ci), ("backward", ci), ("image", vp), ("image_stride", cll), ("skip_flag", vp),
-                ("tile_rows_dev", vp), ("x2_wamax", vp), ("x2_rows32", ci)]
+                ("tile_rows_dev", vp), ("x2_wamax", vp), ("x_amax", vp), ("x2_rows32", ci)]
 
 
 class ReduceDesc(C.Structure):

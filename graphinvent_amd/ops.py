@@ -542,6 +542,8 @@ def mlp_chain(chains, backward=False, x2=False, rows32=False):
                 y.W[t] = w.data_ptr()
             for t, b in enumerate(ly.get("bias") or ()):
                 y.bias[t] = b.data_ptr()
+            y.out_amax = _ptr(ly.get("out_amax"))            # fp16x2 kernels: max |out| of the layer (amax cell)
+        c.x_amax = _ptr(spec.get("x_amax"))
     images = []
     if x2:
         for c, spec in zip(arr, chains):

@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define GI_ABI_VERSION 15
+#define GI_ABI_VERSION 16
 #define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
 #define GI_MAX_NODES 128      /* max max_n_nodes */
 #define GI_P0_MAX_CLASSES 256 /* max distinct node feature rows for the pass-0 shortcut */
@@ -297,6 +297,10 @@ typedef struct {
     float* out; int ldo;
     const float* act; int ldact;          /* backward only */
     int K, N;
+    float* out_amax;                      /* NULL, or an amax cell (GI_AMAX_WORDS floats, csrc/gi_x2.h): the fp16x2 chain kernels
+                                             (x2_wamax != NULL) publish max |out| of this layer over ALL groups into it — what
+                                             the fp16x2 weight-gradient launches of the stack scale their operands with
+                                             (activations: forward chain, dZ: backward chain).  Ignored by the fp32 chain. */
 } gi_chain_layer;
 
 typedef struct {
@@ -330,6 +334,8 @@ typedef struct {
                                              the fp32 chain: gi_ggnn_backward's dZ chains run this way, gi_ggnn_forward
                                              uses x2_rows32 below).  Pack and launch must agree; a
                                              bounded launch walks 64-row blocks (the value behind tile_rows_dev is unused) */
+    float* x_amax;                        /* NULL, or an amax cell for max |X rows read| (after the x_idx gather; all groups) —
+                                             published by the fp16x2 chain kernels like layer[].out_amax */
     int x2_rows32;                        /* with x2_wamax: != 0 = the ROW-INDEPENDENT fp16x2 chain — 32-row blocks, every row
                                              of the activation tile scaled by its OWN power of two (the product is formed
                                              transposed, so that a lane holds one row: its maximum is an in-register

@@ -180,6 +180,9 @@ def test_ctypes_structs_have_the_sizes_and_offsets_of_the_header(tmp_path):
             ("gi_graph", "x2_guard_host", L.Graph.x2_guard_host.offset),
             ("gi_gemm_params", "m_dev", L.GemmParams.m_dev.offset),
             ("gi_chain_params", "x2_wamax", L.ChainParams.x2_wamax.offset),
+            ("gi_chain_params", "x_amax", L.ChainParams.x_amax.offset),
+            ("gi_chain_params", "x2_rows32", L.ChainParams.x2_rows32.offset),
+            ("gi_chain_layer", "out_amax", L.ChainLayer.out_amax.offset),
             ("gi_chain_params", "image_stride", L.ChainParams.image_stride.offset),
             ("gi_graph", "p0_cache", L.Graph.p0_cache.offset),
             ("gi_ggnn_dims", "drop_seed", L.GgnnDims.drop_seed.offset)]

@@ -390,6 +390,43 @@ def test_gemm_fp16x2_split_vs_fp64_with_amax_cells_from_the_producers(M, N, K, b
         assert rel(S[:, :, :K + 1].double().sum(0).cpu(), refw) < 2e-6
 
 
+@pytest.mark.parametrize("route", ["fp32", "bf3_r3", "bf3_b3v", "bf3_b3p"])
+@pytest.mark.parametrize("layout", ["forward", "dgrad_wt_copy", "dgrad_w_as_stored"])
+def test_every_gemm_route_publishes_c_amax(route, layout, bf3_kernel_switches):
+    """gi_gemm_params.c_amax: whichever kernel a launch is routed to, the cell holds max |stored value| afterwards — the
+    fp16x2 launch that reads the tensor next takes its scale from it, and a cell left at zero reads as scale 1 (fp16
+    planes of raw values).  Round 6 found the bf16x3 kernel of gi_gemm_b3v.hip not publishing: in a model whose
+    node-level stacks END in a layer >= 192 wide (A = 432, tests/test_dims_gpu.py) that kernel produces the dZ the
+    fp16x2 layers below read, and every gradient upstream was ~5e-4 off."""
+    lib = bf3_kernel_switches
+    lib.gi_b3p_enable(1 if route == "bf3_b3p" else 0)
+    lib.gi_b3v_enable(1 if route == "bf3_b3v" else 0)
+    if route == "bf3_b3p": os.environ["GI_B3P_ALL"] = "1"
+    M, N, K = 700, 250, 300
+    g = torch.Generator().manual_seed(5)
+    X = (torch.randn(M, ops.r4(K), generator=g) * 1e-3).to(DEV)
+    cell = torch.zeros(1, L.AMAX_WORDS, device=DEV)
+    Y = torch.zeros(M, ops.r4(N), device=DEV)
+    bf3 = 0 if route == "fp32" else L.GEMM_BF3
+    if layout == "forward":
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+        ops.gemm(X, W, Y, M, N, K, ops.r4(K), K, ops.r4(N), flags=L.EPI_BIAS | L.EPI_SELU | bf3 | (L.GEMM_BF3B_F32 if bf3 else 0),
+                 bias=torch.randn(N, generator=g).to(DEV), c_amax=cell[0])
+    else:
+        Wt = (torch.randn(K, N, generator=g) / K ** 0.5).to(DEV)
+        act = torch.randn(M, ops.r4(N), generator=g).to(DEV)
+        if layout == "dgrad_wt_copy" and bf3:
+            ops.gemm(X, ops.bf3_pack(Wt, transpose=True, as_f32=True), Y, M, N, K, ops.r4(K), ops.r4(K), ops.r4(N),
+                     flags=L.EPI_DSELU | bf3 | L.GEMM_BF3B_F32, act=act, ldact=ops.r4(N), c_amax=cell[0])
+        else:
+            if bf3 and route != "bf3_b3p" and route != "bf3_b3v":
+                pytest.skip("W as stored on the 16-bit pipe: the 32-deep-tile kernels only")
+            ops.gemm(X, Wt, Y, M, N, K, ops.r4(K), N, ops.r4(N), flags=L.EPI_DSELU | bf3, act=act, ldact=ops.r4(N),
+                     b_major=True, c_amax=cell[0])
+    assert float(Y[:, :N].abs().max()) > 0
+    assert float(cell.max()) == float(Y[:, :N].abs().max())
+
+
 def test_gemm_fp16x2_needs_both_amax_cells():
     X = torch.randn(256, 64, device=DEV); W = torch.randn(128, 64, device=DEV); Y = torch.zeros(256, 128, device=DEV)
     with pytest.raises(RuntimeError, match="GI_EINVAL"):
@@ -471,7 +508,20 @@ def _chain_case(sizes, off, seed, two=False, x2=False, in_scale=1.0, rows32=Fals
                           layers=[dict(W=[dev(w) for w in Ws[c][l]], bias=[dev(b) for b in bs[c][l]],
                                        out=bufs[l], K=sizes[l], N=sizes[l + 1])
                                   for l in range(len(sizes) - 1)]))
+    # fp16x2 kernels: amax cells for the input rows and every layer's output (gi_chain_params.x_amax,
+    # gi_chain_layer.out_amax — what the stack's fp16x2 weight-gradient launches take their operand scales from)
+    fcells = torch.zeros(nchains, len(sizes), L.AMAX_WORDS, device=DEV)
+    if x2:
+        for c in range(nchains):
+            specs[c]["x_amax"] = fcells[c, 0]
+            for l in range(len(sizes) - 1):
+                specs[c]["layers"][l]["out_amax"] = fcells[c, l + 1]
     ops.mlp_chain(specs, backward=False, x2=x2, rows32=rows32)
+    if x2:
+        for c in range(nchains):
+            assert float(fcells[c, 0].max()) == float(h[idx.long(), :K0].abs().max()), c
+            for l in range(len(sizes) - 1):
+                assert float(fcells[c, l + 1].max()) == float(outs[c][l][:, :sizes[l + 1]].abs().max()), (c, l)
     refs = []
     for c in range(nchains):
         acts = []
@@ -504,7 +554,19 @@ def _chain_case(sizes, off, seed, two=False, x2=False, in_scale=1.0, rows32=Fals
         bspecs.append(dict(X=dev(dZ), x_idx=None, grp_off=dev(offt), group_rows=rows_g, rows=E,
                            layers=layers))
         bouts.append((dZ, douts))
+    bcells = torch.zeros(nchains, len(sizes), L.AMAX_WORDS, device=DEV)
+    if x2:
+        for c in range(nchains):
+            bspecs[c]["x_amax"] = bcells[c, 0]
+            for i in range(L_):
+                bspecs[c]["layers"][i]["out_amax"] = bcells[c, i + 1]
     ops.mlp_chain(bspecs, backward=True, x2=x2, rows32=rows32)
+    if x2:
+        for c in range(nchains):
+            assert float(bcells[c, 0].max()) == float(bouts[c][0][:, :sizes[-1]].abs().max()), c
+            for i in range(L_):                              # chain layer i writes douts[L_ - 1 - i]
+                l = L_ - 1 - i
+                assert float(bcells[c, i + 1].max()) == float(bouts[c][1][l][:, :sizes[l]].abs().max()), (c, l)
     for c in range(nchains):
         dZ, douts = bouts[c]
         z = dZ[:, :sizes[-1]].double()
