@@ -50,6 +50,7 @@ int gi_gemm_bf3_launch(const gi_gemm_params* probs, int n, void* stream);
 // ... and gi_gemm_bf3_launch those with plain fp32 operands (no images, no gathers) to gi_gemm_b3v.hip: forward,
 // dgrad (W as stored, b_major) and weight-gradient (a_major + b_major, split-K slabs) layouts on 32-deep k tiles
 bool gi_b3v_eligible(const gi_gemm_params* probs, int n);
+bool gi_b3v_wants(const gi_gemm_params* probs, int n);      // every problem carries GI_GEMM_T128 and the kernel can run them
 int gi_b3v_launch(const gi_gemm_params* probs, int n, void* stream);
 extern "C" int gi_b3v_enable(int on);
 // ... and forward / dgrad launches (both operands fp32 with k contiguous) to the 512-thread ping-pong kernel of

@@ -106,7 +106,9 @@ struct GpBatch {
 // (weight-gradient slabs).
 // X2 (GI_GEMM_X2): operands as two scaled fp16 values each (gi_x2.h) — two LDS planes, three f16 MFMA products per
 // fp32 product (24 MFMAs per wave and k tile in 6 groups instead of 48 in 12), scales from a_amax / b_amax.
-template <bool AM, bool BMJ, int EPI, bool X2>
+// BIDX (weight-gradient layout only): the reduction rows of B are gathered through p.b_idx (the first layer of a message
+// stack reads h[u_src]) — the index of a reduction row is wave-uniform, i.e. scalar loads ahead of the row loads.
+template <bool AM, bool BMJ, int EPI, bool X2, bool BIDX = false>
 __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, unsigned char* const smem) {
     constexpr int NP = X2 ? 2 : 3;
     constexpr int A_BYTES = NP * GP_PLA, STAGE = NP * (GP_PLA + GP_PLB);
@@ -219,7 +221,8 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
         const int kr = kb + kt * GP_BK + 8 * kcw;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int row = decltype(st)::value ? kr + j : min(kr + j, ke - 1);
+            int row = decltype(st)::value ? kr + j : min(kr + j, ke - 1);
+            if (BIDX) row = __builtin_amdgcn_readfirstlane(p.b_idx[row]);
             xb[i][j] = *(const float*)((const char*)p.B + (size_t)row * (size_t)p.ldb * 4 + b_off[i]);
         }
     };
@@ -476,14 +479,14 @@ __device__ __forceinline__ void gp_tile(const GpBatch& b, const int tile_id, uns
 // TILE STREAM — as many workgroups as the device has CUs, each walking tiles id, id + grid, ... (longest reductions
 // first: gi_gemm_batch's order) — so no CU waits for a 512-thread / 144 KB workgroup to be torn down and set up
 // between two tiles.
-template <bool AM, bool BMJ, int EPI, bool X2 = false>
+template <bool AM, bool BMJ, int EPI, bool X2 = false, bool BIDX = false>
 __global__ __launch_bounds__(512, 2) void gi_b3p_kernel(const GpBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];        // 2 stages
-    for (int tile = blockIdx.x; tile < b.total; tile += gridDim.x) gp_tile<AM, BMJ, EPI, X2>(b, tile, smem);
+    for (int tile = blockIdx.x; tile < b.total; tile += gridDim.x) gp_tile<AM, BMJ, EPI, X2, BIDX>(b, tile, smem);
 }
 
 int g_b3p_enabled = -1, g_b3p_stream_cus = -1;
-bool g_b3p_attr_set[2][3][4] = {};
+bool g_b3p_attr_set[2][4][4] = {};
 
 }  // namespace
 
@@ -516,7 +519,10 @@ bool gi_b3p_eligible(const gi_gemm_params* probs, int n) {
         if (p.a_major != probs[0].a_major || p.b_major != probs[0].b_major) return false;
         if (p.a_major && !p.b_major) return false;
         if (!p.b_major && !(p.flags & GI_GEMM_BF3B_F32)) return false;      // contig B must be plain fp32, not an image
-        if (p.a_idx || p.b_idx || p.k_dev) return false;
+        if (p.a_idx || p.k_dev) return false;
+        // a gathered B: the weight-gradient layout only, fp16x2 only, every problem of the launch alike (one kernel)
+        if (p.b_idx && !(p.a_major && p.b_major && (p.flags & GI_GEMM_X2) && (p.flags & GI_GEMM_SPLITK))) return false;
+        if ((p.b_idx != nullptr) != (probs[0].b_idx != nullptr)) return false;
     }
     return true;
 }
@@ -538,7 +544,7 @@ int gi_b3p_launch(const gi_gemm_params* probs, int n, void* stream) {
         if (!p.ngroups && !p.C) return GI_EINVAL;
         if (splitk && (!am || !bmj || p.m_dev)) return GI_EINVAL;            // slabs: weight-gradient layout only
         if (p.ones_col >= 0 && (!bmj || p.ones_col != p.N - 1)) return GI_EINVAL;
-        const int f = p.flags & ~(GI_GEMM_BF3 | GI_GEMM_BF3B_F32 | GI_GEMM_SPLITK | GI_GEMM_X2);
+        const int f = p.flags & ~(GI_GEMM_BF3 | GI_GEMM_BF3B_F32 | GI_GEMM_SPLITK | GI_GEMM_X2 | GI_GEMM_T128);
         if (f & ~(GI_EPI_BIAS | GI_EPI_SELU | GI_EPI_DSELU | GI_EPI_ACCUM | GI_EPI_MULACT)) return GI_EINVAL;
         if (((p.flags & GI_GEMM_X2) != 0) != ((probs[0].flags & GI_GEMM_X2) != 0)) return GI_EINVAL;
         if ((p.flags & GI_GEMM_X2) && (!p.a_amax || !p.b_amax)) return GI_EINVAL;
@@ -590,7 +596,11 @@ int gi_b3p_launch(const gi_gemm_params* probs, int n, void* stream) {
     int li;
     const bool x2 = (probs[0].flags & GI_GEMM_X2) != 0;
 #define GP_PICK(A, B, E) (x2 ? (kern_t)gi_b3p_kernel<A, B, E, true> : (kern_t)gi_b3p_kernel<A, B, E, false>)
-    if (am) { li = 2; if (epi != 3) epi = 0; fn = epi == 3 ? GP_PICK(true, true, 3) : GP_PICK(true, true, 0); }
+    const bool bidx = probs[0].b_idx != nullptr;
+    for (int i = 0; i < n; ++i)
+        if ((probs[i].b_idx != nullptr) != bidx || (bidx && !(am && x2 && (probs[i].flags & GI_GEMM_SPLITK)))) return GI_EINVAL;
+    if (am && bidx) { if (epi != 3) return GI_EINVAL; li = 3; fn = (kern_t)gi_b3p_kernel<true, true, 3, true, true>; }
+    else if (am) { li = 2; if (epi != 3) epi = 0; fn = epi == 3 ? GP_PICK(true, true, 3) : GP_PICK(true, true, 0); }
     else if (bmj) { li = 1; if (epi != 2) epi = 0; fn = epi == 2 ? GP_PICK(false, true, 2) : GP_PICK(false, true, 0); }
     else {
         li = 0;

@@ -45,7 +45,6 @@ __device__ float gv_sink[256];                     // where out-of-range lanes o
 constexpr int GV_BM = 128, GV_BN = 128, GV_BK = 32;
 constexpr int GV_CH = 128 * 16;                    // bytes of one k chunk (8 bf16) of all 128 rows
 constexpr int GV_PLANE = 4 * GV_CH;                // 8 KB
-constexpr int GV_OPER = 3 * GV_PLANE;              // 24 KB
 
 __device__ __forceinline__ unsigned gv_lds(int plane, int kc, int row) {
     return plane * GV_PLANE + kc * GV_CH + ((row * 16 + kc * 32) & (GV_CH - 1));
@@ -72,11 +71,16 @@ struct GvBatch {
 
 // EPI: 0 = epilogue from the run-time flags, 1 = bias + SELU (forward), 2 = * selu'(act) (dgrad), 3 = plain store
 // (weight-gradient slabs).
-template <bool AM, bool BMJ, int EPI>
-__global__ __launch_bounds__(256, 3) void gi_b3v_kernel(const GvBatch b) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GV_OPER];
+// X2 (GI_GEMM_X2, round 6): the operands as two scaled fp16 planes (gi_x2.h) — 32 KB of LDS instead of 48, 24 instead of
+// 48 MFMAs per wave and k tile; scales from a_amax / b_amax.  BIDX (weight-gradient layout): B's reduction rows gathered
+// through p.b_idx (wave-uniform indices).
+template <bool AM, bool BMJ, int EPI, bool X2 = false, bool BIDX = false>
+__global__ __launch_bounds__(256, X2 ? 4 : 3) void gi_b3v_kernel(const GvBatch b) {
+    constexpr int NP = X2 ? 2 : 3;
+    constexpr int OPER = NP * GV_PLANE;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * OPER];
     unsigned char* const As = smem;
-    unsigned char* const Bs = smem + GV_OPER;
+    unsigned char* const Bs = smem + OPER;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lhi = lane >> 5;
 
@@ -114,6 +118,8 @@ __global__ __launch_bounds__(256, 3) void gi_b3v_kernel(const GvBatch b) {
     }
     const int nk = ke > kb ? (ke - kb + GV_BK - 1) / GV_BK : 0;
     const int n_full = ke > kb ? (ke - kb) / GV_BK : 0;
+    float sa = 1.f, ia = 1.f, sb = 1.f, ib = 1.f;               // fp16x2: per-tensor power-of-two scales
+    if (X2) { gx_scale(gx_amax_read(p.a_amax), sa, ia); gx_scale(gx_amax_read(p.b_amax), sb, ib); }
 
     // ---- staging coordinates -----------------------------------------------------------------------
     // contig operand: 8 float4 per 32-deep row -> c8 = tid & 7, rows (tid >> 3) + 32 i: 4 float4 per thread
@@ -189,24 +195,30 @@ __global__ __launch_bounds__(256, 3) void gi_b3v_kernel(const GvBatch b) {
             const int kr = k0 + 8 * wid;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int row = ST ? kr + j : min(kr + j, ke - 1);
+                int row = ST ? kr + j : min(kr + j, ke - 1);
+                if (BIDX) row = __builtin_amdgcn_readfirstlane(p.b_idx[row]);
                 mb[j] = *(const gv_f32x2_u*)((const char*)p.B + (size_t)row * (size_t)p.ldb * 4 + b_off[0]);
             }
         }
     };
     // 8 consecutive k of one row -> the three planes' 16-byte chunks
-    auto split8 = [&](const float (&x)[8], gv_u32x4& q0, gv_u32x4& q1, gv_u32x4& q2) __attribute__((always_inline)) {
-        unsigned a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;
+    auto split8 = [&](const float (&x)[8], float s, gv_u32x4& q0, gv_u32x4& q1, gv_u32x4& q2) __attribute__((always_inline)) {
+        unsigned a0, a1, a2 = 0, b0, b1, b2 = 0, c0, c1, c2 = 0, d0, d1, d2 = 0;
+        if (X2) {
+            gx_split2(x[0], x[1], s, a0, a1); gx_split2(x[2], x[3], s, b0, b1);
+            gx_split2(x[4], x[5], s, c0, c1); gx_split2(x[6], x[7], s, d0, d1);
+        } else {
         gv_split2(x[0], x[1], a0, a1, a2);
         gv_split2(x[2], x[3], b0, b1, b2);
         gv_split2(x[4], x[5], c0, c1, c2);
         gv_split2(x[6], x[7], d0, d1, d2);
+        }
         q0.x = a0; q0.y = b0; q0.z = c0; q0.w = d0;
         q1.x = a1; q1.y = b1; q1.z = c1; q1.w = d1;
         q2.x = a2; q2.y = b2; q2.z = c2; q2.w = d2;
     };
     auto store_contig = [&](auto steady_c, int kt, unsigned char* S, v4f (&r)[4], const unsigned (&w)[4], int cmax,
-                            int kend) __attribute__((always_inline)) {
+                            int kend, float scale) __attribute__((always_inline)) {
         constexpr bool ST = decltype(steady_c)::value;
         const int k0 = kb + kt * GV_BK;
 #pragma unroll
@@ -214,16 +226,19 @@ __global__ __launch_bounds__(256, 3) void gi_b3v_kernel(const GvBatch b) {
             v4f v = r[i];
             if (!ST) v = gi_fix4(v, k0 + 4 * c8, cmax, kend, true);
             gv_u32x2 w0, w1, w2;
-            unsigned x0, x1, x2, y0, y1, y2;
-            gv_split2(v.x, v.y, x0, x1, x2);
-            gv_split2(v.z, v.w, y0, y1, y2);
+            unsigned x0, x1, x2 = 0, y0, y1, y2 = 0;
+            if (X2) { gx_split2(v.x, v.y, scale, x0, x1); gx_split2(v.z, v.w, scale, y0, y1); }
+            else { gv_split2(v.x, v.y, x0, x1, x2); gv_split2(v.z, v.w, y0, y1, y2); }
             w0.x = x0; w0.y = y0; w1.x = x1; w1.y = y1; w2.x = x2; w2.y = y2;
             *reinterpret_cast<gv_u32x2*>(S + w[i]) = w0;
             *reinterpret_cast<gv_u32x2*>(S + GV_PLANE + w[i]) = w1;
-            *reinterpret_cast<gv_u32x2*>(S + 2 * GV_PLANE + w[i]) = w2;
+            if (!X2) *reinterpret_cast<gv_u32x2*>(S + 2 * GV_PLANE + w[i]) = w2;
         }
     };
-    auto store_major = [&](auto steady_c, int kt, unsigned char* S, gv_f32x2 (&m)[8], bool ones) __attribute__((always_inline)) {
+    auto store_major = [&](auto steady_c, int kt, unsigned char* S, gv_f32x2 (&m)[8], bool ones, float scale) __attribute__((always_inline)) {
+        // fp16x2: the ones column is staged as 1 / scale, i.e. exactly 1.0 AFTER the scale whatever the tensor's amax (the
+        // epilogue leaves that column's 1 / sb out)
+        const float one = X2 ? ib : 1.f;
         constexpr bool ST = decltype(steady_c)::value;
         const int kr = kb + kt * GV_BK + 8 * wid;
         float x[8], y[8];
@@ -231,8 +246,8 @@ __global__ __launch_bounds__(256, 3) void gi_b3v_kernel(const GvBatch b) {
         for (int j = 0; j < 8; ++j) {
             x[j] = m[j].x; y[j] = m[j].y;
             if (ones) {                                          // (block-uniform branch; lane-wise select)
-                x[j] = ones_j == 0 ? 1.f : x[j];
-                y[j] = ones_j == 1 ? 1.f : y[j];
+                x[j] = ones_j == 0 ? one : x[j];
+                y[j] = ones_j == 1 ? one : y[j];
             }
             if (!ST) {                                           // zero fill along the reduction (wave-uniform)
                 const bool ok = kr + j < ke;
@@ -246,22 +261,22 @@ __global__ __launch_bounds__(256, 3) void gi_b3v_kernel(const GvBatch b) {
         for (int j = 0; j < 8; ++j) { const float a = x[j], c = y[j]; x[j] = swp ? c : a; y[j] = swp ? a : c; }
         const int sw = swp ? 1 : 0;
         gv_u32x4 q0, q1, q2;
-        split8(x, q0, q1, q2);
+        split8(x, scale, q0, q1, q2);
         const unsigned o0 = gv_lds(0, wid, 2 * lane + sw);
         *reinterpret_cast<gv_u32x4*>(S + o0) = q0;
         *reinterpret_cast<gv_u32x4*>(S + GV_PLANE + o0) = q1;
-        *reinterpret_cast<gv_u32x4*>(S + 2 * GV_PLANE + o0) = q2;
-        split8(y, q0, q1, q2);
+        if (!X2) *reinterpret_cast<gv_u32x4*>(S + 2 * GV_PLANE + o0) = q2;
+        split8(y, scale, q0, q1, q2);
         const unsigned o1 = gv_lds(0, wid, 2 * lane + 1 - sw);
         *reinterpret_cast<gv_u32x4*>(S + o1) = q0;
         *reinterpret_cast<gv_u32x4*>(S + GV_PLANE + o1) = q1;
-        *reinterpret_cast<gv_u32x4*>(S + 2 * GV_PLANE + o1) = q2;
+        if (!X2) *reinterpret_cast<gv_u32x4*>(S + 2 * GV_PLANE + o1) = q2;
     };
     auto sstore = [&](auto steady_c, int kt) __attribute__((always_inline)) {
-        if (!AM) store_contig(steady_c, kt, As, ra, a_w, a_cmax, p.K);
-        else store_major(steady_c, kt, As, ma, false);
-        if (!BMJ) store_contig(steady_c, kt, Bs, rb, b_w, b_cmax, p.K);
-        else store_major(steady_c, kt, Bs, mb, tile_has_ones);
+        if (!AM) store_contig(steady_c, kt, As, ra, a_w, a_cmax, p.K, sa);
+        else store_major(steady_c, kt, As, ma, false, sa);
+        if (!BMJ) store_contig(steady_c, kt, Bs, rb, b_w, b_cmax, p.K, sb);
+        else store_major(steady_c, kt, Bs, mb, tile_has_ones, sb);
     };
 
     f32x16 acc[2][2];
@@ -281,21 +296,28 @@ __global__ __launch_bounds__(256, 3) void gi_b3v_kernel(const GvBatch b) {
                 const unsigned oa = gv_lds(0, 2 * s + lhi, wm * 64 + t * 32 + l31);
                 const unsigned ob = gv_lds(0, 2 * s + lhi, wn * 64 + t * 32 + l31);
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
+                for (int pl = 0; pl < NP; ++pl) {
                     af[t][pl] = *reinterpret_cast<const gv_bf16x8*>(As + pl * GV_PLANE + oa);
                     bf[t][pl] = *reinterpret_cast<const gv_bf16x8*>(Bs + pl * GV_PLANE + ob);
                 }
             }
             // smallest terms first; four independent accumulators between two MFMAs on the same one
             constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 1, 2, 0, 1, 0};
+            constexpr int XA[3] = {1, 0, 0}, XB[3] = {0, 1, 0};      // fp16x2: a2 b1 + a1 b2 + a1 b1
 #pragma unroll
-            for (int term = 0; term < 6; ++term)
+            for (int term = 0; term < (X2 ? 3 : 6); ++term)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int u = 0; u < 2; ++u)
-                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][TA[term]], bf[u][TB[term]],
-                                                                            acc[t][u], 0, 0, 0);
+                    for (int u = 0; u < 2; ++u) {
+                        if (X2)
+                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gx_f16x8, af[t][XA[term]]),
+                                                                               __builtin_bit_cast(gx_f16x8, bf[u][XB[term]]),
+                                                                               acc[t][u], 0, 0, 0);
+                        else
+                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t][TA[term]], bf[u][TB[term]],
+                                                                                acc[t][u], 0, 0, 0);
+                    }
         }
     };
 
@@ -335,6 +357,7 @@ __global__ __launch_bounds__(256, 3) void gi_b3v_kernel(const GvBatch b) {
             const int colc = col_ok ? col : p.N - 1;
             const int row0 = m0 + wm * 64 + t * 32 + 4 * lhi;
             const float bv = (flags & GI_EPI_BIAS) ? p.bias[colc] : 0.f;
+            const float ibc = (X2 && BMJ && col == p.ones_col) ? 1.f : ib;             // (the ones column was staged as 1 / sb)
             float av[16], cv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {                        // every load of the block before the first store
@@ -345,7 +368,7 @@ __global__ __launch_bounds__(256, 3) void gi_b3v_kernel(const GvBatch b) {
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float x = acc[t][u][r] + bv;
+                float x = X2 ? (acc[t][u][r] * ia) * ibc + bv : acc[t][u][r] + bv;    // (two steps: ia * ib alone may leave fp32's range)
                 if (flags & GI_EPI_SELU) x = gi_selu(x);
                 if (flags & GI_EPI_DSELU) x *= gi_selu_grad(av[r]);
                 if (flags & GI_EPI_MULACT) x *= av[r];
@@ -391,13 +414,24 @@ bool gi_b3v_eligible(const gi_gemm_params* probs, int n) {
     if (!gi_b3v_enable(-1)) return false;
     for (int i = 0; i < n; ++i) {
         const gi_gemm_params& p = probs[i];
-        if (!(p.flags & GI_GEMM_BF3) || (p.flags & (GI_GEMM_BF3A | GI_GEMM_X2))) return false;
+        if (!(p.flags & GI_GEMM_BF3) || (p.flags & GI_GEMM_BF3A)) return false;
+        // fp16x2 (round 6): the weight-gradient layout, every problem of the launch alike
+        if (((p.flags & GI_GEMM_X2) != 0) != ((probs[0].flags & GI_GEMM_X2) != 0)) return false;
+        if ((p.flags & GI_GEMM_X2) && !(p.a_major && p.b_major && p.a_amax && p.b_amax)) return false;
         if (p.a_major != probs[0].a_major || p.b_major != probs[0].b_major) return false;
         if (p.a_major && !p.b_major) return false;
         if (!p.b_major && !(p.flags & GI_GEMM_BF3B_F32)) return false;      // contig B must be plain fp32, not an image
-        if (p.a_idx || p.b_idx || p.k_dev) return false;
+        if (p.a_idx || p.k_dev) return false;
+        if (p.b_idx && !((p.flags & GI_GEMM_X2) && (p.flags & GI_GEMM_SPLITK))) return false;    // gathered B: fp16x2 slabs only
+        if ((p.b_idx != nullptr) != (probs[0].b_idx != nullptr)) return false;
     }
     return true;
+}
+// fp16x2 weight-gradient launches go to the pipelined 128 x 256 kernel (gi_gemm_b3p.hip) unless they ask for this one
+bool gi_b3v_wants(const gi_gemm_params* probs, int n) {
+    for (int i = 0; i < n; ++i)
+        if (!(probs[i].flags & GI_GEMM_T128)) return false;
+    return n > 0 && gi_b3v_eligible(probs, n);
 }
 
 int gi_b3v_launch(const gi_gemm_params* probs, int n, void* stream) {
@@ -417,10 +451,13 @@ int gi_b3v_launch(const gi_gemm_params* probs, int n, void* stream) {
         if (!p.ngroups && !p.C) return GI_EINVAL;
         if (splitk && (!am || !bmj || p.m_dev)) return GI_EINVAL;            // slabs: weight-gradient layout only
         if (p.ones_col >= 0 && (!bmj || p.ones_col != p.N - 1)) return GI_EINVAL;
-        const int f = p.flags & ~(GI_GEMM_BF3 | GI_GEMM_BF3B_F32 | GI_GEMM_SPLITK);
+        const int f = p.flags & ~(GI_GEMM_BF3 | GI_GEMM_BF3B_F32 | GI_GEMM_SPLITK | GI_GEMM_X2 | GI_GEMM_T128);
         if (f & ~(GI_EPI_BIAS | GI_EPI_SELU | GI_EPI_DSELU | GI_EPI_ACCUM | GI_EPI_MULACT)) return GI_EINVAL;
         if ((f & GI_EPI_BIAS) && !p.bias) return GI_EINVAL;
         if ((f & (GI_EPI_DSELU | GI_EPI_MULACT)) && !p.act) return GI_EINVAL;
+        if (((p.flags & GI_GEMM_X2) != 0) != ((probs[0].flags & GI_GEMM_X2) != 0)) return GI_EINVAL;
+        if ((p.flags & GI_GEMM_X2) && (!am || !bmj || !splitk || f != 0 || !p.a_amax || !p.b_amax)) return GI_EINVAL;
+        if ((p.b_idx != nullptr) != (probs[0].b_idx != nullptr) || (p.b_idx && !(p.flags & GI_GEMM_X2))) return GI_EINVAL;
         const long long lim = 0xffffffffLL / 4;
         const int bcols = p.ones_col >= 0 ? p.ones_col : p.N;
         if (!am) {
@@ -452,8 +489,18 @@ int gi_b3v_launch(const gi_gemm_params* probs, int n, void* stream) {
     for (int i = 0; i < k; ++i) bounded |= b.p[i].m_dev != nullptr;
     b.remap = (total >= 512 && !bounded && !am) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    GiProfScope prof(st, GI_PROF_GEMM | GI_PROF_PIPE_BF3, flops);
-    gi_gemm_log_launch(am ? "b2" : (bmj ? "b1" : "b0"), b.p, k, total, flops);
+    const bool x2 = (probs[0].flags & GI_GEMM_X2) != 0, bidx = probs[0].b_idx != nullptr;
+    GiProfScope prof(st, GI_PROF_GEMM | (x2 ? GI_PROF_PIPE_X2 : GI_PROF_PIPE_BF3), flops);
+    gi_gemm_log_launch(x2 ? "v2" : (am ? "b2" : (bmj ? "b1" : "b0")), b.p, k, total, flops);
+    if (x2) {                                            // (weight-gradient slabs: plain stores)
+        if (epi != 3) return GI_EINVAL;
+        // weight-gradient launches: consecutive tile ids = the tiles of ONE slab, which read the same rows of both
+        // operands — one XCD (one L2) per slab instead of eight (gi_gemm_b3p.hip)
+        if (total >= 16 && !bounded) b.remap = 1;
+        if (bidx) hipLaunchKernelGGL((gi_b3v_kernel<true, true, 3, true, true>), dim3(total), dim3(256), 0, st, b);
+        else hipLaunchKernelGGL((gi_b3v_kernel<true, true, 3, true, false>), dim3(total), dim3(256), 0, st, b);
+        return gi_launch_status();
+    }
 #define GV_LAUNCH(A, B, E) hipLaunchKernelGGL((gi_b3v_kernel<A, B, E>), dim3(total), dim3(256), 0, st, b)
     if (am) { if (epi == 3) GV_LAUNCH(true, true, 3); else GV_LAUNCH(true, true, 0); }
     else if (bmj) { if (epi == 2) GV_LAUNCH(false, true, 2); else GV_LAUNCH(false, true, 0); }

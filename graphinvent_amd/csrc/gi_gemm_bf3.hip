@@ -464,6 +464,7 @@ extern "C" int gi_bf3_pack(const gi_bf3_pack_desc* descs, int n, void* stream) {
 
 // gi_gemm_batch hands launches whose problems all carry GI_GEMM_BF3 to this launcher
 int gi_gemm_bf3_launch(const gi_gemm_params* probs, int n, void* stream) {
+    if (gi_b3v_wants(probs, n)) return gi_b3v_launch(probs, n, stream);        // GI_GEMM_T128: fp16x2 weight gradients, 128 x 128 tiles
     if (gi_b3p_eligible(probs, n)) return gi_b3p_launch(probs, n, stream);     // forward / dgrad: ping-pong kernel
     if (gi_b3v_eligible(probs, n)) return gi_b3v_launch(probs, n, stream);     // 32-deep tiles, all three layouts
     B3Batch b;

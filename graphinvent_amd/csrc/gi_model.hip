@@ -110,6 +110,10 @@ struct Ws {
     long long img_f[2], img_b[2], img_f_n[2], img_b_n[2], img_b_stride[2];
     long long chain_amax[2];            // fp16x2 chains: amax cells of the stack's weights, [layer][bond type] (gi_chain_params.x2_wamax)
     long long img_fx[2], chain_amax_f[2];   // the same for the FORWARD chain of the message rows (gi_chain_params.x2_rows32)
+    // fp16x2 weight gradients of the message / energy stacks (round 6): amax cells of their operands, published by the
+    // fp16x2 chain kernels — [pass][0: layer inputs X_l, 1: dZ_l][layer] (msg_cells)
+    long long msg_amax[2];
+    long long amax_pool;                // cells for weight-gradient operands nobody publishes a maximum of (AmaxPool)
     // AlphaDropout training mode: the workspace is allocated twice; float i of the second half holds
     // the backward factor d y / d z of activation i of the first (0: mode off)
     long long fshift;
@@ -122,6 +126,16 @@ struct Ws {
 
 bool chain_fits(const Mlp& q, int dx_cols);
 long long chain_image_floats(const Mlp& q, int groups, bool backward, long long* stride);
+// Round 6: EVERY weight-gradient problem of a backward can run as an fp16x2 launch.  Operands whose largest magnitude
+// no kernel publishes (GRU gate gradients, aggregated messages, h, the stacks' first / last layers, the graph-level
+// stacks at small batches) get it from one gi_absmax launch per hand-over, on the stream of the weight-gradient launches
+// and in front of them: a cell per distinct tensor from this pool, zeroed once per backward call.
+constexpr int AMAX_POOL_CELLS = 160;
+// amax cells of one pass of one stack family: [0: layer inputs, 1: dZ][layer]
+constexpr long long MSG_CELLS_PER_PASS = 2LL * GI_CHAIN_MAXL * GI_AMAX_WORDS;
+inline float* msg_cell(float* pass_base, int which, int layer) {
+    return pass_base ? pass_base + ((long long)which * GI_CHAIN_MAXL + layer) * GI_AMAX_WORDS : nullptr;
+}
 
 // Layers of the node-level readout stacks that run on the bf16 MFMA pipe (gi_gemm_bf3.hip: fp32 operands split
 // three ways, fp32 accumulate — the same result to ~3e-7): wide enough for 128 x 128 tiles in both directions.
@@ -278,16 +292,18 @@ void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
             w.img_f[k] = take(w.img_f_n[k], 1);
             w.img_b[k] = take(w.img_b_n[k], 1);
             w.chain_amax[k] = take((long long)GI_AMAX_WORDS * GI_CHAIN_MAXL * GI_MAX_GROUPS, 1);
-            w.img_fx[k] = take(w.img_f_n[k], 1);               // fp16x2 forward image (message rows; pass 0 stays fp32)
+            w.img_fx[k] = take(w.img_f_n[k], 1);               // fp16x2 forward image (every forward chain, pass 0 included)
             w.chain_amax_f[k] = take((long long)GI_AMAX_WORDS * GI_CHAIN_MAXL * GI_MAX_GROUPS, 1);
+            w.msg_amax[k] = take(MSG_CELLS_PER_PASS * (long long)d.passes, 1);
         }
     }
+    w.amax_pool = take((long long)AMAX_POOL_CELLS * GI_AMAX_WORDS, 1);
     w.fshift = d.dropout ? gi_r4l(o) : 0;
     w.total = d.dropout ? 2 * gi_r4l(o) : o;
 }
 
 // ---- wgrad slab plan ----------------------------------------------------------------------------
-struct SlabEntry { long long off, stride; int nsplit, calls, done, n_out, n_in, ld, tn, bidx, launched, reduced, bf3, single_last, sep; };   // sep: bias column by gi_bias_slabs, reduced with the last batch   // single_last: the last call wrote ONE slab (the pass-0 rows, defer_wgrad)
+struct SlabEntry { long long off, stride; int nsplit, calls, done, n_out, n_in, ld, tn, bidx, launched, reduced, bf3, single_last, sep, x2all; };   // x2all: fp16x2 launch when the call has (or can make) the operands' amax cells (plan_slabs)   // sep: bias column by gi_bias_slabs, reduced with the last batch   // single_last: the last call wrote ONE slab (the pass-0 rows, defer_wgrad)
 struct SlabPlan {
     SlabEntry e[160];
     long long total;
@@ -308,13 +324,49 @@ struct SlabPlan {
 // (ZINC shape 4.38 -> 4.34 ms).
 constexpr int BF3_WGRAD_SLAB_ROWS = 920, BF3_WGRAD_MIN_ROWS = 768, BF3_WGRAD_SHORT_SLAB_ROWS = 336;
 constexpr int BF3_WGRAD_SMALL_MIN = 16000;
-bool bf3_wgrad_ok(int n_out, int n_in, int red_rows) {
-    return bf3_enabled() && gi_b3p_enable(-1) && n_out >= BF3_MIN_WIDTH && n_in >= BF3_MIN_WIDTH &&
+bool bf3_wgrad_ok(int n_out, int n_in, int red_rows, int min_width = BF3_MIN_WIDTH) {
+    return bf3_enabled() && gi_b3p_enable(-1) && n_out >= min_width && n_in >= min_width &&
            red_rows >= BF3_WGRAD_MIN_ROWS;
 }
-int bf3_wgrad_nsplit(int red_rows, int decide_rows) {
-    const int L = decide_rows >= BF3_MIN_ROWS ? BF3_WGRAD_SLAB_ROWS : BF3_WGRAD_SHORT_SLAB_ROWS;
+int bf3_wgrad_nsplit(int red_rows, int decide_rows, int slab_rows = 0) {
+    const int L = slab_rows > 0 ? slab_rows : (decide_rows >= BF3_MIN_ROWS ? BF3_WGRAD_SLAB_ROWS : BF3_WGRAD_SHORT_SLAB_ROWS);
     return std::max(1, (red_rows + L / 2) / L);
+}
+// Round 6: the message / energy stacks' weight gradients as fp16x2 launches of gi_b3p_kernel.  What they lacked was the
+// largest magnitude of their operands (the stacks' activations and dZ, written by the chain kernels): the fp16x2 chain
+// kernels now publish them (gi_chain_layer.out_amax, gi_chain_params.x_amax) whenever BOTH directions of a stack run
+// on those kernels — 410 us of the 594-us weight-gradient queue that bounds the backward of the message passes
+// (profiles/r05) were these problems on the fp32 MFMA.  And every OTHER weight gradient too (wgrad_x2_all_possible):
+// operands without a publishing producer get their cell from gi_absmax (Run::AmaxPool).
+// Their launches are a few dozen workgroups each (250 x 251 outputs = two 128 x 256 tiles per slab), i.e. latency-bound:
+// SHORT slabs (GI_MSG_SLAB_ROWS, default below) trade slab traffic for workgroups.  GI_MSG_WGRAD_X2=0 / GI_WGRAD_X2_ALL=0:
+// as before.
+constexpr int X2ALL_MIN_WIDTH = 32, X2ALL_MIN_ROWS = 512;
+int msg_slab_rows() {
+    static const int v = getenv("GI_MSG_SLAB_ROWS") ? std::max(64, atoi(getenv("GI_MSG_SLAB_ROWS"))) : 460;
+    return v;
+}
+int x2all_slab_rows(int decide_rows) { return decide_rows >= BF3_MIN_ROWS ? msg_slab_rows() : BF3_WGRAD_SHORT_SLAB_ROWS; }
+bool msg_wgrad_x2_possible(const Model& m, bool call_x2);
+// MEASURED (round 6, profiles/r06/ab_wgrad_x2_all.txt) AND NOT THE DEFAULT: with every weight gradient on the 16-bit pipe the
+// headline step is 2.02 ms against 1.886 (the 128 x 128-tile kernel; 2.04-2.06 through the pipelined one): a launch
+// of either kernel is >= 30 us whatever its size (per workgroup ~2 us per 32-deep k tile: the fp32 -> 2 x fp16 split is
+// VALU work the small problems cannot hide), and the operands' gi_absmax passes add 15-40 us per hand-over, while the
+// fp32 kernel runs the same small problems as 1 500 light workgroups.  What IS on by default: the stacks' hidden layers
+// through the chain kernels' cells (msg_wgrad_x2_possible, -0.8 %), and the pool for round-4-rule problems that lack a
+// producer's cell (a wide first / last layer: fp16x2 instead of the spilling bf16x3 instantiation).
+bool wgrad_x2_all_enabled() {
+    static const int v = getenv("GI_WGRAD_X2_ALL") ? atoi(getenv("GI_WGRAD_X2_ALL")) : 0;
+    return v != 0;
+}
+bool wgrad_x2_pool_possible(const Model& m, bool call_x2) {
+    return !m.d.dropout && call_x2 && x2_enabled() && bf3_enabled() && gi_b3p_enable(-1);
+}
+bool wgrad_x2_all_possible(const Model& m, bool call_x2) { return wgrad_x2_all_enabled() && wgrad_x2_pool_possible(m, call_x2); }
+bool msg_wgrad_x2_possible(const Model& m, bool call_x2) {
+    static const int v = getenv("GI_MSG_WGRAD_X2") ? atoi(getenv("GI_MSG_WGRAD_X2")) : 1;
+    return v != 0 && !m.d.dropout && m.d.passes > 0 && chain_fwd_x2_enabled(call_x2) && gi_b3p_enable(-1) &&
+           chain_fits(m.msg[0], m.d.H) && (m.d.kind != GI_KIND_ATTGGNN || chain_fits(m.eatt[0], m.d.H));
 }
 
 // The bias gradient as its own launch (GiBiasSlab, gi_common.h) when the "ones" column would start a new column of
@@ -356,8 +408,12 @@ void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {   /
     long long o = 0;
     int maxEt = 0;
     for (int t = 0; t < d.Fe; ++t) maxEt = std::max(maxEt, Et ? Et[t] : E);
+    // x2all (round 6): a problem the round-4 rule leaves on the fp32 MFMA becomes an fp16x2 launch of gi_b3p_kernel when
+    // the call can give both operands an amax cell (defer_wgrad; without them it runs on the fp32 MFMA with THIS plan's
+    // slab count).  Such launches are a few dozen 128 x 256-tile workgroups, i.e. latency-bound: SHORT slabs.
+    const bool allx = wgrad_x2_all_possible(m, x2_enabled());
     auto add = [&](int widx, int bidx, int n_out, int n_in, int red, int calls, double share, bool bf3 = false,
-                   int decide_rows = -1) {
+                   int decide_rows = -1, bool gathered = false, bool chain_cells = false) {
         SlabEntry& e = sp.e[widx];
         e.bidx = bidx; e.launched = 0; e.reduced = 0;
         e.n_out = n_out; e.n_in = n_in; e.ld = gi_r4(n_in + 1); e.calls = calls; e.done = 0;
@@ -365,22 +421,32 @@ void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {   /
         if (decide_rows < 0) decide_rows = red;
         e.bf3 = bf3 && !d.dropout && bf3_wgrad_ok(n_out, n_in, decide_rows);
         if (e.bf3) e.nsplit = bf3_wgrad_nsplit(red, decide_rows);
+        e.x2all = 0;
+        if ((allx || chain_cells) && !e.bf3 && n_out >= X2ALL_MIN_WIDTH && n_in >= X2ALL_MIN_WIDTH && decide_rows >= X2ALL_MIN_ROWS &&
+            (!gathered || (allx && msg_wgrad_x2_possible(m, x2_enabled())))) {
+            e.x2all = 1;
+            e.nsplit = bf3_wgrad_nsplit(red, decide_rows, x2all_slab_rows(decide_rows));
+        }
         e.stride = gi_r4l((long long)n_out * e.ld);
         e.off = o;
         o += e.stride * e.nsplit * calls;
     };
-    auto add_mlp = [&](const Mlp& q, int red, int calls, double share = 1.0, bool bf3 = false, int decide_rows = -1) {
+    // stack: a message / energy stack — first layer gathered, the others' operand maxima published by the fp16x2 chains
+    const bool msg_cells = msg_wgrad_x2_possible(m, x2_enabled());
+    auto add_mlp = [&](const Mlp& q, int red, int calls, double share = 1.0, bool bf3 = false, int decide_rows = -1,
+                       bool stack = false) {
         for (int l = 0; l < q.layers(); ++l)
-            add(q.w(l), q.b(l), q.fan_out(l), q.fan_in(l), red, calls, share, bf3, decide_rows);
+            add(q.w(l), q.b(l), q.fan_out(l), q.fan_in(l), red, calls, share, bf3, decide_rows, stack && l == 0,
+                stack && l > 0 && msg_cells);
     };
     const int R = S + 1;
     for (int t = 0; t < d.Fe; ++t) {
         const int et = Et ? Et[t] : E / d.Fe;
         static const int force_msg = getenv("GI_B3W_MSG") ? atoi(getenv("GI_B3W_MSG")) : -1;   // (measurement aid)
         const bool m3 = force_msg >= 0 ? force_msg != 0 : E >= BF3_WGRAD_SMALL_MIN;
-        add_mlp(m.msg[t], et, d.passes, E > 0 ? 1.5 * (double)et / E : 1.0, m3, E);
+        add_mlp(m.msg[t], et, d.passes, E > 0 ? 1.5 * (double)et / E : 1.0, m3, E, true);
         if (d.kind == GI_KIND_ATTGGNN)
-            add_mlp(m.eatt[t], et, d.passes, E > 0 ? 1.5 * (double)et / E : 1.0, m3, E);
+            add_mlp(m.eatt[t], et, d.passes, E > 0 ? 1.5 * (double)et / E : 1.0, m3, E, true);
     }
     add(m.gru_wih, m.gru_bih, 3 * d.H, d.M, R, d.passes, 1.0);
     add(m.gru_whh, m.gru_bhh, 3 * d.H, d.H, R, d.passes, 1.0);
@@ -408,6 +474,17 @@ struct Run {
     float* img_fx[2] = {nullptr, nullptr};       // != null: the forward chain of the MESSAGE rows runs as row-independent fp16x2
     float* chain_amax_f[2] = {nullptr, nullptr}; // (gi_chain_params.x2_rows32) from this image / these cells; pass-0 rows: img_f
     long long img_b_stride[2] = {0, 0};
+    // amax cells of the CURRENT pass's message-row launches, per stack family (null: pass-0 class rows, fp32 chains,
+    // dropout): the fp16x2 chain kernels publish into them, defer_stack_wgrads hands them to the fp16x2
+    // weight-gradient launches (msg_cell)
+    float* msg_cells[2] = {nullptr, nullptr};
+    // weight-gradient operands without a published maximum (AMAX_POOL_CELLS): pool of cells in ws, the tensors that
+    // already have one in this call, the stream the pool lives on (zeroed there at first use)
+    struct AmaxPool {
+        float* base = nullptr; int used = 0; hipStream_t st = nullptr; bool zeroed = false;
+        struct Key { const float* x; int rows, cols, ld; float* cell; } have[AMAX_POOL_CELLS];
+    } pool;
+    bool wgrad_x2 = false;                  // this call: weight gradients without cells may take fp16x2 through the pool
     const struct Mlp* eatt0 = nullptr;      // identifies the energy stacks (second image)
     bool hold_kicks = false;                // no weight-gradient launches on the side stream for now
     bool p0_on_main = false;                // everything queued went to the side stream before the pass-0 dZ chain; the
@@ -620,10 +697,11 @@ struct Deferred {
     int widx[96][GI_MAX_GROUPS];     // weight indices each problem's slabs belong to
     int nw[96];
     unsigned char sep_bias[96];      // the problem's bias-gradient column is written by gi_bias_slabs, not by a ones column
+    unsigned char want_amax[96];     // fp16x2 problem whose a_amax (bit 0) / b_amax (bit 1) cell comes from the pool at launch time
     GiBiasSlab bias[160];            // ... collected over the whole backward, launched once (flush_bias)
     int nbias = 0;
     int n = 0;
-    gi_gemm_params& next() { gemm_defaults(p[n]); nw[n] = 0; sep_bias[n] = 0; return p[n++]; }
+    gi_gemm_params& next() { gemm_defaults(p[n]); nw[n] = 0; sep_bias[n] = 0; want_amax[n] = 0; return p[n++]; }
 };
 
 void flush_batch(Run& r, Batch& b, bool wgrad) {
@@ -720,7 +798,8 @@ gi_reduce_desc reduce_desc(const SlabEntry& e, float* slabs, float* const* grads
 }
 
 void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* widx, const Grp& g,
-                 const float* dZ, int lddz, const float* X, int ldx, const int* b_idx, int rows) {
+                 const float* dZ, int lddz, const float* X, int ldx, const int* b_idx, int rows,
+                 const float* dz_amax = nullptr, const float* x_amax = nullptr) {
     if (q.n == 96) flush_deferred(r, q);          // list full (very deep configurations only)
     gi_gemm_params& p = q.next();
     SlabEntry& e0 = sp.e[widx[0]];
@@ -735,11 +814,35 @@ void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* wid
     // nine ways the launch was 2 200 workgroups that mostly store zeros, 50 us + their share of the final reduction
     // behind the last dZ chain with nothing left to overlap (profiles/r04/x2/critical_path_amax_cells.txt)
     const bool one_slab = g.n && g.dim_slot == 2;
-    if (e0.bf3 && !b_idx && !one_slab) {                                    // bf16 pipe, 128 x 256 tiles (gi_gemm_b3p.hip)
-        p.flags |= GI_GEMM_BF3;
-        if (!g.n)
+    // Which arithmetic (plan_slabs chose the slab count; a launch is one arithmetic, launch_wgrad_batches sorts them):
+    //   bf3   (the round-4 rule: node-level hidden layers, message / graph-level stacks of big batches): 16-bit pipe;
+    //         fp16x2 when both operands have an amax cell — the producers' (node-level layers, the fp16x2 chains) or,
+    //         round 6, one from the pool (Run::AmaxPool: gi_absmax in front of the launch) — else bf16x3;
+    //   x2all (round 6: everything else that is big enough): fp16x2 under the same condition, else the fp32 MFMA with
+    //         the plan's slab count.
+    // A gathered B (the first layer of a message stack reads h[u_src]) needs published cells: the pool's gi_absmax
+    // would measure rows the launch does not read.
+    if ((e0.bf3 || e0.x2all) && !one_slab) {
+        const float* ca = dz_amax;
+        const float* cb = x_amax;
+        if (!g.n && !(ca && cb))
             if (const Run::Bf3* e = r.bf3_layer(r.P[widx[0]], rows))
-                if (e->amax && e->in_ok && e->dz_ok) { p.flags |= GI_GEMM_X2; p.a_amax = e->amax + 2 * GI_AMAX_WORDS; p.b_amax = e->amax + GI_AMAX_WORDS; }
+                if (e->amax) { if (e->dz_ok) ca = e->amax + 2 * GI_AMAX_WORDS; if (e->in_ok) cb = e->amax + GI_AMAX_WORDS; }
+        const bool pool = r.wgrad_x2 && !b_idx && (e0.bf3 || wgrad_x2_all_enabled());
+        if ((ca && cb) || pool) {
+            if (!b_idx || e0.x2all) {
+                p.flags |= GI_GEMM_BF3 | GI_GEMM_X2;
+                p.a_amax = ca; p.b_amax = cb;
+                q.want_amax[q.n - 1] = (ca ? 0 : 1) | (cb ? 0 : 2);
+                // which kernel: the pipelined 128 x 256 one (one workgroup per CU, ~30 us per launch whatever its size)
+                // for the big node-level problems, 128 x 128 tiles / 256 threads / 32 KB for the many small ones
+                // (GI_WGRAD_T128: 0 never, 1 the round-6 set, 2 every fp16x2 weight gradient)
+                static const int t128 = getenv("GI_WGRAD_T128") ? atoi(getenv("GI_WGRAD_T128")) : 0;
+                if (t128 == 2 || (t128 == 1 && !e0.bf3)) p.flags |= GI_GEMM_T128;
+            }
+        } else if (e0.bf3 && !b_idx) {
+            p.flags |= GI_GEMM_BF3;
+        }
     }
     const int slot = q.n - 1;
     if (!(p.flags & GI_GEMM_BF3) && !one_slab && wgrad_sep_bias(e0.n_in)) {   // plain n_out x n_in problem; db by gi_bias_slabs
@@ -779,15 +882,72 @@ void launch_wgrad_batch(Run& r, const gi_gemm_params* p, int n, hipStream_t st) 
     if (nb && r.ok()) r.chk(gi_gemm_batch(b, nb, st));
 }
 
+// The amax cells the queued fp16x2 problems still lack (Deferred::want_amax): one cell of the pool per distinct operand
+// tensor of this backward call, filled by gi_absmax launches on `st` in front of the GEMMs that read them.  A problem
+// the pool has no cell left for goes back to the fp32 MFMA (its slab count stays the plan's).
+void resolve_pool_amax(Run& r, gi_gemm_params* p, const unsigned char* want, int n, hipStream_t st) {
+    Run::AmaxPool& pool = r.pool;
+    gi_absmax_desc ad[GI_ABSMAX_MAX];
+    int na = 0;
+    auto flush = [&]() { if (na && r.ok()) r.chk(gi_absmax(ad, na, st)); na = 0; };
+    auto cell_of = [&](const float* x, int rows, int cols, int ld) -> float* {
+        for (int i = 0; i < pool.used; ++i) {
+            const Run::AmaxPool::Key& k = pool.have[i];
+            if (k.x == x && k.rows == rows && k.cols == cols && k.ld == ld) return k.cell;
+        }
+        if (!pool.base || pool.used >= AMAX_POOL_CELLS) return nullptr;
+        if (!pool.zeroed) {
+            r.chk((int)hipMemsetAsync(pool.base, 0, sizeof(float) * AMAX_POOL_CELLS * GI_AMAX_WORDS, st));
+            pool.zeroed = true; pool.st = st;
+        }
+        float* cell = pool.base + (long long)pool.used * GI_AMAX_WORDS;
+        pool.have[pool.used++] = Run::AmaxPool::Key{x, rows, cols, ld, cell};
+        if (na == GI_ABSMAX_MAX) flush();
+        ad[na].x = x; ad[na].rows = rows; ad[na].cols = cols; ad[na].ld = ld; ad[na].out = cell;
+        ++na;
+        return cell;
+    };
+    bool any = false;
+    for (int i = 0; i < n; ++i) any |= want && want[i];
+    if (!any) return;
+    if (pool.zeroed && pool.st != st) {            // (a second stream joins: order it behind the pool's kernels so far)
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) {
+            r.chk((int)hipEventRecord(e, pool.st));
+            r.chk((int)hipStreamWaitEvent(st, e, 0));
+            (void)hipEventDestroy(e);              // (destruction is deferred until the event has completed)
+        }
+        pool.st = st;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (!want[i]) continue;
+        gi_gemm_params& q = p[i];
+        const int bcols = q.ones_col >= 0 ? q.ones_col : q.N;
+        if ((want[i] & 1) && !q.a_amax) q.a_amax = cell_of(q.A, q.K, q.M, q.lda);       // dZ [rows, n_out]
+        if ((want[i] & 2) && !q.b_amax) q.b_amax = cell_of(q.B, q.K, bcols, q.ldb);     // X  [rows, n_in]
+        if (!q.a_amax || !q.b_amax) {              // pool exhausted
+            q.flags &= ~(GI_GEMM_BF3 | GI_GEMM_X2); q.a_amax = q.b_amax = nullptr;
+        }
+    }
+    flush();
+}
+
 // consecutive queued problems, up to 8 per launch; the bf16x3 ones (one workgroup per CU, equal tiles) are packed
 // separately, biggest first, into launches of about one round of the device
-void launch_wgrad_batches(Run& r, Deferred& dq, const gi_gemm_params* p, const unsigned char* sep, int n, hipStream_t st) {
-    gi_gemm_params rest[96], b3[2][96];                           // b3[0]: bf16x3, b3[1]: fp16x2 (a launch is one or the other)
-    int nr = 0, n3[2] = {0, 0};
+void launch_wgrad_batches(Run& r, Deferred& dq, const gi_gemm_params* p_in, const unsigned char* sep, int n, hipStream_t st) {
+    gi_gemm_params p[96];
+    for (int i = 0; i < n; ++i) p[i] = p_in[i];
+    resolve_pool_amax(r, p, dq.want_amax, n, st);
+    // b3[0]: bf16x3; fp16x2: b3[1 + 2 (128 x 128-tile kernel) + 1 (gathered B)] (a launch is ONE kernel instantiation)
+    gi_gemm_params rest[96], b3[5][96];
+    int nr = 0, n3[5] = {0, 0, 0, 0, 0};
     GiBiasSlab* const bias = dq.bias;
     int& nbias = dq.nbias;
     for (int i = 0; i < n; ++i) {
-        if (p[i].flags & GI_GEMM_BF3) { const int x = (p[i].flags & GI_GEMM_X2) ? 1 : 0; b3[x][n3[x]++] = p[i]; }
+        if (p[i].flags & GI_GEMM_BF3) {
+            const int x = (p[i].flags & GI_GEMM_X2) ? 1 + ((p[i].flags & GI_GEMM_T128) ? 2 : 0) + (p[i].b_idx ? 1 : 0) : 0;
+            b3[x][n3[x]++] = p[i];
+        }
         else rest[nr++] = p[i];
         if (sep && sep[i]) {                                      // bias-gradient column of this problem's slabs
             const gi_gemm_params& q = p[i];
@@ -813,13 +973,14 @@ void launch_wgrad_batches(Run& r, Deferred& dq, const gi_gemm_params* p, const u
         if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
         return c;
     }();
-    for (int x = 1; x >= 0; --x) {
+    for (int x = 4; x >= 0; --x) {
         gi_gemm_params* q = b3[x];
         for (int i = 1; i < n3[x]; ++i)                           // stable insertion sort, most tiles first
             for (int j = i; j > 0 && tiles(q[j]) > tiles(q[j - 1]); --j) std::swap(q[j], q[j - 1]);
+        const int cap = x >= 3 ? 1 << 30 : cus;                   // (the 128 x 128 kernel: several workgroups per CU, any size)
         for (int base = 0; base < n3[x] && r.ok();) {
             int k = 0, t = 0;
-            while (base + k < n3[x] && k < 8 && (k == 0 || t + tiles(q[base + k]) <= cus)) { t += tiles(q[base + k]); ++k; }
+            while (base + k < n3[x] && k < 8 && (k == 0 || t + tiles(q[base + k]) <= cap)) { t += tiles(q[base + k]); ++k; }
             r.chk(gi_gemm_batch(q + base, k, st));
             base += k;
         }
@@ -894,6 +1055,7 @@ void kick_deferred(Run& r, Deferred& q, SideStream* side, bool all) {
         q.p[i - n] = q.p[i];
         q.nw[i - n] = q.nw[i];
         q.sep_bias[i - n] = q.sep_bias[i];
+        q.want_amax[i - n] = q.want_amax[i];
         for (int k = 0; k < q.nw[i]; ++k) q.widx[i - n][k] = q.widx[i][k];
     }
     q.n -= n;
@@ -1096,11 +1258,14 @@ void chain_fwd_params(gi_chain_params& c, const Run& r, float* ws, const Mlp* ml
         c.x2_rows32 = 1;
     }
     c.skip_flag = r.skip;
+    float* const cells = (c.x2_rows32 && g.dim_slot != 2) ? r.msg_cells[mlps == r.eatt0 ? 1 : 0] : nullptr;
+    c.x_amax = msg_cell(cells, 0, 0);
     for (int l = 0; l < L; ++l) {
         gi_chain_layer& y = c.layer[l];
         y.K = q.fan_in(l); y.N = q.fan_out(l);
         y.out = (l == L - 1) ? final_dst : ws + acts[l];
         y.ldo = (l == L - 1) ? ld_final : ldh;
+        if (l < L - 1) y.out_amax = msg_cell(cells, 0, l + 1);      // = the input of layer l + 1
         for (int t = 0; t < g.n; ++t) { y.W[t] = r.P[mlps[t].w(l)]; y.bias[t] = r.P[mlps[t].b(l)]; }
     }
 }
@@ -1124,12 +1289,15 @@ int chain_bwd_params(gi_chain_params& c, const Run& r, float* ws, const Mlp* mlp
         if (bwd_x2r && c.x2_wamax) c.x2_rows32 = 1;
     }
     chain_groups(c, g, rows);
+    float* const cells = (c.x2_wamax && g.dim_slot != 2) ? r.msg_cells[mlps == r.eatt0 ? 1 : 0] : nullptr;
+    c.x_amax = msg_cell(cells, 1, L - 1);                   // Zlast = dZ of the last layer
     int n = 0;
     for (int l = L - 1; l >= 0; --l) {
         if (l == 0 && !dX) break;
         gi_chain_layer& y = c.layer[n++];
         y.K = q.fan_out(l);
         y.N = (l == 0) ? dx_cols : q.fan_in(l);
+        if (l > 0) y.out_amax = msg_cell(cells, 1, l - 1);   // this layer writes dZ of layer l - 1
         // W_l is [fan_out][fan_in] row-major: for l == 0 only its leading dx_cols columns are used,
         // which needs fan_in == dx_cols (rows are read with stride N)
         y.out = (l == 0) ? dX : ws + dzs[l - 1];
@@ -1154,8 +1322,9 @@ void defer_stack_wgrads(Run& r, float* ws, SlabPlan& sp, float* slabs, Deferred&
         const float* Xl = (l == 0) ? X : ws + acts[l - 1];
         int widx[GI_MAX_GROUPS];
         for (int t = 0; t < g.n; ++t) widx[t] = mlps[t].w(l);
+        float* const cells = g.dim_slot != 2 ? r.msg_cells[mlps == r.eatt0 ? 1 : 0] : nullptr;
         defer_wgrad(r, dq, sp, slabs, widx, g, dZ, lddz, Xl, l == 0 ? ldx : ldh,
-                    l == 0 ? a_idx : nullptr, rows);
+                    l == 0 ? a_idx : nullptr, rows, msg_cell(cells, 1, l), msg_cell(cells, 0, l));
     }
 }
 
@@ -1521,6 +1690,22 @@ extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* pa
         r.chk((int)hipStreamWaitEvent(fside.st, start, 0));
         prep = fside.st;
     }
+    // amax cells of the message / energy stacks' activations (this forward's chains publish into them, the backward's
+    // chains add the dZ maxima, its fp16x2 weight gradients read both): zeroed first thing on the side stream
+    const bool msgx = E > 0 && d.passes > 0 && msg_wgrad_x2_possible(m, r.x2);
+    float* msg_cells_base[2] = {nullptr, nullptr};
+    hipEvent_t msg_cells_ready = nullptr;
+    if (msgx) {
+        for (int k = 0; k < (attn ? 2 : 1); ++k)
+            if (w.img_f_n[k] > 0 && r.img_fx[k]) {
+                msg_cells_base[k] = ws + w.msg_amax[k];
+                r.chk((int)hipMemsetAsync(msg_cells_base[k], 0, sizeof(float) * MSG_CELLS_PER_PASS * d.passes, prep));
+            }
+        if (side_stream) {
+            msg_cells_ready = fside.next();
+            r.chk((int)hipEventRecord(msg_cells_ready, fside.st));
+        }
+    }
     if ((run_flags & GI_RUN_PREPACK_BWD) && !r.drop) {
         bf3_prepare(r, m, ws, w, true, R, BF3_DO_PACK, prep);
         if (d.passes > 0 && E > 0)
@@ -1568,6 +1753,12 @@ extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* pa
     for (int p = 0; p < d.passes; ++p) {
         const float* hx = ws + w.hx[p];
         r.pass = p;
+        for (int k = 0; k < 2; ++k)     // (pass 0 on the class rows: one-slab fp32 weight gradients, no cells)
+            r.msg_cells[k] = (msg_cells_base[k] && !(p == 0 && w.D0 > 0)) ? msg_cells_base[k] + p * MSG_CELLS_PER_PASS : nullptr;
+        if (msg_cells_ready && (r.msg_cells[0] || r.msg_cells[1])) {
+            r.chk((int)hipStreamWaitEvent(r.st, msg_cells_ready, 0));    // (zeroed ~100 us ago: never stalls)
+            msg_cells_ready = nullptr;
+        }
         if (p == 0 && p0cache) {
             r.chk(gi_p0_cache_lookup(gfix, d.B, d.N, d.Fe, p0c, attn ? 2 : 1, ws + w.m[0],
                                      attn ? ws + w.een[0] : nullptr, w.ldM, r.st));
@@ -1771,6 +1962,8 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
     SideStream* const passes_side = side_stream ? &side_obj : nullptr;
     r.side = passes_side;
     r.sp = &sp; r.slabs = slabs; r.grads = grads;
+    r.wgrad_x2 = wgrad_x2_pool_possible(m, r.x2);
+    r.pool.base = r.wgrad_x2 ? ws + w.amax_pool : nullptr;
     const Grp none{0, nullptr, 0};
     const float* hxP = ws + w.hx[d.passes];
     float* dh = ws + w.dh;
@@ -1906,7 +2099,10 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
     const bool fuse_scatter = (gi_fuse_flags() & GI_FUSE_DH_SCATTER) && (d.H & 3) == 0 && d.H >= 4;
     const float* scat0 = nullptr;
     const float* scat1 = nullptr;
+    const bool msgx = E > 0 && msg_wgrad_x2_possible(m, r.x2) && chain_x2_enabled(r.x2);
     for (int p = d.passes - 1; p >= 0; --p) {
+        for (int k = 0; k < (attn ? 2 : 1); ++k)   // the cells this pass's forward chains published into (gi_ggnn_forward_ex)
+            r.msg_cells[k] = (msgx && w.img_b_n[k] > 0 && !(p == 0 && w.D0 > 0)) ? ws + w.msg_amax[k] + p * MSG_CELLS_PER_PASS : nullptr;
         const float* hx = ws + w.hx[p];
         float* gi = ws + w.gi[p];
         float* gh = ws + w.gh[p];

@@ -1449,11 +1449,29 @@ __global__ __launch_bounds__(256) void absmax_kernel(const AbsmaxArgs a) {
     }
     gx_amax_publish(m, d.out);
 }
-// rows with a pitch (ld > cols): one row per workgroup pass
-__global__ __launch_bounds__(256) void absmax_rows_kernel(const gi_absmax_desc d) {
+// rows with a pitch (ld > cols; the padding columns are never written: masked): ALL such tensors of a call in one launch,
+// a workgroup = a block of whole rows of one tensor, 2 048 float4 slots (round 6: one launch per tensor, one row per
+// workgroup pass and scalar loads cost ~10 us per activation tensor — the weight-gradient operands' cells, gi_model.hip)
+__global__ __launch_bounds__(256) void absmax_pitched_kernel(const AbsmaxArgs a) {
+    int i = 0;
+    while (i < a.n - 1 && (int)blockIdx.x >= a.start[i + 1]) ++i;
+    const gi_absmax_desc& d = a.d[i];
+    const int cols4 = (d.cols + 3) >> 2;
+    const int rpw = max(1, 2048 / cols4);                               // rows per workgroup
+    const int row0 = ((int)blockIdx.x - a.start[i]) * rpw;
+    const int nrows = min(rpw, d.rows - row0);
+    const bool vec = (((uintptr_t)d.x & 15) == 0) && (d.ld & 3) == 0;
     float m = 0.f;
-    for (int r = blockIdx.x; r < d.rows; r += gridDim.x)
-        for (int c = threadIdx.x; c < d.cols; c += 256) m = fmaxf(m, fabsf(d.x[(long long)r * d.ld + c]));
+    for (int slot = threadIdx.x; slot < nrows * cols4; slot += 256) {
+        const int r = slot / cols4, c = 4 * (slot - r * cols4);
+        const float* src = d.x + (long long)(row0 + r) * d.ld + c;
+        if (vec && c + 3 < d.cols) {
+            const v4f v = *reinterpret_cast<const v4f*>(src);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        } else {
+            for (int q = 0; q < 4 && c + q < d.cols; ++q) m = fmaxf(m, fabsf(src[q]));
+        }
+    }
     gx_amax_publish(m, d.out);
 }
 // ---- bias-gradient column of weight-gradient slabs (GiBiasSlab, gi_common.h) ----------------------------------------
@@ -1622,16 +1640,20 @@ extern "C" int gi_host_flag_destroy(int* host) {
 extern "C" int gi_absmax(const gi_absmax_desc* descs, int n, void* stream) {
     (void)hipGetLastError();
     if (!descs || n < 1 || n > GI_ABSMAX_MAX) return GI_EINVAL;
-    AbsmaxArgs a;
+    AbsmaxArgs a, ap;
     memset(&a, 0, sizeof(a));
-    int total = 0, k = 0;
+    memset(&ap, 0, sizeof(ap));
+    int total = 0, k = 0, ptotal = 0, pk = 0;
     for (int i = 0; i < n; ++i) {
         const gi_absmax_desc& d = descs[i];
         if (!d.x || !d.out || d.rows < 0 || d.cols < 0 || d.ld < d.cols) return GI_EINVAL;
         const long long elems = (long long)d.rows * d.cols;
         if (elems == 0) continue;
-        if (d.ld != d.cols && d.rows > 1) {                  // pitched rows: their own small launch
-            hipLaunchKernelGGL(absmax_rows_kernel, dim3(std::min(d.rows, 1024)), dim3(256), 0, (hipStream_t)stream, d);
+        if (d.ld != d.cols && d.rows > 1) {                  // pitched rows: one launch for all of them
+            const int rpw = std::max(1, 2048 / ((d.cols + 3) / 4));
+            ap.d[pk] = d; ap.start[pk] = ptotal;
+            ptotal += gi_cdiv(d.rows, rpw);
+            ++pk;
             continue;
         }
         if (elems > 0x7fffffffLL * 64) return GI_ELIMIT;
@@ -1642,6 +1664,8 @@ extern "C" int gi_absmax(const gi_absmax_desc* descs, int n, void* stream) {
         ++k;
     }
     a.start[k] = total; a.n = k;
+    ap.start[pk] = ptotal; ap.n = pk;
     if (total > 0) hipLaunchKernelGGL(absmax_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, a);
+    if (ptotal > 0) hipLaunchKernelGGL(absmax_pitched_kernel, dim3(ptotal), dim3(256), 0, (hipStream_t)stream, ap);
     return gi_launch_status();
 }

@@ -27,6 +27,7 @@ EPI_BIAS, EPI_SELU, EPI_DSELU, EPI_ACCUM, GEMM_SPLITK = 1, 2, 4, 8, 16
 EPI_MULACT = 64
 GEMM_BF3A, GEMM_BF3B_F32 = 256, 512       # with GEMM_BF3: A is an image too / B is the plain fp32 matrix
 AMAX_WORDS = 2048     # floats of an amax cell (include/graphinvent_amd.h GI_AMAX_WORDS)
+GEMM_T128 = 2048      # with GEMM_BF3 | GEMM_X2, weight-gradient layout: the 128 x 128-tile kernel (gi_gemm_b3v.hip)
 GEMM_X2 = 1024        # with GEMM_BF3 and fp32 operands: two scaled fp16 planes per operand, three products (needs a_amax / b_amax)
 GEMM_BF3 = 128        # GI_GEMM_BF3: B is a gi_bf3_pack image; the launch runs as bf16x3 splits on the bf16 MFMA pipe
 KIND_GGNN, KIND_ATTGGNN = 0, 1

@@ -30,6 +30,15 @@
  *       GI_CHAIN_X2=0           only the dZ chains back on the fp32 chain kernel (gi_chain_params.x2_wamax unused)
  *       GI_CHAIN_FWD_X2=0       only the FORWARD chains back on the fp32 chain kernel (default: the row-independent
  *                               fp16x2 kernel, gi_chain_params.x2_rows32)
+ *       GI_WGRAD_X2_ALL=1       (round 6; measured slower, off by default) EVERY weight gradient of at least 32 x 32 outputs
+ *                               over >= 512 rows as an fp16x2 launch; operands nobody publishes a maximum of get their amax
+ *                               cell from gi_absmax in front of the launch.  Default: the round-4 set + the message / energy
+ *                               stacks' hidden layers (cells published by the fp16x2 chain kernels)
+ *                               GI_WGRAD_T128=0 / 1 / 2: none (default) / the round-6 set / all fp16x2 weight gradients on the
+ *                               128 x 128-tile kernel of gi_gemm_b3v.hip (GI_GEMM_T128) instead of the pipelined 128 x 256 one
+ *       GI_MSG_WGRAD_X2=0       the fp16x2 chain kernels' amax cells are not used for the message / energy stacks' weight
+ *                               gradients (their first, gathered layer then stays on the fp32 MFMA);
+ *                               GI_MSG_SLAB_ROWS=<n>: reduction rows per split-K slab of the new launches (default 460)
  *       GI_GEMM_LOG=<file>      one line per GEMM launch (tools/gemm_launch_report.py)
  *     and measurement aids that pick between kernels / schedules that compute the same thing (the A/B files under
  *     profiles/r04 name them): GI_B3P, GI_B3V, GI_B3P_ALL, GI_B3P_STREAM, GI_B3V_GROUPED (which 16-bit-pipe kernel),
@@ -211,6 +220,9 @@ int gi_host_flag_destroy(int* host);
                               it is staged like A: no image, 4 bytes per element through L2 instead of 6 */
 #define GI_GEMM_BF3A   256 /* with GI_GEMM_BF3: A is a pre-split bf16 image too ([3][M][Kp], gi_bf3_pack of an [M, K]
                               matrix or the `planes` output of a producing launch); no a_idx */
+#define GI_GEMM_T128  2048 /* with GI_GEMM_BF3 | GI_GEMM_X2, weight-gradient layout: prefer the 128 x 128-tile kernel (256 threads,
+                              32 KB of LDS, several workgroups per CU: gi_gemm_b3v.hip) to the software-pipelined
+                              128 x 256-tile one (one 512-thread workgroup per CU) — launches of many small problems */
 #define GI_GEMM_X2    1024 /* with GI_GEMM_BF3 and plain fp32 operands: split every operand into TWO scaled fp16 values
                               instead of three bf16 (csrc/gi_x2.h): three f16 MFMA products per fp32 product instead of
                               six, the same ~3e-7 distance from the fp64 product.  Needs the largest magnitude of both

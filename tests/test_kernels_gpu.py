@@ -427,6 +427,74 @@ def test_every_gemm_route_publishes_c_amax(route, layout, bf3_kernel_switches):
     assert float(cell.max()) == float(Y[:, :N].abs().max())
 
 
+@pytest.mark.parametrize("kernel", ["b3p", "t128"])
+@pytest.mark.parametrize("gather", [False, True])
+@pytest.mark.parametrize("rows,n_out,n_in,nsplit", [(7111, 250, 250, 16), (1300, 384, 128, 3), (517, 257, 129, 5), (600, 128, 250, 2),
+                                                    (40, 130, 200, 2)])
+def test_gemm_fp16x2_weight_gradient_layout_both_kernels_gathered_and_grouped(rows, n_out, n_in, nsplit, gather, kernel,
+                                                                              bf3_kernel_switches):
+    """[dW | db] = dZ^T [X | 1] as fp16x2 launches (round 6: EVERY weight gradient of the model can take this form): the
+    pipelined 128 x 256 kernel (gi_gemm_b3p.hip) and the 128 x 128-tile kernel (gi_gemm_b3v.hip, GI_GEMM_T128); plain
+    split-K slabs and bond-type groups (three groups, the middle one empty, own slab counts); X rows read as stored or
+    gathered through b_idx (the first layer of a message stack reads h[u_src]); the ones column exactly 1.0 whatever the
+    tensor's scale; dZ of magnitude 1e-3, X of magnitude 30.  Against the fp64 product at 2e-6 of max |ref|; slab tails
+    beyond the reduction range exactly zero, nothing written outside [n_out, n_in + 1]."""
+    lib = bf3_kernel_switches
+    lib.gi_b3p_enable(1); lib.gi_b3v_enable(1)
+    g = torch.Generator().manual_seed(rows + n_out + n_in + (7 if gather else 0))
+    lddz, ldx, ldc = ops.r4(n_out) + 4, ops.r4(n_in), ops.r4(n_in + 1) + 4
+    dZ = torch.randn(rows, lddz, generator=g) * 1e-3; dZ[:, n_out:] = float("nan")
+    src_rows = 900 if gather else rows
+    Xs = torch.randn(src_rows, ldx, generator=g) * 30
+    idx = torch.randint(0, src_rows, (rows,), generator=g, dtype=torch.int32) if gather else None
+    X = Xs[idx.long()] if gather else Xs
+    cells = torch.zeros(2, L.AMAX_WORDS, device=DEV)
+    ops.absmax([dZ[:, :n_out].to(DEV)], cells[0:1])
+    ops.absmax([X[:, :n_in].contiguous().to(DEV)], cells[1:2])
+    F = L.GEMM_SPLITK | L.GEMM_BF3 | L.GEMM_X2 | (L.GEMM_T128 if kernel == "t128" else 0)
+    stride = ops.r4(n_out * ldc)
+    common = dict(flags=F, a_major=True, b_major=True, ones_col=n_in, c_split_stride=stride, a_amax=cells[0], b_amax=cells[1],
+                  b_idx=idx.to(DEV) if gather else None)
+    # plain slabs
+    C = torch.full((nsplit, stride), 7.0, device=DEV)
+    ops.gemm(dZ.to(DEV), Xs.to(DEV), C, n_out, n_in + 1, rows, lddz, ldx, ldc, nsplit=nsplit, **common)
+    S = C[:, :n_out * ldc].view(nsplit, n_out, ldc)
+    ref = torch.cat([dZ[:, :n_out].double().t() @ X[:, :n_in].double(), dZ[:, :n_out].double().sum(0)[:, None]], 1)
+    assert bool((S[:, :, n_in + 1:] == 7.0).all())
+    assert rel(S[:, :, :n_in + 1].double().sum(0).cpu(), ref) < 2e-6
+    # grouped: rows [0, a) | empty | [a, rows), slab counts 2 / 1 / nsplit
+    a = rows // 3
+    off = torch.tensor([0, a, a, rows], dtype=torch.int32)
+    gs = (2, 1, nsplit)
+    Cg = [torch.full((n, stride), 7.0, device=DEV) for n in gs]
+    ops.gemm(dZ.to(DEV), Xs.to(DEV), None, n_out, n_in + 1, rows, lddz, ldx, ldc, grp_off=off.to(DEV), ngroups=3, Cg=Cg,
+             gsplit=gs, **common)
+    for t, (lo, hi) in enumerate(((0, a), (a, a), (a, rows))):
+        St = Cg[t][:, :n_out * ldc].view(gs[t], n_out, ldc)
+        rt = torch.cat([dZ[lo:hi, :n_out].double().t() @ X[lo:hi, :n_in].double(), dZ[lo:hi, :n_out].double().sum(0)[:, None]], 1)
+        assert bool((St[:, :, n_in + 1:] == 7.0).all()), t
+        got = St[:, :, :n_in + 1].double().sum(0).cpu()
+        assert float((got - rt).abs().max()) <= 2e-6 * max(float(ref.abs().max()), 1e-30), t
+
+
+def test_absmax_of_pitched_tensors_in_one_launch_ignores_the_padding_columns():
+    """gi_absmax on activation-like tensors (row pitch > columns, padding columns never written — NaN here): every
+    tensor's cell == max |x| over its real columns; odd column counts, unaligned bases, a single row, many rows."""
+    g = torch.Generator().manual_seed(2)
+    specs = [(7111, 250, 252), (1000, 501, 504), (3, 37, 40), (1, 128, 136), (513, 129, 132), (2048, 3, 4)]
+    ts = []
+    for rows, cols, ld in specs:
+        t = torch.randn(rows, ld, generator=g) * (1 + len(ts))
+        t[:, cols:] = float("nan")
+        ts.append(t.to(DEV)[:, :cols])
+    base = torch.randn(50, 24, generator=g).to(DEV)
+    ts.append(base[:, 1:20])                                       # base not 16-byte aligned
+    cells = torch.zeros(len(ts), L.AMAX_WORDS, device=DEV)
+    ops.absmax(ts, cells)
+    for i, t in enumerate(ts):
+        assert float(cells[i].max()) == float(t.abs().max()), i
+
+
 def test_gemm_fp16x2_needs_both_amax_cells():
     X = torch.randn(256, 64, device=DEV); W = torch.randn(128, 64, device=DEV); Y = torch.zeros(256, 128, device=DEV)
     with pytest.raises(RuntimeError, match="GI_EINVAL"):
