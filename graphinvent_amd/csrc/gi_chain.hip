@@ -67,6 +67,13 @@ struct ChainArgs {
     int remap;
     int dbg;                                // TIMING-ONLY lab switches of the fp16x2 kernel (GI_DBG_X2 bit mask; results wrong)
 };
+// The TIMING-ONLY lab switches (results wrong) exist in a lab build only (make EXTRA=-DGI_CHAIN_X2_LAB): release kernels
+// carry no such branches (round-5 advisor).
+#ifdef GI_CHAIN_X2_LAB
+#define CH_DBG(m) (args.dbg & (m))
+#else
+#define CH_DBG(m) 0
+#endif
 __device__ __forceinline__ int chain_block_id(const ChainArgs& a, int bid) {
     const int total = a.chain_off[a.nchains];
     if (!a.remap || (int)gridDim.x != total) return bid;
@@ -253,9 +260,9 @@ __global__ __launch_bounds__(512) void gi_chain_kernel(const ChainArgs args) {
         const int coff = col_ok ? 4 * col : 0x40000000;     // beyond any tile: dropped / reads 0
         float av[RB][16];
         const bool dselu = BWD && Ly.act != nullptr;
-        if (dselu && (args.dbg & 1)) {
+        if (dselu && CH_DBG(1)) {
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) av[rb][r] = 1.f;
         } else
@@ -653,7 +660,7 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
         const gi_chain_layer& Ly = P.layer[l];
         const int col = wid * 32 + l31;
         const int coff = col < Ly.N ? 4 * col : 0x40000000;
-        if (args.dbg & 1) {
+        if (CH_DBG(1)) {
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -701,7 +708,7 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
         if (Ly.out_amax && tid == 0) cx_amax_publish_wg(wg_max_from_lds(), Ly.out_amax);   // for the stack's fp16x2 weight gradients
-        if (l + 1 < L && !(args.dbg & 4)) {                  // next layer's A operand: split, in place
+        if (l + 1 < L && !CH_DBG(4)) {                  // next layer's A operand: split, in place
             gx_scale(wg_max_from_lds(), sa, ia);
             // A lane holds ONE column of 16 rows per row block: written one by one that is 64 two-byte stores per
             // thread into 8 of the 32 banks (round 4: 45 % of the kernel's LDS cycles were bank conflicts).  Neighbouring
@@ -728,7 +735,7 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the new planes are written (no barrier in the k loop)
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(Ly.out + (long long)r0 * ldo), 0, nvalid * ldo * 4, 0x00020000);
-        if (!(args.dbg & 2))
+        if (!CH_DBG(2))
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -798,7 +805,9 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
     // before the wait of step s the youngest four are tiles s + 1 and s + 2, so "at most 4 outstanding" means tile s is
     // complete.  An epilogue drains everything (vmcnt(0): tiles up to s + 3 are in LDS) and leaves <= 36 stores and (dZ
     // chain) the next layer's 32 activation loads in flight; the three steps after it need no load to complete, and
-    // waiting for those (older than the 2 + 2 loads issued since) would only stall: "at most 60" (the counter's range).
+    // waiting for those (older than the 2 + 2 loads issued since) would only stall: "at most 60".  (vmcnt is a 6-bit counter: with 36 stores + 32 prefetch loads + 4 DMA pieces
+    // in flight more than 63 operations can be outstanding — the counter then saturates and vmcnt(60) waits for the oldest
+    // few, which only delays issue; correctness does not depend on it: the tile a step reads was drained by the epilogue.)
 #define GI_CHAIN_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory")
     int l = 0, kt = 0, nk = (P.layer[0].K + CX_KT - 1) / CX_KT, lN = P.layer[0].N;
     int since_epi = 3;
@@ -807,7 +816,7 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
         since_epi = __builtin_amdgcn_readfirstlane(since_epi + 1);
         dma_tile(s + 3);
         const int slot = s & (CX_RING - 1);
-        if (swid * 32 < __builtin_amdgcn_readfirstlane(lN) && !(args.dbg & 8)) {
+        if (swid * 32 < __builtin_amdgcn_readfirstlane(lN) && !CH_DBG(8)) {
             read_frags(slot, kt, af, bf);
             __builtin_amdgcn_sched_barrier(0);
             mma(af, bf);
@@ -815,7 +824,7 @@ __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) 
         }
         kt = __builtin_amdgcn_readfirstlane(kt + 1);
         if (kt == __builtin_amdgcn_readfirstlane(nk)) {       // layer done
-            if (args.dbg & 16) {                              // (lab: no epilogue at all)
+            if (CH_DBG(16)) {                              // (lab: no epilogue at all)
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __syncthreads();
             } else
@@ -996,7 +1005,7 @@ __global__ __launch_bounds__(512, DUAL ? 4 : 1) void gi_chain_x2r_kernel(const C
         // vmcnt arithmetic of the k loop assumes.
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         // Part two: the row's planes for the next layer (its own scale), its outputs
-        const bool more = l + 1 < L && !(args.dbg & 8);      // (lab bit 8: no rewrite of the activation planes)
+        const bool more = l + 1 < L && !CH_DBG(8);      // (lab bit 8: no rewrite of the activation planes)
         if (more) {
             row_scale_from_lds(l31, sa, ia);
 #pragma unroll
@@ -1023,7 +1032,7 @@ __global__ __launch_bounds__(512, DUAL ? 4 : 1) void gi_chain_x2r_kernel(const C
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the new planes are written (the output tile is staged)
         if (Ly.out_amax && swid == 0 && lane == 0) cx_amax_publish_wg(blk_max, Ly.out_amax);
-        if (!(args.dbg & 16)) {
+        if (!CH_DBG(16)) {
             if (DUAL) {                                      // the lane's 4 x 4 channels of its row straight to HBM
                 if (live) {
                     float* orow = Ly.out + (long long)(r0 + l31) * ldo;
@@ -1134,20 +1143,20 @@ __global__ __launch_bounds__(512, DUAL ? 4 : 1) void gi_chain_x2r_kernel(const C
         if (__builtin_amdgcn_readfirstlane(since_epi) < (DUAL ? 2 : 3)) { GI_CHAIN_WAIT(60); }
         else if (DUAL) { GI_CHAIN_WAIT(2); } else { GI_CHAIN_WAIT(4); }
         since_epi = __builtin_amdgcn_readfirstlane(since_epi + 1);
-        if (!DUAL && !(args.dbg & 1)) dma_tile(s + 3);
+        if (!DUAL && !CH_DBG(1)) dma_tile(s + 3);
         const int slot = s & (RING - 1);
         const bool active = swid * 32 < __builtin_amdgcn_readfirstlane(lN);
-        if (active && !(args.dbg & 2)) read_frags(slot, kt);
+        if (active && !CH_DBG(2)) read_frags(slot, kt);
         if (DUAL) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers: the slot is free
-            if (!(args.dbg & 1)) dma_tile(s + 2);
+            if (!CH_DBG(1)) dma_tile(s + 2);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (active && !(args.dbg & 4)) mma();
+        if (active && !CH_DBG(4)) mma();
         __builtin_amdgcn_sched_barrier(0);
         kt = __builtin_amdgcn_readfirstlane(kt + 1);
         if (kt == __builtin_amdgcn_readfirstlane(nk)) {       // layer done
-            if (args.dbg & 32) {                              // (lab: no epilogue at all)
+            if (CH_DBG(32)) {                              // (lab: no epilogue at all)
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __syncthreads();
             } else

@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include "gi_common.h"
 
@@ -471,8 +472,9 @@ struct Run {
     float* img_f[2] = {nullptr, nullptr};   // packed chain weight images [msg, energy stack]; null: the
     float* img_b[2] = {nullptr, nullptr};   // stack runs layer by layer
     float* chain_amax[2] = {nullptr, nullptr};   // != null: the stack's chains run as fp16x2 (gi_chain.hip), images packed that way
-    float* img_fx[2] = {nullptr, nullptr};       // != null: the forward chain of the MESSAGE rows runs as row-independent fp16x2
-    float* chain_amax_f[2] = {nullptr, nullptr}; // (gi_chain_params.x2_rows32) from this image / these cells; pass-0 rows: img_f
+    float* img_fx[2] = {nullptr, nullptr};       // != null: EVERY forward chain of the stack (message rows, pass-0 rows, the row-cache
+    float* chain_amax_f[2] = {nullptr, nullptr}; // insert) runs as row-independent fp16x2 (gi_chain_params.x2_rows32) from this image /
+                                                 // these cells; img_f then aliases it (the fp32 image is not packed)
     long long img_b_stride[2] = {0, 0};
     // amax cells of the CURRENT pass's message-row launches, per stack family (null: pass-0 class rows, fp32 chains,
     // dropout): the fp16x2 chain kernels publish into them, defer_stack_wgrads hands them to the fp16x2
@@ -1521,18 +1523,50 @@ void bf3_prepare(Run& r, const Model& m, float* ws, const Ws& w, bool backward, 
     r.nbf3 = n;
 }
 
-// per device: "the weight images a forward prepacked for its backward are written" (GI_RUN_PREPACK_BWD -> GI_BWD_PREPACKED).
-// Every forward records it on the side stream behind its packs; that stream is in order, so the latest record covers
-// every earlier forward's images too (several forwards, then their backwards: GraphGeneratorRL.py:131-132).
-hipEvent_t prepack_event() {
-    constexpr int MAXDEV = 16;
-    static hipEvent_t ev[MAXDEV];
-    static bool made[MAXDEV] = {};
+// "The weight images a forward prepacked for its backward are written" (GI_RUN_PREPACK_BWD -> GI_BWD_PREPACKED), PER
+// WORKSPACE: the forward stamps (ws, arithmetic flavour) into a small registry and records the entry's event on the side
+// stream behind its packs; a backward handed GI_BWD_PREPACKED looks its ws up — found with the same flavour: it waits
+// for that event instead of packing; NOT found (the flag was set without such a forward, another ws, a forward that
+// failed): it packs itself.  Round-5 advisor: the flag used to be trusted blindly and the event was one per device,
+// shared by every model and stream.  Several forwards before their backwards (GraphGeneratorRL.py:131-132) each have
+// their entry; the oldest entry is recycled (its backward then simply packs again).
+struct PrepackEntry { const float* ws; bool x2; hipEvent_t ev; int dev; bool valid; unsigned long long age; };
+static PrepackEntry g_prepack[32];
+static unsigned long long g_prepack_clock = 0;
+static std::mutex g_prepack_mu;
+hipEvent_t prepack_stamp(const float* ws, bool x2) {
+    std::lock_guard<std::mutex> lock(g_prepack_mu);
     int dev = 0;
     (void)hipGetDevice(&dev);
-    dev = (dev >= 0 && dev < MAXDEV) ? dev : 0;
-    if (!made[dev]) { (void)hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming); made[dev] = true; }
-    return ev[dev];
+    PrepackEntry* slot = nullptr;
+    for (PrepackEntry& e : g_prepack)
+        if (e.valid && e.ws == ws && e.dev == dev) slot = &e;
+    if (!slot) {
+        slot = &g_prepack[0];
+        for (PrepackEntry& e : g_prepack) {
+            if (!e.valid) { slot = &e; break; }
+            if (e.age < slot->age) slot = &e;
+        }
+    }
+    if (slot->ev && slot->dev != dev) { (void)hipEventDestroy(slot->ev); slot->ev = nullptr; }
+    if (!slot->ev && hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming) != hipSuccess) { slot->valid = false; return nullptr; }
+    slot->ws = ws; slot->x2 = x2; slot->dev = dev; slot->valid = true; slot->age = ++g_prepack_clock;
+    return slot->ev;
+}
+void prepack_forget(const float* ws) {          // a forward that packs nothing ahead into this workspace
+    std::lock_guard<std::mutex> lock(g_prepack_mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (PrepackEntry& e : g_prepack)
+        if (e.valid && e.ws == ws && e.dev == dev) e.valid = false;
+}
+hipEvent_t prepack_lookup(const float* ws, bool x2) {     // (both calls of a two-phase backward find it)
+    std::lock_guard<std::mutex> lock(g_prepack_mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (PrepackEntry& e : g_prepack)
+        if (e.valid && e.ws == ws && e.dev == dev && e.x2 == x2) return e.ev;
+    return nullptr;
 }
 
 static bool sizes_ok(int S, int E, int U, int D0) {
@@ -1674,6 +1708,7 @@ extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* pa
                     r.chk(rp.rc);
                     r.img_fx[k] = ws + w.img_fx[k];
                     r.chain_amax_f[k] = ws + w.chain_amax_f[k];
+                    r.img_f[k] = r.img_fx[k];                   // (nothing may read the fp32 image: it was not packed)
                 } else {
                     chain_pack(r, k ? m.eatt : m.msg, d.Fe, false, r.img_f[k]);
                 }
@@ -1738,12 +1773,15 @@ extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* pa
                     }
             }
     bf3_prepare(r, m, ws, w, false, R, BF3_DO_AMAX, prep);
+    hipEvent_t packed = nullptr;                  // this workspace's "images written" event (prepack_stamp)
+    if ((run_flags & GI_RUN_PREPACK_BWD) && !r.drop) packed = prepack_stamp(ws, r.x2);
+    else prepack_forget(ws);
     if (side_stream) {
         cells_ready = fside.next();
         r.chk((int)hipEventRecord(cells_ready, fside.st));
-        if (run_flags & GI_RUN_PREPACK_BWD) r.chk((int)hipEventRecord(prepack_event(), fside.st));
-    } else if (run_flags & GI_RUN_PREPACK_BWD) {
-        r.chk((int)hipEventRecord(prepack_event(), r.st));
+        if (packed) r.chk((int)hipEventRecord(packed, fside.st));
+    } else if (packed) {
+        r.chk((int)hipEventRecord(packed, r.st));
     }
     // pass-0 row cache (inference loops): only in front of the one-launch stack path, whose kernel can skip
     int* const p0c = static_cast<int*>(gp->p0_cache);
@@ -1857,7 +1895,8 @@ extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* pa
     // finished hundreds of microseconds ago: a wait that never stalls).  The caller therefore needs no cross-stream
     // bookkeeping of its own for `ws` (torch: no Tensor.record_stream, which would keep the caching allocator from
     // reusing the block until the low-priority side stream has drained).
-    if (side_stream && (run_flags & GI_RUN_PREPACK_BWD)) r.chk((int)hipStreamWaitEvent(r.st, prepack_event(), 0));
+    if (side_stream && packed) r.chk((int)hipStreamWaitEvent(r.st, packed, 0));
+    if (!r.ok()) prepack_forget(ws);              // (a failed forward's images are not to be trusted)
     return r.rc;
 }
 
@@ -1901,7 +1940,8 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
                                       const gi_graph* gp, float* ws, float* slabs,
                                       const float* y_out, int ldout, const float* d_out, int lddout,
                                       float* const* grads, void* stream, void* side_stream, int phase) {
-    const bool prepacked = (phase & GI_BWD_PREPACKED) != 0, no_x2 = (phase & GI_BWD_NO_X2) != 0;
+    bool prepacked = (phase & GI_BWD_PREPACKED) != 0;
+    const bool no_x2 = (phase & GI_BWD_NO_X2) != 0;
     phase &= ~(GI_BWD_PREPACKED | GI_BWD_NO_X2);
     if (phase != GI_BWD_ALL && phase != GI_BWD_READOUT && phase != GI_BWD_PASSES) return GI_EINVAL;
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
@@ -1944,7 +1984,10 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
     r.skinny = ws + w.skinny; r.skinny_floats = w.skinny_floats;
     r.x2 = x2_enabled() && !no_x2;
     r.guard = gp->x2_guard; r.guard_host = nullptr;       // (the backward only counts: dZ rows never trip)
-    if (prepacked) r.chk((int)hipStreamWaitEvent(r.st, prepack_event(), 0));   // images written by the forward's side stream
+    if (prepacked) {                                      // images written by THIS workspace's forward (side stream)?
+        if (hipEvent_t ev = prepack_lookup(ws, r.x2)) r.chk((int)hipStreamWaitEvent(r.st, ev, 0));
+        else prepacked = false;                           // no such forward on record: pack here
+    }
     const long long out_fshift = r.drop ? (long long)d.B * ldout : 0;   // logits -> their factors
     const int R = w.R;
     int maxUt = 0;

@@ -96,7 +96,7 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dro
     ``no_x2``: this forward (and its backward) as bf16x3 splits (``GI_RUN_NO_X2``)."""
     lib = _L.load()
     if bounds is not None:
-        return _forward_bounded(lib, consts, nodes, edges, params, kind, bounds, p0_cache, sticky_err)
+        return _forward_bounded(lib, consts, nodes, edges, params, kind, bounds, p0_cache, sticky_err, guard, no_x2)
     drop = dropout_seed is not None
     nodes, lay, gfix, S, E, U, D0, Ut = _ops.compact_count(nodes, edges, nodedup=drop,
                                                            allow_multi_bond=kind == _L.KIND_GGNN)
@@ -142,7 +142,11 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dro
     return (out[:B] if drop else out), (dims, graph, ws)
 
 
-def _forward_bounded(lib, consts, nodes, edges, params, kind, bounds, p0_cache=None, sticky_err=None):
+def _forward_bounded(lib, consts, nodes, edges, params, kind, bounds, p0_cache=None, sticky_err=None, guard=None,
+                     no_x2=False):
+    """The host-sync-free forward.  Runs under the SAME fp16x2 dynamic-range guard and the same trip state as the
+    blocking forward (round-5 advisor: it used to call plain gi_ggnn_forward, so after a trip the blocking forwards ran
+    bf16x3 while these kept running unguarded fp16x2 — and the two are documented to agree bit for bit)."""
     if nodes.dim() != 3:
         raise ValueError("nodes must be [B, N, Fn]")
     B, N = nodes.shape[0], nodes.shape[1]
@@ -168,8 +172,12 @@ def _forward_bounded(lib, consts, nodes, edges, params, kind, bounds, p0_cache=N
     gs = graph.c_struct()
     if p0_cache is not None:
         gs.p0_cache = p0_cache.data_ptr()
-    _L.check(lib.gi_ggnn_forward(C.byref(dims), _ptr_table(params), C.byref(gs), box["ws"].data_ptr(),
-                                 out.data_ptr(), apd, torch.cuda.current_stream(dev).cuda_stream),
+    if guard is not None:
+        gs.x2_guard, gs.x2_guard_host = guard[0].data_ptr(), guard[1]
+    # (no side stream: everything in line on the caller's stream — this forward may be recorded into a hipGraph)
+    _L.check(lib.gi_ggnn_forward_ex(C.byref(dims), _ptr_table(params), C.byref(gs), box["ws"].data_ptr(),
+                                    out.data_ptr(), apd, torch.cuda.current_stream(dev).cuda_stream, 0,
+                                    _L.RUN_NO_X2 if no_x2 else 0),
              "gi_ggnn_forward (bounded)")
     return out, (dims, graph, box["ws"])
 
@@ -389,11 +397,10 @@ class _FusedMPNN(torch.nn.Module):
             st = self.__dict__["_x2_guard"] = {}
         g = st.get(device)
         if g is None:
-            host, dev = C.c_void_p(), C.c_void_p()
-            with torch.cuda.device(device):
-                _L.check(_L.load().gi_host_flag_create(C.byref(host), C.byref(dev)), "gi_host_flag_create")
-            g = st[device] = (torch.zeros(_L.X2_GUARD_WORDS, dtype=torch.int32, device=device), dev.value,
-                              C.cast(host, C.POINTER(C.c_int)))
+            # (counters on the device, the flag's device pointer, the flag: ops.HostFlag releases the pinned int with
+            # the model — round-5 advisor: the raw allocation was never freed and made the module unpicklable)
+            flag = _ops.HostFlag(device)
+            g = st[device] = (torch.zeros(_L.X2_GUARD_WORDS, dtype=torch.int32, device=device), flag.dev, flag)
         return g
 
     def _x2_off(self) -> bool:
@@ -401,7 +408,7 @@ class _FusedMPNN(torch.nn.Module):
         if self.__dict__.get("_x2_forced_off"):
             return True
         for g in (self.__dict__.get("_x2_guard") or {}).values():
-            if g[2][0] != 0:
+            if g[2].value != 0:
                 self.__dict__["_x2_forced_off"] = True
                 return True
         return False
@@ -420,7 +427,7 @@ class _FusedMPNN(torch.nn.Module):
         for g in (self.__dict__.get("_x2_guard") or {}).values():
             g[0].zero_()
             torch.cuda.synchronize(g[0].device)             # (no launch may set the flag after it was cleared)
-            g[2][0] = 0
+            g[2].value = 0
         self.__dict__["_x2_forced_off"] = False
 
     def reset_pass0_cache(self) -> None:
@@ -443,7 +450,11 @@ class _FusedMPNN(torch.nn.Module):
         st = self.__dict__.get("_p0_state")
         if st is None:
             st = self.__dict__["_p0_state"] = {"buf": None, "key": None}
-        key = (_L.WEIGHTS_EPOCH[0], id(params), tuple((_ops._version(p), p.data_ptr()) for p in params))
+        # ... and the arithmetic the rows were computed in: a tripped fp16x2 guard (bf16x3 from then on) or a flipped
+        # process-wide switch must not be served rows of the other arithmetic
+        lib = _L.load()
+        key = (_L.WEIGHTS_EPOCH[0], id(params), tuple((_ops._version(p), p.data_ptr()) for p in params),
+               self._x2_off(), lib.gi_bf3_enable(-1), lib.gi_x2_enable(-1))
         buf = st["buf"]
         if buf is None or buf.device != nodes.device:
             dims = _dims_from_constants(self.constants, nodes.shape[0], self._KIND)
@@ -523,15 +534,27 @@ class _FusedMPNN(torch.nn.Module):
             self.__dict__.pop("_bucket", None)
         return cache
 
+    #: runtime-only attributes: caches that refer to THIS module's tensors, device-side scratch, pinned host memory
+    _RUNTIME_KEYS = ("_param_cache", "_bucket", "_anchor", "_grad_bucket", "_grad_ready_hook",
+                     "_early_exchange_pending", "_last_bounded_graph", "_p0_state", "_bounded_err", "_x2_guard",
+                     "_x2_forced_off")
+
+    def __getstate__(self):
+        """Whole-module pickling (``torch.save(model)``: the reference's v1.0 checkpoints are pickled modules,
+        util.py:841-849) keeps parameters, buffers and configuration; the runtime state above is rebuilt on first use."""
+        state = dict(self.__dict__)
+        for k in self._RUNTIME_KEYS:
+            state.pop(k, None)
+        state["_grad_bucket"] = None
+        return state
+
     def __deepcopy__(self, memo):
         # the caches below refer to THIS module's tensors: a copy (the RL agent / prior models,
         # Workflow.py:187-188) must rebuild its own
         cls = self.__class__
         new = cls.__new__(cls)
         memo[id(self)] = new
-        skip = ("_param_cache", "_bucket", "_anchor", "_grad_bucket", "_grad_ready_hook",
-                "_early_exchange_pending", "_last_bounded_graph", "_p0_state", "_bounded_err", "_x2_guard",
-                "_x2_forced_off")
+        skip = self._RUNTIME_KEYS
         import copy as _copy
         for k, v in self.__dict__.items():
             new.__dict__[k] = None if k in skip else _copy.deepcopy(v, memo)
@@ -553,12 +576,15 @@ class _FusedMPNN(torch.nn.Module):
                 # persistent device state must exist BEFORE the capture: allocated inside it, its zero-fill would be
                 # recorded and every replay would clear what the previous ones accumulated (round-4 advisor finding)
                 if nodes.device not in (self.__dict__.get("_bounded_err") or {}) or \
-                        (self.cache_pass0 and (self.__dict__.get("_p0_state") or {}).get("buf") is None):
+                        (self.cache_pass0 and (self.__dict__.get("_p0_state") or {}).get("buf") is None) or \
+                        (self.x2_guard and nodes.device not in (self.__dict__.get("_x2_guard") or {})):
                     raise RuntimeError("run one sync-free forward of this model outside the capture first: its sticky "
-                                       "error word and pass-0 row cache are allocated (and zero-filled) on first use")
+                                       "error word, pass-0 row cache and fp16x2 guard counters are allocated (and "
+                                       "zero-filled) on first use")
             bounds = self.sync_free_bounds or _ops.default_bounds(nodes.shape[0], nodes.shape[1], edges.shape[3])
             out, tape = ggnn_forward_raw(self.constants, nodes, edges, params, self._KIND, None, bounds,
-                                         self._pass0_cache(params, nodes), self._bounded_err_word(nodes.device))
+                                         self._pass0_cache(params, nodes), self._bounded_err_word(nodes.device),
+                                         guard=self._x2_guard_state(nodes.device), no_x2=self._x2_off())
             self.__dict__["_last_bounded_graph"] = tape[1]
             return out
         if self.autograd_params:

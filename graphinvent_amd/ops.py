@@ -476,6 +476,16 @@ class HostFlag:
         if self._host is not None:
             L.load().gi_host_flag_destroy(self._host)
             self._host = None
+            self._view = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:            # interpreter shutdown: the library may be gone
+            pass
+
+    def __reduce__(self):
+        raise TypeError("a HostFlag wraps pinned host memory of this process and cannot be pickled")
 
 
 def x2_weight_guard(tensors, cells: torch.Tensor, counter: torch.Tensor, host_flag: int = 0) -> None:

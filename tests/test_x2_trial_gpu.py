@@ -435,6 +435,43 @@ def test_guard_trips_the_model_into_bf16x3_and_reports_it(wname):
         assert torch.equal(again, ref_x2) and not model.x2_guard_stats()["tripped"]
 
 
+def test_sync_free_forward_runs_under_the_same_guard_and_trip_state():
+    """Round-5 advisor: the host-sync-free forward called plain gi_ggnn_forward — no guard, no GI_RUN_NO_X2 after a trip —
+    so blocking forwards ran bf16x3 while sync-free / generation forwards kept running unguarded fp16x2, and the pass-0
+    row cache could serve rows of the other arithmetic.  Now: (a) a planted weight trips the guard FROM a sync-free
+    forward, (b) after the trip blocking and sync-free forwards agree bit for bit (both bf16x3), with the row cache on,
+    (c) reset re-arms both."""
+    sh = synthetic.SHAPES["gdb13"]
+    cfg = O.shaped_config(sh["n_atom_types"], sh["n_formal_charge"], sh["max_n_nodes"], hidden_node_features=128,
+                          message_size=128)
+    model = mpnn.GGNN(O.as_constants(dict(cfg, device="cuda")))
+    model.load_state_dict(O.init_params(cfg, seed=4))
+    model = model.to(DEV).eval()
+    n8, e8, _ = synthetic.make_batch(600, **sh, seed=3)
+    nodes, edges = (torch.from_numpy(np.ascontiguousarray(x)).float().to(DEV) for x in (n8, e8))
+    with torch.no_grad():
+        model.sync_free = False
+        ref_blocking = model(nodes, edges).clone()
+        model.sync_free = True
+        assert torch.equal(model(nodes, edges), ref_blocking)                 # fp16x2, both paths, cache on
+        w = dict(model.named_parameters())["APDReadout.fAddNet1.seq.3.weight"]
+        w[[1, 2, 3]] *= 2.0 ** -30
+        model.reset_pass0_cache()                                            # (p.data-style write: versions did move here, belt and braces)
+        model(nodes, edges)                                                  # sync-free, still fp16x2: the guard notices
+        torch.cuda.synchronize()
+        st = model.x2_guard_stats()
+        assert st["weight_lines"] == 3 and st["tripped"], st
+        sf = model(nodes, edges).clone()                                     # bf16x3 now, sync-free
+        model.sync_free = False
+        bl = model(nodes, edges).clone()                                     # bf16x3, blocking
+        assert torch.equal(sf, bl)
+        model.last_bounded_error()
+        w[[1, 2, 3]] *= 2.0 ** 30
+        model.x2_guard_reset()
+        model.sync_free = True
+        assert torch.equal(model(nodes, edges), ref_blocking) and not model.x2_guard_stats()["tripped"]
+
+
 if __name__ == "__main__":
     print("forward layout, Y = A W^T, M x N x K = %d x %d x %d; errors against the fp64 product" % (M, N, K))
     print("%-30s %-8s %10s %10s %10s" % ("case", "mode", "tensor", "row", "column"))
