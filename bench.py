@@ -34,7 +34,9 @@ Rank 0 prints one JSON line.  Besides the contract fields it carries
                 ONE pair of input tensors rewritten in place between rounds — the GraphGenerator.build_graphs
                 pattern (GraphGenerator.py:118-157), which cannot prefetch graph_compact: host-sync-free
                 forward (model.sync_free) against the forward with the blocking 24-int read-back
-  cpu_baseline  the oracle (CPU restatement of the reference algorithm, kind "port") on the host
+  loader_inclusive  the same step fed from host memory through BlockStreamLoader (PCIe-inclusive rate; N == 1 only)
+  cpu_baseline  the unmodified reference model when a checkout is visible (kind "reference"), else the oracle
+                (CPU restatement of the reference algorithm, kind "port", + the committed port/reference ratio) on the host
                 cores at their best thread count, same workload, bounded sample; N == 1 only
 config.fuse_flags = the GI_FUSE launch-count reductions in use (include/graphinvent_amd.h, default 15).
 """
@@ -65,7 +67,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 # v_mfma_f32_32x32x16_bf16 / _f16) over the products one fp32 product costs (6 bf16, 3 f16)
 PEAK_16BIT_MFMA_TFLOPS = 2382.0
 PIPES = (("fp32_mfma", PEAK_FP32_MFMA_TFLOPS), ("bf16x3", PEAK_16BIT_MFMA_TFLOPS / 6), ("fp16x2", PEAK_16BIT_MFMA_TFLOPS / 3))
-PROFILE_DIR = "r05"            # profiles/<dir>/: rocprofv3 kernel stats + PMC passes of this command
+PROFILE_DIR = "r06"            # profiles/<dir>/: rocprofv3 kernel stats + PMC passes of this command
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
 
 
@@ -278,6 +280,35 @@ def generation_loop(model, cfg, batches, device, rounds: int):
     return out
 
 
+def loader_inclusive(trainer, device, n_graphs: int = 16000, block: int = 8000):
+    """The same training step fed from HOST memory through the replacement of the reference's input pipeline
+    (BlockDatasetLoader.py:32-63 -> graphinvent_amd.loader.BlockStreamLoader: int8 blocks into pinned memory on a
+    background thread, vectorised row gather, async H2D one batch ahead, graph compaction of that batch on the copy
+    stream, int8 straight into the model and the fused loss): graphs/s over one epoch of a synthetic int8 dataset
+    in host memory.  NOT `value` (whose inputs are resident in HBM): the PCIe-inclusive rate next to it."""
+    from graphinvent_amd.loader import ArraySource, BlockStreamLoader
+    sh = synthetic.SHAPES["gdb13"]
+    parts = [synthetic.make_batch(4000, **sh, seed=100 + s) for s in range(n_graphs // 4000)]
+    nodes, edges, apds = (np.concatenate([p[i] for p in parts]) for i in range(3))
+    loader = BlockStreamLoader(ArraySource(nodes, edges, apds), BATCH, block_size=block, seed=0, device=device)
+    rates = []
+    for epoch in range(2):                                     # (epoch 0 warms the pinned buffers and the thread up)
+        loader.set_epoch(epoch)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        n = 0
+        for nb, eb, ab in loader:
+            trainer.step(nb, eb, ab)
+            n += nb.shape[0]
+        torch.cuda.synchronize()
+        rates.append((n, time.perf_counter() - t0))
+    n, dt = rates[-1]
+    return {"value": round(n / dt, 1), "unit": "graphs/s", "ms_per_step": round(dt / (n / BATCH) * 1e3, 3),
+            "graphs": n, "bytes_per_graph": int((nodes.nbytes + edges.nbytes + apds.nbytes) / n_graphs),
+            "pinned_MB": round(loader.pinned_bytes / 1e6, 1),
+            "note": "one epoch of a 16 000-graph int8 dataset in host memory through BlockStreamLoader (blocks of 8 000 rows, "
+                    "shuffled, H2D + compaction one batch ahead), same model / optimizer as the timed region; this rank only"}
+
+
 def own_pipe(handle):
     """(frac_own_pipe, per-pipe table) of the last gi_prof_collect: every GEMM launch against the matrix pipe it ran on."""
     ms = (C.c_double * 3)(); work = (C.c_double * 3)(); n = (C.c_int * 3)()
@@ -311,8 +342,34 @@ def committed_traffic():
                                 "(tools/collect_profiles.sh)"}
 
 
+def reference_checkout():
+    """Directory of an UNMODIFIED reference checkout if one is visible ($GI_REFERENCE, else /root/reference — which
+    exists in the build container only, never on the GPU box), else None."""
+    for root in (os.environ.get("GI_REFERENCE"), "/root/reference"):
+        if root and os.path.isfile(os.path.join(root, "graphinvent", "gnn", "mpnn.py")):
+            return root
+    return None
+
+
+def port_over_reference():
+    """The committed build-container measurement (tools/port_over_reference.py): oracle port / unmodified reference
+    model, same cores, same batch — quoted next to a "port" baseline, which the GPU box cannot check itself."""
+    path = os.path.join(ROOT, "profiles", PROFILE_DIR, "port_over_reference.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return {"port_over_reference": t["port_over_reference"],
+                "port_over_reference_note": f"profiles/{PROFILE_DIR}/port_over_reference.json: build container, "
+                                            f"{t['threads']} threads, B={t['batch']}: reference {t['reference_graphs_per_s']} "
+                                            f"graphs/s, port {t['port_graphs_per_s']} graphs/s (tools/port_over_reference.py)"}
+    except (OSError, KeyError, ValueError):
+        return {"port_over_reference": None}
+
+
 def cpu_baseline(cfg, threads: int = 0, n_timed: int = 3):
-    """The oracle (reference algorithm on torch-CPU ops) timed on the host cores.  threads = 0: the
+    """The reference algorithm on torch-CPU ops, timed on the host cores: the UNMODIFIED reference model
+    (gnn.mpnn.GGNN of a visible checkout, kind "reference") when there is one, else the oracle port (kind "port",
+    with the committed port / reference ratio of the build container).  threads = 0: the
     thread count is chosen by a one-step probe of 8 / 16 / 32 threads — more threads make this
     workload SLOWER on the 256-CPU box (16: ~1130 graphs/s, 64: ~540, 256: 6; the GEMMs are small),
     and the baseline should be the CPU's best."""
@@ -320,6 +377,19 @@ def cpu_baseline(cfg, threads: int = 0, n_timed: int = 3):
     ocfg = {k: cfg[k] for k in O.GDB13_DEFAULTS}
     ocfg["device"] = "cpu"
     model = O.OracleGGNN(ocfg, seed=0)
+    kind, extra = "port", port_over_reference()
+    ref_root = reference_checkout()
+    if ref_root:
+        try:
+            sys.path.insert(0, os.path.join(ref_root, "graphinvent"))
+            import gnn.mpnn as ref_mpnn                        # the unmodified reference package (torch only)
+            ref = ref_mpnn.GGNN(O.as_constants(ocfg))
+            ref.load_state_dict({k: v.detach().clone() for k, v in model.named_oracle_params().items()})
+            model, kind, extra = ref, "reference", {"reference_checkout": ref_root}
+        except Exception as e:                                 # (an incomplete checkout: fall back to the port)
+            extra = dict(extra, reference_import_error=repr(e)[:160])
+        finally:
+            sys.path.pop(0)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     sh = synthetic.SHAPES["gdb13"]
     n8, e8, a8 = synthetic.make_batch(BATCH, **sh, seed=0)
@@ -355,10 +425,11 @@ def cpu_baseline(cfg, threads: int = 0, n_timed: int = 3):
     torch.set_num_threads(threads)
     one()
     dt = timed(n_timed)
-    return dict(value=round(BATCH / dt, 1), unit="graphs/s", cores=threads, kind="port",
+    return dict(value=round(BATCH / dt, 1), unit="graphs/s", cores=threads, kind=kind,
                 sample=f"{n_timed} timed steps (+1 warm-up) of the same B={BATCH} GGNN "
-                       f"training step (fwd+KL+bwd+Adam), torch-CPU oracle, {threads} threads of "
-                       f"{os.cpu_count()} host CPUs{probe}")
+                       f"training step (fwd+KL+bwd+Adam), "
+                       + ("the unmodified reference gnn.mpnn.GGNN" if kind == "reference" else "torch-CPU oracle")
+                       + f", {threads} threads of {os.cpu_count()} host CPUs{probe}", **extra)
 
 
 def main():
@@ -387,6 +458,7 @@ def main():
     ap.add_argument("--probe-only", action="store_true",
                     help="run ONLY the beyond-Infinity-Cache seg_sum probe (for rocprofv3 --pmc passes "
                          "over the aggregation kernel) and print its JSON")
+    ap.add_argument("--no-loader", action="store_true", help="skip the host-fed (loader_inclusive) leg")
     ap.add_argument("--no-forward-only", action="store_true",
                     help="skip the no_grad forward-rate leg (keeps kernel traces to training steps only)")
     ap.add_argument("--no-extra-configs", action="store_true",
@@ -432,7 +504,7 @@ def main():
         if world > 1:
             dist.barrier()
 
-    total_steps = args.steps + args.warmup + 64
+    total_steps = args.steps + args.warmup + 160          # (+ the profiled / one-stream / arithmetic-mode / loader legs)
     wl = Workload(SHAPE, MODEL, BATCH, rank, device, total_steps,
                   prefetch=not args.no_prefetch_compact)
     cfg, model, trainer, batches = wl.cfg, wl.model, wl.trainer, wl.batches
@@ -477,6 +549,19 @@ def main():
         if lib.load().gi_bf3_enable(-1) else "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere")
     # fp16x2 dynamic-range guard (gi_graph.x2_guard): counted on the device during every warm-up and timed step
     gs = model.x2_guard_stats()
+    # dZ rows the counted launches saw: every fp16x2 dgrad problem of the node-level stacks (hidden layers with an amax
+    # producer on both sides) reads R compact rows per step
+    try:
+        _, _, _, S0, _, _, _, _ = ops.compact_count(batches[0][0], batches[0][1])
+        n_x2_dgrad = sum(max(0, depth - 1) for depth, hid in ((cfg["gather_att_depth"], cfg["gather_att_hidden_dim"]),
+                                                               (cfg["gather_emb_depth"], cfg["gather_emb_hidden_dim"]),
+                                                               (cfg["mlp1_depth"], cfg["mlp1_hidden_dim"]),
+                                                               (cfg["mlp1_depth"], cfg["mlp1_hidden_dim"])) if hid >= 192)
+        seen = n_x2_dgrad * (S0 + 1) * (args.steps + args.warmup)
+        gs["dgrad_rows_checked"] = seen
+        gs["dgrad_rows_frac"] = round(gs["dgrad_rows"] / seen, 7) if seen else None
+    except Exception:
+        pass
     result["x2_guard"] = dict(gs, steps_observed=args.steps + args.warmup,
                               note="rows of a forward fp16x2 launch's activations / rows+columns of its weights more "
                                    "than 2^24 below the tensor's largest magnitude (fewer than ~14 bits left): any "
@@ -654,6 +739,8 @@ def main():
                                   "note": "this rank only, no_grad forward of the same batches"}
     if rank == 0 and not args.no_forward_only:
         result["generation_loop"] = generation_loop(model, cfg, batches, device, rounds=max(args.steps, 10))
+    if rank == 0 and world == 1 and headline and not args.no_loader and not args.no_forward_only:
+        result["loader_inclusive"] = loader_inclusive(trainer, device)
     barrier()
 
     # ---- the non-headline BASELINE configurations, observed by the same run ----------------------
