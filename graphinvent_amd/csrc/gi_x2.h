@@ -35,12 +35,29 @@ __device__ __forceinline__ void gx_scale(float amax, float& s, float& inv) {
 }
 // two fp32 values (already multiplied by nothing: the scale is applied here) -> their two fp16 planes, packed pairwise
 __device__ __forceinline__ void gx_split2(float x0, float x1, float s, unsigned& p0, unsigned& p1) {
+#ifdef GI_X2_SPLIT4
+    // FOUR instructions per pair on v_fma_mixlo / mixhi_f16 (round 6; tools/split_lab.hip: both planes bit-identical to the
+    // six-instruction form below over fp16 normals, subnormals and zeros): the product x s rounded straight to fp16 (one
+    // rounding of the exact product: s is a power of two), the residual x s - h1 formed by ONE fma from the fp16 half and
+    // rounded straight to fp16 (x s - h1 is exact in fp32, so fp16(fma) == fp16(fl32(x s) - h1)).
+    // (plain C: with -fno-slp-vectorize hipcc selects v_fma_mixlo / mixhi_f16 for these — real VALU instructions the
+    // scheduler and gi_gemm_b3p.hip's sched_group_barrier pattern can place; the SLP vectoriser turns them back into
+    // v_pk_fma_f32 + v_cvt_pk_f16_f32)
+    gx_f16x2 h, r;
+    h.x = (_Float16)__builtin_fmaf(x0, s, 0.f);
+    h.y = (_Float16)__builtin_fmaf(x1, s, 0.f);
+    r.x = (_Float16)__builtin_fmaf(x0, s, -(float)h.x);
+    r.y = (_Float16)__builtin_fmaf(x1, s, -(float)h.y);
+    p0 = __builtin_bit_cast(unsigned, h);
+    p1 = __builtin_bit_cast(unsigned, r);
+#else
     const float y0 = x0 * s, y1 = x1 * s;
     gx_f32x2 v = {y0, y1};
     const gx_f16x2 h = __builtin_convertvector(v, gx_f16x2);            // v_cvt_pk_f16_f32 (RNE)
     p0 = __builtin_bit_cast(unsigned, h);
     gx_f32x2 r = {y0 - (float)h.x, y1 - (float)h.y};                    // v_fma_mix_f32 x 2 (exact)
     p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, gx_f16x2));
+#endif
 }
 // A tensor's largest magnitude lives in an "amax cell": GI_AMAX_WORDS floats = 64 slots one 128-byte line apart.
 // Thousands of waves finish their epilogues within microseconds of one another; into ONE word their atomics queue on
