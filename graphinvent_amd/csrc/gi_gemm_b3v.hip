@@ -217,14 +217,16 @@ __global__ __launch_bounds__(256, X2 ? 4 : 3) void gi_b3v_kernel(const GvBatch b
         q1.x = a1; q1.y = b1; q1.z = c1; q1.w = d1;
         q2.x = a2; q2.y = b2; q2.z = c2; q2.w = d2;
     };
+    float rowmax[4] = {0.f, 0.f, 0.f, 0.f};        // fp16x2 guard (gi_gemm_params.x2_guard): max |a| staged of the thread's four contig A rows
     auto store_contig = [&](auto steady_c, int kt, unsigned char* S, v4f (&r)[4], const unsigned (&w)[4], int cmax,
-                            int kend, float scale) __attribute__((always_inline)) {
+                            int kend, float scale, bool track) __attribute__((always_inline)) {
         constexpr bool ST = decltype(steady_c)::value;
         const int k0 = kb + kt * GV_BK;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             v4f v = r[i];
             if (!ST) v = gi_fix4(v, k0 + 4 * c8, cmax, kend, true);
+            if (X2 && track) rowmax[i] = fmaxf(fmaxf(rowmax[i], fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             gv_u32x2 w0, w1, w2;
             unsigned x0, x1, x2 = 0, y0, y1, y2 = 0;
             if (X2) { gx_split2(v.x, v.y, scale, x0, x1); gx_split2(v.z, v.w, scale, y0, y1); }
@@ -273,9 +275,9 @@ __global__ __launch_bounds__(256, X2 ? 4 : 3) void gi_b3v_kernel(const GvBatch b
         if (!X2) *reinterpret_cast<gv_u32x4*>(S + 2 * GV_PLANE + o1) = q2;
     };
     auto sstore = [&](auto steady_c, int kt) __attribute__((always_inline)) {
-        if (!AM) store_contig(steady_c, kt, As, ra, a_w, a_cmax, p.K, sa);
+        if (!AM) store_contig(steady_c, kt, As, ra, a_w, a_cmax, p.K, sa, true);
         else store_major(steady_c, kt, As, ma, false, sa);
-        if (!BMJ) store_contig(steady_c, kt, Bs, rb, b_w, b_cmax, p.K, sb);
+        if (!BMJ) store_contig(steady_c, kt, Bs, rb, b_w, b_cmax, p.K, sb, false);
         else store_major(steady_c, kt, Bs, mb, tile_has_ones, sb);
     };
 
@@ -340,6 +342,25 @@ __global__ __launch_bounds__(256, X2 ? 4 : 3) void gi_b3v_kernel(const GvBatch b
             if (kt + 1 < nk) gload(GEN, kt + 1);
             compute();
             __syncthreads();
+        }
+    }
+
+    // ---- fp16x2 dynamic-range guard (forward / dgrad layouts; see gi_gemm_bf3.hip): rows of A whose largest scaled
+    // magnitude is below 2^-11 keep fewer than ~14 bits.  Once per launch: the workgroups of the first column tile.
+    if (X2 && !AM && p.x2_guard && bx == 0 && !(p.flags & GI_GEMM_SPLITK)) {
+        int n_low = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float m = rowmax[i];
+            m = fmaxf(m, __shfl_xor(m, 1));
+            m = fmaxf(m, __shfl_xor(m, 2));
+            m = fmaxf(m, __shfl_xor(m, 4));                     // the eight lanes (k chunks) of a row
+            const bool real_row = m0 + crow + 32 * i < m_end;
+            n_low += (c8 == 0 && real_row && m > 0.f && m * sa < 0x1p-11f) ? 1 : 0;
+        }
+        if (n_low) {
+            atomicAdd(p.x2_guard, n_low);
+            if (p.x2_guard_host) *reinterpret_cast<volatile int*>(p.x2_guard_host) = 1;
         }
     }
 
@@ -417,7 +438,11 @@ bool gi_b3v_eligible(const gi_gemm_params* probs, int n) {
         if (!(p.flags & GI_GEMM_BF3) || (p.flags & GI_GEMM_BF3A)) return false;
         // fp16x2 (round 6): the weight-gradient layout, every problem of the launch alike
         if (((p.flags & GI_GEMM_X2) != 0) != ((probs[0].flags & GI_GEMM_X2) != 0)) return false;
-        if ((p.flags & GI_GEMM_X2) && !(p.a_major && p.b_major && p.a_amax && p.b_amax)) return false;
+        if ((p.flags & GI_GEMM_X2) && !(p.a_amax && p.b_amax)) return false;
+        if ((p.flags & GI_GEMM_X2) && !(p.a_major && p.b_major)) {       // forward / dgrad layouts as fp16x2: measurement switch
+            static const bool fwd_x2 = getenv("GI_B3V_X2_FWD") && atoi(getenv("GI_B3V_X2_FWD")) != 0;
+            if (!fwd_x2) return false;
+        }
         if (p.a_major != probs[0].a_major || p.b_major != probs[0].b_major) return false;
         if (p.a_major && !p.b_major) return false;
         if (!p.b_major && !(p.flags & GI_GEMM_BF3B_F32)) return false;      // contig B must be plain fp32, not an image
@@ -456,7 +481,7 @@ int gi_b3v_launch(const gi_gemm_params* probs, int n, void* stream) {
         if ((f & GI_EPI_BIAS) && !p.bias) return GI_EINVAL;
         if ((f & (GI_EPI_DSELU | GI_EPI_MULACT)) && !p.act) return GI_EINVAL;
         if (((p.flags & GI_GEMM_X2) != 0) != ((probs[0].flags & GI_GEMM_X2) != 0)) return GI_EINVAL;
-        if ((p.flags & GI_GEMM_X2) && (!am || !bmj || !splitk || f != 0 || !p.a_amax || !p.b_amax)) return GI_EINVAL;
+        if ((p.flags & GI_GEMM_X2) && (!p.a_amax || !p.b_amax || (splitk && f != 0))) return GI_EINVAL;
         if ((p.b_idx != nullptr) != (probs[0].b_idx != nullptr) || (p.b_idx && !(p.flags & GI_GEMM_X2))) return GI_EINVAL;
         const long long lim = 0xffffffffLL / 4;
         const int bcols = p.ones_col >= 0 ? p.ones_col : p.N;
@@ -492,6 +517,14 @@ int gi_b3v_launch(const gi_gemm_params* probs, int n, void* stream) {
     const bool x2 = (probs[0].flags & GI_GEMM_X2) != 0, bidx = probs[0].b_idx != nullptr;
     GiProfScope prof(st, GI_PROF_GEMM | (x2 ? GI_PROF_PIPE_X2 : GI_PROF_PIPE_BF3), flops);
     gi_gemm_log_launch(x2 ? "v2" : (am ? "b2" : (bmj ? "b1" : "b0")), b.p, k, total, flops);
+    if (x2 && !am) {                                     // forward / dgrad layouts (GI_B3V_X2_FWD)
+        if (bidx) return GI_EINVAL;
+#define GV_LAUNCH_X2(A, B, E) hipLaunchKernelGGL((gi_b3v_kernel<A, B, E, true, false>), dim3(total), dim3(256), 0, st, b)
+        if (bmj) { if (epi == 2) GV_LAUNCH_X2(false, true, 2); else GV_LAUNCH_X2(false, true, 0); }
+        else { if (epi == 1) GV_LAUNCH_X2(false, false, 1); else if (epi == 2) GV_LAUNCH_X2(false, false, 2); else GV_LAUNCH_X2(false, false, 0); }
+#undef GV_LAUNCH_X2
+        return gi_launch_status();
+    }
     if (x2) {                                            // (weight-gradient slabs: plain stores)
         if (epi != 3) return GI_EINVAL;
         // weight-gradient launches: consecutive tile ids = the tiles of ONE slab, which read the same rows of both

@@ -55,6 +55,7 @@
  *     queue, 1..8), GI_SIDE_PRIO (0: gi_side_stream_create with a middle instead of the lowest priority), GI_CHAIN_RING3_SMALL (chain launches
  *     of at most that many row blocks on the three-slot weight ring), GI_DBG_X2 (only in a library built with -DGI_CHAIN_X2_LAB; results WRONG: parts of the fp16x2 chain kernel switched
  *     off for timing),
+ *     GI_B3V_X2_FWD (1: the fp16x2 forward / dgrad launches of the node-level stacks on the 32-deep-tile kernel of gi_gemm_b3v.hip),
  *     GI_B3P_WGRAD_REMAP / GI_WGRAD_SLAB_ORDER
  *     (0: the 16-bit-pipe / fp32 weight-gradient tiles in dispatch order / per-slab order instead of slab-per-XCD); graphinvent_amd/gnn/mpnn.py reads GI_PREPACK (0: gi_ggnn_forward_ex without a side stream and without
  *     GI_RUN_PREPACK_BWD: the round-4 schedule).

@@ -20,7 +20,7 @@ if not f: print("no counter file"); sys.exit(0)
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(lambda: collections.defaultdict(int))
 for r in csv.DictReader(open(f[0])):
     k = r["Kernel_Name"]
-    m = re.search(r"(gi_gemm\w*_kernel<[^>]*>|gi_b3[pv]_kernel<[^>]*>|gi_chain_kernel<[^>]*>|\w+_kernel)", k)
+    m = re.search(r"(gi_gemm\w*_kernel<[^>]*>|gi_b3[pv]_kernel<[^>]*>|gi_chain\w*_kernel<[^>]*>|\w+_kernel)", k)
     key = m.group(1) if m else k[:40]
     agg[key][r["Counter_Name"]] += float(r["Counter_Value"]); n[key][r["Counter_Name"]] += 1
 print("per-dispatch averages (rocprofv3 --pmc %s), kernel: {counter: avg} dispatches" % sys.argv[1])
