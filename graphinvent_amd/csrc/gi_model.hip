@@ -303,6 +303,28 @@ void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
     w.total = d.dropout ? 2 * gi_r4l(o) : o;
 }
 
+// ---- gi_graph.wcache: what a forward derives from the weights alone, kept across forwards -----------------------
+// [per stack family: fp16x2 forward image | its max |W| cells [layer][bond type]] [max |W| cell of every node-level
+// 16-bit-pipe layer].  Sizes depend on the model only (not on the batch).
+struct Wc { long long img_fx[2], chain_amax_f[2], bf3_wamax, total; };
+void wcache_layout(const Model& m, Wc& c) {
+    memset(&c, 0, sizeof(c));
+    const gi_ggnn_dims& d = m.d;
+    long long o = 0;
+    auto take = [&](long long n) { long long r = o; o += gi_r4l(n); return r; };
+    for (int k = 0; k < (d.kind == GI_KIND_ATTGGNN ? 2 : 1); ++k) {
+        const Mlp& q = k ? m.eatt[0] : m.msg[0];
+        if (d.passes > 0 && chain_fits(q, d.H)) {
+            c.img_fx[k] = take(chain_image_floats(q, d.Fe, false, nullptr));
+            c.chain_amax_f[k] = take((long long)GI_AMAX_WORDS * GI_CHAIN_MAXL * GI_MAX_GROUPS);
+        } else {
+            c.img_fx[k] = c.chain_amax_f[k] = -1;
+        }
+    }
+    c.bf3_wamax = take((long long)GI_AMAX_WORDS * GI_BF3_PACK_MAX);
+    c.total = o;
+}
+
 // ---- wgrad slab plan ----------------------------------------------------------------------------
 struct SlabEntry { long long off, stride; int nsplit, calls, done, n_out, n_in, ld, tn, bidx, launched, reduced, bf3, single_last, sep, x2all; };   // x2all: fp16x2 launch when the call has (or can make) the operands' amax cells (plan_slabs)   // sep: bias column by gi_bias_slabs, reduced with the last batch   // single_last: the last call wrote ONE slab (the pass-0 rows, defer_wgrad)
 struct SlabPlan {
@@ -506,7 +528,9 @@ struct Run {
     // and the dgrad launch of the layer above (c_amax of add_dgrad).  A stack's first layer reads h (GRU gate kernel)
     // and its last layer's dZ comes from the loss / gather backward: nobody measures those, so fp16x2 launches that
     // would need them stay bf16x3 (round-4 advisor finding: a zeroed cell reads as scale 1).
-    struct Bf3 { const float* W; const unsigned short* img; float* amax; bool in_ok, dz_ok; } bf3[GI_BF3_PACK_MAX];
+    struct Bf3 { const float* W; const unsigned short* img; float* amax; float* wamax; bool in_ok, dz_ok; } bf3[GI_BF3_PACK_MAX];   // wamax: the max |W| cell (amax[0], or its place in gi_graph.wcache)
+    float* wc_bf3 = nullptr;                // gi_graph.wcache: the node-level layers' max |W| cells ...
+    bool wc_valid = false;                  // ... and whether the cache's contents match the weights (nothing to derive)
     int nbf3 = 0;
     const Bf3* bf3_layer(const float* W, int rows) const {
         if (rows < BF3_MIN_ROWS) return nullptr;
@@ -746,7 +770,7 @@ void add_fwd(Batch& b, Run& r, const float* W, const float* bias, int in, int ou
     if (const Run::Bf3* e = r.bf3_layer(W, rows)) {
         p.flags |= GI_GEMM_BF3 | GI_GEMM_BF3B_F32;                             // (B = W [out][in] as stored)
         if (e->amax && e->in_ok) {
-            p.flags |= GI_GEMM_X2; p.a_amax = e->amax + GI_AMAX_WORDS; p.b_amax = e->amax;
+            p.flags |= GI_GEMM_X2; p.a_amax = e->amax + GI_AMAX_WORDS; p.b_amax = e->wamax;
             p.x2_guard = r.guard; p.x2_guard_host = r.guard_host;           // activation rows outside the per-tensor range
         }
     }
@@ -775,7 +799,7 @@ void add_dgrad(Batch& b, Run& r, int widx, int n_out, int n_in, int ncols, const
                 p.B = reinterpret_cast<const float*>(e->img); p.b_major = 0; p.ldb = gi_r4(n_out);
                 p.flags |= GI_GEMM_BF3 | GI_GEMM_BF3B_F32;
                 if (e->amax && e->dz_ok) {
-                    p.flags |= GI_GEMM_X2; p.a_amax = e->amax + 2 * GI_AMAX_WORDS; p.b_amax = e->amax;
+                    p.flags |= GI_GEMM_X2; p.a_amax = e->amax + 2 * GI_AMAX_WORDS; p.b_amax = e->wamax;
                     p.x2_guard = r.guard ? r.guard + 2 : nullptr;            // dZ rows: counted, never a trip (sums over rows)
                 }
                 return;
@@ -1509,16 +1533,20 @@ void bf3_prepare(Run& r, const Model& m, float* ws, const Ws& w, bool backward, 
             // max |dZ of its output| (the c_amax of the launches that produce them; zeroed once per forward: the
             // backward runs on the same workspace)
             r.bf3[n].amax = x2 ? am + 4LL * GI_AMAX_WORDS * n : nullptr;
-            ad[n].x = d[n].W; ad[n].rows = 1; ad[n].cols = fi * fo; ad[n].ld = fi * fo; ad[n].out = r.bf3[n].amax;
-            wd[n].x = d[n].W; wd[n].rows = fo; wd[n].cols = fi; wd[n].ld = fi; wd[n].out = r.bf3[n].amax;
+            r.bf3[n].wamax = !x2 ? nullptr : (r.wc_bf3 ? r.wc_bf3 + (long long)GI_AMAX_WORDS * n : r.bf3[n].amax);
+            ad[n].x = d[n].W; ad[n].rows = 1; ad[n].cols = fi * fo; ad[n].ld = fi * fo; ad[n].out = r.bf3[n].wamax;
+            wd[n].x = d[n].W; wd[n].rows = fo; wd[n].cols = fi; wd[n].ld = fi; wd[n].out = r.bf3[n].wamax;
             used += std::max(gi_bf3_image_elems(fo, fi), gi_bf3_image_elems(fi, fo));
             ++n;
         }
     if (n && backward && (what & BF3_DO_PACK)) r.chk(gi_bf3_pack(d, n, st));
     if (n && x2 && (what & BF3_DO_AMAX)) {
-        r.chk((int)hipMemsetAsync(am, 0, sizeof(float) * 4 * GI_AMAX_WORDS * n, st));
-        r.chk(gi_absmax(ad, n, st));
-        if (r.guard && r.ok()) r.chk(gi_x2_weight_guard(wd, n, r.guard + 1, r.guard_host, st));
+        r.chk((int)hipMemsetAsync(am, 0, sizeof(float) * 4 * GI_AMAX_WORDS * n, st));      // (the activations' / dZ cells: every forward)
+        if (!(r.wc_bf3 && r.wc_valid)) {                  // max |W| + the weights' dynamic-range check: unless cached
+            if (r.wc_bf3) r.chk((int)hipMemsetAsync(r.wc_bf3, 0, sizeof(float) * GI_AMAX_WORDS * n, st));
+            r.chk(gi_absmax(ad, n, st));
+            if (r.guard && r.ok()) r.chk(gi_x2_weight_guard(wd, n, r.guard + 1, r.guard_host, st));
+        }
     }
     r.nbf3 = n;
 }
@@ -1697,17 +1725,28 @@ extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* pa
     const bool attn = d.kind == GI_KIND_ATTGGNN;
 
     r.eatt0 = m.eatt;
+    // gi_graph.wcache: the weights-only data of this forward live in (and, when valid, come from) the caller's cache
+    Wc wc;
+    wcache_layout(m, wc);
+    float* const wcache = (gp->wcache && !r.drop && r.x2 && bf3_enabled()) ? gp->wcache : nullptr;
+    if (wcache && ((uintptr_t)wcache & 15)) return GI_EINVAL;
+    r.wc_valid = wcache && gp->wcache_valid != 0;
+    r.wc_bf3 = wcache ? wcache + wc.bf3_wamax : nullptr;
     if (d.passes > 0 && E > 0)          // packed weight images of the chain kernel, once per forward
         for (int k = 0; k < (attn ? 2 : 1); ++k)
             if (w.img_f_n[k] > 0) {
                 r.img_f[k] = ws + w.img_f[k];
                 if (!r.drop && chain_fwd_x2_enabled(r.x2)) {   // the row-independent fp16x2 chain: its image instead of the fp32 one
+                    float* const img = (wcache && wc.img_fx[k] >= 0) ? wcache + wc.img_fx[k] : ws + w.img_fx[k];
+                    float* const cells = (wcache && wc.img_fx[k] >= 0) ? wcache + wc.chain_amax_f[k] : ws + w.chain_amax_f[k];
+                    if (!(r.wc_valid && wc.img_fx[k] >= 0)) {
                     Run rp = r;
-                    rp.chain_amax[k] = ws + w.chain_amax_f[k];
-                    chain_pack(rp, k ? m.eatt : m.msg, d.Fe, false, ws + w.img_fx[k]);
+                    rp.chain_amax[k] = cells;
+                    chain_pack(rp, k ? m.eatt : m.msg, d.Fe, false, img);
                     r.chk(rp.rc);
-                    r.img_fx[k] = ws + w.img_fx[k];
-                    r.chain_amax_f[k] = ws + w.chain_amax_f[k];
+                    }
+                    r.img_fx[k] = img;
+                    r.chain_amax_f[k] = cells;
                     r.img_f[k] = r.img_fx[k];                   // (nothing may read the fp32 image: it was not packed)
                 } else {
                     chain_pack(r, k ? m.eatt : m.msg, d.Fe, false, r.img_f[k]);
@@ -1754,7 +1793,7 @@ extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* pa
                 }
     }
     // the forward chains' weights through the fp16x2 guard (output channels / input columns below the per-tensor range)
-    if (r.guard && r.ok())
+    if (r.guard && r.ok() && !r.wc_valid)
         for (int k = 0; k < (attn ? 2 : 1); ++k)
             if (r.img_fx[k]) {
                 const Mlp* mlps = k ? m.eatt : m.msg;
@@ -1922,6 +1961,14 @@ extern "C" long long gi_p0_cache_words(const gi_ggnn_dims* d) {
     return gi_p0_cache_words_for((m.d.kind == GI_KIND_ATTGGNN ? 2 : 1) * w.ldM);
 }
 
+extern "C" long long gi_ggnn_wcache_floats(const gi_ggnn_dims* d) {
+    Model m;
+    if (int rc = build_model(d, m)) return rc;
+    Wc c;
+    wcache_layout(m, c);
+    return c.total;
+}
+
 extern "C" int gi_ggnn_first_readout_param(const gi_ggnn_dims* d) {
     Model m;
     const int rc = build_model(d, m);
@@ -1964,6 +2011,7 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
     if (E > 0 && (!u_src || !in_perm || !mu_off || !mu_dst || !mu_slot || !out_perm || U == 0))
         return GI_EINVAL;
     if (m.nparams > 160) return GI_ELIMIT;
+    if (gp->wcache) return GI_EINVAL;     // (a forward that used the weights cache left no max |W| cells in ws)
     const gi_ggnn_dims& d = m.d;
     gi_compact_layout_t L;
     rc = gi_compact_layout(d.B, d.N, d.Fe, &L);

@@ -70,7 +70,8 @@ def _set_dropout(dims, c, kind: int, seed: int) -> None:
 
 
 def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dropout_seed=None,
-                     bounds=None, p0_cache=None, sticky_err=None, want_backward=False, guard=None, no_x2=False):
+                     bounds=None, p0_cache=None, sticky_err=None, want_backward=False, guard=None, no_x2=False,
+                     wcache=None):
     """graph_compact + the fused forward.  Returns (logits, tape); the tape
     (dims, CompactGraph, workspace, per-type edge counts) is what backward consumes.
 
@@ -93,10 +94,14 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dro
     chains' image) are packed NOW on the side stream, which idles during a forward (``GI_RUN_PREPACK_BWD``); the tape
     remembers, and ``ggnn_backward_raw`` waits for them instead of packing in front of its first launches.
     ``guard = (counters, host_flag_dev_ptr)``: the fp16x2 dynamic-range guard (``gi_graph.x2_guard``);
-    ``no_x2``: this forward (and its backward) as bf16x3 splits (``GI_RUN_NO_X2``)."""
+    ``no_x2``: this forward (and its backward) as bf16x3 splits (``GI_RUN_NO_X2``).
+    ``wcache = state`` (a dict with ``buf`` / ``valid``, see ``_FusedMPNN._weights_cache``): the weights-only data of the
+    forward (fp16x2 chain image, max |W| cells) live in ``buf`` across forwards and are re-derived only when ``valid`` is
+    False; the tape cannot feed a backward."""
     lib = _L.load()
     if bounds is not None:
-        return _forward_bounded(lib, consts, nodes, edges, params, kind, bounds, p0_cache, sticky_err, guard, no_x2)
+        return _forward_bounded(lib, consts, nodes, edges, params, kind, bounds, p0_cache, sticky_err, guard, no_x2,
+                                wcache)
     drop = dropout_seed is not None
     nodes, lay, gfix, S, E, U, D0, Ut = _ops.compact_count(nodes, edges, nodedup=drop,
                                                            allow_multi_bond=kind == _L.KIND_GGNN)
@@ -131,9 +136,14 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dro
     side = _side_stream(dev) if (PREPACK_SIDE and not drop) else 0
     if want_backward and not drop:
         flags |= _L.RUN_PREPACK_BWD
+    if wcache is not None and not drop and not want_backward:
+        gs.wcache, gs.wcache_valid = wcache["buf"].data_ptr(), int(bool(wcache["valid"]))
     _L.check(lib.gi_ggnn_forward_ex(C.byref(dims), _ptr_table(params), C.byref(gs), ws.data_ptr(),
                                     out.data_ptr(), apd, torch.cuda.current_stream(dev).cuda_stream, side, flags),
              "gi_ggnn_forward")
+    if gs.wcache:
+        wcache["valid"] = True                              # (derived on this stream, in order before any later forward)
+        graph.no_backward = True
     # (no ws.record_stream(side stream): gi_ggnn_forward_ex orders the side stream's packs into ws before everything
     # enqueued on the current stream after it, so a tape dropped without a backward may free ws at once)
     # what the backward of THIS tape must repeat: the run flags and the process-wide arithmetic switches of the forward
@@ -143,7 +153,7 @@ def ggnn_forward_raw(consts, nodes, edges, params, kind: int = _L.KIND_GGNN, dro
 
 
 def _forward_bounded(lib, consts, nodes, edges, params, kind, bounds, p0_cache=None, sticky_err=None, guard=None,
-                     no_x2=False):
+                     no_x2=False, wcache=None):
     """The host-sync-free forward.  Runs under the SAME fp16x2 dynamic-range guard and the same trip state as the
     blocking forward (round-5 advisor: it used to call plain gi_ggnn_forward, so after a trip the blocking forwards ran
     bf16x3 while these kept running unguarded fp16x2 — and the two are documented to agree bit for bit)."""
@@ -174,6 +184,9 @@ def _forward_bounded(lib, consts, nodes, edges, params, kind, bounds, p0_cache=N
         gs.p0_cache = p0_cache.data_ptr()
     if guard is not None:
         gs.x2_guard, gs.x2_guard_host = guard[0].data_ptr(), guard[1]
+    if wcache is not None:
+        gs.wcache, gs.wcache_valid = wcache["buf"].data_ptr(), int(bool(wcache["valid"]))
+        wcache["valid"] = True
     # (no side stream: everything in line on the caller's stream — this forward may be recorded into a hipGraph)
     _L.check(lib.gi_ggnn_forward_ex(C.byref(dims), _ptr_table(params), C.byref(gs), box["ws"].data_ptr(),
                                     out.data_ptr(), apd, torch.cuda.current_stream(dev).cuda_stream, 0,
@@ -244,6 +257,8 @@ def ggnn_backward_raw(tape, out, d_out, params, early_hook=None, bucket=None):
     second call differentiates the message passes."""
     lib = _L.load()
     dims, graph, ws = tape
+    if getattr(graph, "no_backward", False):
+        raise RuntimeError("this tape comes from a forward that used the weights cache (inference): it cannot feed a backward")
     d_out = d_out.contiguous().float()
     dev = out.device
     if dev.index != torch.cuda.current_device():     # autograd may run backward on another device
@@ -328,9 +343,10 @@ class _GGNNDirect(torch.autograd.Function):
         params = owner._params()
         seed = owner._next_dropout_seed()
         cache = owner._pass0_cache(params, nodes) if anchor is None and seed is None else None
+        wcache = owner._weights_cache(params, nodes) if anchor is None and seed is None else None
         out, tape = ggnn_forward_raw(owner.constants, nodes, edges, params, owner._KIND, seed, None, cache,
                                      want_backward=anchor is not None, guard=owner._x2_guard_state(nodes.device),
-                                     no_x2=owner._x2_off())
+                                     no_x2=owner._x2_off(), wcache=wcache)
         ctx.owner = owner
         ctx.tape = tape
         # the parameters are not saved tensors here: remember their versions so that an in-place
@@ -431,10 +447,11 @@ class _FusedMPNN(torch.nn.Module):
         self.__dict__["_x2_forced_off"] = False
 
     def reset_pass0_cache(self) -> None:
-        """Forget the cached pass-0 rows (next no-grad forward recomputes them)."""
-        st = self.__dict__.get("_p0_state")
-        if st is not None:
-            st["key"] = None
+        """Forget the cached pass-0 rows and the cached weights-only data (next no-grad forward recomputes them)."""
+        for name in ("_p0_state", "_w_state"):
+            st = self.__dict__.get(name)
+            if st is not None:
+                st["key"] = None
 
     def pass0_cache_stats(self) -> dict:
         """{"forwards", "hits", "rows"} of the pass-0 row cache since it was last emptied (one read-back)."""
@@ -452,9 +469,7 @@ class _FusedMPNN(torch.nn.Module):
             st = self.__dict__["_p0_state"] = {"buf": None, "key": None}
         # ... and the arithmetic the rows were computed in: a tripped fp16x2 guard (bf16x3 from then on) or a flipped
         # process-wide switch must not be served rows of the other arithmetic
-        lib = _L.load()
-        key = (_L.WEIGHTS_EPOCH[0], id(params), tuple((_ops._version(p), p.data_ptr()) for p in params),
-               self._x2_off(), lib.gi_bf3_enable(-1), lib.gi_x2_enable(-1))
+        key = self._cache_key(params)
         buf = st["buf"]
         if buf is None or buf.device != nodes.device:
             dims = _dims_from_constants(self.constants, nodes.shape[0], self._KIND)
@@ -467,6 +482,35 @@ class _FusedMPNN(torch.nn.Module):
             buf.zero_()                              # weights changed: empty table (stream-ordered)
             st["key"] = key
         return buf
+
+    #: True (default): forwards that need no gradient keep what they derive from the weights alone — the fp16x2 chain
+    #: image, the max |W| cells, the weights' dynamic-range check — in a device buffer across calls
+    #: (``gi_graph.wcache``) and re-derive it only when the weights or the arithmetic change (the pass-0 row cache's key)
+    cache_weights = True
+
+    def _cache_key(self, params):
+        lib = _L.load()
+        return (_L.WEIGHTS_EPOCH[0], id(params), tuple((_ops._version(p), p.data_ptr()) for p in params),
+                self._x2_off(), lib.gi_bf3_enable(-1), lib.gi_x2_enable(-1))
+
+    def _weights_cache(self, params, nodes):
+        if not self.cache_weights or not nodes.is_cuda:
+            return None
+        st = self.__dict__.get("_w_state")
+        if st is None:
+            st = self.__dict__["_w_state"] = {"buf": None, "key": None, "valid": False}
+        key = self._cache_key(params)
+        buf = st["buf"]
+        if buf is None or buf.device != nodes.device:
+            dims = _dims_from_constants(self.constants, nodes.shape[0], self._KIND)
+            n = _L.load().gi_ggnn_wcache_floats(C.byref(dims))
+            if n < 0:
+                _L.check(int(n), "gi_ggnn_wcache_floats")
+            st["buf"] = torch.empty(max(int(n), 4), dtype=torch.float32, device=nodes.device)
+            st["key"], st["valid"] = key, False
+        elif st["key"] != key:
+            st["key"], st["valid"] = key, False
+        return st
 
     _grad_ready_hook = None
     _early_exchange_pending = False     # set by dp.DataParallel while its early all-reduce runs
@@ -536,7 +580,7 @@ class _FusedMPNN(torch.nn.Module):
 
     #: runtime-only attributes: caches that refer to THIS module's tensors, device-side scratch, pinned host memory
     _RUNTIME_KEYS = ("_param_cache", "_bucket", "_anchor", "_grad_bucket", "_grad_ready_hook",
-                     "_early_exchange_pending", "_last_bounded_graph", "_p0_state", "_bounded_err", "_x2_guard",
+                     "_early_exchange_pending", "_last_bounded_graph", "_p0_state", "_w_state", "_bounded_err", "_x2_guard",
                      "_x2_forced_off")
 
     def __getstate__(self):
@@ -577,14 +621,16 @@ class _FusedMPNN(torch.nn.Module):
                 # recorded and every replay would clear what the previous ones accumulated (round-4 advisor finding)
                 if nodes.device not in (self.__dict__.get("_bounded_err") or {}) or \
                         (self.cache_pass0 and (self.__dict__.get("_p0_state") or {}).get("buf") is None) or \
-                        (self.x2_guard and nodes.device not in (self.__dict__.get("_x2_guard") or {})):
+                        (self.x2_guard and nodes.device not in (self.__dict__.get("_x2_guard") or {})) or \
+                        (self.cache_weights and not (self.__dict__.get("_w_state") or {}).get("valid")):
                     raise RuntimeError("run one sync-free forward of this model outside the capture first: its sticky "
                                        "error word, pass-0 row cache and fp16x2 guard counters are allocated (and "
                                        "zero-filled) on first use")
             bounds = self.sync_free_bounds or _ops.default_bounds(nodes.shape[0], nodes.shape[1], edges.shape[3])
             out, tape = ggnn_forward_raw(self.constants, nodes, edges, params, self._KIND, None, bounds,
                                          self._pass0_cache(params, nodes), self._bounded_err_word(nodes.device),
-                                         guard=self._x2_guard_state(nodes.device), no_x2=self._x2_off())
+                                         guard=self._x2_guard_state(nodes.device), no_x2=self._x2_off(),
+                                         wcache=self._weights_cache(params, nodes))
             self.__dict__["_last_bounded_graph"] = tape[1]
             return out
         if self.autograd_params:

@@ -67,7 +67,7 @@
 extern "C" {
 #endif
 
-#define GI_ABI_VERSION 16
+#define GI_ABI_VERSION 17
 #define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
 #define GI_MAX_NODES 128      /* max max_n_nodes */
 #define GI_P0_MAX_CLASSES 256 /* max distinct node feature rows for the pass-0 shortcut */
@@ -190,6 +190,14 @@ typedef struct gi_graph {
     int* x2_guard_host;       /* NULL, or ONE int of host memory mapped into the device (gi_host_flag_create): set to 1
                                  by the launch that increments counter [0] or [1], so that the host learns of a trip
                                  without a read-back and can run the following calls with GI_RUN_NO_X2 */
+    float* wcache;            /* NULL, or gi_ggnn_wcache_floats() floats of device memory (16-byte aligned) that OUTLIVE the
+                                 call: everything a FORWARD derives from the weights alone — the fp16x2 forward chains'
+                                 two-plane weight image and their max |W| cells, max |W| of the node-level fp16x2 layers —
+                                 kept across forwards of an inference / generation loop (round 6).  Forward only
+                                 (gi_ggnn_backward does not read it: pass a graph without it to a forward that needs a tape). */
+    int wcache_valid;         /* with wcache: 0 = (re)derive everything into it now (first forward, or the weights /
+                                 the arithmetic switches changed since: the CALLER keeps that key), != 0 = its contents
+                                 match the weights: no pack, no amax pass, no weight guard launches */
 } gi_graph;
 #define GI_X2_GUARD_WORDS 4
 /* One int of pinned host memory that kernels can write (hipHostMalloc mapped): *host = the caller's view,
@@ -712,6 +720,8 @@ int gi_ggnn_forward_ex(const gi_ggnn_dims* d, const float* const* params, const 
  * (gnn/mpnn.py does, from the parameters' versions).  words[0] = hit flag of the latest forward, [1] = rows
  * in the table, [2] / [3] = forwards / hits so far.  Returns the buffer size in 4-byte words, < 0 on error. */
 long long gi_p0_cache_words(const gi_ggnn_dims* d);
+/* floats of gi_graph.wcache for this model (independent of the batch) */
+long long gi_ggnn_wcache_floats(const gi_ggnn_dims* d);
 /* consumes (overwrites) the activations in ws; y_out = the logits forward returned; grads[i]
  * receives the gradient of params[i]; slabs = gi_ggnn_slab_floats() floats of scratch.
  * side_stream (may be NULL): a second hipStream_t of the same device.  When given, the weight-

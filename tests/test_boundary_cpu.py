@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.gi_abi_version() == L.ABI_VERSION == 16
+    assert lib.gi_abi_version() == L.ABI_VERSION == 17
 
 
 def test_host_side_planning_functions():
@@ -178,6 +178,7 @@ def test_ctypes_structs_have_the_sizes_and_offsets_of_the_header(tmp_path):
     offs = [("gi_gemm_params", "c_amax", L.GemmParams.c_amax.offset),
             ("gi_gemm_params", "x2_guard_host", L.GemmParams.x2_guard_host.offset),
             ("gi_graph", "x2_guard_host", L.Graph.x2_guard_host.offset),
+            ("gi_graph", "wcache_valid", L.Graph.wcache_valid.offset),
             ("gi_gemm_params", "m_dev", L.GemmParams.m_dev.offset),
             ("gi_chain_params", "x2_wamax", L.ChainParams.x2_wamax.offset),
             ("gi_chain_params", "x_amax", L.ChainParams.x_amax.offset),

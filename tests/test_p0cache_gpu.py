@@ -147,3 +147,49 @@ def test_cache_inside_a_captured_hipgraph():
         assert float((out - refs[k]).abs().max()) <= 1e-6 * float(refs[k].abs().max())
     st = model.pass0_cache_stats()
     assert st["hits"] >= 2 and model.last_bounded_error() == 0
+
+
+@pytest.mark.parametrize("kind,shape,B", [("GGNN", "gdb13", 1000), ("AttGGNN", "gdb13", 300)])
+@pytest.mark.parametrize("sync_free", [False, True])
+def test_weights_cache_is_bitwise_transparent_and_follows_the_weights(kind, shape, B, sync_free):
+    """gi_graph.wcache (round 6): the fp16x2 forward chains' weight image, the max |W| cells and the weights' range check
+    are derived ONCE per weight version and kept in a device buffer across the forwards of an inference / generation
+    loop.  Logits with the cache == logits without it, bit for bit (first forward = derive, later forwards = reuse);
+    every way this package changes weights invalidates it (in-place write, FusedAdam through raw pointers,
+    load_state_dict); a training forward in between neither uses nor disturbs it."""
+    model, cfg, sh = _model(kind, shape)
+    model.sync_free = sync_free
+    nodes, edges = _batch(sh, B, 5)
+
+    def fwd(cache):
+        model.cache_weights = cache
+        with torch.no_grad():
+            return model(nodes, edges).clone()
+
+    ref = fwd(False)
+    assert torch.equal(fwd(True), ref) and model.__dict__["_w_state"]["valid"]          # derive
+    assert torch.equal(fwd(True), ref) and torch.equal(fwd(True), ref)                 # reuse
+    # (a) in-place write under no_grad: the version counter moves
+    with torch.no_grad():
+        dict(model.named_parameters())["msg_nns.0.seq.3.weight"].mul_(1.25)
+    ref2 = fwd(False)
+    assert not torch.equal(ref2, ref)
+    assert torch.equal(fwd(True), ref2) and torch.equal(fwd(True), ref2)
+    # (b) a training step through FusedAdam (raw-pointer update, lib.WEIGHTS_EPOCH) with a training forward in between
+    model.train()
+    opt = FusedAdam(model.parameters(), lr=1e-2)
+    out = model(nodes.float(), edges.float())
+    out.square().mean().backward()
+    opt.step()
+    model.eval()
+    ref3 = fwd(False)
+    assert not torch.equal(ref3, ref2)
+    assert torch.equal(fwd(True), ref3) and torch.equal(fwd(True), ref3)
+    # (c) load_state_dict
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    sd["gru.weight_hh"] = sd["gru.weight_hh"] * 0.5
+    model.load_state_dict(sd)
+    ref4 = fwd(False)
+    assert torch.equal(fwd(True), ref4) and torch.equal(fwd(True), ref4)
+    if sync_free:
+        model.last_bounded_error()
