@@ -45,6 +45,12 @@ int gi_seg_softmax_fwd_n(const float* en, const float* emb, int ld, const int* p
 int gi_gru_gates_fwd_n(float* gi, float* gh, int ldg, const float* hx_prev, float* hx_new, int ldh,
                        const int* seg_off, int rows, int H, int Fn, const int* rows_dev, void* stream);
 
+// the fused GRU update of the forward (gi_gru.hip): both projections + the gate arithmetic in one launch
+bool gi_gru_fused_ok(int H, int M, int lda, int ldh, int ldg);
+int gi_gru_fused_fwd(const float* agg, int lda, const float* hx, int ldh, const float* Wih, const float* Whh,
+                     const float* bih, const float* bhh, float* gi, float* gh, int ldg, float* hx_new,
+                     const int* seg_off, int rows, const int* rows_dev, int H, int M, void* stream);
+
 // gi_gemm_batch hands launches whose problems all carry GI_GEMM_BF3 to gi_gemm_bf3.hip
 int gi_gemm_bf3_launch(const gi_gemm_params* probs, int n, void* stream);
 // ... and gi_gemm_bf3_launch those with plain fp32 operands (no images, no gathers) to gi_gemm_b3v.hip: forward,

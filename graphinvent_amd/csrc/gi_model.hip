@@ -1511,7 +1511,12 @@ extern "C" int gi_ggnn_num_params(const gi_ggnn_dims* d) {
 enum { BF3_DO_AMAX = 1, BF3_DO_PACK = 2 };
 void bf3_prepare(Run& r, const Model& m, float* ws, const Ws& w, bool backward, int rows, int what, hipStream_t st) {
     r.nbf3 = 0;
-    if (!bf3_enabled() || r.drop || rows < BF3_MIN_ROWS || w.bf3_floats <= 0) return;
+    if (!bf3_enabled() || r.drop || w.bf3_floats <= 0) return;
+    // Too few rows for the 16-bit pipe: nothing to prepare — EXCEPT the max |W| cells of gi_graph.wcache when this forward
+    // is the one that derives the cache: a later, larger batch of the same weights will find it marked valid (round 6:
+    // a B = 1 forward followed by a B = 1000 one read cells nobody had written).
+    const bool derive_only = rows < BF3_MIN_ROWS;
+    if (derive_only && !(r.wc_bf3 && !r.wc_valid && (what & BF3_DO_AMAX) && !backward)) return;
     const Mlp* t1[4] = {&m.att, &m.emb, &m.add1, &m.conn1};
     gi_bf3_pack_desc d[GI_BF3_PACK_MAX];
     gi_absmax_desc ad[GI_BF3_PACK_MAX], wd[GI_BF3_PACK_MAX];       // (flattened for gi_absmax; [out][in] for the guard)
@@ -1539,16 +1544,16 @@ void bf3_prepare(Run& r, const Model& m, float* ws, const Ws& w, bool backward, 
             used += std::max(gi_bf3_image_elems(fo, fi), gi_bf3_image_elems(fi, fo));
             ++n;
         }
-    if (n && backward && (what & BF3_DO_PACK)) r.chk(gi_bf3_pack(d, n, st));
+    if (n && backward && (what & BF3_DO_PACK) && !derive_only) r.chk(gi_bf3_pack(d, n, st));
     if (n && x2 && (what & BF3_DO_AMAX)) {
-        r.chk((int)hipMemsetAsync(am, 0, sizeof(float) * 4 * GI_AMAX_WORDS * n, st));      // (the activations' / dZ cells: every forward)
+        if (!derive_only) r.chk((int)hipMemsetAsync(am, 0, sizeof(float) * 4 * GI_AMAX_WORDS * n, st));      // (the activations' / dZ cells: every forward)
         if (!(r.wc_bf3 && r.wc_valid)) {                  // max |W| + the weights' dynamic-range check: unless cached
             if (r.wc_bf3) r.chk((int)hipMemsetAsync(r.wc_bf3, 0, sizeof(float) * GI_AMAX_WORDS * n, st));
             r.chk(gi_absmax(ad, n, st));
             if (r.guard && r.ok()) r.chk(gi_x2_weight_guard(wd, n, r.guard + 1, r.guard_host, st));
         }
     }
-    r.nbf3 = n;
+    r.nbf3 = derive_only ? 0 : n;
 }
 
 // "The weight images a forward prepacked for its backward are written" (GI_RUN_PREPACK_BWD -> GI_BWD_PREPACKED), PER
@@ -1885,7 +1890,14 @@ extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* pa
             r.chk(gi_seg_sum_n(ws + w.m[p], w.ldM, in_perm, seg_off, R, d.M, ws + w.agg[p], w.ldM, 0, r.dims,
                                r.st));
         }
-        // GRU update (gnn/mpnn.py:296-297): both input projections in one launch, then the gate kernel
+        // GRU update (gnn/mpnn.py:296-297): projections + gates in ONE launch (gi_gru.hip, round 6) ...
+        if (gi_gru_fused_ok(d.H, d.M, w.ldM, w.ldhx, w.ld3H)) {
+            r.chk(gi_gru_fused_fwd(ws + w.agg[p], w.ldM, hx, w.ldhx, params[m.gru_wih], params[m.gru_whh],
+                                   params[m.gru_bih], params[m.gru_bhh], ws + w.gi[p], ws + w.gh[p], w.ld3H,
+                                   ws + w.hx[p + 1], seg_off, R, r.dims, d.H, d.M, r.st));
+            continue;
+        }
+        // ... or (GI_GRU_FUSED=0, widths that are not multiples of 4): both input projections in one launch, then the gate kernel
         {
             Batch b;
             add_fwd(b, r, params[m.gru_wih], params[m.gru_bih], d.M, 3 * d.H, ws + w.agg[p], w.ldM, R,

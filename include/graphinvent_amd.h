@@ -39,6 +39,10 @@
  *       GI_MSG_WGRAD_X2=0       the fp16x2 chain kernels' amax cells are not used for the message / energy stacks' weight
  *                               gradients (their first, gathered layer then stays on the fp32 MFMA);
  *                               GI_MSG_SLAB_ROWS=<n>: reduction rows per split-K slab of the new launches (default 460)
+ *       GI_GRU_PAD_LDS=0        (measurement aid) the fused GRU launch without the unused dynamic LDS that keeps it at one
+ *                               workgroup per CU
+ *       GI_GRU_FUSED=0          the forward's GRU update as a two-projection GEMM launch + the gate kernel (default, round 6:
+ *                               one fused launch, csrc/gi_gru.hip)
  *       GI_GEMM_LOG=<file>      one line per GEMM launch (tools/gemm_launch_report.py)
  *     and measurement aids that pick between kernels / schedules that compute the same thing (the A/B files under
  *     profiles/r04 name them): GI_B3P, GI_B3V, GI_B3P_ALL, GI_B3P_STREAM, GI_B3V_GROUPED (which 16-bit-pipe kernel),
@@ -67,7 +71,7 @@
 extern "C" {
 #endif
 
-#define GI_ABI_VERSION 17
+#define GI_ABI_VERSION 18
 #define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
 #define GI_MAX_NODES 128      /* max max_n_nodes */
 #define GI_P0_MAX_CLASSES 256 /* max distinct node feature rows for the pass-0 shortcut */
@@ -509,6 +513,16 @@ int gi_compress_slots_f(float* t1, int ldt, const int* cidx, int B, int N, int W
  * with >=1 incoming edge (gnn/summation_mpnn.py:107,124,143-144 update only those nodes).
  * In: gi,gh [rows,3H] (+bias already added), hx_prev [rows, ldh]; out: hx_new (cols [0,H) and
  * the feature tail [H,H+Fn) copied); gi is overwritten with (r|z|n), gh keeps W_hn h + b_hn. */
+/* The whole GRU update of a message pass (torch.nn.GRUCell as called at gnn/mpnn.py:296-297, with the node mask of
+ * gnn/summation_mpnn.py:146) in ONE launch: gi = agg W_ih^T + b_ih, gh = h W_hh^T + b_hh on the fp32 MFMA and the gate
+ * arithmetic in registers.  agg [rows, lda] (M columns), hx [rows, ldh] = [h (H) | features | padding], W_ih [3H, M],
+ * W_hh [3H, H] row-major.  Writes h' and the copied tail into hx_new [rows, ldh], and what gi_gru_gates_bwd reads: the
+ * gates r, z, n into gi[:, 0:3H], gh_n into gh[:, 2H:3H] (gi / gh rows of nodes without incoming edges, and gh[:, 0:2H],
+ * are left untouched).  H % 4 == M % 4 == lda % 4 == ldh % 4 == 0, 16-byte aligned agg / hx / hx_new; GI_EINVAL otherwise
+ * (callers then use gi_gemm_batch + gi_gru_gates_fwd). */
+int gi_gru_forward(const float* agg, int lda, const float* hx, int ldh, const float* Wih, const float* Whh,
+                   const float* bih, const float* bhh, float* gi, float* gh, int ldg, float* hx_new,
+                   const int* seg_off, int rows, int H, int M, void* stream);
 int gi_gru_gates_fwd(float* gi, float* gh, int ldg, const float* hx_prev, float* hx_new, int ldh,
                      const int* seg_off, int rows, int H, int Fn, void* stream);
 /* In: dh_new (+ up to three more partial gradients dh_b/c/d or NULL, all [rows, lddh]);

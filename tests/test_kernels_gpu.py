@@ -991,6 +991,59 @@ def test_gru_gates_forward_and_backward_kernels(H, Fn):
                    y[:, :3 * H] if y.shape[1] >= 3 * H else y[:, :H]) < 1e-6
 
 
+@pytest.mark.parametrize("R,H,M,Fn", [(7258, 128, 128, 8), (1000, 100, 100, 8), (333, 256, 64, 19), (65, 24, 36, 4), (1, 128, 128, 8)])
+def test_fused_gru_update_vs_fp64_and_vs_the_two_launch_path(R, H, M, Fn):
+    """gi_gru_forward (csrc/gi_gru.hip, round 6): projections + gates of torch.nn.GRUCell (gnn/mpnn.py:296-297) with the
+    node mask (summation_mpnn.py:146) in one launch, against (a) the fp64 arithmetic — h' and the stored gates r, z, n,
+    gh_n at 2e-6 — and (b) the two-launch path it replaces (gi_gemm x 2 + gi_gru_gates_fwd) at 2e-6; the feature tail /
+    padding of the state rows is copied, rows of nodes without incoming edges keep their state bit for bit, nothing is
+    written outside [R, 3H] of gi / gh."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(R + H + M)
+    lda, ldh, ldg = ops.r4(M) + 4, ops.r4(H + Fn), ops.r4(3 * H) + 4
+    agg = torch.randn(R, lda, generator=g); agg[:, M:] = float("nan")
+    hx = torch.randn(R, ldh, generator=g)
+    Wih = torch.randn(3 * H, M, generator=g) / M ** 0.5; Whh = torch.randn(3 * H, H, generator=g) / H ** 0.5
+    bih = torch.randn(3 * H, generator=g) * 0.3; bhh = torch.randn(3 * H, generator=g) * 0.3
+    deg = torch.randint(0, 3, (R,), generator=g)
+    seg = torch.cat([torch.zeros(1, dtype=torch.int64), deg.cumsum(0)]).int()
+    live = deg > 0
+    # fp64 reference
+    gi64 = agg[:, :M].double() @ Wih.double().t() + bih.double()
+    gh64 = hx[:, :H].double() @ Whh.double().t() + bhh.double()
+    r = torch.sigmoid(gi64[:, :H] + gh64[:, :H]); z = torch.sigmoid(gi64[:, H:2 * H] + gh64[:, H:2 * H])
+    n = torch.tanh(gi64[:, 2 * H:] + r * gh64[:, 2 * H:])
+    h_new = torch.where(live[:, None], (1 - z) * n + z * hx[:, :H].double(), hx[:, :H].double())
+    dev = lambda t: t.to(DEV)
+    gi_d = torch.full((R, ldg), 7.0, device=DEV); gh_d = torch.full((R, ldg), 7.0, device=DEV)
+    hx_new = torch.full((R, ldh), 7.0, device=DEV)
+    hx_d, seg_d = dev(hx), dev(seg)
+    agg_d, Wih_d, Whh_d, bih_d, bhh_d = dev(agg), dev(Wih), dev(Whh), dev(bih), dev(bhh)     # (kept alive: raw pointers below)
+    L.check(lib.gi_gru_forward(agg_d.data_ptr(), lda, hx_d.data_ptr(), ldh, Wih_d.data_ptr(), Whh_d.data_ptr(),
+                               bih_d.data_ptr(), bhh_d.data_ptr(), gi_d.data_ptr(), gh_d.data_ptr(), ldg,
+                               hx_new.data_ptr(), seg_d.data_ptr(), R, H, M, _stream()), "gi_gru_forward")
+    assert rel(hx_new[:, :H], h_new) < 2e-6
+    assert torch.equal(hx_new[:, H:].cpu(), hx[:, H:])
+    assert torch.equal(hx_new[~live.to(DEV), :H].cpu(), hx[~live, :H])
+    e = live
+    if bool(e.any()):
+        for got, want in ((gi_d[:, :H], r), (gi_d[:, H:2 * H], z), (gi_d[:, 2 * H:3 * H], n), (gh_d[:, 2 * H:3 * H], gh64[:, 2 * H:])):
+            assert rel(got.cpu()[e], want[e]) < 2e-6
+    assert bool((gi_d[:, 3 * H:] == 7.0).all()) and bool((gh_d[:, 3 * H:] == 7.0).all()) and bool((gh_d[:, :2 * H] == 7.0).all())
+    assert bool((gi_d[~live.to(DEV)] == 7.0).all())
+    # the two-launch path on the same operands
+    gi2 = torch.zeros(R, ldg, device=DEV); gh2 = torch.zeros(R, ldg, device=DEV); hx2 = torch.full((R, ldh), 7.0, device=DEV)
+    ops.gemm(agg_d, Wih_d, gi2, R, 3 * H, M, lda, M, ldg, flags=L.EPI_BIAS, bias=bih_d)
+    ops.gemm(hx_d, Whh_d, gh2, R, 3 * H, H, ldh, H, ldg, flags=L.EPI_BIAS, bias=bhh_d)
+    L.check(lib.gi_gru_gates_fwd(gi2.data_ptr(), gh2.data_ptr(), ldg, hx_d.data_ptr(), hx2.data_ptr(), ldh,
+                                 seg_d.data_ptr(), R, H, Fn, _stream()), "gates_fwd")
+    assert rel(hx_new[:, :H], hx2[:, :H]) < 2e-6
+    # limits are reported
+    assert lib.gi_gru_forward(agg_d.data_ptr(), lda, hx_d.data_ptr(), ldh, Wih_d.data_ptr(), Whh_d.data_ptr(),
+                              bih_d.data_ptr(), bhh_d.data_ptr(), gi_d.data_ptr(), gh_d.data_ptr(), ldg,
+                              hx_new.data_ptr(), seg_d.data_ptr(), R, H - 2, M, _stream()) == -1
+
+
 @pytest.mark.parametrize("two", [False, True])
 def test_gru_gates_backward_with_fused_scatter_is_bit_exact(two):
     """gi_gru_gates_bwd_ex(sc0[, sc1]) == gi_seg_sum(sc, out_perm, src_off, dh, accumulate) launches in front

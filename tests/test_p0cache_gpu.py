@@ -193,3 +193,19 @@ def test_weights_cache_is_bitwise_transparent_and_follows_the_weights(kind, shap
     assert torch.equal(fwd(True), ref4) and torch.equal(fwd(True), ref4)
     if sync_free:
         model.last_bounded_error()
+
+
+def test_weights_cache_derived_by_a_tiny_batch_serves_a_large_one():
+    """The cache's first forward may be a B = 1 call (too few rows for the 16-bit-pipe layers): what it derives must be
+    complete — a following B = 1000 forward of the same weights, which does take those launches, reads the max |W| cells
+    from the cache (round 6: they had not been written, every graph of the large batch got the same logits)."""
+    model, cfg, sh = _model("GGNN", "gdb13")
+    small, big = _batch(sh, 1, 3), _batch(sh, 1000, 4)
+    model.cache_weights = False
+    with torch.no_grad():
+        want = model(*big).clone()
+    model.cache_weights = True
+    with torch.no_grad():
+        model(*small)
+        assert model.__dict__["_w_state"]["valid"]
+        assert torch.equal(model(*big), want)

@@ -351,7 +351,14 @@ def test_trained_checkpoint_parity_in_every_arithmetic_mode(shape, B, over, mode
         assert flipped < 1e-5 * total, (flipped, total)
         assert _rel(out, o32) < 1e-4 and _rel(out, o64) < 1e-4, (_rel(out, o32), _rel(out, o64))
         assert abs(float(loss) - float(l64)) < 1e-4 * abs(float(l64))
-        rows = [(k, _rel(gr, g64[k]), _rel(g32[k], g64[k]), _rel(gr, g32[k])) for k, gr in zip(names, grads)]
+        # A tensor whose gradient has VANISHED on the fitted model (round 6: a checkpoint whose termination output sits on
+        # SELU's floor has max |g| = 7e-16 for the whole fTermNet2 stack, 1e-13 of the largest gradient tensor) has no
+        # meaningful relative error — 1.6e-3 "of" 7e-16 is rounding noise at 1e-18.  Denominators are floored at 1e-9 of
+        # the largest gradient tensor's maximum: below that a gradient is zero for any optimizer step.
+        floor = 1e-9 * max(float(g64[k].abs().max()) for k in names)
+        relf = lambda a, b: float((torch.as_tensor(a).detach().double().cpu() - torch.as_tensor(b).detach().double().cpu()).abs().max()
+                                  / max(float(torch.as_tensor(b).detach().double().abs().max()), floor))
+        rows = [(k, relf(gr, g64[k]), relf(g32[k], g64[k]), relf(gr, g32[k])) for k, gr in zip(names, grads)]
         worst = max(rows, key=lambda r: r[1])
         worst_ref = max(rows, key=lambda r: r[2])
         over_bar = [r for r in rows if r[1] >= 1e-4]
@@ -368,7 +375,7 @@ def test_trained_checkpoint_parity_in_every_arithmetic_mode(shape, B, over, mode
         l2_ref = (sum(float((g32[k].double() - g64[k]).pow(2).sum()) for k in names) / den) ** 0.5
         den_own = sum(float(g64_own[k].pow(2).sum()) for k in names)
         l2_e2e = (sum(float((gr.double().cpu() - g64_own[k]).pow(2).sum()) for k, gr in zip(names, grads)) / den_own) ** 0.5
-        e2e = max(((k, _rel(gr, g64_own[k])) for k, gr in zip(names, grads)), key=lambda r: r[1])
+        e2e = max(((k, relf(gr, g64_own[k])) for k, gr in zip(names, grads)), key=lambda r: r[1])
         print(f"[trained checkpoint, {shape}, {mode}] the gradient as a whole, relative L2 distance from fp64: backward operator "
               f"(same d loss / d logits) HIP {l2_hip:.2e}, fp32 oracle {l2_ref:.2e}; end to end (the fp64 oracle's own logits "
               f"and gradient) HIP {l2_e2e:.2e}, its worst tensor {e2e[1]:.2e} ({e2e[0]})")
