@@ -23,7 +23,12 @@
 
 namespace {
 
-constexpr int GU_TM = 64, GU_TN = 64, GU_KC = 16, GU_LD = GU_KC + 2;
+#ifndef GI_GRU_KC
+#define GI_GRU_KC 16
+#endif
+constexpr int GU_TM = 64, GU_TN = 64, GU_KC = GI_GRU_KC, GU_LD = GU_KC + 2;
+constexpr int GU_QPR = GU_KC / 4;                               // float4 per row of a chunk
+constexpr int GU_NA = GU_TM * GU_QPR / 256, GU_NW = 3 * GU_TN * GU_QPR / 256;    // float4 per thread and chunk: A, W
 typedef float gu_f32x2 __attribute__((ext_vector_type(2)));
 
 struct GruArgs {
@@ -70,36 +75,44 @@ __global__ __launch_bounds__(512) void gru_fused_fwd_kernel(const GruArgs a) {
         }
     }
 
-    // ---- staging (per group): thread -> one float4 of the A chunk, three of the B chunk ---------------------------
-    const int s_row = tg >> 2, s_q = tg & 3;                     // A: 64 rows x 4 float4
-    const long long a_row = min(row0 + s_row, rows - 1);
+    // ---- staging (per group): thread -> GU_NA float4 of the A chunk, GU_NW of the B chunk ------------------------------
     const int K = grp ? H : M;
-    const float* const Arow = grp ? a.hx + a_row * a.ldh : a.agg + a_row * a.lda;
+    const float* const Abase = grp ? a.hx : a.agg;
+    const int lda_ = grp ? a.ldh : a.lda;
     const float* const W = grp ? a.Whh : a.Wih;
     const int nci = (M + GU_KC - 1) / GU_KC, nch = (H + GU_KC - 1) / GU_KC;
     const int mine = grp ? nch : nci, nc = max(nci, nch);
-    v4f ra_[2], rb_[2][3];                                       // TWO register stages: chunk c + 2 is requested while chunk c is multiplied
+    v4f ra_[2][GU_NA], rb_[2][GU_NW];                            // TWO register stages: chunk c + 2 is requested while chunk c is multiplied
     // (loads are UNCONDITIONAL — addresses clamped into the row, values beyond K zeroed by a select when they are written
     // to LDS: a conditional load is a branch in the k loop)
     auto gload = [&](int c, int set) {
         const int kc0 = min(c, mine - 1) * GU_KC;
-        ra_[set] = *(const v4f*)(Arow + min(kc0 + 4 * s_q, K - 4));
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int idx = tg + 256 * i, wr = idx >> 2;         // 192 weight rows x 4 float4
+        for (int i = 0; i < GU_NA; ++i) {
+            const int idx = tg + 256 * i, ar = idx / GU_QPR, aq = idx % GU_QPR;
+            const long long row = min(row0 + ar, rows - 1);
+            ra_[set][i] = *(const v4f*)(Abase + row * lda_ + min(kc0 + 4 * aq, K - 4));
+        }
+#pragma unroll
+        for (int i = 0; i < GU_NW; ++i) {
+            const int idx = tg + 256 * i, wr = idx / GU_QPR;      // 192 weight rows x GU_QPR float4
             const int unit = min(j0 + (wr & 63), H - 1);         // (units beyond H: any readable row, discarded)
             const float* wrow = W + (long long)((wr >> 6) * H + unit) * K;
-            rb_[set][i] = *(const v4f_u*)(wrow + min(kc0 + 4 * (idx & 3), K - 4));
+            rb_[set][i] = *(const v4f_u*)(wrow + min(kc0 + 4 * (idx % GU_QPR), K - 4));
         }
     };
     auto sstore = [&](int c, int set) {
         const int buf = c & 1, kc0 = c * GU_KC;
         const v4f zero = {0.f, 0.f, 0.f, 0.f};
-        *(v4f_u*)&As[buf][s_row][4 * s_q] = (kc0 + 4 * s_q < K) ? ra_[set] : zero;      // (K % 4 == 0: a float4 is inside or outside)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < GU_NA; ++i) {
+            const int idx = tg + 256 * i, ar = idx / GU_QPR, aq = idx % GU_QPR;
+            *(v4f_u*)&As[buf][ar][4 * aq] = (kc0 + 4 * aq < K) ? ra_[set][i] : zero;      // (K % 4 == 0: a float4 is inside or outside)
+        }
+#pragma unroll
+        for (int i = 0; i < GU_NW; ++i) {
             const int idx = tg + 256 * i;
-            *(v4f_u*)&Ws[buf][idx >> 2][4 * (idx & 3)] = (kc0 + 4 * (idx & 3) < K) ? rb_[set][i] : zero;
+            *(v4f_u*)&Ws[buf][idx / GU_QPR][4 * (idx % GU_QPR)] = (kc0 + 4 * (idx % GU_QPR) < K) ? rb_[set][i] : zero;
         }
     };
 
@@ -112,7 +125,7 @@ __global__ __launch_bounds__(512) void gru_fused_fwd_kernel(const GruArgs a) {
     auto compute = [&](int c) {
         const int buf = c & 1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < GU_QPR; ++q) {
             const gu_f32x2 av = *(const gu_f32x2*)&As[buf][rh * 32 + l31][4 * q + 2 * lg];
             gu_f32x2 bv[3];
 #pragma unroll
