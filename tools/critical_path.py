@@ -41,7 +41,7 @@ def main():
     def first(pred, after=0.0):
         return next(r for r in mq if pred(r["Kernel_Name"]) and r["s"] >= after)
 
-    gates_f = [r for r in mq if "gru_gates_fwd" in r["Kernel_Name"]]
+    gates_f = [r for r in mq if "gru_gates_fwd" in r["Kernel_Name"] or "gru_fused_fwd" in r["Kernel_Name"]]   # (round 6: the fused update)
     gather_f = first(lambda n: "gather_fwd" in n)
     kl = first(lambda n: "kl_loss" in n)
     mean = first(lambda n: "mean_rows" in n)
