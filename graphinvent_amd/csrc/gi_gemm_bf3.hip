@@ -41,7 +41,12 @@ typedef unsigned gi_u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-__device__ float b3_sink[256];                    // where out-of-range lanes of edge tiles store
+__device__ float b3_sink[256];
+#ifdef B3_PIN            // lab: keep the steady loop's global loads where the source has them (two k tiles ahead)
+#define B3_SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define B3_SB()
+#endif                    // where out-of-range lanes of edge tiles store
 
 constexpr int B3_BM = 128, B3_BN = 128, B3_BK = 16;
 constexpr int B3_ROWB = B3_BK * 2;                 // bytes of one row of one plane of a k tile (16 bf16)
@@ -139,6 +144,9 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
     const int m_end = p.m_dev ? min(p.M, *p.m_dev) : p.M;
     const int m0 = by * B3_BM, n0 = bx * B3_BN;
     if (m0 >= m_end) return;                                   // (bounded launch: beyond the rows on the device)
+#ifdef B3_LAB_EMPTY                        // lab, TIMING ONLY: the launch itself
+    if (p.K != 123456) return;
+#endif
     const int K = p.K, Kp = b3_r32(K), nk = Kp / B3_BK;
     float sa = 1.f, ia = 1.f, sb = 1.f, ib = 1.f;               // fp16x2: per-tensor power-of-two scales
     if (X2) { gx_scale(gx_amax_read(p.a_amax), sa, ia); gx_scale(gx_amax_read(p.b_amax), sb, ib); }
@@ -208,6 +216,9 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) rp[pl] = *reinterpret_cast<const gi_u32x4*>(pbase + pl * aplane + ap_off);
         } else if (STEADY) {
+#ifdef B3_LAB_NO_GLOAD                     // lab, TIMING ONLY: the steady loop re-uses what the prologue loaded
+            return;
+#endif
             const char* abase = (const char*)p.A + (size_t)k0 * 4;
 #pragma unroll
             for (int i = 0; i < 2; ++i) ra[i] = *(const v4f_u*)(abase + a_voff[i]);
@@ -248,9 +259,14 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
             gi_u32x2 w0, w1, w2;
             unsigned x0, x1, x2, y0, y1, y2;
             if (X2) {
+#ifdef B3_LAB_NO_SPLIT                     // lab, TIMING ONLY: the raw bits instead of the two planes
+                x0 = __builtin_bit_cast(unsigned, v.x); x1 = __builtin_bit_cast(unsigned, v.y);
+                y0 = __builtin_bit_cast(unsigned, v.z); y1 = __builtin_bit_cast(unsigned, v.w);
+#else
                 rowmax[i] = fmaxf(fmaxf(rowmax[i], fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                 gx_split2(v.x, v.y, sa, x0, x1);
                 gx_split2(v.z, v.w, sa, y0, y1);
+#endif
             } else {
                 b3_split2(v.x, v.y, x0, x1, x2);
                 b3_split2(v.z, v.w, y0, y1, y2);
@@ -269,8 +285,13 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
                 gi_u32x2 w0, w1, w2;
                 unsigned x0, x1, x2, y0, y1, y2;
                 if (X2) {
+#ifdef B3_LAB_NO_SPLIT
+                    x0 = __builtin_bit_cast(unsigned, v.x); x1 = __builtin_bit_cast(unsigned, v.y);
+                    y0 = __builtin_bit_cast(unsigned, v.z); y1 = __builtin_bit_cast(unsigned, v.w);
+#else
                     gx_split2(v.x, v.y, sb, x0, x1);
                     gx_split2(v.z, v.w, sb, y0, y1);
+#endif
                 } else {
                     b3_split2(v.x, v.y, x0, x1, x2);
                     b3_split2(v.z, v.w, y0, y1, y2);
@@ -311,6 +332,14 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
         }
         if (X2) {                                    // a2 b1 + a1 b2 + a1 b1 on the f16 MFMA (smallest terms first)
             constexpr int XA[3] = {1, 0, 0}, XB[3] = {0, 1, 0};
+#ifdef B3_LAB_NO_MFMA                      // lab, TIMING ONLY: one MFMA per wave and k tile instead of twelve
+#define B3_U(x) __builtin_bit_cast(gi_u32x4, x)
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                __builtin_bit_cast(gx_f16x8, B3_U(af[0][0]) ^ B3_U(af[1][0]) ^ B3_U(af[0][1]) ^ B3_U(af[1][1])),
+                __builtin_bit_cast(gx_f16x8, B3_U(bf[0][0]) ^ B3_U(bf[1][0]) ^ B3_U(bf[0][1]) ^ B3_U(bf[1][1])), acc[0][0], 0, 0, 0);
+#undef B3_U
+            return;
+#endif
 #pragma unroll
             for (int term = 0; term < 3; ++term)
 #pragma unroll
@@ -348,12 +377,17 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
     sstore(GEN, 0, 0, ra0, rb0, rp0, rf0);
     __syncthreads();
     int kt = 0;
+#ifdef B3_LAB_NO_LOOP                      // lab, TIMING ONLY: prologue + epilogue
+    kt = nk;
+#endif
     for (; kt + 3 < n_full; kt += 2) {                           // every tile touched is full: kt + 1 .. kt + 3
         gload(ST, kt + 2, ra0, rb0, rp0, rf0);
+        B3_SB();
         compute(0);
         sstore(ST, kt + 1, 1, ra1, rb1, rp1, rf1);
         __syncthreads();
         gload(ST, kt + 3, ra1, rb1, rp1, rf1);
+        B3_SB();
         compute(1);
         sstore(ST, kt + 2, 0, ra0, rb0, rp0, rf0);
         __syncthreads();
@@ -390,6 +424,15 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
         }
     }
 
+#ifdef B3_LAB_NO_EPI                       // lab, TIMING ONLY: one store per thread instead of the epilogue
+    {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[0][0][r] + acc[0][1][r] + acc[1][0][r] + acc[1][1][r];
+        if (t == 123.456f) p.C[tid] = t;
+        return;
+    }
+#endif
     // ---- epilogue (C/D layout of a 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) --
     const int flags = EPI == 1 ? (GI_EPI_BIAS | GI_EPI_SELU) : (EPI == 2 ? GI_EPI_DSELU : p.flags);
     const bool need_act = (flags & (GI_EPI_DSELU | GI_EPI_MULACT)) != 0;
@@ -425,7 +468,11 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + 8 * (r >> 2) + (r & 3);
                 const bool ok = col_ok & (row < m_end);
+#ifdef B3_LAB_NO_STORE                     // lab, TIMING ONLY
+                float* dst = (ok && v[r] == 123.456f) ? p.C + (long long)row * p.ldc + col : b3_sink + tid;
+#else
                 float* dst = ok ? p.C + (long long)row * p.ldc + col : b3_sink + tid;
+#endif
                 *dst = v[r];
                 amax = fmaxf(amax, ok ? fabsf(v[r]) : 0.f);
             }

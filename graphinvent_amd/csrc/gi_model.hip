@@ -365,6 +365,11 @@ int bf3_wgrad_nsplit(int red_rows, int decide_rows, int slab_rows = 0) {
 // SHORT slabs (GI_MSG_SLAB_ROWS, default below) trade slab traffic for workgroups.  GI_MSG_WGRAD_X2=0 / GI_WGRAD_X2_ALL=0:
 // as before.
 constexpr int X2ALL_MIN_WIDTH = 32, X2ALL_MIN_ROWS = 512;
+// GI_P0_GRU_MAIN (default 1): pass 0's GRU weight gradients run in the main queue's last launch (gi_ggnn_backward_phase)
+bool p0_gru_on_main() {
+    static const int v = getenv("GI_P0_GRU_MAIN") ? atoi(getenv("GI_P0_GRU_MAIN")) : 1;
+    return v != 0;
+}
 int msg_slab_rows() {
     static const int v = getenv("GI_MSG_SLAB_ROWS") ? std::max(64, atoi(getenv("GI_MSG_SLAB_ROWS"))) : 460;
     return v;
@@ -2222,6 +2227,12 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
                                    d.H, r.st));
         }
         float* dagg = ws + w.dagg[p];
+        // Pass 0 of the class-row path: the main queue has ~100 us of short launches left, the weight-gradient queue
+        // everything deferred so far.  GI_P0_GRU_MAIN (default 1): hand that over NOW and keep pass 0's own GRU weight
+        // gradients for the main queue's last launch (with the pass-0 message stack's), so that both queues end together.
+        if (p == 0 && w.D0 > 0 && r.side && p0_gru_on_main() && !r.p0_on_main) {
+            kick_deferred(r, dq, r.side, true); flush_bias(r, dq, r.side->st); r.hold_kicks = r.p0_on_main = true;
+        }
         {
             const int wih = m.gru_wih, whh = m.gru_whh;
             defer_wgrad(r, dq, sp, slabs, &wih, none, gi, w.ld3H, agg, w.ldM, nullptr, R);
@@ -2246,7 +2257,7 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
                 {m.eatt, w.aact[p], w.adz[p], w.ldEa, ws + w.een[p], w.ldM,
                  p > 0 ? ws + w.dxa : nullptr}};
             if (p0) {   // per class row: sum over its (hundreds of) edge slots, both stacks in one launch
-                if (r.side) { kick_deferred(r, dq, r.side, true); flush_bias(r, dq, r.side->st); r.hold_kicks = r.p0_on_main = true; }
+                if (r.side && !r.p0_on_main) { kick_deferred(r, dq, r.side, true); flush_bias(r, dq, r.side->st); r.hold_kicks = r.p0_on_main = true; }
                 r.chk(gi_class_sum_dselu(ws + w.tmp_emb, ws + w.tmp_en, w.ldM, gp->cls_edges,
                                          gp->cls_off, w.D0, d.M, ws + w.m[p], ws + w.een[p], w.ldM,
                                          r.st));
@@ -2270,7 +2281,7 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
         } else if (p == 0 && w.D0 > 0) {
             // pass 0: d m0 = selu'(m0) * (cmat^T . d agg): split-K over the R rows, slabs summed with
             // the SELU backward folded in; then the MLP backward on the D0 class rows (no d h needed)
-            if (r.side) { kick_deferred(r, dq, r.side, true); flush_bias(r, dq, r.side->st); r.hold_kicks = r.p0_on_main = true; }   // nothing queued waits for the pass-0 chain
+            if (r.side && !r.p0_on_main) { kick_deferred(r, dq, r.side, true); flush_bias(r, dq, r.side->st); r.hold_kicks = r.p0_on_main = true; }   // nothing queued waits for the pass-0 chain
             gi_gemm_params q;
             gemm_defaults(q);
             q.A = gp->cmat; q.lda = gp->ldc0; q.a_major = 1;

@@ -158,7 +158,32 @@ int main(int argc, char** argv) {
         (void)hipMemcpy(am, hm.data(), hm.size() * 4, hipMemcpyHostToDevice);
         printf("[fp16x2] ");
     }
-    auto launch = [&] { const int rc = gi_gemm_batch(probs, n, 0); if (rc) { printf("rc %d\n", rc); exit(1); } };
+    // GI_LAB_TWO=1 (4-problem classes): problems {0, 2} and {1, 3} as two launches on two streams, the timed region
+    // ends when both streams have finished (do two half launches that drift out of phase beat one full launch?)
+    const bool two = getenv("GI_LAB_TWO") && atoi(getenv("GI_LAB_TWO")) && n == 4;
+    hipStream_t s2[2] = {nullptr, nullptr};
+    hipEvent_t ej[2] = {nullptr, nullptr}, es = nullptr;
+    gi_gemm_params half[2][2];
+    if (two) {
+        for (int i = 0; i < 2; ++i) { (void)hipStreamCreateWithFlags(&s2[i], hipStreamNonBlocking); (void)hipEventCreateWithFlags(&ej[i], hipEventDisableTiming); }
+        (void)hipEventCreateWithFlags(&es, hipEventDisableTiming);
+        half[0][0] = probs[0]; half[0][1] = probs[2]; half[1][0] = probs[1]; half[1][1] = probs[3];
+        printf("[two streams] ");
+    }
+    int lab_reps = 1;
+    auto launch = [&] {
+        if (two) {                                  // lab_reps launches per stream between one fork and one join
+            (void)hipEventRecord(es, 0);
+            for (int h = 0; h < 2; ++h) {
+                (void)hipStreamWaitEvent(s2[h], es, 0);
+                for (int i = 0; i < lab_reps; ++i) { const int rc = gi_gemm_batch(half[h], 2, s2[h]); if (rc) { printf("rc %d\n", rc); exit(1); } }
+                (void)hipEventRecord(ej[h], s2[h]);
+                (void)hipStreamWaitEvent(0, ej[h], 0);
+            }
+            return;
+        }
+        for (int i = 0; i < lab_reps; ++i) { const int rc = gi_gemm_batch(probs, n, 0); if (rc) { printf("rc %d\n", rc); exit(1); } }
+    };
     for (int i = 0; i < 5; ++i) launch();
     (void)hipDeviceSynchronize();
     // ---- spot check against double-precision dot products ------------------------------------------
@@ -199,7 +224,8 @@ int main(int argc, char** argv) {
     const int rounds = 7, reps = 20;
     for (int r = 0; r < rounds; ++r) {
         (void)hipEventRecord(e0);
-        for (int i = 0; i < reps; ++i) launch();
+        if (two) { lab_reps = reps; launch(); lab_reps = 1; }
+        else for (int i = 0; i < reps; ++i) launch();
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         best = ms < best ? ms : best; sum += ms;
