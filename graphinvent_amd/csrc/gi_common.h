@@ -49,7 +49,7 @@ int gi_gru_gates_fwd_n(float* gi, float* gh, int ldg, const float* hx_prev, floa
 bool gi_gru_fused_ok(int H, int M, int lda, int ldh, int ldg);
 int gi_gru_fused_fwd(const float* agg, int lda, const float* hx, int ldh, const float* Wih, const float* Whh,
                      const float* bih, const float* bhh, float* gi, float* gh, int ldg, float* hx_new,
-                     const int* seg_off, int rows, const int* rows_dev, int H, int M, float* h_amax, void* stream);
+                     const int* seg_off, int rows, const int* rows_dev, int H, int M, void* stream);
 
 // gi_gemm_batch hands launches whose problems all carry GI_GEMM_BF3 to gi_gemm_bf3.hip
 int gi_gemm_bf3_launch(const gi_gemm_params* probs, int n, void* stream);

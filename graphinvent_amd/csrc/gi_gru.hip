@@ -20,7 +20,6 @@
 
 #include "gi_common.h"
 #include "gi_mfma.h"
-#include "gi_x2.h"
 
 namespace {
 
@@ -42,7 +41,6 @@ struct GruArgs {
     const int* seg_off;                     // [R + 1]: incoming-edge CSR offsets (node mask)
     int rows; const int* rows_dev;          // rows_dev != NULL: the real row count lives on the device (bounded forward)
     int H, M;
-    float* h_amax;                          // != NULL: amax cell (gi_x2.h) that takes max |h'| over the rows x H written here
 };
 
 // 512 threads = TWO groups of 2 x 2 waves: group 0 accumulates the input projection (agg W_ih^T, reduction over M), group 1
@@ -176,7 +174,6 @@ __global__ __launch_bounds__(512) void gru_fused_fwd_kernel(const GruArgs a) {
     const float br = a.bih[jc] + a.bhh[jc], bz = a.bih[H + jc] + a.bhh[H + jc];
     const float bin = a.bih[2 * H + jc], bhn = a.bhh[2 * H + jc];
     float hp[16];
-    float amax = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int lr = rh * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
@@ -201,10 +198,7 @@ __global__ __launch_bounds__(512) void gru_fused_fwd_kernel(const GruArgs a) {
             hrow[2 * H + j] = ghn;
         }
         a.hx_new[(long long)row * a.ldh + j] = hn_out;
-        amax = fmaxf(amax, fabsf(hn_out));
     }
-    // the node-level stacks' first layers read h' next: as fp16x2 launches they scale it by its largest magnitude
-    if (a.h_amax) gx_amax_publish(amax, a.h_amax);
 }
 
 }  // namespace
@@ -218,13 +212,13 @@ bool gi_gru_fused_ok(int H, int M, int lda, int ldh, int ldg) {
 
 int gi_gru_fused_fwd(const float* agg, int lda, const float* hx, int ldh, const float* Wih, const float* Whh,
                      const float* bih, const float* bhh, float* gi, float* gh, int ldg, float* hx_new,
-                     const int* seg_off, int rows, const int* rows_dev, int H, int M, float* h_amax, void* stream) {
+                     const int* seg_off, int rows, const int* rows_dev, int H, int M, void* stream) {
     (void)hipGetLastError();
     if (rows <= 0) return 0;
     if (!agg || !hx || !Wih || !Whh || !bih || !bhh || !gi || !gh || !hx_new || !seg_off) return GI_EINVAL;
     if (!gi_gru_fused_ok(H, M, lda, ldh, ldg)) return GI_EINVAL;
     if ((((uintptr_t)agg | (uintptr_t)hx | (uintptr_t)hx_new) & 15) != 0) return GI_EINVAL;
-    GruArgs a{agg, lda, hx, ldh, Wih, Whh, bih, bhh, gi, gh, ldg, hx_new, seg_off, rows, rows_dev, H, M, h_amax};
+    GruArgs a{agg, lda, hx, ldh, Wih, Whh, bih, bhh, gi, gh, ldg, hx_new, seg_off, rows, rows_dev, H, M};
     hipStream_t st = (hipStream_t)stream;
     GiProfScope prof(st, GI_PROF_GEMM, 2.0 * (double)rows * 3.0 * H * ((double)M + H));
     // ONE workgroup per CU: the kernel is MFMA-bound with one wave per SIMD (four waves = four SIMDs), and the dispatcher
@@ -245,6 +239,6 @@ int gi_gru_fused_fwd(const float* agg, int lda, const float* hx, int ldh, const 
 // C ABI (include/graphinvent_amd.h): the fused update by itself (tests; gi_ggnn_forward calls the function above)
 extern "C" int gi_gru_forward(const float* agg, int lda, const float* hx, int ldh, const float* Wih, const float* Whh,
                               const float* bih, const float* bhh, float* gi, float* gh, int ldg, float* hx_new,
-                              const int* seg_off, int rows, int H, int M, float* h_amax, void* stream) {
-    return gi_gru_fused_fwd(agg, lda, hx, ldh, Wih, Whh, bih, bhh, gi, gh, ldg, hx_new, seg_off, rows, nullptr, H, M, h_amax, stream);
+                              const int* seg_off, int rows, int H, int M, void* stream) {
+    return gi_gru_fused_fwd(agg, lda, hx, ldh, Wih, Whh, bih, bhh, gi, gh, ldg, hx_new, seg_off, rows, nullptr, H, M, stream);
 }

@@ -115,7 +115,6 @@ struct Ws {
     // fp16x2 chain kernels — [pass][0: layer inputs X_l, 1: dZ_l][layer] (msg_cells)
     long long msg_amax[2];
     long long amax_pool;                // cells for weight-gradient operands nobody publishes a maximum of (AmaxPool)
-    long long h_amax;                   // max |h after the last message pass| (published by the fused GRU launch: first_layer_x2)
     // AlphaDropout training mode: the workspace is allocated twice; float i of the second half holds
     // the backward factor d y / d z of activation i of the first (0: mode off)
     long long fshift;
@@ -171,22 +170,6 @@ static bool chain_fwd_x2_enabled(bool call_x2) {
 }
 bool bf3_wide(const Mlp& q, int l) { return q.fan_in(l) >= BF3_MIN_WIDTH && q.fan_out(l) >= BF3_MIN_WIDTH; }
 bool bf3_layer_ok(const Mlp& q, int l) { return bf3_enabled() && bf3_wide(q, l); }
-// Round 6: the node-level stacks' FIRST layers (K = H: the state after the last message pass) as fp16x2 launches too —
-// forward and weight gradient; their dgrad (N = H = one column tile, accumulated over the four stacks) stays on the fp32
-// MFMA.  What they lacked was max |h|: the fused GRU launch of the last pass publishes it (gi_gru.hip, h_amax).  Static
-// part of the condition (the model, the switches); per call: fp16x2 on, no dropout, >= BF3_MIN_ROWS node rows.
-// GI_FIRST_X2=0: as before (fp32 MFMA; bf16x3 where the layer is >= 192 wide on both sides).
-int first_layer_x2_mode() {                   // 1: forward and weight gradient, 2: forward only, 3: weight gradient only
-    static const int v = getenv("GI_FIRST_X2") ? atoi(getenv("GI_FIRST_X2")) : 1;
-    return v;
-}
-bool first_layer_x2_static(const gi_ggnn_dims& d) {
-    return first_layer_x2_mode() != 0 && bf3_enabled() && gi_b3p_enable(-1) && !d.dropout && d.passes > 0 &&
-           gi_gru_fused_ok(d.H, d.M, gi_r4(d.M), gi_r4(d.H + d.Fn), gi_r4(3 * d.H));
-}
-bool first_layer_x2_ok(const Mlp& q) {       // wide output, a reduction the 16-deep k tiles can walk, a layer above it
-    return q.layers() > 1 && !bf3_wide(q, 0) && q.fan_out(0) >= BF3_MIN_WIDTH && q.fan_in(0) >= 32 && (q.fan_in(0) & 3) == 0;
-}
 
 // A forward / dgrad problem with few output tiles and a long reduction (the first layer of fAddNet2 at
 // the ChEMBL shape: 250 x 500 outputs, K = N*A + G = 9 252 — 32 workgroups walking 290 k tiles each,
@@ -316,7 +299,6 @@ void make_ws(const Model& m, int S, int E, int U, int D0, Ws& w) {
         }
     }
     w.amax_pool = take((long long)AMAX_POOL_CELLS * GI_AMAX_WORDS, 1);
-    w.h_amax = take(GI_AMAX_WORDS, 1);
     w.fshift = d.dropout ? gi_r4l(o) : 0;
     w.total = d.dropout ? 2 * gi_r4l(o) : o;
 }
@@ -496,13 +478,8 @@ void plan_slabs(const Model& m, int S, int E, const int* Et, SlabPlan& sp) {   /
     }
     add(m.gru_wih, m.gru_bih, 3 * d.H, d.M, R, d.passes, 1.0);
     add(m.gru_whh, m.gru_bhh, 3 * d.H, d.H, R, d.passes, 1.0);
-    {   // node-level stacks: hidden layers by the round-4 rule; first layers (first_layer_x2) with published cells
-        const bool firsts = first_layer_x2_static(d) && first_layer_x2_mode() != 2 && x2_enabled() && R >= BF3_MIN_ROWS;
-        for (const Mlp* q : {&m.att, &m.emb, &m.add1, &m.conn1})
-            for (int l = 0; l < q->layers(); ++l)
-                add(q->w(l), q->b(l), q->fan_out(l), q->fan_in(l), R, 1, 1.0, true, -1, false,
-                    l == 0 && firsts && first_layer_x2_ok(*q));
-    }
+    add_mlp(m.att, R, 1, 1.0, true); add_mlp(m.emb, R, 1, 1.0, true); add_mlp(m.add1, R, 1, 1.0, true);
+    add_mlp(m.conn1, R, 1, 1.0, true);
     static const int force_g = getenv("GI_B3W_G") ? atoi(getenv("GI_B3W_G")) : -1;             // (measurement aid)
     const bool g3 = force_g >= 0 ? force_g != 0 : d.B >= BF3_WGRAD_SMALL_MIN / 4;
     add_mlp(m.add2, d.B, 1, 1.0, g3); add_mlp(m.conn2, d.B, 1, 1.0, g3); add_mlp(m.term2, d.B, 1, 1.0, g3);
@@ -556,8 +533,7 @@ struct Run {
     // and the dgrad launch of the layer above (c_amax of add_dgrad).  A stack's first layer reads h (GRU gate kernel)
     // and its last layer's dZ comes from the loss / gather backward: nobody measures those, so fp16x2 launches that
     // would need them stay bf16x3 (round-4 advisor finding: a zeroed cell reads as scale 1).
-    struct Bf3 { const float* W; const unsigned short* img; float* amax; float* wamax; bool in_ok, dz_ok; const float* in_cell; } bf3[GI_BF3_PACK_MAX];   // in_cell: max |layer input| lives elsewhere (first layers: Run::h_amax); img == NULL in a backward: no 16-bit dgrad   // wamax: the max |W| cell (amax[0], or its place in gi_graph.wcache)
-    float* h_amax = nullptr;                // != null: the fused GRU launch of the last pass publishes max |h| here and the node-level stacks' first layers run fp16x2 (first_layer_x2)
+    struct Bf3 { const float* W; const unsigned short* img; float* amax; float* wamax; bool in_ok, dz_ok; } bf3[GI_BF3_PACK_MAX];   // wamax: the max |W| cell (amax[0], or its place in gi_graph.wcache)
     float* wc_bf3 = nullptr;                // gi_graph.wcache: the node-level layers' max |W| cells ...
     bool wc_valid = false;                  // ... and whether the cache's contents match the weights (nothing to derive)
     int nbf3 = 0;
@@ -799,7 +775,7 @@ void add_fwd(Batch& b, Run& r, const float* W, const float* bias, int in, int ou
     if (const Run::Bf3* e = r.bf3_layer(W, rows)) {
         p.flags |= GI_GEMM_BF3 | GI_GEMM_BF3B_F32;                             // (B = W [out][in] as stored)
         if (e->amax && e->in_ok) {
-            p.flags |= GI_GEMM_X2; p.a_amax = e->in_cell ? e->in_cell : e->amax + GI_AMAX_WORDS; p.b_amax = e->wamax;
+            p.flags |= GI_GEMM_X2; p.a_amax = e->amax + GI_AMAX_WORDS; p.b_amax = e->wamax;
             p.x2_guard = r.guard; p.x2_guard_host = r.guard_host;           // activation rows outside the per-tensor range
         }
     }
@@ -882,7 +858,7 @@ void defer_wgrad(Run& r, Deferred& q, SlabPlan& sp, float* slabs, const int* wid
         const float* cb = x_amax;
         if (!g.n && !(ca && cb))
             if (const Run::Bf3* e = r.bf3_layer(r.P[widx[0]], rows))
-                if (e->amax) { if (e->dz_ok) ca = e->amax + 2 * GI_AMAX_WORDS; if (e->in_ok) cb = e->in_cell ? e->in_cell : e->amax + GI_AMAX_WORDS; }
+                if (e->amax) { if (e->dz_ok) ca = e->amax + 2 * GI_AMAX_WORDS; if (e->in_ok) cb = e->amax + GI_AMAX_WORDS; }
         const bool pool = r.wgrad_x2 && !b_idx && (e0.bf3 || wgrad_x2_all_enabled());
         if ((ca && cb) || pool) {
             if (!b_idx || e0.x2all) {
@@ -1562,7 +1538,7 @@ void bf3_prepare(Run& r, const Model& m, float* ws, const Ws& w, bool backward, 
             d[n].rows = backward ? fi : fo; d[n].cols = backward ? fo : fi;
             d[n].image = img + used; d[n].as_f32 = 1;     // (W^T as fp32: 4 bytes per element through L2, not 6)
             r.bf3[n].W = d[n].W; r.bf3[n].img = backward ? d[n].image : nullptr;
-            r.bf3[n].in_ok = l > 0; r.bf3[n].dz_ok = l + 1 < q->layers(); r.bf3[n].in_cell = nullptr;
+            r.bf3[n].in_ok = l > 0; r.bf3[n].dz_ok = l + 1 < q->layers();
             // fp16x2 (gi_x2.h): three amax cells per layer — max |W| (gi_absmax, in the forward), max |layer input| and
             // max |dZ of its output| (the c_amax of the launches that produce them; zeroed once per forward: the
             // backward runs on the same workspace)
@@ -1573,23 +1549,7 @@ void bf3_prepare(Run& r, const Model& m, float* ws, const Ws& w, bool backward, 
             used += std::max(gi_bf3_image_elems(fo, fi), gi_bf3_image_elems(fi, fo));
             ++n;
         }
-    const int n_img = n;                         // (the entries above have W^T images in a backward; the ones below do not)
-    // first layers (first_layer_x2): forward and weight gradient only — no image, max |input| = the GRU launch's cell.
-    // BEHIND the hidden layers, so that those keep their places in gi_graph.wcache whether or not these are present.
-    if (x2 && (r.h_amax || (derive_only && first_layer_x2_static(m.d))))
-        for (const Mlp* q : t1) {
-            if (n >= GI_BF3_PACK_MAX || !first_layer_x2_ok(*q)) continue;
-            if (!derive_only && first_layer_x2_mode() == (backward ? 2 : 3)) continue;
-            const int fi = q->fan_in(0), fo = q->fan_out(0);
-            r.bf3[n].W = r.P[q->w(0)]; r.bf3[n].img = nullptr;
-            r.bf3[n].in_ok = true; r.bf3[n].dz_ok = true; r.bf3[n].in_cell = r.h_amax;
-            r.bf3[n].amax = am + 4LL * GI_AMAX_WORDS * n;
-            r.bf3[n].wamax = r.wc_bf3 ? r.wc_bf3 + (long long)GI_AMAX_WORDS * n : r.bf3[n].amax;
-            ad[n].x = r.bf3[n].W; ad[n].rows = 1; ad[n].cols = fi * fo; ad[n].ld = fi * fo; ad[n].out = r.bf3[n].wamax;
-            wd[n].x = r.bf3[n].W; wd[n].rows = fo; wd[n].cols = fi; wd[n].ld = fi; wd[n].out = r.bf3[n].wamax;
-            ++n;
-        }
-    if (n_img && backward && (what & BF3_DO_PACK) && !derive_only) r.chk(gi_bf3_pack(d, n_img, st));
+    if (n && backward && (what & BF3_DO_PACK) && !derive_only) r.chk(gi_bf3_pack(d, n, st));
     if (n && x2 && (what & BF3_DO_AMAX)) {
         if (!derive_only) r.chk((int)hipMemsetAsync(am, 0, sizeof(float) * 4 * GI_AMAX_WORDS * n, st));      // (the activations' / dZ cells: every forward)
         if (!(r.wc_bf3 && r.wc_valid)) {                  // max |W| + the weights' dynamic-range check: unless cached
@@ -1819,23 +1779,16 @@ extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* pa
     const bool msgx = E > 0 && d.passes > 0 && msg_wgrad_x2_possible(m, r.x2);
     float* msg_cells_base[2] = {nullptr, nullptr};
     hipEvent_t msg_cells_ready = nullptr;
-    // ... and the cell of max |h after the last pass| (first_layer_x2: the last pass's fused GRU launch publishes it)
-    if (r.x2 && !r.drop && R >= BF3_MIN_ROWS && first_layer_x2_static(d)) {
-        r.h_amax = ws + w.h_amax;
-        r.chk((int)hipMemsetAsync(r.h_amax, 0, sizeof(float) * GI_AMAX_WORDS, prep));
-    }
-    hipEvent_t h_cell_ready = nullptr;
-    if (msgx)
+    if (msgx) {
         for (int k = 0; k < (attn ? 2 : 1); ++k)
             if (w.img_f_n[k] > 0 && r.img_fx[k]) {
                 msg_cells_base[k] = ws + w.msg_amax[k];
                 r.chk((int)hipMemsetAsync(msg_cells_base[k], 0, sizeof(float) * MSG_CELLS_PER_PASS * d.passes, prep));
             }
-    if ((msgx || r.h_amax) && side_stream) {
-        msg_cells_ready = h_cell_ready = fside.next();
-        r.chk((int)hipEventRecord(msg_cells_ready, fside.st));
-        if (!msgx) msg_cells_ready = nullptr;
-        if (!r.h_amax) h_cell_ready = nullptr;
+        if (side_stream) {
+            msg_cells_ready = fside.next();
+            r.chk((int)hipEventRecord(msg_cells_ready, fside.st));
+        }
     }
     if ((run_flags & GI_RUN_PREPACK_BWD) && !r.drop) {
         bf3_prepare(r, m, ws, w, true, R, BF3_DO_PACK, prep);
@@ -1891,7 +1844,6 @@ extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* pa
             r.msg_cells[k] = (msg_cells_base[k] && !(p == 0 && w.D0 > 0)) ? msg_cells_base[k] + p * MSG_CELLS_PER_PASS : nullptr;
         if (msg_cells_ready && (r.msg_cells[0] || r.msg_cells[1])) {
             r.chk((int)hipStreamWaitEvent(r.st, msg_cells_ready, 0));    // (zeroed ~100 us ago: never stalls)
-            if (h_cell_ready == msg_cells_ready) h_cell_ready = nullptr;
             msg_cells_ready = nullptr;
         }
         if (p == 0 && p0cache) {
@@ -1945,14 +1897,11 @@ extern "C" int gi_ggnn_forward_ex(const gi_ggnn_dims* dp, const float* const* pa
         }
         // GRU update (gnn/mpnn.py:296-297): projections + gates in ONE launch (gi_gru.hip, round 6) ...
         if (gi_gru_fused_ok(d.H, d.M, w.ldM, w.ldhx, w.ld3H)) {
-            float* const h_cell = p == d.passes - 1 ? r.h_amax : nullptr;       // the readout's input: max |h| for its first layers
-            if (h_cell && h_cell_ready) { r.chk((int)hipStreamWaitEvent(r.st, h_cell_ready, 0)); h_cell_ready = nullptr; }
             r.chk(gi_gru_fused_fwd(ws + w.agg[p], w.ldM, hx, w.ldhx, params[m.gru_wih], params[m.gru_whh],
                                    params[m.gru_bih], params[m.gru_bhh], ws + w.gi[p], ws + w.gh[p], w.ld3H,
-                                   ws + w.hx[p + 1], seg_off, R, r.dims, d.H, d.M, h_cell, r.st));
+                                   ws + w.hx[p + 1], seg_off, R, r.dims, d.H, d.M, r.st));
             continue;
         }
-        r.h_amax = nullptr;                         // (the two-launch path publishes nothing: first layers as before)
         // ... or (GI_GRU_FUSED=0, widths that are not multiples of 4): both input projections in one launch, then the gate kernel
         {
             Batch b;
@@ -2100,7 +2049,6 @@ extern "C" int gi_ggnn_backward_phase(const gi_ggnn_dims* dp, const float* const
     r.skinny = ws + w.skinny; r.skinny_floats = w.skinny_floats;
     r.x2 = x2_enabled() && !no_x2;
     r.guard = gp->x2_guard; r.guard_host = nullptr;       // (the backward only counts: dZ rows never trip)
-    if (r.x2 && !r.drop && w.R >= BF3_MIN_ROWS && first_layer_x2_static(d)) r.h_amax = ws + w.h_amax;   // (as its forward: first_layer_x2)
     if (prepacked) {                                      // images written by THIS workspace's forward (side stream)?
         if (hipEvent_t ev = prepack_lookup(ws, r.x2)) r.chk((int)hipStreamWaitEvent(r.st, ev, 0));
         else prepacked = false;                           // no such forward on record: pack here

@@ -36,7 +36,7 @@ BWD_PREPACKED, BWD_NO_X2 = 0x100, 0x200        # OR-ed into the phase (GI_BWD_PR
 RUN_PREPACK_BWD, RUN_NO_X2 = 1, 2              # gi_ggnn_forward_ex flags (GI_RUN_*)
 X2_GUARD_WORDS = 4                             # GI_X2_GUARD_WORDS
 COUNTS = 24          # GI_COUNTS
-ABI_VERSION = 19
+ABI_VERSION = 18
 #: bumped by code that rewrites model weights through raw pointers (optim.FusedAdam.step,
 #: dp.DataParallel.broadcast_parameters): invalidates gnn.mpnn's pass-0 row cache
 WEIGHTS_EPOCH = [0]     # GI_ABI_VERSION
@@ -199,7 +199,7 @@ SIGNATURES = {
                                     ci, vp, ci, C.POINTER(vp), vp, vp, ci]),
     "gi_ggnn_first_readout_param": (ci, [C.POINTER(GgnnDims)]),
     "gi_ggnn_wcache_floats": (cll, [C.POINTER(GgnnDims)]),
-    "gi_gru_forward": (ci, [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, ci, ci, ci, vp, vp]),
+    "gi_gru_forward": (ci, [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, ci, ci, ci, vp]),
     "gi_fuse_flags": (ci, []),
     "gi_gru_gates_bwd_ex": (ci, [vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, ci, vp, vp, ci, vp, vp,
                                  vp]),

@@ -73,7 +73,7 @@
 extern "C" {
 #endif
 
-#define GI_ABI_VERSION 19
+#define GI_ABI_VERSION 18
 #define GI_MAX_GROUPS 8       /* max bond types (n_edge_features) */
 #define GI_MAX_NODES 128      /* max max_n_nodes */
 #define GI_P0_MAX_CLASSES 256 /* max distinct node feature rows for the pass-0 shortcut */
@@ -521,12 +521,10 @@ int gi_compress_slots_f(float* t1, int ldt, const int* cidx, int B, int N, int W
  * W_hh [3H, H] row-major.  Writes h' and the copied tail into hx_new [rows, ldh], and what gi_gru_gates_bwd reads: the
  * gates r, z, n into gi[:, 0:3H], gh_n into gh[:, 2H:3H] (gi / gh rows of nodes without incoming edges, and gh[:, 0:2H],
  * are left untouched).  H % 4 == M % 4 == lda % 4 == ldh % 4 == 0, 16-byte aligned agg / hx / hx_new; GI_EINVAL otherwise
- * (callers then use gi_gemm_batch + gi_gru_gates_fwd).  h_amax (ABI 19; may be NULL): an amax cell (GI_AMAX_WORDS floats,
- * zeroed by the caller) that takes max |hx_new[:, 0:H]| — what an fp16x2 launch reading the new state scales it by
- * (gi_gemm_params.a_amax / b_amax). */
+ * (callers then use gi_gemm_batch + gi_gru_gates_fwd). */
 int gi_gru_forward(const float* agg, int lda, const float* hx, int ldh, const float* Wih, const float* Whh,
                    const float* bih, const float* bhh, float* gi, float* gh, int ldg, float* hx_new,
-                   const int* seg_off, int rows, int H, int M, float* h_amax, void* stream);
+                   const int* seg_off, int rows, int H, int M, void* stream);
 int gi_gru_gates_fwd(float* gi, float* gh, int ldg, const float* hx_prev, float* hx_new, int ldh,
                      const int* seg_off, int rows, int H, int Fn, void* stream);
 /* In: dh_new (+ up to three more partial gradients dh_b/c/d or NULL, all [rows, lddh]);

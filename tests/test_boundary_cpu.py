@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.gi_abi_version() == L.ABI_VERSION == 19
+    assert lib.gi_abi_version() == L.ABI_VERSION == 18
 
 
 def test_host_side_planning_functions():
