@@ -147,12 +147,18 @@ def timed_steps(wl: Workload, steps: int, warmup: int, world: int, device):
         wl.run_step()
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     rb0 = dict(ops.READBACKS)
+    wait0 = ops.HOST_WAIT[0]
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = wl.run_step()
+    t_enq = time.perf_counter() - t0                               # the host has enqueued everything
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     wl.readbacks = {k: ops.READBACKS[k] - rb0[k] for k in rb0}     # of the timed steps' forwards
+    # host side of the loop: what it costs to enqueue a step (the loop's wall time up to its last enqueue minus the time
+    # spent waiting for the device at the prefetched counts) — the margin by which the host stays ahead of the device
+    wl.host = {"enqueue_ms_per_step": round((t_enq - (ops.HOST_WAIT[0] - wait0)) / steps * 1e3, 4),
+               "wait_for_device_ms_per_step": round((ops.HOST_WAIT[0] - wait0) / steps * 1e3, 4)}
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -510,6 +516,7 @@ def main():
     cfg, model, trainer, batches = wl.cfg, wl.model, wl.trainer, wl.batches
     dt, loss_val = timed_steps(wl, args.steps, args.warmup, world, device)
     first_readbacks = dict(wl.readbacks)
+    first_host = dict(wl.host)
     if world > 1:
         # every rank stepped on different graphs: the weights can only still be identical if the
         # gradient exchange (incl. its overlap with the backward) delivered the same mean everywhere
@@ -569,6 +576,7 @@ def main():
                                    "dgrad_rows is informational (the backward's outputs are sums over rows)")
     # graph_compact's sizes: found on the host (counting phase one batch ahead) / read back behind the stream
     result["config"]["compact_readbacks_timed_steps"] = first_readbacks
+    result["config"]["host"] = first_host
     if args.backend != "nccl":
         result["config"]["backend"] = args.backend + " (control-flow smoke test, not a measurement)"
 

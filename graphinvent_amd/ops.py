@@ -5,6 +5,7 @@ on torch's current HIP stream and takes/returns CUDA tensors; nothing here compu
 from __future__ import annotations
 
 import ctypes as C
+import time
 import weakref
 from dataclasses import dataclass
 from typing import Optional, Sequence
@@ -217,6 +218,9 @@ def _unpack_counts(counts, Fe: int, allow_multi_bond: bool = True):
 #: how forward passes got their sizes so far: from a finished prefetch (no wait on the step's stream) or by a
 #: blocking read-back behind everything queued on it (bench.py reports the split over its timed region)
 READBACKS = {"prefetched": 0, "blocking": 0, "bounded": 0}     # "bounded": no read-back at all (compact_bounded)
+#: seconds the HOST spent waiting for a prefetched count (the one place a training loop on resident or loader-fed batches
+#: blocks): wall time of a loop minus this = what the host needs to enqueue it (bench.py: "host")
+HOST_WAIT = [0.0]
 _PREFETCHED: "dict" = {}
 _PINNED: "list" = []
 _PINNED_NEXT = 0
@@ -278,7 +282,9 @@ def compact_count(nodes: torch.Tensor, edges: torch.Tensor, nodedup: bool = Fals
         hit = None                                           # same address, different tensors: stale
     if hit is not None:
         nodes_c, lay, gfix, Fe, pinned, done = hit[:6]
-        done.synchronize()                                   # normally long finished
+        t_wait = time.perf_counter()
+        done.synchronize()                                   # normally long finished; a host that runs ahead of the device waits here
+        HOST_WAIT[0] += time.perf_counter() - t_wait
         cur = torch.cuda.current_stream(nodes_c.device)
         cur.wait_event(done)
         gfix.record_stream(cur)
