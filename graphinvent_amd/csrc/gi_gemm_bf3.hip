@@ -149,7 +149,11 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
 #endif
     const int K = p.K, Kp = b3_r32(K), nk = Kp / B3_BK;
     float sa = 1.f, ia = 1.f, sb = 1.f, ib = 1.f;               // fp16x2: per-tensor power-of-two scales
+#ifdef B3_LAB_NO_AMAX                       // lab, TIMING ONLY
+    if (X2) { sa = sb = 0x1p10f; ia = ib = 0x1p-10f; }
+#else
     if (X2) { gx_scale(gx_amax_read(p.a_amax), sa, ia); gx_scale(gx_amax_read(p.b_amax), sb, ib); }
+#endif
     const unsigned char* const Bimg = reinterpret_cast<const unsigned char*>(p.B);
     const long long bplane = (long long)p.N * Kp * 2;          // bytes per plane of the image
 
@@ -372,10 +376,12 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
     const std::true_type ST{};
     const std::false_type GEN{};
     const int n_full = K / B3_BK;                                // k tiles that are full in k
+#ifndef B3_LAB_NO_PROLOGUE                  // lab, TIMING ONLY (with B3_LAB_NO_LOOP)
     gload(GEN, 0, ra0, rb0, rp0, rf0);
     gload(GEN, min(1, nk - 1), ra1, rb1, rp1, rf1);
     sstore(GEN, 0, 0, ra0, rb0, rp0, rf0);
     __syncthreads();
+#endif
     int kt = 0;
 #ifdef B3_LAB_NO_LOOP                      // lab, TIMING ONLY: prologue + epilogue
     kt = nk;
@@ -446,19 +452,29 @@ __global__ __launch_bounds__(256, 3) void gi_gemm_bf3_kernel(const B3Batch b) {
             const bool col_ok = col < p.N;
             const int colc = col_ok ? col : p.N - 1;
             const int row0 = m0 + wm * 64 + t * 32 + 4 * lhi;
+#ifdef B3_LAB_NO_BIAS                       // lab, TIMING ONLY
+            const float bv = 0.25f;
+#else
             const float bv = (flags & GI_EPI_BIAS) ? p.bias[colc] : 0.f;
+#endif
             float av[16], cv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {                        // every load of the block before the first store
                 const int row = min(row0 + 8 * (r >> 2) + (r & 3), m_end - 1);
+#ifdef B3_LAB_NO_ACT                        // lab, TIMING ONLY
+                if (need_act) av[r] = 0.5f + r;
+#else
                 if (need_act) av[r] = p.act[(long long)row * p.ldact + colc];
+#endif
                 if (need_c) cv[r] = p.C[(long long)row * p.ldc + colc];
             }
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float x = X2 ? (acc[t][u][r] * ia) * ib + bv : acc[t][u][r] + bv;
+#ifndef B3_LAB_NO_SELU                      // lab, TIMING ONLY
                 if (flags & GI_EPI_SELU) x = gi_selu(x);
+#endif
                 if (flags & GI_EPI_DSELU) x *= gi_selu_grad(av[r]);
                 if (flags & GI_EPI_MULACT) x *= av[r];
                 if (flags & GI_EPI_ACCUM) x += cv[r];
