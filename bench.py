@@ -122,16 +122,26 @@ class Workload:
         self.trainer = dp.DataParallel(self.model, self.opt, self.sched, loss_fn=apd_kl_loss)
         self.trainer.broadcast_parameters()
         self.i = 0
+        self.prefetched_upto = 0
 
     # Like the block loader (graphinvent_amd/loader.py), the loop hands the NEXT batch to
     # ops.prefetch_compact before stepping on the current one: the counting phase of graph_compact
     # (and its host read-back) for batch k+1 runs on a side stream during step k.  Every step still
     # compacts its own batch — the result is consumed once, nothing is cached across steps.
+    # PREFETCH_AHEAD = 2: the count of batch k needs the device to have finished step k - 3 (its prefetch was enqueued
+    # behind step k - 3's launches), so the host may run up to two steps ahead of the device and a host hiccup of a
+    # millisecond or two (a shared box) does not drain the queue; with 1 it could be one step ahead (1.0-1.4 ms of host
+    # work per 1.85-ms step: profiles/r06/README.md).
+    PREFETCH_AHEAD = int(os.environ.get("GI_BENCH_PREFETCH_AHEAD", "2"))
+
     def run_step(self):
         nb = len(self.batches)
         if self.prefetch:
-            nxt = self.batches[(self.i + 1) % nb]
-            ops.prefetch_compact(nxt[0], nxt[1])
+            for a in range(1, self.PREFETCH_AHEAD + 1):
+                if self.i + a > self.prefetched_upto:
+                    nxt = self.batches[(self.i + a) % nb]
+                    ops.prefetch_compact(nxt[0], nxt[1])
+                    self.prefetched_upto = self.i + a
         loss = self.trainer.step(*self.batches[self.i % nb])
         self.i += 1
         return loss
@@ -443,7 +453,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="threads of the CPU baseline; 0 = pick the fastest of 8 / 16 / 32 by a probe")
