@@ -560,6 +560,81 @@ __global__ __launch_bounds__(256) void gi_chain_pack_x2_kernel(const PackArgs a)
     reinterpret_cast<cx_u32x4*>(P.image)[(long long)g * a.stride16 + (long long)tile_in_group * (CX_TILE / 4) + q] = v;
 }
 
+// The same image AND the max |W| cells it is scaled by, in ONE launch (round 6): memset + gi_absmax + the kernel above were
+// three dependent launches (3 + 7 + 12 us and two gaps) in front of the forward's first chain, i.e. on the critical path
+// of every training step.  CXF_SPLIT workgroups per weight matrix: each takes the largest magnitude of the WHOLE matrix
+// itself (<= 256 KB out of L2; the same reduction order in every workgroup, so they agree bit for bit), workgroup 0 of
+// the matrix writes all 64 slots of its cell (nothing to zero beforehand), and each packs every CXF_SPLIT-th tile.
+constexpr int CXF_SPLIT = 8;
+__global__ __launch_bounds__(1024) void gi_chain_pack_x2_fused_kernel(const PackArgs a) {
+    static_assert(CX_TILE / 4 == 1024, "one 16-byte piece of a tile per thread");
+    const gi_chain_params& P = a.c;
+    __shared__ float red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int mat = blockIdx.x / CXF_SPLIT, part = blockIdx.x - mat * CXF_SPLIT;
+    const int l = mat / P.ngroups, g = mat - l * P.ngroups;
+    const gi_chain_layer& Ly = P.layer[l];
+    const float* __restrict__ W = Ly.W[g];
+    const int K = Ly.K, N = Ly.N, n_el = K * N;
+    float m = 0.f;
+    // eight loads in flight (clamped: a repeated element changes no maximum); 16-byte loads when the matrix allows
+    if ((((uintptr_t)W & 15) | (n_el & 3)) == 0) {
+        const int n4 = n_el >> 2;
+        for (int base = tid; base < n4; base += 8 * 1024) {
+            v4f v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const v4f*>(W)[min(base + u * 1024, n4 - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+        }
+    } else {
+        for (int base = tid; base < n_el; base += 8 * 1024) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = W[min(base + u * 1024, n_el - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m = fmaxf(m, fabsf(v[u]));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) red[wid] = m;
+    __syncthreads();
+    m = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+    float* cell = P.x2_wamax + ((long long)l * P.ngroups + g) * GI_AMAX_WORDS;
+    if (part == 0 && tid < GX_AMAX_SLOTS) cell[tid * GX_AMAX_STRIDE] = tid ? 0.f : m;
+    float s, inv;
+    gx_scale(m, s, inv);
+    int tile0 = 0;                                           // the layer's first tile within its group's image
+    for (int j = 0; j < l; ++j) tile0 += (P.layer[j].K + CX_KT - 1) / CX_KT;
+    const int nk = (K + CX_KT - 1) / CX_KT;
+    const int q = tid, plane = q >> 9, chunk = (q >> 8) & 1, n = q & (CH_W - 1);
+    typedef unsigned cx_u32x4 __attribute__((ext_vector_type(4)));
+    for (int tile = part; tile < nk; tile += CXF_SPLIT) {
+        const int k0 = tile * CX_KT + chunk * 8;
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            const bool ok = n < N && k < K;
+            const long long at = !P.backward ? (long long)n * K + k : (long long)k * N + n;   // B[n][k] = W[n][k] / W[k][n]
+            w[j] = ok ? W[ok ? at : 0] : 0.f;
+        }
+        unsigned o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned p0, p1;
+            gx_split2(w[2 * j], w[2 * j + 1], s, p0, p1);
+            o[j] = plane ? p1 : p0;
+        }
+        cx_u32x4 v = {o[0], o[1], o[2], o[3]};
+        reinterpret_cast<cx_u32x4*>(P.image)[(long long)g * a.stride16 + (long long)(tile0 + tile) * (CX_TILE / 4) + q] = v;
+    }
+}
+
 template <bool BWD>
 __global__ __launch_bounds__(512) void gi_chain_x2_kernel(const ChainArgs args) {
     __shared__ __attribute__((aligned(16))) unsigned char Ah[2 * CX_PLANE];
@@ -1223,7 +1298,13 @@ extern "C" int gi_mlp_chain_pack(const gi_chain_params* chains, int nchains, voi
         a.c = p;
         a.tiles = chain_tiles(p);
         const long long n4 = (long long)p.ngroups * a.tiles * (CH_TILE / 4);
-        if (p.x2_wamax) {                   // fp16x2 image: max |W| per (layer, bond type) first, then the two planes
+        const bool fused = !(getenv("GI_CHAIN_PACK_FUSED") && atoi(getenv("GI_CHAIN_PACK_FUSED")) == 0);   // (read per call: a test compares both)
+        if (p.x2_wamax && fused) {          // fp16x2 image and its max |W| cells in one launch
+            a.tiles = cx_tiles(p);
+            a.stride16 = (p.image_stride ? p.image_stride : (long long)chain_tiles(p) * CH_TILE) / 4;
+            hipLaunchKernelGGL(gi_chain_pack_x2_fused_kernel, dim3((unsigned)(p.nlayers * p.ngroups * CXF_SPLIT)), dim3(1024), 0,
+                               (hipStream_t)stream, a);
+        } else if (p.x2_wamax) {            // (GI_CHAIN_PACK_FUSED=0) max |W| per (layer, bond type) first, then the two planes
             const size_t cells = (size_t)p.nlayers * p.ngroups;
             if (hipMemsetAsync(p.x2_wamax, 0, cells * GI_AMAX_WORDS * sizeof(float), (hipStream_t)stream) != hipSuccess)
                 return (int)hipGetLastError();

@@ -576,3 +576,4 @@ def mlp_chain(chains, backward=False, x2=False, rows32=False):
     L.check(lib.gi_mlp_chain(arr, len(chains), _stream()), "gi_mlp_chain")
     for im in images:
         im.record_stream(torch.cuda.current_stream(im.device))
+    return images       # (tests: [max |W| cells per chain ...] + [packed image per chain ...] when x2, else the images)

@@ -43,6 +43,8 @@
  *                               workgroup per CU
  *       GI_GRU_FUSED=0          the forward's GRU update as a two-projection GEMM launch + the gate kernel (default, round 6:
  *                               one fused launch, csrc/gi_gru.hip)
+ *       GI_CHAIN_PACK_FUSED=0   the fp16x2 chain image as memset + gi_absmax + pack launches (default, round 6: one launch that
+ *                               also writes the max |W| cells)
  *       GI_P0_GRU_MAIN=0        pass 0's GRU weight gradients go to the weight-gradient queue with everything else (default,
  *                               round 6: they ride in the main queue's last launch, so that both queues end together)
  *       GI_GEMM_LOG=<file>      one line per GEMM launch (tools/gemm_launch_report.py)

@@ -702,6 +702,48 @@ def test_mlp_chain_fp16x2_row_independent_variant(sizes, off, in_scale):
         _chain_case(sizes, off, seed=sum(sizes) + 1, two=True, x2=True, rows32=True)
 
 
+@pytest.mark.parametrize("backward", [False, True])
+def test_mlp_chain_fp16x2_pack_in_one_launch_equals_the_three_launches(backward, monkeypatch):
+    """gi_mlp_chain_pack of an fp16x2 chain (round 6): ONE launch that takes max |W| of every (layer, group) matrix,
+    writes its amax cell and packs the two-plane image — against memset + gi_absmax + the pack kernel
+    (GI_CHAIN_PACK_FUSED=0): the cells' maxima and the images bit for bit, forward (W as stored) and dZ chain (W^T),
+    ragged widths, an empty group."""
+    sizes, off = (100, 250, 136, 250, 36), [0, 300, 300, 1000]
+    g = torch.Generator().manual_seed(77)
+    G, E = len(off) - 1, off[-1]
+    order = sizes[::-1] if backward else sizes
+    Ws = [[(torch.randn(o, i, generator=g) * 10.0 ** (l - 2)).to(DEV) for _ in range(G)]
+          for l, (i, o) in enumerate(zip(sizes, sizes[1:]))]
+    if backward:
+        Ws = Ws[::-1]
+    X = torch.randn(E, ops.r4(order[0]), generator=g).to(DEV)
+    got = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("GI_CHAIN_PACK_FUSED", fused)
+        outs = [torch.zeros(E, ops.r4(n), device=DEV) for n in order[1:]]
+        layers = []
+        for l in range(len(order) - 1):
+            ly = dict(W=Ws[l], out=outs[l], K=order[l], N=order[l + 1])
+            if not backward:
+                ly["bias"] = [torch.zeros(order[l + 1], device=DEV) for _ in range(G)]
+            layers.append(ly)
+        spec = dict(X=X, grp_off=torch.tensor(off, dtype=torch.int32, device=DEV),
+                    group_rows=[off[t + 1] - off[t] for t in range(G)], rows=E, layers=layers)
+        cells, image = ops.mlp_chain([spec], backward=backward, x2=True)
+        torch.cuda.synchronize()
+        slots = cells.view(-1, L.AMAX_WORDS)[:, ::L.AMAX_WORDS // 64]          # (64 slots a 128-byte line apart; the rest is never written)
+        # the image buffer has the fp32 layout's size; the fp16x2 tiles (16-deep, 16 KB each) fill the front of each group's share
+        per_group = image.numel() // G
+        written = sum((k + 15) // 16 for k in order[:-1]) * 4096
+        img = image.view(torch.int32).view(G, per_group)[:, :written]
+        got[fused] = (slots.max(1).values.cpu(), img.cpu(), [o.cpu() for o in outs])
+    want = torch.stack([w.abs().max().cpu() for lw in Ws for w in lw])
+    assert torch.equal(got["1"][0], want) and torch.equal(got["0"][0], want)
+    assert torch.equal(got["0"][1], got["1"][1])
+    for a, b in zip(got["0"][2], got["1"][2]):
+        assert torch.equal(a, b)
+
+
 def test_mlp_chain_fp16x2_rows32_two_workgroups_per_cu():
     """More row blocks than CUs -> the launcher takes the two-workgroups-per-CU build of the kernel (two-slot weight ring,
     outputs stored from registers): 264 and 700 blocks in three ragged groups, forward and dZ chain, one and two chains."""

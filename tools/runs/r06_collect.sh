@@ -7,8 +7,8 @@ timeout 2400 python -m pytest tests -m gpu -q > $O/gpu_suite.log 2>&1; echo "sui
 GI_X2=0 timeout 900 python -m pytest tests/test_model_gpu.py tests/test_attggnn_gpu.py tests/test_dims_gpu.py -q > $O/gpu_model_tests_bf16x3_only.log 2>&1; tail -1 $O/gpu_model_tests_bf16x3_only.log
 GI_BF3=0 timeout 900 python -m pytest tests/test_model_gpu.py tests/test_attggnn_gpu.py tests/test_dims_gpu.py -q > $O/gpu_model_tests_fp32_mfma_only.log 2>&1; tail -1 $O/gpu_model_tests_fp32_mfma_only.log
 timeout 600 python -m pytest tests/test_dims_gpu.py -q -s 2>&1 | grep "GEMM-family\|passed\|failed" > $O/untuned_dimensions_pipes.txt; cat $O/untuned_dimensions_pipes.txt
-timeout 600 python bench.py > $O/bench_default.log 2>&1; grep '^{"metric"' $O/bench_default.log > $O/bench_default.json; python -c "
-import json; d=json.load(open('$O/bench_default.json')); print('bench', d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline'].get('frac_own_pipe'), d['cpu_baseline']['value'], d.get('loader_inclusive',{}).get('value'), d.get('x2_guard'))"
+timeout 600 python bench.py > $O/bench_first_run.log 2>&1; grep '^{"metric"' $O/bench_first_run.log > $O/bench_first_run.json; python -c "
+import json; d=json.load(open('$O/bench_first_run.json')); print('bench', d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline'].get('frac_own_pipe'), d['cpu_baseline']['value'], d.get('loader_inclusive',{}).get('value'), d.get('x2_guard'))"
 for i in 1 2 3; do python bench.py --no-cpu-baseline --no-extra-configs --no-probe --no-forward-only --no-one-stream --steps 20 --warmup 5 2>/dev/null | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print(d['ms_per_step'])"; done > $O/bench_default_repeats.txt; cat $O/bench_default_repeats.txt
 bash tools/collect_profiles.sh r06 > $O/collect_profiles.log 2>&1; tail -3 $O/collect_profiles.log
 GI_TRACE_ALL=1 bash tools/collect_traces.sh r06 > $O/collect_traces.log 2>&1; tail -30 $O/collect_traces.log
