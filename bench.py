@@ -137,7 +137,8 @@ class Workload:
     def run_step(self):
         nb = len(self.batches)
         if self.prefetch:
-            for a in range(1, self.PREFETCH_AHEAD + 1):
+            # (a batch's pending count is keyed by the batch: with nb resident batches at most nb - 1 can be pending)
+            for a in range(1, min(self.PREFETCH_AHEAD, nb - 1) + 1):
                 if self.i + a > self.prefetched_upto:
                     nxt = self.batches[(self.i + a) % nb]
                     ops.prefetch_compact(nxt[0], nxt[1])
