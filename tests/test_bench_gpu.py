@@ -59,6 +59,11 @@ def _check(d, world: int, backend: str, batch: int = 1000):
     assert abs(sum(p["gflop"] for p in pipes.values()) - rf["useful_gflop_per_step"] * 3) < 0.02 * rf["useful_gflop_per_step"] * 3
     assert 0 < rf["frac_own_pipe"] <= rf["frac"] + 1e-4
     assert "overlapped" in d["config"]["allreduce"]
+    # host side of the timed loop: what enqueuing a step costs, and how long the host waited for the device
+    host = d["config"]["host"]
+    assert host["enqueue_ms_per_step"] > 0 and host["wait_for_device_ms_per_step"] >= 0
+    assert host["enqueue_ms_per_step"] + host["wait_for_device_ms_per_step"] <= d["ms_per_step"] * 1.05
+    assert d["config"]["compact_readbacks_timed_steps"]["blocking"] == 0     # every count was prefetched
 
 
 def test_bench_two_ranks_gloo_sharing_the_gpu():
