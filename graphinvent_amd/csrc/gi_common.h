@@ -7,15 +7,23 @@
 #define GI_SELU_ALPHA 1.6732632423543772848170429916717f
 #define GI_SELU_SCALE 1.0507009873554804934193349852946f
 
-// exp(x) for x <= 0 to ~2 ulp in 6 instructions: v_exp_f32 (2^t, 1 ulp) on t = x * log2(e), with the
-// rounding error of that product and the low part of log2(e) folded back in as a first-order factor.
-// (libm expf costs ~25 VALU instructions per value — 1.2 us per layer epilogue of the chain kernel,
-// measured; the bare __expf = v_exp_f32(x * log2e) loses up to |x| ulp to the rounded product.)
+// exp(x) for x <= 0 as v_exp_f32 (2^t, 1 ulp) on t = fl(x * log2(e)): 2 instructions.  The rounded product costs exp up to
+// |t| ulp, i.e. an ABSOLUTE error of at most exp(x) |x| 8.6e-8 <= 3.2e-8 — invisible in SELU, whose exp(x) - 1 rounds at
+// 6e-8 whatever exp's last bits are (measured on the device against the fp64 value over x in [-20, -1e-6]: max |err|
+// 2.04e-7, mean signed error -6.4e-9; with the first-order correction of rounds 2-5 — the product's rounding error and
+// the low part of log2(e) folded back in, three more instructions — 1.93e-7 and -7.0e-9: the same).  Round 6 dropped the
+// correction: 60 -> 48 cycles per value in every forward epilogue of the path, headline step -0.75 %
+// (profiles/r06/ab_head_selu_bare_exp.txt).  -DGI_EXP_CORRECTED brings it back.  (libm expf costs ~25 VALU instructions.)
 __device__ __forceinline__ float gi_exp_nonpos(float x) {
-    const float l2e_hi = 1.44269502162933349609375f, l2e_lo = 1.925963033500011e-8f;
+    const float l2e_hi = 1.44269502162933349609375f;
+#ifdef GI_EXP_CORRECTED
+    const float l2e_lo = 1.925963033500011e-8f;
     const float t = x * l2e_hi;
     const float r = fmaf(x, l2e_hi, -t) + x * l2e_lo;          // (exact product - t) + low part
     return __builtin_amdgcn_exp2f(t) * fmaf(r, 0.693147182464599609375f, 1.f);
+#else
+    return __builtin_amdgcn_exp2f(x * l2e_hi);
+#endif
 }
 // SELU as torch.nn.SELU (gnn/modules.py:126,164): scale * (x > 0 ? x : alpha * (exp(x) - 1)) —
 // the same exp(x) - 1 form ATen's CPU/GPU elu kernels evaluate.
