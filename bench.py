@@ -39,6 +39,9 @@ Rank 0 prints one JSON line.  Besides the contract fields it carries
                 (CPU restatement of the reference algorithm, kind "port", + the committed port/reference ratio) on the host
                 cores at their best thread count, same workload, bounded sample; N == 1 only
 config.fuse_flags = the GI_FUSE launch-count reductions in use (include/graphinvent_amd.h, default 15).
+config.host = what the timed loop cost the HOST per step: enqueue_ms_per_step (Python + torch + the library's launches)
+and wait_for_device_ms_per_step (blocked on the prefetched counts, i.e. the device is the bound when this is > 0); the
+counts of the next TWO batches are prefetched, so the host may run two steps ahead of the device.
 """
 import argparse
 import ctypes as C
